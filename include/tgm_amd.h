@@ -1,0 +1,117 @@
+/*
+ * tgm_amd.h -- C ABI of libtgm_amd.so: the MI355X (gfx950) kernels behind the
+ * drop-in hooks of tgm_amd.
+ *
+ * The reference (tgm-team/tgm) is pure Python/PyTorch and has no FFI of its own
+ * (SURVEY.md F1), so each entry point below names the reference *Python*
+ * routine it replaces (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer into a contiguous buffer (the Python
+ *     side passes torch.Tensor.data_ptr()); no torch types cross the boundary;
+ *   - `stream` is a hipStream_t (torch.cuda.current_stream().cuda_stream);
+ *     all work is enqueued asynchronously, nothing here synchronises;
+ *   - nothing here allocates device memory: callers pass outputs/workspaces;
+ *   - return value: 0 = ok, negative = TGMX_E_* (message: tgmx_last_error()).
+ *   - `status` words are device int32 bit-sets written by kernels (TGMX_ST_*),
+ *     so input validation costs no host round trip; the caller reads them when
+ *     it chooses to (the hooks: every call by default, or deferred).
+ */
+#ifndef TGM_AMD_H
+#define TGM_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TGMX_ABI_VERSION 1
+
+#define TGMX_OK 0
+#define TGMX_E_INVALID (-1)  /* bad argument (null pointer, size, alignment) */
+#define TGMX_E_LAUNCH (-2)   /* hipLaunch / runtime error                    */
+#define TGMX_E_UNSUPPORTED (-3)
+
+/* bits of a device-side status word */
+#define TGMX_ST_SEED_RANGE 1 /* a hop-0 seed id outside [0, num_nodes)        */
+#define TGMX_ST_SEED_TIME 2  /* a hop-0 seed time < 0                         */
+#define TGMX_ST_EDGE_RANGE 4 /* an edge endpoint outside [0, num_nodes)       */
+
+typedef void* tgmx_stream_t;
+
+/* One adjacency / ring record: 16 bytes, 16-byte aligned, so one lane moves
+ * one record with a single dwordx4 access. */
+typedef struct tgmx_adj {
+  int32_t nbr; /* neighbor node id, -1 = empty slot                          */
+  int32_t eid; /* row of the resident edge_x table holding the edge features */
+  int64_t ts;  /* edge timestamp                                             */
+} tgmx_adj_t;
+
+int tgmx_version(void);
+const char* tgmx_last_error(void);
+
+/* ------------------------------------------------------------------------
+ * k-most-recent neighbor lookup over a static per-node index (CSR).
+ * Replaces RecencyNeighborHook._get_recency_neighbors
+ * (tgm/hooks/neighbors/recency.py:239-321) for a chronological loader whose
+ * batch boundaries were known when the index was built.
+ *
+ *   indptr[num_nodes+1], adj[indptr[num_nodes]]: node n's entries, ordered by
+ *     (batch_idx, time, role, eid); entries with eid in [ev_lo, ev_hi) are
+ *     visible, of which only the last B are observable (B = max(num_nbrs)).
+ *   edge_x [num_edges, D] row-major float32 (NULL iff D == 0)
+ *   seeds[S] (int32; -1 = pad seed allowed iff allow_pad), qtimes[S]
+ *   out_nid [S,k] int32 (pad -1), out_ts [S,k] int64 (pad 0),
+ *   out_x [S,k,D] float32 (pad 0): oldest -> newest, right aligned.
+ * ------------------------------------------------------------------------ */
+int tgmx_recency_lookup_csr(const int64_t* indptr, const tgmx_adj_t* adj,
+                            const float* edge_x, int32_t D,
+                            const int32_t* seeds, const int64_t* qtimes, int64_t S,
+                            int32_t k, int32_t B, int64_t ev_lo, int64_t ev_hi,
+                            int32_t num_nodes, int32_t allow_pad,
+                            int32_t* out_nid, int64_t* out_ts, float* out_x,
+                            int32_t* status, tgmx_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Streaming mode: per-node rings of B records, the exact state machine of the
+ * reference hook (recency.py:93-102 state, :239-321 lookup, :323-399 update).
+ *   ring   [num_nodes, B] records (init nbr=-1, eid=0, ts=0), write_pos[num_nodes]
+ *   ring_x [num_nodes, B, D] feature row of every slot (need not be zeroed:
+ *          rows of empty slots are never read)
+ * ------------------------------------------------------------------------ */
+int tgmx_ring_lookup(const tgmx_adj_t* ring, const int32_t* write_pos,
+                     const float* ring_x, int32_t D,
+                     const int32_t* seeds, const int64_t* qtimes, int64_t S,
+                     int32_t k, int32_t B, int32_t num_nodes, int32_t allow_pad,
+                     int32_t* out_nid, int64_t* out_ts, float* out_x,
+                     int32_t* status, tgmx_stream_t stream);
+
+/* Append one batch of n edges (src[i], dst[i], ts[i], edge_x[i, :]) to the rings:
+ * per node in stable (time, role, i) order, last B kept (recency.py:323-399).
+ * edge_x may be NULL (rows of zeros, recency.py:325-328).  eid0 = store index of
+ * the batch's first edge or -1 (recorded in the slot, informational).
+ * scratch: >= 3 * (directed ? n : 2n) int32.  */
+int tgmx_ring_update(tgmx_adj_t* ring, int32_t* write_pos, float* ring_x, int32_t D, int32_t B,
+                     int32_t num_nodes, const int32_t* src, const int32_t* dst, const int64_t* ts,
+                     const float* edge_x, int64_t n, int64_t eid0, int32_t directed,
+                     int32_t* scratch, int32_t* status, tgmx_stream_t stream);
+
+/* ring.fill(pad), write_pos.zero_()  (recency.py:111-117) */
+int tgmx_ring_reset(tgmx_adj_t* ring, int32_t* write_pos, int32_t B, int32_t num_nodes,
+                    tgmx_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Index build helper: pack (nbr, eid, ts) columns, already permuted into
+ * index order, into 16-byte records.  perm[m] (int64) = position in the
+ * canonical entry list: entry e < num_edges is (src->dst, role 0), entry
+ * num_edges+e is (dst->src, role 1).
+ * ------------------------------------------------------------------------ */
+int tgmx_pack_adj(const int64_t* perm, int64_t m, const int32_t* src, const int32_t* dst,
+                  const int64_t* ts, int64_t num_edges, tgmx_adj_t* adj, tgmx_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TGM_AMD_H */

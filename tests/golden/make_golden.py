@@ -1,0 +1,339 @@
+#!/usr/bin/env python
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE.
+
+Runs only in the build container (needs /root/reference; PyG is replaced by the
+names-only placeholder in tests/golden/_pyg_stub).  Nothing here travels as
+code: the outputs are plain .npz data -- inputs + the reference's outputs -- and
+the tests compare the oracle and the HIP path against them.
+
+    python tests/golden/make_golden.py            # (re)write every fixture
+
+Fixture families:
+  g1_*   the reference's own hand-built sampler graphs (its unit-test inputs)
+  g2_*   random small streams: heavy timestamp ties, self loops, non-bipartite,
+         directed / undirected, unequal k per hop, negatives as a third seed group
+  g3_*   wiki-shaped medium stream, k=[20,20], bs=200: SHA-256 of every output
+  g4_*   epoch boundary (reset_state) and train -> val carry-over
+  g5_*   TemporalAttention / TGAT eval-mode forward
+  g6_*   Time2Vec on int64 deltas up to 2^31
+  g7_*   DeduplicationHook
+"""
+from __future__ import annotations
+
+import hashlib
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.dont_write_bytecode = True
+sys.path.insert(0, os.path.join(HERE, '_pyg_stub'))
+sys.path.insert(0, '/root/reference')
+sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+from tgm import DGraph  # noqa: E402
+from tgm.data import DGData, DGDataLoader  # noqa: E402
+from tgm.hooks import DeduplicationHook, HookManager, RecencyNeighborHook  # noqa: E402
+from tgm.hooks.base import StatelessHook  # noqa: E402
+from tgm.nn import TGAT, TemporalAttention, Time2Vec  # noqa: E402
+
+from tgm_amd.synth import make_stream  # noqa: E402
+
+
+class ReplayNegatives(StatelessHook):
+    """Feeds pre-generated negatives (one per edge, indexed by global edge id)."""
+
+    _cls_requires = {'edge_src', 'edge_dst', 'edge_time'}
+    _cls_produces = {'neg', 'neg_time'}
+
+    def __init__(self, neg_per_edge: torch.Tensor) -> None:
+        super().__init__()
+        self.neg_per_edge = neg_per_edge
+        self.cursor = 0
+        self.__post_init__()
+
+    def __call__(self, dg, batch):
+        n = batch.edge_src.numel()
+        batch.neg = self.neg_per_edge[self.cursor : self.cursor + n].clone()
+        batch.neg_time = batch.edge_time.clone()
+        self.cursor += n
+        return batch
+
+
+def run_sampler(src, dst, ts, edge_x, num_nodes, num_nbrs, bs, directed, neg=None, plan=('epoch',), segments=None):
+    """plan: sequence of 'epoch' | 'reset'.  segments: list of (lo, hi) edge ranges
+    iterated in order inside each epoch (separate DGData each, like a train/val split)."""
+    E = len(src)
+    segments = segments or [(0, E)]
+    seed_keys = ['edge_src', 'edge_dst'] + (['neg'] if neg is not None else [])
+    time_keys = ['edge_time', 'edge_time'] + (['neg_time'] if neg is not None else [])
+    hook = RecencyNeighborHook(
+        num_nodes=num_nodes, num_nbrs=list(num_nbrs), seed_nodes_keys=seed_keys, seed_times_keys=time_keys, directed=directed
+    )
+    hm = HookManager(keys=['k'])
+    replay = None
+    if neg is not None:
+        replay = ReplayNegatives(torch.as_tensor(neg, dtype=torch.int32))
+        hm.register('k', replay)
+    hm.register('k', hook)
+    graphs = []
+    for lo, hi in segments:
+        d = DGData.from_raw(
+            torch.as_tensor(ts[lo:hi], dtype=torch.int64),
+            torch.stack([torch.as_tensor(src[lo:hi], dtype=torch.int32), torch.as_tensor(dst[lo:hi], dtype=torch.int32)], 1),
+            None if edge_x is None else torch.as_tensor(edge_x[lo:hi], dtype=torch.float32),
+        )
+        graphs.append((lo, DGraph(d)))
+    outs = []
+    with hm.activate('k'):
+        for step in plan:
+            if step == 'reset':
+                hm.reset_state()
+                continue
+            for lo, dg in graphs:
+                if replay is not None:
+                    replay.cursor = lo
+                for batch in DGDataLoader(dg, batch_size=bs, hook_manager=hm):
+                    hops = []
+                    for h in range(len(num_nbrs)):
+                        hops.append(
+                            dict(
+                                seed_nids=batch.seed_nids[h].numpy().copy(),
+                                seed_times=batch.seed_times[h].numpy().copy(),
+                                nbr_nids=batch.nbr_nids[h].numpy().copy(),
+                                nbr_edge_time=batch.nbr_edge_time[h].numpy().copy(),
+                                nbr_edge_x=batch.nbr_edge_x[h].numpy().copy(),
+                            )
+                        )
+                    outs.append(hops)
+    return outs
+
+
+def save_sampler_case(name, src, dst, ts, edge_x, num_nodes, num_nbrs, bs, directed, neg=None, plan=('epoch',), segments=None, digest_only=False, verbatim=()):
+    outs = run_sampler(src, dst, ts, edge_x, num_nodes, num_nbrs, bs, directed, neg, plan, segments)
+    meta = dict(
+        name=name, num_nodes=int(num_nodes), num_nbrs=list(num_nbrs), batch_size=int(bs), directed=bool(directed),
+        has_neg=neg is not None, plan=list(plan), segments=[list(s) for s in (segments or [(0, len(src))])],
+        num_batches=len(outs), digest_only=bool(digest_only),
+    )  # fmt: skip
+    arrays = dict(src=np.asarray(src, np.int32), dst=np.asarray(dst, np.int32), ts=np.asarray(ts, np.int64))
+    if edge_x is not None and not digest_only:
+        arrays['edge_x'] = np.asarray(edge_x, np.float32)
+    if neg is not None:
+        arrays['neg'] = np.asarray(neg, np.int32)
+    digests = {}
+    for b, hops in enumerate(outs):
+        for h, d in enumerate(hops):
+            for key, val in d.items():
+                if digest_only:
+                    digests[f'b{b}_h{h}_{key}'] = hashlib.sha256(np.ascontiguousarray(val).tobytes()).hexdigest()
+                    if b in verbatim and key in ('nbr_nids', 'nbr_edge_time'):
+                        arrays[f'b{b}_h{h}_{key}'] = val
+                else:
+                    arrays[f'b{b}_h{h}_{key}'] = val
+    meta['digests'] = digests
+    arrays['meta'] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **arrays)
+    print(f'{name}: {len(outs)} batches')
+
+
+def g1_cases():
+    # basic 4-edge graph
+    src, dst, ts = [0, 0, 2, 2], [1, 2, 3, 0], [1, 2, 3, 4]
+    x = np.array([[1], [2], [5], [2]], np.float32)
+    save_sampler_case('g1_basic_1hop', src, dst, ts, x, 4, [1], 1, False)
+    save_sampler_case('g1_basic_1hop_directed', src, dst, ts, x, 4, [1], 1, True)
+    save_sampler_case('g1_basic_reset', src, dst, ts, x, 4, [1], 1, False, plan=('epoch', 'reset', 'epoch'))
+    # star graph exceeding the buffer
+    src, dst, ts = [0] * 100, list(range(1, 101)), list(range(100))
+    x = np.arange(1, 101, dtype=np.float32).reshape(-1, 1)
+    save_sampler_case('g1_buffer_k2', src, dst, ts, x, 101, [2], 2, False)
+    # two-hop graph
+    src, dst, ts = [0, 1, 3, 4, 5, 5], [1, 2, 2, 2, 0, 2], [1, 2, 3, 4, 5, 6]
+    x = np.array([[1], [3], [5], [6], [5], [7]], np.float32)
+    save_sampler_case('g1_two_hop', src, dst, ts, x, 6, [1, 1], 1, False)
+    save_sampler_case('g1_two_hop_directed', src, dst, ts, x, 6, [1, 1], 1, True)
+    # no edge features
+    save_sampler_case('g1_no_edge_feat', [1, 2, 3], [2, 3, 4], [1, 2, 3], None, 5, [1], 3, True)
+
+
+def g2_cases():
+    rng = np.random.default_rng(20260928)
+    variants = [([2], 3), ([3, 2], 4), ([2, 3], 5), ([1, 1, 2], 2), ([4], 7), ([3, 3], 1), ([5, 2], 8), ([2, 2, 2], 6)]
+    for i in range(16):
+        num_nbrs, bs = variants[i % len(variants)]
+        N = int(rng.integers(3, 12))
+        E = int(rng.integers(5, 80))
+        src = rng.integers(0, N, E)
+        dst = rng.integers(0, N, E)  # self loops & non-bipartite on purpose
+        ts = np.sort(rng.integers(1, max(2, E // 3), E))  # heavy ties, all >= 1
+        D = int(rng.integers(0, 4))
+        x = rng.random((E, D), dtype=np.float32) if D else None
+        directed = bool(i % 2)
+        neg = rng.integers(0, N, E) if i % 3 == 0 else None
+        plan = ('epoch', 'reset', 'epoch') if i % 5 == 0 else ('epoch',)
+        save_sampler_case(f'g2_rand_{i:02d}', src, dst, ts, x, N, num_nbrs, bs, directed, neg=neg, plan=plan)
+
+
+def g3_case():
+    st = make_stream('wiki', seed=1337, num_edges=20_000, edge_dim=8)
+    rng = np.random.default_rng(7)
+    neg = rng.integers(8227, st.num_nodes, st.num_edges)
+    save_sampler_case(
+        'g3_wiki_medium', st.src.numpy(), st.dst.numpy(), st.ts.numpy(), st.edge_x.numpy(), st.num_nodes, [20, 20], 200, False,
+        neg=neg, digest_only=True, verbatim=(0, 1, 50, 99),
+    )  # fmt: skip
+
+
+def g4_case():
+    rng = np.random.default_rng(99)
+    N, E, D = 40, 600, 3
+    src, dst = rng.integers(0, N, E), rng.integers(0, N, E)
+    ts = np.sort(rng.integers(1, 200, E))
+    x = rng.random((E, D), dtype=np.float32)
+    neg = rng.integers(0, N, E)
+    # train [0,420) then val [420,600) sharing hook state; reset; second epoch
+    save_sampler_case(
+        'g4_epoch_carry', src, dst, ts, x, N, [4, 3], 32, False, neg=neg,
+        plan=('epoch', 'reset', 'epoch'), segments=[(0, 420), (420, 600)],
+    )  # fmt: skip
+
+
+def _jitter_params(module, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for p in module.parameters():
+            p.add_(0.05 * torch.randn(p.shape, generator=g))
+
+
+def g5_cases():
+    torch.manual_seed(1337)
+    # --- TemporalAttention alone, incl. all-masked rows and head padding (node_dim 1 -> pad 1)
+    for tag, (heads, nd, ed, td, Bn, k) in {
+        'pad': (2, 1, 6, 5, 7, 4),
+        'nopad': (2, 4, 3, 6, 5, 3),
+        'h4': (4, 7, 5, 9, 6, 5),
+    }.items():
+        m = TemporalAttention(n_heads=heads, node_dim=nd, edge_dim=ed, time_dim=td, dropout=0.1).eval()
+        _jitter_params(m, 5)
+        g = torch.Generator().manual_seed(11)
+        node_x = torch.randn(Bn, nd, generator=g)
+        time_feat = torch.randn(Bn, td, generator=g)
+        edge_feat = torch.randn(Bn, k, ed, generator=g)
+        nbr_node_feat = torch.randn(Bn, k, nd, generator=g)
+        nbr_time_feat = torch.randn(Bn, k, td, generator=g)
+        mask = torch.rand(Bn, k, generator=g) > 0.4
+        mask[0] = False  # a row with no valid neighbor
+        mask[1] = True
+        with torch.no_grad():
+            out = m(node_x=node_x, time_feat=time_feat, edge_feat=edge_feat, nbr_node_feat=nbr_node_feat,
+                    nbr_time_feat=nbr_time_feat, valid_nbr_mask=mask)  # fmt: skip
+        arrays = {f'w_{n}': p.detach().numpy() for n, p in m.state_dict().items()}
+        arrays.update(node_x=node_x.numpy(), time_feat=time_feat.numpy(), edge_feat=edge_feat.numpy(),
+                      nbr_node_feat=nbr_node_feat.numpy(), nbr_time_feat=nbr_time_feat.numpy(), mask=mask.numpy(), out=out.numpy())  # fmt: skip
+        arrays['meta'] = np.frombuffer(json.dumps(dict(n_heads=heads, node_dim=nd, edge_dim=ed, time_dim=td)).encode(), dtype=np.uint8)
+        np.savez_compressed(os.path.join(HERE, f'g5_attn_{tag}.npz'), **arrays)
+        print(f'g5_attn_{tag}: out {tuple(out.shape)}')
+
+    # --- full TGAT on reference sampler outputs
+    cases = {
+        # name: (stream kwargs, num_nbrs, bs, batch index to keep, TGAT dims)
+        'small_unix': (dict(shape='review', num_edges=3000, edge_dim=6, n_src=150, n_dst=40), [4, 4], 16, 100,
+                       dict(node_dim=1, time_dim=10, embed_dim=12, n_heads=2)),
+        'small_nd8': (dict(shape='wiki', num_edges=3000, edge_dim=5, n_src=120, n_dst=30, node_dim=8), [3, 3], 10, 150,
+                      dict(node_dim=8, time_dim=7, embed_dim=8, n_heads=2)),
+        'one_layer': (dict(shape='wiki', num_edges=2000, edge_dim=4, n_src=80, n_dst=20), [5], 12, 80,
+                      dict(node_dim=1, time_dim=6, embed_dim=10, n_heads=2)),
+        'example_dims': (dict(shape='wiki', num_edges=4000, edge_dim=172, n_src=300, n_dst=60), [20, 20], 8, 300,
+                         dict(node_dim=1, time_dim=100, embed_dim=172, n_heads=2)),
+    }
+    for name, (skw, num_nbrs, bs, keep, dims) in cases.items():
+        st = make_stream(seed=4242, **skw)
+        rng = np.random.default_rng(3)
+        lo = st.num_nodes - skw['n_dst'] if skw['shape'] != 'comment' else 0
+        neg = rng.integers(lo, st.num_nodes, st.num_edges)
+        outs = run_sampler(st.src.numpy(), st.dst.numpy(), st.ts.numpy(), st.edge_x.numpy(), st.num_nodes, num_nbrs, bs, False, neg=neg)
+        hops = outs[keep]
+        enc = TGAT(edge_dim=st.edge_dim, num_layers=len(num_nbrs), dropout=0.1, **dims).eval()
+        _jitter_params(enc, 17)
+        T = lambda a: torch.from_numpy(a)
+        with torch.no_grad():
+            z = enc(
+                st.node_x,
+                [T(h['seed_nids']) for h in hops],
+                [T(h['seed_times']) for h in hops],
+                [T(h['nbr_nids']) for h in hops],
+                [T(h['nbr_edge_x']) for h in hops],
+                [T(h['nbr_edge_time']) for h in hops],
+            )
+        arrays = {f'w_{n}': p.detach().numpy() for n, p in enc.state_dict().items()}
+        arrays['z'] = z.numpy()
+        arrays['node_x'] = st.node_x.numpy()
+        for h, d in enumerate(hops):
+            for key in ('seed_nids', 'seed_times', 'nbr_nids', 'nbr_edge_time'):
+                arrays[f'h{h}_{key}'] = d[key]
+            if name != 'example_dims':
+                arrays[f'h{h}_nbr_edge_x'] = d['nbr_edge_x']
+        meta = dict(stream=skw, stream_seed=4242, num_nbrs=num_nbrs, batch_size=bs, batch_index=keep, neg_seed=3, neg_lo=int(lo),
+                    dims=dims, edge_dim=st.edge_dim, nbr_edge_x_stored=name != 'example_dims')  # fmt: skip
+        arrays['meta'] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+        np.savez_compressed(os.path.join(HERE, f'g5_tgat_{name}.npz'), **arrays)
+        print(f'g5_tgat_{name}: z {tuple(z.shape)}  |z|max {z.abs().max():.3f}')
+
+
+def g6_case():
+    enc = Time2Vec(time_dim=100).eval()
+    t = torch.tensor(
+        [0, 1, 2, 3, 7, 59, 60, 3600, 86_399, 86_400, 604_800, 2_678_373, 16_777_216, 16_777_217, 123_456_789,
+         999_999_937, 1_500_000_000, 2_147_483_646, 2_147_483_647, 2_147_483_648],
+        dtype=torch.int64,
+    )  # fmt: skip
+    with torch.no_grad():
+        out = enc(t)
+    enc2 = Time2Vec(time_dim=16).eval()
+    _jitter_params(enc2, 23)
+    with torch.no_grad():
+        out2 = enc2(t)
+    np.savez_compressed(
+        os.path.join(HERE, 'g6_time2vec.npz'), t=t.numpy(), out_default=out.numpy(), w2=enc2.w.weight.detach().numpy(),
+        b2=enc2.w.bias.detach().numpy(), out_jitter=out2.numpy(),
+    )  # fmt: skip
+    print('g6_time2vec:', tuple(out.shape))
+
+
+def g7_case():
+    rng = np.random.default_rng(5)
+    N, E = 30, 200
+    src, dst = rng.integers(0, N, E), rng.integers(0, N, E)
+    ts = np.sort(rng.integers(1, 100, E))
+    neg = rng.integers(0, N, E)
+    d = DGData.from_raw(torch.as_tensor(ts), torch.stack([torch.as_tensor(src, dtype=torch.int32), torch.as_tensor(dst, dtype=torch.int32)], 1))
+    dg = DGraph(d)
+    hm = HookManager(keys=['k'])
+    hm.register('k', ReplayNegatives(torch.as_tensor(neg, dtype=torch.int32)))
+    hm.register('k', RecencyNeighborHook(num_nodes=N, num_nbrs=[3, 2], seed_nodes_keys=['edge_src', 'edge_dst', 'neg'],
+                                        seed_times_keys=['edge_time', 'edge_time', 'neg_time']))  # fmt: skip
+    hm.register('k', DeduplicationHook(seed_nodes_keys=['neg', 'nbr_nids']))
+    arrays = dict(src=src.astype(np.int32), dst=dst.astype(np.int32), ts=ts.astype(np.int64), neg=neg.astype(np.int32))
+    nb = 0
+    with hm.activate('k'):
+        for b, batch in enumerate(DGDataLoader(dg, batch_size=25, hook_manager=hm)):
+            arrays[f'b{b}_unique_nids'] = batch.unique_nids.numpy().copy()
+            arrays[f'b{b}_local_src'] = batch.global_to_local(batch.edge_src).numpy().copy()
+            nb += 1
+    arrays['meta'] = np.frombuffer(json.dumps(dict(num_nodes=N, num_nbrs=[3, 2], batch_size=25, num_batches=nb)).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, 'g7_dedup.npz'), **arrays)
+    print('g7_dedup:', nb, 'batches')
+
+
+if __name__ == '__main__':
+    import warnings
+
+    warnings.filterwarnings('ignore')
+    only = sys.argv[1:]
+    for fam, fn in [('g1', g1_cases), ('g2', g2_cases), ('g3', g3_case), ('g4', g4_case), ('g5', g5_cases), ('g6', g6_case), ('g7', g7_case)]:
+        if not only or fam in only:
+            fn()

@@ -1,0 +1,90 @@
+"""ctypes binding of ``libtgm_amd.so`` (C ABI: ``include/tgm_amd.h``).
+
+The library is built in-tree by ``__graft_entry__.build()`` /
+``tgm_amd/csrc/Makefile``.  There is deliberately NO fallback: if the shared
+object is missing, or no ROCm device is visible, every compute entry point
+raises :class:`NativeLibraryError`.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_int32, c_int64, c_size_t, c_void_p
+from typing import Optional
+
+import torch
+
+from .exceptions import NativeLibraryError
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libtgm_amd.so')
+
+# every symbol include/tgm_amd.h declares: name -> (restype, argtypes)
+_P = c_void_p
+SIGNATURES = {
+    'tgmx_version': (c_int32, []),
+    'tgmx_last_error': (c_char_p, []),
+    'tgmx_recency_lookup_csr': (
+        c_int32,
+        [_P, _P, _P, c_int32, _P, _P, c_int64, c_int32, c_int32, c_int64, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P],
+    ),
+    'tgmx_ring_lookup': (
+        c_int32,
+        [_P, _P, _P, c_int32, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P],
+    ),
+    'tgmx_ring_update': (
+        c_int32,
+        [_P, _P, _P, c_int32, c_int32, c_int32, _P, _P, _P, _P, c_int64, c_int64, c_int32, _P, _P, _P],
+    ),
+    'tgmx_ring_reset': (c_int32, [_P, _P, c_int32, c_int32, _P]),
+    'tgmx_pack_adj': (c_int32, [_P, c_int64, _P, _P, _P, c_int64, _P, _P]),
+}
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+def load(path: str = LIB_PATH) -> ctypes.CDLL:
+    """dlopen the kernel library and type every exported entry point."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise NativeLibraryError(
+            f'{path} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            '(or `make -C tgm_amd/csrc`). tgm_amd has no CPU fallback.'
+        )
+    try:
+        lib = ctypes.CDLL(path)
+    except OSError as e:  # pragma: no cover - depends on the box
+        raise NativeLibraryError(f'failed to load {path}: {e}') from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise NativeLibraryError(f'{path} does not export {name}; rebuild it') from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def require_device(t: torch.Tensor, what: str) -> None:
+    if t.device.type != 'cuda':
+        raise NativeLibraryError(
+            f'{what} lives on {t.device}; tgm_amd kernels run only on a ROCm device (there is no CPU fallback). '
+            "Create the DGraph with device='cuda'."
+        )
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().tgmx_last_error()
+        raise RuntimeError(f'{what} failed (rc={rc}): {msg.decode() if msg else "?"}')
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor]) -> int:
+    return 0 if t is None else t.data_ptr()

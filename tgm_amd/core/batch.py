@@ -1,0 +1,52 @@
+"""``DGBatch`` -- the mutable record hooks read from and write onto.
+
+Mirrors tgm/core/batch.py:11-45 (same field names, order and defaults) so that
+hooks written against the reference keep working.  Two private, optional
+fields are added by :meth:`DGraph.materialize`: ``_edge_lo`` (index of the
+batch's first edge in the device-resident edge store; the batch's edges are
+the contiguous range ``[_edge_lo, _edge_lo + len(edge_src))``) and
+``_event_lo`` (the slice's first global event index).  They let device hooks
+address the resident store by edge id instead of copying feature rows.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Any, Optional
+
+from torch import Tensor
+
+
+@dataclass
+class DGBatch:
+    edge_src: Tensor
+    edge_dst: Tensor
+    edge_time: Tensor
+    edge_x: Optional[Tensor] = None
+    edge_type: Optional[Tensor] = None
+
+    node_x_time: Optional[Tensor] = None
+    node_x_nids: Optional[Tensor] = None
+    node_x: Optional[Tensor] = None
+
+    node_y_time: Optional[Tensor] = None
+    node_y_nids: Optional[Tensor] = None
+    node_y: Optional[Tensor] = None
+
+    _edge_lo: Optional[int] = field(default=None, repr=False, compare=False)
+    _event_lo: Optional[int] = field(default=None, repr=False, compare=False)
+
+    def __str__(self) -> str:
+        def describe(v: Any) -> str:
+            if isinstance(v, Tensor):
+                return str(list(v.shape))
+            if isinstance(v, str):
+                return v
+            if isinstance(v, dict):
+                return 'dict(' + '|'.join(sorted({describe(x) for x in v})) + f' x{len(v)})'
+            if isinstance(v, (list, tuple)):
+                kinds = '|'.join(sorted({describe(x) for x in v}))
+                return f'{type(v).__name__}({kinds} x{len(v)})'
+            return type(v).__name__
+
+        parts = [f'{k} = {describe(v)}' for k, v in vars(self).items() if not k.startswith('_')]
+        return 'DGBatch(' + ', '.join(parts) + ')'

@@ -1,0 +1,474 @@
+// k-most-recent temporal neighbor lookup (CSR index and streaming rings) for gfx950.
+//
+// Work decomposition: ONE 64-lane wave per seed.
+//   phase A (index, latency bound, tiny traffic): the wave locates the seed's
+//     observable window of <= B adjacency records with a 64-ary cooperative
+//     search (CSR) or reads its ring row (streaming), loads the window as one
+//     coalesced dwordx4-per-lane access, finds the rightmost entry with
+//     ts < q by ballot, and redistributes the k winners with lane shuffles.
+//   phase B (gather, HBM bound, ~all of the bytes): the seed's [k, D] output
+//     block is contiguous, so the wave streams it as flat 16-byte vectors --
+//     every store instruction writes 1 KiB contiguous, every load reads the
+//     matching 16 bytes of edge_x[eid[slot]] (row pieces are contiguous).
+//     The [S, B, D] intermediate the reference materialises
+//     (tgm/hooks/neighbors/recency.py:258) never exists.
+// Rows are copied, never recomputed, so features are bit-exact by construction.
+#include "common.h"
+
+namespace tgmx {
+
+struct __align__(16) Rec {
+  int nbr;
+  int eid;
+  long long ts;
+};
+static_assert(sizeof(Rec) == sizeof(tgmx_adj_t), "record layout");
+
+struct LookupArgs {
+  const int64_t* indptr;    // CSR
+  const Rec* recs;          // CSR adjacency or ring rows
+  const int32_t* write_pos; // ring
+  const float* edge_x;
+  const int32_t* seeds;
+  const int64_t* qtimes;
+  int32_t* out_nid;
+  int64_t* out_ts;
+  float* out_x;
+  int32_t* status;
+  long long S;
+  long long ev_lo, ev_hi;
+  int D, k, B, N, allow_pad;
+  int row_vecs;  // D / VEC
+  FastDiv dv;    // division by row_vecs
+};
+
+template <int VEC>
+struct VecOf;
+template <>
+struct VecOf<4> { using type = float4; };
+template <>
+struct VecOf<2> { using type = float2; };
+template <>
+struct VecOf<1> { using type = float; };
+
+template <typename T>
+__device__ __forceinline__ T zero_vec();
+template <>
+__device__ __forceinline__ float4 zero_vec<float4>() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+template <>
+__device__ __forceinline__ float2 zero_vec<float2>() { return make_float2(0.f, 0.f); }
+template <>
+__device__ __forceinline__ float zero_vec<float>() { return 0.f; }
+
+// Number of records in [a, z) whose eid < bound, given that those records form
+// a prefix (true for batch-boundary bounds).  64 probes/round.
+__device__ __forceinline__ long long wave_prefix_count(const Rec* recs, long long a, long long z,
+                                                       long long bound, int lane) {
+  long long lo = a, hi = z;
+  while (hi - lo > kWave) {
+    const long long len = hi - lo;
+    const long long stride = (len + kWave - 1) / kWave;
+    long long idx = lo + (long long)(lane + 1) * stride - 1;
+    if (idx > hi - 1) idx = hi - 1;
+    const bool less = (long long)recs[idx].eid < bound;
+    const int c = __popcll(__ballot(less));
+    long long nlo = lo, nhi = hi;
+    if (c > 0) {
+      long long p = lo + (long long)c * stride - 1;
+      if (p > hi - 1) p = hi - 1;
+      nlo = p + 1;
+    }
+    if (c < kWave) {
+      long long p = lo + (long long)(c + 1) * stride - 1;
+      if (p > hi - 1) p = hi - 1;
+      nhi = p;  // recs[p] is >= bound: the answer is <= p
+    }
+    lo = nlo;
+    hi = nhi < nlo ? nlo : nhi;
+  }
+  const long long idx = lo + lane;
+  const bool less = idx < hi && (long long)recs[idx].eid < bound;
+  return lo + __popcll(__ballot(less)) - a;
+}
+
+template <bool RING, int VEC, bool SMALL>
+__global__ __launch_bounds__(256) void recency_lookup_kernel(const LookupArgs a) {
+  using V = typename VecOf<VEC>::type;
+  extern __shared__ __attribute__((aligned(16))) int lds_eid_all[];
+  const int lane = lane_id();
+  const int wave_in_block = threadIdx.x >> 6;
+  int* lds_eid = lds_eid_all + wave_in_block * a.k;
+  const long long waves_total = (long long)gridDim.x * (blockDim.x >> 6);
+  const int k = a.k, B = a.B;
+
+  for (long long s = (long long)blockIdx.x * (blockDim.x >> 6) + wave_in_block; s < a.S; s += waves_total) {
+    const int n = a.seeds[s];
+    const long long q = a.qtimes[s];
+
+    bool live = n >= 0 && n < a.N;
+    if (lane == 0) {
+      int st = 0;
+      if (n >= a.N || n < -1 || (n == -1 && !a.allow_pad)) st |= TGMX_ST_SEED_RANGE;
+      if (q < 0 && !a.allow_pad) st |= TGMX_ST_SEED_TIME;
+      if (st) atomicOr(a.status, st);
+    }
+
+    // ---- phase A: window [w0, w0 + wlen) in "oldest -> newest" order ---------
+    long long w0 = 0;  // CSR: absolute record index; RING: row base
+    int wlen = 0, wrot = 0;
+    if (live) {
+      if (RING) {
+        w0 = (long long)n * B;
+        wrot = a.write_pos[n] % B;  // unrolled position i lives in slot (wrot + i) % B
+        wlen = B;
+      } else {
+        const long long ra = a.indptr[n], rz = a.indptr[n + 1];
+        const long long p_hi = ra + wave_prefix_count(a.recs, ra, rz, a.ev_hi, lane);
+        const long long p_lo = a.ev_lo <= 0 ? ra : ra + wave_prefix_count(a.recs, ra, rz, a.ev_lo, lane);
+        w0 = p_hi - B > p_lo ? p_hi - B : p_lo;
+        wlen = (int)(p_hi - w0);
+      }
+    }
+    auto slot_of = [&](int i) -> long long {
+      if (RING) {
+        int sl = wrot + i;
+        if (sl >= B) sl -= B;
+        return w0 + sl;
+      }
+      return w0 + i;
+    };
+
+    int cnt = 0;  // 1 + unrolled position of the rightmost entry with ts < q
+    if (SMALL) {
+      Rec r;
+      r.nbr = -1; r.eid = 0; r.ts = 0;
+      if (lane < wlen) r = a.recs[slot_of(lane)];
+      const bool ok = lane < wlen && r.nbr >= 0 && r.ts < q;
+      const unsigned long long m = __ballot(ok);
+      cnt = m ? 64 - __clzll((long long)m) : 0;
+      const int i = cnt - k + lane;  // unrolled position feeding output slot `lane`
+      const int from = i > 0 ? i : 0;
+      const int g_nbr = __shfl(r.nbr, from);
+      const int g_eid = __shfl(r.eid, from);
+      const long long g_ts = __shfl(r.ts, from);
+      if (lane < k) {
+        const bool has = i >= 0 && g_nbr >= 0;
+        a.out_nid[s * k + lane] = has ? g_nbr : -1;
+        a.out_ts[s * k + lane] = has ? g_ts : 0;
+        lds_eid[lane] = has ? (RING ? (int)slot_of(from) : g_eid) : -1;
+      }
+    } else {
+      for (int top = wlen; top > 0 && cnt == 0; top -= kWave) {
+        const int lo = top > kWave ? top - kWave : 0;
+        const int i = lo + lane;
+        bool ok = false;
+        if (i < top) {
+          const Rec r = a.recs[slot_of(i)];
+          ok = r.nbr >= 0 && r.ts < q;
+        }
+        const unsigned long long m = __ballot(ok);
+        if (m) cnt = lo + 64 - __clzll((long long)m);
+      }
+      for (int c = lane; c < k; c += kWave) {
+        const int i = cnt - k + c;
+        Rec r;
+        r.nbr = -1; r.eid = 0; r.ts = 0;
+        if (i >= 0) r = a.recs[slot_of(i)];
+        const bool has = r.nbr >= 0;
+        a.out_nid[s * k + c] = has ? r.nbr : -1;
+        a.out_ts[s * k + c] = has ? r.ts : 0;
+        lds_eid[c] = has ? (RING ? (int)slot_of(i) : r.eid) : -1;
+      }
+    }
+    if (a.D == 0) continue;
+    __builtin_amdgcn_wave_barrier();  // lds_eid written above is read cross-lane below
+
+    // ---- phase B: stream the [k, D] block ------------------------------------
+    const V* __restrict__ X = reinterpret_cast<const V*>(a.edge_x);
+    V* __restrict__ O = reinterpret_cast<V*>(a.out_x + s * (long long)k * a.D);
+    const int total = k * a.row_vecs;
+    constexpr int U = 4;
+    for (int f0 = lane; f0 < total; f0 += kWave * U) {
+      V v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int f = f0 + u * kWave;
+        v[u] = zero_vec<V>();
+        if (f < total) {
+          const int slot = (int)a.dv.div((uint32_t)f);
+          const int col = f - slot * a.row_vecs;
+          const int e = lds_eid[slot];
+          if (e >= 0) v[u] = X[(long long)e * a.row_vecs + col];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int f = f0 + u * kWave;
+        if (f < total) O[f] = v[u];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();  // next seed reuses lds_eid
+  }
+}
+
+template <bool RING>
+static int launch_lookup(LookupArgs a, hipStream_t stream) {
+  if (a.S == 0) return TGMX_OK;
+  const bool small = a.B <= kWave && a.k <= kWave;
+  int vec = 1;
+  if (a.D > 0) {
+    const bool al16 = (((uintptr_t)a.edge_x | (uintptr_t)a.out_x) & 15) == 0;
+    const bool al8 = (((uintptr_t)a.edge_x | (uintptr_t)a.out_x) & 7) == 0;
+    if (a.D % 4 == 0 && al16) vec = 4;
+    else if (a.D % 2 == 0 && al8) vec = 2;
+  }
+  a.row_vecs = a.D > 0 ? a.D / vec : 1;
+  a.dv = make_fastdiv((uint32_t)a.row_vecs);
+  if ((unsigned long long)a.k * a.row_vecs * (unsigned long long)a.row_vecs >= (1ull << 32)) {
+    set_error("recency_lookup: k*D^2 too large for the slot divider (k=%d, D=%d)", a.k, a.D);
+    return TGMX_E_UNSUPPORTED;
+  }
+  const int waves_per_block = 4;
+  long long blocks = (a.S + waves_per_block - 1) / waves_per_block;
+  if (blocks > (1 << 20)) blocks = 1 << 20;
+  const dim3 grid((unsigned)blocks), block(waves_per_block * kWave);
+  const size_t lds = (size_t)waves_per_block * a.k * sizeof(int);
+#define TGMX_LAUNCH(VEC_, SMALL_) \
+  hipLaunchKernelGGL((recency_lookup_kernel<RING, VEC_, SMALL_>), grid, block, lds, stream, a)
+  if (small) {
+    if (vec == 4) TGMX_LAUNCH(4, true);
+    else if (vec == 2) TGMX_LAUNCH(2, true);
+    else TGMX_LAUNCH(1, true);
+  } else {
+    if (vec == 4) TGMX_LAUNCH(4, false);
+    else if (vec == 2) TGMX_LAUNCH(2, false);
+    else TGMX_LAUNCH(1, false);
+  }
+#undef TGMX_LAUNCH
+  TGMX_CHECK_LAUNCH("recency_lookup");
+  return TGMX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Streaming rings: batched append (tgm/hooks/neighbors/recency.py:323-399).
+// Entry j < n is (src[j] -> dst[j]), entry n + j is (dst[j] -> src[j]).  The
+// reference's stable argsort by (node, time) is restated as an all-pairs rank:
+// before(j) = #{j' same node : (t', j') < (t, j)} -- exact, deterministic, and
+// O(m^2 / lanes) for the m = 2*batch_size <= ~10^4 entries of a batch.
+// ---------------------------------------------------------------------------
+struct UpdateArgs {
+  Rec* ring;
+  int32_t* write_pos;
+  float* ring_x;        // [N*B, D] feature row of every ring slot
+  const float* edge_x;  // [n, D] rows of this batch (null -> zeros)
+  const int32_t* src;
+  const int32_t* dst;
+  const int64_t* ts;
+  int32_t* scratch;  // [3m]: node, write_pos increment, ring row written (-1 = dropped)
+  int32_t* status;
+  long long n, m, eid0;
+  int B, N, D;
+};
+
+__global__ __launch_bounds__(256) void ring_update_rank_kernel(const UpdateArgs a) {
+  __shared__ int t_node[256];
+  __shared__ long long t_time[256];
+  const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  int node = -1, nbr = -1;
+  long long t = 0, i = 0;
+  if (j < a.m) {
+    const bool rev = j >= a.n;
+    i = rev ? j - a.n : j;
+    const int s = a.src[i], d = a.dst[i];
+    node = rev ? d : s;
+    nbr = rev ? s : d;
+    t = a.ts[i];
+    if (node < 0 || node >= a.N || nbr < 0 || nbr >= a.N) {
+      atomicOr(a.status, TGMX_ST_EDGE_RANGE);
+      node = -1;
+    }
+  }
+  int before = 0, total = 0;
+  for (long long base = 0; base < a.m; base += 256) {
+    const long long jj = base + threadIdx.x;
+    int nn = -2;
+    long long tt = 0;
+    if (jj < a.m) {
+      const bool rev = jj >= a.n;
+      const long long ii = rev ? jj - a.n : jj;
+      nn = rev ? a.dst[ii] : a.src[ii];
+      tt = a.ts[ii];
+    }
+    __syncthreads();
+    t_node[threadIdx.x] = nn;
+    t_time[threadIdx.x] = tt;
+    __syncthreads();
+    const int lim = (a.m - base) < 256 ? (int)(a.m - base) : 256;
+    if (node >= 0) {
+      for (int x = 0; x < lim; ++x) {
+        const bool same = t_node[x] == node;
+        const long long tx = t_time[x];
+        total += same;
+        before += same && (tx < t || (tx == t && base + x < j));
+      }
+    }
+  }
+  if (j >= a.m) return;
+  int inc = 0, row = -1;
+  if (node >= 0) {
+    const int drop = total > a.B ? total - a.B : 0;
+    if (before >= drop) {
+      const int w = a.write_pos[node] % a.B;
+      const int slot = (w + before - drop) % a.B;
+      Rec r;
+      r.nbr = nbr;
+      r.eid = a.eid0 >= 0 ? (int)(a.eid0 + i) : -1;
+      r.ts = t;
+      row = node * a.B + slot;
+      a.ring[row] = r;
+    }
+    if (before == total - 1) inc = total - drop;
+  }
+  a.scratch[j] = node;
+  a.scratch[a.m + j] = inc;
+  a.scratch[2 * a.m + j] = row;
+}
+
+// one wave per appended entry: copy its D-float feature row into the ring slot
+__global__ __launch_bounds__(256) void ring_update_feat_kernel(const UpdateArgs a) {
+  const long long j = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (j >= a.m) return;
+  const int row = a.scratch[2 * a.m + j];
+  if (row < 0) return;
+  const long long i = j >= a.n ? j - a.n : j;
+  float* __restrict__ o = a.ring_x + (long long)row * a.D;
+  if (a.edge_x) {
+    const float* __restrict__ x = a.edge_x + i * a.D;
+    for (int c = lane_id(); c < a.D; c += kWave) o[c] = x[c];
+  } else {
+    for (int c = lane_id(); c < a.D; c += kWave) o[c] = 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void ring_update_commit_kernel(const UpdateArgs a) {
+  const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= a.m) return;
+  const int inc = a.scratch[a.m + j];
+  if (inc > 0) {
+    const int node = a.scratch[j];
+    a.write_pos[node] = (a.write_pos[node] + inc) % a.B;  // one committer per node
+  }
+}
+
+__global__ __launch_bounds__(256) void ring_reset_kernel(Rec* ring, int32_t* write_pos, long long nrec, int N) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long step = (long long)gridDim.x * blockDim.x;
+  Rec pad;
+  pad.nbr = -1; pad.eid = 0; pad.ts = 0;
+  for (long long x = i; x < nrec; x += step) ring[x] = pad;
+  for (long long x = i; x < N; x += step) write_pos[x] = 0;
+}
+
+__global__ __launch_bounds__(256) void pack_adj_kernel(const int64_t* perm, long long m, const int32_t* src,
+                                                       const int32_t* dst, const int64_t* ts, long long E, Rec* adj) {
+  const long long step = (long long)gridDim.x * blockDim.x;
+  for (long long x = (long long)blockIdx.x * blockDim.x + threadIdx.x; x < m; x += step) {
+    const long long p = perm[x];
+    const bool rev = p >= E;
+    const long long e = rev ? p - E : p;
+    Rec r;
+    r.nbr = rev ? src[e] : dst[e];
+    r.eid = (int)e;
+    r.ts = ts[e];
+    adj[x] = r;
+  }
+}
+
+}  // namespace tgmx
+
+using namespace tgmx;
+
+extern "C" int tgmx_recency_lookup_csr(const int64_t* indptr, const tgmx_adj_t* adj, const float* edge_x, int32_t D,
+                                       const int32_t* seeds, const int64_t* qtimes, int64_t S, int32_t k, int32_t B,
+                                       int64_t ev_lo, int64_t ev_hi, int32_t num_nodes, int32_t allow_pad,
+                                       int32_t* out_nid, int64_t* out_ts, float* out_x, int32_t* status,
+                                       tgmx_stream_t stream) {
+  TGMX_REQUIRE(S >= 0 && k > 0 && B >= k && D >= 0 && num_nodes > 0, "recency_lookup_csr: bad sizes S=%lld k=%d B=%d D=%d N=%d",
+               (long long)S, k, B, D, num_nodes);
+  if (S == 0) return TGMX_OK;
+  TGMX_REQUIRE(indptr && adj && seeds && qtimes && out_nid && out_ts && status, "recency_lookup_csr: null pointer");
+  TGMX_REQUIRE(D == 0 || (edge_x && out_x), "recency_lookup_csr: D=%d but edge_x/out_x is null", D);
+  TGMX_REQUIRE(((uintptr_t)adj & 15) == 0, "recency_lookup_csr: adj must be 16-byte aligned");
+  LookupArgs a{};
+  a.indptr = indptr; a.recs = reinterpret_cast<const Rec*>(adj); a.write_pos = nullptr; a.edge_x = edge_x;
+  a.seeds = seeds; a.qtimes = qtimes; a.out_nid = out_nid; a.out_ts = out_ts; a.out_x = out_x; a.status = status;
+  a.S = S; a.ev_lo = ev_lo; a.ev_hi = ev_hi; a.D = D; a.k = k; a.B = B; a.N = num_nodes; a.allow_pad = allow_pad;
+  return launch_lookup<false>(a, (hipStream_t)stream);
+}
+
+extern "C" int tgmx_ring_lookup(const tgmx_adj_t* ring, const int32_t* write_pos, const float* ring_x, int32_t D,
+                                const int32_t* seeds, const int64_t* qtimes, int64_t S, int32_t k, int32_t B,
+                                int32_t num_nodes, int32_t allow_pad, int32_t* out_nid, int64_t* out_ts, float* out_x,
+                                int32_t* status, tgmx_stream_t stream) {
+  TGMX_REQUIRE(S >= 0 && k > 0 && B >= k && D >= 0 && num_nodes > 0, "ring_lookup: bad sizes S=%lld k=%d B=%d D=%d N=%d",
+               (long long)S, k, B, D, num_nodes);
+  if (S == 0) return TGMX_OK;
+  TGMX_REQUIRE(ring && write_pos && seeds && qtimes && out_nid && out_ts && status, "ring_lookup: null pointer");
+  TGMX_REQUIRE(D == 0 || (ring_x && out_x), "ring_lookup: D=%d but ring_x/out_x is null", D);
+  TGMX_REQUIRE(((uintptr_t)ring & 15) == 0, "ring_lookup: ring must be 16-byte aligned");
+  TGMX_REQUIRE((long long)B * num_nodes < 2147483647LL, "ring_lookup: num_nodes*B overflows int32");
+  LookupArgs a{};
+  a.indptr = nullptr; a.recs = reinterpret_cast<const Rec*>(ring); a.write_pos = write_pos; a.edge_x = ring_x;
+  a.seeds = seeds; a.qtimes = qtimes; a.out_nid = out_nid; a.out_ts = out_ts; a.out_x = out_x; a.status = status;
+  a.S = S; a.ev_lo = 0; a.ev_hi = 0; a.D = D; a.k = k; a.B = B; a.N = num_nodes; a.allow_pad = allow_pad;
+  return launch_lookup<true>(a, (hipStream_t)stream);
+}
+
+extern "C" int tgmx_ring_update(tgmx_adj_t* ring, int32_t* write_pos, float* ring_x, int32_t D, int32_t B,
+                                int32_t num_nodes, const int32_t* src, const int32_t* dst, const int64_t* ts,
+                                const float* edge_x, int64_t n, int64_t eid0, int32_t directed, int32_t* scratch,
+                                int32_t* status, tgmx_stream_t stream) {
+  TGMX_REQUIRE(n >= 0 && B > 0 && num_nodes > 0 && D >= 0, "ring_update: bad sizes n=%lld B=%d N=%d D=%d", (long long)n, B,
+               num_nodes, D);
+  if (n == 0) return TGMX_OK;
+  TGMX_REQUIRE(ring && write_pos && src && dst && ts && scratch && status, "ring_update: null pointer");
+  TGMX_REQUIRE(D == 0 || ring_x, "ring_update: D=%d but ring_x is null", D);
+  TGMX_REQUIRE(eid0 < 0 || eid0 + n <= 2147483647LL, "ring_update: edge ids overflow int32");
+  TGMX_REQUIRE((long long)B * num_nodes < 2147483647LL, "ring_update: num_nodes*B overflows int32");
+  UpdateArgs a{};
+  a.ring = reinterpret_cast<Rec*>(ring); a.write_pos = write_pos; a.ring_x = ring_x; a.edge_x = edge_x;
+  a.src = src; a.dst = dst; a.ts = ts; a.scratch = scratch; a.status = status;
+  a.n = n; a.m = directed ? n : 2 * n; a.eid0 = eid0; a.B = B; a.N = num_nodes; a.D = D;
+  const unsigned blocks = (unsigned)((a.m + 255) / 256);
+  hipLaunchKernelGGL(ring_update_rank_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+  if (D > 0)
+    hipLaunchKernelGGL(ring_update_feat_kernel, dim3((unsigned)((a.m + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(ring_update_commit_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+  TGMX_CHECK_LAUNCH("ring_update");
+  return TGMX_OK;
+}
+
+extern "C" int tgmx_ring_reset(tgmx_adj_t* ring, int32_t* write_pos, int32_t B, int32_t num_nodes,
+                               tgmx_stream_t stream) {
+  TGMX_REQUIRE(ring && write_pos && B > 0 && num_nodes > 0, "ring_reset: bad arguments");
+  const long long nrec = (long long)B * num_nodes;
+  long long blocks = (nrec + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(ring_reset_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<Rec*>(ring), write_pos, nrec, num_nodes);
+  TGMX_CHECK_LAUNCH("ring_reset");
+  return TGMX_OK;
+}
+
+extern "C" int tgmx_pack_adj(const int64_t* perm, int64_t m, const int32_t* src, const int32_t* dst, const int64_t* ts,
+                             int64_t num_edges, tgmx_adj_t* adj, tgmx_stream_t stream) {
+  TGMX_REQUIRE(m >= 0 && num_edges >= 0, "pack_adj: bad sizes");
+  if (m == 0) return TGMX_OK;
+  TGMX_REQUIRE(perm && src && dst && ts && adj, "pack_adj: null pointer");
+  long long blocks = (m + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(pack_adj_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, perm, (long long)m, src,
+                     dst, ts, (long long)num_edges, reinterpret_cast<Rec*>(adj));
+  TGMX_CHECK_LAUNCH("pack_adj");
+  return TGMX_OK;
+}

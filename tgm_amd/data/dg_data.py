@@ -1,0 +1,266 @@
+"""``DGData`` -- host-side ingest container for a temporal graph.
+
+Keeps the reference's field names and normalisation rules
+(tgm/data/dg_data.py:29-84 fields, :86-394 validation) because the rest of
+the drop-in surface (``DGraph``, hooks) reads these fields: one global,
+sorted ``time[int64]`` timeline over all events; ``edge_mask[int32]`` =
+position of every edge in that timeline; ``edge_index[int32, E x 2]``;
+``edge_x[float32, E x D]``; optional dynamic node events / labels and static
+node features.  Ingest is one-shot host work and is deliberately plain torch;
+everything per-batch lives on the device (see ``core/store.py``).
+
+Only ``from_raw`` is provided (csv / pandas / TGB loaders are out of scope,
+SURVEY.md section 2.1).
+"""
+from __future__ import annotations
+
+import warnings
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+from torch import Tensor
+
+from ..constants import PADDED_NODE_ID
+from ..core.timedelta import TimeDeltaDG
+from ..exceptions import EmptyGraphError, InvalidNodeIDError
+
+_INT_DTYPES = (torch.int8, torch.int16, torch.int32, torch.int64, torch.uint8)
+_I32_MAX = torch.iinfo(torch.int32).max
+
+
+def _need_tensor(x, name: str) -> None:
+    if not isinstance(x, Tensor):
+        raise TypeError(f'{name} must be a Tensor, got: {type(x)}')
+    if x.is_floating_point() and torch.isnan(x).any():
+        raise ValueError(f'{name} contains NaN values')
+
+
+def _need_integral(x: Tensor, name: str) -> None:
+    if x.dtype not in _INT_DTYPES:
+        raise TypeError(f'{name} must have integer dtype but got: {x.dtype}')
+
+
+def _as_f32(x: Tensor, name: str) -> Tensor:
+    if x.dtype == torch.float64:
+        warnings.warn(f'Downcasting {name} from torch.float64 to torch.float32', UserWarning)
+    return x if x.dtype == torch.float32 else x.to(torch.float32)
+
+
+def _as_i32(x: Tensor, name: str) -> Tensor:
+    if x.dtype == torch.int64:
+        warnings.warn(f'Downcasting {name} from torch.int64 to torch.int32', UserWarning)
+    return x if x.dtype == torch.int32 else x.to(torch.int32)
+
+
+def _check_node_ids(x: Tensor, what: str) -> None:
+    if torch.any(x == PADDED_NODE_ID):
+        raise InvalidNodeIDError(
+            f'{what} contains node ids matching PADDED_NODE_ID: {PADDED_NODE_ID}, which marks empty '
+            'neighbor slots. Remap node ids to non-negative integers.'
+        )
+    if not torch.all(x < _I32_MAX):
+        raise InvalidNodeIDError(f'{what} contains node ids that exceed the int32 limit ({_I32_MAX}).')
+
+
+@dataclass
+class DGData:
+    time_delta: TimeDeltaDG | str
+    time: Tensor  # [num_events] int64, sorted
+
+    edge_mask: Tensor  # [E] int32 -> index into ``time``
+    edge_index: Tensor  # [E, 2] int32
+    edge_x: Optional[Tensor] = None  # [E, D] float32
+
+    node_x_mask: Optional[Tensor] = None
+    node_x_nids: Optional[Tensor] = None
+    node_x: Optional[Tensor] = None
+
+    node_y_mask: Optional[Tensor] = None
+    node_y_nids: Optional[Tensor] = None
+    node_y: Optional[Tensor] = None
+
+    static_node_x: Optional[Tensor] = None  # [N, d0] float32
+    edge_type: Optional[Tensor] = None
+    node_type: Optional[Tensor] = None
+
+    def __post_init__(self) -> None:
+        if isinstance(self.time_delta, str):
+            self.time_delta = TimeDeltaDG(self.time_delta)
+
+        _need_tensor(self.time, 'timestamps')
+        _need_integral(self.time, 'timestamps')
+        if not torch.all(self.time >= 0):
+            raise ValueError('timestamps must all be non-negative')
+        if not torch.all(self.time < _I32_MAX):
+            raise ValueError(f'timestamps exceed the int32 limit ({_I32_MAX}).')
+        self.time = self.time.to(torch.int64)
+        if len(self.time) > _I32_MAX:
+            raise ValueError(f'Number of events ({len(self.time)}) exceeds the int32 limit ({_I32_MAX}).')
+
+        _need_tensor(self.edge_index, 'edge_index')
+        _need_integral(self.edge_index, 'edge_index')
+        if self.edge_index.ndim != 2 or self.edge_index.shape[1] != 2:
+            raise ValueError(f'edge_index must have shape [num_edges, 2], got: {self.edge_index.shape}')
+        _check_node_ids(self.edge_index, 'Edge events')
+        self.edge_index = _as_i32(self.edge_index, 'edge_index')
+        E = self.edge_index.shape[0]
+        if E == 0:
+            raise EmptyGraphError('graphs without edge events are not supported')
+
+        _need_tensor(self.edge_mask, 'edge_mask')
+        _need_integral(self.edge_mask, 'edge_mask')
+        self.edge_mask = self.edge_mask.to(torch.int32)
+
+        if self.edge_x is not None:
+            _need_tensor(self.edge_x, 'edge_x')
+            if self.edge_x.ndim != 2 or self.edge_x.shape[0] != E:
+                raise ValueError(f'edge features must have shape [num_edges, D_edge], got {E} edges and shape {self.edge_x.shape}')
+            self.edge_x = _as_f32(self.edge_x, 'edge_x')
+
+        n_node_events = self._check_node_events('node_x')
+        n_node_labels = self._check_node_events('node_y')
+
+        num_nodes = int(self.edge_index.max()) + 1
+        if self.node_x_nids is not None:
+            num_nodes = max(num_nodes, int(self.node_x_nids.max()) + 1)
+        if self.node_y_nids is not None and int(self.node_y_nids.max()) + 1 > num_nodes:
+            raise InvalidNodeIDError(
+                f"Dynamic node labels reference node ids outside the graph's range (max label id "
+                f'{int(self.node_y_nids.max())}, num_nodes {num_nodes}).'
+            )
+
+        if self.static_node_x is not None:
+            _need_tensor(self.static_node_x, 'static_node_x')
+            if self.static_node_x.ndim != 2:
+                raise ValueError(f'static_node_x must be [N, D_node_static], got shape {self.static_node_x.shape}')
+            if self.static_node_x.shape[0] < num_nodes:
+                raise ValueError(
+                    f'static_node_x has shape {self.static_node_x.shape} but the data needs features for at least {num_nodes} nodes'
+                )
+            self.static_node_x = _as_f32(self.static_node_x, 'static_node_x')
+
+        if self.edge_type is not None:
+            _need_tensor(self.edge_type, 'edge_type')
+            _need_integral(self.edge_type, 'edge_type')
+            if self.edge_type.ndim != 1 or self.edge_type.shape[0] != E:
+                raise ValueError(f'edge_type must have shape [num_edges], got {self.edge_type.shape}')
+        if self.node_type is not None:
+            _need_tensor(self.node_type, 'node_type')
+            _need_integral(self.node_type, 'node_type')
+            if self.node_type.ndim != 1 or self.node_type.shape[0] < num_nodes:
+                raise ValueError(f'node_type must have shape [num_nodes], got {self.node_type.shape}')
+
+        if self.time.ndim != 1 or self.time.shape[0] != E + n_node_events + n_node_labels:
+            raise ValueError(
+                f'time must have shape [num_edges + num_node_events + num_node_labels], got {E} edges, '
+                f'{n_node_events} node events, {n_node_labels} node labels, shape {self.time.shape}'
+            )
+
+        if not torch.all(self.time[1:] >= self.time[:-1]):
+            self._sort_timeline()
+
+    # ------------------------------------------------------------------
+    def _check_node_events(self, prefix: str) -> int:
+        mask = getattr(self, f'{prefix}_mask')
+        if mask is None:
+            return 0
+        _need_tensor(mask, f'{prefix}_mask')
+        _need_integral(mask, f'{prefix}_mask')
+        mask = mask.to(torch.int32)
+        setattr(self, f'{prefix}_mask', mask)
+        n = mask.shape[0]
+        if n == 0:
+            raise ValueError(f'{prefix}_mask is an empty tensor, please double-check your inputs')
+        nids = getattr(self, f'{prefix}_nids')
+        _need_tensor(nids, f'{prefix}_nids')
+        _need_integral(nids, f'{prefix}_nids')
+        if nids.ndim != 1 or nids.shape[0] != n:
+            raise ValueError(f'{prefix}_nids must have shape [{n}], got {nids.shape}')
+        _check_node_ids(nids, f'{prefix} events')
+        setattr(self, f'{prefix}_nids', _as_i32(nids, f'{prefix}_nids'))
+        vals = getattr(self, prefix)
+        if vals is not None:
+            _need_tensor(vals, prefix)
+            if vals.ndim != 2 or vals.shape[0] != n:
+                raise ValueError(f'{prefix} must have shape [{n}, D], got {vals.shape}')
+            setattr(self, prefix, _as_f32(vals, prefix))
+        return n
+
+    def _sort_timeline(self) -> None:
+        """Reorder every event array to the (stable) time-sorted order."""
+        warnings.warn('Timestamps in DGData are not globally sorted; reordering all events', UserWarning)
+        order = torch.argsort(self.time, stable=True)
+        rank = torch.empty_like(order)
+        rank[order] = torch.arange(len(order))
+        self.time = self.time[order]
+
+        def regroup(mask: Tensor, *payload):
+            new_pos = rank[mask.long()]
+            o = torch.argsort(new_pos, stable=True)
+            return (new_pos[o].to(torch.int32),) + tuple(None if p is None else p[o] for p in payload)
+
+        self.edge_mask, self.edge_index, self.edge_x, self.edge_type = regroup(
+            self.edge_mask, self.edge_index, self.edge_x, self.edge_type
+        )
+        if self.node_x_mask is not None:
+            self.node_x_mask, self.node_x_nids, self.node_x = regroup(self.node_x_mask, self.node_x_nids, self.node_x)
+        if self.node_y_mask is not None:
+            self.node_y_mask, self.node_y_nids, self.node_y = regroup(self.node_y_mask, self.node_y_nids, self.node_y)
+
+    # ------------------------------------------------------------------
+    @property
+    def num_nodes(self) -> int:
+        n = int(self.edge_index.max()) + 1
+        if self.node_x_nids is not None:
+            n = max(n, int(self.node_x_nids.max()) + 1)
+        return n
+
+    @classmethod
+    def from_raw(
+        cls,
+        edge_time: Tensor,
+        edge_index: Tensor,
+        edge_x: Optional[Tensor] = None,
+        node_x_time: Optional[Tensor] = None,
+        node_x_nids: Optional[Tensor] = None,
+        node_x: Optional[Tensor] = None,
+        node_y_time: Optional[Tensor] = None,
+        node_y_nids: Optional[Tensor] = None,
+        node_y: Optional[Tensor] = None,
+        static_node_x: Optional[Tensor] = None,
+        time_delta: TimeDeltaDG | str = 'r',
+        edge_type: Optional[Tensor] = None,
+        node_type: Optional[Tensor] = None,
+    ) -> 'DGData':
+        """Concatenate edge / node-event / node-label timelines (in that order) and
+        record each group's positions; same argument list as tgm/data/dg_data.py:592-607."""
+        E = edge_time.shape[0]
+        pieces = [edge_time]
+        edge_mask = torch.arange(E)
+        node_x_mask = node_y_mask = None
+        off = E
+        if node_x_time is not None:
+            pieces.append(node_x_time)
+            node_x_mask = torch.arange(off, off + node_x_time.shape[0])
+            off += node_x_time.shape[0]
+        if node_y_time is not None:
+            pieces.append(node_y_time)
+            node_y_mask = torch.arange(off, off + node_y_time.shape[0])
+        time = torch.cat([p.to(torch.int64) if p.dtype in _INT_DTYPES else p for p in pieces])
+        return cls(
+            time_delta=time_delta,
+            time=time,
+            edge_mask=edge_mask,
+            edge_index=edge_index,
+            edge_x=edge_x,
+            node_x_mask=node_x_mask,
+            node_x_nids=node_x_nids,
+            node_x=node_x,
+            node_y_mask=node_y_mask,
+            node_y_nids=node_y_nids,
+            node_y=node_y,
+            static_node_x=static_node_x,
+            edge_type=edge_type,
+            node_type=node_type,
+        )

@@ -1,0 +1,94 @@
+"""``DGDataLoader`` -- iterate a ``DGraph`` in event- or time-unit batches.
+
+Same constructor and behaviour as tgm/data/loader.py:64-170 (batch_size,
+batch_unit, on_empty, hook_manager, drop_last), but it is a plain Python
+iterator instead of a ``torch.utils.data.DataLoader`` subclass: a batch here is
+two integers plus zero-copy views, so the DataLoader machinery (sampler,
+fetcher, collate indirection) would be the dominant per-batch cost.  Like the
+reference it always runs in the caller's process (hook state must not fork).
+"""
+from __future__ import annotations
+
+from typing import Any, Iterator, Literal, Optional
+
+from ..core import DGBatch, DGraph, TimeDeltaDG
+from ..exceptions import EmptyBatchError, EventOrderedConversionError, InvalidDiscretizationError
+
+
+class DGDataLoader:
+    def __init__(
+        self,
+        dg: DGraph,
+        batch_size: int = 1,
+        batch_unit: str = 'r',
+        on_empty: Literal['skip', 'raise', None] = 'skip',
+        hook_manager: Optional[Any] = None,
+        **kwargs: Any,
+    ) -> None:
+        if batch_size <= 0:
+            raise ValueError(f'batch_size must be > 0 but got {batch_size}')
+        if on_empty not in ('skip', 'raise', None):
+            raise ValueError(f"Invalid on_empty={on_empty}, expected one of: ['skip', 'raise', None]")
+
+        unit = TimeDeltaDG(batch_unit)
+        if dg.time_delta.is_event_ordered and unit.is_time_ordered:
+            raise EventOrderedConversionError('Cannot iterate event-ordered dg using time-ordered batch_unit')
+        if dg.time_delta.is_time_ordered and unit.is_time_ordered:
+            unit = TimeDeltaDG(batch_unit, value=batch_size)
+            if dg.time_delta.is_coarser_than(unit):
+                raise InvalidDiscretizationError(
+                    f'DGraph time delta {dg.time_delta} is strictly coarser than batch_unit={batch_unit}, '
+                    f'batch_size={batch_size}; choose a larger batch or iterate event-ordered.'
+                )
+            batch_size = int(unit.convert(dg.time_delta))
+
+        assert dg.start_time is not None and dg.end_time is not None
+        self._dg = dg
+        self._batch_size = batch_size
+        self._hook_manager = hook_manager
+        self._on_empty = on_empty
+
+        if unit.is_event_ordered:
+            self._slice_op = dg.slice_events
+            start, stop = 0, dg.num_events
+            # an event-ordered view over a sub-range starts at its own first event
+            lb, _ = dg._event_range
+            start, stop = lb, lb + dg.num_events
+        else:
+            self._slice_op = dg.slice_time
+            start, stop = dg.start_time, dg.end_time + 1
+        if kwargs.get('drop_last', False):
+            stop = stop - batch_size
+        self._starts = range(start, stop, batch_size)
+
+    @property
+    def dgraph(self) -> DGraph:
+        return self._dg
+
+    def __len__(self) -> int:
+        return len(self._starts)
+
+    def __call__(self, slice_start) -> DGBatch:
+        """Materialize the batch beginning at ``slice_start`` and run the active hooks."""
+        s = slice_start[0] if isinstance(slice_start, (list, tuple)) else slice_start
+        view = self._slice_op(s, s + self._batch_size)
+        batch = view.materialize()
+        if self._hook_manager is not None:
+            batch = self._hook_manager.execute_active_hooks(view, batch)
+        return batch
+
+    @staticmethod
+    def _is_batch_empty(batch: DGBatch) -> bool:
+        n = batch.edge_src.numel()
+        n += batch.node_x_nids.numel() if batch.node_x_nids is not None else 0
+        n += batch.node_y_nids.numel() if batch.node_y_nids is not None else 0
+        return n == 0
+
+    def __iter__(self) -> Iterator[DGBatch]:
+        for s in self._starts:
+            batch = self(s)
+            if self._on_empty is not None and self._is_batch_empty(batch):
+                if self._on_empty == 'raise':
+                    raise EmptyBatchError('Empty batch encountered')
+                continue
+            yield batch

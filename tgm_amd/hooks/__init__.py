@@ -1,0 +1,20 @@
+from .base import BaseDGHook, DGHook, SeedableHook, StatefulHook, StatelessHook
+from .dedup import DeduplicationHook
+from .hook_manager import HookManager
+from .negatives import RandomNegativeEdgeSamplerHook
+from .recency import RecencyNeighborHook
+from .registry import hook, list_hooks
+
+__all__ = [
+    'BaseDGHook',
+    'DGHook',
+    'DeduplicationHook',
+    'HookManager',
+    'RandomNegativeEdgeSamplerHook',
+    'RecencyNeighborHook',
+    'SeedableHook',
+    'StatefulHook',
+    'StatelessHook',
+    'hook',
+    'list_hooks',
+]

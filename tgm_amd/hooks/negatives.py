@@ -1,0 +1,58 @@
+"""Random negative destinations for link prediction.
+
+Same contract as tgm/hooks/negatives/sampler.py:15-65: ``neg`` = uniform int32
+ids in ``[low, high)`` (one per positive edge, times ``neg_ratio``), ``neg_time``
+= a copy of the batch's edge times.  This is a single ``randint`` on the batch's
+device; it produces the third seed group the neighbor sampler consumes.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from ..core import DGBatch, DGraph
+from .base import StatelessHook
+from .registry import hook
+
+
+@hook
+class RandomNegativeEdgeSamplerHook(StatelessHook):
+    """Random sampling of negative edges for dynamic link prediction.
+
+    Key words: negative sampler, random, uniform, training, link prediction.
+    """
+
+    _cls_requires = {'edge_src', 'edge_dst', 'edge_time'}
+    _cls_produces = {'neg', 'neg_time'}
+
+    def __init__(self, low: int, high: int, neg_ratio: float = 1.0, id: Optional[str] = None, seed: Optional[int] = None) -> None:
+        super().__init__()
+        if not 0 < neg_ratio <= 1:
+            raise ValueError(f'neg_ratio must be in (0, 1], got: {neg_ratio}')
+        if not low < high:
+            raise ValueError(f'low ({low}) must be strictly less than high ({high})')
+        self.low, self.high, self.neg_ratio = low, high, neg_ratio
+        self._seed = seed
+        self._gen: Optional[torch.Generator] = None
+        self._id = id
+        self.__post_init__()
+
+    def __call__(self, dg: DGraph, batch: DGBatch) -> DGBatch:
+        n = round(self.neg_ratio * batch.edge_dst.size(0))
+        device = dg.device
+        if n == 0:
+            neg = torch.empty((0,), dtype=torch.int32, device=device)
+            neg_time = torch.empty((0,), dtype=torch.int64, device=device)
+        else:
+            gen = None
+            if self._seed is not None:
+                if self._gen is None or self._gen.device != torch.empty(0, device=device).device:
+                    self._gen = torch.Generator(device=device)
+                    self._gen.manual_seed(self._seed)
+                gen = self._gen
+            neg = torch.randint(self.low, self.high, (n,), dtype=torch.int32, device=device, generator=gen)
+            neg_time = batch.edge_time.clone()
+        self.add_batch_attribute(batch, 'neg', neg)
+        self.add_batch_attribute(batch, 'neg_time', neg_time)
+        return batch

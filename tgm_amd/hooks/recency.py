@@ -1,0 +1,363 @@
+"""``RecencyNeighborHook`` -- k-most-recent temporal neighbor sampling on MI355X.
+
+Drop-in for tgm/hooks/neighbors/recency.py:18 (same constructor, same
+``requires`` / ``produces``, same six batch attributes with the same dtypes,
+shapes, padding and ordering) whose per-batch work runs in the HIP kernels of
+``csrc/recency.hip``:
+
+``mode='ring'`` (default)
+    The reference's state machine, kept on the device: per-node rings of
+    ``B = max(num_nbrs)`` 16-byte records + their feature rows, looked up for
+    every hop and then appended to with the batch's edges.  Works for any batch
+    sequence, exactly like the reference.
+``mode='csr'``
+    Stateless lookup into a static per-node index of the resident stream
+    (``tgm_amd.index``); valid for chronological loaders whose batch boundaries
+    are known (``batch_size=`` / ``batch_starts=``).  No per-batch update, any
+    batch can be sampled at any time on any GPU.
+
+Seed validation (recency.py:173-237) happens inside the lookup kernel (device
+status word).  ``validate='sync'`` (default) reads the word every call and
+raises ``ValueError`` like the reference; ``'deferred'`` only raises when
+:meth:`check` is called, keeping the stream fully asynchronous.
+"""
+from __future__ import annotations
+
+import warnings
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+from torch import Tensor
+
+from .. import _native
+from ..constants import PADDED_NODE_ID
+from ..core import DGBatch, DGraph
+from ..index import TemporalCSR, build_csr
+from .base import SeedableHook, StatefulHook
+from .registry import hook
+
+_ST_SEED_RANGE, _ST_SEED_TIME, _ST_EDGE_RANGE = 1, 2, 4
+
+
+@hook
+class RecencyNeighborHook(StatefulHook, SeedableHook):
+    """Load neighbors using recency sampling: each node keeps its most recent neighbors.
+
+    Args:
+        num_nodes: total number of nodes to track.
+        num_nbrs: neighbors to sample at each hop.
+        seed_nodes_keys / seed_times_keys: batch attributes naming hop-0 seeds / query times.
+        directed: only aggregate src->dst interactions.
+        id: suffix for the hook name and every produced attribute.
+        mode: 'ring' (streaming state, default) or 'csr' (static index, stateless).
+        validate: 'sync' | 'deferred' | 'off'.
+        batch_size / batch_starts: loader schedule, required by ``mode='csr'``.
+
+    Key words: k-hop neighbour, recency, historical.
+    """
+
+    _cls_requires = {'edge_src', 'edge_dst', 'edge_time'}
+    _cls_produces = {'seed_nids', 'seed_times', 'nbr_nids', 'nbr_edge_time', 'nbr_edge_x', 'seed_node_nbr_mask'}
+
+    def __init__(
+        self,
+        num_nodes: int,
+        num_nbrs: List[int],
+        seed_nodes_keys: List[str],
+        seed_times_keys: List[str],
+        directed: bool = False,
+        id: Optional[str] = None,
+        mode: str = 'ring',
+        validate: str = 'sync',
+        batch_size: Optional[int] = None,
+        batch_starts: Optional[Sequence[int]] = None,
+    ) -> None:
+        super().__init__()
+        if not len(num_nbrs):
+            raise ValueError('num_nbrs must be non-empty')
+        if not all(isinstance(x, int) and x > 0 for x in num_nbrs):
+            raise ValueError('Each value in num_nbrs must be a positive integer')
+        if len(seed_nodes_keys) != len(seed_times_keys):
+            raise ValueError(
+                f'len(seed_nodes_keys) ({len(seed_nodes_keys)}) != len(seed_times_keys) ({len(seed_times_keys)})\n'
+                f'seed_nodes_keys={seed_nodes_keys}, seed_times_keys={seed_times_keys}'
+            )
+        if mode not in ('ring', 'csr'):
+            raise ValueError(f"mode must be 'ring' or 'csr', got {mode!r}")
+        if validate not in ('sync', 'deferred', 'off'):
+            raise ValueError(f"validate must be 'sync', 'deferred' or 'off', got {validate!r}")
+        if mode == 'csr' and batch_size is None and batch_starts is None:
+            raise ValueError("mode='csr' needs the loader schedule: pass batch_size= or batch_starts=")
+
+        self._num_nodes = int(num_nodes)
+        self._num_nbrs = list(num_nbrs)
+        self._max_nbrs = max(num_nbrs)
+        self._directed = bool(directed)
+        self._seed_nodes_keys = list(seed_nodes_keys)
+        self._seed_times_keys = list(seed_times_keys)
+        self._mode = mode
+        self._validate = validate
+        self._batch_size = batch_size
+        self._batch_starts = batch_starts
+        self._warned_seed_None = False
+
+        self._device: Optional[torch.device] = None
+        self._edge_x_dim: Optional[int] = None
+        # ring state (device)
+        self._ring: Optional[Tensor] = None  # [N*B, 2] int64 == 16-byte records
+        self._ring_x: Optional[Tensor] = None  # [N*B, D] float32
+        self._write_pos: Optional[Tensor] = None  # [N] int32
+        self._scratch: Optional[Tensor] = None
+        self._status: Optional[Tensor] = None  # [1] int32 device status word
+        # csr state
+        self._csr: Optional[TemporalCSR] = None
+        self._csr_store = None
+        self._epoch_lo: Optional[int] = None  # first edge index visible in this epoch
+
+        self._id = id
+        self.seed_keys = list(seed_nodes_keys)
+        self.__post_init__()
+
+    # ------------------------------------------------------------------
+    @property
+    def num_nbrs(self) -> List[int]:
+        return self._num_nbrs
+
+    @property
+    def mode(self) -> str:
+        return self._mode
+
+    def reset_state(self) -> None:
+        """Forget all history (recency.py:111-117)."""
+        if self._mode == 'ring':
+            if self._ring is not None:
+                lib = _native.load()
+                with torch.cuda.device(self._device):
+                    _native.check(
+                        lib.tgmx_ring_reset(
+                            self._ring.data_ptr(), self._write_pos.data_ptr(), self._max_nbrs, self._num_nodes, _native.stream_ptr()
+                        ),
+                        'tgmx_ring_reset',
+                    )
+        else:
+            self._epoch_lo = None  # re-anchored at the next batch's first edge
+
+    def check(self) -> None:
+        """Raise the ``ValueError`` the reference would have raised for bad seeds
+        seen since the last check (one device->host read)."""
+        if self._status is None:
+            return
+        st = int(self._status.item())
+        if st:
+            self._status.zero_()
+            self._raise_status(st)
+
+    def _raise_status(self, st: int) -> None:
+        if st & _ST_SEED_RANGE:
+            raise ValueError(f'Seed nodes must satisfy 0 <= x < {self._num_nodes}')
+        if st & _ST_SEED_TIME:
+            raise ValueError('Seed times must be >= 0')
+        if st & _ST_EDGE_RANGE:
+            raise ValueError(f'Batch edge endpoints must satisfy 0 <= x < {self._num_nodes}')
+
+    # ------------------------------------------------------------------
+    def _ensure_state(self, dg: DGraph, device: torch.device) -> None:
+        if self._edge_x_dim is None:
+            self._edge_x_dim = dg.edge_x_dim or 0
+        if self._device == device and self._status is not None:
+            return
+        if device.type != 'cuda':
+            raise _native.NativeLibraryError(
+                f'RecencyNeighborHook got a batch on {device}; tgm_amd kernels run only on a ROCm device '
+                "(no CPU fallback). Create the DGraph with device='cuda'."
+            )
+        _native.load()
+        N, B, D = self._num_nodes, self._max_nbrs, self._edge_x_dim
+        old = self._device
+        self._device = device
+        if self._status is None or old != device:
+            self._status = torch.zeros(1, dtype=torch.int32, device=device)
+        if self._mode == 'ring':
+            if self._ring is None:
+                self._ring = torch.empty((N * B, 2), dtype=torch.int64, device=device)
+                self._ring_x = torch.empty((N * B, max(D, 1)), dtype=torch.float32, device=device) if D else None
+                self._write_pos = torch.empty(N, dtype=torch.int32, device=device)
+                self.reset_state()
+            elif old != device:  # migrate state (recency.py:401-408)
+                self._ring = self._ring.to(device)
+                self._ring_x = None if self._ring_x is None else self._ring_x.to(device)
+                self._write_pos = self._write_pos.to(device)
+                self._scratch = None
+
+    def _ensure_csr(self, dg: DGraph, batch: DGBatch) -> TemporalCSR:
+        store = dg._storage
+        if self._csr is None or self._csr_store is not store or self._csr.device != self._device:
+            arr = store.on(self._device)
+            first = batch._edge_lo or 0
+            self._csr = build_csr(
+                arr.src,
+                arr.dst,
+                arr.ts,
+                self._num_nodes,
+                batch_starts=self._batch_starts,
+                batch_size=self._batch_size,
+                first_edge=first,
+                directed=self._directed,
+            )
+            self._csr_store = store
+        return self._csr
+
+    # ------------------------------------------------------------------
+    def __call__(self, dg: DGraph, batch: DGBatch) -> DGBatch:
+        device = batch.edge_src.device
+        seeds, seed_times, seed_mask = self._get_seed_tensors(batch, device)
+        D = self._edge_x_dim if self._edge_x_dim is not None else (dg.edge_x_dim or 0)
+
+        out_seed_n: List[Tensor] = []
+        out_seed_t: List[Tensor] = []
+        out_n: List[Tensor] = []
+        out_t: List[Tensor] = []
+        out_x: List[Tensor] = []
+
+        if not seeds.numel():
+            # reference: CPU empties, and the update is skipped (recency.py:127-139)
+            for _ in self._num_nbrs:
+                out_seed_n.append(torch.empty(0, dtype=torch.int32))
+                out_seed_t.append(torch.empty(0, dtype=torch.int64))
+                out_n.append(torch.empty(0, dtype=torch.int32))
+                out_t.append(torch.empty(0, dtype=torch.int64))
+                out_x.append(torch.empty(0, dg.edge_x_dim or 0, dtype=torch.float32))
+        else:
+            self._ensure_state(dg, device)
+            D = self._edge_x_dim
+            lib = _native.load()
+            B, N = self._max_nbrs, self._num_nodes
+            status_p = self._status.data_ptr()
+            with torch.cuda.device(device):
+                stream = _native.stream_ptr()
+                if self._mode == 'csr':
+                    if batch._edge_lo is None:
+                        raise ValueError("mode='csr' needs batches materialized by tgm_amd.DGraph (batch._edge_lo is unset)")
+                    csr = self._ensure_csr(dg, batch)
+                    ev_hi = int(batch._edge_lo)
+                    if self._epoch_lo is None:
+                        self._epoch_lo = ev_hi
+                    ev_lo = self._epoch_lo
+                    edge_x = dg._storage.on(device).edge_x
+                    table_p, indptr_p, adj_p = _native.ptr(edge_x), csr.indptr.data_ptr(), csr.adj.data_ptr()
+                else:
+                    ring_p, wpos_p, table_p = self._ring.data_ptr(), self._write_pos.data_ptr(), _native.ptr(self._ring_x)
+
+                cur_n, cur_t = seeds, seed_times
+                for hop, k in enumerate(self._num_nbrs):
+                    S = cur_n.numel()
+                    nid = torch.empty((S, k), dtype=torch.int32, device=device)
+                    nts = torch.empty((S, k), dtype=torch.int64, device=device)
+                    nx = torch.empty((S, k, D), dtype=torch.float32, device=device)
+                    if self._mode == 'csr':
+                        rc = lib.tgmx_recency_lookup_csr(
+                            indptr_p, adj_p, table_p, D, cur_n.data_ptr(), cur_t.data_ptr(), S, k, B, ev_lo, ev_hi, N,
+                            1 if hop else 0, nid.data_ptr(), nts.data_ptr(), nx.data_ptr(), status_p, stream,
+                        )
+                    else:
+                        rc = lib.tgmx_ring_lookup(
+                            ring_p, wpos_p, table_p, D, cur_n.data_ptr(), cur_t.data_ptr(), S, k, B, N,
+                            1 if hop else 0, nid.data_ptr(), nts.data_ptr(), nx.data_ptr(), status_p, stream,
+                        )  # fmt: skip
+                    if rc:
+                        _native.check(rc, 'recency lookup')
+                    out_seed_n.append(cur_n)
+                    out_seed_t.append(cur_t)
+                    out_n.append(nid)
+                    out_t.append(nts)
+                    out_x.append(nx)
+                    cur_n, cur_t = nid.view(-1), nts.view(-1)
+
+                if self._validate == 'sync':
+                    self.check()  # before the update, so bad seeds leave the state untouched
+
+                n_edges = batch.edge_src.numel()
+                if self._mode == 'ring' and n_edges:
+                    m = n_edges if self._directed else 2 * n_edges
+                    if self._scratch is None or self._scratch.numel() < 3 * m:
+                        self._scratch = torch.empty(3 * m, dtype=torch.int32, device=device)
+                    ex = batch.edge_x
+                    if ex is not None and D:
+                        if ex.dtype != torch.float32 or not ex.is_contiguous():
+                            ex = ex.to(torch.float32).contiguous()
+                    else:
+                        ex = None
+                    src, dst, tt = batch.edge_src, batch.edge_dst, batch.edge_time
+                    if not (src.is_contiguous() and dst.is_contiguous() and tt.is_contiguous()):
+                        src, dst, tt = src.contiguous(), dst.contiguous(), tt.contiguous()
+                    eid0 = -1 if batch._edge_lo is None else int(batch._edge_lo)
+                    rc = lib.tgmx_ring_update(
+                        ring_p, wpos_p, table_p, D, B, N, src.data_ptr(), dst.data_ptr(), tt.data_ptr(), _native.ptr(ex),
+                        n_edges, eid0, 1 if self._directed else 0, self._scratch.data_ptr(), status_p, stream,
+                    )
+                    if rc:
+                        _native.check(rc, 'tgmx_ring_update')
+                    if self._validate == 'sync':
+                        self.check()
+
+        self.add_batch_attribute(batch, 'seed_nids', out_seed_n)
+        self.add_batch_attribute(batch, 'seed_times', out_seed_t)
+        self.add_batch_attribute(batch, 'nbr_nids', out_n)
+        self.add_batch_attribute(batch, 'nbr_edge_time', out_t)
+        self.add_batch_attribute(batch, 'nbr_edge_x', out_x)
+        self.add_batch_attribute(batch, 'seed_node_nbr_mask', seed_mask)
+        return batch
+
+    # ------------------------------------------------------------------
+    def _get_seed_tensors(self, batch: DGBatch, device: torch.device) -> Tuple[Tensor, Tensor, Dict[str, Tensor]]:
+        """Concatenate the hop-0 seeds (recency.py:173-237).  Structural checks
+        (missing / non-tensor / non-1-D) raise here; value checks (id range,
+        negative time) are done by the lookup kernel."""
+        seeds: List[Tensor] = []
+        times: List[Tensor] = []
+        mask: Dict[str, Tensor] = {}
+        offset = 0
+        for node_attr, time_attr in zip(self._seed_nodes_keys, self._seed_times_keys):
+            missing = [a for a in (node_attr, time_attr) if not hasattr(batch, a)]
+            if missing:
+                raise ValueError(f'Missing seed attributes {missing} on batch')
+            seed, time = getattr(batch, node_attr), getattr(batch, time_attr)
+            skip = False
+            for name, tensor in ((node_attr, seed), (time_attr, time)):
+                if tensor is None:
+                    if not self._warned_seed_None:
+                        warnings.warn(
+                            f'Seed attribute {name} is None on this batch, skipping this batch. '
+                            'Future occurrences will also be skipped but the warning will be suppressed',
+                            UserWarning,
+                        )
+                        self._warned_seed_None = True
+                    skip = True
+                    break
+                if not isinstance(tensor, Tensor):
+                    raise ValueError(f'{name} must be a Tensor, got {type(tensor)}')
+                if tensor.ndim != 1:
+                    raise ValueError(f'{name} must be 1-D, got shape {tensor.shape}')
+            if skip:
+                continue
+            if device.type != 'cuda' and self._validate != 'off' and seed.numel():
+                # host tensors: the value checks are free, do them eagerly like the reference
+                if bool((seed < 0).any()) or bool((seed >= self._num_nodes).any()):
+                    raise ValueError(
+                        f'Seed nodes in {node_attr} must satisfy 0 <= x < {self._num_nodes}, '
+                        f'got values in range [{seed.min().item()}, {seed.max().item()}]'
+                    )
+                if bool((time < 0).any()):
+                    raise ValueError(f'Seed times in {time_attr} must be >= 0, got min value: {time.min().item()}')
+            seeds.append(seed.to(device=device, dtype=torch.int32))
+            times.append(time.to(device=device, dtype=torch.int64))
+            n = seed.shape[0]
+            mask[node_attr] = torch.arange(offset, offset + n, device=device)
+            offset += n
+        if seeds:
+            return torch.cat(seeds), torch.cat(times), mask  # fresh tensors owned by the batch
+        return (
+            torch.empty(0, dtype=torch.int32, device=device),
+            torch.empty(0, dtype=torch.int64, device=device),
+            mask,
+        )
