@@ -88,14 +88,19 @@ int tgmx_ring_lookup(const tgmx_adj_t* ring, const int32_t* write_pos,
                      int32_t* out_nid, int64_t* out_ts, float* out_x,
                      int32_t* status, tgmx_stream_t stream);
 
-/* Append one batch of n edges (src[i], dst[i], ts[i], edge_x[i, :]) to the rings:
- * per node in stable (time, role, i) order, last B kept (recency.py:323-399).
+/* Append one batch of n edges (src[i], dst[i], ts[i], edge_x[i, :]) to the rings
+ * exactly as recency.py:323-399 does: stable sort of the cat[src-role, dst-role]
+ * entries by key = node * (max_t + 1) + t, per-run "keep last B", scatter at
+ * (write_pos + rank) % B (collisions: last wins), write_pos += kept.
+ * key_wrap32 = 1 evaluates node * (max_t + 1) in int32 like the reference does
+ * (recency.py:347; it wraps at dataset scale and the reference's results depend on
+ * it); key_wrap32 = 0 uses int64 (the intended per-node chronological order).
  * edge_x may be NULL (rows of zeros, recency.py:325-328).  eid0 = store index of
  * the batch's first edge or -1 (recorded in the slot, informational).
- * scratch: >= 3 * (directed ? n : 2n) int32.  */
+ * scratch: >= 4 * (directed ? n : 2n) int32.  */
 int tgmx_ring_update(tgmx_adj_t* ring, int32_t* write_pos, float* ring_x, int32_t D, int32_t B,
                      int32_t num_nodes, const int32_t* src, const int32_t* dst, const int64_t* ts,
-                     const float* edge_x, int64_t n, int64_t eid0, int32_t directed,
+                     const float* edge_x, int64_t n, int64_t eid0, int32_t directed, int32_t key_wrap32,
                      int32_t* scratch, int32_t* status, tgmx_stream_t stream);
 
 /* ring.fill(pad), write_pos.zero_()  (recency.py:111-117) */

@@ -1,0 +1,258 @@
+"""GPU parity: the HIP sampler (through the C ABI, via the drop-in hook) against
+the golden vectors recorded from the reference and against the CPU oracle.
+
+Bit-exact bar: neighbor ids, timestamps and the copied feature rows.
+"""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda'
+
+
+def _mk():
+    from tgm_amd import DGData, DGDataLoader, DGraph
+    from tgm_amd.hooks import HookManager, RecencyNeighborHook
+    from tgm_amd.hooks.base import StatelessHook
+
+    class ReplayNegatives(StatelessHook):
+        _cls_requires = {'edge_src', 'edge_dst', 'edge_time'}
+        _cls_produces = {'neg', 'neg_time'}
+
+        def __init__(self, neg):
+            super().__init__()
+            self.neg = neg
+            self.base = 0
+            self.__post_init__()
+
+        def __call__(self, dg, batch):
+            lo = self.base + batch._edge_lo
+            batch.neg = self.neg[lo : lo + batch.edge_src.numel()].clone()
+            batch.neg_time = batch.edge_time.clone()
+            return batch
+
+    return DGData, DGDataLoader, DGraph, HookManager, RecencyNeighborHook, ReplayNegatives
+
+
+def _graph(a, lo, hi, edge_x):
+    DGData, _, DGraph, *_ = _mk()
+    T = torch.from_numpy
+    d = DGData.from_raw(
+        T(a['ts'][lo:hi]),
+        torch.stack([T(a['src'][lo:hi]), T(a['dst'][lo:hi])], 1),
+        None if edge_x is None else edge_x[lo:hi],
+    )
+    return DGraph(d, device=DEV)
+
+
+def _compare(meta, a, b, batch, L, tag):
+    for h in range(L):
+        got = dict(
+            seed_nids=batch.seed_nids[h], seed_times=batch.seed_times[h], nbr_nids=batch.nbr_nids[h],
+            nbr_edge_time=batch.nbr_edge_time[h], nbr_edge_x=batch.nbr_edge_x[h],
+        )  # fmt: skip
+        for key, t in got.items():
+            name = f'b{b}_h{h}_{key}'
+            val = t.cpu().numpy()
+            if meta.get('digest_only'):
+                assert hashlib.sha256(np.ascontiguousarray(val).tobytes()).hexdigest() == meta['digests'][name], f'{tag} {name}'
+            else:
+                exp = a[name]
+                assert val.dtype == exp.dtype, f'{tag} {name}: dtype {val.dtype} vs {exp.dtype}'
+                assert val.shape == exp.shape, f'{tag} {name}: shape {val.shape} vs {exp.shape}'
+                np.testing.assert_array_equal(val, exp, err_msg=f'{tag} {name}')
+
+
+def _edge_x_of(case, a):
+    if case == 'g3_wiki_medium':
+        from tgm_amd.synth import make_stream
+
+        return make_stream('wiki', seed=1337, num_edges=20_000, edge_dim=8).edge_x
+    return torch.from_numpy(a['edge_x']) if 'edge_x' in a else None
+
+
+@pytest.mark.parametrize('case', gu.sampler_cases() + ['g3_wiki_medium'])
+def test_ring_mode_matches_reference_goldens(case):
+    """Default (streaming) mode == the reference on every fixture, incl. the int32-key regime (g3)."""
+    _, DGDataLoader, _, HookManager, RecencyNeighborHook, ReplayNegatives = _mk()
+    meta, a = gu.load(case)
+    edge_x = _edge_x_of(case, a)
+    keys = ['edge_src', 'edge_dst'] + (['neg'] if meta['has_neg'] else [])
+    tkeys = ['edge_time', 'edge_time'] + (['neg_time'] if meta['has_neg'] else [])
+    hook = RecencyNeighborHook(meta['num_nodes'], meta['num_nbrs'], keys, tkeys, directed=meta['directed'])
+    hm = HookManager(keys=['k'])
+    replay = None
+    if meta['has_neg']:
+        replay = ReplayNegatives(torch.from_numpy(a['neg']).to(DEV))
+        hm.register('k', replay)
+    hm.register('k', hook)
+    graphs = [(lo, _graph(a, lo, hi, edge_x)) for lo, hi in meta['segments']]
+    b = 0
+    with hm.activate('k'):
+        for step in meta['plan']:
+            if step == 'reset':
+                hm.reset_state()
+                continue
+            for lo, dg in graphs:
+                if replay is not None:
+                    replay.base = lo
+                for batch in DGDataLoader(dg, batch_size=meta['batch_size'], hook_manager=hm):
+                    _compare(meta, a, b, batch, len(meta['num_nbrs']), case)
+                    b += 1
+    assert b == meta['num_batches']
+
+
+@pytest.mark.parametrize('case', gu.sampler_cases())
+def test_csr_mode_matches_reference_goldens(case):
+    """Static-index mode on one resident store with train/val as views of it."""
+    DGData, DGDataLoader, DGraph, HookManager, RecencyNeighborHook, ReplayNegatives = _mk()
+    meta, a = gu.load(case)
+    edge_x = _edge_x_of(case, a)
+    E = len(a['src'])
+    full = _graph(a, 0, E, edge_x)
+    keys = ['edge_src', 'edge_dst'] + (['neg'] if meta['has_neg'] else [])
+    tkeys = ['edge_time', 'edge_time'] + (['neg_time'] if meta['has_neg'] else [])
+    hook = RecencyNeighborHook(
+        meta['num_nodes'], meta['num_nbrs'], keys, tkeys, directed=meta['directed'], mode='csr', batch_starts=gu.batch_starts(meta)
+    )
+    hm = HookManager(keys=['k'])
+    if meta['has_neg']:
+        hm.register('k', ReplayNegatives(torch.from_numpy(a['neg']).to(DEV)))
+    hm.register('k', hook)
+    b = 0
+    with hm.activate('k'):
+        for step in meta['plan']:
+            if step == 'reset':
+                hm.reset_state()
+                continue
+            for lo, hi in meta['segments']:
+                view = full.slice_events(lo, hi)
+                for batch in DGDataLoader(view, batch_size=meta['batch_size'], hook_manager=hm):
+                    _compare(meta, a, b, batch, len(meta['num_nbrs']), case)
+                    b += 1
+    assert b == meta['num_batches']
+
+
+def _random_stream(seed, N, E, D, tmax):
+    rng = np.random.default_rng(seed)
+    src = rng.integers(0, N, E).astype(np.int32)
+    dst = rng.integers(0, N, E).astype(np.int32)
+    ts = np.sort(rng.integers(1, tmax, E)).astype(np.int64)
+    x = rng.random((E, D), dtype=np.float32) if D else None
+    neg = rng.integers(0, N, E).astype(np.int32)
+    return dict(src=src, dst=dst, ts=ts, neg=neg), (None if x is None else torch.from_numpy(x))
+
+
+@pytest.mark.parametrize(
+    'N,E,D,tmax,num_nbrs,bs,directed,key_arith',
+    [
+        (300, 6000, 12, 50_000, [10, 10], 100, False, 'int32'),  # no wrap: 300*50k < 2^31
+        (3000, 8000, 4, 3_000_000, [5, 4], 64, False, 'int32'),  # wrapping keys
+        (3000, 8000, 4, 3_000_000, [5, 4], 64, False, 'int64'),
+        (500, 5000, 3, 1000, [70], 128, True, 'int32'),  # B > 64: general (chunked) path
+        (200, 4000, 6, 400, [3, 8, 2], 50, False, 'int32'),  # k < B on some hops, heavy ties
+        (100, 3000, 0, 300, [4, 4], 37, False, 'int32'),  # no edge features
+        (50, 3000, 5, 200, [20], 1000, False, 'int32'),  # runs longer than B inside one batch
+        (400, 3000, 7, 2000, [6], 60, False, 'int32'),  # D not a multiple of 4 (scalar gather path)
+        (400, 3000, 6, 2000, [6], 60, False, 'int32'),  # D % 2 == 0 (float2 path)
+    ],
+)
+def test_ring_mode_matches_oracle_random(N, E, D, tmax, num_nbrs, bs, directed, key_arith):
+    from oracle.ring_port import RingSamplerCPU
+
+    _, DGDataLoader, _, HookManager, RecencyNeighborHook, ReplayNegatives = _mk()
+    a, edge_x = _random_stream(1234 + N + E, N, E, D, tmax)
+    hook = RecencyNeighborHook(N, num_nbrs, ['edge_src', 'edge_dst', 'neg'], ['edge_time', 'edge_time', 'neg_time'],
+                               directed=directed, key_arith=key_arith)  # fmt: skip
+    hm = HookManager(keys=['k'])
+    hm.register('k', ReplayNegatives(torch.from_numpy(a['neg']).to(DEV)))
+    hm.register('k', hook)
+    oracle = RingSamplerCPU(N, num_nbrs, D, directed, key_arith=key_arith)
+    dg = _graph(a, 0, E, edge_x)
+    T = torch.from_numpy
+    with hm.activate('k'):
+        for b, batch in enumerate(DGDataLoader(dg, batch_size=bs, hook_manager=hm)):
+            lo, hi = b * bs, min((b + 1) * bs, E)
+            seeds = T(np.concatenate([a['src'][lo:hi], a['dst'][lo:hi], a['neg'][lo:hi]]))
+            times = T(np.concatenate([a['ts'][lo:hi]] * 3))
+            hops = oracle.step(seeds, times, T(a['src'][lo:hi]), T(a['dst'][lo:hi]), T(a['ts'][lo:hi]),
+                               None if edge_x is None else edge_x[lo:hi])  # fmt: skip
+            for h, (_, _, o_i, o_t, o_x) in enumerate(hops):
+                assert torch.equal(batch.nbr_nids[h].cpu(), o_i), f'b{b} h{h} ids'
+                assert torch.equal(batch.nbr_edge_time[h].cpu(), o_t), f'b{b} h{h} times'
+                assert torch.equal(batch.nbr_edge_x[h].cpu(), o_x), f'b{b} h{h} feats'
+
+
+def test_csr_mode_equals_ring_int64_random():
+    """Stateless CSR lookup == streaming rings with the intended key order, mid-size, non-bipartite."""
+    DGData, DGDataLoader, DGraph, HookManager, RecencyNeighborHook, ReplayNegatives = _mk()
+    N, E, D, bs, num_nbrs = 2000, 40_000, 16, 200, [20, 20]
+    a, edge_x = _random_stream(77, N, E, D, 20_000)  # ~2 edges per timestamp: ties across roles
+    outs = {}
+    for mode in ('ring', 'csr'):
+        hook = RecencyNeighborHook(N, num_nbrs, ['edge_src', 'edge_dst', 'neg'], ['edge_time', 'edge_time', 'neg_time'],
+                                   mode=mode, key_arith='int64', batch_size=bs, validate='deferred')  # fmt: skip
+        hm = HookManager(keys=['k'])
+        hm.register('k', ReplayNegatives(torch.from_numpy(a['neg']).to(DEV)))
+        hm.register('k', hook)
+        dg = _graph(a, 0, E, edge_x)
+        res = []
+        with hm.activate('k'):
+            for batch in DGDataLoader(dg, batch_size=bs, hook_manager=hm):
+                res.append([(batch.nbr_nids[h], batch.nbr_edge_time[h], batch.nbr_edge_x[h]) for h in range(2)])
+        hook.check()
+        outs[mode] = res
+    assert len(outs['ring']) == len(outs['csr']) == E // bs
+    for b, (r, c) in enumerate(zip(outs['ring'], outs['csr'])):
+        for h in range(2):
+            for x, y in zip(r[h], c[h]):
+                assert torch.equal(x, y), f'batch {b} hop {h}'
+
+
+def test_edge_cases_and_errors():
+    DGData, DGDataLoader, DGraph, HookManager, RecencyNeighborHook, _ = _mk()
+    a = dict(src=np.array([1, 2, 3], np.int32), dst=np.array([2, 3, 4], np.int32), ts=np.array([1, 2, 3], np.int64))
+    dg = _graph(a, 0, 3, None)
+    # no edge features -> [S, k, 0]
+    hook = RecencyNeighborHook(5, [1], ['edge_src', 'edge_dst'], ['edge_time', 'edge_time'], directed=True)
+    batch = hook(dg, dg.materialize())
+    assert batch.nbr_edge_x[0].shape == (6, 1, 0) and batch.nbr_nids[0].shape == (6, 1)
+    assert batch.seed_node_nbr_mask['edge_dst'].tolist() == [3, 4, 5]
+    # id suffix
+    hook = RecencyNeighborHook(5, [1], ['edge_src'], ['edge_time'], id='foo')
+    batch = hook(dg, dg.materialize())
+    assert hasattr(batch, 'nbr_nids_foo') and hasattr(batch, 'seed_node_nbr_mask_foo')
+    # out-of-range seed id / negative time raise ValueError (kernel-side validation, sync mode)
+    hook = RecencyNeighborHook(5, [1], ['foo'], ['bar'])
+    batch = dg.materialize()
+    batch.foo, batch.bar = torch.tensor([7], dtype=torch.int32, device=DEV), torch.tensor([1], device=DEV)
+    with pytest.raises(ValueError):
+        hook(dg, batch)
+    batch.foo = torch.tensor([-1], dtype=torch.int32, device=DEV)
+    with pytest.raises(ValueError):
+        hook(dg, batch)
+    batch.foo, batch.bar = torch.tensor([1], dtype=torch.int32, device=DEV), torch.tensor([-4], device=DEV)
+    with pytest.raises(ValueError):
+        hook(dg, batch)
+    # structural errors
+    batch.foo = 'nope'
+    with pytest.raises(ValueError):
+        hook(dg, batch)
+    batch.foo = torch.zeros(2, 3, device=DEV)
+    batch.bar = torch.zeros(2, 3, device=DEV)
+    with pytest.raises(ValueError):
+        hook(dg, batch)
+    del batch.foo
+    with pytest.raises(ValueError):
+        hook(dg, batch)
+    # None seeds: warn once, emit empties, skip the update
+    batch.foo, batch.bar = None, None
+    with pytest.warns(UserWarning):
+        out = hook(dg, batch)
+    assert out.nbr_nids[0].numel() == 0 and out.nbr_edge_x[0].shape == (0, 0)

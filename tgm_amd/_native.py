@@ -34,7 +34,7 @@ SIGNATURES = {
     ),
     'tgmx_ring_update': (
         c_int32,
-        [_P, _P, _P, c_int32, c_int32, c_int32, _P, _P, _P, _P, c_int64, c_int64, c_int32, _P, _P, _P],
+        [_P, _P, _P, c_int32, c_int32, c_int32, _P, _P, _P, _P, c_int64, c_int64, c_int32, c_int32, _P, _P, _P],
     ),
     'tgmx_ring_reset': (c_int32, [_P, _P, c_int32, c_int32, _P]),
     'tgmx_pack_adj': (c_int32, [_P, c_int64, _P, _P, _P, c_int64, _P, _P]),

@@ -250,11 +250,24 @@ static int launch_lookup(LookupArgs a, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------
-// Streaming rings: batched append (tgm/hooks/neighbors/recency.py:323-399).
+// Streaming rings: batched append -- a faithful restatement of
+// tgm/hooks/neighbors/recency.py:323-399 INCLUDING its key arithmetic.
+//
 // Entry j < n is (src[j] -> dst[j]), entry n + j is (dst[j] -> src[j]).  The
-// reference's stable argsort by (node, time) is restated as an all-pairs rank:
-// before(j) = #{j' same node : (t', j') < (t, j)} -- exact, deterministic, and
-// O(m^2 / lanes) for the m = 2*batch_size <= ~10^4 entries of a batch.
+// reference stably argsorts key = node * (max_t + 1) + t, where the product is
+// evaluated in int32 (an int32 tensor times a 0-dim int64 tensor stays int32) and
+// therefore wraps at dataset scale; it then treats every RUN of equal node ids
+// in that order as one group: keeps the run's last B entries, scatters them at
+// (write_pos[node] + rank_in_run) % B (runs of one node collide: the later one in
+// sorted order wins) and advances write_pos by the number of kept entries.
+// key_wrap32 = 0 evaluates the key in int64 (the intended (node, time) order).
+//
+// The sort of the m = 2 * batch_size entries is an all-pairs rank: exact, stable,
+// deterministic, no atomics; O(m^2 / lanes), microseconds for m <= ~10^4.
+//   k1 sort : rank every entry, scatter (entry, node) to its sorted position
+//   k2 place: run boundaries -> keep / ring slot per sorted position
+//   k3 write: resolve slot collisions (last wins), write records, commit write_pos
+//   k4 feat : one wave per written record copies its D-float feature row
 // ---------------------------------------------------------------------------
 struct UpdateArgs {
   Rec* ring;
@@ -264,82 +277,156 @@ struct UpdateArgs {
   const int32_t* src;
   const int32_t* dst;
   const int64_t* ts;
-  int32_t* scratch;  // [3m]: node, write_pos increment, ring row written (-1 = dropped)
+  int32_t* sorted_j;     // scratch [m]: entry index at sorted position p
+  int32_t* sorted_node;  // scratch [m]: its node (-1 = invalid entry)
+  int32_t* target;       // scratch [m]: ring row it is placed at (-1 = dropped)
+  int32_t* winner;       // scratch [m]: ring row it finally owns (-1 = none)
   int32_t* status;
   long long n, m, eid0;
-  int B, N, D;
+  int B, N, D, key_wrap32;
 };
 
-__global__ __launch_bounds__(256) void ring_update_rank_kernel(const UpdateArgs a) {
-  __shared__ int t_node[256];
-  __shared__ long long t_time[256];
+__device__ __forceinline__ long long update_key(int node, long long t, long long span, int wrap32) {
+  if (wrap32) {
+    const unsigned int prod = (unsigned int)node * (unsigned int)(int)span;  // int32 multiply, two's complement wrap
+    return (long long)(int)prod + t;
+  }
+  return (long long)node * span + t;
+}
+
+__device__ __forceinline__ void update_entry(const UpdateArgs& a, long long j, int& node, int& nbr, long long& t,
+                                             long long& i) {
+  const bool rev = j >= a.n;
+  i = rev ? j - a.n : j;
+  const int s = a.src[i], d = a.dst[i];
+  node = rev ? d : s;
+  nbr = rev ? s : d;
+  t = a.ts[i];
+}
+
+__global__ __launch_bounds__(256) void ring_update_sort_kernel(const UpdateArgs a) {
+  __shared__ long long t_key[256];
+  __shared__ long long red[256];
+  // span = max(ts) + 1 over the batch (every block reduces it redundantly: n is small)
+  long long mx = -0x7fffffffffffffffLL;
+  for (long long x = threadIdx.x; x < a.n; x += 256) {
+    const long long v = a.ts[x];
+    mx = v > mx ? v : mx;
+  }
+  red[threadIdx.x] = mx;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] = red[threadIdx.x + w] > red[threadIdx.x] ? red[threadIdx.x + w] : red[threadIdx.x];
+    __syncthreads();
+  }
+  const long long span = red[0] + 1;
+
   const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   int node = -1, nbr = -1;
-  long long t = 0, i = 0;
+  long long t = 0, i = 0, key = 0;
+  bool valid = false;
   if (j < a.m) {
-    const bool rev = j >= a.n;
-    i = rev ? j - a.n : j;
-    const int s = a.src[i], d = a.dst[i];
-    node = rev ? d : s;
-    nbr = rev ? s : d;
-    t = a.ts[i];
-    if (node < 0 || node >= a.N || nbr < 0 || nbr >= a.N) {
-      atomicOr(a.status, TGMX_ST_EDGE_RANGE);
-      node = -1;
-    }
+    update_entry(a, j, node, nbr, t, i);
+    valid = node >= 0 && node < a.N && nbr >= 0 && nbr < a.N;
+    if (!valid) atomicOr(a.status, TGMX_ST_EDGE_RANGE);
+    key = update_key(node, t, span, a.key_wrap32);
   }
-  int before = 0, total = 0;
+  int rank = 0;
   for (long long base = 0; base < a.m; base += 256) {
     const long long jj = base + threadIdx.x;
-    int nn = -2;
-    long long tt = 0;
+    long long kk = 0;
     if (jj < a.m) {
-      const bool rev = jj >= a.n;
-      const long long ii = rev ? jj - a.n : jj;
-      nn = rev ? a.dst[ii] : a.src[ii];
-      tt = a.ts[ii];
+      int n2, b2;
+      long long t2, i2;
+      update_entry(a, jj, n2, b2, t2, i2);
+      kk = update_key(n2, t2, span, a.key_wrap32);
     }
     __syncthreads();
-    t_node[threadIdx.x] = nn;
-    t_time[threadIdx.x] = tt;
+    t_key[threadIdx.x] = kk;
     __syncthreads();
     const int lim = (a.m - base) < 256 ? (int)(a.m - base) : 256;
-    if (node >= 0) {
+    for (int x = 0; x < lim; ++x) {
+      const long long kx = t_key[x];
+      rank += (kx < key) || (kx == key && base + x < j);
+    }
+  }
+  if (j < a.m) {
+    a.sorted_j[rank] = (int)j;
+    a.sorted_node[rank] = valid ? node : -1;
+  }
+}
+
+__global__ __launch_bounds__(256) void ring_update_place_kernel(const UpdateArgs a) {
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= a.m) return;
+  const int node = a.sorted_node[p];
+  int tgt = -1;
+  if (node >= 0) {
+    long long lo = p, hi = p + 1;
+    while (lo > 0 && a.sorted_node[lo - 1] == node) --lo;
+    while (hi < a.m && a.sorted_node[hi] == node) ++hi;
+    const int cnt = (int)(hi - lo), pos = (int)(p - lo);
+    const int drop = cnt > a.B ? cnt - a.B : 0;
+    if (pos >= drop) tgt = node * a.B + (a.write_pos[node] % a.B + pos - drop) % a.B;
+  }
+  a.target[p] = tgt;
+}
+
+__global__ __launch_bounds__(256) void ring_update_write_kernel(const UpdateArgs a) {
+  __shared__ int t_tgt[256];
+  __shared__ int t_node[256];
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  int tgt = -1, node = -1;
+  if (p < a.m) {
+    tgt = a.target[p];
+    node = a.sorted_node[p];
+  }
+  bool overwritten = false, later_kept = false;
+  int kept_total = 0;
+  for (long long base = 0; base < a.m; base += 256) {
+    const long long pp = base + threadIdx.x;
+    __syncthreads();
+    t_tgt[threadIdx.x] = pp < a.m ? a.target[pp] : -1;
+    t_node[threadIdx.x] = pp < a.m ? a.sorted_node[pp] : -2;
+    __syncthreads();
+    if (tgt >= 0) {
+      const int lim = (a.m - base) < 256 ? (int)(a.m - base) : 256;
       for (int x = 0; x < lim; ++x) {
-        const bool same = t_node[x] == node;
-        const long long tx = t_time[x];
-        total += same;
-        before += same && (tx < t || (tx == t && base + x < j));
+        const bool kept_same_node = t_node[x] == node && t_tgt[x] >= 0;
+        kept_total += kept_same_node;
+        const bool later = base + x > p;
+        later_kept |= later && kept_same_node;
+        overwritten |= later && t_tgt[x] == tgt;
       }
     }
   }
-  if (j >= a.m) return;
-  int inc = 0, row = -1;
-  if (node >= 0) {
-    const int drop = total > a.B ? total - a.B : 0;
-    if (before >= drop) {
-      const int w = a.write_pos[node] % a.B;
-      const int slot = (w + before - drop) % a.B;
+  if (p >= a.m) return;
+  int win = -1;
+  if (tgt >= 0) {
+    if (!overwritten) {
+      const long long j = a.sorted_j[p];
+      int nd, nbr;
+      long long t, i;
+      update_entry(a, j, nd, nbr, t, i);
       Rec r;
       r.nbr = nbr;
       r.eid = a.eid0 >= 0 ? (int)(a.eid0 + i) : -1;
       r.ts = t;
-      row = node * a.B + slot;
-      a.ring[row] = r;
+      a.ring[tgt] = r;
+      win = tgt;
     }
-    if (before == total - 1) inc = total - drop;
+    if (!later_kept) a.write_pos[node] = (a.write_pos[node] % a.B + kept_total) % a.B;  // one committer per node
   }
-  a.scratch[j] = node;
-  a.scratch[a.m + j] = inc;
-  a.scratch[2 * a.m + j] = row;
+  a.winner[p] = win;
 }
 
-// one wave per appended entry: copy its D-float feature row into the ring slot
+// one wave per sorted position: copy the winning entry's D-float feature row
 __global__ __launch_bounds__(256) void ring_update_feat_kernel(const UpdateArgs a) {
-  const long long j = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (j >= a.m) return;
-  const int row = a.scratch[2 * a.m + j];
+  const long long p = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (p >= a.m) return;
+  const int row = a.winner[p];
   if (row < 0) return;
+  const long long j = a.sorted_j[p];
   const long long i = j >= a.n ? j - a.n : j;
   float* __restrict__ o = a.ring_x + (long long)row * a.D;
   if (a.edge_x) {
@@ -347,16 +434,6 @@ __global__ __launch_bounds__(256) void ring_update_feat_kernel(const UpdateArgs 
     for (int c = lane_id(); c < a.D; c += kWave) o[c] = x[c];
   } else {
     for (int c = lane_id(); c < a.D; c += kWave) o[c] = 0.f;
-  }
-}
-
-__global__ __launch_bounds__(256) void ring_update_commit_kernel(const UpdateArgs a) {
-  const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= a.m) return;
-  const int inc = a.scratch[a.m + j];
-  if (inc > 0) {
-    const int node = a.scratch[j];
-    a.write_pos[node] = (a.write_pos[node] + inc) % a.B;  // one committer per node
   }
 }
 
@@ -426,8 +503,8 @@ extern "C" int tgmx_ring_lookup(const tgmx_adj_t* ring, const int32_t* write_pos
 
 extern "C" int tgmx_ring_update(tgmx_adj_t* ring, int32_t* write_pos, float* ring_x, int32_t D, int32_t B,
                                 int32_t num_nodes, const int32_t* src, const int32_t* dst, const int64_t* ts,
-                                const float* edge_x, int64_t n, int64_t eid0, int32_t directed, int32_t* scratch,
-                                int32_t* status, tgmx_stream_t stream) {
+                                const float* edge_x, int64_t n, int64_t eid0, int32_t directed, int32_t key_wrap32,
+                                int32_t* scratch, int32_t* status, tgmx_stream_t stream) {
   TGMX_REQUIRE(n >= 0 && B > 0 && num_nodes > 0 && D >= 0, "ring_update: bad sizes n=%lld B=%d N=%d D=%d", (long long)n, B,
                num_nodes, D);
   if (n == 0) return TGMX_OK;
@@ -435,15 +512,18 @@ extern "C" int tgmx_ring_update(tgmx_adj_t* ring, int32_t* write_pos, float* rin
   TGMX_REQUIRE(D == 0 || ring_x, "ring_update: D=%d but ring_x is null", D);
   TGMX_REQUIRE(eid0 < 0 || eid0 + n <= 2147483647LL, "ring_update: edge ids overflow int32");
   TGMX_REQUIRE((long long)B * num_nodes < 2147483647LL, "ring_update: num_nodes*B overflows int32");
+  TGMX_REQUIRE(2 * n < 2147483647LL, "ring_update: batch too large");
   UpdateArgs a{};
   a.ring = reinterpret_cast<Rec*>(ring); a.write_pos = write_pos; a.ring_x = ring_x; a.edge_x = edge_x;
-  a.src = src; a.dst = dst; a.ts = ts; a.scratch = scratch; a.status = status;
-  a.n = n; a.m = directed ? n : 2 * n; a.eid0 = eid0; a.B = B; a.N = num_nodes; a.D = D;
+  a.src = src; a.dst = dst; a.ts = ts; a.status = status;
+  a.n = n; a.m = directed ? n : 2 * n; a.eid0 = eid0; a.B = B; a.N = num_nodes; a.D = D; a.key_wrap32 = key_wrap32;
+  a.sorted_j = scratch; a.sorted_node = scratch + a.m; a.target = scratch + 2 * a.m; a.winner = scratch + 3 * a.m;
   const unsigned blocks = (unsigned)((a.m + 255) / 256);
-  hipLaunchKernelGGL(ring_update_rank_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
-  if (D > 0)
-    hipLaunchKernelGGL(ring_update_feat_kernel, dim3((unsigned)((a.m + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
-  hipLaunchKernelGGL(ring_update_commit_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(ring_update_sort_kernel, dim3(blocks), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(ring_update_place_kernel, dim3(blocks), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(ring_update_write_kernel, dim3(blocks), dim3(256), 0, st, a);
+  if (D > 0) hipLaunchKernelGGL(ring_update_feat_kernel, dim3((unsigned)((a.m + 3) / 4)), dim3(256), 0, st, a);
   TGMX_CHECK_LAUNCH("ring_update");
   return TGMX_OK;
 }

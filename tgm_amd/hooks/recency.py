@@ -52,6 +52,10 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
         mode: 'ring' (streaming state, default) or 'csr' (static index, stateless).
         validate: 'sync' | 'deferred' | 'off'.
         batch_size / batch_starts: loader schedule, required by ``mode='csr'``.
+        key_arith: ring mode only.  'int32' (default) reproduces the reference bit for bit,
+            including the int32 wrap of its update sort key (recency.py:347) that leaves
+            stale / empty ring slots at dataset scale; 'int64' is the intended per-node
+            chronological order (what ``mode='csr'`` implements).
 
     Key words: k-hop neighbour, recency, historical.
     """
@@ -71,8 +75,12 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
         validate: str = 'sync',
         batch_size: Optional[int] = None,
         batch_starts: Optional[Sequence[int]] = None,
+        key_arith: str = 'int32',
     ) -> None:
         super().__init__()
+        if key_arith not in ('int32', 'int64'):
+            raise ValueError(f"key_arith must be 'int32' or 'int64', got {key_arith!r}")
+        self._key_wrap32 = 1 if key_arith == 'int32' else 0
         if not len(num_nbrs):
             raise ValueError('num_nbrs must be non-empty')
         if not all(isinstance(x, int) and x > 0 for x in num_nbrs):
@@ -279,8 +287,8 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
                 n_edges = batch.edge_src.numel()
                 if self._mode == 'ring' and n_edges:
                     m = n_edges if self._directed else 2 * n_edges
-                    if self._scratch is None or self._scratch.numel() < 3 * m:
-                        self._scratch = torch.empty(3 * m, dtype=torch.int32, device=device)
+                    if self._scratch is None or self._scratch.numel() < 4 * m:
+                        self._scratch = torch.empty(4 * m, dtype=torch.int32, device=device)
                     ex = batch.edge_x
                     if ex is not None and D:
                         if ex.dtype != torch.float32 or not ex.is_contiguous():
@@ -293,7 +301,7 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
                     eid0 = -1 if batch._edge_lo is None else int(batch._edge_lo)
                     rc = lib.tgmx_ring_update(
                         ring_p, wpos_p, table_p, D, B, N, src.data_ptr(), dst.data_ptr(), tt.data_ptr(), _native.ptr(ex),
-                        n_edges, eid0, 1 if self._directed else 0, self._scratch.data_ptr(), status_p, stream,
+                        n_edges, eid0, 1 if self._directed else 0, self._key_wrap32, self._scratch.data_ptr(), status_p, stream,
                     )
                     if rc:
                         _native.check(rc, 'tgmx_ring_update')
