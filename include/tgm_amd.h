@@ -40,6 +40,7 @@ extern "C" {
 #define TGMX_ST_EDGE_RANGE 4 /* an edge endpoint outside [0, num_nodes)       */
 
 typedef void* tgmx_stream_t;
+typedef void* tgmx_event_t; /* hipEvent_t */
 
 /* One adjacency / ring record: 16 bytes, 16-byte aligned, so one lane moves
  * one record with a single dwordx4 access. */
@@ -51,6 +52,14 @@ typedef struct tgmx_adj {
 
 int tgmx_version(void);
 const char* tgmx_last_error(void);
+
+/* HIP timing events.  The lookup entry points accept an optional (ev_start,
+ * ev_stop) pair which they record on `stream` immediately before / after their
+ * kernel, so a caller can time exactly that launch on the stream it runs on
+ * (bench.py's roofline leg).  tgmx_event_elapsed_ms synchronises on `stop`. */
+int tgmx_event_create(tgmx_event_t* ev);
+int tgmx_event_destroy(tgmx_event_t ev);
+int tgmx_event_elapsed_ms(tgmx_event_t start, tgmx_event_t stop, float* ms);
 
 /* ------------------------------------------------------------------------
  * k-most-recent neighbor lookup over a static per-node index (CSR).
@@ -72,7 +81,8 @@ int tgmx_recency_lookup_csr(const int64_t* indptr, const tgmx_adj_t* adj,
                             int32_t k, int32_t B, int64_t ev_lo, int64_t ev_hi,
                             int32_t num_nodes, int32_t allow_pad,
                             int32_t* out_nid, int64_t* out_ts, float* out_x,
-                            int32_t* status, tgmx_stream_t stream);
+                            int32_t* status, tgmx_stream_t stream,
+                            tgmx_event_t ev_start, tgmx_event_t ev_stop);
 
 /* ------------------------------------------------------------------------
  * Streaming mode: per-node rings of B records, the exact state machine of the
@@ -86,7 +96,8 @@ int tgmx_ring_lookup(const tgmx_adj_t* ring, const int32_t* write_pos,
                      const int32_t* seeds, const int64_t* qtimes, int64_t S,
                      int32_t k, int32_t B, int32_t num_nodes, int32_t allow_pad,
                      int32_t* out_nid, int64_t* out_ts, float* out_x,
-                     int32_t* status, tgmx_stream_t stream);
+                     int32_t* status, tgmx_stream_t stream,
+                     tgmx_event_t ev_start, tgmx_event_t ev_stop);
 
 /* Append one batch of n edges (src[i], dst[i], ts[i], edge_x[i, :]) to the rings
  * exactly as recency.py:323-399 does: stable sort of the cat[src-role, dst-role]

@@ -158,7 +158,9 @@ def _random_stream(seed, N, E, D, tmax):
         (500, 5000, 3, 1000, [70], 128, True, 'int32'),  # B > 64: general (chunked) path
         (200, 4000, 6, 400, [3, 8, 2], 50, False, 'int32'),  # k < B on some hops, heavy ties
         (100, 3000, 0, 300, [4, 4], 37, False, 'int32'),  # no edge features
-        (50, 3000, 5, 200, [20], 1000, False, 'int32'),  # runs longer than B inside one batch
+        (50, 3000, 5, 200, [20], 1000, False, 'int32'),  # runs longer than B inside one batch (fused update, m=2000)
+        (60, 9000, 5, 300, [20], 2500, False, 'int32'),  # m=5000 entries: multi-kernel update path
+        (4000, 9000, 3, 2_000_000, [6, 2], 1500, False, 'int32'),  # multi-kernel path with wrapping keys
         (400, 3000, 7, 2000, [6], 60, False, 'int32'),  # D not a multiple of 4 (scalar gather path)
         (400, 3000, 6, 2000, [6], 60, False, 'int32'),  # D % 2 == 0 (float2 path)
     ],

@@ -24,13 +24,16 @@ _P = c_void_p
 SIGNATURES = {
     'tgmx_version': (c_int32, []),
     'tgmx_last_error': (c_char_p, []),
+    'tgmx_event_create': (c_int32, [ctypes.POINTER(c_void_p)]),
+    'tgmx_event_destroy': (c_int32, [_P]),
+    'tgmx_event_elapsed_ms': (c_int32, [_P, _P, ctypes.POINTER(ctypes.c_float)]),
     'tgmx_recency_lookup_csr': (
         c_int32,
-        [_P, _P, _P, c_int32, _P, _P, c_int64, c_int32, c_int32, c_int64, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P],
+        [_P, _P, _P, c_int32, _P, _P, c_int64, c_int32, c_int32, c_int64, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P],
     ),
     'tgmx_ring_lookup': (
         c_int32,
-        [_P, _P, _P, c_int32, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P],
+        [_P, _P, _P, c_int32, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P],
     ),
     'tgmx_ring_update': (
         c_int32,
@@ -88,3 +91,27 @@ def stream_ptr() -> int:
 
 def ptr(t: Optional[torch.Tensor]) -> int:
     return 0 if t is None else t.data_ptr()
+
+
+class KernelTimer:
+    """A (start, stop) pair of HIP events recorded by the library right around one kernel launch."""
+
+    def __init__(self) -> None:
+        lib = load()
+        a, b = c_void_p(), c_void_p()
+        check(lib.tgmx_event_create(ctypes.byref(a)), 'tgmx_event_create')
+        check(lib.tgmx_event_create(ctypes.byref(b)), 'tgmx_event_create')
+        self.start, self.stop = a.value, b.value
+
+    def elapsed_ms(self) -> float:
+        ms = ctypes.c_float()
+        check(load().tgmx_event_elapsed_ms(self.start, self.stop, ctypes.byref(ms)), 'tgmx_event_elapsed_ms')
+        return float(ms.value)
+
+    def __del__(self) -> None:
+        try:
+            lib = load()
+            lib.tgmx_event_destroy(self.start)
+            lib.tgmx_event_destroy(self.stop)
+        except Exception:
+            pass

@@ -17,3 +17,28 @@ void set_error(const char* fmt, ...) {
 
 extern "C" int tgmx_version(void) { return TGMX_ABI_VERSION; }
 extern "C" const char* tgmx_last_error(void) { return tgmx::g_err; }
+
+extern "C" int tgmx_event_create(tgmx_event_t* ev) {
+  TGMX_REQUIRE(ev, "event_create: null pointer");
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) {
+    tgmx::set_error("event_create: hipEventCreate failed");
+    return TGMX_E_LAUNCH;
+  }
+  *ev = (tgmx_event_t)e;
+  return TGMX_OK;
+}
+
+extern "C" int tgmx_event_destroy(tgmx_event_t ev) {
+  if (ev) hipEventDestroy((hipEvent_t)ev);
+  return TGMX_OK;
+}
+
+extern "C" int tgmx_event_elapsed_ms(tgmx_event_t start, tgmx_event_t stop, float* ms) {
+  TGMX_REQUIRE(start && stop && ms, "event_elapsed_ms: null pointer");
+  if (hipEventSynchronize((hipEvent_t)stop) != hipSuccess || hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop) != hipSuccess) {
+    tgmx::set_error("event_elapsed_ms: events not recorded");
+    return TGMX_E_LAUNCH;
+  }
+  return TGMX_OK;
+}

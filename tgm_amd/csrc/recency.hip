@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void recency_lookup_kernel(const LookupArgs a)
 }
 
 template <bool RING>
-static int launch_lookup(LookupArgs a, hipStream_t stream) {
+static int launch_lookup(LookupArgs a, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
   if (a.S == 0) return TGMX_OK;
   const bool small = a.B <= kWave && a.k <= kWave;
   int vec = 1;
@@ -235,6 +235,7 @@ static int launch_lookup(LookupArgs a, hipStream_t stream) {
   const size_t lds = (size_t)waves_per_block * a.k * sizeof(int);
 #define TGMX_LAUNCH(VEC_, SMALL_) \
   hipLaunchKernelGGL((recency_lookup_kernel<RING, VEC_, SMALL_>), grid, block, lds, stream, a)
+  if (ev_start) hipEventRecord(ev_start, stream);
   if (small) {
     if (vec == 4) TGMX_LAUNCH(4, true);
     else if (vec == 2) TGMX_LAUNCH(2, true);
@@ -245,6 +246,7 @@ static int launch_lookup(LookupArgs a, hipStream_t stream) {
     else TGMX_LAUNCH(1, false);
   }
 #undef TGMX_LAUNCH
+  if (ev_stop) hipEventRecord(ev_stop, stream);
   TGMX_CHECK_LAUNCH("recency_lookup");
   return TGMX_OK;
 }
@@ -420,6 +422,153 @@ __global__ __launch_bounds__(256) void ring_update_write_kernel(const UpdateArgs
   a.winner[p] = win;
 }
 
+// Small batches (m <= kFusedMaxM entries, i.e. every TGB-style batch size): the
+// whole sort/place/write sequence in ONE workgroup with the working set in LDS
+// (gfx950: 160 KiB per CU).  O(m log^2 m): a bitonic sort of (key, entry index)
+// pairs replaces the all-pairs rank, and slot collisions / per-node totals are
+// resolved through two open-addressing hash tables in LDS (atomicMax / atomicAdd).
+constexpr int kFusedMaxM = 1024;
+constexpr int kFusedThreads = 1024;
+constexpr int kFusedHash = 2 * kFusedMaxM;  // load factor <= 0.5
+
+__device__ __forceinline__ int lds_hash_slot(int* keys, int key) {
+  // keys[] initialised to -1; returns the slot holding `key` (inserting it if absent)
+  unsigned h = ((unsigned)key * 2654435761u) >> (32 - 11);  // 11 = log2(kFusedHash)
+  for (;;) {
+    const int old = atomicCAS(&keys[h], -1, key);
+    if (old == -1 || old == key) return (int)h;
+    h = (h + 1) & (kFusedHash - 1);
+  }
+}
+static_assert(kFusedHash == 2048, "lds_hash_slot assumes 2^11 slots");
+
+__global__ __launch_bounds__(kFusedThreads) void ring_update_fused_kernel(const UpdateArgs a) {
+  __shared__ long long s_key[kFusedMaxM];  // sort key (sorted in place)
+  __shared__ long long s_t[kFusedMaxM];    // timestamp of entry j
+  __shared__ int s_pay[kFusedMaxM];        // entry index, permuted with the keys
+  __shared__ int s_node[kFusedMaxM];       // node of entry j (-1 invalid)
+  __shared__ int s_nbr[kFusedMaxM];        // neighbor of entry j
+  __shared__ int s_sn[kFusedMaxM];         // node at sorted position p
+  __shared__ int s_tgt[kFusedMaxM];        // ring row placed at (-1 dropped)
+  __shared__ int s_w[kFusedMaxM];          // write_pos[node] % B at sorted position p
+  __shared__ int h_slot_key[kFusedHash], h_slot_maxp[kFusedHash];
+  __shared__ int h_node_key[kFusedHash], h_node_cnt[kFusedHash], h_node_maxp[kFusedHash];
+  __shared__ long long red[kFusedThreads / kWave];
+  const int m = (int)a.m;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int kWaves = kFusedThreads / kWave;
+  int P = 64;
+  while (P < m) P <<= 1;
+
+  // phase 0: span = max(ts) + 1; clear the hash tables
+  long long mx = -0x7fffffffffffffffLL;
+  for (int x = tid; x < a.n; x += kFusedThreads) {
+    const long long v = a.ts[x];
+    mx = v > mx ? v : mx;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const long long o = __shfl_xor(mx, off);
+    mx = o > mx ? o : mx;
+  }
+  if (lane == 0) red[wave] = mx;
+  for (int x = tid; x < kFusedHash; x += kFusedThreads) {
+    h_slot_key[x] = -1; h_slot_maxp[x] = -1;
+    h_node_key[x] = -1; h_node_cnt[x] = 0; h_node_maxp[x] = -1;
+  }
+  __syncthreads();
+  mx = red[0];
+  for (int w = 1; w < kWaves; ++w) mx = red[w] > mx ? red[w] : mx;
+  const long long span = mx + 1;
+
+  // phase 1: stage every entry in LDS (padding sorts to the end)
+  for (int j = tid; j < P; j += kFusedThreads) {
+    long long key = 0x7fffffffffffffffLL;
+    if (j < m) {
+      int node, nbr;
+      long long t, i;
+      update_entry(a, j, node, nbr, t, i);
+      const bool valid = node >= 0 && node < a.N && nbr >= 0 && nbr < a.N;
+      if (!valid) atomicOr(a.status, TGMX_ST_EDGE_RANGE);
+      key = update_key(node, t, span, a.key_wrap32);
+      s_t[j] = t;
+      s_node[j] = valid ? node : -1;
+      s_nbr[j] = nbr;
+    }
+    s_key[j] = key;
+    s_pay[j] = j;
+  }
+  __syncthreads();
+
+  // phase 2: bitonic sort of (key, entry index) -- unique pairs, so the order is the stable one
+  for (int k = 2; k <= P; k <<= 1) {
+    for (int jj = k >> 1; jj > 0; jj >>= 1) {
+      for (int i = tid; i < P; i += kFusedThreads) {
+        const int o = i ^ jj;
+        if (o > i) {
+          const long long ka = s_key[i], kb = s_key[o];
+          const int pa = s_pay[i], pb = s_pay[o];
+          const bool a_after_b = ka > kb || (ka == kb && pa > pb);
+          if (a_after_b == ((i & k) == 0)) {
+            s_key[i] = kb; s_key[o] = ka;
+            s_pay[i] = pb; s_pay[o] = pa;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int p = tid; p < m; p += kFusedThreads) s_sn[p] = s_node[s_pay[p]];
+  __syncthreads();
+
+  // phase 3: runs of equal node in sorted order -> keep / ring slot; feed the hash tables
+  for (int p = tid; p < m; p += kFusedThreads) {
+    const int node = s_sn[p];
+    int tgt = -1, w = 0;
+    if (node >= 0) {
+      int lo = p, hi = p + 1;
+      while (lo > 0 && s_sn[lo - 1] == node) --lo;
+      while (hi < m && s_sn[hi] == node) ++hi;
+      const int cnt = hi - lo, pos = p - lo;
+      const int drop = cnt > a.B ? cnt - a.B : 0;
+      w = a.write_pos[node] % a.B;
+      if (pos >= drop) {
+        tgt = node * a.B + (w + pos - drop) % a.B;
+        atomicMax(&h_slot_maxp[lds_hash_slot(h_slot_key, tgt)], p);
+        const int hn = lds_hash_slot(h_node_key, node);
+        atomicAdd(&h_node_cnt[hn], 1);
+        atomicMax(&h_node_maxp[hn], p);
+      }
+    }
+    s_w[p] = w;
+    s_tgt[p] = tgt;
+  }
+  __syncthreads();
+
+  // phase 4: the last entry (in sorted order) placed on a slot owns it; the last kept entry
+  // of a node commits write_pos += #kept.  Stores only -- no dependent global loads.
+  for (int p = tid; p < m; p += kFusedThreads) {
+    const int tgt = s_tgt[p];
+    const int j = s_pay[p];
+    int win = -1;
+    if (tgt >= 0) {
+      const int node = s_sn[p];
+      if (h_slot_maxp[lds_hash_slot(h_slot_key, tgt)] == p) {
+        const long long i = j >= a.n ? j - a.n : j;
+        Rec r;
+        r.nbr = s_nbr[j];
+        r.eid = a.eid0 >= 0 ? (int)(a.eid0 + i) : -1;
+        r.ts = s_t[j];
+        a.ring[tgt] = r;
+        win = tgt;
+      }
+      const int hn = lds_hash_slot(h_node_key, node);
+      if (h_node_maxp[hn] == p) a.write_pos[node] = (s_w[p] + h_node_cnt[hn]) % a.B;
+    }
+    a.winner[p] = win;
+    a.sorted_j[p] = j;
+  }
+}
+
 // one wave per sorted position: copy the winning entry's D-float feature row
 __global__ __launch_bounds__(256) void ring_update_feat_kernel(const UpdateArgs a) {
   const long long p = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -469,7 +618,7 @@ extern "C" int tgmx_recency_lookup_csr(const int64_t* indptr, const tgmx_adj_t* 
                                        const int32_t* seeds, const int64_t* qtimes, int64_t S, int32_t k, int32_t B,
                                        int64_t ev_lo, int64_t ev_hi, int32_t num_nodes, int32_t allow_pad,
                                        int32_t* out_nid, int64_t* out_ts, float* out_x, int32_t* status,
-                                       tgmx_stream_t stream) {
+                                       tgmx_stream_t stream, tgmx_event_t ev_start, tgmx_event_t ev_stop) {
   TGMX_REQUIRE(S >= 0 && k > 0 && B >= k && D >= 0 && num_nodes > 0, "recency_lookup_csr: bad sizes S=%lld k=%d B=%d D=%d N=%d",
                (long long)S, k, B, D, num_nodes);
   if (S == 0) return TGMX_OK;
@@ -480,13 +629,13 @@ extern "C" int tgmx_recency_lookup_csr(const int64_t* indptr, const tgmx_adj_t* 
   a.indptr = indptr; a.recs = reinterpret_cast<const Rec*>(adj); a.write_pos = nullptr; a.edge_x = edge_x;
   a.seeds = seeds; a.qtimes = qtimes; a.out_nid = out_nid; a.out_ts = out_ts; a.out_x = out_x; a.status = status;
   a.S = S; a.ev_lo = ev_lo; a.ev_hi = ev_hi; a.D = D; a.k = k; a.B = B; a.N = num_nodes; a.allow_pad = allow_pad;
-  return launch_lookup<false>(a, (hipStream_t)stream);
+  return launch_lookup<false>(a, (hipStream_t)stream, (hipEvent_t)ev_start, (hipEvent_t)ev_stop);
 }
 
 extern "C" int tgmx_ring_lookup(const tgmx_adj_t* ring, const int32_t* write_pos, const float* ring_x, int32_t D,
                                 const int32_t* seeds, const int64_t* qtimes, int64_t S, int32_t k, int32_t B,
                                 int32_t num_nodes, int32_t allow_pad, int32_t* out_nid, int64_t* out_ts, float* out_x,
-                                int32_t* status, tgmx_stream_t stream) {
+                                int32_t* status, tgmx_stream_t stream, tgmx_event_t ev_start, tgmx_event_t ev_stop) {
   TGMX_REQUIRE(S >= 0 && k > 0 && B >= k && D >= 0 && num_nodes > 0, "ring_lookup: bad sizes S=%lld k=%d B=%d D=%d N=%d",
                (long long)S, k, B, D, num_nodes);
   if (S == 0) return TGMX_OK;
@@ -498,7 +647,7 @@ extern "C" int tgmx_ring_lookup(const tgmx_adj_t* ring, const int32_t* write_pos
   a.indptr = nullptr; a.recs = reinterpret_cast<const Rec*>(ring); a.write_pos = write_pos; a.edge_x = ring_x;
   a.seeds = seeds; a.qtimes = qtimes; a.out_nid = out_nid; a.out_ts = out_ts; a.out_x = out_x; a.status = status;
   a.S = S; a.ev_lo = 0; a.ev_hi = 0; a.D = D; a.k = k; a.B = B; a.N = num_nodes; a.allow_pad = allow_pad;
-  return launch_lookup<true>(a, (hipStream_t)stream);
+  return launch_lookup<true>(a, (hipStream_t)stream, (hipEvent_t)ev_start, (hipEvent_t)ev_stop);
 }
 
 extern "C" int tgmx_ring_update(tgmx_adj_t* ring, int32_t* write_pos, float* ring_x, int32_t D, int32_t B,
@@ -520,9 +669,13 @@ extern "C" int tgmx_ring_update(tgmx_adj_t* ring, int32_t* write_pos, float* rin
   a.sorted_j = scratch; a.sorted_node = scratch + a.m; a.target = scratch + 2 * a.m; a.winner = scratch + 3 * a.m;
   const unsigned blocks = (unsigned)((a.m + 255) / 256);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(ring_update_sort_kernel, dim3(blocks), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(ring_update_place_kernel, dim3(blocks), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(ring_update_write_kernel, dim3(blocks), dim3(256), 0, st, a);
+  if (a.m <= kFusedMaxM) {
+    hipLaunchKernelGGL(ring_update_fused_kernel, dim3(1), dim3(kFusedThreads), 0, st, a);
+  } else {
+    hipLaunchKernelGGL(ring_update_sort_kernel, dim3(blocks), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(ring_update_place_kernel, dim3(blocks), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(ring_update_write_kernel, dim3(blocks), dim3(256), 0, st, a);
+  }
   if (D > 0) hipLaunchKernelGGL(ring_update_feat_kernel, dim3((unsigned)((a.m + 3) / 4)), dim3(256), 0, st, a);
   TGMX_CHECK_LAUNCH("ring_update");
   return TGMX_OK;

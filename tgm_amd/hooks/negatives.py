@@ -26,7 +26,16 @@ class RandomNegativeEdgeSamplerHook(StatelessHook):
     _cls_requires = {'edge_src', 'edge_dst', 'edge_time'}
     _cls_produces = {'neg', 'neg_time'}
 
-    def __init__(self, low: int, high: int, neg_ratio: float = 1.0, id: Optional[str] = None, seed: Optional[int] = None) -> None:
+    def __init__(
+        self,
+        low: int,
+        high: int,
+        neg_ratio: float = 1.0,
+        id: Optional[str] = None,
+        seed: Optional[int] = None,
+        like: str = 'edge_dst',
+        time_key: str = 'edge_time',
+    ) -> None:
         super().__init__()
         if not 0 < neg_ratio <= 1:
             raise ValueError(f'neg_ratio must be in (0, 1], got: {neg_ratio}')
@@ -35,11 +44,15 @@ class RandomNegativeEdgeSamplerHook(StatelessHook):
         self.low, self.high, self.neg_ratio = low, high, neg_ratio
         self._seed = seed
         self._gen: Optional[torch.Generator] = None
+        # extensions (defaults = the reference's behaviour): draw one negative per element of
+        # batch.<like> and copy batch.<time_key>; used to sample for a rank's shard of the batch
+        self._like, self._time_key = like, time_key
         self._id = id
         self.__post_init__()
+        self._requires |= {like, time_key}
 
     def __call__(self, dg: DGraph, batch: DGBatch) -> DGBatch:
-        n = round(self.neg_ratio * batch.edge_dst.size(0))
+        n = round(self.neg_ratio * getattr(batch, self._like).size(0))
         device = dg.device
         if n == 0:
             neg = torch.empty((0,), dtype=torch.int32, device=device)
@@ -52,7 +65,7 @@ class RandomNegativeEdgeSamplerHook(StatelessHook):
                     self._gen.manual_seed(self._seed)
                 gen = self._gen
             neg = torch.randint(self.low, self.high, (n,), dtype=torch.int32, device=device, generator=gen)
-            neg_time = batch.edge_time.clone()
+            neg_time = getattr(batch, self._time_key).clone()
         self.add_batch_attribute(batch, 'neg', neg)
         self.add_batch_attribute(batch, 'neg_time', neg_time)
         return batch

@@ -39,6 +39,25 @@ from .registry import hook
 _ST_SEED_RANGE, _ST_SEED_TIME, _ST_EDGE_RANGE = 1, 2, 4
 
 
+class _NullCtx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NULL = _NullCtx()
+
+
+def _on_device(device: torch.device):
+    """Device guard that costs nothing when ``device`` is already current."""
+    idx = device.index
+    if idx is None or idx == torch.cuda.current_device():
+        return _NULL
+    return torch.cuda.device(device)
+
+
 @hook
 class RecencyNeighborHook(StatefulHook, SeedableHook):
     """Load neighbors using recency sampling: each node keeps its most recent neighbors.
@@ -121,6 +140,15 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
         self._csr: Optional[TemporalCSR] = None
         self._csr_store = None
         self._epoch_lo: Optional[int] = None  # first edge index visible in this epoch
+
+        # optional kernel timing (bench.py): every `profile_every`-th call brackets the
+        # lookup launch of hop `profile_hop` with HIP events on the launch stream
+        self._mask_cache: Dict[tuple, Dict[str, Tensor]] = {}
+        self.profile_hop: Optional[int] = None
+        self.profile_every: int = 1
+        self.profile_log: List[tuple] = []
+        self.profile_pool: List[_native.KernelTimer] = []  # pre-created timers, one consumed per timed launch
+        self._calls = 0
 
         self._id = id
         self.seed_keys = list(seed_nodes_keys)
@@ -241,7 +269,7 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
             lib = _native.load()
             B, N = self._max_nbrs, self._num_nodes
             status_p = self._status.data_ptr()
-            with torch.cuda.device(device):
+            with _on_device(device):
                 stream = _native.stream_ptr()
                 if self._mode == 'csr':
                     if batch._edge_lo is None:
@@ -257,23 +285,31 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
                     ring_p, wpos_p, table_p = self._ring.data_ptr(), self._write_pos.data_ptr(), _native.ptr(self._ring_x)
 
                 cur_n, cur_t = seeds, seed_times
+                self._calls += 1
+                timed_hop = self.profile_hop if (self.profile_hop is not None and self._calls % self.profile_every == 0) else -1
                 for hop, k in enumerate(self._num_nbrs):
                     S = cur_n.numel()
                     nid = torch.empty((S, k), dtype=torch.int32, device=device)
                     nts = torch.empty((S, k), dtype=torch.int64, device=device)
                     nx = torch.empty((S, k, D), dtype=torch.float32, device=device)
+                    timer = None
+                    if hop == timed_hop and self.profile_pool:
+                        timer = self.profile_pool.pop()
+                    ev0, ev1 = (timer.start, timer.stop) if timer else (None, None)
                     if self._mode == 'csr':
                         rc = lib.tgmx_recency_lookup_csr(
                             indptr_p, adj_p, table_p, D, cur_n.data_ptr(), cur_t.data_ptr(), S, k, B, ev_lo, ev_hi, N,
-                            1 if hop else 0, nid.data_ptr(), nts.data_ptr(), nx.data_ptr(), status_p, stream,
+                            1 if hop else 0, nid.data_ptr(), nts.data_ptr(), nx.data_ptr(), status_p, stream, ev0, ev1,
                         )
                     else:
                         rc = lib.tgmx_ring_lookup(
                             ring_p, wpos_p, table_p, D, cur_n.data_ptr(), cur_t.data_ptr(), S, k, B, N,
-                            1 if hop else 0, nid.data_ptr(), nts.data_ptr(), nx.data_ptr(), status_p, stream,
+                            1 if hop else 0, nid.data_ptr(), nts.data_ptr(), nx.data_ptr(), status_p, stream, ev0, ev1,
                         )  # fmt: skip
                     if rc:
                         _native.check(rc, 'recency lookup')
+                    if timer is not None:
+                        self.profile_log.append((timer, S, k, nid))  # nid kept alive: valid slots are counted later
                     out_seed_n.append(cur_n)
                     out_seed_t.append(cur_t)
                     out_n.append(nid)
@@ -357,11 +393,24 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
                     )
                 if bool((time < 0).any()):
                     raise ValueError(f'Seed times in {time_attr} must be >= 0, got min value: {time.min().item()}')
-            seeds.append(seed.to(device=device, dtype=torch.int32))
-            times.append(time.to(device=device, dtype=torch.int64))
+            if seed.device != device or seed.dtype != torch.int32:
+                seed = seed.to(device=device, dtype=torch.int32)
+            if time.device != device or time.dtype != torch.int64:
+                time = time.to(device=device, dtype=torch.int64)
+            seeds.append(seed)
+            times.append(time)
             n = seed.shape[0]
-            mask[node_attr] = torch.arange(offset, offset + n, device=device)
+            mask[node_attr] = (offset, n)
             offset += n
+        # the index ranges only depend on the group sizes: build them once per layout
+        layout = (device, tuple(mask.items()))
+        cached = self._mask_cache.get(layout)
+        if cached is None:
+            cached = {k: torch.arange(o, o + n, device=device) for k, (o, n) in mask.items()}
+            if len(self._mask_cache) > 64:
+                self._mask_cache.clear()
+            self._mask_cache[layout] = cached
+        mask = dict(cached)
         if seeds:
             return torch.cat(seeds), torch.cat(times), mask  # fresh tensors owned by the batch
         return (
