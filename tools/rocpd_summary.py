@@ -18,7 +18,7 @@ def main():
     md = '--md' in sys.argv
     db = sqlite3.connect(path)
     cur = db.cursor()
-    rows = cur.execute('select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels group by name order by sum(duration) desc').fetchall()
+    rows = cur.execute("select name || ' [grid ' || grid_x || ']', count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels group by name, grid_x order by sum(duration) desc").fetchall()
     total = sum(r[2] for r in rows) or 1
     if rows:
         print('| kernel | calls | total ms | avg us | min us | max us | % |' if md else f'{"kernel":80s} {"calls":>7s} {"total ms":>10s} {"avg us":>9s} {"min us":>9s} {"max us":>9s} {"%":>6s}')
