@@ -127,6 +127,54 @@ int tgmx_ring_reset(tgmx_adj_t* ring, int32_t* write_pos, int32_t B, int32_t num
 int tgmx_pack_adj(const int64_t* perm, int64_t m, const int32_t* src, const int32_t* dst,
                   const int64_t* ts, int64_t num_edges, tgmx_adj_t* adj, tgmx_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * TGAT / TemporalAttention forward (fp32, eval mode).  The attention is
+ * restructured (q-length 1 => the W_KV projection folds onto the query / output
+ * side, see csrc/tgat.hip); these are its building blocks, composed by
+ * tgm_amd/nn/tgat.py in the order of tgm/nn/encoder/tgat.py:95-149.
+ * ------------------------------------------------------------------------ */
+
+/* out[n, T] = cos(fma(float(x[i]), w[t], b[t]))        Time2Vec.forward
+ * (tgm/nn/modules/time_encoding.py:22-24); x is int64 (x_is_int64) or float32. */
+int tgmx_time2vec(const void* x, int32_t x_is_int64, const float* w, const float* b, int32_t T,
+                  int64_t n, float* out, tgmx_stream_t stream);
+
+/* out[i, :] = table[idx[i], :], negative idx wraps (pad id -1 -> last row)
+ * (tgm/nn/encoder/tgat.py:128-130 leaf features). */
+int tgmx_gather_rows(const float* table, int64_t num_rows, int32_t dim, const int32_t* idx,
+                     int64_t n, float* out, int64_t ldo, tgmx_stream_t stream);
+
+/* out[R, O] = [x[:, :d] | 0 pad | time_feat]: residual / query input
+ * (tgm/nn/modules/attention.py:93-95).  time_feat [R, T] may be NULL: then it is
+ * Time2Vec(0) = cos(tb), what TGAT.forward passes (tgat.py:139). */
+int tgmx_tgat_rres(const float* x, int64_t ldx, int32_t d, const float* tb, const float* time_feat,
+                   int32_t T, int32_t O, int64_t R, float* out, tgmx_stream_t stream);
+
+/* C[b] = act(A[b] (M x K, lda) * B[b]^T (B is N x K, ldb) + bias), b < batch with
+ * element strides; exact-fp32 MFMA.  Replaces the nn.Linear calls of
+ * attention.py:96,125 and tgat.py:36-38 and the folded W_K / W_V contractions. */
+int tgmx_sgemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
+                  int64_t M, int32_t N, int32_t K, const float* bias, int32_t relu, int32_t batch,
+                  int64_t strideA, int64_t strideB, int64_t strideC, tgmx_stream_t stream);
+
+/* Per-row masked softmax attention over the k sampled slots
+ * (attention.py:103-122 after folding): qf [R,H,C], nbrf [R,k,d], ex [R,k,D]
+ * -> zbar [R,H,C], C = d + D + T.  Neighbor time features are either computed in
+ * the kernel, cos(fma(float(seed_t[r] - nbr_t[r,s]), tw, tb)) (tgat.py:143-145), or
+ * read from nbr_time_feat [R,k,T] when it is non-NULL; the valid-neighbor mask is
+ * nbr_id[r,s] != -1, or mask [R,k] (bytes) when it is non-NULL. */
+int tgmx_tgat_attn_reduce(const float* qf, const float* nbrf, int32_t d, const float* ex, int32_t D,
+                          const int64_t* seed_t, const int64_t* nbr_t, const int32_t* nbr_id,
+                          const float* tw, const float* tb, const float* nbr_time_feat,
+                          const uint8_t* mask, int32_t T, int32_t H, int32_t k, int64_t R,
+                          float scale, float* zbar, tgmx_stream_t stream);
+
+/* out[R, O + d0] = [LayerNorm(y + res) * gamma + beta | z0]
+ * (attention.py:127 + the concat of tgat.py:36). */
+int tgmx_ln_residual_concat(const float* y, const float* res, const float* gamma, const float* beta,
+                            int32_t O, float eps, const float* z0, int32_t d0, int64_t R, float* out,
+                            tgmx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

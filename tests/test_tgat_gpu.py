@@ -1,0 +1,100 @@
+"""GPU parity of the aggregation path (Time2Vec, TemporalAttention, TGAT forward) through the
+C ABI, against the reference's outputs (goldens g5 / g6) and the torch-fp32 oracle.
+
+Tolerance (fp32 path; BASELINE north_star: 1e-5 relative):
+    |got - ref| <= 1e-5 * max(1, |ref|)   element-wise.
+"""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+RTOL = 1e-5
+
+
+def close(got, ref, tag):
+    got, ref = got.detach().cpu(), ref.detach().cpu()
+    assert got.shape == ref.shape and got.dtype == torch.float32, f'{tag}: {got.shape} {got.dtype} vs {ref.shape}'
+    assert torch.isfinite(got).all(), f'{tag}: non-finite output'
+    err = (got - ref).abs()
+    worst = (err / (RTOL * ref.abs().clamp(min=1.0))).max().item()
+    assert worst <= 1.0, f'{tag}: worst error {worst:.2f}x the 1e-5 bound (max abs err {err.max().item():.3e})'
+
+
+def test_time2vec_matches_reference():
+    from tgm_amd.nn import Time2Vec
+
+    z = np.load(gu.GOLDEN_DIR + '/g6_time2vec.npz')
+    t = torch.from_numpy(z['t']).to(DEV)
+    enc = Time2Vec(100).to(DEV)
+    close(enc(t), torch.from_numpy(z['out_default']), 'time2vec default')
+    enc2 = Time2Vec(16).to(DEV)
+    enc2.load_state_dict({'w.weight': torch.from_numpy(z['w2']), 'w.bias': torch.from_numpy(z['b2'])})
+    close(enc2(t), torch.from_numpy(z['out_jitter']), 'time2vec jitter')
+    # float input and a 2-D shape
+    close(enc2(t.float().view(4, 5)), torch.from_numpy(z['out_jitter']).view(4, 5, 16), 'time2vec float 2-D')
+
+
+@pytest.mark.parametrize('case', gu.ATTN_CASES)
+def test_temporal_attention_matches_reference(case):
+    from tgm_amd.nn import TemporalAttention
+
+    meta, a = gu.load(case)
+    T = lambda k: torch.from_numpy(a[k]).to(DEV)
+    m = TemporalAttention(meta['n_heads'], meta['node_dim'], meta['edge_dim'], meta['time_dim'], dropout=0.1).to(DEV).eval()
+    m.load_state_dict({k[2:]: torch.from_numpy(v) for k, v in a.items() if k.startswith('w_')})
+    out = m(node_x=T('node_x'), time_feat=T('time_feat'), edge_feat=T('edge_feat'), nbr_node_feat=T('nbr_node_feat'),
+            nbr_time_feat=T('nbr_time_feat'), valid_nbr_mask=T('mask'))  # fmt: skip
+    close(out, torch.from_numpy(a['out']), case)
+    m.train()
+    with pytest.raises(NotImplementedError):
+        m(node_x=T('node_x'), time_feat=T('time_feat'), edge_feat=T('edge_feat'), nbr_node_feat=T('nbr_node_feat'),
+          nbr_time_feat=T('nbr_time_feat'), valid_nbr_mask=T('mask'))  # fmt: skip
+
+
+@pytest.mark.parametrize('case', gu.TGAT_CASES)
+def test_tgat_forward_matches_reference(case):
+    from tgm_amd.nn import TGAT
+
+    meta, params, inputs, z_ref = gu.tgat_case(case)
+    enc = TGAT(edge_dim=meta['edge_dim'], num_layers=len(meta['num_nbrs']), dropout=0.1, **meta['dims']).to(DEV).eval()
+    enc.load_state_dict(params)
+    dev = lambda v: [t.to(DEV) for t in v] if isinstance(v, list) else v.to(DEV)
+    z = enc(**{k: dev(v) for k, v in inputs.items()})
+    close(z, z_ref, case)
+
+
+def test_tgat_headline_shape_vs_oracle():
+    """Example dims at the headline batch shape (600 seeds, k=[20,20] -> 12 600 attention rows in layer 1),
+    sampler outputs produced by the HIP sampler, embeddings vs the torch-fp32 oracle."""
+    from oracle import tgat_ref
+    from tgm_amd import DGData, DGDataLoader, DGraph
+    from tgm_amd.hooks import HookManager, RandomNegativeEdgeSamplerHook, RecencyNeighborHook
+    from tgm_amd.nn import TGAT
+    from tgm_amd.synth import make_stream
+
+    st = make_stream('wiki', seed=11, num_edges=30_000)
+    dg = DGraph(DGData.from_raw(st.ts, torch.stack([st.src, st.dst], 1), st.edge_x, static_node_x=st.node_x), device=DEV)
+    hm = HookManager(keys=['k'])
+    hm.register('k', RandomNegativeEdgeSamplerHook(8227, st.num_nodes, seed=3))
+    hm.register('k', RecencyNeighborHook(st.num_nodes, [20, 20], ['edge_src', 'edge_dst', 'neg'], ['edge_time', 'edge_time', 'neg_time']))
+    torch.manual_seed(5)
+    enc = TGAT(node_dim=1, edge_dim=172, time_dim=100, embed_dim=172, num_layers=2).to(DEV).eval()
+    with torch.no_grad():
+        for p in enc.parameters():
+            p.add_(0.03 * torch.randn_like(p))
+    params = {k: v.detach().cpu() for k, v in enc.state_dict().items()}
+    batch = None
+    with hm.activate('k'):
+        for b, batch in enumerate(DGDataLoader(dg, batch_size=200, hook_manager=hm)):
+            if b == 120:
+                break
+    z = enc(dg.static_node_x, batch.seed_nids, batch.seed_times, batch.nbr_nids, batch.nbr_edge_x, batch.nbr_edge_time)
+    cpu = lambda v: [t.cpu() for t in v]
+    z_ref = tgat_ref.tgat_forward(params, 2, st.node_x, cpu(batch.seed_nids), cpu(batch.seed_times), cpu(batch.nbr_nids),
+                                  cpu(batch.nbr_edge_x), cpu(batch.nbr_edge_time))  # fmt: skip
+    assert z.shape == (600, 172)
+    close(z, z_ref, 'headline shape')

@@ -40,6 +40,18 @@ SIGNATURES = {
         [_P, _P, _P, c_int32, c_int32, c_int32, _P, _P, _P, _P, c_int64, c_int64, c_int32, c_int32, _P, _P, _P],
     ),
     'tgmx_ring_reset': (c_int32, [_P, _P, c_int32, c_int32, _P]),
+    'tgmx_time2vec': (c_int32, [_P, c_int32, _P, _P, c_int32, c_int64, _P, _P]),
+    'tgmx_gather_rows': (c_int32, [_P, c_int64, c_int32, _P, c_int64, _P, c_int64, _P]),
+    'tgmx_tgat_rres': (c_int32, [_P, c_int64, c_int32, _P, _P, c_int32, c_int32, c_int64, _P, _P]),
+    'tgmx_sgemm_nt': (
+        c_int32,
+        [_P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int32, c_int32, _P, c_int32, c_int32, c_int64, c_int64, c_int64, _P],
+    ),
+    'tgmx_tgat_attn_reduce': (
+        c_int32,
+        [_P, _P, c_int32, _P, c_int32, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int64, ctypes.c_float, _P, _P],
+    ),
+    'tgmx_ln_residual_concat': (c_int32, [_P, _P, _P, _P, c_int32, ctypes.c_float, _P, c_int32, c_int64, _P, _P]),
     'tgmx_pack_adj': (c_int32, [_P, c_int64, _P, _P, _P, c_int64, _P, _P]),
 }
 

@@ -1,0 +1,452 @@
+// TGAT / TemporalAttention forward (fp32) for gfx950.
+//
+// Restructured attention (derivation: oracle/tgat_fold.py): the query length is 1,
+// so the per-slot W_KV projection of the reference (tgm/nn/modules/attention.py:98-101,
+// 28 GFLOP per batch at the headline config) is folded onto the query / output side.
+// What remains per row r (one 64-lane wave per row):
+//     score[h][s] = qf[r,h,:] . z[r,s,:] * dh^-1/2      z = [nbr_x | edge_x | cos(dt w + b)]
+//     A[h][:]     = softmax(mask(score[h][:]))
+//     zbar[r,h,:] = sum_s A[h][s] z[r,s,:]
+// -- two streaming passes over the row's [k, C] gathered features (the second one
+// hits L1/L2), wave-level reductions, no GEMM: HBM-bound.  The dense contractions
+// that are left ([R,O]x[O,O], [R,dh]x[dh,C], [R,C]x[C,dh], merge MLP) run on the
+// exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) in sgemm_nt below.
+#include "common.h"
+
+namespace tgmx {
+
+using floatx16 = __attribute__((__vector_size__(16 * sizeof(float)))) float;
+
+// ---------------------------------------------------------------------------
+// C[M,N] = act(A[M,K] * B[N,K]^T + bias[N]);  row-major, arbitrary leading dims,
+// optional batch (grid.z) with element strides.  Block tile 128 x 64, 4 waves,
+// each wave owns 32 rows x 64 cols = two 32x32 MFMA accumulators; K staged in
+// LDS 16 at a time (k-major, +1 padded rows: conflict-free operand reads).
+// ---------------------------------------------------------------------------
+constexpr int GBM = 128, GBN = 64, GBK = 16;
+
+struct GemmArgs {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;
+  long long lda, ldb, ldc, sA, sB, sC;
+  long long M;
+  int N, K, relu;
+};
+
+__global__ __launch_bounds__(256) void sgemm_nt_kernel(const GemmArgs g) {
+  __shared__ float As[GBK][GBM + 1];
+  __shared__ float Bs[GBK][GBN + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* __restrict__ A = g.A + (long long)blockIdx.z * g.sA;
+  const float* __restrict__ B = g.B + (long long)blockIdx.z * g.sB;
+  float* __restrict__ C = g.C + (long long)blockIdx.z * g.sC;
+  const long long m0 = (long long)blockIdx.x * GBM;
+  const int n0 = blockIdx.y * GBN;
+  floatx16 acc0 = {0}, acc1 = {0};
+  const int half = lane >> 5, l31 = lane & 31;
+
+  for (int k0 = 0; k0 < g.K; k0 += GBK) {
+#pragma unroll
+    for (int i = 0; i < GBM * GBK / 256; ++i) {
+      const int e = tid + i * 256;
+      const int m = e / GBK, k = e % GBK;
+      const long long gm = m0 + m;
+      const int gk = k0 + k;
+      As[k][m] = (gm < g.M && gk < g.K) ? A[gm * g.lda + gk] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < GBN * GBK / 256; ++i) {
+      const int e = tid + i * 256;
+      const int n = e / GBK, k = e % GBK;
+      const int gn = n0 + n, gk = k0 + k;
+      Bs[k][n] = (gn < g.N && gk < g.K) ? B[(long long)gn * g.ldb + gk] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < GBK; kk += 2) {
+      const float a = As[kk + half][wave * 32 + l31];
+      const float b0 = Bs[kk + half][l31];
+      const float b1 = Bs[kk + half][32 + l31];
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const long long row = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    if (row >= g.M) continue;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int col = n0 + t * 32 + l31;
+      if (col < g.N) {
+        float v = t ? acc1[r] : acc0[r];
+        if (g.bias) v += g.bias[col];
+        if (g.relu) v = v > 0.f ? v : 0.f;
+        C[row * g.ldc + col] = v;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// out[i, :] = table[idx[i] (negative wraps, like Python indexing), :]
+// (tgat.py:128-130: pad id -1 reads the LAST row of node_x)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ table, long long rows, int dim,
+                                                          const int32_t* __restrict__ idx, long long n,
+                                                          float* __restrict__ out, long long ldo) {
+  const long long total = n * dim;
+  const long long step = (long long)gridDim.x * blockDim.x;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += step) {
+    const long long i = e / dim;
+    const int c = (int)(e - i * dim);
+    long long r = idx[i];
+    if (r < 0) r += rows;
+    out[i * ldo + c] = table[r * dim + c];
+  }
+}
+
+// Rres[r] = [x[r, :d] | 0 (pad) | cos(tb)]  -- the residual == query input (attention.py:93-95);
+// Time2Vec of the zero vector is cos(fma(0, w, b)) = cos(b).
+__global__ __launch_bounds__(256) void tgat_rres_kernel(const float* __restrict__ x, long long ldx, int d,
+                                                        const float* __restrict__ tb, const float* __restrict__ tfeat,
+                                                        int T, int O, long long R, float* __restrict__ out) {
+  const long long total = R * O;
+  const long long step = (long long)gridDim.x * blockDim.x;
+  const int t0 = O - T;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += step) {
+    const long long r = e / O;
+    const int c = (int)(e - r * O);
+    float v = 0.f;
+    if (c < d) v = x[r * ldx + c];
+    else if (c >= t0) v = tfeat ? tfeat[r * T + (c - t0)] : cosf(tb[c - t0]);
+    out[e] = v;
+  }
+}
+
+// out[i, t] = cos(fma(float(x[i]), w[t], b[t]))   (Time2Vec.forward, time_encoding.py:22-24)
+template <typename TI>
+__global__ __launch_bounds__(256) void time2vec_kernel(const TI* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ b, int T, long long n,
+                                                       float* __restrict__ out) {
+  const long long total = n * T;
+  const long long step = (long long)gridDim.x * blockDim.x;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += step) {
+    const long long i = e / T;
+    const int t = (int)(e - i * T);
+    out[e] = cosf(__fmaf_rn((float)x[i], w[t], b[t]));
+  }
+}
+
+// out[r, :O] = LayerNorm(y[r] + res[r]) * gamma + beta ; out[r, O:O+d0] = z0[r]   (one wave per row)
+__global__ __launch_bounds__(256) void ln_residual_concat_kernel(const float* __restrict__ y, const float* __restrict__ res,
+                                                                 const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, int O, float eps,
+                                                                 const float* __restrict__ z0, int d0, long long R,
+                                                                 float* __restrict__ out) {
+  const int lane = lane_id();
+  const long long r = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const float* yr = y + r * O;
+  const float* rr = res + r * O;
+  float s = 0.f;
+  for (int c = lane; c < O; c += kWave) s += yr[c] + rr[c];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float mean = s / (float)O;
+  float v = 0.f;
+  for (int c = lane; c < O; c += kWave) {
+    const float t = yr[c] + rr[c] - mean;
+    v += t * t;
+  }
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  const float rstd = 1.0f / sqrtf(v / (float)O + eps);
+  float* orow = out + r * (O + d0);
+  for (int c = lane; c < O; c += kWave) orow[c] = (yr[c] + rr[c] - mean) * rstd * gamma[c] + beta[c];
+  for (int c = lane; c < d0; c += kWave) orow[O + c] = z0[r * d0 + c];
+}
+
+// ---------------------------------------------------------------------------
+// Per-row attention over the k sampled neighbor slots (one wave per row).
+// ---------------------------------------------------------------------------
+struct AttnArgs {
+  const float* qf;    // [R, H, C] folded queries, C = d + D + T laid out [nbr | edge | time]
+  const float* nbrf;  // [R, k, d] neighbor node features / embeddings
+  const float* ex;    // [R, k, D] sampled edge features
+  const int64_t* seed_t;  // [R]
+  const int64_t* nbr_t;   // [R, k]
+  const int32_t* nbr_id;  // [R, k] (-1 = empty slot -> masked)
+  const float* tw;    // [T] Time2Vec weight
+  const float* tb;    // [T] Time2Vec bias
+  const float* tfeat;       // optional [R, k, T]: precomputed neighbor time features (then tw/tb/times unused)
+  const unsigned char* mask;  // optional [R, k]: valid-neighbor mask (then nbr_id unused)
+  float* zbar;        // [R, H, C]
+  long long R;
+  int d, D, T, k, C;
+  float scale;        // dh^-1/2
+};
+
+// sum over the 64 lanes of P[j], delivered to lane j: 63 shuffles instead of 64 * 6.
+// (template steps: every register index must be a compile-time constant, or P spills to scratch)
+template <int HALF>
+__device__ __forceinline__ void reduce_scatter_step(float (&P)[64], int lane) {
+  const bool upper = (lane & HALF) != 0;
+#pragma unroll
+  for (int i = 0; i < HALF; ++i) {
+    const float send = upper ? P[i] : P[i + HALF];
+    const float recv = __shfl_xor(send, HALF);
+    const float keep = upper ? P[i + HALF] : P[i];
+    P[i] = keep + recv;
+  }
+}
+__device__ __forceinline__ float reduce_scatter64(float (&P)[64], int lane) {
+  reduce_scatter_step<32>(P, lane);
+  reduce_scatter_step<16>(P, lane);
+  reduce_scatter_step<8>(P, lane);
+  reduce_scatter_step<4>(P, lane);
+  reduce_scatter_step<2>(P, lane);
+  reduce_scatter_step<1>(P, lane);
+  return P[0];
+}
+
+template <int H>
+__global__ __launch_bounds__(256) void tgat_attn_reduce_kernel(const AttnArgs a) {
+  constexpr int G = 64 / H;  // slots whose (slot, head) scores fit one reduce-scatter
+  extern __shared__ __attribute__((aligned(16))) float lds_all[];
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  const int k = a.k, T = a.T, d = a.d, D = a.D, C = a.C;
+  // per-wave LDS: cos cache [k][T], dt [k], valid [k], A [H][k]
+  float* s_cos = lds_all + (size_t)wave * (k * T + k * (H + 2));
+  float* s_dt = s_cos + k * T;
+  float* s_valid = s_dt + k;
+  float* s_A = s_valid + k;
+
+  const long long r = (long long)blockIdx.x * (blockDim.x >> 6) + wave;
+  if (r >= a.R) return;
+  const float* __restrict__ q = a.qf + r * (long long)H * C;
+  const float* __restrict__ nb = a.nbrf + r * (long long)k * d;
+  const float* __restrict__ ex = a.ex + r * (long long)k * D;
+
+  // slot metadata + Time2Vec of every slot (computed once, reused by both passes)
+  const long long st = a.tfeat ? 0 : a.seed_t[r];
+  for (int s = lane; s < k; s += kWave) {
+    if (!a.tfeat) s_dt[s] = (float)(st - a.nbr_t[r * k + s]);  // int64 subtract, then round-to-nearest f32 (tgat.py:143-145)
+    const bool ok = a.mask ? a.mask[r * k + s] != 0 : a.nbr_id[r * k + s] != -1;
+    s_valid[s] = ok ? 1.f : 0.f;
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (int e = lane; e < k * T; e += kWave) {
+    const int s = e / T, t = e - s * T;
+    // Linear(1,T) is one fma (time_encoding.py:23-24)
+    s_cos[e] = a.tfeat ? a.tfeat[r * (long long)k * T + e] : cosf(__fmaf_rn(s_dt[s], a.tw[t], a.tb[t]));
+  }
+  __builtin_amdgcn_wave_barrier();
+
+  for (int s0 = 0; s0 < k; s0 += G) {
+    const int gs = (k - s0) < G ? (k - s0) : G;
+    // ---- pass 1: P[s*H + h] = partial of qf[h] . z[s] over this lane's columns ----
+    float P[64];
+#pragma unroll
+    for (int j = 0; j < 64; ++j) P[j] = 0.f;
+    for (int c = lane; c < d; c += kWave) {
+      float qv[H];
+#pragma unroll
+      for (int h = 0; h < H; ++h) qv[h] = q[h * C + c];
+#pragma clang loop unroll(full)
+      for (int s = 0; s < G; ++s) {
+        if (s < gs) {
+          const float z = nb[(long long)(s0 + s) * d + c];
+#pragma unroll
+          for (int h = 0; h < H; ++h) P[s * H + h] = __fmaf_rn(qv[h], z, P[s * H + h]);
+        }
+      }
+    }
+    for (int c = lane; c < D; c += kWave) {
+      float qv[H];
+#pragma unroll
+      for (int h = 0; h < H; ++h) qv[h] = q[h * C + d + c];
+#pragma clang loop unroll(full)
+      for (int s = 0; s < G; ++s) {
+        if (s < gs) {
+          const float z = ex[(long long)(s0 + s) * D + c];
+#pragma unroll
+          for (int h = 0; h < H; ++h) P[s * H + h] = __fmaf_rn(qv[h], z, P[s * H + h]);
+        }
+      }
+    }
+    for (int c = lane; c < T; c += kWave) {
+      float qv[H];
+#pragma unroll
+      for (int h = 0; h < H; ++h) qv[h] = q[h * C + d + D + c];
+#pragma clang loop unroll(full)
+      for (int s = 0; s < G; ++s) {
+        if (s < gs) {
+          const float z = s_cos[(s0 + s) * T + c];
+#pragma unroll
+          for (int h = 0; h < H; ++h) P[s * H + h] = __fmaf_rn(qv[h], z, P[s * H + h]);
+        }
+      }
+    }
+    const float sc = reduce_scatter64(P, lane);  // lane j = s*H + h now holds the full dot product
+    const int s = lane / H, h = lane - s * H;
+    if (s < gs) s_A[h * k + s0 + s] = s_valid[s0 + s] != 0.f ? sc * a.scale : -1e10f;  // masked_fill (attention.py:117)
+  }
+  __builtin_amdgcn_wave_barrier();
+
+  // ---- softmax over the k slots of every head (attention.py:118) ----
+  if (lane < H) {
+    float* row = s_A + lane * k;
+    float mx = row[0];
+    for (int s = 1; s < k; ++s) mx = fmaxf(mx, row[s]);
+    float sum = 0.f;
+    for (int s = 0; s < k; ++s) {
+      const float e = expf(row[s] - mx);
+      row[s] = e;
+      sum += e;
+    }
+    for (int s = 0; s < k; ++s) row[s] = row[s] / sum;
+  }
+  __builtin_amdgcn_wave_barrier();
+
+  // ---- pass 2: zbar[h][c] = sum_s A[h][s] z[s][c]  (features re-read: L1/L2 hits) ----
+  float* __restrict__ zb = a.zbar + r * (long long)H * C;
+  for (int c = lane; c < d; c += kWave) {
+    float acc[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) acc[h] = 0.f;
+    for (int s = 0; s < k; ++s) {
+      const float z = nb[(long long)s * d + c];
+#pragma unroll
+      for (int h = 0; h < H; ++h) acc[h] = __fmaf_rn(s_A[h * k + s], z, acc[h]);
+    }
+#pragma unroll
+    for (int h = 0; h < H; ++h) zb[h * C + c] = acc[h];
+  }
+  for (int c = lane; c < D; c += kWave) {
+    float acc[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) acc[h] = 0.f;
+    for (int s = 0; s < k; ++s) {
+      const float z = ex[(long long)s * D + c];
+#pragma unroll
+      for (int h = 0; h < H; ++h) acc[h] = __fmaf_rn(s_A[h * k + s], z, acc[h]);
+    }
+#pragma unroll
+    for (int h = 0; h < H; ++h) zb[h * C + d + c] = acc[h];
+  }
+  for (int c = lane; c < T; c += kWave) {
+    float acc[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) acc[h] = 0.f;
+    for (int s = 0; s < k; ++s) {
+      const float z = s_cos[s * T + c];
+#pragma unroll
+      for (int h = 0; h < H; ++h) acc[h] = __fmaf_rn(s_A[h * k + s], z, acc[h]);
+    }
+#pragma unroll
+    for (int h = 0; h < H; ++h) zb[h * C + d + D + c] = acc[h];
+  }
+}
+
+}  // namespace tgmx
+
+using namespace tgmx;
+
+extern "C" int tgmx_sgemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
+                             int32_t N, int32_t K, const float* bias, int32_t relu, int32_t batch, int64_t strideA,
+                             int64_t strideB, int64_t strideC, tgmx_stream_t stream) {
+  TGMX_REQUIRE(M >= 0 && N > 0 && K > 0 && batch > 0, "sgemm_nt: bad sizes M=%lld N=%d K=%d batch=%d", (long long)M, N, K, batch);
+  if (M == 0) return TGMX_OK;
+  TGMX_REQUIRE(A && B && C, "sgemm_nt: null pointer");
+  TGMX_REQUIRE(lda >= K && ldb >= K && ldc >= N, "sgemm_nt: leading dimension smaller than the row length");
+  GemmArgs g{A, B, C, bias, lda, ldb, ldc, strideA, strideB, strideC, M, N, K, relu};
+  const dim3 grid((unsigned)((M + GBM - 1) / GBM), (unsigned)((N + GBN - 1) / GBN), (unsigned)batch);
+  hipLaunchKernelGGL(sgemm_nt_kernel, grid, dim3(256), 0, (hipStream_t)stream, g);
+  TGMX_CHECK_LAUNCH("sgemm_nt");
+  return TGMX_OK;
+}
+
+extern "C" int tgmx_gather_rows(const float* table, int64_t num_rows, int32_t dim, const int32_t* idx, int64_t n, float* out,
+                                int64_t ldo, tgmx_stream_t stream) {
+  TGMX_REQUIRE(num_rows > 0 && dim > 0 && n >= 0 && ldo >= dim, "gather_rows: bad sizes");
+  if (n == 0) return TGMX_OK;
+  TGMX_REQUIRE(table && idx && out, "gather_rows: null pointer");
+  long long blocks = (n * dim + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, table, (long long)num_rows,
+                     dim, idx, (long long)n, out, (long long)ldo);
+  TGMX_CHECK_LAUNCH("gather_rows");
+  return TGMX_OK;
+}
+
+extern "C" int tgmx_tgat_rres(const float* x, int64_t ldx, int32_t d, const float* tb, const float* time_feat, int32_t T,
+                              int32_t O, int64_t R, float* out, tgmx_stream_t stream) {
+  TGMX_REQUIRE(d > 0 && T > 0 && O >= d + T && R >= 0 && ldx >= d, "tgat_rres: bad sizes d=%d T=%d O=%d", d, T, O);
+  if (R == 0) return TGMX_OK;
+  TGMX_REQUIRE(x && (tb || time_feat) && out, "tgat_rres: null pointer");
+  long long blocks = (R * O + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(tgat_rres_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (long long)ldx, d, tb, time_feat,
+                     T, O, (long long)R, out);
+  TGMX_CHECK_LAUNCH("tgat_rres");
+  return TGMX_OK;
+}
+
+extern "C" int tgmx_ln_residual_concat(const float* y, const float* res, const float* gamma, const float* beta, int32_t O,
+                                       float eps, const float* z0, int32_t d0, int64_t R, float* out, tgmx_stream_t stream) {
+  TGMX_REQUIRE(O > 0 && d0 >= 0 && R >= 0, "ln_residual_concat: bad sizes");
+  if (R == 0) return TGMX_OK;
+  TGMX_REQUIRE(y && res && gamma && beta && out && (d0 == 0 || z0), "ln_residual_concat: null pointer");
+  hipLaunchKernelGGL(ln_residual_concat_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, y, res, gamma,
+                     beta, O, eps, z0, d0, (long long)R, out);
+  TGMX_CHECK_LAUNCH("ln_residual_concat");
+  return TGMX_OK;
+}
+
+extern "C" int tgmx_tgat_attn_reduce(const float* qf, const float* nbrf, int32_t d, const float* ex, int32_t D,
+                                     const int64_t* seed_t, const int64_t* nbr_t, const int32_t* nbr_id, const float* tw,
+                                     const float* tb, const float* nbr_time_feat, const uint8_t* mask, int32_t T, int32_t H,
+                                     int32_t k, int64_t R, float scale, float* zbar, tgmx_stream_t stream) {
+  TGMX_REQUIRE(d > 0 && D >= 0 && T > 0 && k > 0 && R >= 0, "tgat_attn_reduce: bad sizes d=%d D=%d T=%d k=%d", d, D, T, k);
+  TGMX_REQUIRE(H == 1 || H == 2 || H == 4 || H == 8, "tgat_attn_reduce: n_heads=%d unsupported (1, 2, 4 or 8)", H);
+  if (R == 0) return TGMX_OK;
+  TGMX_REQUIRE(qf && nbrf && (D == 0 || ex) && zbar, "tgat_attn_reduce: null pointer");
+  TGMX_REQUIRE(nbr_time_feat || (seed_t && nbr_t && tw && tb), "tgat_attn_reduce: need times + Time2Vec params or nbr_time_feat");
+  TGMX_REQUIRE(mask || nbr_id, "tgat_attn_reduce: need nbr_id or mask");
+  AttnArgs a{qf, nbrf, ex, seed_t, nbr_t, nbr_id, tw, tb, nbr_time_feat, mask, zbar, R, d, D, T, k, d + D + T, scale};
+  const size_t per_wave = ((size_t)k * T + (size_t)k * (H + 2)) * sizeof(float);
+  int waves = 4;
+  while (waves > 1 && per_wave * waves > 64 * 1024) waves >>= 1;
+  TGMX_REQUIRE(per_wave * waves <= 64 * 1024, "tgat_attn_reduce: k*T=%d too large for the LDS time-encoding cache", k * T);
+  const dim3 grid((unsigned)((R + waves - 1) / waves)), block(waves * kWave);
+  const size_t lds = per_wave * waves;
+  hipStream_t st = (hipStream_t)stream;
+  switch (H) {
+    case 1: hipLaunchKernelGGL(tgat_attn_reduce_kernel<1>, grid, block, lds, st, a); break;
+    case 2: hipLaunchKernelGGL(tgat_attn_reduce_kernel<2>, grid, block, lds, st, a); break;
+    case 4: hipLaunchKernelGGL(tgat_attn_reduce_kernel<4>, grid, block, lds, st, a); break;
+    default: hipLaunchKernelGGL(tgat_attn_reduce_kernel<8>, grid, block, lds, st, a); break;
+  }
+  TGMX_CHECK_LAUNCH("tgat_attn_reduce");
+  return TGMX_OK;
+}
+
+extern "C" int tgmx_time2vec(const void* x, int32_t x_is_int64, const float* w, const float* b, int32_t T, int64_t n,
+                             float* out, tgmx_stream_t stream) {
+  TGMX_REQUIRE(T > 0 && n >= 0, "time2vec: bad sizes");
+  if (n == 0) return TGMX_OK;
+  TGMX_REQUIRE(x && w && b && out, "time2vec: null pointer");
+  long long blocks = (n * T + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  if (x_is_int64)
+    hipLaunchKernelGGL(time2vec_kernel<int64_t>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const int64_t*)x, w, b,
+                       T, (long long)n, out);
+  else
+    hipLaunchKernelGGL(time2vec_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float*)x, w, b, T,
+                       (long long)n, out);
+  TGMX_CHECK_LAUNCH("time2vec");
+  return TGMX_OK;
+}
