@@ -1,0 +1,164 @@
+"""Host logic (no GPU): DGData validation, DGraph slicing, loader iteration, HookManager ordering,
+hook constructor / seed errors -- modelled on the reference's own unit tests for these pieces."""
+import numpy as np
+import pytest
+import torch
+
+from tgm_amd import DGBatch, DGData, DGDataLoader, DGraph
+from tgm_amd.core import TimeDeltaDG
+from tgm_amd.exceptions import (BadHookProtocolError, EmptyGraphError, EventOrderedConversionError, InvalidNodeIDError,
+                                UnresolvableHookDependenciesError)  # fmt: skip
+from tgm_amd.hooks import DeduplicationHook, HookManager, RandomNegativeEdgeSamplerHook, RecencyNeighborHook, StatelessHook
+
+
+def _data(E=50, N=9, D=3, seed=0, unit='r'):
+    rng = np.random.default_rng(seed)
+    ts = torch.from_numpy(np.sort(rng.integers(0, 40, E)).astype(np.int64))
+    ei = torch.from_numpy(rng.integers(0, N, (E, 2)).astype(np.int32))
+    return DGData.from_raw(ts, ei, torch.rand(E, D), time_delta=unit), ts, ei
+
+
+def test_dgdata_normalises_and_validates():
+    with pytest.warns(UserWarning):
+        d = DGData.from_raw(torch.LongTensor([3, 1, 2]), torch.LongTensor([[0, 1], [1, 2], [2, 0]]), torch.rand(3, 2).double())
+    assert d.edge_index.dtype == torch.int32 and d.edge_x.dtype == torch.float32 and d.time.dtype == torch.int64
+    assert d.time.tolist() == [1, 2, 3] and d.edge_index.tolist() == [[1, 2], [2, 0], [0, 1]]  # re-sorted with payload
+    with pytest.raises(InvalidNodeIDError):
+        DGData.from_raw(torch.LongTensor([1]), torch.IntTensor([[0, -1]]))
+    with pytest.raises(ValueError):
+        DGData.from_raw(torch.LongTensor([-1]), torch.IntTensor([[0, 1]]))
+    with pytest.raises(EmptyGraphError):
+        DGData.from_raw(torch.LongTensor([]), torch.zeros((0, 2), dtype=torch.int32))
+    with pytest.raises(ValueError):
+        DGData.from_raw(torch.LongTensor([1, 2]), torch.IntTensor([[0, 1], [1, 2]]), torch.rand(3, 2))
+    with pytest.raises(TypeError):
+        DGraph('not data')
+
+
+def test_slices_are_views_and_match_numpy():
+    data, ts, ei = _data()
+    dg = DGraph(data)
+    assert dg.num_events == 50 and dg.num_edge_events == 50 and dg.edge_x_dim == 3
+    assert dg.start_time == int(ts[0]) and dg.end_time == int(ts[-1])
+    v = dg.slice_events(10, 25)
+    b = v.materialize()
+    assert b._edge_lo == 10 and torch.equal(b.edge_src, ei[10:25, 0]) and torch.equal(b.edge_time, ts[10:25])
+    assert b.edge_src.data_ptr() == dg.edge_src[10:].data_ptr()  # zero-copy window
+    t = dg.slice_time(5, 17)  # [5, 17)
+    m = (ts >= 5) & (ts < 17)
+    assert torch.equal(t.edge_time, ts[m]) and torch.equal(t.edge_x, data.edge_x[m])
+    assert t.slice_events(0, 3).num_events <= 3
+    with pytest.raises(ValueError):
+        dg.slice_events(5, 2)
+    assert dg.slice_time(1000, 2000).materialize().edge_src.numel() == 0
+
+
+def test_loader_event_and_time_batches():
+    data, ts, _ = _data(unit='s')
+    dg = DGraph(data)
+    sizes = [b.edge_src.numel() for b in DGDataLoader(dg, batch_size=8)]
+    assert sum(sizes) == 50 and sizes[:-1] == [8] * 6 and len(DGDataLoader(dg, batch_size=8, drop_last=True)._starts) == 6
+    got = torch.cat([b.edge_time for b in DGDataLoader(dg, batch_size=5, batch_unit='s')])
+    assert torch.equal(got, ts)  # time windows of 5 s cover everything exactly once, empty ones skipped
+    with pytest.raises(ValueError):
+        DGDataLoader(dg, batch_size=0)
+    with pytest.raises(EventOrderedConversionError):
+        DGDataLoader(DGraph(_data()[0]), batch_size=2, batch_unit='s')
+    assert TimeDeltaDG('h').convert('m') == 60 and TimeDeltaDG('m', 30).is_coarser_than('s')
+
+
+class _Produces(StatelessHook):
+    def __init__(self, req, prod, log, name):
+        super().__init__()
+        self._cls = name
+        self._requires |= set(req)
+        self._produces |= set(prod)
+        self.log = log
+
+    def __call__(self, dg, batch):
+        self.log.append(self._cls)
+        for p in self.produces:
+            setattr(batch, p, torch.zeros(1))
+        return batch
+
+
+def test_hook_manager_orders_by_dependencies_and_neg_before_nbr():
+    data, _, _ = _data()
+    dg = DGraph(data)
+    log = []
+    hm = HookManager(keys=['a', 'b'])
+    nbr = _Produces({'edge_src'}, {'nbr_nids'}, log, 'nbr')
+    neg = _Produces({'edge_dst'}, {'neg'}, log, 'neg')
+    user = _Produces({'nbr_nids', 'neg'}, {'z'}, log, 'user')
+    hm.register('a', user)
+    hm.register('a', nbr)
+    hm.register('a', neg)  # registered last, must still run before the neighbor hook
+    with pytest.raises(RuntimeError):
+        hm.execute_active_hooks(dg, dg.materialize())
+    with hm.activate('a'):
+        hm.execute_active_hooks(dg, dg.materialize())
+        with pytest.raises(RuntimeError):
+            hm.register('a', neg)
+    assert log == ['neg', 'nbr', 'user']
+    with pytest.raises(KeyError):
+        hm.set_active_hooks('nope')
+    with pytest.raises(BadHookProtocolError):
+        hm.register('a', object())
+    hm2 = HookManager(keys=['k'])
+    hm2.register('k', _Produces({'never_made'}, {'q'}, log, 'x'))
+    with pytest.raises(UnresolvableHookDependenciesError):
+        hm2.resolve_hooks()
+    hm3 = HookManager(keys=['k'])  # cycle
+    hm3.register('k', _Produces({'p'}, {'q'}, log, 'x'))
+    hm3.register('k', _Produces({'q'}, {'p'}, log, 'y'))
+    with pytest.raises(UnresolvableHookDependenciesError):
+        hm3.resolve_hooks('k')
+    with pytest.raises(ValueError):
+        HookManager(keys=[])
+
+
+def test_recency_hook_contract_on_host():
+    h = RecencyNeighborHook(num_nbrs=[1], num_nodes=1, seed_nodes_keys=['edge_src'], seed_times_keys=['edge_time'])
+    assert h.has_state and h.requires == {'edge_src', 'edge_dst', 'edge_time'}
+    assert h.produces == {'seed_nids', 'nbr_nids', 'nbr_edge_time', 'nbr_edge_x', 'seed_times', 'seed_node_nbr_mask'}
+    hid = RecencyNeighborHook(num_nbrs=[1], num_nodes=1, seed_nodes_keys=['foo'], seed_times_keys=['bar'], id='x')
+    assert hid.produces == {p + '_x' for p in h.produces} and 'foo' in hid.requires and 'x' in repr(hid)
+    for bad in ([0], [-1], []):
+        with pytest.raises(ValueError):
+            RecencyNeighborHook(num_nbrs=bad, num_nodes=2, seed_nodes_keys=['a'], seed_times_keys=['b'])
+    with pytest.raises(ValueError):
+        RecencyNeighborHook(num_nbrs=[1], num_nodes=2, seed_nodes_keys=['a', 'b'], seed_times_keys=['a'])
+    with pytest.raises(ValueError):
+        RecencyNeighborHook(num_nbrs=[1], num_nodes=2, seed_nodes_keys=['a'], seed_times_keys=['a'], mode='csr')
+    # host-side seed checks (structure + values) run before any device work
+    data, _, _ = _data()
+    dg = DGraph(data)
+    hook = RecencyNeighborHook(num_nbrs=[1], num_nodes=2, seed_nodes_keys=['foo'], seed_times_keys=['bar'])
+    batch = dg.materialize()
+    with pytest.raises(ValueError):
+        hook(dg, batch)  # missing attributes
+    batch.foo, batch.bar = torch.IntTensor([5]), torch.LongTensor([1])
+    with pytest.raises(ValueError):
+        hook(dg, batch)  # id out of range
+    batch.foo, batch.bar = torch.IntTensor([1]), torch.LongTensor([-1])
+    with pytest.raises(ValueError):
+        hook(dg, batch)  # negative time
+    batch.foo, batch.bar = None, None
+    with pytest.warns(UserWarning):
+        out = hook(dg, batch)  # None seeds: empties, no device needed
+    assert out.nbr_nids[0].numel() == 0 and out.nbr_edge_x[0].shape == (0, 3)
+
+
+def test_negative_and_dedup_hooks_on_host():
+    data, _, ei = _data()
+    dg = DGraph(data)
+    b = RandomNegativeEdgeSamplerHook(3, 9, seed=1)(dg, dg.slice_events(0, 7).materialize())
+    assert b.neg.dtype == torch.int32 and b.neg.shape == (7,) and int(b.neg.min()) >= 3 and int(b.neg.max()) < 9
+    assert torch.equal(b.neg_time, b.edge_time) and b.neg_time.data_ptr() != b.edge_time.data_ptr()
+    with pytest.raises(ValueError):
+        RandomNegativeEdgeSamplerHook(5, 5)
+    b.nbr_nids = [torch.IntTensor([[8, -1], [2, 2]])]
+    b = DeduplicationHook(['neg', 'nbr_nids'])(dg, b)
+    exp = torch.unique(torch.cat([b.edge_src, b.edge_dst, b.neg, torch.IntTensor([8, 2, 2])]))
+    assert torch.equal(b.unique_nids, exp) and torch.equal(b.unique_nids[b.global_to_local(b.edge_src).long()], b.edge_src)
+    assert 'edge_src = [7]' in str(b) and isinstance(b, DGBatch)

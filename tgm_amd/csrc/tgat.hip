@@ -19,12 +19,15 @@ using floatx16 = __attribute__((__vector_size__(16 * sizeof(float)))) float;
 
 // ---------------------------------------------------------------------------
 // C[M,N] = act(A[M,K] * B[N,K]^T + bias[N]);  row-major, arbitrary leading dims,
-// optional batch (grid.z) with element strides.  Block tile 128 x 64, 4 waves,
-// each wave owns 32 rows x 64 cols = two 32x32 MFMA accumulators; K staged in
-// LDS 16 at a time (k-major, +1 padded rows: conflict-free operand reads).
+// optional batch (grid.z) with element strides.  Exact-fp32 MFMA
+// (v_mfma_f32_32x32x2_f32), operands loaded STRAIGHT INTO THE MFMA REGISTER LAYOUT:
+// both A and B are K-contiguous, so lane (i = lane & 31, half = lane >> 5) loads the
+// 8 consecutive k of "its" row -- A[m0+i][k0 + 8*half ..] and B[n0+i][k0 + 8*half ..]
+// (two 16-byte loads each) -- and the kk-th MFMA of a 16-wide k step consumes
+// k0+kk from the lower half-wave and k0+8+kk from the upper one.  No LDS, no
+// barriers; a wave owns a 32 x 64 output tile (two accumulators), four waves stack
+// along M.  The next step's operands are loaded before the current step's 16 MFMAs.
 // ---------------------------------------------------------------------------
-constexpr int GBM = 128, GBN = 64, GBK = 16;
-
 struct GemmArgs {
   const float* A;
   const float* B;
@@ -35,52 +38,72 @@ struct GemmArgs {
   int N, K, relu;
 };
 
+template <bool VEC>
+__device__ __forceinline__ void load_k8(const float* __restrict__ row, int kb, int K, float (&v)[8]) {
+  if (VEC && kb + 8 <= K) {
+    const float4 x = *reinterpret_cast<const float4*>(row + kb);
+    const float4 y = *reinterpret_cast<const float4*>(row + kb + 4);
+    v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+    v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
+  } else {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = kb + u < K ? row[kb + u] : 0.f;
+  }
+}
+
+template <bool AV, bool BV>
 __global__ __launch_bounds__(256) void sgemm_nt_kernel(const GemmArgs g) {
-  __shared__ float As[GBK][GBM + 1];
-  __shared__ float Bs[GBK][GBN + 1];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, half = lane >> 5;
+  const long long m0 = (long long)blockIdx.x * 128 + wave * 32;
+  if (m0 >= g.M) return;  // whole wave out of range (no block-level sync anywhere)
+  const int n0 = blockIdx.y * 64;
   const float* __restrict__ A = g.A + (long long)blockIdx.z * g.sA;
   const float* __restrict__ B = g.B + (long long)blockIdx.z * g.sB;
   float* __restrict__ C = g.C + (long long)blockIdx.z * g.sC;
-  const long long m0 = (long long)blockIdx.x * GBM;
-  const int n0 = blockIdx.y * GBN;
-  floatx16 acc0 = {0}, acc1 = {0};
-  const int half = lane >> 5, l31 = lane & 31;
+  // rows / columns past the edge are clamped for the loads; their results are never stored
+  const long long ra = m0 + i < g.M ? m0 + i : g.M - 1;
+  const int c0 = n0 + i < g.N ? n0 + i : g.N - 1;
+  const int c1 = n0 + 32 + i < g.N ? n0 + 32 + i : g.N - 1;
+  const float* __restrict__ pa = A + ra * g.lda;
+  const float* __restrict__ pb0 = B + (long long)c0 * g.ldb;
+  const float* __restrict__ pb1 = B + (long long)c1 * g.ldb;
 
-  for (int k0 = 0; k0 < g.K; k0 += GBK) {
-#pragma unroll
-    for (int i = 0; i < GBM * GBK / 256; ++i) {
-      const int e = tid + i * 256;
-      const int m = e / GBK, k = e % GBK;
-      const long long gm = m0 + m;
-      const int gk = k0 + k;
-      As[k][m] = (gm < g.M && gk < g.K) ? A[gm * g.lda + gk] : 0.f;
+  floatx16 acc0 = {0}, acc1 = {0};
+  float a[8], b0[8], b1[8], an[8], b0n[8], b1n[8];
+  int kb = half * 8;
+  load_k8<AV>(pa, kb, g.K, a);
+  load_k8<BV>(pb0, kb, g.K, b0);
+  load_k8<BV>(pb1, kb, g.K, b1);
+  for (int k0 = 0; k0 < g.K; k0 += 16) {
+    const bool more = k0 + 16 < g.K;
+    if (more) {
+      load_k8<AV>(pa, kb + 16, g.K, an);
+      load_k8<BV>(pb0, kb + 16, g.K, b0n);
+      load_k8<BV>(pb1, kb + 16, g.K, b1n);
     }
 #pragma unroll
-    for (int i = 0; i < GBN * GBK / 256; ++i) {
-      const int e = tid + i * 256;
-      const int n = e / GBK, k = e % GBK;
-      const int gn = n0 + n, gk = k0 + k;
-      Bs[k][n] = (gn < g.N && gk < g.K) ? B[(long long)gn * g.ldb + gk] : 0.f;
+    for (int kk = 0; kk < 8; ++kk) {
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], b0[kk], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], b1[kk], acc1, 0, 0, 0);
     }
-    __syncthreads();
+    if (more) {
 #pragma unroll
-    for (int kk = 0; kk < GBK; kk += 2) {
-      const float a = As[kk + half][wave * 32 + l31];
-      const float b0 = Bs[kk + half][l31];
-      const float b1 = Bs[kk + half][32 + l31];
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+      for (int u = 0; u < 8; ++u) {
+        a[u] = an[u];
+        b0[u] = b0n[u];
+        b1[u] = b1n[u];
+      }
     }
-    __syncthreads();
+    kb += 16;
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const long long row = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    const long long row = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
     if (row >= g.M) continue;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      const int col = n0 + t * 32 + l31;
+      const int col = n0 + t * 32 + i;
       if (col < g.N) {
         float v = t ? acc1[r] : acc0[r];
         if (g.bias) v += g.bias[col];
@@ -211,9 +234,10 @@ __device__ __forceinline__ float reduce_scatter64(float (&P)[64], int lane) {
   return P[0];
 }
 
-template <int H>
+// H heads, G slots per score group (G * H <= 64: one reduce-scatter delivers the group's scores)
+template <int H, int G>
 __global__ __launch_bounds__(256) void tgat_attn_reduce_kernel(const AttnArgs a) {
-  constexpr int G = 64 / H;  // slots whose (slot, head) scores fit one reduce-scatter
+  static_assert(G * H <= 64, "a score group must fit the 64 lanes");
   extern __shared__ __attribute__((aligned(16))) float lds_all[];
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
@@ -257,11 +281,12 @@ __global__ __launch_bounds__(256) void tgat_attn_reduce_kernel(const AttnArgs a)
       for (int h = 0; h < H; ++h) qv[h] = q[h * C + c];
 #pragma clang loop unroll(full)
       for (int s = 0; s < G; ++s) {
-        if (s < gs) {
-          const float z = nb[(long long)(s0 + s) * d + c];
+        // no branch: slots past the group's end re-read the last slot (their lanes are discarded),
+        // so all G loads are independent and in flight together
+        const int sl = s0 + s < k ? s0 + s : k - 1;
+        const float z = nb[(long long)sl * d + c];
 #pragma unroll
-          for (int h = 0; h < H; ++h) P[s * H + h] = __fmaf_rn(qv[h], z, P[s * H + h]);
-        }
+        for (int h = 0; h < H; ++h) P[s * H + h] = __fmaf_rn(qv[h], z, P[s * H + h]);
       }
     }
     for (int c = lane; c < D; c += kWave) {
@@ -270,11 +295,12 @@ __global__ __launch_bounds__(256) void tgat_attn_reduce_kernel(const AttnArgs a)
       for (int h = 0; h < H; ++h) qv[h] = q[h * C + d + c];
 #pragma clang loop unroll(full)
       for (int s = 0; s < G; ++s) {
-        if (s < gs) {
-          const float z = ex[(long long)(s0 + s) * D + c];
+        // no branch: slots past the group's end re-read the last slot (their lanes are discarded),
+        // so all G loads are independent and in flight together
+        const int sl = s0 + s < k ? s0 + s : k - 1;
+        const float z = ex[(long long)sl * D + c];
 #pragma unroll
-          for (int h = 0; h < H; ++h) P[s * H + h] = __fmaf_rn(qv[h], z, P[s * H + h]);
-        }
+        for (int h = 0; h < H; ++h) P[s * H + h] = __fmaf_rn(qv[h], z, P[s * H + h]);
       }
     }
     for (int c = lane; c < T; c += kWave) {
@@ -283,11 +309,12 @@ __global__ __launch_bounds__(256) void tgat_attn_reduce_kernel(const AttnArgs a)
       for (int h = 0; h < H; ++h) qv[h] = q[h * C + d + D + c];
 #pragma clang loop unroll(full)
       for (int s = 0; s < G; ++s) {
-        if (s < gs) {
-          const float z = s_cos[(s0 + s) * T + c];
+        // no branch: slots past the group's end re-read the last slot (their lanes are discarded),
+        // so all G loads are independent and in flight together
+        const int sl = s0 + s < k ? s0 + s : k - 1;
+        const float z = s_cos[sl * T + c];
 #pragma unroll
-          for (int h = 0; h < H; ++h) P[s * H + h] = __fmaf_rn(qv[h], z, P[s * H + h]);
-        }
+        for (int h = 0; h < H; ++h) P[s * H + h] = __fmaf_rn(qv[h], z, P[s * H + h]);
       }
     }
     const float sc = reduce_scatter64(P, lane);  // lane j = s*H + h now holds the full dot product
@@ -312,43 +339,41 @@ __global__ __launch_bounds__(256) void tgat_attn_reduce_kernel(const AttnArgs a)
   __builtin_amdgcn_wave_barrier();
 
   // ---- pass 2: zbar[h][c] = sum_s A[h][s] z[s][c]  (features re-read: L1/L2 hits) ----
+  // slots are consumed 8 at a time so that 8 independent loads are in flight per lane
   float* __restrict__ zb = a.zbar + r * (long long)H * C;
-  for (int c = lane; c < d; c += kWave) {
-    float acc[H];
+  constexpr int U = 8;
+  auto weighted_sum = [&](const float* __restrict__ base, long long slot_stride, int dim, int col0) {
+    for (int c = lane; c < dim; c += kWave) {
+      float acc[H];
 #pragma unroll
-    for (int h = 0; h < H; ++h) acc[h] = 0.f;
-    for (int s = 0; s < k; ++s) {
-      const float z = nb[(long long)s * d + c];
+      for (int h = 0; h < H; ++h) acc[h] = 0.f;
+      for (int s0 = 0; s0 < k; s0 += U) {
+        float z[U];
 #pragma unroll
-      for (int h = 0; h < H; ++h) acc[h] = __fmaf_rn(s_A[h * k + s], z, acc[h]);
+        for (int u = 0; u < U; ++u) {
+          const int s = s0 + u < k ? s0 + u : k - 1;  // clamped: the tail is multiplied by 0 below
+          z[u] = base[(long long)s * slot_stride + c];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (s0 + u < k) {
+#pragma unroll
+            for (int h = 0; h < H; ++h) acc[h] = __fmaf_rn(s_A[h * k + s0 + u], z[u], acc[h]);
+          }
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < H; ++h) zb[h * C + col0 + c] = acc[h];
     }
-#pragma unroll
-    for (int h = 0; h < H; ++h) zb[h * C + c] = acc[h];
-  }
-  for (int c = lane; c < D; c += kWave) {
-    float acc[H];
-#pragma unroll
-    for (int h = 0; h < H; ++h) acc[h] = 0.f;
-    for (int s = 0; s < k; ++s) {
-      const float z = ex[(long long)s * D + c];
-#pragma unroll
-      for (int h = 0; h < H; ++h) acc[h] = __fmaf_rn(s_A[h * k + s], z, acc[h]);
-    }
-#pragma unroll
-    for (int h = 0; h < H; ++h) zb[h * C + d + c] = acc[h];
-  }
-  for (int c = lane; c < T; c += kWave) {
-    float acc[H];
-#pragma unroll
-    for (int h = 0; h < H; ++h) acc[h] = 0.f;
-    for (int s = 0; s < k; ++s) {
-      const float z = s_cos[s * T + c];
-#pragma unroll
-      for (int h = 0; h < H; ++h) acc[h] = __fmaf_rn(s_A[h * k + s], z, acc[h]);
-    }
-#pragma unroll
-    for (int h = 0; h < H; ++h) zb[h * C + d + D + c] = acc[h];
-  }
+  };
+  weighted_sum(nb, d, d, 0);
+  if (D > 0) weighted_sum(ex, D, D, d);
+  weighted_sum(s_cos, T, T, d + D);
+}
+
+template <int H, int G>
+static void launch_attn(dim3 grid, dim3 block, size_t lds, hipStream_t st, const AttnArgs& a) {
+  if constexpr (G * H <= 64) hipLaunchKernelGGL((tgat_attn_reduce_kernel<H, G>), grid, block, lds, st, a);
 }
 
 }  // namespace tgmx
@@ -363,8 +388,14 @@ extern "C" int tgmx_sgemm_nt(const float* A, int64_t lda, const float* B, int64_
   TGMX_REQUIRE(A && B && C, "sgemm_nt: null pointer");
   TGMX_REQUIRE(lda >= K && ldb >= K && ldc >= N, "sgemm_nt: leading dimension smaller than the row length");
   GemmArgs g{A, B, C, bias, lda, ldb, ldc, strideA, strideB, strideC, M, N, K, relu};
-  const dim3 grid((unsigned)((M + GBM - 1) / GBM), (unsigned)((N + GBN - 1) / GBN), (unsigned)batch);
-  hipLaunchKernelGGL(sgemm_nt_kernel, grid, dim3(256), 0, (hipStream_t)stream, g);
+  const dim3 grid((unsigned)((M + 127) / 128), (unsigned)((N + 63) / 64), (unsigned)batch), block(256);
+  auto vec_ok = [](const float* p, long long ld, long long stride) { return ((uintptr_t)p & 15) == 0 && ld % 4 == 0 && stride % 4 == 0; };
+  const bool av = vec_ok(A, lda, strideA), bv = vec_ok(B, ldb, strideB);
+  hipStream_t st = (hipStream_t)stream;
+  if (av && bv) hipLaunchKernelGGL((sgemm_nt_kernel<true, true>), grid, block, 0, st, g);
+  else if (av) hipLaunchKernelGGL((sgemm_nt_kernel<true, false>), grid, block, 0, st, g);
+  else if (bv) hipLaunchKernelGGL((sgemm_nt_kernel<false, true>), grid, block, 0, st, g);
+  else hipLaunchKernelGGL((sgemm_nt_kernel<false, false>), grid, block, 0, st, g);
   TGMX_CHECK_LAUNCH("sgemm_nt");
   return TGMX_OK;
 }
@@ -424,12 +455,26 @@ extern "C" int tgmx_tgat_attn_reduce(const float* qf, const float* nbrf, int32_t
   const dim3 grid((unsigned)((R + waves - 1) / waves)), block(waves * kWave);
   const size_t lds = per_wave * waves;
   hipStream_t st = (hipStream_t)stream;
+  // slots per score group: the smallest instantiated G >= min(k, 64 / H)
+  const int want = k < 64 / H ? k : 64 / H;
+#define TGMX_ATTN(H_, G_) launch_attn<H_, G_>(grid, block, lds, st, a)
+#define TGMX_ATTN_H(H_)                                     \
+  do {                                                      \
+    if (want <= 4 && 4 * H_ <= 64) TGMX_ATTN(H_, 4);        \
+    else if (want <= 8 && 8 * H_ <= 64) TGMX_ATTN(H_, 8);   \
+    else if (want <= 10 && 10 * H_ <= 64) TGMX_ATTN(H_, 10); \
+    else if (want <= 16 && 16 * H_ <= 64) TGMX_ATTN(H_, 16); \
+    else if (want <= 20 && 20 * H_ <= 64) TGMX_ATTN(H_, 20); \
+    else TGMX_ATTN(H_, 64 / H_);                            \
+  } while (0)
   switch (H) {
-    case 1: hipLaunchKernelGGL(tgat_attn_reduce_kernel<1>, grid, block, lds, st, a); break;
-    case 2: hipLaunchKernelGGL(tgat_attn_reduce_kernel<2>, grid, block, lds, st, a); break;
-    case 4: hipLaunchKernelGGL(tgat_attn_reduce_kernel<4>, grid, block, lds, st, a); break;
-    default: hipLaunchKernelGGL(tgat_attn_reduce_kernel<8>, grid, block, lds, st, a); break;
+    case 1: TGMX_ATTN_H(1); break;
+    case 2: TGMX_ATTN_H(2); break;
+    case 4: TGMX_ATTN_H(4); break;
+    default: TGMX_ATTN_H(8); break;
   }
+#undef TGMX_ATTN_H
+#undef TGMX_ATTN
   TGMX_CHECK_LAUNCH("tgat_attn_reduce");
   return TGMX_OK;
 }
