@@ -175,6 +175,53 @@ int tgmx_ln_residual_concat(const float* y, const float* res, const float* gamma
                             int32_t O, float eps, const float* z0, int32_t d0, int64_t R, float* out,
                             tgmx_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * TGN memory module (tgm/nn/encoder/tgn.py:80-251), forward arithmetic.
+ * A node's stored events ("the events of the last batch in which it appeared",
+ * per role) are a window (st_lo[node], st_cnt[node]) into an append-only device log
+ * {log_other int32, log_t int64, log_raw [.,D] f32}.
+ * ------------------------------------------------------------------------ */
+
+/* Replace the store of every node of a batch role (tgn.py:218-229).  Entries are given
+ * in node-sorted (stable) order: perm[p] = batch entry at sorted position p, node_sorted[p]
+ * its node, [left[p], right[p]) the sorted run of that node; log rows [base, base+n) are written. */
+int tgmx_tgn_store(const int64_t* perm, const int32_t* node_sorted, const int64_t* left,
+                   const int64_t* right, const int32_t* other, const int64_t* t, const float* raw,
+                   int32_t D, int64_t n, int64_t base, int32_t* log_other, int64_t* log_t,
+                   float* log_raw, int64_t* st_lo, int32_t* st_cnt, tgmx_stream_t stream);
+
+/* aggr[r] = Last / Mean aggregation of node nodes[r]'s stored messages
+ * [mem[v] | mem[other] | raw | Time2Vec(t - last_update[v])], source-role store first
+ * (tgn.py:191-209, 43-74); new_lu[r] = max stored t (0 if none); aggr = 0 if none. */
+int tgmx_tgn_aggregate(const int32_t* nodes, int64_t R, const float* memory,
+                       const int64_t* last_update, int32_t M, int32_t num_nodes,
+                       const int64_t* st_lo_s, const int32_t* st_cnt_s, const int64_t* st_lo_d,
+                       const int32_t* st_cnt_d, const int32_t* log_other, const int64_t* log_t,
+                       const float* log_raw, int32_t D, const float* tw, const float* tb, int32_t T,
+                       int32_t mean, float* aggr, int64_t* new_lu, tgmx_stream_t stream);
+
+/* torch.nn.GRUCell gates from gi = x W_ih^T + b_ih and gh = h W_hh^T + b_hh ([R, 3M], r|z|n). */
+int tgmx_tgn_gru_gate(const float* gi, const float* gh, const float* h, int32_t M, int64_t R,
+                      float* out, tgmx_stream_t stream);
+
+/* memory[nodes[r]] = val[r]; last_update[nodes[r]] = lu[r] for rows with flag[r] (flag NULL: all). */
+int tgmx_tgn_commit(const int32_t* nodes, const uint8_t* flag, const float* val, const int64_t* lu,
+                    int32_t M, int32_t num_nodes, int64_t R, float* memory, int64_t* last_update,
+                    tgmx_stream_t stream);
+
+/* GraphAttentionEmbedding (tgn.py:14-40): edge_attr[e] = [Time2Vec(last_update_local[src[e]] - t[e]) | msg[e]] */
+int tgmx_tconv_edge_attr(const int64_t* last_update_local, const int64_t* src, const int64_t* t,
+                         const float* msg, const float* tw, const float* tb, int32_t T, int32_t D,
+                         int64_t E, float* out, tgmx_stream_t stream);
+
+/* TransformerConv attention (third-party definition, PyG 2.6.1): for every target i,
+ * out[i] += sum_j softmax_j(q_i.(k_j + e_ij)/sqrt(C)) (v_j + e_ij) per head; edges of target i are
+ * order[seg_lo[i] .. seg_hi[i]) (edge ids sorted by target), src[e] = source j. */
+int tgmx_tconv_attend(const float* q, const float* k, const float* v, const float* eproj,
+                      const int64_t* order, const int64_t* src, const int64_t* seg_lo,
+                      const int64_t* seg_hi, int64_t U, int32_t H, int32_t C, float scale, float* out,
+                      tgmx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,6 +17,7 @@ Fixture families:
   g5_*   TemporalAttention / TGAT eval-mode forward
   g6_*   Time2Vec on int64 deltas up to 2^31
   g7_*   DeduplicationHook
+  g8_*   TGNMemory (in-tree arithmetic: messages, Last/Mean aggregation, GRU, store semantics)
 """
 from __future__ import annotations
 
@@ -329,11 +330,58 @@ def g7_case():
     print('g7_dedup:', nb, 'batches')
 
 
+def g8_cases():
+    """TGN memory module, in-tree arithmetic only (tgm/nn/encoder/tgn.py:43-251): train-mode lookahead
+    `memory(n_id)`, `update_state`, the train->eval flush and eval-mode updates, for Last / Mean aggregation.
+    Streams have no two events of one node with equal float32 time inside a batch: the reference orders a node's
+    stored events with a NON-stable sort (tgn.py:226), so tie-breaking there is unspecified."""
+    from tgm.nn.encoder.tgn import IdentityMessage, LastAggregator, MeanAggregator, TGNMemory
+
+    for tag, aggr_cls, base, step in (('last', LastAggregator, 0, 3), ('mean', MeanAggregator, 0, 3), ('last_unix', LastAggregator, 1_200_000_000, 700)):
+        rng = np.random.default_rng(31)
+        N, E, D, M, T, bs = 40, 400, 5, 8, 6, 16
+        src = rng.integers(0, N, E).astype(np.int32)
+        dst = rng.integers(0, N, E).astype(np.int32)
+        ts = (base + np.cumsum(rng.integers(1, step + 1, E) * (256 if base else 1))).astype(np.int64)
+        raw = rng.random((E, D), dtype=np.float32)
+        neg = rng.integers(0, N, E).astype(np.int32)
+        torch.manual_seed(7)
+        mem = TGNMemory(N, D, M, T, message_module=IdentityMessage(D, M, T), aggregator_module=aggr_cls())
+        _jitter_params(mem, 41)
+        arrays = dict(src=src, dst=dst, ts=ts, raw=raw, neg=neg)
+        arrays.update({f'w_{n}': p.detach().numpy().copy() for n, p in mem.state_dict().items() if n not in ('memory', 'last_update', '_assoc')})
+        T_ = torch.from_numpy
+        nb_train = 18
+        mem.train()
+        b = 0
+        with torch.no_grad():
+            for lo in range(0, E, bs):
+                hi = min(lo + bs, E)
+                if b == nb_train:
+                    mem.eval()  # flushes the message store into the memory (tgn.py:245-251)
+                    arrays['flush_memory'] = mem.memory.numpy().copy()
+                    arrays['flush_last_update'] = mem.last_update.numpy().copy()
+                n_id = torch.unique(torch.cat([T_(src[lo:hi]), T_(dst[lo:hi]), T_(neg[lo:hi])])).long()
+                z, lu = mem(n_id)
+                arrays[f'b{b}_n_id'] = n_id.numpy().copy()
+                arrays[f'b{b}_z'] = z.numpy().copy()
+                arrays[f'b{b}_last_update'] = lu.numpy().copy()
+                mem.update_state(T_(src[lo:hi]).long(), T_(dst[lo:hi]).long(), T_(ts[lo:hi]), T_(raw[lo:hi]))
+                if b % 5 == 4 or b >= nb_train:
+                    arrays[f'b{b}_memory'] = mem.memory.numpy().copy()
+                    arrays[f'b{b}_mem_last_update'] = mem.last_update.numpy().copy()
+                b += 1
+        meta = dict(num_nodes=N, raw_msg_dim=D, memory_dim=M, time_dim=T, batch_size=bs, aggr=tag.split('_')[0], num_batches=b, train_batches=nb_train)
+        arrays['meta'] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+        np.savez_compressed(os.path.join(HERE, f'g8_tgn_{tag}.npz'), **arrays)
+        print(f'g8_tgn_{tag}: {b} batches')
+
+
 if __name__ == '__main__':
     import warnings
 
     warnings.filterwarnings('ignore')
     only = sys.argv[1:]
-    for fam, fn in [('g1', g1_cases), ('g2', g2_cases), ('g3', g3_case), ('g4', g4_case), ('g5', g5_cases), ('g6', g6_case), ('g7', g7_case)]:
+    for fam, fn in [('g1', g1_cases), ('g2', g2_cases), ('g3', g3_case), ('g4', g4_case), ('g5', g5_cases), ('g6', g6_case), ('g7', g7_case), ('g8', g8_cases)]:
         if not only or fam in only:
             fn()

@@ -1,0 +1,96 @@
+"""GPU parity of the TGN memory path: HIP TGNMemory vs the reference's outputs (goldens g8) and the
+oracle; GraphAttentionEmbedding vs our CPU restatement of the published TransformerConv definition
+(third-party arithmetic: unpinned upstream).  Tolerance 1e-5 relative (floor 1e-5), ints exact."""
+import pytest
+import torch
+
+import golden_util as gu
+from test_tgn_oracle_cpu import CASES, close, drive
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _memory(meta, a):
+    from tgm_amd.nn import IdentityMessage, LastAggregator, MeanAggregator, TGNMemory
+
+    D, M, T = meta['raw_msg_dim'], meta['memory_dim'], meta['time_dim']
+    aggr = LastAggregator() if meta['aggr'] == 'last' else MeanAggregator()
+    mem = TGNMemory(meta['num_nodes'], D, M, T, message_module=IdentityMessage(D, M, T), aggregator_module=aggr).to(DEV)
+    missing = mem.load_state_dict({k[2:]: torch.from_numpy(v) for k, v in a.items() if k.startswith('w_')}, strict=False)
+    assert set(missing.missing_keys) <= {'memory', 'last_update', '_assoc'} and not missing.unexpected_keys
+    mem.reset_state()
+    return mem.train()
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_tgn_memory_matches_reference(case):
+    meta, a = gu.load(case)
+    T = torch.from_numpy
+    mem = _memory(meta, a)
+    for ev in drive(meta, a, mem, to=lambda t: t.to(DEV)):
+        if ev[0] == 'fwd':
+            _, b, z, lu = ev
+            close(z.cpu(), T(a[f'b{b}_z']), f'{case} b{b} z')
+            assert torch.equal(lu.cpu(), T(a[f'b{b}_last_update'])), f'{case} b{b} last_update'
+        elif ev[0] == 'state':
+            b = ev[1]
+            close(mem.memory.cpu(), T(a[f'b{b}_memory']), f'{case} b{b} memory')
+            assert torch.equal(mem.last_update.cpu(), T(a[f'b{b}_mem_last_update']))
+        else:
+            close(mem.memory.cpu(), T(a['flush_memory']), f'{case} flush')
+            assert torch.equal(mem.last_update.cpu(), T(a['flush_last_update']))
+
+
+@pytest.mark.parametrize('aggr', ['last', 'mean'])
+def test_tgn_memory_matches_oracle_review_shaped(aggr):
+    """Example dims (memory/time 100, msg 16) on a review-shaped stream with hubs, bs=512."""
+    from oracle.tgn_ref import TGNMemoryRef
+    from tgm_amd.nn import IdentityMessage, LastAggregator, MeanAggregator, TGNMemory
+    from tgm_amd.synth import make_stream
+
+    st = make_stream('review', seed=5, num_edges=6000, n_src=900, n_dst=120)
+    # strictly increasing times: a node's events inside a batch never tie (the reference leaves ties unspecified)
+    ts = st.ts[0] + torch.arange(st.num_edges) * 300
+    N, D, M, T_, bs = st.num_nodes, 16, 100, 100, 512
+    torch.manual_seed(3)
+    mem = TGNMemory(N, D, M, T_, IdentityMessage(D, M, T_), LastAggregator() if aggr == 'last' else MeanAggregator()).to(DEV).train()
+    params = {k: v.detach().cpu().clone() for k, v in mem.state_dict().items() if k not in ('memory', 'last_update', '_assoc')}
+    ref = TGNMemoryRef(N, D, M, T_, params, aggr)
+    g = torch.Generator().manual_seed(9)
+    for b, lo in enumerate(range(0, st.num_edges, bs)):
+        hi = min(lo + bs, st.num_edges)
+        if b == 8:
+            mem.eval()
+            ref.eval()
+            close(mem.memory.cpu(), ref.memory, 'flush')
+        src, dst, t, raw = st.src[lo:hi], st.dst[lo:hi], ts[lo:hi], st.edge_x[lo:hi]
+        neg = torch.randint(900, N, (hi - lo,), generator=g, dtype=torch.int32)
+        n_id = torch.unique(torch.cat([src, dst, neg]))
+        z, lu = mem(n_id.to(DEV))
+        z_ref, lu_ref = ref.forward(n_id.long())
+        close(z.cpu(), z_ref, f'b{b} z')
+        assert torch.equal(lu.cpu(), lu_ref)
+        mem.update_state(src.to(DEV), dst.to(DEV), t.to(DEV), raw.to(DEV))
+        ref.update_state(src, dst, t, raw)
+    close(mem.memory.cpu(), ref.memory, 'final memory')
+    assert torch.equal(mem.last_update.cpu(), ref.last_update)
+
+
+def test_graph_attention_embedding_matches_restatement():
+    from oracle.tgn_ref import graph_attention_embedding_ref
+    from tgm_amd.nn import GraphAttentionEmbedding, Time2Vec
+
+    torch.manual_seed(0)
+    U, E, M, D, T_, emb = 300, 4000, 100, 16, 100, 100
+    enc = GraphAttentionEmbedding(M, emb, D, Time2Vec(T_)).to(DEV).eval()
+    x = torch.randn(U, M)
+    last_update = torch.randint(1_000_000, 2_000_000, (U,))
+    edge_index = torch.stack([torch.randint(0, U, (E,)), torch.randint(0, 40, (E,))])  # few targets: long segments
+    edge_index[1, :500] = torch.randint(0, U, (500,))
+    t = torch.randint(0, 1_000_000, (E,))
+    msg = torch.rand(E, D)
+    out = enc(x.to(DEV), last_update.to(DEV), edge_index.to(DEV), t.to(DEV), msg.to(DEV))
+    ref = graph_attention_embedding_ref({k: v.cpu() for k, v in enc.state_dict().items()}, x, last_update, edge_index, t, msg)
+    assert out.shape == (U, emb)
+    close(out.cpu(), ref, 'graph attention embedding')

@@ -51,6 +51,15 @@ SIGNATURES = {
         c_int32,
         [_P, _P, c_int32, _P, c_int32, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int64, ctypes.c_float, _P, _P],
     ),
+    'tgmx_tgn_store': (c_int32, [_P, _P, _P, _P, _P, _P, _P, c_int32, c_int64, c_int64, _P, _P, _P, _P, _P, _P]),
+    'tgmx_tgn_aggregate': (
+        c_int32,
+        [_P, c_int64, _P, _P, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P, c_int32, _P, _P, c_int32, c_int32, _P, _P, _P],
+    ),
+    'tgmx_tgn_gru_gate': (c_int32, [_P, _P, _P, c_int32, c_int64, _P, _P]),
+    'tgmx_tgn_commit': (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int64, _P, _P, _P]),
+    'tgmx_tconv_edge_attr': (c_int32, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int64, _P, _P]),
+    'tgmx_tconv_attend': (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, ctypes.c_float, _P, _P]),
     'tgmx_ln_residual_concat': (c_int32, [_P, _P, _P, _P, c_int32, ctypes.c_float, _P, c_int32, c_int64, _P, _P]),
     'tgmx_pack_adj': (c_int32, [_P, c_int64, _P, _P, _P, c_int64, _P, _P]),
 }

@@ -1,0 +1,288 @@
+"""TGN memory module + graph-attention embedding (tgm/nn/encoder/tgn.py) on HIP kernels.
+
+Same classes, constructor arguments, parameter / buffer names (``time_enc``, ``memory_updater``,
+``memory``, ``last_update``; ``conv.lin_{key,query,value,edge,skip}``) and call protocol as the
+reference (``memory(n_id)``, ``memory.update_state(src, dst, t, raw_msg)``, ``reset_state``,
+``detach``, ``train``/``eval`` with the flush of tgn.py:245-251).  Forward arithmetic only.
+
+Execution model: the reference's per-node Python dict of stored events is an append-only device
+log + a (lo, cnt) window per node and role; commits over a batch's touched nodes run on all 2*bs
+batch entries with a first-occurrence flag (no ``unique``, no host synchronisation); the GRU
+contractions run on the exact-fp32 MFMA GEMM.  ``torch.sort`` / ``searchsorted`` are used as
+device-side glue to group a batch's entries by node.
+
+Tie note: the reference orders a node's events inside one batch with a NON-stable sort
+(tgn.py:226), so which of two events with the same float32 timestamp ``LastAggregator`` picks is
+unspecified there; here it is the earlier edge of the batch.
+"""
+from __future__ import annotations
+
+import copy
+from typing import Callable, Optional, Tuple
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from .. import _native
+from . import _ops
+from .time_encoding import Time2Vec
+
+
+class LastAggregator(nn.Module):
+    """Keep, per node, the message with the largest timestamp (tgn.py:43-56)."""
+
+    mean = 0
+
+
+class MeanAggregator(nn.Module):
+    """Average a node's messages (tgn.py:59-63)."""
+
+    mean = 1
+
+
+class IdentityMessage(nn.Module):
+    """message = [mem[src] | mem[dst] | raw_msg | t_enc]  (tgn.py:66-74)."""
+
+    def __init__(self, raw_msg_dim: int, memory_dim: int, time_dim: int) -> None:
+        super().__init__()
+        self.out_channels = raw_msg_dim + 2 * memory_dim + time_dim
+
+
+class TGNMemory(nn.Module):
+    def __init__(self, num_nodes: int, raw_msg_dim: int, memory_dim: int, time_dim: int, message_module: Callable,
+                 aggregator_module: Callable) -> None:  # fmt: skip
+        super().__init__()
+        if not isinstance(message_module, IdentityMessage):
+            raise NotImplementedError('tgm_amd TGNMemory supports IdentityMessage only')
+        if not isinstance(aggregator_module, (LastAggregator, MeanAggregator)):
+            raise NotImplementedError('tgm_amd TGNMemory supports LastAggregator / MeanAggregator only')
+        self.num_nodes, self.raw_msg_dim, self.memory_dim, self.time_dim = num_nodes, raw_msg_dim, memory_dim, time_dim
+        self.msg_s_module = message_module
+        self.msg_d_module = copy.deepcopy(message_module)
+        self.aggr_module = aggregator_module
+        self.time_enc = Time2Vec(time_dim=time_dim)
+        self.memory_updater = nn.GRUCell(message_module.out_channels, memory_dim)
+        self.register_buffer('memory', torch.zeros(num_nodes, memory_dim))
+        self.register_buffer('last_update', torch.zeros(num_nodes, dtype=torch.long))
+        self.register_buffer('_assoc', torch.empty(num_nodes, dtype=torch.long))
+        # message store: per role a (lo, cnt) window per node into the shared event log
+        self._st_lo = [None, None]
+        self._st_cnt = [None, None]
+        self._log_other: Optional[Tensor] = None
+        self._log_t: Optional[Tensor] = None
+        self._log_raw: Optional[Tensor] = None
+        self._log_len = 0
+        self.memory_updater.reset_parameters()
+
+    # -- state ------------------------------------------------------------------
+    @property
+    def device(self) -> torch.device:
+        return self.time_enc.w.weight.device
+
+    def reset_parameters(self) -> None:
+        self.memory_updater.reset_parameters()
+        self.reset_state()
+
+    def reset_state(self) -> None:
+        self.memory.zero_()
+        self.last_update.zero_()
+        self._reset_message_store()
+
+    def detach(self) -> None:
+        self.memory.detach_()
+
+    def _reset_message_store(self) -> None:
+        dev = self.memory.device
+        for r in (0, 1):
+            self._st_lo[r] = torch.zeros(self.num_nodes, dtype=torch.int64, device=dev)
+            self._st_cnt[r] = torch.zeros(self.num_nodes, dtype=torch.int32, device=dev)
+        self._log_len = 0
+
+    def _ensure_store(self, extra: int) -> None:
+        dev = self.memory.device
+        if self._st_lo[0] is None or self._st_lo[0].device != dev:
+            self._reset_message_store()
+            self._log_other = None
+        need = self._log_len + extra
+        cap = 0 if self._log_other is None else self._log_other.numel()
+        if need > cap or (self._log_other is not None and self._log_other.device != dev):
+            new_cap = max(need, 2 * cap, 1 << 16)
+            other = torch.empty(new_cap, dtype=torch.int32, device=dev)
+            t = torch.empty(new_cap, dtype=torch.int64, device=dev)
+            raw = torch.empty((new_cap, max(self.raw_msg_dim, 1)), dtype=torch.float32, device=dev)
+            if self._log_len:
+                other[: self._log_len] = self._log_other[: self._log_len]
+                t[: self._log_len] = self._log_t[: self._log_len]
+                raw[: self._log_len] = self._log_raw[: self._log_len]
+            self._log_other, self._log_t, self._log_raw = other, t, raw
+
+    # -- kernels ----------------------------------------------------------------
+    def _updated(self, nodes: Tensor) -> Tuple[Tensor, Tensor]:
+        """Look-ahead memory for int32 node ids ``nodes`` [R] (tgn.py:191-216); writes nothing."""
+        lib = _native.load()
+        _native.require_device(nodes, 'n_id')
+        self._ensure_store(0)
+        dev, R, M, D, T = nodes.device, nodes.numel(), self.memory_dim, self.raw_msg_dim, self.time_dim
+        W = 2 * M + D + T
+        stream = _native.stream_ptr()
+        aggr = torch.empty((R, W), dtype=torch.float32, device=dev)
+        new_lu = torch.empty(R, dtype=torch.int64, device=dev)
+        tw, tb = self.time_enc.w.weight.detach().reshape(-1), self.time_enc.w.bias.detach()
+        _native.check(
+            lib.tgmx_tgn_aggregate(
+                nodes.data_ptr(), R, self.memory.data_ptr(), self.last_update.data_ptr(), M, self.num_nodes,
+                self._st_lo[0].data_ptr(), self._st_cnt[0].data_ptr(), self._st_lo[1].data_ptr(), self._st_cnt[1].data_ptr(),
+                _native.ptr(self._log_other), _native.ptr(self._log_t), _native.ptr(self._log_raw), D, tw.data_ptr(), tb.data_ptr(),
+                T, self.aggr_module.mean, aggr.data_ptr(), new_lu.data_ptr(), stream,
+            ),
+            'tgmx_tgn_aggregate',
+        )  # fmt: skip
+        h = _ops.gather_rows(self.memory.detach(), nodes)
+        gru = self.memory_updater
+        gi = torch.empty((R, 3 * M), dtype=torch.float32, device=dev)
+        gh = torch.empty((R, 3 * M), dtype=torch.float32, device=dev)
+        _ops.sgemm_nt(aggr, gru.weight_ih.detach(), gi, bias=gru.bias_ih.detach())
+        _ops.sgemm_nt(h, gru.weight_hh.detach(), gh, bias=gru.bias_hh.detach())
+        out = torch.empty((R, M), dtype=torch.float32, device=dev)
+        _native.check(lib.tgmx_tgn_gru_gate(gi.data_ptr(), gh.data_ptr(), h.data_ptr(), M, R, out.data_ptr(), stream), 'tgmx_tgn_gru_gate')
+        return out, new_lu
+
+    def _commit(self, nodes: Tensor, flag: Optional[Tensor]) -> None:
+        lib = _native.load()
+        CH = 1 << 16  # bounds the [rows, msg_dim] scratch when all N nodes are flushed
+        # every row is computed from the OLD memory first (the reference evaluates all of n_id at once), then written
+        done = []
+        for lo in range(0, nodes.numel(), CH):
+            part = nodes[lo : lo + CH]
+            done.append((lo, part) + self._updated(part))
+        for lo, part, mem, lu in done:
+            fl = None if flag is None else flag[lo : lo + CH]
+            _native.check(
+                lib.tgmx_tgn_commit(part.data_ptr(), _native.ptr(fl), mem.data_ptr(), lu.data_ptr(), self.memory_dim, self.num_nodes,
+                                    part.numel(), self.memory.data_ptr(), self.last_update.data_ptr(), _native.stream_ptr()),
+                'tgmx_tgn_commit',
+            )  # fmt: skip
+
+    def _store_role(self, role: int, node: Tensor, other: Tensor, t: Tensor, raw: Optional[Tensor]) -> None:
+        lib = _native.load()
+        n = node.numel()
+        self._ensure_store(n)
+        node_sorted, perm = torch.sort(node, stable=True)
+        left = torch.searchsorted(node_sorted, node_sorted, right=False)
+        right = torch.searchsorted(node_sorted, node_sorted, right=True)
+        _native.check(
+            lib.tgmx_tgn_store(perm.data_ptr(), node_sorted.data_ptr(), left.data_ptr(), right.data_ptr(), other.data_ptr(), t.data_ptr(),
+                               _native.ptr(raw), self.raw_msg_dim, n, self._log_len, self._log_other.data_ptr(), self._log_t.data_ptr(),
+                               self._log_raw.data_ptr(), self._st_lo[role].data_ptr(), self._st_cnt[role].data_ptr(), _native.stream_ptr()),
+            'tgmx_tgn_store',
+        )  # fmt: skip
+        self._log_len += n
+
+    # -- reference protocol -------------------------------------------------------
+    def forward(self, n_id: Tensor) -> Tuple[Tensor, Tensor]:
+        """train mode: memory as it would be after committing the stored messages (nothing is written);
+        eval mode: the table rows (tgn.py:157-163)."""
+        _native.require_device(n_id, 'n_id')
+        if self.training:
+            return self._updated(n_id.to(torch.int32).contiguous())
+        idx = n_id.long()
+        return self.memory[idx], self.last_update[idx]
+
+    def update_state(self, src: Tensor, dst: Tensor, t: Tensor, raw_msg: Tensor) -> None:
+        """tgn.py:165-177.  The commit runs over all 2*bs batch entries with a first-occurrence flag."""
+        _native.require_device(src, 'src')
+        src32, dst32 = src.to(torch.int32).contiguous(), dst.to(torch.int32).contiguous()
+        t = t.to(torch.int64).contiguous()
+        raw = _ops._f32c(raw_msg, 'raw_msg') if self.raw_msg_dim else None
+        both = torch.cat([src32, dst32])
+        srt, _ = torch.sort(both)
+        first = torch.ones(srt.numel(), dtype=torch.uint8, device=srt.device)
+        first[1:] = (srt[1:] != srt[:-1]).to(torch.uint8)
+        if self.training:
+            self._commit(srt, first)
+            self._store_role(0, src32, dst32, t, raw)
+            self._store_role(1, dst32, src32, t, raw)
+        else:
+            self._store_role(0, src32, dst32, t, raw)
+            self._store_role(1, dst32, src32, t, raw)
+            self._commit(srt, first)
+
+    def train(self, mode: bool = True) -> 'TGNMemory':
+        if self.training and not mode and self.memory.device.type == 'cuda':
+            # entering eval: flush every node's stored messages into the memory, clear the stores (tgn.py:245-251)
+            self._commit(torch.arange(self.num_nodes, dtype=torch.int32, device=self.memory.device), None)
+            self._reset_message_store()
+        super().train(mode)
+        return self
+
+
+class TransformerConv(nn.Module):
+    """Graph transformer operator with edge features -- parameters named like
+    ``torch_geometric.nn.TransformerConv`` (2.6.1; third-party to the reference, parity unpinned):
+    concat=True, root_weight=True, beta=False, bias=True; attention dropout must be inactive."""
+
+    def __init__(self, in_channels: int, out_channels: int, heads: int = 1, dropout: float = 0.0, edge_dim: Optional[int] = None) -> None:
+        super().__init__()
+        self.in_channels, self.out_channels, self.heads, self.dropout, self.edge_dim = in_channels, out_channels, heads, dropout, edge_dim
+        hc = heads * out_channels
+        self.lin_key = nn.Linear(in_channels, hc)
+        self.lin_query = nn.Linear(in_channels, hc)
+        self.lin_value = nn.Linear(in_channels, hc)
+        self.lin_edge = nn.Linear(edge_dim, hc, bias=False)
+        self.lin_skip = nn.Linear(in_channels, hc, bias=True)
+
+    def forward(self, x: Tensor, edge_index: Tensor, edge_attr: Tensor) -> Tensor:
+        if self.training and self.dropout > 0:
+            raise NotImplementedError('tgm_amd TransformerConv: attention dropout / backward not implemented; call .eval()')
+        lib = _native.load()
+        x = _ops._f32c(x, 'x')
+        dev, U, H, C = x.device, x.shape[0], self.heads, self.out_channels
+        HC = H * C
+        f32 = dict(dtype=torch.float32, device=dev)
+        q, k, v, out = (torch.empty((U, HC), **f32) for _ in range(4))
+        _ops.sgemm_nt(x, self.lin_query.weight.detach(), q, bias=self.lin_query.bias.detach())
+        _ops.sgemm_nt(x, self.lin_key.weight.detach(), k, bias=self.lin_key.bias.detach())
+        _ops.sgemm_nt(x, self.lin_value.weight.detach(), v, bias=self.lin_value.bias.detach())
+        _ops.sgemm_nt(x, self.lin_skip.weight.detach(), out, bias=self.lin_skip.bias.detach())
+        E = edge_index.shape[1]
+        if E:
+            eproj = torch.empty((E, HC), **f32)
+            _ops.sgemm_nt(_ops._f32c(edge_attr, 'edge_attr'), self.lin_edge.weight.detach(), eproj)
+            src, tgt = edge_index[0].contiguous(), edge_index[1].contiguous()  # flow: source_to_target
+            tgt_sorted, order = torch.sort(tgt, stable=True)
+            ids = torch.arange(U, device=dev, dtype=tgt.dtype)
+            seg_lo = torch.searchsorted(tgt_sorted, ids, right=False)
+            seg_hi = torch.searchsorted(tgt_sorted, ids, right=True)
+            _native.check(
+                lib.tgmx_tconv_attend(q.data_ptr(), k.data_ptr(), v.data_ptr(), eproj.data_ptr(), order.data_ptr(), src.data_ptr(),
+                                      seg_lo.data_ptr(), seg_hi.data_ptr(), U, H, C, float(C) ** -0.5, out.data_ptr(), _native.stream_ptr()),
+                'tgmx_tconv_attend',
+            )  # fmt: skip
+        return out
+
+
+class GraphAttentionEmbedding(nn.Module):
+    """tgn.py:14-40: edge_attr = [Time2Vec(last_update[src] - t) | msg], then TransformerConv(heads=2, dropout=0.1)."""
+
+    def __init__(self, in_channels: int, out_channels: int, msg_dim: int, time_enc: nn.Module) -> None:
+        super().__init__()
+        self.time_enc = time_enc
+        self.conv = TransformerConv(in_channels, out_channels // 2, heads=2, dropout=0.1, edge_dim=msg_dim + time_enc.time_dim)
+
+    def forward(self, x: Tensor, last_update: Tensor, edge_index: Tensor, t: Tensor, msg: Tensor) -> Tensor:
+        lib = _native.load()
+        _native.require_device(x, 'x')
+        E, T = edge_index.shape[1], self.time_enc.time_dim
+        msg = _ops._f32c(msg, 'msg')
+        D = msg.shape[1]
+        edge_index = edge_index.to(torch.int64)
+        edge_attr = torch.empty((E, T + D), dtype=torch.float32, device=x.device)
+        tw, tb = self.time_enc.w.weight.detach().reshape(-1), self.time_enc.w.bias.detach()
+        _native.check(
+            lib.tgmx_tconv_edge_attr(last_update.to(torch.int64).contiguous().data_ptr(), edge_index[0].contiguous().data_ptr(),
+                                     t.to(torch.int64).contiguous().data_ptr(), msg.data_ptr(), tw.data_ptr(), tb.data_ptr(), T, D, E,
+                                     edge_attr.data_ptr(), _native.stream_ptr()),
+            'tgmx_tconv_edge_attr',
+        )  # fmt: skip
+        return self.conv(x, edge_index, edge_attr)
