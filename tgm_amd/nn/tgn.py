@@ -73,6 +73,7 @@ class TGNMemory(nn.Module):
         self._log_t: Optional[Tensor] = None
         self._log_raw: Optional[Tensor] = None
         self._log_len = 0
+        self.shard_commits = True  # under torch.distributed (world > 1): shard update_state's commit across ranks
         self.memory_updater.reset_parameters()
 
     # -- state ------------------------------------------------------------------
@@ -153,16 +154,54 @@ class TGNMemory(nn.Module):
         CH = 1 << 16  # bounds the [rows, msg_dim] scratch when all N nodes are flushed
         # every row is computed from the OLD memory first (the reference evaluates all of n_id at once), then written
         done = []
-        for lo in range(0, nodes.numel(), CH):
-            part = nodes[lo : lo + CH]
-            done.append((lo, part) + self._updated(part))
+        if self._sharded(nodes.numel()):
+            done.append((0, nodes) + self._updated_sharded(nodes))
+        else:
+            for lo in range(0, nodes.numel(), CH):
+                part = nodes[lo : lo + CH]
+                done.append((lo, part) + self._updated(part))
         for lo, part, mem, lu in done:
-            fl = None if flag is None else flag[lo : lo + CH]
+            fl = None if flag is None else flag[lo : lo + part.numel()]
             _native.check(
                 lib.tgmx_tgn_commit(part.data_ptr(), _native.ptr(fl), mem.data_ptr(), lu.data_ptr(), self.memory_dim, self.num_nodes,
                                     part.numel(), self.memory.data_ptr(), self.last_update.data_ptr(), _native.stream_ptr()),
                 'tgmx_tgn_commit',
             )  # fmt: skip
+
+    # -- one process per GPU: shard the commit rows, all-gather the updated memory rows ------------
+    def _sharded(self, rows: int) -> bool:
+        import torch.distributed as dist
+
+        return self.shard_commits and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and rows >= dist.get_world_size()
+
+    def _updated_sharded(self, nodes: Tensor) -> Tuple[Tensor, Tensor]:
+        """Each rank evaluates a contiguous slice of the commit rows from its replica of the (identical)
+        store and memory; ONE all-gather (RCCL over xGMI when the backend is nccl) of fixed-size
+        (memory row, last_update) records gives every replica all rows, applied in the same order
+        everywhere, so replicas stay bit-identical.  Payload: rows * (4*M + 8) bytes per step."""
+        import torch.distributed as dist
+
+        world, rank = dist.get_world_size(), dist.get_rank()
+        R, M, dev = nodes.numel(), self.memory_dim, nodes.device
+        per = (R + world - 1) // world
+        lo, hi = min(rank * per, R), min((rank + 1) * per, R)
+        mem_l = torch.zeros((per, M), dtype=torch.float32, device=dev)
+        lu_l = torch.zeros(per, dtype=torch.int64, device=dev)
+        if hi > lo:
+            m, l = self._updated(nodes[lo:hi])
+            mem_l[: hi - lo], lu_l[: hi - lo] = m, l
+        mem_g = torch.empty((world * per, M), dtype=torch.float32, device=dev)
+        lu_g = torch.empty(world * per, dtype=torch.int64, device=dev)
+        if dist.get_backend() == 'gloo':  # CPU collective (tests): stage through the host
+            mc, lc = torch.empty(mem_g.shape), torch.empty(lu_g.shape, dtype=torch.int64)
+            dist.all_gather_into_tensor(mc, mem_l.cpu())
+            dist.all_gather_into_tensor(lc, lu_l.cpu())
+            mem_g.copy_(mc)
+            lu_g.copy_(lc)
+        else:
+            dist.all_gather_into_tensor(mem_g, mem_l)
+            dist.all_gather_into_tensor(lu_g, lu_l)
+        return mem_g[:R], lu_g[:R]
 
     def _store_role(self, role: int, node: Tensor, other: Tensor, t: Tensor, raw: Optional[Tensor]) -> None:
         lib = _native.load()
