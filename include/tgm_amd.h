@@ -108,7 +108,7 @@ int tgmx_ring_lookup(const tgmx_adj_t* ring, const int32_t* write_pos,
  * it); key_wrap32 = 0 uses int64 (the intended per-node chronological order).
  * edge_x may be NULL (rows of zeros, recency.py:325-328).  eid0 = store index of
  * the batch's first edge or -1 (recorded in the slot, informational).
- * scratch: >= 4 * (directed ? n : 2n) int32.  */
+ * scratch: >= 12 * m + 16 int32, m = (directed ? n : 2n).  */
 int tgmx_ring_update(tgmx_adj_t* ring, int32_t* write_pos, float* ring_x, int32_t D, int32_t B,
                      int32_t num_nodes, const int32_t* src, const int32_t* dst, const int64_t* ts,
                      const float* edge_x, int64_t n, int64_t eid0, int32_t directed, int32_t key_wrap32,

@@ -283,6 +283,13 @@ struct UpdateArgs {
   int32_t* sorted_node;  // scratch [m]: its node (-1 = invalid entry)
   int32_t* target;       // scratch [m]: ring row it is placed at (-1 = dropped)
   int32_t* winner;       // scratch [m]: ring row it finally owns (-1 = none)
+  // large-batch path only:
+  long long* span;       // scratch: max(ts) + 1
+  long long* key;        // scratch [m]: sort key of entry j
+  int32_t* node;         // scratch [m]: node of entry j (-1 invalid)
+  int32_t* rank;         // scratch [m]: sorted position of entry j
+  int32_t* kept;         // scratch [m]
+  int32_t* flags;        // scratch [m]
   int32_t* status;
   long long n, m, eid0;
   int B, N, D, key_wrap32;
@@ -306,10 +313,12 @@ __device__ __forceinline__ void update_entry(const UpdateArgs& a, long long j, i
   t = a.ts[i];
 }
 
-__global__ __launch_bounds__(256) void ring_update_sort_kernel(const UpdateArgs a) {
-  __shared__ long long t_key[256];
+// ---- large batches (m > kFusedMaxM): exact all-pairs passes, tiled in 2-D over (entry, other)
+// so that the O(m^2) compares spread over the whole chip; partial counts meet in global atomics.
+constexpr int kTile = 256;  // "other" entries staged in LDS per block: (m/256)^2 blocks fill the chip
+
+__global__ __launch_bounds__(256) void ring_update_span_kernel(const UpdateArgs a) {
   __shared__ long long red[256];
-  // span = max(ts) + 1 over the batch (every block reduces it redundantly: n is small)
   long long mx = -0x7fffffffffffffffLL;
   for (long long x = threadIdx.x; x < a.n; x += 256) {
     const long long v = a.ts[x];
@@ -321,95 +330,152 @@ __global__ __launch_bounds__(256) void ring_update_sort_kernel(const UpdateArgs 
     if ((int)threadIdx.x < w) red[threadIdx.x] = red[threadIdx.x + w] > red[threadIdx.x] ? red[threadIdx.x + w] : red[threadIdx.x];
     __syncthreads();
   }
-  const long long span = red[0] + 1;
+  if (threadIdx.x == 0) *a.span = red[0] + 1;
+}
 
+__global__ __launch_bounds__(256) void ring_update_keys_kernel(const UpdateArgs a) {
   const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  int node = -1, nbr = -1;
-  long long t = 0, i = 0, key = 0;
-  bool valid = false;
-  if (j < a.m) {
-    update_entry(a, j, node, nbr, t, i);
-    valid = node >= 0 && node < a.N && nbr >= 0 && nbr < a.N;
-    if (!valid) atomicOr(a.status, TGMX_ST_EDGE_RANGE);
-    key = update_key(node, t, span, a.key_wrap32);
-  }
-  int rank = 0;
-  for (long long base = 0; base < a.m; base += 256) {
-    const long long jj = base + threadIdx.x;
-    long long kk = 0;
-    if (jj < a.m) {
-      int n2, b2;
-      long long t2, i2;
-      update_entry(a, jj, n2, b2, t2, i2);
-      kk = update_key(n2, t2, span, a.key_wrap32);
+  if (j >= a.m) return;
+  int node, nbr;
+  long long t, i;
+  update_entry(a, j, node, nbr, t, i);
+  const bool valid = node >= 0 && node < a.N && nbr >= 0 && nbr < a.N;
+  if (!valid) atomicOr(a.status, TGMX_ST_EDGE_RANGE);
+  a.key[j] = update_key(node, t, *a.span, a.key_wrap32);
+  a.node[j] = valid ? node : -1;
+  a.rank[j] = 0;
+}
+
+// rank[j] += #{x in tile : (key_x, x) < (key_j, j)}
+__global__ __launch_bounds__(256) void ring_update_rank_kernel(const UpdateArgs a) {
+  __shared__ long long t_key[kTile];
+  const long long x0 = (long long)blockIdx.y * kTile;
+  const int lim = (a.m - x0) < kTile ? (int)(a.m - x0) : kTile;
+  for (int x = threadIdx.x; x < kTile; x += 256) t_key[x] = x < lim ? a.key[x0 + x] : 0x7fffffffffffffffLL;
+  __syncthreads();
+  const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= a.m) return;
+  const long long kj = a.key[j];
+  int cnt = 0;
+  for (int x = 0; x < kTile; x += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const long long kx = t_key[x + u];
+      cnt += (kx < kj) || (kx == kj && x0 + x + u < j);
     }
-    __syncthreads();
-    t_key[threadIdx.x] = kk;
-    __syncthreads();
-    const int lim = (a.m - base) < 256 ? (int)(a.m - base) : 256;
-    for (int x = 0; x < lim; ++x) {
-      const long long kx = t_key[x];
-      rank += (kx < key) || (kx == key && base + x < j);
-    }
   }
-  if (j < a.m) {
-    a.sorted_j[rank] = (int)j;
-    a.sorted_node[rank] = valid ? node : -1;
-  }
+  if (cnt) atomicAdd(&a.rank[j], cnt);
+}
+
+__global__ __launch_bounds__(256) void ring_update_scatter_kernel(const UpdateArgs a) {
+  const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= a.m) return;
+  const int r = a.rank[j];
+  a.sorted_j[r] = (int)j;
+  a.sorted_node[r] = a.node[j];
 }
 
 __global__ __launch_bounds__(256) void ring_update_place_kernel(const UpdateArgs a) {
-  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  // Runs of equal node ids are found through a bitmask of run starts over an LDS window
+  // [p0 - 256, p0 + 512) of the sorted node ids (O(1) words per lookup even for hub nodes);
+  // only runs that leave the window continue with a scan through global memory.
+  __shared__ int win[768];
+  __shared__ unsigned long long starts[12];
+  const long long p0 = (long long)blockIdx.x * blockDim.x;
+  const long long w0 = p0 - 256;
+  for (int x = threadIdx.x; x < 768; x += 256) {
+    const long long q = w0 + x;
+    win[x] = (q >= 0 && q < a.m) ? a.sorted_node[q] : -7;
+  }
+  __syncthreads();
+  for (int x = threadIdx.x; x < 768; x += 256) {
+    const bool st = x > 0 && win[x] != win[x - 1];
+    const unsigned long long m = __ballot(st);
+    if ((threadIdx.x & 63) == 0) starts[x >> 6] = m;
+  }
+  __syncthreads();
+  const long long p = p0 + threadIdx.x;
   if (p >= a.m) return;
-  const int node = a.sorted_node[p];
+  const int x = 256 + threadIdx.x;
+  const int node = win[x];
   int tgt = -1;
   if (node >= 0) {
-    long long lo = p, hi = p + 1;
-    while (lo > 0 && a.sorted_node[lo - 1] == node) --lo;
-    while (hi < a.m && a.sorted_node[hi] == node) ++hi;
+    // run start: nearest start bit at or left of x
+    long long lo = -1;
+    {
+      int w = x >> 6;
+      unsigned long long m = starts[w] & (~0ull >> (63 - (x & 63)));
+      while (!m && w > 0) m = starts[--w];
+      if (m) lo = w0 + w * 64 + 63 - __clzll((long long)m);
+    }
+    if (lo < 0) {  // run began before the window
+      lo = w0 > 0 ? w0 : 0;
+      while (lo > 0 && a.sorted_node[lo - 1] == node) --lo;
+    }
+    // run end: nearest start bit right of x
+    long long hi = -1;
+    {
+      int w = x >> 6;
+      unsigned long long m = (x & 63) == 63 ? 0ull : starts[w] & (~0ull << ((x & 63) + 1));
+      while (!m && w < 11) m = starts[++w];
+      if (m) hi = w0 + w * 64 + __ffsll((long long)m) - 1;
+    }
+    if (hi < 0) {  // run continues past the window
+      hi = w0 + 768;
+      while (hi < a.m && a.sorted_node[hi] == node) ++hi;
+    }
+    if (hi > a.m) hi = a.m;
     const int cnt = (int)(hi - lo), pos = (int)(p - lo);
     const int drop = cnt > a.B ? cnt - a.B : 0;
     if (pos >= drop) tgt = node * a.B + (a.write_pos[node] % a.B + pos - drop) % a.B;
   }
   a.target[p] = tgt;
+  a.kept[p] = 0;
+  a.flags[p] = 0;
+}
+
+// per sorted position p (placed entries only), against one tile of the others:
+//   kept[p]  += #{x : same node, placed}       flags[p] |= 1 if a LATER placed entry has the same node
+//                                              flags[p] |= 2 if a LATER entry is placed on the same ring slot
+__global__ __launch_bounds__(256) void ring_update_resolve_kernel(const UpdateArgs a) {
+  __shared__ int2 t_pl[kTile];
+  const long long x0 = (long long)blockIdx.y * kTile;
+  const int lim = (a.m - x0) < kTile ? (int)(a.m - x0) : kTile;
+  for (int x = threadIdx.x; x < kTile; x += 256) t_pl[x] = x < lim ? make_int2(a.sorted_node[x0 + x], a.target[x0 + x]) : make_int2(-3, -2);
+  __syncthreads();
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= a.m) return;
+  const int tgt = a.target[p];
+  if (tgt < 0) return;
+  const int node = a.sorted_node[p];
+  int kept = 0, fl = 0;
+  for (int x = 0; x < kTile; x += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int2 o = t_pl[x + u];
+      const bool same_kept = o.x == node && o.y >= 0;
+      const bool later = x0 + x + u > p;
+      kept += same_kept;
+      fl |= (later && same_kept) ? 1 : 0;
+      fl |= (later && o.y == tgt) ? 2 : 0;
+    }
+  }
+  if (kept) atomicAdd(&a.kept[p], kept);
+  if (fl) atomicOr(&a.flags[p], fl);
 }
 
 __global__ __launch_bounds__(256) void ring_update_write_kernel(const UpdateArgs a) {
-  __shared__ int t_tgt[256];
-  __shared__ int t_node[256];
   const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  int tgt = -1, node = -1;
-  if (p < a.m) {
-    tgt = a.target[p];
-    node = a.sorted_node[p];
-  }
-  bool overwritten = false, later_kept = false;
-  int kept_total = 0;
-  for (long long base = 0; base < a.m; base += 256) {
-    const long long pp = base + threadIdx.x;
-    __syncthreads();
-    t_tgt[threadIdx.x] = pp < a.m ? a.target[pp] : -1;
-    t_node[threadIdx.x] = pp < a.m ? a.sorted_node[pp] : -2;
-    __syncthreads();
-    if (tgt >= 0) {
-      const int lim = (a.m - base) < 256 ? (int)(a.m - base) : 256;
-      for (int x = 0; x < lim; ++x) {
-        const bool kept_same_node = t_node[x] == node && t_tgt[x] >= 0;
-        kept_total += kept_same_node;
-        const bool later = base + x > p;
-        later_kept |= later && kept_same_node;
-        overwritten |= later && t_tgt[x] == tgt;
-      }
-    }
-  }
   if (p >= a.m) return;
+  const int tgt = a.target[p];
   int win = -1;
   if (tgt >= 0) {
-    if (!overwritten) {
-      const long long j = a.sorted_j[p];
+    const int fl = a.flags[p];
+    const int node = a.sorted_node[p];
+    if (!(fl & 2)) {
       int nd, nbr;
       long long t, i;
-      update_entry(a, j, nd, nbr, t, i);
+      update_entry(a, a.sorted_j[p], nd, nbr, t, i);
       Rec r;
       r.nbr = nbr;
       r.eid = a.eid0 >= 0 ? (int)(a.eid0 + i) : -1;
@@ -417,7 +483,7 @@ __global__ __launch_bounds__(256) void ring_update_write_kernel(const UpdateArgs
       a.ring[tgt] = r;
       win = tgt;
     }
-    if (!later_kept) a.write_pos[node] = (a.write_pos[node] % a.B + kept_total) % a.B;  // one committer per node
+    if (!(fl & 1)) a.write_pos[node] = (a.write_pos[node] % a.B + a.kept[p]) % a.B;  // one committer per node
   }
   a.winner[p] = win;
 }
@@ -672,8 +738,20 @@ extern "C" int tgmx_ring_update(tgmx_adj_t* ring, int32_t* write_pos, float* rin
   if (a.m <= kFusedMaxM) {
     hipLaunchKernelGGL(ring_update_fused_kernel, dim3(1), dim3(kFusedThreads), 0, st, a);
   } else {
-    hipLaunchKernelGGL(ring_update_sort_kernel, dim3(blocks), dim3(256), 0, st, a);
+    // 16-byte aligned int64 scratch first, then the int32 arrays
+    long long* s64 = reinterpret_cast<long long*>(scratch + 4 * a.m + ((4 * a.m) & 1));
+    s64 = reinterpret_cast<long long*>(((uintptr_t)s64 + 15) & ~(uintptr_t)15);
+    a.span = s64;
+    a.key = s64 + 2;
+    int32_t* s32 = reinterpret_cast<int32_t*>(a.key + a.m);
+    a.node = s32; a.rank = s32 + a.m; a.kept = s32 + 2 * a.m; a.flags = s32 + 3 * a.m;
+    const dim3 grid2((unsigned)blocks, (unsigned)((a.m + kTile - 1) / kTile));
+    hipLaunchKernelGGL(ring_update_span_kernel, dim3(1), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(ring_update_keys_kernel, dim3(blocks), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(ring_update_rank_kernel, grid2, dim3(256), 0, st, a);
+    hipLaunchKernelGGL(ring_update_scatter_kernel, dim3(blocks), dim3(256), 0, st, a);
     hipLaunchKernelGGL(ring_update_place_kernel, dim3(blocks), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(ring_update_resolve_kernel, grid2, dim3(256), 0, st, a);
     hipLaunchKernelGGL(ring_update_write_kernel, dim3(blocks), dim3(256), 0, st, a);
   }
   if (D > 0) hipLaunchKernelGGL(ring_update_feat_kernel, dim3((unsigned)((a.m + 3) / 4)), dim3(256), 0, st, a);

@@ -323,8 +323,8 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
                 n_edges = batch.edge_src.numel()
                 if self._mode == 'ring' and n_edges:
                     m = n_edges if self._directed else 2 * n_edges
-                    if self._scratch is None or self._scratch.numel() < 4 * m:
-                        self._scratch = torch.empty(4 * m, dtype=torch.int32, device=device)
+                    if self._scratch is None or self._scratch.numel() < 12 * m + 16:
+                        self._scratch = torch.empty(12 * m + 16, dtype=torch.int32, device=device)
                     ex = batch.edge_x
                     if ex is not None and D:
                         if ex.dtype != torch.float32 or not ex.is_contiguous():
