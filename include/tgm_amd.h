@@ -148,7 +148,8 @@ int tgmx_gather_rows(const float* table, int64_t num_rows, int32_t dim, const in
  * (tgm/nn/modules/attention.py:93-95).  time_feat [R, T] may be NULL: then it is
  * Time2Vec(0) = cos(tb), what TGAT.forward passes (tgat.py:139). */
 int tgmx_tgat_rres(const float* x, int64_t ldx, int32_t d, const float* tb, const float* time_feat,
-                   int32_t T, int32_t O, int64_t R, float* out, tgmx_stream_t stream);
+                   int32_t T, int32_t O, int64_t R, float* out, int64_t ldo /* 0 = O; columns [O, ldo) zeroed */,
+                   tgmx_stream_t stream);
 
 /* C[b] = act(A[b] (M x K, lda) * B[b]^T (B is N x K, ldb) + bias), b < batch with
  * element strides; exact-fp32 MFMA.  Replaces the nn.Linear calls of
@@ -167,13 +168,54 @@ int tgmx_tgat_attn_reduce(const float* qf, const float* nbrf, int32_t d, const f
                           const int64_t* seed_t, const int64_t* nbr_t, const int32_t* nbr_id,
                           const float* tw, const float* tb, const float* nbr_time_feat,
                           const uint8_t* mask, int32_t T, int32_t H, int32_t k, int64_t R,
-                          float scale, float* zbar, tgmx_stream_t stream);
+                          float scale, int32_t head_stride /* floats between heads in qf / zbar rows, 0 = C */,
+                          float* zbar, tgmx_stream_t stream);
 
 /* out[R, O + d0] = [LayerNorm(y + res) * gamma + beta | z0]
  * (attention.py:127 + the concat of tgat.py:36). */
-int tgmx_ln_residual_concat(const float* y, const float* res, const float* gamma, const float* beta,
-                            int32_t O, float eps, const float* z0, int32_t d0, int64_t R, float* out,
+int tgmx_ln_residual_concat(const float* y, int64_t ldy, const float* res, int64_t ldr,
+                            const float* gamma, const float* beta, int32_t O, float eps, const float* z0,
+                            int32_t d0, int64_t R, float* out, int64_t ldo /* leading dims: 0 = dense */,
                             tgmx_stream_t stream);
+
+/* Whole TGAT forward in one call (tgm/nn/encoder/tgat.py:95-149): enqueues the leaf gathers and,
+ * per layer, the row-batched kernel sequence above.  hops[i] are the sampler's hop-i outputs
+ * (rows_i = S0 * k_0 * ... * k_{i-1}); workspace from tgmx_tgat_workspace_bytes(); out [S0, emb]. */
+#define TGMX_TGAT_MAX_LAYERS 4
+/* Weight matrices are passed as zero-padded copies whose rows start 16-byte aligned
+ * (p4(x) = x rounded up to a multiple of 4; dh = O / H; C = d + D + T): */
+typedef struct tgmx_tgat_layer {
+  const float* W_Q;   /* [O, p4(O)]          attn.{l}.W_Q.weight, rows padded                          */
+  const float* W_K_t; /* [C, H * p4(dh)]     W_KV[:O]^T, head h's dh columns at column h * p4(dh)      */
+  const float* W_V;   /* [O, p4(C)]          W_KV[O:], rows padded                                     */
+  const float* W_O;   /* [O, p4(O)]                                                                    */
+  const float* b_O;   /* [O]                                                                           */
+  const float* ln_g;  /* [O]  layer_norm.weight                                                        */
+  const float* ln_b;  /* [O]                                                                           */
+  const float* fc1_w; /* [emb, p4(O + d0)]   merge_layers.{l}.fc1.weight, rows padded                  */
+  const float* fc1_b; /* [emb]                                                                         */
+  const float* fc2_w; /* [emb_out, p4(emb)]                                                            */
+  const float* fc2_b; /* [emb_out]                                                                     */
+  int32_t d, D, T, O, H, emb, emb_out;
+  float ln_eps;
+} tgmx_tgat_layer_t;
+typedef struct tgmx_tgat_model {
+  const float* tw; /* [T] time_encoder.w.weight */
+  const float* tb; /* [T] time_encoder.w.bias   */
+  int32_t num_layers, d0;
+  tgmx_tgat_layer_t layers[TGMX_TGAT_MAX_LAYERS];
+} tgmx_tgat_model_t;
+typedef struct tgmx_tgat_hop {
+  const int64_t* seed_t; /* [rows_i]        seed_times[i]    */
+  const int32_t* nbr_id; /* [rows_i, k]     nbr_nids[i]      */
+  const int64_t* nbr_t;  /* [rows_i, k]     nbr_edge_time[i] */
+  const float* edge_x;   /* [rows_i, k, D]  nbr_edge_x[i]    */
+  int32_t k;
+} tgmx_tgat_hop_t;
+size_t tgmx_tgat_workspace_bytes(const tgmx_tgat_model_t* model, int64_t S0, const tgmx_tgat_hop_t* hops);
+int tgmx_tgat_forward(const tgmx_tgat_model_t* model, const float* node_x, int64_t num_nodes,
+                      const int32_t* seed_ids, int64_t S0, const tgmx_tgat_hop_t* hops,
+                      float* workspace, size_t workspace_bytes, float* out, tgmx_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * TGN memory module (tgm/nn/encoder/tgn.py:80-251), forward arithmetic.

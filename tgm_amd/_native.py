@@ -42,14 +42,14 @@ SIGNATURES = {
     'tgmx_ring_reset': (c_int32, [_P, _P, c_int32, c_int32, _P]),
     'tgmx_time2vec': (c_int32, [_P, c_int32, _P, _P, c_int32, c_int64, _P, _P]),
     'tgmx_gather_rows': (c_int32, [_P, c_int64, c_int32, _P, c_int64, _P, c_int64, _P]),
-    'tgmx_tgat_rres': (c_int32, [_P, c_int64, c_int32, _P, _P, c_int32, c_int32, c_int64, _P, _P]),
+    'tgmx_tgat_rres': (c_int32, [_P, c_int64, c_int32, _P, _P, c_int32, c_int32, c_int64, _P, c_int64, _P]),
     'tgmx_sgemm_nt': (
         c_int32,
         [_P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int32, c_int32, _P, c_int32, c_int32, c_int64, c_int64, c_int64, _P],
     ),
     'tgmx_tgat_attn_reduce': (
         c_int32,
-        [_P, _P, c_int32, _P, c_int32, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int64, ctypes.c_float, _P, _P],
+        [_P, _P, c_int32, _P, c_int32, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int64, ctypes.c_float, c_int32, _P, _P],
     ),
     'tgmx_tgn_store': (c_int32, [_P, _P, _P, _P, _P, _P, _P, c_int32, c_int64, c_int64, _P, _P, _P, _P, _P, _P]),
     'tgmx_tgn_aggregate': (
@@ -60,9 +60,32 @@ SIGNATURES = {
     'tgmx_tgn_commit': (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int64, _P, _P, _P]),
     'tgmx_tconv_edge_attr': (c_int32, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int64, _P, _P]),
     'tgmx_tconv_attend': (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, ctypes.c_float, _P, _P]),
-    'tgmx_ln_residual_concat': (c_int32, [_P, _P, _P, _P, c_int32, ctypes.c_float, _P, c_int32, c_int64, _P, _P]),
+    'tgmx_ln_residual_concat': (c_int32, [_P, c_int64, _P, c_int64, _P, _P, c_int32, ctypes.c_float, _P, c_int32, c_int64, _P, c_int64, _P]),
     'tgmx_pack_adj': (c_int32, [_P, c_int64, _P, _P, _P, c_int64, _P, _P]),
 }
+
+TGAT_MAX_LAYERS = 4
+
+
+class TgatLayer(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in ('W_Q', 'W_K_t', 'W_V', 'W_O', 'b_O', 'ln_g', 'ln_b', 'fc1_w', 'fc1_b', 'fc2_w', 'fc2_b')] + [
+        (n, c_int32) for n in ('d', 'D', 'T', 'O', 'H', 'emb', 'emb_out')
+    ] + [('ln_eps', ctypes.c_float)]
+
+
+class TgatModel(ctypes.Structure):
+    _fields_ = [('tw', c_void_p), ('tb', c_void_p), ('num_layers', c_int32), ('d0', c_int32), ('layers', TgatLayer * TGAT_MAX_LAYERS)]
+
+
+class TgatHop(ctypes.Structure):
+    _fields_ = [('seed_t', c_void_p), ('nbr_id', c_void_p), ('nbr_t', c_void_p), ('edge_x', c_void_p), ('k', c_int32)]
+
+
+SIGNATURES['tgmx_tgat_workspace_bytes'] = (c_size_t, [ctypes.POINTER(TgatModel), c_int64, ctypes.POINTER(TgatHop)])
+SIGNATURES['tgmx_tgat_forward'] = (
+    c_int32,
+    [ctypes.POINTER(TgatModel), _P, c_int64, _P, c_int64, ctypes.POINTER(TgatHop), _P, c_size_t, _P, _P],
+)
 
 _lib: Optional[ctypes.CDLL] = None
 

@@ -44,4 +44,29 @@ inline FastDiv make_fastdiv(uint32_t div) {
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
 
+// cos(x) for Time2Vec arguments (float32 x up to ~2^31 * w): the argument is reduced in DOUBLE
+// precision (x - k*pi/2 with a two-term pi/2: exact to ~1e-16 * k, far below float resolution for
+// every float32 input), then a float minimax polynomial on [-pi/4, pi/4].  ~35 instructions and no
+// divergence, vs ~130 for the library cosf whose large-argument (Payne-Hanek) path every wave takes
+// here because a row's 100 frequencies span 9 decades.  Max error ~1.5 ulp (< 2e-7 absolute).
+__device__ __forceinline__ float cos_t2v(float x) {
+  const double xd = (double)x;
+  const double kd = __builtin_rint(xd * 0.63661977236758134308);
+  double r = __builtin_fma(-kd, 1.57079632679489655800e+00, xd);
+  r = __builtin_fma(-kd, 6.12323399573676603587e-17, r);
+  const float rf = (float)r;
+  const int q = (int)((long long)kd & 3);
+  const float r2 = rf * rf;
+  float sp = -1.9515295891e-4f;
+  sp = __fmaf_rn(sp, r2, 8.3321608736e-3f);
+  sp = __fmaf_rn(sp, r2, -1.6666654611e-1f);
+  const float sn = __fmaf_rn(sp * r2, rf, rf);
+  float cp = 2.443315711809948e-5f;
+  cp = __fmaf_rn(cp, r2, -1.388731625493765e-3f);
+  cp = __fmaf_rn(cp, r2, 4.166664568298827e-2f);
+  const float cs = __fmaf_rn(cp * r2, r2, __fmaf_rn(-0.5f, r2, 1.0f));
+  const float v = (q & 1) ? sn : cs;  // q: 0 -> cos r, 1 -> -sin r, 2 -> -cos r, 3 -> sin r
+  return (q == 1 || q == 2) ? -v : v;
+}
+
 }  // namespace tgmx

@@ -136,16 +136,17 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
 // Time2Vec of the zero vector is cos(fma(0, w, b)) = cos(b).
 __global__ __launch_bounds__(256) void tgat_rres_kernel(const float* __restrict__ x, long long ldx, int d,
                                                         const float* __restrict__ tb, const float* __restrict__ tfeat,
-                                                        int T, int O, long long R, float* __restrict__ out) {
-  const long long total = R * O;
+                                                        int T, int O, long long R, float* __restrict__ out, long long ldo) {
+  // columns [O, ldo) of a padded row are zero-filled
+  const long long total = R * ldo;
   const long long step = (long long)gridDim.x * blockDim.x;
   const int t0 = O - T;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += step) {
-    const long long r = e / O;
-    const int c = (int)(e - r * O);
+    const long long r = e / ldo;
+    const int c = (int)(e - r * ldo);
     float v = 0.f;
     if (c < d) v = x[r * ldx + c];
-    else if (c >= t0) v = tfeat ? tfeat[r * T + (c - t0)] : cosf(tb[c - t0]);
+    else if (c >= t0 && c < O) v = tfeat ? tfeat[r * T + (c - t0)] : cos_t2v(tb[c - t0]);
     out[e] = v;
   }
 }
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(256) void time2vec_kernel(const TI* __restrict__ x,
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += step) {
     const long long i = e / T;
     const int t = (int)(e - i * T);
-    out[e] = cosf(__fmaf_rn((float)x[i], w[t], b[t]));
+    out[e] = cos_t2v(__fmaf_rn((float)x[i], w[t], b[t]));
   }
 }
 
@@ -169,12 +170,13 @@ __global__ __launch_bounds__(256) void ln_residual_concat_kernel(const float* __
                                                                  const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, int O, float eps,
                                                                  const float* __restrict__ z0, int d0, long long R,
-                                                                 float* __restrict__ out) {
+                                                                 float* __restrict__ out, long long ldy, long long ldr,
+                                                                 long long ldo) {
   const int lane = lane_id();
   const long long r = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (r >= R) return;
-  const float* yr = y + r * O;
-  const float* rr = res + r * O;
+  const float* yr = y + r * ldy;
+  const float* rr = res + r * ldr;
   float s = 0.f;
   for (int c = lane; c < O; c += kWave) s += yr[c] + rr[c];
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
@@ -186,9 +188,10 @@ __global__ __launch_bounds__(256) void ln_residual_concat_kernel(const float* __
   }
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   const float rstd = 1.0f / sqrtf(v / (float)O + eps);
-  float* orow = out + r * (O + d0);
+  float* orow = out + r * ldo;
   for (int c = lane; c < O; c += kWave) orow[c] = (yr[c] + rr[c] - mean) * rstd * gamma[c] + beta[c];
   for (int c = lane; c < d0; c += kWave) orow[O + c] = z0[r * d0 + c];
+  for (int c = O + d0 + lane; c < ldo; c += kWave) orow[c] = 0.f;  // padding of a padded row
 }
 
 // ---------------------------------------------------------------------------
@@ -209,6 +212,7 @@ struct AttnArgs {
   long long R;
   int d, D, T, k, C;
   float scale;        // dh^-1/2
+  int Cs;             // stride (floats) between consecutive heads of qf / zbar rows (>= C; padded layouts)
 };
 
 // sum over the 64 lanes of P[j], delivered to lane j: 63 shuffles instead of 64 * 6.
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(256) void tgat_attn_reduce_kernel(const AttnArgs a)
 
   const long long r = (long long)blockIdx.x * (blockDim.x >> 6) + wave;
   if (r >= a.R) return;
-  const float* __restrict__ q = a.qf + r * (long long)H * C;
+  const float* __restrict__ q = a.qf + r * (long long)H * a.Cs;
   const float* __restrict__ nb = a.nbrf + r * (long long)k * d;
   const float* __restrict__ ex = a.ex + r * (long long)k * D;
 
@@ -265,7 +269,7 @@ __global__ __launch_bounds__(256) void tgat_attn_reduce_kernel(const AttnArgs a)
   for (int e = lane; e < k * T; e += kWave) {
     const int s = e / T, t = e - s * T;
     // Linear(1,T) is one fma (time_encoding.py:23-24)
-    s_cos[e] = a.tfeat ? a.tfeat[r * (long long)k * T + e] : cosf(__fmaf_rn(s_dt[s], a.tw[t], a.tb[t]));
+    s_cos[e] = a.tfeat ? a.tfeat[r * (long long)k * T + e] : cos_t2v(__fmaf_rn(s_dt[s], a.tw[t], a.tb[t]));
   }
   __builtin_amdgcn_wave_barrier();
 
@@ -278,7 +282,7 @@ __global__ __launch_bounds__(256) void tgat_attn_reduce_kernel(const AttnArgs a)
     for (int c = lane; c < d; c += kWave) {
       float qv[H];
 #pragma unroll
-      for (int h = 0; h < H; ++h) qv[h] = q[h * C + c];
+      for (int h = 0; h < H; ++h) qv[h] = q[h * a.Cs + c];
 #pragma clang loop unroll(full)
       for (int s = 0; s < G; ++s) {
         // no branch: slots past the group's end re-read the last slot (their lanes are discarded),
@@ -292,7 +296,7 @@ __global__ __launch_bounds__(256) void tgat_attn_reduce_kernel(const AttnArgs a)
     for (int c = lane; c < D; c += kWave) {
       float qv[H];
 #pragma unroll
-      for (int h = 0; h < H; ++h) qv[h] = q[h * C + d + c];
+      for (int h = 0; h < H; ++h) qv[h] = q[h * a.Cs + d + c];
 #pragma clang loop unroll(full)
       for (int s = 0; s < G; ++s) {
         // no branch: slots past the group's end re-read the last slot (their lanes are discarded),
@@ -306,7 +310,7 @@ __global__ __launch_bounds__(256) void tgat_attn_reduce_kernel(const AttnArgs a)
     for (int c = lane; c < T; c += kWave) {
       float qv[H];
 #pragma unroll
-      for (int h = 0; h < H; ++h) qv[h] = q[h * C + d + D + c];
+      for (int h = 0; h < H; ++h) qv[h] = q[h * a.Cs + d + D + c];
 #pragma clang loop unroll(full)
       for (int s = 0; s < G; ++s) {
         // no branch: slots past the group's end re-read the last slot (their lanes are discarded),
@@ -340,7 +344,7 @@ __global__ __launch_bounds__(256) void tgat_attn_reduce_kernel(const AttnArgs a)
 
   // ---- pass 2: zbar[h][c] = sum_s A[h][s] z[s][c]  (features re-read: L1/L2 hits) ----
   // slots are consumed 8 at a time so that 8 independent loads are in flight per lane
-  float* __restrict__ zb = a.zbar + r * (long long)H * C;
+  float* __restrict__ zb = a.zbar + r * (long long)H * a.Cs;
   constexpr int U = 8;
   auto weighted_sum = [&](const float* __restrict__ base, long long slot_stride, int dim, int col0) {
     for (int c = lane; c < dim; c += kWave) {
@@ -363,7 +367,7 @@ __global__ __launch_bounds__(256) void tgat_attn_reduce_kernel(const AttnArgs a)
         }
       }
 #pragma unroll
-      for (int h = 0; h < H; ++h) zb[h * C + col0 + c] = acc[h];
+      for (int h = 0; h < H; ++h) zb[h * a.Cs + col0 + c] = acc[h];
     }
   };
   weighted_sum(nb, d, d, 0);
@@ -371,9 +375,173 @@ __global__ __launch_bounds__(256) void tgat_attn_reduce_kernel(const AttnArgs a)
   weighted_sum(s_cos, T, T, d + D);
 }
 
+// ---------------------------------------------------------------------------
+// Register-resident variant for the shapes TGAT actually runs (k <= G slots in one score group,
+// D a multiple of 4 with D/4 <= 64, T <= 128, times given): every lane keeps "its" float4 column of
+// all k slots' edge features (and of the neighbor features) plus its two Time2Vec columns in
+// registers, so the row's [k, C] block is read from memory exactly ONCE, as 16-byte loads issued
+// back to back; no LDS at all (slot metadata and attention weights travel by v_readlane).
+// ---------------------------------------------------------------------------
+template <int H, int G, bool NBV>
+__global__ __launch_bounds__(256) void tgat_attn_reduce_reg_kernel(const AttnArgs a) {
+  static_assert(G * H <= 64, "a score group must fit the 64 lanes");
+  const int lane = lane_id();
+  const long long r = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (r >= a.R) return;
+  const int k = a.k, T = a.T, d = a.d, D = a.D, C = a.C;
+  const int D4 = D >> 2, d4 = d >> 2;
+  const float* __restrict__ q = a.qf + r * (long long)H * a.Cs;
+  const float* __restrict__ nb = a.nbrf + r * (long long)k * d;
+  const float4* __restrict__ ex4 = reinterpret_cast<const float4*>(a.ex + r * (long long)k * D);
+
+  // slot metadata: lane s holds slot s
+  float my_dt = 0.f;
+  bool my_ok = false;
+  if (lane < k) {
+    my_dt = (float)(a.seed_t[r] - a.nbr_t[r * k + lane]);  // int64 subtract, then round-to-nearest f32
+    my_ok = a.mask ? a.mask[r * k + lane] != 0 : a.nbr_id[r * k + lane] != -1;
+  }
+
+  // ---- the row's features, straight into registers (all loads independent) ----
+  const bool e_on = lane < D4;
+  float4 ze[G];
+#pragma unroll
+  for (int s = 0; s < G; ++s) {
+    const int sl = s < k ? s : k - 1;
+    ze[s] = e_on ? ex4[sl * D4 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float4 zn[NBV ? G : 1];
+  float zs[NBV ? 1 : G];
+  if (NBV) {
+    const float4* __restrict__ nb4 = reinterpret_cast<const float4*>(nb);
+#pragma unroll
+    for (int s = 0; s < G; ++s) {
+      const int sl = s < k ? s : k - 1;
+      zn[NBV ? s : 0] = lane < d4 ? nb4[sl * d4 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < G; ++s) {
+      const int sl = s < k ? s : k - 1;
+      zs[NBV ? 0 : s] = lane < d ? nb[sl * d + lane] : 0.f;
+    }
+  }
+  // folded query columns of this lane
+  float4 qe[H], qn4[H];
+  float qn[H], qt0[H], qt1[H];
+  const bool t0_on = lane < T, t1_on = lane + kWave < T;
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    const float* qh = q + h * a.Cs;
+    qe[h] = e_on ? make_float4(qh[d + 4 * lane], qh[d + 4 * lane + 1], qh[d + 4 * lane + 2], qh[d + 4 * lane + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (NBV) qn4[h] = lane < d4 ? make_float4(qh[4 * lane], qh[4 * lane + 1], qh[4 * lane + 2], qh[4 * lane + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    else qn[h] = lane < d ? qh[lane] : 0.f;
+    qt0[h] = t0_on ? qh[d + D + lane] : 0.f;
+    qt1[h] = t1_on ? qh[d + D + lane + kWave] : 0.f;
+  }
+  const float w0 = t0_on ? a.tw[lane] : 0.f, b0 = t0_on ? a.tb[lane] : 0.f;
+  const float w1 = t1_on ? a.tw[lane + kWave] : 0.f, b1 = t1_on ? a.tb[lane + kWave] : 0.f;
+
+  // ---- Time2Vec columns + partial scores ----
+  float tz0[G], tz1[G], P[64];
+#pragma unroll
+  for (int j = 0; j < 64; ++j) P[j] = 0.f;
+#pragma unroll
+  for (int s = 0; s < G; ++s) {
+    const float dt = __shfl(my_dt, s);  // compile-time lane: v_readlane
+    tz0[s] = t0_on ? cos_t2v(__fmaf_rn(dt, w0, b0)) : 0.f;
+    tz1[s] = t1_on ? cos_t2v(__fmaf_rn(dt, w1, b1)) : 0.f;
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      float p = qe[h].x * ze[s].x;
+      p = __fmaf_rn(qe[h].y, ze[s].y, p);
+      p = __fmaf_rn(qe[h].z, ze[s].z, p);
+      p = __fmaf_rn(qe[h].w, ze[s].w, p);
+      if (NBV) {
+        p = __fmaf_rn(qn4[h].x, zn[NBV ? s : 0].x, p);
+        p = __fmaf_rn(qn4[h].y, zn[NBV ? s : 0].y, p);
+        p = __fmaf_rn(qn4[h].z, zn[NBV ? s : 0].z, p);
+        p = __fmaf_rn(qn4[h].w, zn[NBV ? s : 0].w, p);
+      } else {
+        p = __fmaf_rn(qn[h], zs[NBV ? 0 : s], p);
+      }
+      p = __fmaf_rn(qt0[h], tz0[s], p);
+      p = __fmaf_rn(qt1[h], tz1[s], p);
+      P[s * H + h] = p;
+    }
+  }
+  float sc = reduce_scatter64(P, lane);  // lane j = s*H + h holds score(s, h)
+
+  // ---- masked softmax over the slots of each head: lanes j, j +- H, ... share a head ----
+  const int js = lane / H;
+  const bool live = js < k;
+  const bool ok = __shfl(my_ok ? 1 : 0, js < k ? js : 0) != 0;
+  sc = live ? (ok ? sc * a.scale : -1e10f) : -__builtin_inff();
+  float mx = sc;
+#pragma unroll
+  for (int o = H; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  float ev = live ? expf(sc - mx) : 0.f;
+  float sum = ev;
+#pragma unroll
+  for (int o = H; o < 64; o <<= 1) sum += __shfl_xor(sum, o);
+  const float A = ev / sum;
+
+  // ---- zbar[h] = sum_s A[h][s] z[s], from registers ----
+  float* __restrict__ zb = a.zbar + r * (long long)H * a.Cs;
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    float4 ae = make_float4(0.f, 0.f, 0.f, 0.f), an4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float an = 0.f, at0 = 0.f, at1 = 0.f;
+#pragma unroll
+    for (int s = 0; s < G; ++s) {
+      const float w = __shfl(A, s * H + h);  // 0 for s >= k
+      ae.x = __fmaf_rn(w, ze[s].x, ae.x); ae.y = __fmaf_rn(w, ze[s].y, ae.y);
+      ae.z = __fmaf_rn(w, ze[s].z, ae.z); ae.w = __fmaf_rn(w, ze[s].w, ae.w);
+      if (NBV) {
+        an4.x = __fmaf_rn(w, zn[NBV ? s : 0].x, an4.x); an4.y = __fmaf_rn(w, zn[NBV ? s : 0].y, an4.y);
+        an4.z = __fmaf_rn(w, zn[NBV ? s : 0].z, an4.z); an4.w = __fmaf_rn(w, zn[NBV ? s : 0].w, an4.w);
+      } else {
+        an = __fmaf_rn(w, zs[NBV ? 0 : s], an);
+      }
+      at0 = __fmaf_rn(w, tz0[s], at0);
+      at1 = __fmaf_rn(w, tz1[s], at1);
+    }
+    float* zh = zb + h * a.Cs;
+    if (NBV) {
+      if (lane < d4) { zh[4 * lane] = an4.x; zh[4 * lane + 1] = an4.y; zh[4 * lane + 2] = an4.z; zh[4 * lane + 3] = an4.w; }
+    } else if (lane < d) {
+      zh[lane] = an;
+    }
+    if (e_on) { zh[d + 4 * lane] = ae.x; zh[d + 4 * lane + 1] = ae.y; zh[d + 4 * lane + 2] = ae.z; zh[d + 4 * lane + 3] = ae.w; }
+    if (t0_on) zh[d + D + lane] = at0;
+    if (t1_on) zh[d + D + lane + kWave] = at1;
+  }
+}
+
 template <int H, int G>
 static void launch_attn(dim3 grid, dim3 block, size_t lds, hipStream_t st, const AttnArgs& a) {
   if constexpr (G * H <= 64) hipLaunchKernelGGL((tgat_attn_reduce_kernel<H, G>), grid, block, lds, st, a);
+}
+
+// register-resident fast path; returns false when the shape does not qualify
+template <int H>
+static bool launch_attn_reg(hipStream_t st, const AttnArgs& a) {
+  const bool edge_ok = a.D > 0 && a.D % 4 == 0 && a.D / 4 <= 64 && ((uintptr_t)a.ex & 15) == 0;
+  const bool nbv = a.d % 4 == 0 && a.d / 4 <= 64 && ((uintptr_t)a.nbrf & 15) == 0;
+  if (!edge_ok || a.tfeat || a.T > 128 || !(nbv || a.d <= 64)) return false;
+  const dim3 grid((unsigned)((a.R + 3) / 4)), block(256);
+#define TGMX_REG(G_)                                                                                        \
+  if constexpr (G_ * H <= 64) {                                                                             \
+    if (a.k <= G_) {                                                                                        \
+      if (nbv) hipLaunchKernelGGL((tgat_attn_reduce_reg_kernel<H, G_, true>), grid, block, 0, st, a);       \
+      else hipLaunchKernelGGL((tgat_attn_reduce_reg_kernel<H, G_, false>), grid, block, 0, st, a);          \
+      return true;                                                                                          \
+    }                                                                                                       \
+  }
+  TGMX_REG(10)
+  TGMX_REG(20)
+#undef TGMX_REG
+  return false;
 }
 
 }  // namespace tgmx
@@ -414,25 +582,32 @@ extern "C" int tgmx_gather_rows(const float* table, int64_t num_rows, int32_t di
 }
 
 extern "C" int tgmx_tgat_rres(const float* x, int64_t ldx, int32_t d, const float* tb, const float* time_feat, int32_t T,
-                              int32_t O, int64_t R, float* out, tgmx_stream_t stream) {
+                              int32_t O, int64_t R, float* out, int64_t ldo, tgmx_stream_t stream) {
   TGMX_REQUIRE(d > 0 && T > 0 && O >= d + T && R >= 0 && ldx >= d, "tgat_rres: bad sizes d=%d T=%d O=%d", d, T, O);
   if (R == 0) return TGMX_OK;
   TGMX_REQUIRE(x && (tb || time_feat) && out, "tgat_rres: null pointer");
-  long long blocks = (R * O + 255) / 256;
+  if (ldo == 0) ldo = O;
+  TGMX_REQUIRE(ldo >= O, "tgat_rres: ldo < O");
+  long long blocks = (R * ldo + 255) / 256;
   if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(tgat_rres_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (long long)ldx, d, tb, time_feat,
-                     T, O, (long long)R, out);
+                     T, O, (long long)R, out, (long long)ldo);
   TGMX_CHECK_LAUNCH("tgat_rres");
   return TGMX_OK;
 }
 
-extern "C" int tgmx_ln_residual_concat(const float* y, const float* res, const float* gamma, const float* beta, int32_t O,
-                                       float eps, const float* z0, int32_t d0, int64_t R, float* out, tgmx_stream_t stream) {
+extern "C" int tgmx_ln_residual_concat(const float* y, int64_t ldy, const float* res, int64_t ldr, const float* gamma,
+                                       const float* beta, int32_t O, float eps, const float* z0, int32_t d0, int64_t R, float* out,
+                                       int64_t ldo, tgmx_stream_t stream) {
   TGMX_REQUIRE(O > 0 && d0 >= 0 && R >= 0, "ln_residual_concat: bad sizes");
   if (R == 0) return TGMX_OK;
   TGMX_REQUIRE(y && res && gamma && beta && out && (d0 == 0 || z0), "ln_residual_concat: null pointer");
+  if (ldy == 0) ldy = O;
+  if (ldr == 0) ldr = O;
+  if (ldo == 0) ldo = O + d0;
+  TGMX_REQUIRE(ldy >= O && ldr >= O && ldo >= O + d0, "ln_residual_concat: leading dimension too small");
   hipLaunchKernelGGL(ln_residual_concat_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, y, res, gamma,
-                     beta, O, eps, z0, d0, (long long)R, out);
+                     beta, O, eps, z0, d0, (long long)R, out, (long long)ldy, (long long)ldr, (long long)ldo);
   TGMX_CHECK_LAUNCH("ln_residual_concat");
   return TGMX_OK;
 }
@@ -440,14 +615,16 @@ extern "C" int tgmx_ln_residual_concat(const float* y, const float* res, const f
 extern "C" int tgmx_tgat_attn_reduce(const float* qf, const float* nbrf, int32_t d, const float* ex, int32_t D,
                                      const int64_t* seed_t, const int64_t* nbr_t, const int32_t* nbr_id, const float* tw,
                                      const float* tb, const float* nbr_time_feat, const uint8_t* mask, int32_t T, int32_t H,
-                                     int32_t k, int64_t R, float scale, float* zbar, tgmx_stream_t stream) {
+                                     int32_t k, int64_t R, float scale, int32_t head_stride, float* zbar, tgmx_stream_t stream) {
   TGMX_REQUIRE(d > 0 && D >= 0 && T > 0 && k > 0 && R >= 0, "tgat_attn_reduce: bad sizes d=%d D=%d T=%d k=%d", d, D, T, k);
   TGMX_REQUIRE(H == 1 || H == 2 || H == 4 || H == 8, "tgat_attn_reduce: n_heads=%d unsupported (1, 2, 4 or 8)", H);
   if (R == 0) return TGMX_OK;
   TGMX_REQUIRE(qf && nbrf && (D == 0 || ex) && zbar, "tgat_attn_reduce: null pointer");
   TGMX_REQUIRE(nbr_time_feat || (seed_t && nbr_t && tw && tb), "tgat_attn_reduce: need times + Time2Vec params or nbr_time_feat");
   TGMX_REQUIRE(mask || nbr_id, "tgat_attn_reduce: need nbr_id or mask");
-  AttnArgs a{qf, nbrf, ex, seed_t, nbr_t, nbr_id, tw, tb, nbr_time_feat, mask, zbar, R, d, D, T, k, d + D + T, scale};
+  TGMX_REQUIRE(head_stride == 0 || head_stride >= d + D + T, "tgat_attn_reduce: head_stride smaller than d + D + T");
+  AttnArgs a{qf, nbrf, ex, seed_t, nbr_t, nbr_id, tw, tb, nbr_time_feat, mask, zbar, R, d, D, T, k, d + D + T, scale,
+             head_stride ? head_stride : d + D + T};
   const size_t per_wave = ((size_t)k * T + (size_t)k * (H + 2)) * sizeof(float);
   int waves = 4;
   while (waves > 1 && per_wave * waves > 64 * 1024) waves >>= 1;
@@ -455,6 +632,10 @@ extern "C" int tgmx_tgat_attn_reduce(const float* qf, const float* nbrf, int32_t
   const dim3 grid((unsigned)((R + waves - 1) / waves)), block(waves * kWave);
   const size_t lds = per_wave * waves;
   hipStream_t st = (hipStream_t)stream;
+  if ((H == 1 && launch_attn_reg<1>(st, a)) || (H == 2 && launch_attn_reg<2>(st, a))) {
+    TGMX_CHECK_LAUNCH("tgat_attn_reduce(reg)");
+    return TGMX_OK;
+  }
   // slots per score group: the smallest instantiated G >= min(k, 64 / H)
   const int want = k < 64 / H ? k : 64 / H;
 #define TGMX_ATTN(H_, G_) launch_attn<H_, G_>(grid, block, lds, st, a)
@@ -493,5 +674,123 @@ extern "C" int tgmx_time2vec(const void* x, int32_t x_is_int64, const float* w, 
     hipLaunchKernelGGL(time2vec_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float*)x, w, b, T,
                        (long long)n, out);
   TGMX_CHECK_LAUNCH("time2vec");
+  return TGMX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Whole TGAT forward as ONE host call (tgm/nn/encoder/tgat.py:95-149): leaf gathers, then per
+// layer the row-batched sequence rres -> Q -> folded query -> per-level attention -> W_V fold ->
+// W_O -> LayerNorm+concat -> merge MLP.  ~25 launches enqueued back to back from C++: the Python
+// side only fills two small structs.  Workspace layout is private to this function.
+// ---------------------------------------------------------------------------
+static inline size_t align_up(size_t x) { return (x + 63) & ~(size_t)63; }
+static inline int pad4(int x) { return (x + 3) & ~3; }
+
+// Internal activation layouts are padded so that every GEMM operand row starts 16-byte aligned
+// (vector operand loads): O -> Op, per-head dh -> dhp, C -> Cp, O + d0 -> Kc.  The caller passes
+// weight copies padded the same way (tgmx_tgat_layer_t).
+extern "C" size_t tgmx_tgat_workspace_bytes(const tgmx_tgat_model_t* m, int64_t S0, const tgmx_tgat_hop_t* hops) {
+  if (!m || !hops || m->num_layers <= 0) return 0;
+  const int L = m->num_layers;
+  long long rows[TGMX_TGAT_MAX_LAYERS + 1], off[TGMX_TGAT_MAX_LAYERS + 2];
+  rows[0] = S0;
+  for (int i = 0; i < L; ++i) rows[i + 1] = rows[i] * hops[i].k;
+  off[0] = 0;
+  for (int i = 0; i <= L; ++i) off[i + 1] = off[i] + rows[i];
+  size_t floats = align_up((size_t)off[L + 1] * m->d0);  // z0
+  size_t per_layer_max = 0, emb_rows = 0;
+  for (int j = 1; j <= L; ++j) {
+    const tgmx_tgat_layer_t& ly = m->layers[j - 1];
+    const size_t R = (size_t)off[L - j + 1];
+    const size_t Op = pad4(ly.O), dhp = pad4(ly.O / ly.H), Cp = pad4(ly.d + ly.D + ly.T), Kc = pad4(ly.O + m->d0);
+    const size_t need = align_up(R * Op) * 3 + align_up(R * ly.H * dhp) + align_up(R * ly.H * Cp) * 2 + align_up(R * Kc) + align_up(R * pad4(ly.emb));
+    per_layer_max = need > per_layer_max ? need : per_layer_max;
+    const size_t e = R * (size_t)pad4(ly.emb_out);
+    emb_rows = e > emb_rows ? e : emb_rows;
+  }
+  floats += per_layer_max + 2 * align_up(emb_rows);
+  return floats * sizeof(float) + 256;
+}
+
+extern "C" int tgmx_tgat_forward(const tgmx_tgat_model_t* m, const float* node_x, int64_t num_nodes, const int32_t* seed_ids,
+                                 int64_t S0, const tgmx_tgat_hop_t* hops, float* workspace, size_t workspace_bytes, float* out,
+                                 tgmx_stream_t stream) {
+  TGMX_REQUIRE(m && hops && node_x && seed_ids && out, "tgat_forward: null pointer");
+  const int L = m->num_layers;
+  TGMX_REQUIRE(L >= 1 && L <= TGMX_TGAT_MAX_LAYERS, "tgat_forward: num_layers=%d outside [1, %d]", L, TGMX_TGAT_MAX_LAYERS);
+  if (S0 == 0) return TGMX_OK;
+  TGMX_REQUIRE(workspace && workspace_bytes >= tgmx_tgat_workspace_bytes(m, S0, hops), "tgat_forward: workspace too small");
+  const int d0 = m->d0;
+  long long rows[TGMX_TGAT_MAX_LAYERS + 1], off[TGMX_TGAT_MAX_LAYERS + 2];
+  rows[0] = S0;
+  for (int i = 0; i < L; ++i) rows[i + 1] = rows[i] * hops[i].k;
+  off[0] = 0;
+  for (int i = 0; i <= L; ++i) off[i + 1] = off[i] + rows[i];
+
+  float* w = reinterpret_cast<float*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  auto take = [&](size_t n) { float* p = w; w += align_up(n); return p; };
+  float* z0 = take((size_t)off[L + 1] * d0);
+  size_t emb_rows = 0;  // ping-pong buffers for the layer outputs
+  for (int j = 1; j <= L; ++j) {
+    const size_t e = (size_t)off[L - j + 1] * pad4(m->layers[j - 1].emb_out);
+    emb_rows = e > emb_rows ? e : emb_rows;
+  }
+  float* pp[2] = {take(emb_rows), take(emb_rows)};
+  float* scratch0 = w;
+
+  int rc;
+  // leaves: z0[level i] = node_x[V_i], V_0 = seeds, V_i = hop (i-1) neighbor ids (pad -1 -> last row)
+  rc = tgmx_gather_rows(node_x, num_nodes, d0, seed_ids, rows[0], z0, d0, stream);
+  if (rc) return rc;
+  for (int i = 1; i <= L; ++i) {
+    rc = tgmx_gather_rows(node_x, num_nodes, d0, hops[i - 1].nbr_id, rows[i], z0 + off[i] * d0, d0, stream);
+    if (rc) return rc;
+  }
+
+  const float* prev = z0;
+  long long ld_prev = d0;
+  for (int j = 1; j <= L; ++j) {
+    const tgmx_tgat_layer_t& ly = m->layers[j - 1];
+    const int n_lvl = L - j + 1;
+    const long long R = off[n_lvl];
+    const int O = ly.O, H = ly.H, dh = O / H, C = ly.d + ly.D + ly.T, k = hops[j - 1].k;
+    const int Op = pad4(O), dhp = pad4(dh), Cp = pad4(C), Kc = pad4(O + d0), Ep = pad4(ly.emb);
+    TGMX_REQUIRE(ly.d == (j == 1 ? d0 : m->layers[j - 2].emb_out), "tgat_forward: layer %d input width mismatch", j);
+    w = scratch0;
+    float* rres = take((size_t)R * Op);
+    float* oattn = take((size_t)R * Op);
+    float* y = take((size_t)R * Op);
+    float* Q = take((size_t)R * H * dhp);
+    float* qf = take((size_t)R * H * Cp);
+    float* zbar = take((size_t)R * H * Cp);
+    float* cat = take((size_t)R * Kc);
+    float* h1 = take((size_t)R * Ep);
+    const bool last = j == L;
+    float* nxt = last ? out : pp[j & 1];
+    const long long ld_nxt = ly.emb_out;  // layer outputs stay densely packed: they are the next layer's neighbor features
+    if ((rc = tgmx_tgat_rres(prev, ld_prev, ly.d, m->tb, nullptr, ly.T, O, R, rres, Op, stream))) return rc;
+    // Q[:, head h] = rres @ W_Q[head h rows]^T     (heads written dhp apart)
+    if ((rc = tgmx_sgemm_nt(rres, Op, ly.W_Q, Op, Q, (long long)H * dhp, R, dh, O, nullptr, 0, H, 0, (long long)dh * Op, dhp, stream))) return rc;
+    // qf[:, h, :] = Q[:, head h] @ W_K[head h]  via the transposed padded copy W_K_t [C, H*dhp]
+    if ((rc = tgmx_sgemm_nt(Q, (long long)H * dhp, ly.W_K_t, (long long)H * dhp, qf, (long long)H * Cp, R, C, dh, nullptr, 0, H, dhp, dhp, Cp, stream)))
+      return rc;
+    for (int i = 0; i < n_lvl; ++i) {
+      if (rows[i] == 0) continue;
+      TGMX_REQUIRE(hops[i].k == k, "tgat_forward: layer %d needs the same k at every hop it aggregates", j);
+      const float* nbrf = prev + off[i + 1] * ld_prev;
+      if ((rc = tgmx_tgat_attn_reduce(qf + off[i] * (long long)H * Cp, nbrf, ly.d, hops[i].edge_x, ly.D, hops[i].seed_t, hops[i].nbr_t,
+                                      hops[i].nbr_id, m->tw, m->tb, nullptr, nullptr, ly.T, H, k, rows[i], 1.0f / sqrtf((float)dh), Cp,
+                                      zbar + off[i] * (long long)H * Cp, stream)))
+        return rc;
+    }
+    // Oattn[:, head h] = zbar[:, h, :] @ W_V[head h]^T   (W_V padded copy [O, Cp])
+    if ((rc = tgmx_sgemm_nt(zbar, (long long)H * Cp, ly.W_V, Cp, oattn, Op, R, dh, C, nullptr, 0, H, Cp, (long long)dh * Cp, dh, stream))) return rc;
+    if ((rc = tgmx_sgemm_nt(oattn, Op, ly.W_O, Op, y, Op, R, O, O, ly.b_O, 0, 1, 0, 0, 0, stream))) return rc;
+    if ((rc = tgmx_ln_residual_concat(y, Op, rres, Op, ly.ln_g, ly.ln_b, O, ly.ln_eps, z0, d0, R, cat, Kc, stream))) return rc;
+    if ((rc = tgmx_sgemm_nt(cat, Kc, ly.fc1_w, Kc, h1, Ep, R, ly.emb, O + d0, ly.fc1_b, 1, 1, 0, 0, 0, stream))) return rc;
+    if ((rc = tgmx_sgemm_nt(h1, Ep, ly.fc2_w, Ep, nxt, ld_nxt, R, ly.emb_out, ly.emb, ly.fc2_b, 0, 1, 0, 0, 0, stream))) return rc;
+    prev = nxt;
+    ld_prev = ld_nxt;
+  }
   return TGMX_OK;
 }

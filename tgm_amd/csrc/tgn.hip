@@ -88,7 +88,7 @@ __device__ __forceinline__ void tgn_message_cols(const AggrArgs& a, int lane, co
     if (c < M) v = mem_v[c];
     else if (c < 2 * M) v = mem_o[c - M];
     else if (c < 2 * M + D) v = raw[c - 2 * M];
-    else v = cosf(__fmaf_rn(dt, a.tw[c - 2 * M - D], a.tb[c - 2 * M - D]));
+    else v = cos_t2v(__fmaf_rn(dt, a.tw[c - 2 * M - D], a.tb[c - 2 * M - D]));
     out[c] = accumulate ? out[c] + v * scale : v * scale;
   }
 }
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void tconv_edge_attr_kernel(const int64_t* __r
     const long long e = x / W;
     const int c = (int)(x - e * W);
     float v;
-    if (c < T) v = cosf(__fmaf_rn((float)(lu_local[src[e]] - t[e]), tw[c], tb[c]));
+    if (c < T) v = cos_t2v(__fmaf_rn((float)(lu_local[src[e]] - t[e]), tw[c], tb[c]));
     else v = msg[e * D + (c - T)];
     out[x] = v;
   }

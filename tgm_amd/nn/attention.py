@@ -81,7 +81,7 @@ class TemporalAttention(nn.Module):
         _native.check(
             lib.tgmx_tgat_attn_reduce(
                 qf.data_ptr(), nbrf.data_ptr(), d, _native.ptr(ex), D, _native.ptr(seed_t), _native.ptr(nbr_t), _native.ptr(nbr_id),
-                _native.ptr(tw), _native.ptr(tb), _native.ptr(nbr_time_feat), _native.ptr(mask), T, H, k, R, float(dh) ** -0.5,
+                _native.ptr(tw), _native.ptr(tb), _native.ptr(nbr_time_feat), _native.ptr(mask), T, H, k, R, float(dh) ** -0.5, 0,
                 zbar.data_ptr(), stream,
             ),
             'tgmx_tgat_attn_reduce',
@@ -96,8 +96,8 @@ class TemporalAttention(nn.Module):
         out = torch.empty((R, O + d0), **f32)
         ln = self.layer_norm
         _native.check(
-            lib.tgmx_ln_residual_concat(y.data_ptr(), rres.data_ptr(), ln.weight.detach().data_ptr(), ln.bias.detach().data_ptr(), O,
-                                        float(ln.eps), _native.ptr(z0), d0, R, out.data_ptr(), stream),
+            lib.tgmx_ln_residual_concat(y.data_ptr(), 0, rres.data_ptr(), 0, ln.weight.detach().data_ptr(), ln.bias.detach().data_ptr(), O,
+                                        float(ln.eps), _native.ptr(z0), d0, R, out.data_ptr(), 0, stream),
             'tgmx_ln_residual_concat',
         )  # fmt: skip
         return out
@@ -112,7 +112,7 @@ class TemporalAttention(nn.Module):
         T, O = self.time_dim, self.out_dim
         rres = torch.empty((R, O), dtype=torch.float32, device=node_x.device)
         tf = _ops._f32c(time_feat, 'time_feat')
-        _native.check(lib.tgmx_tgat_rres(node_x.data_ptr(), node_x.stride(0), self.node_dim, 0, tf.data_ptr(), T, O, R, rres.data_ptr(), _native.stream_ptr()), 'tgmx_tgat_rres')
+        _native.check(lib.tgmx_tgat_rres(node_x.data_ptr(), node_x.stride(0), self.node_dim, 0, tf.data_ptr(), T, O, R, rres.data_ptr(), 0, _native.stream_ptr()), 'tgmx_tgat_rres')
         mask = valid_nbr_mask.to(torch.uint8).contiguous()
         return self.attend(
             rres, _ops._f32c(nbr_node_feat, 'nbr_node_feat'), _ops._f32c(edge_feat, 'edge_feat'), k,

@@ -58,81 +58,94 @@ class TGAT(nn.Module):
                                                time_dim=time_dim, dropout=dropout))  # fmt: skip
             self.merge_layers.append(MergeLayer(in_dim1=self.attn[-1].out_dim, in_dim2=node_dim, hidden_dim=embed_dim, output_dim=embed_dim))
 
+    # ------------------------------------------------------------------
+    def _model_desc(self):
+        """ctypes description of the parameters for ``tgmx_tgat_forward`` -- rebuilt only when a
+        parameter was reallocated or modified in place (optimizer step, load_state_dict)."""
+        key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        cached = getattr(self, '_desc_cache', None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        if self.num_layers > _native.TGAT_MAX_LAYERS:
+            raise NotImplementedError(f'tgm_amd TGAT supports up to {_native.TGAT_MAX_LAYERS} layers')
+        m = _native.TgatModel()
+        keep = []  # tensors the struct points into
+
+        def ptr(t: Tensor) -> int:
+            t = t.detach()
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                t = t.float().contiguous()
+            keep.append(t)
+            return t.data_ptr()
+
+        def padded(t: Tensor, cols: int) -> int:
+            """zero-padded copy [rows, cols] so that every row starts 16-byte aligned"""
+            t = t.detach().float()
+            out = torch.zeros((t.shape[0], cols), dtype=torch.float32, device=t.device)
+            out[:, : t.shape[1]] = t
+            keep.append(out)
+            return out.data_ptr()
+
+        p4 = lambda x: (x + 3) // 4 * 4
+        m.tw, m.tb = ptr(self.time_encoder.w.weight.reshape(-1)), ptr(self.time_encoder.w.bias)
+        m.num_layers, m.d0 = self.num_layers, self.node_dim
+        for l, (attn, merge) in enumerate(zip(self.attn, self.merge_layers)):
+            ly = m.layers[l]
+            O, H, dh = attn.out_dim, attn.n_heads, attn.head_dim
+            C = attn.node_dim + attn.edge_dim + attn.time_dim
+            WKV = attn.W_KV.weight.detach().float()
+            wkt = torch.zeros((C, H * p4(dh)), dtype=torch.float32, device=WKV.device)  # W_K^T, heads p4(dh) apart
+            for h in range(H):
+                wkt[:, h * p4(dh) : h * p4(dh) + dh] = WKV[h * dh : (h + 1) * dh].t()
+            keep.append(wkt)
+            ly.W_Q, ly.W_K_t, ly.W_V = padded(attn.W_Q.weight, p4(O)), wkt.data_ptr(), padded(WKV[O:], p4(C))
+            ly.W_O, ly.b_O = padded(attn.W_O.weight, p4(O)), ptr(attn.W_O.bias)
+            ly.ln_g, ly.ln_b, ly.ln_eps = ptr(attn.layer_norm.weight), ptr(attn.layer_norm.bias), float(attn.layer_norm.eps)
+            ly.fc1_w, ly.fc1_b = padded(merge.fc1.weight, p4(O + self.node_dim)), ptr(merge.fc1.bias)
+            ly.fc2_w, ly.fc2_b = padded(merge.fc2.weight, p4(merge.fc1.out_features)), ptr(merge.fc2.bias)
+            ly.d, ly.D, ly.T, ly.O, ly.H = attn.node_dim, attn.edge_dim, attn.time_dim, O, H
+            ly.emb, ly.emb_out = merge.fc1.out_features, merge.fc2.out_features
+        self._desc_cache = (key, (m, keep))
+        return m, keep
+
     def forward(self, node_x: Tensor, seed_nids: List[Tensor], seed_times: List[Tensor], nbr_nids: List[Tensor],
                 nbr_edge_x: List[Tensor], nbr_edge_time: List[Tensor]) -> Tensor:  # fmt: skip
         """Same arguments as the reference (tgat.py:95-103): the sampler's per-hop lists.
-        Returns the seeds' embeddings [len(seed_nids[0]), embed_dim]."""
+        Returns the seeds' embeddings [len(seed_nids[0]), embed_dim].  One native call enqueues the
+        whole forward (``tgmx_tgat_forward``)."""
         L = self.num_layers
-        for m in self.attn:
-            m._check_mode()
+        for m_ in self.attn:
+            m_._check_mode()
         lib = _native.load()
         node_x = _ops._f32c(node_x, 'node_x')
+        if node_x.shape[1] != self.node_dim:
+            raise ValueError(f'node_x has {node_x.shape[1]} features, the model was built for {self.node_dim}')
         dev = node_x.device
-        d0 = node_x.shape[1]
-        f32 = dict(dtype=torch.float32, device=dev)
-        stream = _native.stream_ptr()
-        tw = self.time_encoder.w.weight.detach().reshape(-1)
-        tb = self.time_encoder.w.bias.detach()
-
-        # level i of the hop tree: V_0 = seeds, V_i = hop-(i-1) neighbors flattened (pads included)
-        ids = [seed_nids[0].contiguous()] + [nbr_nids[i].reshape(-1) for i in range(L)]
-        sizes = [int(v.numel()) for v in ids]
-        offs = [0]
-        for n in sizes:
-            offs.append(offs[-1] + n)
-        # leaves z0 for every level, one buffer: z0[offs[i]:offs[i+1]] = node_x[V_i] (pad -1 -> last row)
-        z0 = torch.empty((offs[-1], d0), **f32)
-        for i in range(L + 1):
-            if sizes[i]:
-                _ops.gather_rows(node_x, ids[i], out=z0[offs[i] : offs[i + 1]])
-
-        prev = z0  # z^{j-1} for levels 0 .. L-j+1, rows laid out by `offs`
-        for j in range(1, L + 1):
-            attn, merge = self.attn[j - 1], self.merge_layers[j - 1]
-            n_lvl = L - j + 1  # levels 0 .. L-j get a new embedding
-            Rtot = offs[n_lvl]
-            O, T, d = attn.out_dim, attn.time_dim, attn.node_dim
-            k = nbr_nids[j - 1].shape[-1]
-            rres = torch.empty((Rtot, O), **f32)
-            _native.check(lib.tgmx_tgat_rres(prev.data_ptr(), prev.stride(0), d, tb.data_ptr(), 0, T, O, Rtot, rres.data_ptr(), stream), 'tgmx_tgat_rres')
-            # per level the inputs live in different sampler tensors; everything dense runs once over Rtot rows
-            H, dh, C = attn.n_heads, attn.head_dim, d + attn.edge_dim + T
-            WKV = attn.W_KV.weight.detach()
-            Q = torch.empty((Rtot, O), **f32)
-            _ops.sgemm_nt(rres, attn.W_Q.weight.detach(), Q)
-            qf = torch.empty((Rtot, H, C), **f32)
-            _ops.sgemm_nt(Q, WKV[:O].t().contiguous(), qf, M=Rtot, N=C, K=dh, batch=H, sA=dh, sB=dh, sC=C)
-            zbar = torch.empty((Rtot, H, C), **f32)
-            for i in range(n_lvl):
-                Ri = sizes[i]
-                if not Ri:
-                    continue
-                if nbr_nids[i].shape[-1] != k:
-                    raise ValueError('TGAT needs the same number of neighbors at every hop used by one layer')
-                nbrf = prev[offs[i + 1] : offs[i + 1] + Ri * k]  # z^{j-1}_{i+1} viewed [Ri, k, d]
-                ex = nbr_edge_x[i]
-                ex = ex if ex.is_contiguous() else ex.contiguous()
-                _native.check(
-                    lib.tgmx_tgat_attn_reduce(
-                        qf[offs[i]].data_ptr(), nbrf.data_ptr(), d, _native.ptr(ex), attn.edge_dim,
-                        seed_times[i].contiguous().data_ptr(), nbr_edge_time[i].contiguous().data_ptr(),
-                        nbr_nids[i].contiguous().data_ptr(), tw.data_ptr(), tb.data_ptr(), 0, 0, T, H, k, Ri, float(dh) ** -0.5,
-                        zbar[offs[i]].data_ptr(), stream,
-                    ),
-                    'tgmx_tgat_attn_reduce',
-                )  # fmt: skip
-            oattn = torch.empty((Rtot, O), **f32)
-            _ops.sgemm_nt(zbar.view(Rtot, H * C), WKV[O:], oattn, M=Rtot, N=dh, K=C, batch=H, sA=C, sB=dh * C, sC=dh)
-            y = torch.empty((Rtot, O), **f32)
-            _ops.sgemm_nt(oattn, attn.W_O.weight.detach(), y, bias=attn.W_O.bias.detach())
-            cat = torch.empty((Rtot, O + d0), **f32)
-            ln = attn.layer_norm
-            _native.check(
-                lib.tgmx_ln_residual_concat(y.data_ptr(), rres.data_ptr(), ln.weight.detach().data_ptr(), ln.bias.detach().data_ptr(), O,
-                                            float(ln.eps), z0.data_ptr(), d0, Rtot, cat.data_ptr(), stream),
-                'tgmx_ln_residual_concat',
-            )  # fmt: skip
-            nxt = torch.empty((Rtot, self.embed_dim), **f32)
-            merge.forward_cat(cat, nxt)
-            prev = nxt
-        return prev[: sizes[0]]
+        model, _keep = self._model_desc()
+        hops = (_native.TgatHop * L)()
+        hold = []
+        c = lambda t: t if t.is_contiguous() else t.contiguous()
+        seeds = c(seed_nids[0])
+        S0 = seeds.numel()
+        rows = S0
+        for i in range(L):
+            nid, nt, ex, st = c(nbr_nids[i]), c(nbr_edge_time[i]), c(nbr_edge_x[i]), c(seed_times[i])
+            if nid.shape[0] != rows or st.numel() != rows:
+                raise ValueError(f'hop {i}: expected {rows} rows, got nbr_nids {tuple(nid.shape)} / seed_times {tuple(st.shape)}')
+            hold += [nid, nt, ex, st]
+            h = hops[i]
+            h.seed_t, h.nbr_id, h.nbr_t, h.edge_x, h.k = st.data_ptr(), nid.data_ptr(), nt.data_ptr(), _native.ptr(ex), nid.shape[-1]
+            rows *= nid.shape[-1]
+        out = torch.empty((S0, self.embed_dim), dtype=torch.float32, device=dev)
+        if S0 == 0:
+            return out
+        need = lib.tgmx_tgat_workspace_bytes(model, S0, hops)
+        ws = getattr(self, '_workspace', None)
+        if ws is None or ws.device != dev or ws.numel() < need:
+            ws = self._workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+        _native.check(
+            lib.tgmx_tgat_forward(model, node_x.data_ptr(), node_x.shape[0], seeds.data_ptr(), S0, hops, ws.data_ptr(), ws.numel(),
+                                  out.data_ptr(), _native.stream_ptr()),
+            'tgmx_tgat_forward',
+        )  # fmt: skip
+        return out
