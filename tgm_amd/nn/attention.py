@@ -75,7 +75,6 @@ class TemporalAttention(nn.Module):
         # qf[r, h, :] = Q[r, head h] @ W_K[head h, :]      (one batched launch over heads)
         qf = torch.empty((R, H, C), **f32)
         _ops.sgemm_nt(Q, WK_t, qf, M=R, N=C, K=dh, batch=H, sA=dh, sB=dh, sC=C)
-        qf2 = qf.view(R, H * C)
         zbar = torch.empty((R, H, C), **f32)
         stream = _native.stream_ptr()
         _native.check(
@@ -86,7 +85,6 @@ class TemporalAttention(nn.Module):
             ),
             'tgmx_tgat_attn_reduce',
         )  # fmt: skip
-        del qf2
         # Oattn[:, head h] = zbar[:, h, :] @ W_V[head h, :].T
         oattn = torch.empty((R, O), **f32)
         _ops.sgemm_nt(zbar.view(R, H * C), WV, oattn, M=R, N=dh, K=C, batch=H, sA=C, sB=dh * C, sC=dh)
