@@ -264,6 +264,26 @@ int tgmx_tconv_attend(const float* q, const float* k, const float* v, const floa
                       const int64_t* seg_hi, int64_t U, int32_t H, int32_t C, float scale, float* out,
                       tgmx_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * Discrete-time path (tgm/nn/encoder/tgcn.py): GCNConv normalisation + TGCN gates.
+ * ------------------------------------------------------------------------ */
+
+/* A[N, ld] (dense) = D^-1/2 (A + I) D^-1/2 with A[dst, src] = sum of the weights of edges src -> dst
+ * (weight NULL = 1), self loops added where missing with weight `fill` (1, or 2 for improved=True),
+ * degrees taken at the target: torch_geometric's gcn_norm (third-party to the reference).
+ * workspace: 2 * N floats. */
+int tgmx_gcn_norm_dense(const int64_t* src, const int64_t* dst, const float* weight, int64_t E,
+                        int64_t N, float fill, int32_t add_self_loops, float* A, int64_t ld,
+                        float* workspace, tgmx_stream_t stream);
+
+/* out[N, 2C] = [a[:, :C] | b * sigmoid(gate_pre)]  (gate_pre NULL: no gating)   tgcn.py:118-149 */
+int tgmx_tgcn_concat(const float* a, int64_t lda, const float* b, const float* gate_pre, int32_t C,
+                     int64_t N, float* out, tgmx_stream_t stream);
+
+/* out = sigmoid(u_pre) * H + (1 - sigmoid(u_pre)) * tanh(c_pre), n elements       tgcn.py:151-156 */
+int tgmx_tgcn_output(const float* u_pre, const float* c_pre, const float* H, int64_t n, float* out,
+                     tgmx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,6 +17,8 @@ Fixture families:
   g5_*   TemporalAttention / TGAT eval-mode forward
   g6_*   Time2Vec on int64 deltas up to 2^31
   g7_*   DeduplicationHook
+  g9_*   DGData.discretize
+  g10_*  TGCN cell (gate wiring; GCNConv = placeholder restatement, third-party)
   g8_*   TGNMemory (in-tree arithmetic: messages, Last/Mean aggregation, GRU, store semantics)
 """
 from __future__ import annotations
@@ -377,11 +379,67 @@ def g8_cases():
         print(f'g8_tgn_{tag}: {b} batches')
 
 
+def g9_case():
+    """DGData.discretize (tgm/data/dg_data.py:423-564): seconds -> minutes / hours, with node events and labels."""
+    rng = np.random.default_rng(77)
+    E, N = 500, 12
+    ts = np.sort(rng.integers(0, 20_000, E)).astype(np.int64)
+    ei = rng.integers(0, N, (E, 2)).astype(np.int32)
+    ex = rng.random((E, 3), dtype=np.float32)
+    nt = np.sort(rng.integers(0, 20_000, 60)).astype(np.int64)
+    nn_ = rng.integers(0, N, 60).astype(np.int32)
+    nx = rng.random((60, 2), dtype=np.float32)
+    yt = np.sort(rng.integers(0, 20_000, 40)).astype(np.int64)
+    yn = rng.integers(0, N, 40).astype(np.int32)
+    yv = rng.random((40, 4), dtype=np.float32)
+    arrays = dict(ts=ts, ei=ei, ex=ex, nt=nt, nn=nn_, nx=nx, yt=yt, yn=yn, yv=yv)
+    T_ = torch.from_numpy
+    d = DGData.from_raw(T_(ts), T_(ei), T_(ex), node_x_time=T_(nt), node_x_nids=T_(nn_), node_x=T_(nx), node_y_time=T_(yt),
+                        node_y_nids=T_(yn), node_y=T_(yv), time_delta='s')  # fmt: skip
+    for unit in ('m', 'h'):
+        c = d.discretize(unit)
+        for f in ('time', 'edge_mask', 'edge_index', 'edge_x', 'node_x_mask', 'node_x_nids', 'node_x', 'node_y_mask', 'node_y_nids', 'node_y'):
+            arrays[f'{unit}_{f}'] = getattr(c, f).numpy().copy()
+    np.savez_compressed(os.path.join(HERE, 'g9_discretize.npz'), **arrays)
+    print('g9_discretize: ok')
+
+
+def g10_case():
+    """TGCN cell (tgm/nn/encoder/tgcn.py): three snapshots with a carried hidden state; GCNConv is the
+    placeholder restatement (third-party arithmetic), so this pins the reference's gate wiring."""
+    from tgm.nn.encoder.tgcn import TGCN
+
+    rng = np.random.default_rng(3)
+    N, Fin, C = 37, 5, 8
+    arrays = {}
+    for tag, improved in (('plain', False), ('improved', True)):
+        torch.manual_seed(2)
+        cell = TGCN(Fin, C, improved=improved).eval()
+        _jitter_params(cell, 13)
+        arrays.update({f'{tag}_w_{n}': p.detach().numpy().copy() for n, p in cell.state_dict().items()})
+        H = None
+        with torch.no_grad():
+            for snap in range(3):
+                E = int(rng.integers(60, 120))
+                ei = rng.integers(0, N, (2, E)).astype(np.int64)
+                ei[:, :4] = ei[0, :4]  # a few explicit self loops
+                ew = rng.random(E, dtype=np.float32) + 0.5 if snap == 2 else None
+                x = rng.standard_normal((N, Fin)).astype(np.float32)
+                H = cell(torch.from_numpy(x), torch.from_numpy(ei), None if ew is None else torch.from_numpy(ew), H)
+                arrays[f'{tag}_s{snap}_x'], arrays[f'{tag}_s{snap}_ei'] = x, ei
+                if ew is not None:
+                    arrays[f'{tag}_s{snap}_ew'] = ew
+                arrays[f'{tag}_s{snap}_H'] = H.numpy().copy()
+    arrays['meta'] = np.frombuffer(json.dumps(dict(N=N, Fin=Fin, C=C)).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, 'g10_tgcn.npz'), **arrays)
+    print('g10_tgcn: ok')
+
+
 if __name__ == '__main__':
     import warnings
 
     warnings.filterwarnings('ignore')
     only = sys.argv[1:]
-    for fam, fn in [('g1', g1_cases), ('g2', g2_cases), ('g3', g3_case), ('g4', g4_case), ('g5', g5_cases), ('g6', g6_case), ('g7', g7_case), ('g8', g8_cases)]:
+    for fam, fn in [('g1', g1_cases), ('g2', g2_cases), ('g3', g3_case), ('g4', g4_case), ('g5', g5_cases), ('g6', g6_case), ('g7', g7_case), ('g8', g8_cases), ('g9', g9_case), ('g10', g10_case)]:
         if not only or fam in only:
             fn()

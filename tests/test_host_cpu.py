@@ -162,3 +162,48 @@ def test_negative_and_dedup_hooks_on_host():
     exp = torch.unique(torch.cat([b.edge_src, b.edge_dst, b.neg, torch.IntTensor([8, 2, 2])]))
     assert torch.equal(b.unique_nids, exp) and torch.equal(b.unique_nids[b.global_to_local(b.edge_src).long()], b.edge_src)
     assert 'edge_src = [7]' in str(b) and isinstance(b, DGBatch)
+
+
+def test_discretize_matches_reference_golden():
+    """DGData.discretize against the reference's output (golden g9): bit-exact, all event groups."""
+    import os
+
+    from tgm_amd.exceptions import InvalidDiscretizationError
+
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'g9_discretize.npz'))
+    T = torch.from_numpy
+    d = DGData.from_raw(T(z['ts']), T(z['ei']), T(z['ex']), node_x_time=T(z['nt']), node_x_nids=T(z['nn']), node_x=T(z['nx']),
+                        node_y_time=T(z['yt']), node_y_nids=T(z['yn']), node_y=T(z['yv']), time_delta='s')  # fmt: skip
+    def canon(times, *cols):
+        """rows sorted lexicographically inside each timestamp bucket: the reference orders events that
+        share a (discretized) timestamp with a NON-stable argsort (dg_data.py:360), i.e. unspecified;
+        ours keeps the input order.  Everything else -- which events survive, their buckets, payloads -- is exact."""
+        rows = np.concatenate([np.asarray(times, np.float64)[:, None]] + [np.asarray(c, np.float64).reshape(len(times), -1) for c in cols], 1)
+        return rows[np.lexsort(rows.T[::-1])]
+
+    for unit in ('m', 'h'):
+        with pytest.warns(UserWarning):  # bucketed node events precede later edges: the timeline is re-sorted
+            c = d.discretize(unit)
+        assert c.time_delta == TimeDeltaDG(unit)
+        assert np.array_equal(c.time.numpy(), z[f'{unit}_time']) and c.time.dtype == torch.int64
+        for mask, cols in (('edge_mask', ('edge_index', 'edge_x')), ('node_x_mask', ('node_x_nids', 'node_x')), ('node_y_mask', ('node_y_nids', 'node_y'))):
+            t_got = c.time[getattr(c, mask).long()].numpy()
+            t_exp = z[f'{unit}_time'][z[f'{unit}_{mask}']]
+            got = canon(t_got, *[getattr(c, f).numpy() for f in cols])
+            exp = canon(t_exp, *[z[f'{unit}_{f}'] for f in cols])
+            assert got.shape == exp.shape and np.array_equal(got, exp), f'{unit} {mask}'
+            for f in cols:
+                assert getattr(c, f).numpy().dtype == z[f'{unit}_{f}'].dtype
+        assert np.array_equal(np.sort(np.concatenate([c.edge_mask.numpy(), c.node_x_mask.numpy(), c.node_y_mask.numpy()])), np.arange(len(c.time)))
+    same = d.discretize('s')
+    assert same is not d and torch.equal(same.time, d.time)
+    with pytest.raises(InvalidDiscretizationError):
+        d.discretize('h').discretize('m')
+    with pytest.raises(EventOrderedConversionError):
+        _data()[0].discretize('h')
+    with pytest.raises(ValueError):
+        d.discretize('h', reduce_op='mean')
+    # a coarser graph iterates one snapshot per bucket
+    dg = DGraph(d.discretize('h'))
+    sizes = [b.edge_src.numel() for b in DGDataLoader(dg, batch_unit='h')]
+    assert sum(sizes) == dg.num_edge_events and len(sizes) >= 5

@@ -60,6 +60,9 @@ SIGNATURES = {
     'tgmx_tgn_commit': (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int64, _P, _P, _P]),
     'tgmx_tconv_edge_attr': (c_int32, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int64, _P, _P]),
     'tgmx_tconv_attend': (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, ctypes.c_float, _P, _P]),
+    'tgmx_gcn_norm_dense': (c_int32, [_P, _P, _P, c_int64, c_int64, ctypes.c_float, c_int32, _P, c_int64, _P, _P]),
+    'tgmx_tgcn_concat': (c_int32, [_P, c_int64, _P, _P, c_int32, c_int64, _P, _P]),
+    'tgmx_tgcn_output': (c_int32, [_P, _P, _P, c_int64, _P, _P]),
     'tgmx_ln_residual_concat': (c_int32, [_P, c_int64, _P, c_int64, _P, _P, c_int32, ctypes.c_float, _P, c_int32, c_int64, _P, c_int64, _P]),
     'tgmx_pack_adj': (c_int32, [_P, c_int64, _P, _P, _P, c_int64, _P, _P]),
 }

@@ -209,6 +209,67 @@ class DGData:
             self.node_y_mask, self.node_y_nids, self.node_y = regroup(self.node_y_mask, self.node_y_nids, self.node_y)
 
     # ------------------------------------------------------------------
+    def clone(self) -> 'DGData':
+        """Deep copy (tensors cloned)."""
+        import copy
+        from dataclasses import fields
+
+        vals = {f.name: getattr(self, f.name) for f in fields(self)}
+        return DGData(**{k: (v.clone() if isinstance(v, Tensor) else copy.deepcopy(v)) for k, v in vals.items()})
+
+    def discretize(self, time_delta: 'TimeDeltaDG | str | None', reduce_op: str = 'first') -> 'DGData':
+        """Coarsen the time granularity (tgm/data/dg_data.py:423-564): timestamps become bucket indices
+        ``floor(t * self.time_delta / time_delta)`` and, per bucket, only the FIRST event of every
+        (src, dst) edge / node id is kept, in chronological order.  Sort-bound one-shot work: it runs as
+        torch ops on whatever device the tensors live on (stable sort of a radix key)."""
+        from ..exceptions import EventOrderedConversionError, InvalidDiscretizationError
+
+        if isinstance(time_delta, str):
+            time_delta = TimeDeltaDG(time_delta)
+        if time_delta is None or self.time_delta == time_delta:
+            return self.clone()
+        if self.time_delta.is_event_ordered or time_delta.is_event_ordered:
+            raise EventOrderedConversionError('Cannot discretize a graph with event-ordered time granularity')
+        if self.time_delta.is_coarser_than(time_delta):
+            raise InvalidDiscretizationError(f'Cannot discretize to {time_delta} which is strictly finer than {self.time_delta}')
+        if reduce_op != 'first':
+            raise ValueError(f"Unknown reduce_op: {reduce_op}, expected one of: ['first']")
+
+        factor = self.time_delta.convert(time_delta)
+        buckets = (self.time.to(torch.float64) * factor).floor().int()  # float64: exact for every int32 timestamp
+
+        def first_per_bucket(event_pos: Tensor, ids: Tensor) -> Tensor:
+            """positions (within this event group) of the first event of every (bucket, id) pair, ascending"""
+            b = buckets[event_pos.long()]
+            if ids.ndim == 2:
+                base = int(ids.max()) + 1
+                flat = ids[:, 0] * base + ids[:, 1]  # int32 arithmetic, like the reference
+            else:
+                flat = ids
+            key = b * (int(flat.max()) + 1) + flat
+            skey, order = torch.sort(key, stable=True)
+            head = torch.ones_like(skey, dtype=torch.bool)
+            head[1:] = skey[1:] != skey[:-1]
+            return order[head].sort().values
+
+        keep = first_per_bucket(self.edge_mask, self.edge_index)
+        pick = lambda t: None if t is None else t[keep]
+        kw = dict(
+            time_delta=time_delta, edge_time=buckets[self.edge_mask.long()][keep], edge_index=self.edge_index[keep],
+            edge_x=pick(self.edge_x), edge_type=pick(self.edge_type),
+            static_node_x=None if self.static_node_x is None else self.static_node_x.clone(),
+            node_type=None if self.node_type is None else self.node_type.clone(),
+        )  # fmt: skip
+        for pre in ('node_x', 'node_y'):
+            mask = getattr(self, f'{pre}_mask')
+            if mask is not None:
+                kp = first_per_bucket(mask, getattr(self, f'{pre}_nids'))
+                kw[f'{pre}_time'] = buckets[mask.long()][kp]
+                kw[f'{pre}_nids'] = getattr(self, f'{pre}_nids')[kp]
+                vals = getattr(self, pre)
+                kw[pre] = None if vals is None else vals[kp]
+        return DGData.from_raw(**kw)
+
     @property
     def num_nodes(self) -> int:
         n = int(self.edge_index.max()) + 1

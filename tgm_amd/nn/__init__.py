@@ -1,10 +1,11 @@
 from .attention import TemporalAttention
 from .base import EncoderModule
 from .tgat import TGAT, MergeLayer
+from .tgcn import TGCN, GCNConv
 from .tgn import GraphAttentionEmbedding, IdentityMessage, LastAggregator, MeanAggregator, TGNMemory, TransformerConv
 from .time_encoding import Time2Vec
 
 __all__ = [
-    'EncoderModule', 'GraphAttentionEmbedding', 'IdentityMessage', 'LastAggregator', 'MeanAggregator', 'MergeLayer', 'TGAT',
+    'EncoderModule', 'GCNConv', 'GraphAttentionEmbedding', 'IdentityMessage', 'LastAggregator', 'MeanAggregator', 'MergeLayer', 'TGAT', 'TGCN',
     'TGNMemory', 'TemporalAttention', 'Time2Vec', 'TransformerConv',
 ]  # fmt: skip

@@ -1,0 +1,99 @@
+"""``TGCN`` -- temporal graph convolutional GRU cell (tgm/nn/encoder/tgcn.py:8-157) on HIP kernels.
+
+Parameter names match the reference / PyG (``conv_{u,r,c}.lin.weight``, ``conv_{u,r,c}.bias``,
+``linear_{u,r,c}.{weight,bias}``).  ``GCNConv`` is third-party to the reference (torch_geometric);
+it is implemented from its published definition (parity unpinned upstream).  The three graph
+convolutions share one dense normalised adjacency and run as two exact-fp32 MFMA GEMMs
+(``A_hat @ (X [W_u|W_r|W_c])``); snapshot graphs on this path are small (tgbn-trade: 255 nodes).
+Forward only.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from .. import _native
+from . import _ops
+
+_MAX_DENSE_NODES = 16384  # A_hat is dense: 16384^2 floats = 1 GiB
+
+
+class GCNConv(nn.Module):
+    """x' = D^-1/2 (A + I) D^-1/2 x W^T + b  (PyG parameter layout: ``lin.weight`` [out, in], ``bias`` [out])."""
+
+    def __init__(self, in_channels: int, out_channels: int, improved: bool = False, cached: bool = False, add_self_loops: bool = True) -> None:
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.improved, self.cached, self.add_self_loops = improved, cached, add_self_loops
+        self.lin = nn.Linear(in_channels, out_channels, bias=False)
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+        bound = math.sqrt(6.0 / (in_channels + out_channels))  # glorot
+        nn.init.uniform_(self.lin.weight, -bound, bound)
+
+    def forward(self, x: Tensor, edge_index: Tensor, edge_weight: Optional[Tensor] = None) -> Tensor:
+        x = _ops._f32c(x, 'x')
+        A = normalized_adjacency(edge_index, edge_weight, x.shape[0], 2.0 if self.improved else 1.0, self.add_self_loops)
+        xwt = torch.empty((self.out_channels, x.shape[0]), dtype=torch.float32, device=x.device)
+        _ops.sgemm_nt(self.lin.weight.detach(), x, xwt)  # (X W^T)^T = W X^T
+        out = torch.empty((x.shape[0], self.out_channels), dtype=torch.float32, device=x.device)
+        return _ops.sgemm_nt(A, xwt, out, bias=self.bias.detach(), K=x.shape[0])
+
+
+def normalized_adjacency(edge_index: Tensor, edge_weight: Optional[Tensor], N: int, fill: float, add_self_loops: bool) -> Tensor:
+    """Dense D^-1/2 (A + I) D^-1/2, rows padded to a multiple of 4 floats (16-byte aligned GEMM operand)."""
+    if N > _MAX_DENSE_NODES:
+        raise NotImplementedError(f'tgm_amd GCNConv builds a dense adjacency; {N} nodes exceed {_MAX_DENSE_NODES}')
+    _native.require_device(edge_index, 'edge_index')
+    lib = _native.load()
+    dev = edge_index.device
+    ei = edge_index.to(torch.int64)
+    src, dst = ei[0].contiguous(), ei[1].contiguous()
+    w = None if edge_weight is None else _ops._f32c(edge_weight, 'edge_weight')
+    ld = (N + 3) // 4 * 4
+    A = torch.empty((N, ld), dtype=torch.float32, device=dev)
+    ws = torch.empty(2 * N, dtype=torch.float32, device=dev)
+    _native.check(
+        lib.tgmx_gcn_norm_dense(src.data_ptr(), dst.data_ptr(), _native.ptr(w), src.numel(), N, float(fill), 1 if add_self_loops else 0,
+                                A.data_ptr(), ld, ws.data_ptr(), _native.stream_ptr()),
+        'tgmx_gcn_norm_dense',
+    )  # fmt: skip
+    return A[:, :N]
+
+
+class TGCN(nn.Module):
+    def __init__(self, in_channels: int, out_channels: int, improved: bool = False, cached: bool = False, add_self_loops: bool = True) -> None:
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.improved, self.cached, self.add_self_loops = improved, cached, add_self_loops
+        mk = lambda: GCNConv(in_channels, out_channels, improved=improved, cached=cached, add_self_loops=add_self_loops)
+        self.conv_c, self.linear_c = mk(), nn.Linear(2 * out_channels, out_channels)
+        self.conv_r, self.linear_r = mk(), nn.Linear(2 * out_channels, out_channels)
+        self.conv_u, self.linear_u = mk(), nn.Linear(2 * out_channels, out_channels)
+
+    def forward(self, node_x: Tensor, edge_index: Tensor, edge_weight: Optional[Tensor] = None, H: Optional[Tensor] = None) -> Tensor:
+        lib = _native.load()
+        x = _ops._f32c(node_x, 'node_x')
+        N, C, dev = x.shape[0], self.out_channels, x.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        H = torch.zeros((N, C), **f32) if H is None else _ops._f32c(H, 'H')
+        stream = _native.stream_ptr()
+        A = normalized_adjacency(edge_index, edge_weight, N, 2.0 if self.improved else 1.0, self.add_self_loops)
+        # the three convolutions share A_hat: G = A_hat @ (X [W_u | W_r | W_c]^T) + [b_u | b_r | b_c]
+        W3 = torch.cat([self.conv_u.lin.weight.detach(), self.conv_r.lin.weight.detach(), self.conv_c.lin.weight.detach()])
+        b3 = torch.cat([self.conv_u.bias.detach(), self.conv_r.bias.detach(), self.conv_c.bias.detach()])
+        xwt = torch.empty((3 * C, N), **f32)
+        _ops.sgemm_nt(W3, x, xwt)
+        G = torch.empty((N, 3 * C), **f32)
+        _ops.sgemm_nt(A, xwt, G, bias=b3, K=N)
+        cat = torch.empty((N, 2 * C), **f32)
+        pre = [torch.empty((N, C), **f32) for _ in range(3)]  # u, r, c pre-activations
+        for g, (lin, gate) in enumerate(((self.linear_u, None), (self.linear_r, None), (self.linear_c, pre[1]))):
+            _native.check(lib.tgmx_tgcn_concat(G[:, g * C :].data_ptr(), 3 * C, H.data_ptr(), _native.ptr(gate), C, N, cat.data_ptr(), stream), 'tgmx_tgcn_concat')
+            _ops.sgemm_nt(cat, lin.weight.detach(), pre[g], bias=lin.bias.detach())
+        out = torch.empty((N, C), **f32)
+        _native.check(lib.tgmx_tgcn_output(pre[0].data_ptr(), pre[2].data_ptr(), H.data_ptr(), N * C, out.data_ptr(), stream), 'tgmx_tgcn_output')
+        return out
