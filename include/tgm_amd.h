@@ -169,7 +169,8 @@ int tgmx_tgat_attn_reduce(const float* qf, const float* nbrf, int32_t d, const f
                           const float* tw, const float* tb, const float* nbr_time_feat,
                           const uint8_t* mask, int32_t T, int32_t H, int32_t k, int64_t R,
                           float scale, int32_t head_stride /* floats between heads in qf / zbar rows, 0 = C */,
-                          float* zbar, tgmx_stream_t stream);
+                          float* zbar, float* attn_probs /* optional [R,H,k]: softmax weights, for backward */,
+                          tgmx_stream_t stream);
 
 /* out[R, O + d0] = [LayerNorm(y + res) * gamma + beta | z0]
  * (attention.py:127 + the concat of tgat.py:36). */
@@ -212,10 +213,63 @@ typedef struct tgmx_tgat_hop {
   const float* edge_x;   /* [rows_i, k, D]  nbr_edge_x[i]    */
   int32_t k;
 } tgmx_tgat_hop_t;
+/* Where tgmx_tgat_forward keeps its intermediates (offsets in floats from the 256-byte aligned
+ * workspace base; -1 = not kept).  Row strides: rres/oattn/y Op, Q H*dhp, qf/zbar H*Cp, cat Kc, h1 Ep,
+ * probs H*k, out emb_out.  Level i of the hop tree occupies rows [level_off[i], level_off[i+1]). */
+typedef struct tgmx_tgat_layer_layout {
+  int64_t R, rres, oattn, y, Q, qf, zbar, cat, h1, probs, out;
+  int32_t Op, dhp, Cp, Kc, Ep;
+} tgmx_tgat_layer_layout_t;
+typedef struct tgmx_tgat_layout {
+  int64_t total_bytes, z0;
+  int64_t level_rows[TGMX_TGAT_MAX_LAYERS + 1], level_off[TGMX_TGAT_MAX_LAYERS + 2];
+  tgmx_tgat_layer_layout_t layers[TGMX_TGAT_MAX_LAYERS];
+} tgmx_tgat_layout_t;
+int tgmx_tgat_layout(const tgmx_tgat_model_t* model, int64_t S0, const tgmx_tgat_hop_t* hops,
+                     int32_t save, tgmx_tgat_layout_t* out);
 size_t tgmx_tgat_workspace_bytes(const tgmx_tgat_model_t* model, int64_t S0, const tgmx_tgat_hop_t* hops);
+/* save != 0: every layer keeps its intermediates + attention weights (training); the workspace then
+ * has to be tgmx_tgat_layout(..., save=1).total_bytes large and must outlive the backward pass. */
 int tgmx_tgat_forward(const tgmx_tgat_model_t* model, const float* node_x, int64_t num_nodes,
                       const int32_t* seed_ids, int64_t S0, const tgmx_tgat_hop_t* hops,
-                      float* workspace, size_t workspace_bytes, float* out, tgmx_stream_t stream);
+                      float* workspace, size_t workspace_bytes, int32_t save, float* out,
+                      tgmx_stream_t stream);
+
+/* ---- TGAT backward building blocks (training; composed by tgm_amd/nn/tgat.py) ---------------- */
+
+/* C[b] (+)= A[b]^T B[b]: C[m, n] = sum_r A[r, m] * B[r, n] (weight gradients; reduction over rows),
+ * exact-fp32 MFMA, deterministic two-stage reduction.  workspace: tgmx_sgemm_tn_workspace_bytes(). */
+size_t tgmx_sgemm_tn_workspace_bytes(int64_t R, int32_t M, int32_t N, int32_t batch);
+int tgmx_sgemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
+                  int64_t R, int32_t M, int32_t N, int32_t batch, int64_t strideA, int64_t strideB,
+                  int64_t strideC, int32_t accumulate, float* workspace, tgmx_stream_t stream);
+
+/* out[c] (+)= sum_r in[r * ld + c], c < C (bias / LayerNorm / Time2Vec gradients); workspace 256*C floats */
+int tgmx_colsum(const float* in, int64_t ld, int64_t R, int32_t C, float* out, int32_t accumulate,
+                float* workspace, tgmx_stream_t stream);
+
+/* grad[r, c] = act[r, c] > 0 ? grad[r, c] : 0 */
+int tgmx_relu_mask(float* grad, int64_t ldg, const float* act, int64_t lda, int64_t R, int32_t C,
+                   tgmx_stream_t stream);
+
+/* dst[r, c] (+)= src[r, c], c < C */
+int tgmx_add_cols(float* dst, int64_t ldd, const float* src, int64_t lds, int64_t R, int32_t C,
+                  int32_t accumulate, tgmx_stream_t stream);
+
+/* LayerNorm(y + res) backward: du [R, O] (gradient of y and of res), dgx = dout * xhat (its column sum
+ * is d gamma; d beta is the column sum of dout). */
+int tgmx_ln_backward(const float* dout, int64_t ldd, const float* y, int64_t ldy, const float* res,
+                     int64_t ldr, const float* gamma, int32_t O, float eps, int64_t R, float* du,
+                     int64_t ldu, float* dgx, int64_t ldg, tgmx_stream_t stream);
+
+/* Backward of tgmx_tgat_attn_reduce (needs the saved attention weights): given dzbar [R,H,Cs] ->
+ * dqf [R,H,Cs], dnbr [R,k,d] (accumulated, may be NULL) and per-row partials dtime_rows [R, 2T] of the
+ * Time2Vec weight | bias gradients (column-sum them).  k * H <= 64. */
+int tgmx_tgat_attn_backward(const float* qf, const float* probs, const float* dzbar, const float* nbrf,
+                            int32_t d, const float* ex, int32_t D, const int64_t* seed_t,
+                            const int64_t* nbr_t, const float* tw, const float* tb, int32_t T, int32_t H,
+                            int32_t k, int64_t R, float scale, int32_t head_stride, float* dqf,
+                            float* dnbr, float* dtime_rows, tgmx_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * TGN memory module (tgm/nn/encoder/tgn.py:80-251), forward arithmetic.

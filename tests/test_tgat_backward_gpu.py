@@ -1,0 +1,91 @@
+"""TGAT training path: parameter gradients of the HIP backward vs torch autograd on the CPU restatement
+(the folded algorithm).
+Bar: |g - g_ref| <= 1e-4 * max|g_ref| per parameter tensor (fp32 kernels, sums over up to ~250k terms)."""
+import pytest
+import torch
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _ref_grads(params, n_heads, inputs, dz, dtype):
+    """torch autograd (CPU) through the folded restatement in `dtype`.  Time2Vec is evaluated at the float32
+    argument the model uses (float32(dt), one fma rounded to float32; straight-through for the roundings):
+    at unix-scale timestamps cos / sin are only meaningful there."""
+    import oracle.tgat_ref as tr
+    from oracle import tgat_fold
+
+    def t2v(t, w, b):
+        arg = t.unsqueeze(-1).float().double() * w.reshape(-1).double() + b.double()
+        return torch.cos(arg + (arg.float().double() - arg).detach()).to(dtype)
+
+    p = {k: v.to(dtype).requires_grad_(True) for k, v in params.items()}
+    f = lambda t: t.to(dtype) if t.is_floating_point() else t
+    old = tr.time2vec
+    tr.time2vec = tgat_fold.time2vec = t2v
+    try:
+        z = tgat_fold.tgat_forward_folded(p, n_heads, f(inputs['node_x']), inputs['seed_nids'], inputs['seed_times'], inputs['nbr_nids'],
+                                          [f(x) for x in inputs['nbr_edge_x']], inputs['nbr_edge_time'])  # fmt: skip
+    finally:
+        tr.time2vec = tgat_fold.time2vec = old
+    (z * dz.to(dtype)).sum().backward()
+    return {k: v.grad.float() for k, v in p.items()}
+
+
+def _worst(enc, g_ref):
+    worst = ('', 0.0)
+    for name, p in enc.named_parameters():
+        r = g_ref[name]
+        err = ((p.grad.cpu() - r).abs().max() / r.abs().max().clamp(min=1e-6)).item()
+        if err > worst[1]:
+            worst = (name, err)
+    return worst
+
+
+@pytest.mark.parametrize('case', ['g5_tgat_small_unix', 'g5_tgat_small_nd8', 'g5_tgat_one_layer', 'g5_tgat_example_dims'])
+def test_tgat_parameter_gradients(case):
+    from tgm_amd.nn import TGAT
+
+    meta, params, inputs, z_ref = gu.tgat_case(case)
+    enc = TGAT(edge_dim=meta['edge_dim'], num_layers=len(meta['num_nbrs']), dropout=0.0, **meta['dims']).to(DEV).train()
+    enc.load_state_dict(params)
+    dev = lambda v: [t.to(DEV) for t in v] if isinstance(v, list) else v.to(DEV)
+    z = enc(**{k: dev(v) for k, v in inputs.items()})
+    assert z.requires_grad
+    torch.manual_seed(0)
+    dz = torch.randn(z.shape)
+    z.backward(dz.to(DEV))
+    assert ((z.detach().cpu() - z_ref).abs() <= 1e-5 * z_ref.abs().clamp(min=1)).all()
+    assert all(p.grad is not None for p in enc.parameters())
+    # The merge layer's ReLU makes the gradient discontinuous: a pre-activation that is ~1e-7 gets a different
+    # mask in fp32 and fp64 (torch's own fp32-vs-fp64 autograd differ by 4e-3 on the example-dims case from
+    # exactly that), so the kernels must agree with the fp64 OR the fp32 autograd reference on every parameter.
+    w64 = _worst(enc, _ref_grads(params, meta['dims']['n_heads'], inputs, dz, torch.float64))
+    w32 = _worst(enc, _ref_grads(params, meta['dims']['n_heads'], inputs, dz, torch.float32)) if w64[1] > 1e-4 else w64
+    assert min(w64[1], w32[1]) <= 1e-4, f'{case}: worst rel err vs fp64 {w64}, vs fp32 {w32}'
+
+
+def test_tgat_training_step_reduces_loss():
+    """A few Adam steps on a fixed batch with the HIP forward/backward must drive a regression loss down."""
+    from tgm_amd.nn import TGAT
+
+    meta, params, inputs, _ = gu.tgat_case('g5_tgat_small_nd8')
+    enc = TGAT(edge_dim=meta['edge_dim'], num_layers=2, dropout=0.0, **meta['dims']).to(DEV).train()
+    enc.load_state_dict(params)
+    dev = lambda v: [t.to(DEV) for t in v] if isinstance(v, list) else v.to(DEV)
+    args = {k: dev(v) for k, v in inputs.items()}
+    torch.manual_seed(1)
+    target = torch.randn(30, meta['dims']['embed_dim'], device=DEV)
+    opt = torch.optim.Adam(enc.parameters(), lr=1e-2)
+    losses = []
+    for _ in range(40):
+        opt.zero_grad()
+        loss = ((enc(**args) - target) ** 2).mean()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert losses[-1] < 0.8 * losses[0] and all(b < a * 1.05 for a, b in zip(losses, losses[1:])), losses
+    with pytest.raises(NotImplementedError):
+        TGAT(edge_dim=meta['edge_dim'], num_layers=2, dropout=0.1, **meta['dims']).to(DEV).train()(**args)

@@ -49,7 +49,7 @@ SIGNATURES = {
     ),
     'tgmx_tgat_attn_reduce': (
         c_int32,
-        [_P, _P, c_int32, _P, c_int32, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int64, ctypes.c_float, c_int32, _P, _P],
+        [_P, _P, c_int32, _P, c_int32, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int64, ctypes.c_float, c_int32, _P, _P, _P],
     ),
     'tgmx_tgn_store': (c_int32, [_P, _P, _P, _P, _P, _P, _P, c_int32, c_int64, c_int64, _P, _P, _P, _P, _P, _P]),
     'tgmx_tgn_aggregate': (
@@ -63,6 +63,19 @@ SIGNATURES = {
     'tgmx_gcn_norm_dense': (c_int32, [_P, _P, _P, c_int64, c_int64, ctypes.c_float, c_int32, _P, c_int64, _P, _P]),
     'tgmx_tgcn_concat': (c_int32, [_P, c_int64, _P, _P, c_int32, c_int64, _P, _P]),
     'tgmx_tgcn_output': (c_int32, [_P, _P, _P, c_int64, _P, _P]),
+    'tgmx_sgemm_tn_workspace_bytes': (c_size_t, [c_int64, c_int32, c_int32, c_int32]),
+    'tgmx_sgemm_tn': (
+        c_int32,
+        [_P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int32, c_int32, c_int32, c_int64, c_int64, c_int64, c_int32, _P, _P],
+    ),
+    'tgmx_colsum': (c_int32, [_P, c_int64, c_int64, c_int32, _P, c_int32, _P, _P]),
+    'tgmx_relu_mask': (c_int32, [_P, c_int64, _P, c_int64, c_int64, c_int32, _P]),
+    'tgmx_add_cols': (c_int32, [_P, c_int64, _P, c_int64, c_int64, c_int32, c_int32, _P]),
+    'tgmx_ln_backward': (c_int32, [_P, c_int64, _P, c_int64, _P, c_int64, _P, c_int32, ctypes.c_float, c_int64, _P, c_int64, _P, c_int64, _P]),
+    'tgmx_tgat_attn_backward': (
+        c_int32,
+        [_P, _P, _P, _P, c_int32, _P, c_int32, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int64, ctypes.c_float, c_int32, _P, _P, _P, _P],
+    ),
     'tgmx_ln_residual_concat': (c_int32, [_P, c_int64, _P, c_int64, _P, _P, c_int32, ctypes.c_float, _P, c_int32, c_int64, _P, c_int64, _P]),
     'tgmx_pack_adj': (c_int32, [_P, c_int64, _P, _P, _P, c_int64, _P, _P]),
 }
@@ -84,10 +97,22 @@ class TgatHop(ctypes.Structure):
     _fields_ = [('seed_t', c_void_p), ('nbr_id', c_void_p), ('nbr_t', c_void_p), ('edge_x', c_void_p), ('k', c_int32)]
 
 
+class TgatLayerLayout(ctypes.Structure):
+    _fields_ = [(n, c_int64) for n in ('R', 'rres', 'oattn', 'y', 'Q', 'qf', 'zbar', 'cat', 'h1', 'probs', 'out')] + [
+        (n, c_int32) for n in ('Op', 'dhp', 'Cp', 'Kc', 'Ep')
+    ]
+
+
+class TgatLayout(ctypes.Structure):
+    _fields_ = [('total_bytes', c_int64), ('z0', c_int64), ('level_rows', c_int64 * (TGAT_MAX_LAYERS + 1)),
+                ('level_off', c_int64 * (TGAT_MAX_LAYERS + 2)), ('layers', TgatLayerLayout * TGAT_MAX_LAYERS)]  # fmt: skip
+
+
+SIGNATURES['tgmx_tgat_layout'] = (c_int32, [ctypes.POINTER(TgatModel), c_int64, ctypes.POINTER(TgatHop), c_int32, ctypes.POINTER(TgatLayout)])
 SIGNATURES['tgmx_tgat_workspace_bytes'] = (c_size_t, [ctypes.POINTER(TgatModel), c_int64, ctypes.POINTER(TgatHop)])
 SIGNATURES['tgmx_tgat_forward'] = (
     c_int32,
-    [ctypes.POINTER(TgatModel), _P, c_int64, _P, c_int64, ctypes.POINTER(TgatHop), _P, c_size_t, _P, _P],
+    [ctypes.POINTER(TgatModel), _P, c_int64, _P, c_int64, ctypes.POINTER(TgatHop), _P, c_size_t, c_int32, _P, _P],
 )
 
 _lib: Optional[ctypes.CDLL] = None

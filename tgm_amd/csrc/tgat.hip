@@ -213,6 +213,7 @@ struct AttnArgs {
   int d, D, T, k, C;
   float scale;        // dh^-1/2
   int Cs;             // stride (floats) between consecutive heads of qf / zbar rows (>= C; padded layouts)
+  float* probs;       // optional [R, H, k]: the attention weights, saved for the backward pass
 };
 
 // sum over the 64 lanes of P[j], delivered to lane j: 63 shuffles instead of 64 * 6.
@@ -342,6 +343,8 @@ __global__ __launch_bounds__(256) void tgat_attn_reduce_kernel(const AttnArgs a)
   }
   __builtin_amdgcn_wave_barrier();
 
+  if (a.probs)
+    for (int e = lane; e < H * k; e += kWave) a.probs[r * (long long)H * k + e] = s_A[e];
   // ---- pass 2: zbar[h][c] = sum_s A[h][s] z[s][c]  (features re-read: L1/L2 hits) ----
   // slots are consumed 8 at a time so that 8 independent loads are in flight per lane
   float* __restrict__ zb = a.zbar + r * (long long)H * a.Cs;
@@ -485,6 +488,7 @@ __global__ __launch_bounds__(256) void tgat_attn_reduce_reg_kernel(const AttnArg
 #pragma unroll
   for (int o = H; o < 64; o <<= 1) sum += __shfl_xor(sum, o);
   const float A = ev / sum;
+  if (a.probs && live) a.probs[r * (long long)H * k + (lane - js * H) * k + js] = A;
 
   // ---- zbar[h] = sum_s A[h][s] z[s], from registers ----
   float* __restrict__ zb = a.zbar + r * (long long)H * a.Cs;
@@ -615,7 +619,8 @@ extern "C" int tgmx_ln_residual_concat(const float* y, int64_t ldy, const float*
 extern "C" int tgmx_tgat_attn_reduce(const float* qf, const float* nbrf, int32_t d, const float* ex, int32_t D,
                                      const int64_t* seed_t, const int64_t* nbr_t, const int32_t* nbr_id, const float* tw,
                                      const float* tb, const float* nbr_time_feat, const uint8_t* mask, int32_t T, int32_t H,
-                                     int32_t k, int64_t R, float scale, int32_t head_stride, float* zbar, tgmx_stream_t stream) {
+                                     int32_t k, int64_t R, float scale, int32_t head_stride, float* zbar, float* attn_probs,
+                                     tgmx_stream_t stream) {
   TGMX_REQUIRE(d > 0 && D >= 0 && T > 0 && k > 0 && R >= 0, "tgat_attn_reduce: bad sizes d=%d D=%d T=%d k=%d", d, D, T, k);
   TGMX_REQUIRE(H == 1 || H == 2 || H == 4 || H == 8, "tgat_attn_reduce: n_heads=%d unsupported (1, 2, 4 or 8)", H);
   if (R == 0) return TGMX_OK;
@@ -624,7 +629,7 @@ extern "C" int tgmx_tgat_attn_reduce(const float* qf, const float* nbrf, int32_t
   TGMX_REQUIRE(mask || nbr_id, "tgat_attn_reduce: need nbr_id or mask");
   TGMX_REQUIRE(head_stride == 0 || head_stride >= d + D + T, "tgat_attn_reduce: head_stride smaller than d + D + T");
   AttnArgs a{qf, nbrf, ex, seed_t, nbr_t, nbr_id, tw, tb, nbr_time_feat, mask, zbar, R, d, D, T, k, d + D + T, scale,
-             head_stride ? head_stride : d + D + T};
+             head_stride ? head_stride : d + D + T, attn_probs};
   const size_t per_wave = ((size_t)k * T + (size_t)k * (H + 2)) * sizeof(float);
   int waves = 4;
   while (waves > 1 && per_wave * waves > 64 * 1024) waves >>= 1;
@@ -686,87 +691,101 @@ extern "C" int tgmx_time2vec(const void* x, int32_t x_is_int64, const float* w, 
 static inline size_t align_up(size_t x) { return (x + 63) & ~(size_t)63; }
 static inline int pad4(int x) { return (x + 3) & ~3; }
 
-// Internal activation layouts are padded so that every GEMM operand row starts 16-byte aligned
-// (vector operand loads): O -> Op, per-head dh -> dhp, C -> Cp, O + d0 -> Kc.  The caller passes
-// weight copies padded the same way (tgmx_tgat_layer_t).
-extern "C" size_t tgmx_tgat_workspace_bytes(const tgmx_tgat_model_t* m, int64_t S0, const tgmx_tgat_hop_t* hops) {
-  if (!m || !hops || m->num_layers <= 0) return 0;
+// Workspace layout of tgmx_tgat_forward (offsets in floats from the 256-byte aligned base).  Internal
+// activation rows are padded so that every GEMM operand row starts 16-byte aligned: O -> Op, per-head
+// dh -> dhp, C -> Cp, O + d0 -> Kc, emb -> Ep.  With save == 0 the per-layer scratch is reused by every
+// layer; with save != 0 every layer keeps its own (the backward pass reads them).
+extern "C" int tgmx_tgat_layout(const tgmx_tgat_model_t* m, int64_t S0, const tgmx_tgat_hop_t* hops, int32_t save,
+                                tgmx_tgat_layout_t* out) {
+  TGMX_REQUIRE(m && hops && out, "tgat_layout: null pointer");
   const int L = m->num_layers;
-  long long rows[TGMX_TGAT_MAX_LAYERS + 1], off[TGMX_TGAT_MAX_LAYERS + 2];
+  TGMX_REQUIRE(L >= 1 && L <= TGMX_TGAT_MAX_LAYERS, "tgat_layout: num_layers=%d outside [1, %d]", L, TGMX_TGAT_MAX_LAYERS);
+  long long rows[TGMX_TGAT_MAX_LAYERS + 1];
   rows[0] = S0;
   for (int i = 0; i < L; ++i) rows[i + 1] = rows[i] * hops[i].k;
-  off[0] = 0;
-  for (int i = 0; i <= L; ++i) off[i + 1] = off[i] + rows[i];
-  size_t floats = align_up((size_t)off[L + 1] * m->d0);  // z0
-  size_t per_layer_max = 0, emb_rows = 0;
+  out->level_off[0] = 0;
+  for (int i = 0; i <= L; ++i) {
+    out->level_rows[i] = rows[i];
+    out->level_off[i + 1] = out->level_off[i] + rows[i];
+  }
+  size_t w = 0;
+  auto take = [&](size_t n) { const size_t p = w; w += align_up(n); return (int64_t)p; };
+  out->z0 = take((size_t)out->level_off[L + 1] * m->d0);
+  size_t scratch0 = w, scratch_end = w;
   for (int j = 1; j <= L; ++j) {
     const tgmx_tgat_layer_t& ly = m->layers[j - 1];
-    const size_t R = (size_t)off[L - j + 1];
-    const size_t Op = pad4(ly.O), dhp = pad4(ly.O / ly.H), Cp = pad4(ly.d + ly.D + ly.T), Kc = pad4(ly.O + m->d0);
-    const size_t need = align_up(R * Op) * 3 + align_up(R * ly.H * dhp) + align_up(R * ly.H * Cp) * 2 + align_up(R * Kc) + align_up(R * pad4(ly.emb));
-    per_layer_max = need > per_layer_max ? need : per_layer_max;
-    const size_t e = R * (size_t)pad4(ly.emb_out);
-    emb_rows = e > emb_rows ? e : emb_rows;
+    tgmx_tgat_layer_layout_t& lo = out->layers[j - 1];
+    const size_t R = (size_t)out->level_off[L - j + 1];
+    const int H = ly.H, k = hops[j - 1].k;
+    lo.R = (int64_t)R;
+    lo.Op = pad4(ly.O); lo.dhp = pad4(ly.O / H); lo.Cp = pad4(ly.d + ly.D + ly.T); lo.Kc = pad4(ly.O + m->d0); lo.Ep = pad4(ly.emb);
+    if (!save) w = scratch0;
+    lo.rres = take(R * lo.Op);
+    lo.oattn = take(R * lo.Op);
+    lo.y = take(R * lo.Op);
+    lo.Q = take(R * H * lo.dhp);
+    lo.qf = take(R * H * lo.Cp);
+    lo.zbar = take(R * H * lo.Cp);
+    lo.cat = take(R * lo.Kc);
+    lo.h1 = take(R * lo.Ep);
+    lo.probs = save ? take(R * H * k) : -1;
+    if (save) lo.out = (j == L) ? -1 : take(R * ly.emb_out);
+    scratch_end = w > scratch_end ? w : scratch_end;
   }
-  floats += per_layer_max + 2 * align_up(emb_rows);
-  return floats * sizeof(float) + 256;
+  w = scratch_end;
+  if (!save) {  // ping-pong buffers for the layer outputs
+    size_t emb_rows = 0;
+    for (int j = 1; j < L; ++j) {
+      const size_t e = (size_t)out->level_off[L - j + 1] * m->layers[j - 1].emb_out;
+      emb_rows = e > emb_rows ? e : emb_rows;
+    }
+    const int64_t pp[2] = {take(emb_rows), take(emb_rows)};
+    for (int j = 1; j <= L; ++j) out->layers[j - 1].out = (j == L) ? -1 : pp[j & 1];
+  }
+  out->total_bytes = (int64_t)(w * sizeof(float) + 256);
+  return TGMX_OK;
+}
+
+extern "C" size_t tgmx_tgat_workspace_bytes(const tgmx_tgat_model_t* m, int64_t S0, const tgmx_tgat_hop_t* hops) {
+  tgmx_tgat_layout_t lay;
+  return tgmx_tgat_layout(m, S0, hops, 0, &lay) == TGMX_OK ? (size_t)lay.total_bytes : 0;
 }
 
 extern "C" int tgmx_tgat_forward(const tgmx_tgat_model_t* m, const float* node_x, int64_t num_nodes, const int32_t* seed_ids,
-                                 int64_t S0, const tgmx_tgat_hop_t* hops, float* workspace, size_t workspace_bytes, float* out,
-                                 tgmx_stream_t stream) {
+                                 int64_t S0, const tgmx_tgat_hop_t* hops, float* workspace, size_t workspace_bytes, int32_t save,
+                                 float* out, tgmx_stream_t stream) {
   TGMX_REQUIRE(m && hops && node_x && seed_ids && out, "tgat_forward: null pointer");
-  const int L = m->num_layers;
-  TGMX_REQUIRE(L >= 1 && L <= TGMX_TGAT_MAX_LAYERS, "tgat_forward: num_layers=%d outside [1, %d]", L, TGMX_TGAT_MAX_LAYERS);
   if (S0 == 0) return TGMX_OK;
-  TGMX_REQUIRE(workspace && workspace_bytes >= tgmx_tgat_workspace_bytes(m, S0, hops), "tgat_forward: workspace too small");
-  const int d0 = m->d0;
-  long long rows[TGMX_TGAT_MAX_LAYERS + 1], off[TGMX_TGAT_MAX_LAYERS + 2];
-  rows[0] = S0;
-  for (int i = 0; i < L; ++i) rows[i + 1] = rows[i] * hops[i].k;
-  off[0] = 0;
-  for (int i = 0; i <= L; ++i) off[i + 1] = off[i] + rows[i];
-
-  float* w = reinterpret_cast<float*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
-  auto take = [&](size_t n) { float* p = w; w += align_up(n); return p; };
-  float* z0 = take((size_t)off[L + 1] * d0);
-  size_t emb_rows = 0;  // ping-pong buffers for the layer outputs
-  for (int j = 1; j <= L; ++j) {
-    const size_t e = (size_t)off[L - j + 1] * pad4(m->layers[j - 1].emb_out);
-    emb_rows = e > emb_rows ? e : emb_rows;
-  }
-  float* pp[2] = {take(emb_rows), take(emb_rows)};
-  float* scratch0 = w;
-
-  int rc;
-  // leaves: z0[level i] = node_x[V_i], V_0 = seeds, V_i = hop (i-1) neighbor ids (pad -1 -> last row)
-  rc = tgmx_gather_rows(node_x, num_nodes, d0, seed_ids, rows[0], z0, d0, stream);
+  tgmx_tgat_layout_t lay;
+  int rc = tgmx_tgat_layout(m, S0, hops, save, &lay);
   if (rc) return rc;
-  for (int i = 1; i <= L; ++i) {
-    rc = tgmx_gather_rows(node_x, num_nodes, d0, hops[i - 1].nbr_id, rows[i], z0 + off[i] * d0, d0, stream);
-    if (rc) return rc;
-  }
+  TGMX_REQUIRE(workspace && workspace_bytes >= (size_t)lay.total_bytes, "tgat_forward: workspace too small (%zu < %lld)", workspace_bytes,
+               (long long)lay.total_bytes);
+  const int L = m->num_layers, d0 = m->d0;
+  const int64_t* off = lay.level_off;
+  const int64_t* rows = lay.level_rows;
+  float* base = reinterpret_cast<float*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  float* z0 = base + lay.z0;
+
+  // leaves: z0[level i] = node_x[V_i], V_0 = seeds, V_i = hop (i-1) neighbor ids (pad -1 -> last row)
+  if ((rc = tgmx_gather_rows(node_x, num_nodes, d0, seed_ids, rows[0], z0, d0, stream))) return rc;
+  for (int i = 1; i <= L; ++i)
+    if ((rc = tgmx_gather_rows(node_x, num_nodes, d0, hops[i - 1].nbr_id, rows[i], z0 + off[i] * d0, d0, stream))) return rc;
 
   const float* prev = z0;
   long long ld_prev = d0;
   for (int j = 1; j <= L; ++j) {
     const tgmx_tgat_layer_t& ly = m->layers[j - 1];
+    const tgmx_tgat_layer_layout_t& lo = lay.layers[j - 1];
     const int n_lvl = L - j + 1;
-    const long long R = off[n_lvl];
+    const long long R = lo.R;
     const int O = ly.O, H = ly.H, dh = O / H, C = ly.d + ly.D + ly.T, k = hops[j - 1].k;
-    const int Op = pad4(O), dhp = pad4(dh), Cp = pad4(C), Kc = pad4(O + d0), Ep = pad4(ly.emb);
+    const int Op = lo.Op, dhp = lo.dhp, Cp = lo.Cp, Kc = lo.Kc, Ep = lo.Ep;
     TGMX_REQUIRE(ly.d == (j == 1 ? d0 : m->layers[j - 2].emb_out), "tgat_forward: layer %d input width mismatch", j);
-    w = scratch0;
-    float* rres = take((size_t)R * Op);
-    float* oattn = take((size_t)R * Op);
-    float* y = take((size_t)R * Op);
-    float* Q = take((size_t)R * H * dhp);
-    float* qf = take((size_t)R * H * Cp);
-    float* zbar = take((size_t)R * H * Cp);
-    float* cat = take((size_t)R * Kc);
-    float* h1 = take((size_t)R * Ep);
-    const bool last = j == L;
-    float* nxt = last ? out : pp[j & 1];
+    float *rres = base + lo.rres, *oattn = base + lo.oattn, *y = base + lo.y, *Q = base + lo.Q, *qf = base + lo.qf;
+    float *zbar = base + lo.zbar, *cat = base + lo.cat, *h1 = base + lo.h1;
+    float* probs = lo.probs >= 0 ? base + lo.probs : nullptr;
+    float* nxt = (j == L) ? out : base + lo.out;
     const long long ld_nxt = ly.emb_out;  // layer outputs stay densely packed: they are the next layer's neighbor features
     if ((rc = tgmx_tgat_rres(prev, ld_prev, ly.d, m->tb, nullptr, ly.T, O, R, rres, Op, stream))) return rc;
     // Q[:, head h] = rres @ W_Q[head h rows]^T     (heads written dhp apart)
@@ -780,7 +799,7 @@ extern "C" int tgmx_tgat_forward(const tgmx_tgat_model_t* m, const float* node_x
       const float* nbrf = prev + off[i + 1] * ld_prev;
       if ((rc = tgmx_tgat_attn_reduce(qf + off[i] * (long long)H * Cp, nbrf, ly.d, hops[i].edge_x, ly.D, hops[i].seed_t, hops[i].nbr_t,
                                       hops[i].nbr_id, m->tw, m->tb, nullptr, nullptr, ly.T, H, k, rows[i], 1.0f / sqrtf((float)dh), Cp,
-                                      zbar + off[i] * (long long)H * Cp, stream)))
+                                      zbar + off[i] * (long long)H * Cp, probs ? probs + off[i] * (long long)H * k : nullptr, stream)))
         return rc;
     }
     // Oattn[:, head h] = zbar[:, h, :] @ W_V[head h]^T   (W_V padded copy [O, Cp])

@@ -1,0 +1,452 @@
+// TGAT backward building blocks (fp32) for gfx950 -- the training path of the folded attention
+// (forward: tgat.hip; mathematics: oracle/tgat_fold.py, differentiated by hand).
+//
+//   sgemm_tn        dW[M,N] = sum_r A[r,m] B[r,n]   weight gradients: reduction over the ROW index, both
+//                   operands read row-major (coalesced along m / n), exact-fp32 MFMA, rows split over
+//                   blocks into partials that a second kernel sums in a fixed order (deterministic)
+//   colsum          bias / LayerNorm / Time2Vec parameter gradients (same two-stage scheme)
+//   ln_backward     per-row LayerNorm backward (one wave per row)
+//   attn_backward   per-row backward of masked-softmax attention over the k slots (one wave per row):
+//                   d(folded query), d(neighbor features), per-row Time2Vec gradient partials
+// The "NN" products (dX = dY W) reuse sgemm_nt with transposed weight copies.
+#include "common.h"
+
+namespace tgmx {
+
+using floatx16 = __attribute__((__vector_size__(16 * sizeof(float)))) float;
+
+// sin counterpart of cos_t2v (same double-precision range reduction)
+__device__ __forceinline__ float sin_t2v(float x) {
+  const double xd = (double)x;
+  const double kd = __builtin_rint(xd * 0.63661977236758134308);
+  double r = __builtin_fma(-kd, 1.57079632679489655800e+00, xd);
+  r = __builtin_fma(-kd, 6.12323399573676603587e-17, r);
+  const float rf = (float)r;
+  const int q = (int)((long long)kd & 3);
+  const float r2 = rf * rf;
+  float sp = -1.9515295891e-4f;
+  sp = __fmaf_rn(sp, r2, 8.3321608736e-3f);
+  sp = __fmaf_rn(sp, r2, -1.6666654611e-1f);
+  const float sn = __fmaf_rn(sp * r2, rf, rf);
+  float cp = 2.443315711809948e-5f;
+  cp = __fmaf_rn(cp, r2, -1.388731625493765e-3f);
+  cp = __fmaf_rn(cp, r2, 4.166664568298827e-2f);
+  const float cs = __fmaf_rn(cp * r2, r2, __fmaf_rn(-0.5f, r2, 1.0f));
+  const float v = (q & 1) ? cs : sn;  // q: 0 -> sin r, 1 -> cos r, 2 -> -sin r, 3 -> -cos r
+  return (q >= 2) ? -v : v;
+}
+
+// ---------------------------------------------------------------------------
+// partial[z][m][n] = sum over rows r in split z of A[r, m] * B[r, n]
+// ---------------------------------------------------------------------------
+struct GemmTnArgs {
+  const float* A;
+  const float* B;
+  float* partial;  // [batch, splits, M, N]
+  long long lda, ldb, sA, sB;
+  long long R, rows_per_split;
+  int M, N, splits;
+};
+
+__global__ __launch_bounds__(256) void sgemm_tn_kernel(const GemmTnArgs g) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, half = lane >> 5;
+  const int batch = blockIdx.z / g.splits, split = blockIdx.z - batch * g.splits;
+  const int m0 = (blockIdx.x * 4 + wave) * 32;
+  if (m0 >= g.M) return;
+  const int n0 = blockIdx.y * 64;
+  const float* __restrict__ A = g.A + (long long)batch * g.sA;
+  const float* __restrict__ B = g.B + (long long)batch * g.sB;
+  const long long r0 = (long long)split * g.rows_per_split;
+  long long r1 = r0 + g.rows_per_split;
+  if (r1 > g.R) r1 = g.R;
+  // columns past the edge are clamped for the loads; their results are never stored
+  const int ma = m0 + i < g.M ? m0 + i : g.M - 1;
+  const int nb0 = n0 + i < g.N ? n0 + i : g.N - 1;
+  const int nb1 = n0 + 32 + i < g.N ? n0 + 32 + i : g.N - 1;
+  floatx16 acc0 = {0}, acc1 = {0};
+  for (long long r = r0; r < r1; r += 8) {  // 4 MFMA steps (k = 2 rows each) per iteration
+    float a[4], b0[4], b1[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long long rr = r + 2 * u + half;
+      const bool ok = rr < r1;
+      const long long rc = ok ? rr : r0;
+      const float av = A[rc * g.lda + ma], bv0 = B[rc * g.ldb + nb0], bv1 = B[rc * g.ldb + nb1];
+      a[u] = ok ? av : 0.f;
+      b0[u] = ok ? bv0 : 0.f;
+      b1[u] = ok ? bv1 : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b0[u], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b1[u], acc1, 0, 0, 0);
+    }
+  }
+  float* __restrict__ P = g.partial + ((long long)batch * g.splits + split) * g.M * g.N;
+#pragma unroll
+  for (int rg = 0; rg < 16; ++rg) {
+    const int row = m0 + (rg & 3) + 8 * (rg >> 2) + 4 * half;
+    if (row >= g.M) continue;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int col = n0 + t * 32 + i;
+      if (col < g.N) P[(long long)row * g.N + col] = t ? acc1[rg] : acc0[rg];
+    }
+  }
+}
+
+// out[b][m * ldo + n] (+)= sum_s partial[b][s][m][n]   (fixed summation order: deterministic)
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int splits, int M, int N,
+                                                              float* __restrict__ out, long long ldo, long long s_out, int accumulate) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long MN = (long long)M * N;
+  if (e >= MN) return;
+  const float* p = partial + (long long)blockIdx.y * splits * MN + e;
+  float acc = 0.f;
+  for (int s = 0; s < splits; ++s) acc += p[(long long)s * MN];
+  const int m = (int)(e / N), n = (int)(e - (long long)m * N);
+  float* o = out + (long long)blockIdx.y * s_out + (long long)m * ldo + n;
+  *o = accumulate ? *o + acc : acc;
+}
+
+// partial[z][c] = sum over rows of split z of in[r * ld + c] * (scale ? scale[c] : 1)
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ in, long long ld, long long R, int C,
+                                                             long long rows_per_split, float* __restrict__ partial) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const long long r0 = (long long)blockIdx.y * rows_per_split;
+  long long r1 = r0 + rows_per_split;
+  if (r1 > R) r1 = R;
+  float acc = 0.f;
+  for (long long r = r0; r < r1; ++r) acc += in[r * ld + c];
+  partial[(long long)blockIdx.y * C + c] = acc;
+}
+
+// g[r, c] = h[r, c] > 0 ? g[r, c] : 0
+__global__ __launch_bounds__(256) void relu_mask_kernel(float* __restrict__ g, long long ldg, const float* __restrict__ h, long long ldh,
+                                                        long long R, int C) {
+  const long long total = R * C;
+  const long long step = (long long)gridDim.x * blockDim.x;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += step) {
+    const long long r = e / C;
+    const int c = (int)(e - r * C);
+    if (!(h[r * ldh + c] > 0.f)) g[r * ldg + c] = 0.f;
+  }
+}
+
+// dst[r, c] (+)= src[r, c] for c < C
+__global__ __launch_bounds__(256) void add_cols_kernel(float* __restrict__ dst, long long ldd, const float* __restrict__ src, long long lds,
+                                                       long long R, int C, int accumulate) {
+  const long long total = R * C;
+  const long long step = (long long)gridDim.x * blockDim.x;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += step) {
+    const long long r = e / C;
+    const int c = (int)(e - r * C);
+    const float v = src[r * lds + c];
+    dst[r * ldd + c] = accumulate ? dst[r * ldd + c] + v : v;
+  }
+}
+
+// LayerNorm backward, one wave per row: u = y + res, xhat = (u - mean) * rstd,
+//   du = rstd * (g*dout - mean(g*dout) - xhat * mean(g*dout*xhat)),  dgx = dout * xhat
+__global__ __launch_bounds__(256) void ln_backward_kernel(const float* __restrict__ dout, long long ldd, const float* __restrict__ y,
+                                                          long long ldy, const float* __restrict__ res, long long ldr,
+                                                          const float* __restrict__ gamma, int O, float eps, long long R,
+                                                          float* __restrict__ du, long long ldu, float* __restrict__ dgx, long long ldg) {
+  const int lane = lane_id();
+  const long long r = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const float* yr = y + r * ldy;
+  const float* rr = res + r * ldr;
+  const float* dr = dout + r * ldd;
+  float s = 0.f;
+  for (int c = lane; c < O; c += kWave) s += yr[c] + rr[c];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float mean = s / (float)O;
+  float v = 0.f;
+  for (int c = lane; c < O; c += kWave) {
+    const float t = yr[c] + rr[c] - mean;
+    v += t * t;
+  }
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  const float rstd = 1.0f / sqrtf(v / (float)O + eps);
+  float a1 = 0.f, a2 = 0.f;
+  for (int c = lane; c < O; c += kWave) {
+    const float xh = (yr[c] + rr[c] - mean) * rstd;
+    const float gd = gamma[c] * dr[c];
+    a1 += gd;
+    a2 += gd * xh;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    a1 += __shfl_xor(a1, o);
+    a2 += __shfl_xor(a2, o);
+  }
+  a1 /= (float)O;
+  a2 /= (float)O;
+  for (int c = lane; c < O; c += kWave) {
+    const float xh = (yr[c] + rr[c] - mean) * rstd;
+    du[r * ldu + c] = rstd * (gamma[c] * dr[c] - a1 - xh * a2);
+    dgx[r * ldg + c] = dr[c] * xh;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// attention backward, one wave per row (k * H <= 64)
+// ---------------------------------------------------------------------------
+struct AttnBwdArgs {
+  const float* qf;      // [R, H, Cs]
+  const float* probs;   // [R, H, k]
+  const float* dzbar;   // [R, H, Cs]
+  const float* nbrf;    // [R, k, d]
+  const float* ex;      // [R, k, D]
+  const int64_t* seed_t;
+  const int64_t* nbr_t;
+  const float* tw;
+  const float* tb;
+  float* dqf;           // [R, H, Cs]
+  float* dnbr;          // [R, k, d] accumulated (+=), may be null
+  float* dtime;         // [R, 2T]: per-row partials of d(tw) | d(tb)
+  long long R;
+  int d, D, T, k, C, Cs;
+  float scale;
+};
+
+template <int HALF>
+__device__ __forceinline__ void bwd_reduce_scatter_step(float (&P)[64], int lane) {
+  const bool upper = (lane & HALF) != 0;
+#pragma unroll
+  for (int i = 0; i < HALF; ++i) {
+    const float send = upper ? P[i] : P[i + HALF];
+    const float recv = __shfl_xor(send, HALF);
+    const float keep = upper ? P[i + HALF] : P[i];
+    P[i] = keep + recv;
+  }
+}
+
+template <int H>
+__global__ __launch_bounds__(256) void tgat_attn_backward_kernel(const AttnBwdArgs a) {
+  constexpr int G = 64 / H;
+  extern __shared__ __attribute__((aligned(16))) float lds_all[];
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  const int k = a.k, T = a.T, d = a.d, D = a.D, Cs = a.Cs;
+  float* s_cos = lds_all + (size_t)wave * (2 * k * T + k + 2 * H * k);
+  float* s_sin = s_cos + k * T;
+  float* s_dt = s_sin + k * T;
+  float* s_A = s_dt + k;
+  float* s_ds = s_A + H * k;
+  const long long r = (long long)blockIdx.x * (blockDim.x >> 6) + wave;
+  if (r >= a.R) return;
+  const float* __restrict__ q = a.qf + r * (long long)H * Cs;
+  const float* __restrict__ dz = a.dzbar + r * (long long)H * Cs;
+  const float* __restrict__ nb = a.nbrf + r * (long long)k * d;
+  const float* __restrict__ ex = a.ex + r * (long long)k * D;
+
+  const long long st = a.seed_t[r];
+  for (int s = lane; s < k; s += kWave) s_dt[s] = (float)(st - a.nbr_t[r * k + s]);
+  __builtin_amdgcn_wave_barrier();
+  for (int e = lane; e < k * T; e += kWave) {
+    const int s = e / T, t = e - s * T;
+    const float arg = __fmaf_rn(s_dt[s], a.tw[t], a.tb[t]);
+    s_cos[e] = cos_t2v(arg);
+    s_sin[e] = sin_t2v(arg);
+  }
+  __builtin_amdgcn_wave_barrier();
+
+  // ---- dA[h][s] = dzbar[h] . z[s] ----
+  float P[64];
+#pragma unroll
+  for (int j = 0; j < 64; ++j) P[j] = 0.f;
+  auto accumulate = [&](const float* __restrict__ base, long long slot_stride, int dim, int col0) {
+    for (int c = lane; c < dim; c += kWave) {
+      float gv[H];
+#pragma unroll
+      for (int h = 0; h < H; ++h) gv[h] = dz[h * Cs + col0 + c];
+#pragma clang loop unroll(full)
+      for (int s = 0; s < G; ++s) {
+        const int sl = s < k ? s : k - 1;
+        const float z = base[(long long)sl * slot_stride + c];
+#pragma unroll
+        for (int h = 0; h < H; ++h) P[s * H + h] = __fmaf_rn(gv[h], z, P[s * H + h]);
+      }
+    }
+  };
+  accumulate(nb, d, d, 0);
+  if (D > 0) accumulate(ex, D, D, d);
+  accumulate(s_cos, T, T, d + D);
+  bwd_reduce_scatter_step<32>(P, lane);
+  bwd_reduce_scatter_step<16>(P, lane);
+  bwd_reduce_scatter_step<8>(P, lane);
+  bwd_reduce_scatter_step<4>(P, lane);
+  bwd_reduce_scatter_step<2>(P, lane);
+  bwd_reduce_scatter_step<1>(P, lane);
+  const float dA = P[0];  // lane j = s*H + h
+  const int js = lane / H, jh = lane - js * H;
+  const bool live = js < k;
+  const float A = live ? a.probs[r * (long long)H * k + jh * k + js] : 0.f;
+  float dot = A * dA;
+#pragma unroll
+  for (int o = H; o < 64; o <<= 1) dot += __shfl_xor(dot, o);
+  const float ds = A * (dA - dot);  // softmax backward; masked slots have A == 0
+  if (live) {
+    s_A[jh * k + js] = A;
+    s_ds[jh * k + js] = ds;
+  }
+  __builtin_amdgcn_wave_barrier();
+
+  // ---- dqf[h][c] = scale * sum_s ds[h][s] z[s][c];  dz[s][c] = sum_h A dzbar + scale * ds * qf ----
+  float* __restrict__ dq = a.dqf + r * (long long)H * Cs;
+  auto columns = [&](const float* __restrict__ base, long long slot_stride, int dim, int col0, int part) {
+    for (int c = lane; c < dim; c += kWave) {
+      float acc[H], gv[H], qv[H];
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        acc[h] = 0.f;
+        gv[h] = dz[h * Cs + col0 + c];
+        qv[h] = q[h * Cs + col0 + c];
+      }
+      float dw = 0.f, db = 0.f;
+      for (int s = 0; s < k; ++s) {
+        const float z = base[(long long)s * slot_stride + c];
+        float dzs = 0.f;
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+          acc[h] = __fmaf_rn(s_ds[h * k + s], z, acc[h]);
+          dzs += s_A[h * k + s] * gv[h] + a.scale * s_ds[h * k + s] * qv[h];
+        }
+        if (part == 0 && a.dnbr) a.dnbr[(r * k + s) * (long long)d + c] += dzs;
+        if (part == 2) {
+          const float g = -s_sin[s * T + c] * dzs;  // d cos(arg) / d arg
+          dw = __fmaf_rn(g, s_dt[s], dw);
+          db += g;
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < H; ++h) dq[h * Cs + col0 + c] = acc[h] * a.scale;
+      if (part == 2) {
+        a.dtime[r * 2LL * T + c] = dw;
+        a.dtime[r * 2LL * T + T + c] = db;
+      }
+    }
+  };
+  columns(nb, d, d, 0, 0);
+  if (D > 0) columns(ex, D, D, d, 1);
+  columns(s_cos, T, T, d + D, 2);
+}
+
+}  // namespace tgmx
+
+using namespace tgmx;
+
+static int pick_splits(long long R, long long tiles) {
+  // enough (tile, split) work items to fill ~1024 SIMDs, at least 64 rows per split
+  long long s = (2048 + tiles - 1) / tiles;
+  const long long max_s = (R + 63) / 64;
+  if (s > max_s) s = max_s;
+  if (s < 1) s = 1;
+  if (s > 512) s = 512;
+  return (int)s;
+}
+
+extern "C" size_t tgmx_sgemm_tn_workspace_bytes(int64_t R, int32_t M, int32_t N, int32_t batch) {
+  const long long tiles = (long long)((M + 31) / 32) * ((N + 63) / 64) * batch;
+  return (size_t)pick_splits(R, tiles) * (size_t)M * N * batch * sizeof(float);
+}
+
+extern "C" int tgmx_sgemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t R, int32_t M,
+                             int32_t N, int32_t batch, int64_t strideA, int64_t strideB, int64_t strideC, int32_t accumulate,
+                             float* workspace, tgmx_stream_t stream) {
+  TGMX_REQUIRE(R >= 0 && M > 0 && N > 0 && batch > 0 && lda >= M && ldb >= N && ldc >= N, "sgemm_tn: bad sizes");
+  TGMX_REQUIRE(A && B && C && workspace, "sgemm_tn: null pointer");
+  const long long tiles = (long long)((M + 31) / 32) * ((N + 63) / 64) * batch;
+  const int splits = R > 0 ? pick_splits(R, tiles) : 1;
+  GemmTnArgs g{A, B, workspace, lda, ldb, strideA, strideB, R, R > 0 ? (R + splits - 1) / splits : 0, M, N, splits};
+  g.rows_per_split = (g.rows_per_split + 7) / 8 * 8;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(sgemm_tn_kernel, dim3((unsigned)((M + 127) / 128), (unsigned)((N + 63) / 64), (unsigned)(batch * splits)), dim3(256), 0, st, g);
+  const long long MN = (long long)M * N;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((MN + 255) / 256), (unsigned)batch), dim3(256), 0, st, workspace, splits, M, N, C,
+                     (long long)ldc, (long long)strideC, accumulate);
+  TGMX_CHECK_LAUNCH("sgemm_tn");
+  return TGMX_OK;
+}
+
+extern "C" int tgmx_colsum(const float* in, int64_t ld, int64_t R, int32_t C, float* out, int32_t accumulate, float* workspace,
+                           tgmx_stream_t stream) {
+  TGMX_REQUIRE(R >= 0 && C > 0 && ld >= C, "colsum: bad sizes");
+  TGMX_REQUIRE(in && out && workspace, "colsum: null pointer");
+  int splits = (int)((R + 255) / 256);
+  if (splits > 256) splits = 256;
+  if (splits < 1) splits = 1;
+  const long long rps = (R + splits - 1) / splits;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)((C + 255) / 256), (unsigned)splits), dim3(256), 0, st, in, (long long)ld,
+                     (long long)R, C, rps, workspace);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((C + 255) / 256), 1), dim3(256), 0, st, workspace, splits, 1, C, out, (long long)C,
+                     0LL, accumulate);
+  TGMX_CHECK_LAUNCH("colsum");
+  return TGMX_OK;
+}
+
+extern "C" int tgmx_relu_mask(float* grad, int64_t ldg, const float* act, int64_t lda, int64_t R, int32_t C, tgmx_stream_t stream) {
+  TGMX_REQUIRE(R >= 0 && C > 0, "relu_mask: bad sizes");
+  if (R == 0) return TGMX_OK;
+  TGMX_REQUIRE(grad && act, "relu_mask: null pointer");
+  long long blocks = (R * C + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, grad, (long long)ldg, act, (long long)lda,
+                     (long long)R, C);
+  TGMX_CHECK_LAUNCH("relu_mask");
+  return TGMX_OK;
+}
+
+extern "C" int tgmx_add_cols(float* dst, int64_t ldd, const float* src, int64_t lds, int64_t R, int32_t C, int32_t accumulate,
+                             tgmx_stream_t stream) {
+  TGMX_REQUIRE(R >= 0 && C > 0, "add_cols: bad sizes");
+  if (R == 0) return TGMX_OK;
+  TGMX_REQUIRE(dst && src, "add_cols: null pointer");
+  long long blocks = (R * C + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(add_cols_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dst, (long long)ldd, src, (long long)lds,
+                     (long long)R, C, accumulate);
+  TGMX_CHECK_LAUNCH("add_cols");
+  return TGMX_OK;
+}
+
+extern "C" int tgmx_ln_backward(const float* dout, int64_t ldd, const float* y, int64_t ldy, const float* res, int64_t ldr,
+                                const float* gamma, int32_t O, float eps, int64_t R, float* du, int64_t ldu, float* dgx, int64_t ldg,
+                                tgmx_stream_t stream) {
+  TGMX_REQUIRE(O > 0 && R >= 0, "ln_backward: bad sizes");
+  if (R == 0) return TGMX_OK;
+  TGMX_REQUIRE(dout && y && res && gamma && du && dgx, "ln_backward: null pointer");
+  hipLaunchKernelGGL(ln_backward_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dout, (long long)ldd, y,
+                     (long long)ldy, res, (long long)ldr, gamma, O, eps, (long long)R, du, (long long)ldu, dgx, (long long)ldg);
+  TGMX_CHECK_LAUNCH("ln_backward");
+  return TGMX_OK;
+}
+
+extern "C" int tgmx_tgat_attn_backward(const float* qf, const float* probs, const float* dzbar, const float* nbrf, int32_t d,
+                                       const float* ex, int32_t D, const int64_t* seed_t, const int64_t* nbr_t, const float* tw,
+                                       const float* tb, int32_t T, int32_t H, int32_t k, int64_t R, float scale, int32_t head_stride,
+                                       float* dqf, float* dnbr, float* dtime_rows, tgmx_stream_t stream) {
+  TGMX_REQUIRE(d > 0 && D >= 0 && T > 0 && k > 0 && R >= 0, "tgat_attn_backward: bad sizes");
+  TGMX_REQUIRE((H == 1 || H == 2 || H == 4 || H == 8) && k * H <= 64, "tgat_attn_backward: needs n_heads in {1,2,4,8} and k * n_heads <= 64 (k=%d, H=%d)", k, H);
+  if (R == 0) return TGMX_OK;
+  TGMX_REQUIRE(qf && probs && dzbar && nbrf && (D == 0 || ex) && seed_t && nbr_t && tw && tb && dqf && dtime_rows, "tgat_attn_backward: null pointer");
+  const int C = d + D + T;
+  AttnBwdArgs a{qf, probs, dzbar, nbrf, ex, seed_t, nbr_t, tw, tb, dqf, dnbr, dtime_rows, R, d, D, T, k, C, head_stride ? head_stride : C, scale};
+  const size_t per_wave = ((size_t)2 * k * T + k + 2 * (size_t)H * k) * sizeof(float);
+  int waves = 4;
+  while (waves > 1 && per_wave * waves > 64 * 1024) waves >>= 1;
+  TGMX_REQUIRE(per_wave * waves <= 64 * 1024, "tgat_attn_backward: k*T=%d too large for LDS", k * T);
+  const dim3 grid((unsigned)((R + waves - 1) / waves)), block(waves * kWave);
+  hipStream_t st = (hipStream_t)stream;
+  switch (H) {
+    case 1: hipLaunchKernelGGL(tgat_attn_backward_kernel<1>, grid, block, per_wave * waves, st, a); break;
+    case 2: hipLaunchKernelGGL(tgat_attn_backward_kernel<2>, grid, block, per_wave * waves, st, a); break;
+    case 4: hipLaunchKernelGGL(tgat_attn_backward_kernel<4>, grid, block, per_wave * waves, st, a); break;
+    default: hipLaunchKernelGGL(tgat_attn_backward_kernel<8>, grid, block, per_wave * waves, st, a); break;
+  }
+  TGMX_CHECK_LAUNCH("tgat_attn_backward");
+  return TGMX_OK;
+}

@@ -41,7 +41,7 @@ class TemporalAttention(nn.Module):
     # ------------------------------------------------------------------
     def _check_mode(self) -> None:
         if self.training and self.dropout.p > 0:
-            raise NotImplementedError('tgm_amd TemporalAttention: training-mode dropout / backward are not implemented yet; call .eval()')
+            raise NotImplementedError('tgm_amd TemporalAttention: dropout is not implemented; build the model with dropout=0 (training) or call .eval()')
 
     def attend(
         self,
@@ -81,7 +81,7 @@ class TemporalAttention(nn.Module):
             lib.tgmx_tgat_attn_reduce(
                 qf.data_ptr(), nbrf.data_ptr(), d, _native.ptr(ex), D, _native.ptr(seed_t), _native.ptr(nbr_t), _native.ptr(nbr_id),
                 _native.ptr(tw), _native.ptr(tb), _native.ptr(nbr_time_feat), _native.ptr(mask), T, H, k, R, float(dh) ** -0.5, 0,
-                zbar.data_ptr(), stream,
+                zbar.data_ptr(), 0, stream,
             ),
             'tgmx_tgat_attn_reduce',
         )  # fmt: skip

@@ -10,7 +10,9 @@ Parameter names match the reference (``time_encoder.w.*``, ``attn.{l}.*``,
   the valid-neighbor mask are computed inside the attention kernel from the sampler's
   raw outputs (timestamps, ids): the [R, k, C] key tensor never exists.
 
-Forward / eval only for now (see ``TemporalAttention``).
+With gradients enabled the forward keeps its intermediates and a hand-written backward
+(``nn/_tgat_train.py``, ``csrc/tgat_bwd.hip``) produces the parameter gradients; dropout must be
+inactive (p == 0 or ``.eval()``).
 """
 from __future__ import annotations
 
@@ -136,6 +138,13 @@ class TGAT(nn.Module):
             h = hops[i]
             h.seed_t, h.nbr_id, h.nbr_t, h.edge_x, h.k = st.data_ptr(), nid.data_ptr(), nt.data_ptr(), _native.ptr(ex), nid.shape[-1]
             rows *= nid.shape[-1]
+        if S0 and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            # training: same native forward with every intermediate kept, hand-written backward (nn/_tgat_train.py)
+            from ._tgat_train import TGATFunction
+
+            flat = [t for i in range(L) for t in hold[4 * i : 4 * i + 4]]
+            flat = [flat[4 * i + j] for i in range(L) for j in (3, 0, 1, 2)]  # (seed_t, nbr_id, nbr_t, edge_x) per hop
+            return TGATFunction.apply(self, node_x, seeds, flat, [int(hops[i].k) for i in range(L)], *self.parameters())
         out = torch.empty((S0, self.embed_dim), dtype=torch.float32, device=dev)
         if S0 == 0:
             return out
@@ -144,7 +153,7 @@ class TGAT(nn.Module):
         if ws is None or ws.device != dev or ws.numel() < need:
             ws = self._workspace = torch.empty(need, dtype=torch.uint8, device=dev)
         _native.check(
-            lib.tgmx_tgat_forward(model, node_x.data_ptr(), node_x.shape[0], seeds.data_ptr(), S0, hops, ws.data_ptr(), ws.numel(),
+            lib.tgmx_tgat_forward(model, node_x.data_ptr(), node_x.shape[0], seeds.data_ptr(), S0, hops, ws.data_ptr(), ws.numel(), 0,
                                   out.data_ptr(), _native.stream_ptr()),
             'tgmx_tgat_forward',
         )  # fmt: skip
