@@ -114,6 +114,47 @@ int tgmx_ring_update(tgmx_adj_t* ring, int32_t* write_pos, float* ring_x, int32_
                      const float* edge_x, int64_t n, int64_t eid0, int32_t directed, int32_t key_wrap32,
                      int32_t* scratch, int32_t* status, tgmx_stream_t stream);
 
+/* One whole hook call, RecencyNeighborHook.__call__ (recency.py:119-171), as ONE entry point: concatenate the
+ * hop-0 seed groups (recency.py:173-237), run every hop's lookup (hop h+1 reads hop h's outputs in place, pads
+ * included, recency.py:140-159), then append the batch to the rings (recency.py:161-163 -> :323-399).
+ * Semantics are exactly tgmx_ring_lookup x n_hops followed by tgmx_ring_update; the seed concatenation rides
+ * on the hop-0 lookup launch (its wave of seed s reads group g's arrays and publishes seed_nid0[s] / seed_ts0[s]).
+ *   n_groups = 0: hop-0 seeds are already in seed_nid0 / seed_ts0 (S0 of them).
+ *   n_hops   = 0: update only.          n = 0: lookups only.
+ *   timed_hop >= 0: ev_start / ev_stop are recorded around that hop's lookup launch. */
+#define TGMX_MAX_SEED_GROUPS 8
+#define TGMX_MAX_HOPS 8
+typedef struct tgmx_ring_step {
+  tgmx_adj_t* ring;            /* [num_nodes, B] records */
+  int32_t* write_pos;          /* [num_nodes] */
+  float* ring_x;               /* [num_nodes, B, D] */
+  int32_t D, B, num_nodes;
+  int32_t n_groups;
+  const int32_t* grp_nid[TGMX_MAX_SEED_GROUPS];
+  const int64_t* grp_ts[TGMX_MAX_SEED_GROUPS];
+  int64_t grp_n[TGMX_MAX_SEED_GROUPS];
+  int32_t* seed_nid0;          /* [S0] hop-0 seeds (output when n_groups > 0, input otherwise) */
+  int64_t* seed_ts0;           /* [S0] */
+  int64_t S0;                  /* used only when n_groups == 0 */
+  int32_t n_hops;
+  int32_t k[TGMX_MAX_HOPS];
+  int32_t* out_nid[TGMX_MAX_HOPS];  /* [S_h, k_h] */
+  int64_t* out_ts[TGMX_MAX_HOPS];   /* [S_h, k_h] */
+  float* out_x[TGMX_MAX_HOPS];      /* [S_h, k_h, D] */
+  const int32_t* src;          /* batch edges (n = 0: no update) */
+  const int32_t* dst;
+  const int64_t* ts;
+  const float* edge_x;         /* [n, D] or NULL */
+  int64_t n, eid0;
+  int32_t directed, key_wrap32;
+  int32_t* scratch;            /* >= 12 * m + 16 int32 */
+  int32_t* status;
+  int32_t timed_hop;           /* -1: none */
+  tgmx_event_t ev_start, ev_stop;
+} tgmx_ring_step_t;
+
+int tgmx_ring_step(const tgmx_ring_step_t* step, tgmx_stream_t stream);
+
 /* ring.fill(pad), write_pos.zero_()  (recency.py:111-117) */
 int tgmx_ring_reset(tgmx_adj_t* ring, int32_t* write_pos, int32_t B, int32_t num_nodes,
                     tgmx_stream_t stream);

@@ -113,10 +113,14 @@ class RingSamplerCPU:
         node_k, nbr_k, t_k, x_k = node_s[keep], nbr_s[keep], t_s[keep], x_s[keep]
         off_k = (rank - drop)[keep]
         slot = (self.wpos[node_k] + off_k) % B
-        # duplicates (runs of one node colliding): sequential assignment, last wins
-        self.ids[node_k, slot] = nbr_k.to(torch.int32)
-        self.times[node_k, slot] = t_k
-        self.feats[node_k, slot] = x_k
+        # Duplicate (node, slot) targets (runs of one node colliding): the reference's index_put_ (recency.py:381-395)
+        # runs serially -- last assignment wins -- up to 3000 scattered elements; above that torch parallelises the
+        # scatter and the winner is a thread race, i.e. unspecified.  The restatement defines last-wins at every size
+        # (numpy fancy assignment is sequential), which is what the kernels implement.
+        nk, sl = node_k.numpy(), slot.numpy()
+        self.ids.numpy()[nk, sl] = nbr_k.to(torch.int32).numpy()
+        self.times.numpy()[nk, sl] = t_k.numpy()
+        self.feats.numpy()[nk, sl] = x_k.numpy()
         self.wpos += torch.bincount(node_k, minlength=self.N)
 
     # ------------------------------------------------------------------

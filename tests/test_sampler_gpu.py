@@ -158,20 +158,41 @@ def _random_stream(seed, N, E, D, tmax):
         (500, 5000, 3, 1000, [70], 128, True, 'int32'),  # B > 64: general (chunked) path
         (200, 4000, 6, 400, [3, 8, 2], 50, False, 'int32'),  # k < B on some hops, heavy ties
         (100, 3000, 0, 300, [4, 4], 37, False, 'int32'),  # no edge features
-        (50, 3000, 5, 200, [20], 1000, False, 'int32'),  # runs longer than B inside one batch (fused update, m=2000)
+        (50, 3000, 5, 200, [20], 1000, False, 'int32'),  # runs longer than B inside one batch (mid-size single-workgroup update, m=2000)
         (60, 9000, 5, 300, [20], 2500, False, 'int32'),  # m=5000 entries: multi-kernel update path
-        (4000, 9000, 3, 2_000_000, [6, 2], 1500, False, 'int32'),  # multi-kernel path with wrapping keys
+        (4000, 9000, 3, 2_000_000, [6, 2], 1500, False, 'int32'),  # mid-size update (m=3000) with wrapping keys
+        (9000, 12800, 4, 2_600_000, [20, 3], 1600, False, 'int32'),  # 8-rank global wiki batch: m=3200, wrapping keys
+        (4000, 15000, 3, 2_000_000, [6, 2], 2500, False, 'int32'),  # m=5000: multi-kernel path with wrapping keys
         (400, 3000, 7, 2000, [6], 60, False, 'int32'),  # D not a multiple of 4 (scalar gather path)
         (400, 3000, 6, 2000, [6], 60, False, 'int32'),  # D % 2 == 0 (float2 path)
     ],
 )
 def test_ring_mode_matches_oracle_random(N, E, D, tmax, num_nbrs, bs, directed, key_arith):
+    _check_ring_against_oracle(N, E, D, tmax, num_nbrs, bs, directed, key_arith)
+
+
+@pytest.mark.parametrize('validate', ['deferred', 'off', 'sync'])
+@pytest.mark.parametrize(
+    'N,E,D,tmax,num_nbrs,bs',
+    [
+        (3000, 6000, 4, 3_000_000, [5, 4], 64),  # wrapping keys, one-workgroup plan (m=128)
+        (9000, 9600, 4, 2_600_000, [20, 3], 1600),  # 8-rank global wiki batch (m=3200: 4 elements per thread)
+        (5000, 8000, 4, 2_600_000, [10, 2], 800),  # m=1600: 2 elements per thread
+        (50, 3000, 5, 200, [20], 700),  # hub runs longer than B (m=1400)
+    ],
+)
+def test_ring_step_variants(N, E, D, tmax, num_nbrs, bs, validate):
+    """tgmx_ring_step in every validation mode (one call per batch, or lookups / check / update)."""
+    _check_ring_against_oracle(N, E, D, tmax, num_nbrs, bs, False, 'int32', validate=validate)
+
+
+def _check_ring_against_oracle(N, E, D, tmax, num_nbrs, bs, directed, key_arith, **hook_kw):
     from oracle.ring_port import RingSamplerCPU
 
     _, DGDataLoader, _, HookManager, RecencyNeighborHook, ReplayNegatives = _mk()
     a, edge_x = _random_stream(1234 + N + E, N, E, D, tmax)
     hook = RecencyNeighborHook(N, num_nbrs, ['edge_src', 'edge_dst', 'neg'], ['edge_time', 'edge_time', 'neg_time'],
-                               directed=directed, key_arith=key_arith)  # fmt: skip
+                               directed=directed, key_arith=key_arith, **hook_kw)  # fmt: skip
     hm = HookManager(keys=['k'])
     hm.register('k', ReplayNegatives(torch.from_numpy(a['neg']).to(DEV)))
     hm.register('k', hook)
@@ -189,6 +210,8 @@ def test_ring_mode_matches_oracle_random(N, E, D, tmax, num_nbrs, bs, directed, 
                 assert torch.equal(batch.nbr_nids[h].cpu(), o_i), f'b{b} h{h} ids'
                 assert torch.equal(batch.nbr_edge_time[h].cpu(), o_t), f'b{b} h{h} times'
                 assert torch.equal(batch.nbr_edge_x[h].cpu(), o_x), f'b{b} h{h} feats'
+            assert torch.equal(batch.seed_nids[0].cpu(), seeds) and torch.equal(batch.seed_times[0].cpu(), times)
+    hook.check()
 
 
 def test_csr_mode_equals_ring_int64_random():

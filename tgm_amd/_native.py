@@ -108,6 +108,29 @@ class TgatLayout(ctypes.Structure):
                 ('level_off', c_int64 * (TGAT_MAX_LAYERS + 2)), ('layers', TgatLayerLayout * TGAT_MAX_LAYERS)]  # fmt: skip
 
 
+MAX_SEED_GROUPS = 8
+MAX_HOPS = 8
+
+
+class RingStep(ctypes.Structure):
+    """tgmx_ring_step_t (include/tgm_amd.h)."""
+
+    _fields_ = [
+        ('ring', c_void_p), ('write_pos', c_void_p), ('ring_x', c_void_p),
+        ('D', c_int32), ('B', c_int32), ('num_nodes', c_int32),
+        ('n_groups', c_int32),
+        ('grp_nid', c_void_p * MAX_SEED_GROUPS), ('grp_ts', c_void_p * MAX_SEED_GROUPS), ('grp_n', c_int64 * MAX_SEED_GROUPS),
+        ('seed_nid0', c_void_p), ('seed_ts0', c_void_p), ('S0', c_int64),
+        ('n_hops', c_int32), ('k', c_int32 * MAX_HOPS),
+        ('out_nid', c_void_p * MAX_HOPS), ('out_ts', c_void_p * MAX_HOPS), ('out_x', c_void_p * MAX_HOPS),
+        ('src', c_void_p), ('dst', c_void_p), ('ts', c_void_p), ('edge_x', c_void_p),
+        ('n', c_int64), ('eid0', c_int64), ('directed', c_int32), ('key_wrap32', c_int32),
+        ('scratch', c_void_p), ('status', c_void_p),
+        ('timed_hop', c_int32), ('ev_start', c_void_p), ('ev_stop', c_void_p),
+    ]  # fmt: skip
+
+
+SIGNATURES['tgmx_ring_step'] = (c_int32, [ctypes.POINTER(RingStep), _P])
 SIGNATURES['tgmx_tgat_layout'] = (c_int32, [ctypes.POINTER(TgatModel), c_int64, ctypes.POINTER(TgatHop), c_int32, ctypes.POINTER(TgatLayout)])
 SIGNATURES['tgmx_tgat_workspace_bytes'] = (c_size_t, [ctypes.POINTER(TgatModel), c_int64, ctypes.POINTER(TgatHop)])
 SIGNATURES['tgmx_tgat_forward'] = (
@@ -157,8 +180,14 @@ def check(rc: int, what: str) -> None:
         raise RuntimeError(f'{what} failed (rc={rc}): {msg.decode() if msg else "?"}')
 
 
-def stream_ptr() -> int:
-    return torch.cuda.current_stream().cuda_stream
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
+def stream_ptr(device_index: Optional[int] = None) -> int:
+    """hipStream_t of torch's current stream (on ``device_index``, default: the current device)."""
+    if _raw_stream is not None and device_index is not None:
+        return _raw_stream(device_index)
+    return torch.cuda.current_stream(device_index).cuda_stream
 
 
 def ptr(t: Optional[torch.Tensor]) -> int:

@@ -30,7 +30,7 @@ extern "C" int tgmx_event_create(tgmx_event_t* ev) {
 }
 
 extern "C" int tgmx_event_destroy(tgmx_event_t ev) {
-  if (ev) hipEventDestroy((hipEvent_t)ev);
+  if (ev) (void)hipEventDestroy((hipEvent_t)ev);
   return TGMX_OK;
 }
 

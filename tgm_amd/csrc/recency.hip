@@ -24,7 +24,19 @@ struct __align__(16) Rec {
 };
 static_assert(sizeof(Rec) == sizeof(tgmx_adj_t), "record layout");
 
+// hop-0 seeds given as groups (recency.py:173-237 concatenates them with torch.cat): the lookup wave of seed s
+// reads its (node, time) from the group that covers s and publishes the concatenation as a side effect
+struct SeedGroups {
+  const int32_t* nid[TGMX_MAX_SEED_GROUPS];
+  const int64_t* ts[TGMX_MAX_SEED_GROUPS];
+  long long end[TGMX_MAX_SEED_GROUPS];  // exclusive end offset of group g in the concatenation
+  int32_t* out_nid;
+  int64_t* out_ts;
+  int groups;  // 0: seeds / qtimes are read instead
+};
+
 struct LookupArgs {
+  SeedGroups grp;
   const int64_t* indptr;    // CSR
   const Rec* recs;          // CSR adjacency or ring rows
   const int32_t* write_pos; // ring
@@ -102,8 +114,30 @@ __global__ __launch_bounds__(256) void recency_lookup_kernel(const LookupArgs a)
   const int k = a.k, B = a.B;
 
   for (long long s = (long long)blockIdx.x * (blockDim.x >> 6) + wave_in_block; s < a.S; s += waves_total) {
-    const int n = a.seeds[s];
-    const long long q = a.qtimes[s];
+    int n;
+    long long q;
+    if (a.grp.groups > 0) {
+      const int32_t* pn = a.grp.nid[0];
+      const int64_t* pt = a.grp.ts[0];
+      long long base = 0;
+#pragma unroll
+      for (int g = 1; g < TGMX_MAX_SEED_GROUPS; ++g) {
+        if (g < a.grp.groups && s >= a.grp.end[g - 1]) {
+          pn = a.grp.nid[g];
+          pt = a.grp.ts[g];
+          base = a.grp.end[g - 1];
+        }
+      }
+      n = pn[s - base];
+      q = pt[s - base];
+      if (lane == 0) {
+        a.grp.out_nid[s] = n;
+        a.grp.out_ts[s] = q;
+      }
+    } else {
+      n = a.seeds[s];
+      q = a.qtimes[s];
+    }
 
     bool live = n >= 0 && n < a.N;
     if (lane == 0) {
@@ -235,7 +269,7 @@ static int launch_lookup(LookupArgs a, hipStream_t stream, hipEvent_t ev_start, 
   const size_t lds = (size_t)waves_per_block * a.k * sizeof(int);
 #define TGMX_LAUNCH(VEC_, SMALL_) \
   hipLaunchKernelGGL((recency_lookup_kernel<RING, VEC_, SMALL_>), grid, block, lds, stream, a)
-  if (ev_start) hipEventRecord(ev_start, stream);
+  if (ev_start) (void)hipEventRecord(ev_start, stream);
   if (small) {
     if (vec == 4) TGMX_LAUNCH(4, true);
     else if (vec == 2) TGMX_LAUNCH(2, true);
@@ -246,7 +280,7 @@ static int launch_lookup(LookupArgs a, hipStream_t stream, hipEvent_t ev_start, 
     else TGMX_LAUNCH(1, false);
   }
 #undef TGMX_LAUNCH
-  if (ev_stop) hipEventRecord(ev_stop, stream);
+  if (ev_stop) (void)hipEventRecord(ev_stop, stream);
   TGMX_CHECK_LAUNCH("recency_lookup");
   return TGMX_OK;
 }
@@ -313,7 +347,7 @@ __device__ __forceinline__ void update_entry(const UpdateArgs& a, long long j, i
   t = a.ts[i];
 }
 
-// ---- large batches (m > kFusedMaxM): exact all-pairs passes, tiled in 2-D over (entry, other)
+// ---- large batches (m > kBlockMaxM): exact all-pairs passes, tiled in 2-D over (entry, other)
 // so that the O(m^2) compares spread over the whole chip; partial counts meet in global atomics.
 constexpr int kTile = 256;  // "other" entries staged in LDS per block: (m/256)^2 blocks fill the chip
 
@@ -488,153 +522,6 @@ __global__ __launch_bounds__(256) void ring_update_write_kernel(const UpdateArgs
   a.winner[p] = win;
 }
 
-// Small batches (m <= kFusedMaxM entries, i.e. every TGB-style batch size): the
-// whole sort/place/write sequence in ONE workgroup with the working set in LDS
-// (gfx950: 160 KiB per CU).  O(m log^2 m): a bitonic sort of (key, entry index)
-// pairs replaces the all-pairs rank, and slot collisions / per-node totals are
-// resolved through two open-addressing hash tables in LDS (atomicMax / atomicAdd).
-constexpr int kFusedMaxM = 1024;
-constexpr int kFusedThreads = 1024;
-constexpr int kFusedHash = 2 * kFusedMaxM;  // load factor <= 0.5
-
-__device__ __forceinline__ int lds_hash_slot(int* keys, int key) {
-  // keys[] initialised to -1; returns the slot holding `key` (inserting it if absent)
-  unsigned h = ((unsigned)key * 2654435761u) >> (32 - 11);  // 11 = log2(kFusedHash)
-  for (;;) {
-    const int old = atomicCAS(&keys[h], -1, key);
-    if (old == -1 || old == key) return (int)h;
-    h = (h + 1) & (kFusedHash - 1);
-  }
-}
-static_assert(kFusedHash == 2048, "lds_hash_slot assumes 2^11 slots");
-
-__global__ __launch_bounds__(kFusedThreads) void ring_update_fused_kernel(const UpdateArgs a) {
-  __shared__ long long s_key[kFusedMaxM];  // sort key (sorted in place)
-  __shared__ long long s_t[kFusedMaxM];    // timestamp of entry j
-  __shared__ int s_pay[kFusedMaxM];        // entry index, permuted with the keys
-  __shared__ int s_node[kFusedMaxM];       // node of entry j (-1 invalid)
-  __shared__ int s_nbr[kFusedMaxM];        // neighbor of entry j
-  __shared__ int s_sn[kFusedMaxM];         // node at sorted position p
-  __shared__ int s_tgt[kFusedMaxM];        // ring row placed at (-1 dropped)
-  __shared__ int s_w[kFusedMaxM];          // write_pos[node] % B at sorted position p
-  __shared__ int h_slot_key[kFusedHash], h_slot_maxp[kFusedHash];
-  __shared__ int h_node_key[kFusedHash], h_node_cnt[kFusedHash], h_node_maxp[kFusedHash];
-  __shared__ long long red[kFusedThreads / kWave];
-  const int m = (int)a.m;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  constexpr int kWaves = kFusedThreads / kWave;
-  int P = 64;
-  while (P < m) P <<= 1;
-
-  // phase 0: span = max(ts) + 1; clear the hash tables
-  long long mx = -0x7fffffffffffffffLL;
-  for (int x = tid; x < a.n; x += kFusedThreads) {
-    const long long v = a.ts[x];
-    mx = v > mx ? v : mx;
-  }
-  for (int off = 32; off > 0; off >>= 1) {
-    const long long o = __shfl_xor(mx, off);
-    mx = o > mx ? o : mx;
-  }
-  if (lane == 0) red[wave] = mx;
-  for (int x = tid; x < kFusedHash; x += kFusedThreads) {
-    h_slot_key[x] = -1; h_slot_maxp[x] = -1;
-    h_node_key[x] = -1; h_node_cnt[x] = 0; h_node_maxp[x] = -1;
-  }
-  __syncthreads();
-  mx = red[0];
-  for (int w = 1; w < kWaves; ++w) mx = red[w] > mx ? red[w] : mx;
-  const long long span = mx + 1;
-
-  // phase 1: stage every entry in LDS (padding sorts to the end)
-  for (int j = tid; j < P; j += kFusedThreads) {
-    long long key = 0x7fffffffffffffffLL;
-    if (j < m) {
-      int node, nbr;
-      long long t, i;
-      update_entry(a, j, node, nbr, t, i);
-      const bool valid = node >= 0 && node < a.N && nbr >= 0 && nbr < a.N;
-      if (!valid) atomicOr(a.status, TGMX_ST_EDGE_RANGE);
-      key = update_key(node, t, span, a.key_wrap32);
-      s_t[j] = t;
-      s_node[j] = valid ? node : -1;
-      s_nbr[j] = nbr;
-    }
-    s_key[j] = key;
-    s_pay[j] = j;
-  }
-  __syncthreads();
-
-  // phase 2: bitonic sort of (key, entry index) -- unique pairs, so the order is the stable one
-  for (int k = 2; k <= P; k <<= 1) {
-    for (int jj = k >> 1; jj > 0; jj >>= 1) {
-      for (int i = tid; i < P; i += kFusedThreads) {
-        const int o = i ^ jj;
-        if (o > i) {
-          const long long ka = s_key[i], kb = s_key[o];
-          const int pa = s_pay[i], pb = s_pay[o];
-          const bool a_after_b = ka > kb || (ka == kb && pa > pb);
-          if (a_after_b == ((i & k) == 0)) {
-            s_key[i] = kb; s_key[o] = ka;
-            s_pay[i] = pb; s_pay[o] = pa;
-          }
-        }
-      }
-      __syncthreads();
-    }
-  }
-  for (int p = tid; p < m; p += kFusedThreads) s_sn[p] = s_node[s_pay[p]];
-  __syncthreads();
-
-  // phase 3: runs of equal node in sorted order -> keep / ring slot; feed the hash tables
-  for (int p = tid; p < m; p += kFusedThreads) {
-    const int node = s_sn[p];
-    int tgt = -1, w = 0;
-    if (node >= 0) {
-      int lo = p, hi = p + 1;
-      while (lo > 0 && s_sn[lo - 1] == node) --lo;
-      while (hi < m && s_sn[hi] == node) ++hi;
-      const int cnt = hi - lo, pos = p - lo;
-      const int drop = cnt > a.B ? cnt - a.B : 0;
-      w = a.write_pos[node] % a.B;
-      if (pos >= drop) {
-        tgt = node * a.B + (w + pos - drop) % a.B;
-        atomicMax(&h_slot_maxp[lds_hash_slot(h_slot_key, tgt)], p);
-        const int hn = lds_hash_slot(h_node_key, node);
-        atomicAdd(&h_node_cnt[hn], 1);
-        atomicMax(&h_node_maxp[hn], p);
-      }
-    }
-    s_w[p] = w;
-    s_tgt[p] = tgt;
-  }
-  __syncthreads();
-
-  // phase 4: the last entry (in sorted order) placed on a slot owns it; the last kept entry
-  // of a node commits write_pos += #kept.  Stores only -- no dependent global loads.
-  for (int p = tid; p < m; p += kFusedThreads) {
-    const int tgt = s_tgt[p];
-    const int j = s_pay[p];
-    int win = -1;
-    if (tgt >= 0) {
-      const int node = s_sn[p];
-      if (h_slot_maxp[lds_hash_slot(h_slot_key, tgt)] == p) {
-        const long long i = j >= a.n ? j - a.n : j;
-        Rec r;
-        r.nbr = s_nbr[j];
-        r.eid = a.eid0 >= 0 ? (int)(a.eid0 + i) : -1;
-        r.ts = s_t[j];
-        a.ring[tgt] = r;
-        win = tgt;
-      }
-      const int hn = lds_hash_slot(h_node_key, node);
-      if (h_node_maxp[hn] == p) a.write_pos[node] = (s_w[p] + h_node_cnt[hn]) % a.B;
-    }
-    a.winner[p] = win;
-    a.sorted_j[p] = j;
-  }
-}
-
 // one wave per sorted position: copy the winning entry's D-float feature row
 __global__ __launch_bounds__(256) void ring_update_feat_kernel(const UpdateArgs a) {
   const long long p = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -650,6 +537,230 @@ __global__ __launch_bounds__(256) void ring_update_feat_kernel(const UpdateArgs 
   } else {
     for (int c = lane_id(); c < a.D; c += kWave) o[c] = 0.f;
   }
+}
+
+// Batches of up to kBlockMaxM entries (every TGB-style batch size, and the replicated update of an 8-rank
+// global batch): ONE workgroup with the working set in LDS (gfx950: 160 KiB per CU).
+//   sort  : bitonic network over (key, entry index) pairs -- unique, so the order is the stable one.  Thread t
+//           holds E consecutive elements in registers: compare distances < E are in-register, distances < 64 E
+//           are lane shuffles inside the wave (no barrier, no LDS), only distances >= 64 E go through LDS
+//           (6 of the 45 steps at m = 400; 10 of 78 at m = 4096).
+//   runs  : maximal runs of equal node in sorted order by an inclusive max-scan (hub runs are long).
+//   place : ring slot = (write_pos[node] % B + offset inside the kept part of the run) % B; collisions between
+//           runs of one node are resolved through an LDS open-addressing hash (atomicMax of the sorted position:
+//           the last one wins).
+//   write : winners write their record; the last entry of every run advances write_pos by #kept with one
+//           atomicAdd (every reader takes write_pos % B).
+constexpr int kBlockMaxM = 4096;
+constexpr int kBlockThreads = 1024;
+
+__device__ __forceinline__ bool pair_after(long long ka, int pa, long long kb, int pb) {
+  return ka > kb || (ka == kb && pa > pb);
+}
+
+// element e (mine) against its partner at distance jj in the step of bitonic stage k: keep min or max
+__device__ __forceinline__ void bitonic_select(long long& key, int& pay, long long pk, int pp, int e, int jj, int k) {
+  const bool low = (e & jj) == 0, asc = (e & k) == 0;
+  const bool mine_after = pair_after(key, pay, pk, pp);
+  if ((low == asc) == mine_after) {  // keep-min and mine is larger, or keep-max and mine is smaller
+    key = pk;
+    pay = pp;
+  }
+}
+
+template <int E, int MAXM>
+__global__ __launch_bounds__(kBlockThreads) void ring_update_block_kernel(const UpdateArgs a) {
+  constexpr int H = 2 * MAXM;  // hash load factor <= 0.5
+  constexpr int HBITS = MAXM == 1024 ? 11 : (MAXM == 2048 ? 12 : 13);
+  static_assert((1 << HBITS) == H, "hash size");
+  __shared__ long long s_key[MAXM];  // LDS leg of the sort; afterwards two int[MAXM] scan buffers
+  __shared__ int s_pay[MAXM];        // entry index at sorted position p
+  __shared__ int s_sn[MAXM];         // node at sorted position p (-1 invalid)
+  __shared__ int s_tgt[MAXM];        // ring row placed at (-1 dropped)
+  __shared__ int h_key[H], h_maxp[H];
+  __shared__ long long red[kBlockThreads / kWave];
+  const int m = (int)a.m;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nthr = blockDim.x, nwaves = nthr >> 6;
+  const int P = nthr * E;  // power of two >= m
+
+  long long mx = -0x7fffffffffffffffLL;
+  for (int x = tid; x < a.n; x += nthr) {
+    const long long v = a.ts[x];
+    mx = v > mx ? v : mx;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const long long o = __shfl_xor(mx, off);
+    mx = o > mx ? o : mx;
+  }
+  if (lane == 0) red[wave] = mx;
+  for (int x = tid; x < H; x += nthr) {
+    h_key[x] = -1;
+    h_maxp[x] = -1;
+  }
+  __syncthreads();
+  mx = red[0];
+  for (int w = 1; w < nwaves; ++w) mx = red[w] > mx ? red[w] : mx;
+  const long long span = mx + 1;
+
+  long long key[E];
+  int pay[E];
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    const int j = tid * E + r;
+    key[r] = 0x7fffffffffffffffLL;  // padding sorts to the end
+    pay[r] = j;
+    if (j < m) {
+      int node, nbr;
+      long long t, i;
+      update_entry(a, j, node, nbr, t, i);
+      key[r] = update_key(node, t, span, a.key_wrap32);
+    }
+  }
+
+  for (int k = 2; k <= P; k <<= 1) {
+    for (int jj = k >> 1; jj > 0; jj >>= 1) {
+      if (jj < E) {  // both elements live in this thread
+        if constexpr (E >= 2) {
+          const int e0 = tid * E;
+          auto cswap = [&](int r, int r2) {
+            const bool asc = ((e0 + r) & k) == 0;
+            if (pair_after(key[r], pay[r], key[r2], pay[r2]) == asc) {
+              const long long tk = key[r]; key[r] = key[r2]; key[r2] = tk;
+              const int tp = pay[r]; pay[r] = pay[r2]; pay[r2] = tp;
+            }
+          };
+          if (jj == 1) {
+            cswap(0, 1);
+            if constexpr (E == 4) cswap(2, 3);
+          } else {
+            if constexpr (E == 4) {
+              cswap(0, 2);
+              cswap(1, 3);
+            }
+          }
+        }
+      } else if (jj < kWave * E) {  // partner is another lane of this wave
+        const int lm = jj / E;
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+          const long long pk = __shfl_xor(key[r], lm);
+          const int pp = __shfl_xor(pay[r], lm);
+          bitonic_select(key[r], pay[r], pk, pp, tid * E + r, jj, k);
+        }
+      } else {  // partner is in another wave: exchange through LDS
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+          s_key[tid * E + r] = key[r];
+          s_pay[tid * E + r] = pay[r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+          const int e = tid * E + r;
+          const long long pk = s_key[e ^ jj];
+          const int pp = s_pay[e ^ jj];
+          bitonic_select(key[r], pay[r], pk, pp, e, jj, k);
+        }
+        __syncthreads();
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    const int p = tid * E + r;
+    s_pay[p] = pay[r];
+    if (p < m) {
+      int node, nbr;
+      long long t, i;
+      update_entry(a, pay[r], node, nbr, t, i);
+      const bool valid = node >= 0 && node < a.N && nbr >= 0 && nbr < a.N;
+      if (!valid) atomicOr(a.status, TGMX_ST_EDGE_RANGE);
+      s_sn[p] = valid ? node : -1;
+    }
+  }
+  __syncthreads();
+
+  // run start of every sorted position: inclusive max-scan of (p if p opens a run else 0), ping-pong buffers
+  int* cur = reinterpret_cast<int*>(s_key);
+  int* nxt = cur + MAXM;
+  for (int p = tid; p < m; p += nthr) cur[p] = (p > 0 && s_sn[p - 1] == s_sn[p]) ? 0 : p;
+  __syncthreads();
+  for (int off = 1; off < m; off <<= 1) {
+    for (int p = tid; p < m; p += nthr) {
+      const int v = cur[p];
+      const int u = p >= off ? cur[p - off] : 0;
+      nxt[p] = u > v ? u : v;
+    }
+    __syncthreads();
+    int* sw = cur; cur = nxt; nxt = sw;
+  }
+  int* s_start = cur;
+  int* s_len = nxt;  // run length, stored at the run's start
+  for (int p = tid; p < m; p += nthr)
+    if (p == m - 1 || s_sn[p + 1] != s_sn[p]) s_len[s_start[p]] = p - s_start[p] + 1;
+  __syncthreads();
+
+  auto hash_slot = [&](int tgt) -> int {
+    unsigned h = ((unsigned)tgt * 2654435761u) >> (32 - HBITS);
+    for (;;) {
+      const int old = atomicCAS(&h_key[h], -1, tgt);
+      if (old == -1 || old == tgt) return (int)h;
+      h = (h + 1) & (H - 1);
+    }
+  };
+  for (int p = tid; p < m; p += nthr) {
+    const int node = s_sn[p];
+    int tgt = -1;
+    if (node >= 0) {
+      const int lo = s_start[p], cnt = s_len[lo], pos = p - lo;
+      const int drop = cnt > a.B ? cnt - a.B : 0;
+      if (pos >= drop) {
+        tgt = node * a.B + (a.write_pos[node] % a.B + pos - drop) % a.B;
+        atomicMax(&h_maxp[hash_slot(tgt)], p);
+      }
+    }
+    s_tgt[p] = tgt;
+  }
+  __syncthreads();
+
+  for (int p = tid; p < m; p += nthr) {
+    const int tgt = s_tgt[p];
+    const int j = s_pay[p];
+    int win = -1;
+    if (tgt >= 0) {
+      if (h_maxp[hash_slot(tgt)] == p) {
+        int node, nbr;
+        long long t, i;
+        update_entry(a, j, node, nbr, t, i);
+        Rec r;
+        r.nbr = nbr;
+        r.eid = a.eid0 >= 0 ? (int)(a.eid0 + i) : -1;
+        r.ts = t;
+        a.ring[tgt] = r;
+        win = tgt;
+      }
+      const int lo = s_start[p], cnt = s_len[lo];
+      if (p == lo + cnt - 1) {  // the run's last entry commits the run (every write_pos read is behind the barrier)
+        const int kept = cnt > a.B ? a.B : cnt;
+        int32_t* wp = &a.write_pos[s_sn[p]];
+        const int old = atomicAdd(wp, kept);
+        constexpr int kFold = 1 << 30;
+        if (old < kFold && old + kept >= kFold) atomicSub(wp, kFold / a.B * a.B);  // stay far from int32 overflow
+      }
+    }
+    a.winner[p] = win;
+    a.sorted_j[p] = j;
+  }
+}
+
+static void launch_update_block(const UpdateArgs& a, hipStream_t st) {
+  int P = 64;
+  while (P < a.m) P <<= 1;
+  if (P <= 1024) hipLaunchKernelGGL((ring_update_block_kernel<1, 1024>), dim3(1), dim3(P), 0, st, a);
+  else if (P == 2048) hipLaunchKernelGGL((ring_update_block_kernel<2, 2048>), dim3(1), dim3(1024), 0, st, a);
+  else hipLaunchKernelGGL((ring_update_block_kernel<4, 4096>), dim3(1), dim3(1024), 0, st, a);
+  if (a.D > 0) hipLaunchKernelGGL(ring_update_feat_kernel, dim3((unsigned)((a.m + 3) / 4)), dim3(256), 0, st, a);
 }
 
 __global__ __launch_bounds__(256) void ring_reset_kernel(Rec* ring, int32_t* write_pos, long long nrec, int N) {
@@ -716,46 +827,119 @@ extern "C" int tgmx_ring_lookup(const tgmx_adj_t* ring, const int32_t* write_pos
   return launch_lookup<true>(a, (hipStream_t)stream, (hipEvent_t)ev_start, (hipEvent_t)ev_stop);
 }
 
-extern "C" int tgmx_ring_update(tgmx_adj_t* ring, int32_t* write_pos, float* ring_x, int32_t D, int32_t B,
-                                int32_t num_nodes, const int32_t* src, const int32_t* dst, const int64_t* ts,
-                                const float* edge_x, int64_t n, int64_t eid0, int32_t directed, int32_t key_wrap32,
-                                int32_t* scratch, int32_t* status, tgmx_stream_t stream) {
-  TGMX_REQUIRE(n >= 0 && B > 0 && num_nodes > 0 && D >= 0, "ring_update: bad sizes n=%lld B=%d N=%d D=%d", (long long)n, B,
+static int fill_update_args(UpdateArgs& a, tgmx_adj_t* ring, int32_t* write_pos, float* ring_x, int32_t D, int32_t B,
+                            int32_t num_nodes, const int32_t* src, const int32_t* dst, const int64_t* ts,
+                            const float* edge_x, int64_t n, int64_t eid0, int32_t directed, int32_t key_wrap32,
+                            int32_t* scratch, int32_t* status) {
+  TGMX_REQUIRE(n > 0 && B > 0 && num_nodes > 0 && D >= 0, "ring_update: bad sizes n=%lld B=%d N=%d D=%d", (long long)n, B,
                num_nodes, D);
-  if (n == 0) return TGMX_OK;
   TGMX_REQUIRE(ring && write_pos && src && dst && ts && scratch && status, "ring_update: null pointer");
   TGMX_REQUIRE(D == 0 || ring_x, "ring_update: D=%d but ring_x is null", D);
   TGMX_REQUIRE(eid0 < 0 || eid0 + n <= 2147483647LL, "ring_update: edge ids overflow int32");
   TGMX_REQUIRE((long long)B * num_nodes < 2147483647LL, "ring_update: num_nodes*B overflows int32");
   TGMX_REQUIRE(2 * n < 2147483647LL, "ring_update: batch too large");
-  UpdateArgs a{};
+  a = UpdateArgs{};
   a.ring = reinterpret_cast<Rec*>(ring); a.write_pos = write_pos; a.ring_x = ring_x; a.edge_x = edge_x;
   a.src = src; a.dst = dst; a.ts = ts; a.status = status;
   a.n = n; a.m = directed ? n : 2 * n; a.eid0 = eid0; a.B = B; a.N = num_nodes; a.D = D; a.key_wrap32 = key_wrap32;
   a.sorted_j = scratch; a.sorted_node = scratch + a.m; a.target = scratch + 2 * a.m; a.winner = scratch + 3 * a.m;
+  return TGMX_OK;
+}
+
+static void launch_update_large(UpdateArgs& a, int32_t* scratch, hipStream_t st) {
   const unsigned blocks = (unsigned)((a.m + 255) / 256);
+  // 16-byte aligned int64 scratch first, then the int32 arrays
+  long long* s64 = reinterpret_cast<long long*>(scratch + 4 * a.m + ((4 * a.m) & 1));
+  s64 = reinterpret_cast<long long*>(((uintptr_t)s64 + 15) & ~(uintptr_t)15);
+  a.span = s64;
+  a.key = s64 + 2;
+  int32_t* s32 = reinterpret_cast<int32_t*>(a.key + a.m);
+  a.node = s32; a.rank = s32 + a.m; a.kept = s32 + 2 * a.m; a.flags = s32 + 3 * a.m;
+  const dim3 grid2((unsigned)blocks, (unsigned)((a.m + kTile - 1) / kTile));
+  hipLaunchKernelGGL(ring_update_span_kernel, dim3(1), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(ring_update_keys_kernel, dim3(blocks), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(ring_update_rank_kernel, grid2, dim3(256), 0, st, a);
+  hipLaunchKernelGGL(ring_update_scatter_kernel, dim3(blocks), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(ring_update_place_kernel, dim3(blocks), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(ring_update_resolve_kernel, grid2, dim3(256), 0, st, a);
+  hipLaunchKernelGGL(ring_update_write_kernel, dim3(blocks), dim3(256), 0, st, a);
+  if (a.D > 0) hipLaunchKernelGGL(ring_update_feat_kernel, dim3((unsigned)((a.m + 3) / 4)), dim3(256), 0, st, a);
+}
+
+extern "C" int tgmx_ring_update(tgmx_adj_t* ring, int32_t* write_pos, float* ring_x, int32_t D, int32_t B,
+                                int32_t num_nodes, const int32_t* src, const int32_t* dst, const int64_t* ts,
+                                const float* edge_x, int64_t n, int64_t eid0, int32_t directed, int32_t key_wrap32,
+                                int32_t* scratch, int32_t* status, tgmx_stream_t stream) {
+  TGMX_REQUIRE(n >= 0, "ring_update: bad sizes n=%lld", (long long)n);
+  if (n == 0) return TGMX_OK;
+  UpdateArgs a;
+  const int rc = fill_update_args(a, ring, write_pos, ring_x, D, B, num_nodes, src, dst, ts, edge_x, n, eid0, directed,
+                                  key_wrap32, scratch, status);
+  if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
-  if (a.m <= kFusedMaxM) {
-    hipLaunchKernelGGL(ring_update_fused_kernel, dim3(1), dim3(kFusedThreads), 0, st, a);
-  } else {
-    // 16-byte aligned int64 scratch first, then the int32 arrays
-    long long* s64 = reinterpret_cast<long long*>(scratch + 4 * a.m + ((4 * a.m) & 1));
-    s64 = reinterpret_cast<long long*>(((uintptr_t)s64 + 15) & ~(uintptr_t)15);
-    a.span = s64;
-    a.key = s64 + 2;
-    int32_t* s32 = reinterpret_cast<int32_t*>(a.key + a.m);
-    a.node = s32; a.rank = s32 + a.m; a.kept = s32 + 2 * a.m; a.flags = s32 + 3 * a.m;
-    const dim3 grid2((unsigned)blocks, (unsigned)((a.m + kTile - 1) / kTile));
-    hipLaunchKernelGGL(ring_update_span_kernel, dim3(1), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(ring_update_keys_kernel, dim3(blocks), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(ring_update_rank_kernel, grid2, dim3(256), 0, st, a);
-    hipLaunchKernelGGL(ring_update_scatter_kernel, dim3(blocks), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(ring_update_place_kernel, dim3(blocks), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(ring_update_resolve_kernel, grid2, dim3(256), 0, st, a);
-    hipLaunchKernelGGL(ring_update_write_kernel, dim3(blocks), dim3(256), 0, st, a);
-  }
-  if (D > 0) hipLaunchKernelGGL(ring_update_feat_kernel, dim3((unsigned)((a.m + 3) / 4)), dim3(256), 0, st, a);
+  if (a.m <= kBlockMaxM) launch_update_block(a, st);
+  else launch_update_large(a, scratch, st);
   TGMX_CHECK_LAUNCH("ring_update");
+  return TGMX_OK;
+}
+
+extern "C" int tgmx_ring_step(const tgmx_ring_step_t* s, tgmx_stream_t stream) {
+  TGMX_REQUIRE(s, "ring_step: null argument block");
+  TGMX_REQUIRE(s->n_groups >= 0 && s->n_groups <= TGMX_MAX_SEED_GROUPS && s->n_hops >= 0 && s->n_hops <= TGMX_MAX_HOPS,
+               "ring_step: n_groups=%d n_hops=%d out of range", s->n_groups, s->n_hops);
+  TGMX_REQUIRE(s->B > 0 && s->num_nodes > 0 && s->D >= 0 && s->n >= 0, "ring_step: bad sizes B=%d N=%d D=%d n=%lld", s->B,
+               s->num_nodes, s->D, (long long)s->n);
+  TGMX_REQUIRE(s->ring && s->write_pos && s->status, "ring_step: null state pointer");
+  TGMX_REQUIRE(((uintptr_t)s->ring & 15) == 0, "ring_step: ring must be 16-byte aligned");
+  TGMX_REQUIRE((long long)s->B * s->num_nodes < 2147483647LL, "ring_step: num_nodes*B overflows int32");
+  hipStream_t st = (hipStream_t)stream;
+
+  // ---- hop-0 seeds: groups are concatenated by the hop-0 lookup itself (or by nothing when there is no hop)
+  SeedGroups grp{};
+  long long S = s->S0;
+  if (s->n_groups > 0) {
+    S = 0;
+    for (int g = 0; g < s->n_groups; ++g) {
+      TGMX_REQUIRE(s->grp_n[g] >= 0 && (s->grp_n[g] == 0 || (s->grp_nid[g] && s->grp_ts[g])), "ring_step: seed group %d", g);
+      S += s->grp_n[g];
+      grp.nid[g] = s->grp_nid[g]; grp.ts[g] = s->grp_ts[g]; grp.end[g] = S;
+    }
+    TGMX_REQUIRE(S == 0 || (s->seed_nid0 && s->seed_ts0), "ring_step: null hop-0 seed output");
+    TGMX_REQUIRE(S == 0 || s->n_hops > 0, "ring_step: seed groups need at least one hop");
+    grp.out_nid = s->seed_nid0; grp.out_ts = s->seed_ts0; grp.groups = s->n_groups;
+  }
+
+  // ---- lookups, hop by hop (hop h + 1 consumes hop h's outputs in place)
+  const int32_t* cur_n = s->seed_nid0;
+  const int64_t* cur_t = s->seed_ts0;
+  for (int h = 0; h < s->n_hops && S > 0; ++h) {
+    const int k = s->k[h];
+    TGMX_REQUIRE(k > 0 && s->B >= k, "ring_step: hop %d has k=%d, B=%d", h, k, s->B);
+    TGMX_REQUIRE(cur_n && cur_t && s->out_nid[h] && s->out_ts[h] && (s->D == 0 || (s->ring_x && s->out_x[h])),
+                 "ring_step: null pointer at hop %d", h);
+    LookupArgs a{};
+    if (h == 0) a.grp = grp;
+    a.indptr = nullptr; a.recs = reinterpret_cast<const Rec*>(s->ring); a.write_pos = s->write_pos; a.edge_x = s->ring_x;
+    a.seeds = cur_n; a.qtimes = cur_t; a.out_nid = s->out_nid[h]; a.out_ts = s->out_ts[h]; a.out_x = s->out_x[h];
+    a.status = s->status; a.S = S; a.D = s->D; a.k = k; a.B = s->B; a.N = s->num_nodes; a.allow_pad = h > 0;
+    const bool timed = h == s->timed_hop;
+    const int rc = launch_lookup<true>(a, st, timed ? (hipEvent_t)s->ev_start : nullptr, timed ? (hipEvent_t)s->ev_stop : nullptr);
+    if (rc) return rc;
+    cur_n = s->out_nid[h];
+    cur_t = s->out_ts[h];
+    S *= k;
+  }
+
+  // ---- ring update (after every lookup, recency.py:161-163)
+  if (s->n > 0) {
+    UpdateArgs u;
+    const int rc = fill_update_args(u, s->ring, s->write_pos, s->ring_x, s->D, s->B, s->num_nodes, s->src, s->dst, s->ts,
+                                    s->edge_x, s->n, s->eid0, s->directed, s->key_wrap32, s->scratch, s->status);
+    if (rc) return rc;
+    if (u.m <= kBlockMaxM) launch_update_block(u, st);
+    else launch_update_large(u, s->scratch, st);
+  }
+  TGMX_CHECK_LAUNCH("ring_step");
   return TGMX_OK;
 }
 

@@ -144,6 +144,7 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
         # optional kernel timing (bench.py): every `profile_every`-th call brackets the
         # lookup launch of hop `profile_hop` with HIP events on the launch stream
         self._mask_cache: Dict[tuple, Dict[str, Tensor]] = {}
+        self._step: Optional[_native.RingStep] = None  # argument block of tgmx_ring_step (static fields pre-filled)
         self.profile_hop: Optional[int] = None
         self.profile_every: int = 1
         self.profile_log: List[tuple] = []
@@ -224,6 +225,15 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
                 self._ring_x = None if self._ring_x is None else self._ring_x.to(device)
                 self._write_pos = self._write_pos.to(device)
                 self._scratch = None
+            st = _native.RingStep()
+            st.ring, st.write_pos, st.ring_x = self._ring.data_ptr(), self._write_pos.data_ptr(), _native.ptr(self._ring_x)
+            st.D, st.B, st.num_nodes = D, B, N
+            for hop, k in enumerate(self._num_nbrs[: _native.MAX_HOPS]):
+                st.k[hop] = k
+            st.directed, st.key_wrap32 = (1 if self._directed else 0), self._key_wrap32
+            st.status = self._status.data_ptr()
+            st.timed_hop = -1
+            self._step = st
 
     def _ensure_csr(self, dg: DGraph, batch: DGBatch) -> TemporalCSR:
         store = dg._storage
@@ -246,6 +256,8 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
     # ------------------------------------------------------------------
     def __call__(self, dg: DGraph, batch: DGBatch) -> DGBatch:
         device = batch.edge_src.device
+        if self._mode == 'ring':
+            return self._call_ring(dg, batch, device)
         seeds, seed_times, seed_mask = self._get_seed_tensors(batch, device)
         D = self._edge_x_dim if self._edge_x_dim is not None else (dg.edge_x_dim or 0)
 
@@ -270,19 +282,16 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
             B, N = self._max_nbrs, self._num_nodes
             status_p = self._status.data_ptr()
             with _on_device(device):
-                stream = _native.stream_ptr()
-                if self._mode == 'csr':
-                    if batch._edge_lo is None:
-                        raise ValueError("mode='csr' needs batches materialized by tgm_amd.DGraph (batch._edge_lo is unset)")
-                    csr = self._ensure_csr(dg, batch)
-                    ev_hi = int(batch._edge_lo)
-                    if self._epoch_lo is None:
-                        self._epoch_lo = ev_hi
-                    ev_lo = self._epoch_lo
-                    edge_x = dg._storage.on(device).edge_x
-                    table_p, indptr_p, adj_p = _native.ptr(edge_x), csr.indptr.data_ptr(), csr.adj.data_ptr()
-                else:
-                    ring_p, wpos_p, table_p = self._ring.data_ptr(), self._write_pos.data_ptr(), _native.ptr(self._ring_x)
+                stream = _native.stream_ptr(device.index)
+                if batch._edge_lo is None:
+                    raise ValueError("mode='csr' needs batches materialized by tgm_amd.DGraph (batch._edge_lo is unset)")
+                csr = self._ensure_csr(dg, batch)
+                ev_hi = int(batch._edge_lo)
+                if self._epoch_lo is None:
+                    self._epoch_lo = ev_hi
+                ev_lo = self._epoch_lo
+                edge_x = dg._storage.on(device).edge_x
+                table_p, indptr_p, adj_p = _native.ptr(edge_x), csr.indptr.data_ptr(), csr.adj.data_ptr()
 
                 cur_n, cur_t = seeds, seed_times
                 self._calls += 1
@@ -296,16 +305,10 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
                     if hop == timed_hop and self.profile_pool:
                         timer = self.profile_pool.pop()
                     ev0, ev1 = (timer.start, timer.stop) if timer else (None, None)
-                    if self._mode == 'csr':
-                        rc = lib.tgmx_recency_lookup_csr(
-                            indptr_p, adj_p, table_p, D, cur_n.data_ptr(), cur_t.data_ptr(), S, k, B, ev_lo, ev_hi, N,
-                            1 if hop else 0, nid.data_ptr(), nts.data_ptr(), nx.data_ptr(), status_p, stream, ev0, ev1,
-                        )
-                    else:
-                        rc = lib.tgmx_ring_lookup(
-                            ring_p, wpos_p, table_p, D, cur_n.data_ptr(), cur_t.data_ptr(), S, k, B, N,
-                            1 if hop else 0, nid.data_ptr(), nts.data_ptr(), nx.data_ptr(), status_p, stream, ev0, ev1,
-                        )  # fmt: skip
+                    rc = lib.tgmx_recency_lookup_csr(
+                        indptr_p, adj_p, table_p, D, cur_n.data_ptr(), cur_t.data_ptr(), S, k, B, ev_lo, ev_hi, N,
+                        1 if hop else 0, nid.data_ptr(), nts.data_ptr(), nx.data_ptr(), status_p, stream, ev0, ev1,
+                    )  # fmt: skip
                     if rc:
                         _native.check(rc, 'recency lookup')
                     if timer is not None:
@@ -318,42 +321,129 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
                     cur_n, cur_t = nid.view(-1), nts.view(-1)
 
                 if self._validate == 'sync':
-                    self.check()  # before the update, so bad seeds leave the state untouched
+                    self.check()
 
-                n_edges = batch.edge_src.numel()
-                if self._mode == 'ring' and n_edges:
-                    m = n_edges if self._directed else 2 * n_edges
-                    if self._scratch is None or self._scratch.numel() < 12 * m + 16:
-                        self._scratch = torch.empty(12 * m + 16, dtype=torch.int32, device=device)
-                    ex = batch.edge_x
-                    if ex is not None and D:
-                        if ex.dtype != torch.float32 or not ex.is_contiguous():
-                            ex = ex.to(torch.float32).contiguous()
-                    else:
-                        ex = None
-                    src, dst, tt = batch.edge_src, batch.edge_dst, batch.edge_time
-                    if not (src.is_contiguous() and dst.is_contiguous() and tt.is_contiguous()):
-                        src, dst, tt = src.contiguous(), dst.contiguous(), tt.contiguous()
-                    eid0 = -1 if batch._edge_lo is None else int(batch._edge_lo)
-                    rc = lib.tgmx_ring_update(
-                        ring_p, wpos_p, table_p, D, B, N, src.data_ptr(), dst.data_ptr(), tt.data_ptr(), _native.ptr(ex),
-                        n_edges, eid0, 1 if self._directed else 0, self._key_wrap32, self._scratch.data_ptr(), status_p, stream,
-                    )
-                    if rc:
-                        _native.check(rc, 'tgmx_ring_update')
-                    if self._validate == 'sync':
-                        self.check()
+        return self._publish(batch, out_seed_n, out_seed_t, out_n, out_t, out_x, seed_mask)
 
-        self.add_batch_attribute(batch, 'seed_nids', out_seed_n)
-        self.add_batch_attribute(batch, 'seed_times', out_seed_t)
+    # ------------------------------------------------------------------
+    def _publish(self, batch: DGBatch, seed_n, seed_t, out_n, out_t, out_x, seed_mask) -> DGBatch:
+        self.add_batch_attribute(batch, 'seed_nids', seed_n)
+        self.add_batch_attribute(batch, 'seed_times', seed_t)
         self.add_batch_attribute(batch, 'nbr_nids', out_n)
         self.add_batch_attribute(batch, 'nbr_edge_time', out_t)
         self.add_batch_attribute(batch, 'nbr_edge_x', out_x)
         self.add_batch_attribute(batch, 'seed_node_nbr_mask', seed_mask)
         return batch
 
+    def _call_ring(self, dg: DGraph, batch: DGBatch, device: torch.device) -> DGBatch:
+        """Streaming mode: the whole call (seed concat, every hop, ring update) is ONE tgmx_ring_step."""
+        groups, group_times, seed_mask = self._get_seed_tensors(batch, device, concat=False)
+        S0 = 0
+        for g in groups:
+            S0 += g.shape[0]
+        L = len(self._num_nbrs)
+        if S0 == 0:
+            # reference: CPU empties, and the update is skipped (recency.py:127-139)
+            D0 = dg.edge_x_dim or 0
+            return self._publish(
+                batch,
+                [torch.empty(0, dtype=torch.int32) for _ in range(L)],
+                [torch.empty(0, dtype=torch.int64) for _ in range(L)],
+                [torch.empty(0, dtype=torch.int32) for _ in range(L)],
+                [torch.empty(0, dtype=torch.int64) for _ in range(L)],
+                [torch.empty(0, D0, dtype=torch.float32) for _ in range(L)],
+                seed_mask,
+            )
+        if len(groups) > _native.MAX_SEED_GROUPS or L > _native.MAX_HOPS:
+            raise ValueError(f'at most {_native.MAX_SEED_GROUPS} seed groups and {_native.MAX_HOPS} hops are supported')
+        self._ensure_state(dg, device)
+        D = self._edge_x_dim
+        st = self._step
+        lib = _native.load()
+        empty = torch.empty
+        with _on_device(device):
+            stream = _native.stream_ptr(device.index)
+            # hop-0 seeds (fresh tensors owned by the batch, like the reference's torch.cat)
+            seeds = empty(S0, dtype=torch.int32, device=device)
+            seed_times = empty(S0, dtype=torch.int64, device=device)
+            for g, (a, t) in enumerate(zip(groups, group_times)):
+                if not a.is_contiguous():
+                    a = a.contiguous()
+                if not t.is_contiguous():
+                    t = t.contiguous()
+                if t.shape[0] != a.shape[0]:
+                    raise ValueError(f'seed group {g}: {a.shape[0]} nodes but {t.shape[0]} times')
+                st.grp_nid[g], st.grp_ts[g], st.grp_n[g] = a.data_ptr(), t.data_ptr(), a.shape[0]
+            st.n_groups = len(groups)
+            st.seed_nid0, st.seed_ts0 = seeds.data_ptr(), seed_times.data_ptr()
+
+            out_seed_n, out_seed_t, out_n, out_t, out_x = [], [], [], [], []
+            cur_n, cur_t, S = seeds, seed_times, S0
+            for hop, k in enumerate(self._num_nbrs):
+                nid = empty((S, k), dtype=torch.int32, device=device)
+                nts = empty((S, k), dtype=torch.int64, device=device)
+                nx = empty((S, k, D), dtype=torch.float32, device=device)
+                st.out_nid[hop], st.out_ts[hop], st.out_x[hop] = nid.data_ptr(), nts.data_ptr(), nx.data_ptr()
+                out_seed_n.append(cur_n)
+                out_seed_t.append(cur_t)
+                out_n.append(nid)
+                out_t.append(nts)
+                out_x.append(nx)
+                cur_n, cur_t = nid.view(-1), nts.view(-1)
+                S *= k
+
+            self._calls += 1
+            timer = None
+            st.timed_hop = -1
+            if self.profile_hop is not None and self._calls % self.profile_every == 0 and self.profile_pool:
+                timer = self.profile_pool.pop()
+                st.timed_hop, st.ev_start, st.ev_stop = self.profile_hop, timer.start, timer.stop
+
+            n_edges = batch.edge_src.shape[0]
+            keep = None
+            if n_edges:
+                m = n_edges if self._directed else 2 * n_edges
+                if self._scratch is None or self._scratch.shape[0] < 12 * m + 16:
+                    self._scratch = empty(12 * m + 16, dtype=torch.int32, device=device)
+                    st.scratch = self._scratch.data_ptr()
+                ex = batch.edge_x
+                if ex is not None and D:
+                    if ex.dtype != torch.float32 or not ex.is_contiguous():
+                        ex = ex.to(torch.float32).contiguous()
+                else:
+                    ex = None
+                src, dst, tt = batch.edge_src, batch.edge_dst, batch.edge_time
+                if not (src.is_contiguous() and dst.is_contiguous() and tt.is_contiguous()):
+                    src, dst, tt = src.contiguous(), dst.contiguous(), tt.contiguous()
+                keep = (src, dst, tt, ex)
+                st.src, st.dst, st.ts, st.edge_x = src.data_ptr(), dst.data_ptr(), tt.data_ptr(), _native.ptr(ex)
+                st.eid0 = -1 if batch._edge_lo is None else int(batch._edge_lo)
+
+            if self._validate == 'sync':
+                # bad seeds must leave the state untouched: lookups, host check, then the update
+                st.n, st.n_hops = 0, L
+                rc = lib.tgmx_ring_step(st, stream)
+                if rc:
+                    _native.check(rc, 'tgmx_ring_step')
+                self.check()
+                if n_edges:
+                    st.n, st.n_hops, st.n_groups, st.timed_hop = n_edges, 0, 0, -1
+                    rc = lib.tgmx_ring_step(st, stream)
+                    if rc:
+                        _native.check(rc, 'tgmx_ring_step')
+                    self.check()
+            else:
+                st.n, st.n_hops = n_edges, L
+                rc = lib.tgmx_ring_step(st, stream)
+                if rc:
+                    _native.check(rc, 'tgmx_ring_step')
+            del keep
+            if timer is not None:
+                self.profile_log.append((timer, out_seed_n[self.profile_hop].shape[0], self._num_nbrs[self.profile_hop], out_n[self.profile_hop]))
+        return self._publish(batch, out_seed_n, out_seed_t, out_n, out_t, out_x, seed_mask)
+
     # ------------------------------------------------------------------
-    def _get_seed_tensors(self, batch: DGBatch, device: torch.device) -> Tuple[Tensor, Tensor, Dict[str, Tensor]]:
+    def _get_seed_tensors(self, batch: DGBatch, device: torch.device, concat: bool = True):
         """Concatenate the hop-0 seeds (recency.py:173-237).  Structural checks
         (missing / non-tensor / non-1-D) raise here; value checks (id range,
         negative time) are done by the lookup kernel."""
@@ -411,6 +501,8 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
                 self._mask_cache.clear()
             self._mask_cache[layout] = cached
         mask = dict(cached)
+        if not concat:
+            return seeds, times, mask  # ring mode: the groups are concatenated by the step call itself
         if seeds:
             return torch.cat(seeds), torch.cat(times), mask  # fresh tensors owned by the batch
         return (

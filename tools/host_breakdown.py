@@ -44,3 +44,23 @@ for mode in ('ring', 'csr'):
     for nb in ([20], [20, 20]):
         timeit(f'+ negatives + recency {mode} {nb} deferred', [neg(), RecencyNeighborHook(stream.num_nodes, nb, keys, tkeys, mode=mode, validate='deferred', batch_size=200)])
 timeit('+ negatives + recency ring [20,20] sync-validate', [neg(), RecencyNeighborHook(stream.num_nodes, [20, 20], keys, tkeys)])
+timeit('+ negatives + recency ring [20,20] off', [neg(), RecencyNeighborHook(stream.num_nodes, [20, 20], keys, tkeys, validate='off')])
+
+# raw cost of the step call alone (same argument block re-submitted)
+from tgm_amd import _native
+hook = RecencyNeighborHook(stream.num_nodes, [20, 20], keys, tkeys, validate='deferred')
+hm = HookManager(keys=['k']); hm.register('k', neg()); hm.register('k', hook)
+loader = DGDataLoader(dg, batch_size=200, hook_manager=hm)
+with hm.activate('k'):
+    b = loader(loader._starts[5])
+lib = _native.load()
+st = hook._step
+sp = _native.stream_ptr(0)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(300):
+    lib.tgmx_ring_step(st, sp)
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print(f'{"tgmx_ring_step alone":50s} host {1e6 * (t1 - t0) / 300:7.1f} us/call   total {1e6 * (t2 - t0) / 300:7.1f} us/call', flush=True)
