@@ -568,7 +568,7 @@ __device__ __forceinline__ void bitonic_select(long long& key, int& pay, long lo
   }
 }
 
-template <int E, int MAXM>
+template <int E, int MAXM, bool PRESORTED>
 __global__ __launch_bounds__(kBlockThreads) void ring_update_block_kernel(const UpdateArgs a) {
   constexpr int H = 2 * MAXM;  // hash load factor <= 0.5
   constexpr int HBITS = MAXM == 1024 ? 11 : (MAXM == 2048 ? 12 : 13);
@@ -580,89 +580,100 @@ __global__ __launch_bounds__(kBlockThreads) void ring_update_block_kernel(const 
   __shared__ int h_key[H], h_maxp[H];
   __shared__ long long red[kBlockThreads / kWave];
   const int m = (int)a.m;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nthr = blockDim.x, nwaves = nthr >> 6;
+  const int tid = threadIdx.x;
+  const int nthr = blockDim.x;
   const int P = nthr * E;  // power of two >= m
 
-  long long mx = -0x7fffffffffffffffLL;
-  for (int x = tid; x < a.n; x += nthr) {
-    const long long v = a.ts[x];
-    mx = v > mx ? v : mx;
-  }
-  for (int off = 32; off > 0; off >>= 1) {
-    const long long o = __shfl_xor(mx, off);
-    mx = o > mx ? o : mx;
-  }
-  if (lane == 0) red[wave] = mx;
   for (int x = tid; x < H; x += nthr) {
     h_key[x] = -1;
     h_maxp[x] = -1;
   }
-  __syncthreads();
-  mx = red[0];
-  for (int w = 1; w < nwaves; ++w) mx = red[w] > mx ? red[w] : mx;
-  const long long span = mx + 1;
-
   long long key[E];
   int pay[E];
+  if constexpr (PRESORTED) {
+    // the sorted order was produced by the chunk-sort + merge kernels
 #pragma unroll
-  for (int r = 0; r < E; ++r) {
-    const int j = tid * E + r;
-    key[r] = 0x7fffffffffffffffLL;  // padding sorts to the end
-    pay[r] = j;
-    if (j < m) {
-      int node, nbr;
-      long long t, i;
-      update_entry(a, j, node, nbr, t, i);
-      key[r] = update_key(node, t, span, a.key_wrap32);
+    for (int r = 0; r < E; ++r) {
+      const int p = tid * E + r;
+      key[r] = 0;
+      pay[r] = p < m ? a.sorted_j[p] : p;
     }
-  }
+  } else {
+    const int lane = tid & 63, wave = tid >> 6, nwaves = nthr >> 6;
+    long long mx = -0x7fffffffffffffffLL;
+    for (int x = tid; x < a.n; x += nthr) {
+      const long long v = a.ts[x];
+      mx = v > mx ? v : mx;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      const long long o = __shfl_xor(mx, off);
+      mx = o > mx ? o : mx;
+    }
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = red[0];
+    for (int w = 1; w < nwaves; ++w) mx = red[w] > mx ? red[w] : mx;
+    const long long span = mx + 1;
 
-  for (int k = 2; k <= P; k <<= 1) {
-    for (int jj = k >> 1; jj > 0; jj >>= 1) {
-      if (jj < E) {  // both elements live in this thread
-        if constexpr (E >= 2) {
-          const int e0 = tid * E;
-          auto cswap = [&](int r, int r2) {
-            const bool asc = ((e0 + r) & k) == 0;
-            if (pair_after(key[r], pay[r], key[r2], pay[r2]) == asc) {
-              const long long tk = key[r]; key[r] = key[r2]; key[r2] = tk;
-              const int tp = pay[r]; pay[r] = pay[r2]; pay[r2] = tp;
-            }
-          };
-          if (jj == 1) {
-            cswap(0, 1);
-            if constexpr (E == 4) cswap(2, 3);
-          } else {
-            if constexpr (E == 4) {
-              cswap(0, 2);
-              cswap(1, 3);
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+      const int j = tid * E + r;
+      key[r] = 0x7fffffffffffffffLL;  // padding sorts to the end
+      pay[r] = j;
+      if (j < m) {
+        int node, nbr;
+        long long t, i;
+        update_entry(a, j, node, nbr, t, i);
+        key[r] = update_key(node, t, span, a.key_wrap32);
+      }
+    }
+
+    for (int k = 2; k <= P; k <<= 1) {
+      for (int jj = k >> 1; jj > 0; jj >>= 1) {
+        if (jj < E) {  // both elements live in this thread
+          if constexpr (E >= 2) {
+            const int e0 = tid * E;
+            auto cswap = [&](int r, int r2) {
+              const bool asc = ((e0 + r) & k) == 0;
+              if (pair_after(key[r], pay[r], key[r2], pay[r2]) == asc) {
+                const long long tk = key[r]; key[r] = key[r2]; key[r2] = tk;
+                const int tp = pay[r]; pay[r] = pay[r2]; pay[r2] = tp;
+              }
+            };
+            if (jj == 1) {
+              cswap(0, 1);
+              if constexpr (E == 4) cswap(2, 3);
+            } else {
+              if constexpr (E == 4) {
+                cswap(0, 2);
+                cswap(1, 3);
+              }
             }
           }
-        }
-      } else if (jj < kWave * E) {  // partner is another lane of this wave
-        const int lm = jj / E;
+        } else if (jj < kWave * E) {  // partner is another lane of this wave
+          const int lm = jj / E;
 #pragma unroll
-        for (int r = 0; r < E; ++r) {
-          const long long pk = __shfl_xor(key[r], lm);
-          const int pp = __shfl_xor(pay[r], lm);
-          bitonic_select(key[r], pay[r], pk, pp, tid * E + r, jj, k);
-        }
-      } else {  // partner is in another wave: exchange through LDS
+          for (int r = 0; r < E; ++r) {
+            const long long pk = __shfl_xor(key[r], lm);
+            const int pp = __shfl_xor(pay[r], lm);
+            bitonic_select(key[r], pay[r], pk, pp, tid * E + r, jj, k);
+          }
+        } else {  // partner is in another wave: exchange through LDS
 #pragma unroll
-        for (int r = 0; r < E; ++r) {
-          s_key[tid * E + r] = key[r];
-          s_pay[tid * E + r] = pay[r];
-        }
-        __syncthreads();
+          for (int r = 0; r < E; ++r) {
+            s_key[tid * E + r] = key[r];
+            s_pay[tid * E + r] = pay[r];
+          }
+          __syncthreads();
 #pragma unroll
-        for (int r = 0; r < E; ++r) {
-          const int e = tid * E + r;
-          const long long pk = s_key[e ^ jj];
-          const int pp = s_pay[e ^ jj];
-          bitonic_select(key[r], pay[r], pk, pp, e, jj, k);
+          for (int r = 0; r < E; ++r) {
+            const int e = tid * E + r;
+            const long long pk = s_key[e ^ jj];
+            const int pp = s_pay[e ^ jj];
+            bitonic_select(key[r], pay[r], pk, pp, e, jj, k);
+          }
+          __syncthreads();
         }
-        __syncthreads();
       }
     }
   }
@@ -754,12 +765,113 @@ __global__ __launch_bounds__(kBlockThreads) void ring_update_block_kernel(const 
   }
 }
 
-static void launch_update_block(const UpdateArgs& a, hipStream_t st) {
+// 1024 < m <= kBlockMaxM (the replicated update of a 4- or 8-rank global batch): one workgroup is VALU-bound on
+// the sorting network (37 us at m = 3200), so the sort is spread over the chip:
+//   chunk sort : one 256-thread workgroup per 256 entries -- the same register / shuffle bitonic network
+//   merge      : every entry's global rank = its rank in its chunk + sum over the other chunks of a binary search
+//                (all chunk-sorted keys staged in LDS; pairs are unique, so the ranks are a permutation)
+// and the single-workgroup kernel above runs with PRESORTED = true (runs, placement, collisions, writes).
+constexpr int kChunk = 256;
+
+__global__ __launch_bounds__(kChunk) void ring_update_chunk_sort_kernel(const UpdateArgs a) {
+  __shared__ long long s_key[kChunk];
+  __shared__ int s_pay[kChunk];
+  __shared__ long long red[kChunk / kWave];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  long long mx = -0x7fffffffffffffffLL;
+  for (int x = tid; x < a.n; x += kChunk) {
+    const long long v = a.ts[x];
+    mx = v > mx ? v : mx;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const long long o = __shfl_xor(mx, off);
+    mx = o > mx ? o : mx;
+  }
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = red[0];
+  for (int w = 1; w < kChunk / kWave; ++w) mx = red[w] > mx ? red[w] : mx;
+  const long long span = mx + 1;
+
+  const long long j = (long long)blockIdx.x * kChunk + tid;
+  long long key = 0x7fffffffffffffffLL;  // padding of the last chunk sorts to its end
+  int pay = (int)j;
+  if (j < a.m) {
+    int node, nbr;
+    long long t, i;
+    update_entry(a, j, node, nbr, t, i);
+    key = update_key(node, t, span, a.key_wrap32);
+  }
+  for (int k = 2; k <= kChunk; k <<= 1) {
+    for (int jj = k >> 1; jj > 0; jj >>= 1) {
+      long long pk;
+      int pp;
+      if (jj < kWave) {
+        pk = __shfl_xor(key, jj);
+        pp = __shfl_xor(pay, jj);
+      } else {
+        s_key[tid] = key;
+        s_pay[tid] = pay;
+        __syncthreads();
+        pk = s_key[tid ^ jj];
+        pp = s_pay[tid ^ jj];
+        __syncthreads();
+      }
+      bitonic_select(key, pay, pk, pp, tid, jj, k);
+    }
+  }
+  a.key[j] = key;
+  a.node[j] = pay;  // chunk-sorted entry index
+}
+
+__global__ __launch_bounds__(kChunk) void ring_update_merge_kernel(const UpdateArgs a) {
+  __shared__ long long k_all[kBlockMaxM];
+  __shared__ int p_all[kBlockMaxM];
+  const int m = (int)a.m;
+  const int tid = threadIdx.x;
+  for (int x = tid; x < m; x += kChunk) {
+    // chunk c keeps its len_c real entries first (padding sorted last), so [c*256, c*256 + len_c) is dense
+    k_all[x] = a.key[x];
+    p_all[x] = a.node[x];
+  }
+  __syncthreads();
+  const int c = blockIdx.x;
+  const int e = c * kChunk + tid;
+  if (e >= m) return;
+  const long long key = k_all[e];
+  const int pay = p_all[e];
+  int rank = tid;
+  const int chunks = (m + kChunk - 1) / kChunk;
+  for (int o = 0; o < chunks; ++o) {
+    if (o == c) continue;
+    const int base = o * kChunk;
+    int lo = 0, hi = (m - base) < kChunk ? (m - base) : kChunk;  // count of entries of chunk o that sort before mine
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (pair_after(key, pay, k_all[base + mid], p_all[base + mid])) lo = mid + 1;
+      else hi = mid;
+    }
+    rank += lo;
+  }
+  a.sorted_j[rank] = pay;
+}
+
+static void launch_update_block(UpdateArgs& a, int32_t* scratch, hipStream_t st) {
   int P = 64;
   while (P < a.m) P <<= 1;
-  if (P <= 1024) hipLaunchKernelGGL((ring_update_block_kernel<1, 1024>), dim3(1), dim3(P), 0, st, a);
-  else if (P == 2048) hipLaunchKernelGGL((ring_update_block_kernel<2, 2048>), dim3(1), dim3(1024), 0, st, a);
-  else hipLaunchKernelGGL((ring_update_block_kernel<4, 4096>), dim3(1), dim3(1024), 0, st, a);
+  if (P <= 1024) {
+    hipLaunchKernelGGL((ring_update_block_kernel<1, 1024, false>), dim3(1), dim3(P), 0, st, a);
+  } else {
+    // chunk-sorted keys (16-byte aligned int64) and entry indices live behind the four int32[m] arrays
+    const unsigned chunks = (unsigned)((a.m + kChunk - 1) / kChunk);
+    long long* s64 = reinterpret_cast<long long*>(((uintptr_t)(scratch + 4 * a.m) + 15) & ~(uintptr_t)15);
+    a.key = s64;
+    a.node = reinterpret_cast<int32_t*>(s64 + (long long)chunks * kChunk);
+    hipLaunchKernelGGL(ring_update_chunk_sort_kernel, dim3(chunks), dim3(kChunk), 0, st, a);
+    hipLaunchKernelGGL(ring_update_merge_kernel, dim3(chunks), dim3(kChunk), 0, st, a);
+    if (P == 2048) hipLaunchKernelGGL((ring_update_block_kernel<2, 2048, true>), dim3(1), dim3(1024), 0, st, a);
+    else hipLaunchKernelGGL((ring_update_block_kernel<4, 4096, true>), dim3(1), dim3(1024), 0, st, a);
+  }
   if (a.D > 0) hipLaunchKernelGGL(ring_update_feat_kernel, dim3((unsigned)((a.m + 3) / 4)), dim3(256), 0, st, a);
 }
 
@@ -877,7 +989,7 @@ extern "C" int tgmx_ring_update(tgmx_adj_t* ring, int32_t* write_pos, float* rin
                                   key_wrap32, scratch, status);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
-  if (a.m <= kBlockMaxM) launch_update_block(a, st);
+  if (a.m <= kBlockMaxM) launch_update_block(a, scratch, st);
   else launch_update_large(a, scratch, st);
   TGMX_CHECK_LAUNCH("ring_update");
   return TGMX_OK;
@@ -936,7 +1048,7 @@ extern "C" int tgmx_ring_step(const tgmx_ring_step_t* s, tgmx_stream_t stream) {
     const int rc = fill_update_args(u, s->ring, s->write_pos, s->ring_x, s->D, s->B, s->num_nodes, s->src, s->dst, s->ts,
                                     s->edge_x, s->n, s->eid0, s->directed, s->key_wrap32, s->scratch, s->status);
     if (rc) return rc;
-    if (u.m <= kBlockMaxM) launch_update_block(u, st);
+    if (u.m <= kBlockMaxM) launch_update_block(u, s->scratch, st);
     else launch_update_large(u, s->scratch, st);
   }
   TGMX_CHECK_LAUNCH("ring_step");

@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void tgat_attn_reduce_kernel(const AttnArgs a)
   extern __shared__ __attribute__((aligned(16))) float lds_all[];
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
-  const int k = a.k, T = a.T, d = a.d, D = a.D, C = a.C;
+  const int k = a.k, T = a.T, d = a.d, D = a.D;
   // per-wave LDS: cos cache [k][T], dt [k], valid [k], A [H][k]
   float* s_cos = lds_all + (size_t)wave * (k * T + k * (H + 2));
   float* s_dt = s_cos + k * T;
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256) void tgat_attn_reduce_reg_kernel(const AttnArg
   const int lane = lane_id();
   const long long r = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (r >= a.R) return;
-  const int k = a.k, T = a.T, d = a.d, D = a.D, C = a.C;
+  const int k = a.k, T = a.T, d = a.d, D = a.D;
   const int D4 = D >> 2, d4 = d >> 2;
   const float* __restrict__ q = a.qf + r * (long long)H * a.Cs;
   const float* __restrict__ nb = a.nbrf + r * (long long)k * d;
