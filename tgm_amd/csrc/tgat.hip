@@ -38,25 +38,34 @@ struct GemmArgs {
   int N, K, relu;
 };
 
-template <bool VEC>
-__device__ __forceinline__ void load_k8(const float* __restrict__ row, int kb, int K, float (&v)[8]) {
-  if (VEC && kb + 8 <= K) {
-    const float4 x = *reinterpret_cast<const float4*>(row + kb);
-    const float4 y = *reinterpret_cast<const float4*>(row + kb + 4);
-    v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
-    v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
-  } else {
+// One k-step covers 2 * kGemmK columns of K: lanes 0-31 hold the first kGemmK of their row, lanes 32-63 the next
+// kGemmK (any pairing of k with the two k-slots of the 32x32x2 MFMA is valid as long as A and B agree).
+// kGemmK = 8 measured best on this path's skinny GEMMs (16 / 32 cost occupancy: 216+ VGPRs, one wave per SIMD).
+
+template <bool VEC, int kGemmK>
+__device__ __forceinline__ void load_kn(const float* __restrict__ row, int kb, int K, float (&v)[kGemmK]) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = kb + u < K ? row[kb + u] : 0.f;
+  for (int c = 0; c < kGemmK; c += 4) {
+    if (VEC && kb + c + 4 <= K) {
+      const float4 x = *reinterpret_cast<const float4*>(row + kb + c);
+      v[c] = x.x; v[c + 1] = x.y; v[c + 2] = x.z; v[c + 3] = x.w;
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[c + u] = kb + c + u < K ? row[kb + c + u] : 0.f;
+    }
   }
 }
 
-template <bool AV, bool BV>
+// C[M, N] = A[M, K] . B[N, K]^T (+ bias, relu), both operands K-contiguous and loaded straight into the MFMA
+// register layout (no LDS staging).  SPLIT = false: the 4 waves of a block own 4 row tiles (128 rows).
+// SPLIT = true (few tiles): the 4 waves share ONE 32 x 64 tile, wave w takes k-steps w, w + 4, ... and the
+// partial tiles meet in LDS (fixed summation order: deterministic).
+template <bool AV, bool BV, bool SPLIT, int kGemmK>
 __global__ __launch_bounds__(256) void sgemm_nt_kernel(const GemmArgs g) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 31, half = lane >> 5;
-  const long long m0 = (long long)blockIdx.x * 128 + wave * 32;
-  if (m0 >= g.M) return;  // whole wave out of range (no block-level sync anywhere)
+  const long long m0 = SPLIT ? (long long)blockIdx.x * 32 : (long long)blockIdx.x * 128 + wave * 32;
+  if (!SPLIT && m0 >= g.M) return;  // whole wave out of range (no block-level sync on this path)
   const int n0 = blockIdx.y * 64;
   const float* __restrict__ A = g.A + (long long)blockIdx.z * g.sA;
   const float* __restrict__ B = g.B + (long long)blockIdx.z * g.sB;
@@ -70,32 +79,60 @@ __global__ __launch_bounds__(256) void sgemm_nt_kernel(const GemmArgs g) {
   const float* __restrict__ pb1 = B + (long long)c1 * g.ldb;
 
   floatx16 acc0 = {0}, acc1 = {0};
-  float a[8], b0[8], b1[8], an[8], b0n[8], b1n[8];
-  int kb = half * 8;
-  load_k8<AV>(pa, kb, g.K, a);
-  load_k8<BV>(pb0, kb, g.K, b0);
-  load_k8<BV>(pb1, kb, g.K, b1);
-  for (int k0 = 0; k0 < g.K; k0 += 16) {
-    const bool more = k0 + 16 < g.K;
+  float a[kGemmK], b0[kGemmK], b1[kGemmK], an[kGemmK], b0n[kGemmK], b1n[kGemmK];
+  constexpr int kStep = 2 * kGemmK;
+  const int stride = SPLIT ? 4 * kStep : kStep;
+  int k0 = SPLIT ? wave * kStep : 0;
+  if (k0 < g.K) {
+    load_kn<AV, kGemmK>(pa, k0 + half * kGemmK, g.K, a);
+    load_kn<BV, kGemmK>(pb0, k0 + half * kGemmK, g.K, b0);
+    load_kn<BV, kGemmK>(pb1, k0 + half * kGemmK, g.K, b1);
+  }
+  for (; k0 < g.K; k0 += stride) {
+    const bool more = k0 + stride < g.K;
     if (more) {
-      load_k8<AV>(pa, kb + 16, g.K, an);
-      load_k8<BV>(pb0, kb + 16, g.K, b0n);
-      load_k8<BV>(pb1, kb + 16, g.K, b1n);
+      const int kb = k0 + stride + half * kGemmK;
+      load_kn<AV, kGemmK>(pa, kb, g.K, an);
+      load_kn<BV, kGemmK>(pb0, kb, g.K, b0n);
+      load_kn<BV, kGemmK>(pb1, kb, g.K, b1n);
     }
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
+    for (int kk = 0; kk < kGemmK; ++kk) {
       acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], b0[kk], acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], b1[kk], acc1, 0, 0, 0);
     }
     if (more) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < kGemmK; ++u) {
         a[u] = an[u];
         b0[u] = b0n[u];
         b1[u] = b1n[u];
       }
     }
-    kb += 16;
+  }
+  if (SPLIT) {
+    __shared__ float part[4][32][kWave];  // [wave][acc register (0-15: acc0, 16-31: acc1)][lane]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      part[wave][r][lane] = acc0[r];
+      part[wave][16 + r][lane] = acc1[r];
+    }
+    __syncthreads();
+    // wave w finishes registers 8w .. 8w+7 of every lane
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int rr = wave * 8 + q;
+      float v = part[0][rr][lane] + part[1][rr][lane] + part[2][rr][lane] + part[3][rr][lane];
+      const int r = rr & 15, t = rr >> 4;
+      const long long row = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      const int col = n0 + t * 32 + i;
+      if (row < g.M && col < g.N) {
+        if (g.bias) v += g.bias[col];
+        if (g.relu) v = v > 0.f ? v : 0.f;
+        C[row * g.ldc + col] = v;
+      }
+    }
+    return;
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -560,14 +597,26 @@ extern "C" int tgmx_sgemm_nt(const float* A, int64_t lda, const float* B, int64_
   TGMX_REQUIRE(A && B && C, "sgemm_nt: null pointer");
   TGMX_REQUIRE(lda >= K && ldb >= K && ldc >= N, "sgemm_nt: leading dimension smaller than the row length");
   GemmArgs g{A, B, C, bias, lda, ldb, ldc, strideA, strideB, strideC, M, N, K, relu};
-  const dim3 grid((unsigned)((M + 127) / 128), (unsigned)((N + 63) / 64), (unsigned)batch), block(256);
   auto vec_ok = [](const float* p, long long ld, long long stride) { return ((uintptr_t)p & 15) == 0 && ld % 4 == 0 && stride % 4 == 0; };
   const bool av = vec_ok(A, lda, strideA), bv = vec_ok(B, ldb, strideB);
   hipStream_t st = (hipStream_t)stream;
-  if (av && bv) hipLaunchKernelGGL((sgemm_nt_kernel<true, true>), grid, block, 0, st, g);
-  else if (av) hipLaunchKernelGGL((sgemm_nt_kernel<true, false>), grid, block, 0, st, g);
-  else if (bv) hipLaunchKernelGGL((sgemm_nt_kernel<false, true>), grid, block, 0, st, g);
-  else hipLaunchKernelGGL((sgemm_nt_kernel<false, false>), grid, block, 0, st, g);
+  const dim3 block(256);
+  // K-splitting across the 4 waves of a block (4x the waves, each with a quarter of the dependent MFMA chain) wins
+  // whenever there is more than one 16-wide k-step to hand out; measured on every GEMM shape of the TGAT path
+  // (600 .. 12 600 rows, K = 102 .. 448: 1.1x .. 2.9x) and neutral at 4096^3.
+  const bool split = K > 16;
+  const dim3 grid = split ? dim3((unsigned)((M + 31) / 32), (unsigned)((N + 63) / 64), (unsigned)batch)
+                          : dim3((unsigned)((M + 127) / 128), (unsigned)((N + 63) / 64), (unsigned)batch);
+#define TGMX_GEMM(AV_, BV_) \
+  do { \
+    if (split) hipLaunchKernelGGL((sgemm_nt_kernel<AV_, BV_, true, 8>), grid, block, 0, st, g); \
+    else hipLaunchKernelGGL((sgemm_nt_kernel<AV_, BV_, false, 8>), grid, block, 0, st, g); \
+  } while (0)
+  if (av && bv) TGMX_GEMM(true, true);
+  else if (av) TGMX_GEMM(true, false);
+  else if (bv) TGMX_GEMM(false, true);
+  else TGMX_GEMM(false, false);
+#undef TGMX_GEMM
   TGMX_CHECK_LAUNCH("sgemm_nt");
   return TGMX_OK;
 }

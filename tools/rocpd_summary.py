@@ -18,13 +18,17 @@ def main():
     md = '--md' in sys.argv
     db = sqlite3.connect(path)
     cur = db.cursor()
-    rows = cur.execute("select name || ' [grid ' || grid_x || ']', count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels group by name, grid_x order by sum(duration) desc").fetchall()
+    if '--xyz' in sys.argv:  # one line per launch shape
+        q = "select name || ' [grid ' || grid_x || 'x' || grid_y || 'x' || grid_z || ']', count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels group by name, grid_x, grid_y, grid_z order by sum(duration) desc"
+    else:
+        q = "select name || ' [grid ' || grid_x || ']', count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels group by name, grid_x order by sum(duration) desc"
+    rows = cur.execute(q).fetchall()
     total = sum(r[2] for r in rows) or 1
     if rows:
         print('| kernel | calls | total ms | avg us | min us | max us | % |' if md else f'{"kernel":80s} {"calls":>7s} {"total ms":>10s} {"avg us":>9s} {"min us":>9s} {"max us":>9s} {"%":>6s}')
         if md:
             print('|---|---:|---:|---:|---:|---:|---:|')
-        for name, calls, tot, avg, mn, mx in rows[:25]:
+        for name, calls, tot, avg, mn, mx in rows[: (60 if '--xyz' in sys.argv else 25)]:
             if md:
                 print(f'| `{short(name, 70)}` | {calls} | {tot / 1e6:.3f} | {avg / 1e3:.2f} | {mn / 1e3:.2f} | {mx / 1e3:.2f} | {100 * tot / total:.1f} |')
             else:
