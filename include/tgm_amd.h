@@ -160,13 +160,20 @@ int tgmx_ring_reset(tgmx_adj_t* ring, int32_t* write_pos, int32_t B, int32_t num
                     tgmx_stream_t stream);
 
 /* ------------------------------------------------------------------------
- * Index build helper: pack (nbr, eid, ts) columns, already permuted into
- * index order, into 16-byte records.  perm[m] (int64) = position in the
- * canonical entry list: entry e < num_edges is (src->dst, role 0), entry
- * num_edges+e is (dst->src, role 1).
+ * Static index build (ours: the reference has no index; SURVEY.md Appendix A.3 shows the ring state at the start of
+ * a batch is a pure function of it).  Orders node n's adjacency entries by (batch_idx, time, role, eid) -- role 0 =
+ * n is the source -- with one device radix sort and writes indptr[num_nodes + 1] and the 16-byte records.
+ *   src/dst/ts   the time-sorted stream (the store DGData normalises, tgm/data/dg_data.py:350-394)
+ *   batch_starts [num_batches] increasing first-edge indices of the loader's batches (tgm/data/loader.py:158-170);
+ *                edges before batch_starts[0] form one leading batch
+ *   directed     index source-role entries only (recency.py:332-343)
+ *   workspace    >= tgmx_csr_build_workspace_bytes(num_edges, num_nodes, directed)
+ *   status       TGMX_ST_EDGE_RANGE is raised for endpoints outside [0, num_nodes)
  * ------------------------------------------------------------------------ */
-int tgmx_pack_adj(const int64_t* perm, int64_t m, const int32_t* src, const int32_t* dst,
-                  const int64_t* ts, int64_t num_edges, tgmx_adj_t* adj, tgmx_stream_t stream);
+size_t tgmx_csr_build_workspace_bytes(int64_t num_edges, int32_t num_nodes, int32_t directed);
+int tgmx_csr_build(const int32_t* src, const int32_t* dst, const int64_t* ts, int64_t num_edges, int32_t num_nodes,
+                   const int64_t* batch_starts, int64_t num_batches, int32_t directed, int64_t* indptr,
+                   tgmx_adj_t* adj, void* workspace, size_t workspace_bytes, int32_t* status, tgmx_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * TGAT / TemporalAttention forward (fp32, eval mode).  The attention is

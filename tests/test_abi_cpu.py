@@ -18,7 +18,7 @@ def declared_symbols():
 def test_header_declares_the_expected_families():
     syms = declared_symbols()
     for needed in ('tgmx_version', 'tgmx_last_error', 'tgmx_recency_lookup_csr', 'tgmx_ring_lookup', 'tgmx_ring_update',
-                   'tgmx_ring_reset', 'tgmx_pack_adj', 'tgmx_time2vec', 'tgmx_sgemm_nt', 'tgmx_tgat_attn_reduce'):  # fmt: skip
+                   'tgmx_ring_reset', 'tgmx_csr_build', 'tgmx_time2vec', 'tgmx_sgemm_nt', 'tgmx_tgat_attn_reduce'):  # fmt: skip
         assert needed in syms
 
 

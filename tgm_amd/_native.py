@@ -77,7 +77,6 @@ SIGNATURES = {
         [_P, _P, _P, _P, c_int32, _P, c_int32, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int64, ctypes.c_float, c_int32, _P, _P, _P, _P],
     ),
     'tgmx_ln_residual_concat': (c_int32, [_P, c_int64, _P, c_int64, _P, _P, c_int32, ctypes.c_float, _P, c_int32, c_int64, _P, c_int64, _P]),
-    'tgmx_pack_adj': (c_int32, [_P, c_int64, _P, _P, _P, c_int64, _P, _P]),
 }
 
 TGAT_MAX_LAYERS = 4
@@ -130,6 +129,8 @@ class RingStep(ctypes.Structure):
     ]  # fmt: skip
 
 
+SIGNATURES['tgmx_csr_build_workspace_bytes'] = (c_size_t, [c_int64, c_int32, c_int32])
+SIGNATURES['tgmx_csr_build'] = (c_int32, [_P, _P, _P, c_int64, c_int32, _P, c_int64, c_int32, _P, _P, _P, c_size_t, _P, _P])
 SIGNATURES['tgmx_ring_step'] = (c_int32, [ctypes.POINTER(RingStep), _P])
 SIGNATURES['tgmx_tgat_layout'] = (c_int32, [ctypes.POINTER(TgatModel), c_int64, ctypes.POINTER(TgatHop), c_int32, ctypes.POINTER(TgatLayout)])
 SIGNATURES['tgmx_tgat_workspace_bytes'] = (c_size_t, [ctypes.POINTER(TgatModel), c_int64, ctypes.POINTER(TgatHop)])

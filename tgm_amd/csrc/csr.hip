@@ -1,0 +1,194 @@
+// Static per-node temporal index (CSR) build, fully on the device.
+//
+// Node n's adjacency entries must be ordered by (batch_idx, time, role, eid), role 0 = n is the edge's source.
+// Because the stream is time-sorted and batches are contiguous edge ranges, that order is a closed-form position:
+// inside a maximal run [lo, hi) of edges sharing (batch, timestamp) the source-role entries come first, then the
+// destination-role entries, so   pos(e, src-role) = lo + e,   pos(e, dst-role) = hi + e   (a permutation of
+// [0, 2E)).  One LSD radix sort (rocPRIM) of the 64-bit key (node << 32 | pos) then yields the whole index: keys are
+// unique, so no stability argument is needed; indptr is a binary search per node over the sorted keys (no atomics,
+// no scan), and the records are packed straight from the sorted values.
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "common.h"
+
+namespace tgmx {
+
+struct __align__(16) CsrRec {
+  int nbr;
+  int eid;
+  long long ts;
+};
+static_assert(sizeof(CsrRec) == sizeof(tgmx_adj_t), "record layout");
+
+struct CsrKeyArgs {
+  const int32_t* src;
+  const int32_t* dst;
+  const int64_t* ts;
+  const int64_t* starts;  // [nb] first edge of every batch (increasing); edges before starts[0] form a leading batch
+  long long E, nb;
+  unsigned long long* keys;
+  unsigned int* vals;
+  int32_t* status;
+  int N, directed;
+};
+
+__global__ __launch_bounds__(256) void csr_keys_kernel(const CsrKeyArgs a) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= a.E) return;
+  const int s = a.src[e], d = a.dst[e];
+  if (s < 0 || s >= a.N || d < 0 || d >= a.N) atomicOr(a.status, TGMX_ST_EDGE_RANGE);
+  if (a.directed) {
+    a.keys[e] = ((unsigned long long)(unsigned)s << 32) | (unsigned long long)e;
+    a.vals[e] = (unsigned)e;
+    return;
+  }
+  // batch of e: number of starts <= e
+  long long lo = 0, hi = a.nb;
+  while (lo < hi) {
+    const long long mid = (lo + hi) >> 1;
+    if (a.starts[mid] <= e) lo = mid + 1;
+    else hi = mid;
+  }
+  const long long b_lo = lo > 0 ? a.starts[lo - 1] : 0;
+  const long long b_hi = lo < a.nb ? a.starts[lo] : a.E;
+  // run of equal timestamps around e, clamped to the batch (ts is sorted)
+  const long long t = a.ts[e];
+  long long l = b_lo, h = e;  // first index in [b_lo, e] with ts == t
+  while (l < h) {
+    const long long mid = (l + h) >> 1;
+    if (a.ts[mid] < t) l = mid + 1;
+    else h = mid;
+  }
+  const long long run_lo = l;
+  l = e + 1;
+  h = b_hi;  // first index in (e, b_hi] with ts > t
+  while (l < h) {
+    const long long mid = (l + h) >> 1;
+    if (a.ts[mid] <= t) l = mid + 1;
+    else h = mid;
+  }
+  const long long run_hi = l;
+  a.keys[e] = ((unsigned long long)(unsigned)s << 32) | (unsigned long long)(run_lo + e);
+  a.vals[e] = (unsigned)e;
+  a.keys[a.E + e] = ((unsigned long long)(unsigned)d << 32) | (unsigned long long)(run_hi + e);
+  a.vals[a.E + e] = (unsigned)(a.E + e);
+}
+
+__global__ __launch_bounds__(256) void csr_indptr_kernel(const unsigned long long* __restrict__ keys, long long M, int N,
+                                                         int64_t* __restrict__ indptr) {
+  const long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n > N) return;
+  long long lo = 0, hi = M;  // first sorted position whose node >= n
+  while (lo < hi) {
+    const long long mid = (lo + hi) >> 1;
+    if ((long long)(keys[mid] >> 32) < n) lo = mid + 1;
+    else hi = mid;
+  }
+  indptr[n] = lo;
+}
+
+__global__ __launch_bounds__(256) void csr_pack_kernel(const unsigned int* __restrict__ vals, long long M, long long E,
+                                                       const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
+                                                       const int64_t* __restrict__ ts, CsrRec* __restrict__ adj) {
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= M) return;
+  const long long c = vals[p];
+  const bool rev = c >= E;
+  const long long e = rev ? c - E : c;
+  CsrRec r;
+  r.nbr = rev ? src[e] : dst[e];
+  r.eid = (int)e;
+  r.ts = ts[e];
+  adj[p] = r;
+}
+
+static int key_bits(int N) {
+  int b = 1;
+  while ((1ll << b) < (long long)N) ++b;
+  return 32 + b;
+}
+
+struct CsrWorkspace {
+  size_t keys_in, keys_out, vals_in, vals_out, temp, temp_bytes, total;
+};
+
+static int csr_layout(long long E, int N, int directed, CsrWorkspace& w) {
+  const long long M = directed ? E : 2 * E;
+  auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  size_t off = 0;
+  w.keys_in = off; off = up(off + (size_t)M * 8);
+  w.keys_out = off; off = up(off + (size_t)M * 8);
+  w.vals_in = off; off = up(off + (size_t)M * 4);
+  w.vals_out = off; off = up(off + (size_t)M * 4);
+  size_t tb = 0;
+  const hipError_t err = rocprim::radix_sort_pairs(nullptr, tb, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
+                                                   (const unsigned int*)nullptr, (unsigned int*)nullptr, (size_t)M, 0u,
+                                                   (unsigned)key_bits(N));
+  if (err != hipSuccess) {
+    set_error("csr_build: radix sort workspace query failed: %s", hipGetErrorString(err));
+    return TGMX_E_LAUNCH;
+  }
+  w.temp = off;
+  w.temp_bytes = tb;
+  off = up(off + tb);
+  w.total = off + 256;  // slack for aligning the caller's base pointer
+  return TGMX_OK;
+}
+
+}  // namespace tgmx
+
+using namespace tgmx;
+
+extern "C" size_t tgmx_csr_build_workspace_bytes(int64_t num_edges, int32_t num_nodes, int32_t directed) {
+  if (num_edges <= 0 || num_nodes <= 0) return 256;
+  CsrWorkspace w;
+  if (csr_layout(num_edges, num_nodes, directed, w)) return 0;
+  return w.total;
+}
+
+extern "C" int tgmx_csr_build(const int32_t* src, const int32_t* dst, const int64_t* ts, int64_t num_edges, int32_t num_nodes,
+                              const int64_t* batch_starts, int64_t num_batches, int32_t directed, int64_t* indptr,
+                              tgmx_adj_t* adj, void* workspace, size_t workspace_bytes, int32_t* status,
+                              tgmx_stream_t stream) {
+  TGMX_REQUIRE(num_edges >= 0 && num_nodes > 0 && num_batches >= 0, "csr_build: bad sizes E=%lld N=%d nb=%lld", (long long)num_edges,
+               num_nodes, (long long)num_batches);
+  TGMX_REQUIRE(indptr && status, "csr_build: null pointer");
+  TGMX_REQUIRE(2 * num_edges < 2147483647LL, "csr_build: more than 2^30 edges need 64-bit positions");
+  hipStream_t st = (hipStream_t)stream;
+  const long long M = directed ? num_edges : 2 * num_edges;
+  if (num_edges == 0) {
+    (void)hipMemsetAsync(indptr, 0, sizeof(int64_t) * ((size_t)num_nodes + 1), st);
+    return TGMX_OK;
+  }
+  TGMX_REQUIRE(src && dst && ts && adj && workspace, "csr_build: null pointer");
+  TGMX_REQUIRE(directed || num_batches == 0 || batch_starts, "csr_build: null batch_starts");
+  TGMX_REQUIRE(((uintptr_t)adj & 15) == 0, "csr_build: adj must be 16-byte aligned");
+  CsrWorkspace w;
+  const int rc = csr_layout(num_edges, num_nodes, directed, w);
+  if (rc) return rc;
+  TGMX_REQUIRE(workspace_bytes >= w.total, "csr_build: workspace of %zu bytes, need %zu", workspace_bytes, w.total);
+  char* base = reinterpret_cast<char*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  auto* keys_in = reinterpret_cast<unsigned long long*>(base + w.keys_in);
+  auto* keys_out = reinterpret_cast<unsigned long long*>(base + w.keys_out);
+  auto* vals_in = reinterpret_cast<unsigned int*>(base + w.vals_in);
+  auto* vals_out = reinterpret_cast<unsigned int*>(base + w.vals_out);
+
+  CsrKeyArgs k{src, dst, ts, batch_starts, num_edges, num_batches, keys_in, vals_in, status, num_nodes, directed};
+  hipLaunchKernelGGL(csr_keys_kernel, dim3((unsigned)((num_edges + 255) / 256)), dim3(256), 0, st, k);
+  size_t tb = w.temp_bytes;
+  const hipError_t err = rocprim::radix_sort_pairs(base + w.temp, tb, (const unsigned long long*)keys_in, keys_out,
+                                                   (const unsigned int*)vals_in, vals_out, (size_t)M, 0u,
+                                                   (unsigned)key_bits(num_nodes), st);
+  if (err != hipSuccess) {
+    set_error("csr_build: radix sort failed: %s", hipGetErrorString(err));
+    return TGMX_E_LAUNCH;
+  }
+  hipLaunchKernelGGL(csr_indptr_kernel, dim3((unsigned)((num_nodes + 1 + 255) / 256)), dim3(256), 0, st, keys_out, M, num_nodes,
+                     indptr);
+  hipLaunchKernelGGL(csr_pack_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, vals_out, M, (long long)num_edges, src,
+                     dst, ts, reinterpret_cast<CsrRec*>(adj));
+  TGMX_CHECK_LAUNCH("csr_build");
+  return TGMX_OK;
+}

@@ -884,21 +884,6 @@ __global__ __launch_bounds__(256) void ring_reset_kernel(Rec* ring, int32_t* wri
   for (long long x = i; x < N; x += step) write_pos[x] = 0;
 }
 
-__global__ __launch_bounds__(256) void pack_adj_kernel(const int64_t* perm, long long m, const int32_t* src,
-                                                       const int32_t* dst, const int64_t* ts, long long E, Rec* adj) {
-  const long long step = (long long)gridDim.x * blockDim.x;
-  for (long long x = (long long)blockIdx.x * blockDim.x + threadIdx.x; x < m; x += step) {
-    const long long p = perm[x];
-    const bool rev = p >= E;
-    const long long e = rev ? p - E : p;
-    Rec r;
-    r.nbr = rev ? src[e] : dst[e];
-    r.eid = (int)e;
-    r.ts = ts[e];
-    adj[x] = r;
-  }
-}
-
 }  // namespace tgmx
 
 using namespace tgmx;
@@ -1064,18 +1049,5 @@ extern "C" int tgmx_ring_reset(tgmx_adj_t* ring, int32_t* write_pos, int32_t B, 
   hipLaunchKernelGGL(ring_reset_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                      reinterpret_cast<Rec*>(ring), write_pos, nrec, num_nodes);
   TGMX_CHECK_LAUNCH("ring_reset");
-  return TGMX_OK;
-}
-
-extern "C" int tgmx_pack_adj(const int64_t* perm, int64_t m, const int32_t* src, const int32_t* dst, const int64_t* ts,
-                             int64_t num_edges, tgmx_adj_t* adj, tgmx_stream_t stream) {
-  TGMX_REQUIRE(m >= 0 && num_edges >= 0, "pack_adj: bad sizes");
-  if (m == 0) return TGMX_OK;
-  TGMX_REQUIRE(perm && src && dst && ts && adj, "pack_adj: null pointer");
-  long long blocks = (m + 255) / 256;
-  if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(pack_adj_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, perm, (long long)m, src,
-                     dst, ts, (long long)num_edges, reinterpret_cast<Rec*>(adj));
-  TGMX_CHECK_LAUNCH("pack_adj");
   return TGMX_OK;
 }

@@ -13,9 +13,9 @@ Layout in HBM: ``indptr[N+1]`` int64 and ``adj[M]`` 16-byte records
 lane fetches one record with one dwordx4 load and a window of B records is one
 contiguous B*16-byte read.
 
-The build is one-off setup.  It orders entries with device-side torch sorts
-(plumbing) and packs the records with a HIP kernel; the per-batch path never
-touches torch ops.
+The build is one-off setup and runs in the native library (``tgmx_csr_build``:
+closed-form canonical positions, one rocPRIM radix sort of ``(node, position)``
+keys, a binary search per node for ``indptr``, record packing).
 """
 from __future__ import annotations
 
@@ -67,45 +67,32 @@ def build_csr(
     _native.require_device(src, 'edge stream')
     dev = src.device
     E = int(src.numel())
-    eids = torch.arange(E, device=dev, dtype=torch.int64)
     if batch_starts is None:
         if batch_size is None or batch_size <= 0:
             raise ValueError('build_csr needs batch_starts or a positive batch_size')
         starts = torch.arange(first_edge, max(E, first_edge + 1), batch_size, device=dev, dtype=torch.int64)
     else:
         starts = torch.as_tensor(batch_starts, dtype=torch.int64, device=dev)
-    bidx = torch.searchsorted(starts, eids, right=True)  # 0 for edges before the first boundary
-
-    ts = ts.to(torch.int64)
-    if directed:
-        canon = eids
-        node_c = src.long()
-    else:
-        # runs of equal (batch, time) are contiguous in eid; inside a run the
-        # source-role entries come first, then the destination-role entries.
-        tspan = int(ts.max().item()) + 1 if E else 1
-        key = bidx * tspan + ts
-        run_lo = torch.searchsorted(key, key, right=False)
-        run_hi = torch.searchsorted(key, key, right=True)
-        pos_src = run_lo + eids  # 2*run_lo + (eid - run_lo)
-        pos_dst = run_hi + eids  # 2*run_lo + (run_hi - run_lo) + (eid - run_lo)
-        canon = torch.empty(2 * E, device=dev, dtype=torch.int64)
-        canon[pos_src] = eids
-        canon[pos_dst] = eids + E
-        node_c = torch.cat([src, dst]).long()[canon]
-    order = torch.sort(node_c, stable=True).indices
-    perm = canon[order].contiguous()
-    counts = torch.bincount(node_c, minlength=num_nodes)
-    indptr = torch.zeros(num_nodes + 1, device=dev, dtype=torch.int64)
-    indptr[1:] = torch.cumsum(counts, 0)
-
-    M = int(perm.numel())
+    ts = ts.to(torch.int64).contiguous()
+    src, dst = src.contiguous(), dst.contiguous()
+    M = E if directed else 2 * E
+    indptr = torch.empty(num_nodes + 1, device=dev, dtype=torch.int64)
     adj = torch.empty((max(M, 1), 2), device=dev, dtype=torch.int64)
     lib = _native.load()
-    _native.check(
-        lib.tgmx_pack_adj(
-            perm.data_ptr(), M, src.data_ptr(), dst.data_ptr(), ts.data_ptr(), E, adj.data_ptr(), _native.stream_ptr()
-        ),
-        'tgmx_pack_adj',
-    )
+    ws_bytes = int(lib.tgmx_csr_build_workspace_bytes(E, num_nodes, 1 if directed else 0))
+    if ws_bytes == 0:
+        _native.check(-2, 'tgmx_csr_build_workspace_bytes')
+    workspace = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+    status = torch.zeros(1, device=dev, dtype=torch.int32)
+    with torch.cuda.device(dev):
+        _native.check(
+            lib.tgmx_csr_build(
+                src.data_ptr(), dst.data_ptr(), ts.data_ptr(), E, num_nodes, starts.data_ptr(), int(starts.numel()),
+                1 if directed else 0, indptr.data_ptr(), adj.data_ptr(), workspace.data_ptr(), ws_bytes, status.data_ptr(),
+                _native.stream_ptr(dev.index),
+            ),
+            'tgmx_csr_build',
+        )  # fmt: skip
+    if int(status.item()):
+        raise ValueError(f'Edge endpoints must satisfy 0 <= x < {num_nodes}')
     return TemporalCSR(indptr, adj[:M] if M else adj[:0], num_nodes, E, directed, starts)
