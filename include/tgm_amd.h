@@ -117,17 +117,20 @@ int tgmx_ring_update(tgmx_adj_t* ring, int32_t* write_pos, float* ring_x, int32_
 /* One whole hook call, RecencyNeighborHook.__call__ (recency.py:119-171), as ONE entry point: concatenate the
  * hop-0 seed groups (recency.py:173-237), run every hop's lookup (hop h+1 reads hop h's outputs in place, pads
  * included, recency.py:140-159), then append the batch to the rings (recency.py:161-163 -> :323-399).
- * Semantics are exactly tgmx_ring_lookup x n_hops followed by tgmx_ring_update; the seed concatenation rides
+ * Semantics are exactly tgmx_ring_lookup x n_hops followed by tgmx_ring_update (or, with indptr set,
+ * tgmx_recency_lookup_csr x n_hops against the static index); the seed concatenation rides
  * on the hop-0 lookup launch (its wave of seed s reads group g's arrays and publishes seed_nid0[s] / seed_ts0[s]).
  *   n_groups = 0: hop-0 seeds are already in seed_nid0 / seed_ts0 (S0 of them).
  *   n_hops   = 0: update only.          n = 0: lookups only.
  *   timed_hop >= 0: ev_start / ev_stop are recorded around that hop's lookup launch. */
 #define TGMX_MAX_SEED_GROUPS 8
 #define TGMX_MAX_HOPS 8
-typedef struct tgmx_ring_step {
-  tgmx_adj_t* ring;            /* [num_nodes, B] records */
-  int32_t* write_pos;          /* [num_nodes] */
-  float* ring_x;               /* [num_nodes, B, D] */
+typedef struct tgmx_recency_step {
+  tgmx_adj_t* ring;            /* streaming: [num_nodes, B] records.   static index: adj[M] records */
+  int32_t* write_pos;          /* streaming: [num_nodes].              static index: NULL */
+  float* ring_x;               /* streaming: [num_nodes, B, D].        static index: edge_x[E, D] */
+  const int64_t* indptr;       /* NULL = streaming rings; else the static index (tgmx_csr_build): no update, n must be 0 */
+  int64_t ev_lo, ev_hi;        /* static index: first edge visible in this epoch / first edge of this batch */
   int32_t D, B, num_nodes;
   int32_t n_groups;
   const int32_t* grp_nid[TGMX_MAX_SEED_GROUPS];
@@ -151,9 +154,9 @@ typedef struct tgmx_ring_step {
   int32_t* status;
   int32_t timed_hop;           /* -1: none */
   tgmx_event_t ev_start, ev_stop;
-} tgmx_ring_step_t;
+} tgmx_recency_step_t;
 
-int tgmx_ring_step(const tgmx_ring_step_t* step, tgmx_stream_t stream);
+int tgmx_recency_step(const tgmx_recency_step_t* step, tgmx_stream_t stream);
 
 /* ring.fill(pad), write_pos.zero_()  (recency.py:111-117) */
 int tgmx_ring_reset(tgmx_adj_t* ring, int32_t* write_pos, int32_t B, int32_t num_nodes,

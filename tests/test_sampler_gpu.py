@@ -182,7 +182,7 @@ def test_ring_mode_matches_oracle_random(N, E, D, tmax, num_nbrs, bs, directed, 
     ],
 )
 def test_ring_step_variants(N, E, D, tmax, num_nbrs, bs, validate):
-    """tgmx_ring_step in every validation mode (one call per batch, or lookups / check / update)."""
+    """tgmx_recency_step in every validation mode (one call per batch, or lookups / check / update)."""
     _check_ring_against_oracle(N, E, D, tmax, num_nbrs, bs, False, 'int32', validate=validate)
 
 

@@ -111,11 +111,12 @@ MAX_SEED_GROUPS = 8
 MAX_HOPS = 8
 
 
-class RingStep(ctypes.Structure):
-    """tgmx_ring_step_t (include/tgm_amd.h)."""
+class RecencyStep(ctypes.Structure):
+    """tgmx_recency_step_t (include/tgm_amd.h)."""
 
     _fields_ = [
         ('ring', c_void_p), ('write_pos', c_void_p), ('ring_x', c_void_p),
+        ('indptr', c_void_p), ('ev_lo', c_int64), ('ev_hi', c_int64),
         ('D', c_int32), ('B', c_int32), ('num_nodes', c_int32),
         ('n_groups', c_int32),
         ('grp_nid', c_void_p * MAX_SEED_GROUPS), ('grp_ts', c_void_p * MAX_SEED_GROUPS), ('grp_n', c_int64 * MAX_SEED_GROUPS),
@@ -131,7 +132,7 @@ class RingStep(ctypes.Structure):
 
 SIGNATURES['tgmx_csr_build_workspace_bytes'] = (c_size_t, [c_int64, c_int32, c_int32])
 SIGNATURES['tgmx_csr_build'] = (c_int32, [_P, _P, _P, c_int64, c_int32, _P, c_int64, c_int32, _P, _P, _P, c_size_t, _P, _P])
-SIGNATURES['tgmx_ring_step'] = (c_int32, [ctypes.POINTER(RingStep), _P])
+SIGNATURES['tgmx_recency_step'] = (c_int32, [ctypes.POINTER(RecencyStep), _P])
 SIGNATURES['tgmx_tgat_layout'] = (c_int32, [ctypes.POINTER(TgatModel), c_int64, ctypes.POINTER(TgatHop), c_int32, ctypes.POINTER(TgatLayout)])
 SIGNATURES['tgmx_tgat_workspace_bytes'] = (c_size_t, [ctypes.POINTER(TgatModel), c_int64, ctypes.POINTER(TgatHop)])
 SIGNATURES['tgmx_tgat_forward'] = (

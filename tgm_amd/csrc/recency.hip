@@ -980,15 +980,17 @@ extern "C" int tgmx_ring_update(tgmx_adj_t* ring, int32_t* write_pos, float* rin
   return TGMX_OK;
 }
 
-extern "C" int tgmx_ring_step(const tgmx_ring_step_t* s, tgmx_stream_t stream) {
-  TGMX_REQUIRE(s, "ring_step: null argument block");
+extern "C" int tgmx_recency_step(const tgmx_recency_step_t* s, tgmx_stream_t stream) {
+  TGMX_REQUIRE(s, "recency_step: null argument block");
   TGMX_REQUIRE(s->n_groups >= 0 && s->n_groups <= TGMX_MAX_SEED_GROUPS && s->n_hops >= 0 && s->n_hops <= TGMX_MAX_HOPS,
-               "ring_step: n_groups=%d n_hops=%d out of range", s->n_groups, s->n_hops);
-  TGMX_REQUIRE(s->B > 0 && s->num_nodes > 0 && s->D >= 0 && s->n >= 0, "ring_step: bad sizes B=%d N=%d D=%d n=%lld", s->B,
+               "recency_step: n_groups=%d n_hops=%d out of range", s->n_groups, s->n_hops);
+  TGMX_REQUIRE(s->B > 0 && s->num_nodes > 0 && s->D >= 0 && s->n >= 0, "recency_step: bad sizes B=%d N=%d D=%d n=%lld", s->B,
                s->num_nodes, s->D, (long long)s->n);
-  TGMX_REQUIRE(s->ring && s->write_pos && s->status, "ring_step: null state pointer");
-  TGMX_REQUIRE(((uintptr_t)s->ring & 15) == 0, "ring_step: ring must be 16-byte aligned");
-  TGMX_REQUIRE((long long)s->B * s->num_nodes < 2147483647LL, "ring_step: num_nodes*B overflows int32");
+  const bool csr = s->indptr != nullptr;
+  TGMX_REQUIRE(s->ring && (csr || s->write_pos) && s->status, "recency_step: null state pointer");
+  TGMX_REQUIRE(!csr || s->n == 0, "recency_step: the static index takes no update (n must be 0)");
+  TGMX_REQUIRE(((uintptr_t)s->ring & 15) == 0, "recency_step: ring must be 16-byte aligned");
+  TGMX_REQUIRE(csr || (long long)s->B * s->num_nodes < 2147483647LL, "recency_step: num_nodes*B overflows int32");
   hipStream_t st = (hipStream_t)stream;
 
   // ---- hop-0 seeds: groups are concatenated by the hop-0 lookup itself (or by nothing when there is no hop)
@@ -997,12 +999,12 @@ extern "C" int tgmx_ring_step(const tgmx_ring_step_t* s, tgmx_stream_t stream) {
   if (s->n_groups > 0) {
     S = 0;
     for (int g = 0; g < s->n_groups; ++g) {
-      TGMX_REQUIRE(s->grp_n[g] >= 0 && (s->grp_n[g] == 0 || (s->grp_nid[g] && s->grp_ts[g])), "ring_step: seed group %d", g);
+      TGMX_REQUIRE(s->grp_n[g] >= 0 && (s->grp_n[g] == 0 || (s->grp_nid[g] && s->grp_ts[g])), "recency_step: seed group %d", g);
       S += s->grp_n[g];
       grp.nid[g] = s->grp_nid[g]; grp.ts[g] = s->grp_ts[g]; grp.end[g] = S;
     }
-    TGMX_REQUIRE(S == 0 || (s->seed_nid0 && s->seed_ts0), "ring_step: null hop-0 seed output");
-    TGMX_REQUIRE(S == 0 || s->n_hops > 0, "ring_step: seed groups need at least one hop");
+    TGMX_REQUIRE(S == 0 || (s->seed_nid0 && s->seed_ts0), "recency_step: null hop-0 seed output");
+    TGMX_REQUIRE(S == 0 || s->n_hops > 0, "recency_step: seed groups need at least one hop");
     grp.out_nid = s->seed_nid0; grp.out_ts = s->seed_ts0; grp.groups = s->n_groups;
   }
 
@@ -1011,16 +1013,18 @@ extern "C" int tgmx_ring_step(const tgmx_ring_step_t* s, tgmx_stream_t stream) {
   const int64_t* cur_t = s->seed_ts0;
   for (int h = 0; h < s->n_hops && S > 0; ++h) {
     const int k = s->k[h];
-    TGMX_REQUIRE(k > 0 && s->B >= k, "ring_step: hop %d has k=%d, B=%d", h, k, s->B);
+    TGMX_REQUIRE(k > 0 && s->B >= k, "recency_step: hop %d has k=%d, B=%d", h, k, s->B);
     TGMX_REQUIRE(cur_n && cur_t && s->out_nid[h] && s->out_ts[h] && (s->D == 0 || (s->ring_x && s->out_x[h])),
-                 "ring_step: null pointer at hop %d", h);
+                 "recency_step: null pointer at hop %d", h);
     LookupArgs a{};
     if (h == 0) a.grp = grp;
-    a.indptr = nullptr; a.recs = reinterpret_cast<const Rec*>(s->ring); a.write_pos = s->write_pos; a.edge_x = s->ring_x;
+    a.indptr = s->indptr; a.recs = reinterpret_cast<const Rec*>(s->ring); a.write_pos = s->write_pos; a.edge_x = s->ring_x;
     a.seeds = cur_n; a.qtimes = cur_t; a.out_nid = s->out_nid[h]; a.out_ts = s->out_ts[h]; a.out_x = s->out_x[h];
     a.status = s->status; a.S = S; a.D = s->D; a.k = k; a.B = s->B; a.N = s->num_nodes; a.allow_pad = h > 0;
+    a.ev_lo = s->ev_lo; a.ev_hi = s->ev_hi;
     const bool timed = h == s->timed_hop;
-    const int rc = launch_lookup<true>(a, st, timed ? (hipEvent_t)s->ev_start : nullptr, timed ? (hipEvent_t)s->ev_stop : nullptr);
+    hipEvent_t e0 = timed ? (hipEvent_t)s->ev_start : nullptr, e1 = timed ? (hipEvent_t)s->ev_stop : nullptr;
+    const int rc = csr ? launch_lookup<false>(a, st, e0, e1) : launch_lookup<true>(a, st, e0, e1);
     if (rc) return rc;
     cur_n = s->out_nid[h];
     cur_t = s->out_ts[h];
@@ -1036,7 +1040,7 @@ extern "C" int tgmx_ring_step(const tgmx_ring_step_t* s, tgmx_stream_t stream) {
     if (u.m <= kBlockMaxM) launch_update_block(u, s->scratch, st);
     else launch_update_large(u, s->scratch, st);
   }
-  TGMX_CHECK_LAUNCH("ring_step");
+  TGMX_CHECK_LAUNCH("recency_step");
   return TGMX_OK;
 }
 

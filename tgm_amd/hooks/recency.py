@@ -144,7 +144,7 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
         # optional kernel timing (bench.py): every `profile_every`-th call brackets the
         # lookup launch of hop `profile_hop` with HIP events on the launch stream
         self._mask_cache: Dict[tuple, Dict[str, Tensor]] = {}
-        self._step: Optional[_native.RingStep] = None  # argument block of tgmx_ring_step (static fields pre-filled)
+        self._step: Optional[_native.RecencyStep] = None  # argument block of tgmx_recency_step (static fields pre-filled)
         self.profile_hop: Optional[int] = None
         self.profile_every: int = 1
         self.profile_log: List[tuple] = []
@@ -225,15 +225,18 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
                 self._ring_x = None if self._ring_x is None else self._ring_x.to(device)
                 self._write_pos = self._write_pos.to(device)
                 self._scratch = None
-            st = _native.RingStep()
+        st = _native.RecencyStep()
+        if self._mode == 'ring':
             st.ring, st.write_pos, st.ring_x = self._ring.data_ptr(), self._write_pos.data_ptr(), _native.ptr(self._ring_x)
-            st.D, st.B, st.num_nodes = D, B, N
-            for hop, k in enumerate(self._num_nbrs[: _native.MAX_HOPS]):
-                st.k[hop] = k
-            st.directed, st.key_wrap32 = (1 if self._directed else 0), self._key_wrap32
-            st.status = self._status.data_ptr()
-            st.timed_hop = -1
-            self._step = st
+        else:
+            self._csr = None  # rebuilt (and its pointers re-bound) on the new device
+        st.D, st.B, st.num_nodes = D, B, N
+        for hop, k in enumerate(self._num_nbrs[: _native.MAX_HOPS]):
+            st.k[hop] = k
+        st.directed, st.key_wrap32 = (1 if self._directed else 0), self._key_wrap32
+        st.status = self._status.data_ptr()
+        st.timed_hop = -1
+        self._step = st
 
     def _ensure_csr(self, dg: DGraph, batch: DGBatch) -> TemporalCSR:
         store = dg._storage
@@ -251,79 +254,13 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
                 directed=self._directed,
             )
             self._csr_store = store
+            st = self._step
+            st.indptr, st.ring, st.ring_x = self._csr.indptr.data_ptr(), self._csr.adj.data_ptr(), _native.ptr(arr.edge_x)
         return self._csr
 
     # ------------------------------------------------------------------
     def __call__(self, dg: DGraph, batch: DGBatch) -> DGBatch:
-        device = batch.edge_src.device
-        if self._mode == 'ring':
-            return self._call_ring(dg, batch, device)
-        seeds, seed_times, seed_mask = self._get_seed_tensors(batch, device)
-        D = self._edge_x_dim if self._edge_x_dim is not None else (dg.edge_x_dim or 0)
-
-        out_seed_n: List[Tensor] = []
-        out_seed_t: List[Tensor] = []
-        out_n: List[Tensor] = []
-        out_t: List[Tensor] = []
-        out_x: List[Tensor] = []
-
-        if not seeds.numel():
-            # reference: CPU empties, and the update is skipped (recency.py:127-139)
-            for _ in self._num_nbrs:
-                out_seed_n.append(torch.empty(0, dtype=torch.int32))
-                out_seed_t.append(torch.empty(0, dtype=torch.int64))
-                out_n.append(torch.empty(0, dtype=torch.int32))
-                out_t.append(torch.empty(0, dtype=torch.int64))
-                out_x.append(torch.empty(0, dg.edge_x_dim or 0, dtype=torch.float32))
-        else:
-            self._ensure_state(dg, device)
-            D = self._edge_x_dim
-            lib = _native.load()
-            B, N = self._max_nbrs, self._num_nodes
-            status_p = self._status.data_ptr()
-            with _on_device(device):
-                stream = _native.stream_ptr(device.index)
-                if batch._edge_lo is None:
-                    raise ValueError("mode='csr' needs batches materialized by tgm_amd.DGraph (batch._edge_lo is unset)")
-                csr = self._ensure_csr(dg, batch)
-                ev_hi = int(batch._edge_lo)
-                if self._epoch_lo is None:
-                    self._epoch_lo = ev_hi
-                ev_lo = self._epoch_lo
-                edge_x = dg._storage.on(device).edge_x
-                table_p, indptr_p, adj_p = _native.ptr(edge_x), csr.indptr.data_ptr(), csr.adj.data_ptr()
-
-                cur_n, cur_t = seeds, seed_times
-                self._calls += 1
-                timed_hop = self.profile_hop if (self.profile_hop is not None and self._calls % self.profile_every == 0) else -1
-                for hop, k in enumerate(self._num_nbrs):
-                    S = cur_n.numel()
-                    nid = torch.empty((S, k), dtype=torch.int32, device=device)
-                    nts = torch.empty((S, k), dtype=torch.int64, device=device)
-                    nx = torch.empty((S, k, D), dtype=torch.float32, device=device)
-                    timer = None
-                    if hop == timed_hop and self.profile_pool:
-                        timer = self.profile_pool.pop()
-                    ev0, ev1 = (timer.start, timer.stop) if timer else (None, None)
-                    rc = lib.tgmx_recency_lookup_csr(
-                        indptr_p, adj_p, table_p, D, cur_n.data_ptr(), cur_t.data_ptr(), S, k, B, ev_lo, ev_hi, N,
-                        1 if hop else 0, nid.data_ptr(), nts.data_ptr(), nx.data_ptr(), status_p, stream, ev0, ev1,
-                    )  # fmt: skip
-                    if rc:
-                        _native.check(rc, 'recency lookup')
-                    if timer is not None:
-                        self.profile_log.append((timer, S, k, nid))  # nid kept alive: valid slots are counted later
-                    out_seed_n.append(cur_n)
-                    out_seed_t.append(cur_t)
-                    out_n.append(nid)
-                    out_t.append(nts)
-                    out_x.append(nx)
-                    cur_n, cur_t = nid.view(-1), nts.view(-1)
-
-                if self._validate == 'sync':
-                    self.check()
-
-        return self._publish(batch, out_seed_n, out_seed_t, out_n, out_t, out_x, seed_mask)
+        return self._call_step(dg, batch, batch.edge_src.device)
 
     # ------------------------------------------------------------------
     def _publish(self, batch: DGBatch, seed_n, seed_t, out_n, out_t, out_x, seed_mask) -> DGBatch:
@@ -335,8 +272,8 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
         self.add_batch_attribute(batch, 'seed_node_nbr_mask', seed_mask)
         return batch
 
-    def _call_ring(self, dg: DGraph, batch: DGBatch, device: torch.device) -> DGBatch:
-        """Streaming mode: the whole call (seed concat, every hop, ring update) is ONE tgmx_ring_step."""
+    def _call_step(self, dg: DGraph, batch: DGBatch, device: torch.device) -> DGBatch:
+        """The whole call (seed concat, every hop, ring update in streaming mode) is ONE tgmx_recency_step."""
         groups, group_times, seed_mask = self._get_seed_tensors(batch, device, concat=False)
         S0 = 0
         for g in groups:
@@ -361,8 +298,17 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
         st = self._step
         lib = _native.load()
         empty = torch.empty
+        ring_mode = self._mode == 'ring'
         with _on_device(device):
             stream = _native.stream_ptr(device.index)
+            if not ring_mode:
+                if batch._edge_lo is None:
+                    raise ValueError("mode='csr' needs batches materialized by tgm_amd.DGraph (batch._edge_lo is unset)")
+                self._ensure_csr(dg, batch)
+                ev_hi = int(batch._edge_lo)
+                if self._epoch_lo is None:
+                    self._epoch_lo = ev_hi
+                st.ev_lo, st.ev_hi = self._epoch_lo, ev_hi
             # hop-0 seeds (fresh tensors owned by the batch, like the reference's torch.cat)
             seeds = empty(S0, dtype=torch.int32, device=device)
             seed_times = empty(S0, dtype=torch.int64, device=device)
@@ -399,7 +345,7 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
                 timer = self.profile_pool.pop()
                 st.timed_hop, st.ev_start, st.ev_stop = self.profile_hop, timer.start, timer.stop
 
-            n_edges = batch.edge_src.shape[0]
+            n_edges = batch.edge_src.shape[0] if ring_mode else 0
             keep = None
             if n_edges:
                 m = n_edges if self._directed else 2 * n_edges
@@ -422,21 +368,21 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
             if self._validate == 'sync':
                 # bad seeds must leave the state untouched: lookups, host check, then the update
                 st.n, st.n_hops = 0, L
-                rc = lib.tgmx_ring_step(st, stream)
+                rc = lib.tgmx_recency_step(st, stream)
                 if rc:
-                    _native.check(rc, 'tgmx_ring_step')
+                    _native.check(rc, 'tgmx_recency_step')
                 self.check()
                 if n_edges:
                     st.n, st.n_hops, st.n_groups, st.timed_hop = n_edges, 0, 0, -1
-                    rc = lib.tgmx_ring_step(st, stream)
+                    rc = lib.tgmx_recency_step(st, stream)
                     if rc:
-                        _native.check(rc, 'tgmx_ring_step')
+                        _native.check(rc, 'tgmx_recency_step')
                     self.check()
             else:
                 st.n, st.n_hops = n_edges, L
-                rc = lib.tgmx_ring_step(st, stream)
+                rc = lib.tgmx_recency_step(st, stream)
                 if rc:
-                    _native.check(rc, 'tgmx_ring_step')
+                    _native.check(rc, 'tgmx_recency_step')
             del keep
             if timer is not None:
                 self.profile_log.append((timer, out_seed_n[self.profile_hop].shape[0], self._num_nbrs[self.profile_hop], out_n[self.profile_hop]))

@@ -59,8 +59,8 @@ sp = _native.stream_ptr(0)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(300):
-    lib.tgmx_ring_step(st, sp)
+    lib.tgmx_recency_step(st, sp)
 t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
-print(f'{"tgmx_ring_step alone":50s} host {1e6 * (t1 - t0) / 300:7.1f} us/call   total {1e6 * (t2 - t0) / 300:7.1f} us/call', flush=True)
+print(f'{"tgmx_recency_step alone":50s} host {1e6 * (t1 - t0) / 300:7.1f} us/call   total {1e6 * (t2 - t0) / 300:7.1f} us/call', flush=True)
