@@ -239,18 +239,24 @@ class DGraph:
         event ``(node_x_time[i], node_x_nids[i])``), which is what the reference
         extracts from its sparse tensor via ``_indices()/_values()``.
         """
-        lo, hi = self._edge_range
-        batch = DGBatch(self.edge_src, self.edge_dst, self.edge_time)
+        arr = self._storage.on(self._device)
+        lb, ub = self._storage.event_range(self._slice)
+        if self._storage.num_edges == self._storage.num_events:
+            lo, hi = lb, max(lb, ub)
+        else:
+            lo, hi = self._edge_range
+        n = hi - lo
+        batch = DGBatch(arr.src.narrow(0, lo, n), arr.dst.narrow(0, lo, n), arr.ts.narrow(0, lo, n))
         batch._edge_lo = lo
-        batch._event_lo = self._event_range[0]
-        if materialize_features and self.node_x is not None:
+        batch._event_lo = lb
+        if materialize_features and arr.node_x is not None and self.node_x is not None:
             batch.node_x_time, batch.node_x_nids, batch.node_x = self.node_x_time, self.node_x_nids, self.node_x
-        if materialize_features and self.edge_x is not None:
-            batch.edge_x = self.edge_x
-        if materialize_features and self.node_y is not None:
+        if materialize_features and n > 0 and arr.edge_x is not None:
+            batch.edge_x = arr.edge_x.narrow(0, lo, n)
+        if materialize_features and arr.node_y is not None and self.node_y is not None:
             batch.node_y_time, batch.node_y_nids, batch.node_y = self.node_y_time, self.node_y_nids, self.node_y
-        if self.edge_type is not None:
-            batch.edge_type = self.edge_type
+        if n > 0 and arr.edge_type is not None:
+            batch.edge_type = arr.edge_type.narrow(0, lo, n)
         return batch
 
     def __str__(self) -> str:

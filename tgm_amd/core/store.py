@@ -64,6 +64,7 @@ class EdgeStore:
         self._nx_pos_np = None if data.node_x_mask is None else data.node_x_mask.cpu().numpy()
         self._ny_pos_np = None if data.node_y_mask is None else data.node_y_mask.cpu().numpy()
         self._resident: Dict[torch.device, DeviceArrays] = {}
+        self._last_on = None
         self.num_events = int(self._time_np.shape[0])
         self.num_edges = int(self._edge_pos_np.shape[0])
         self.edge_x_dim: Optional[int] = None if data.edge_x is None else int(data.edge_x.shape[1])
@@ -74,6 +75,14 @@ class EdgeStore:
 
     # -- residency -------------------------------------------------------
     def on(self, device: torch.device) -> DeviceArrays:
+        last = self._last_on
+        if last is not None and last[0] is device:  # per-batch fast path: same device object as last time
+            return last[1]
+        arr = self._on(device)
+        self._last_on = (device, arr)
+        return arr
+
+    def _on(self, device: torch.device) -> DeviceArrays:
         device = torch.device(device)
         if device.type == 'cuda' and device.index is None:
             device = torch.device('cuda', torch.cuda.current_device())
