@@ -317,6 +317,7 @@ struct UpdateArgs {
   int32_t* sorted_node;  // scratch [m]: its node (-1 = invalid entry)
   int32_t* target;       // scratch [m]: ring row it is placed at (-1 = dropped)
   int32_t* winner;       // scratch [m]: ring row it finally owns (-1 = none)
+  Rec* sorted_rec;       // scratch [m] (chunked path): the record of the entry at sorted position p
   // large-batch path only:
   long long* span;       // scratch: max(ts) + 1
   long long* key;        // scratch [m]: sort key of entry j
@@ -554,6 +555,22 @@ __global__ __launch_bounds__(256) void ring_update_feat_kernel(const UpdateArgs 
 constexpr int kBlockMaxM = 4096;
 constexpr int kBlockThreads = 1024;
 
+// max over ts[0, n) of this thread's strided share, 8 independent loads in flight per round
+__device__ __forceinline__ long long strided_max_ts(const int64_t* __restrict__ ts, long long n, int tid, int nthr) {
+  long long mx = -0x7fffffffffffffffLL;
+  for (long long base = tid; base < n; base += 8ll * nthr) {
+    long long v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const long long x = base + (long long)u * nthr;
+      v[u] = x < n ? ts[x] : mx;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) mx = v[u] > mx ? v[u] : mx;
+  }
+  return mx;
+}
+
 __device__ __forceinline__ bool pair_after(long long ka, int pa, long long kb, int pb) {
   return ka > kb || (ka == kb && pa > pb);
 }
@@ -573,38 +590,39 @@ __global__ __launch_bounds__(kBlockThreads) void ring_update_block_kernel(const 
   constexpr int H = 2 * MAXM;  // hash load factor <= 0.5
   constexpr int HBITS = MAXM == 1024 ? 11 : (MAXM == 2048 ? 12 : 13);
   static_assert((1 << HBITS) == H, "hash size");
-  __shared__ long long s_key[MAXM];  // LDS leg of the sort; afterwards two int[MAXM] scan buffers
-  __shared__ int s_pay[MAXM];        // entry index at sorted position p
+  __shared__ long long s_key[MAXM];  // LDS leg of the sort
+  __shared__ int s_pay[MAXM];        // LDS leg of the sort
   __shared__ int s_sn[MAXM];         // node at sorted position p (-1 invalid)
-  __shared__ int s_tgt[MAXM];        // ring row placed at (-1 dropped)
+  __shared__ int s_len[MAXM];        // run length, stored at the run's first position
   __shared__ int h_key[H], h_maxp[H];
   __shared__ long long red[kBlockThreads / kWave];
+  __shared__ int wave_tot[kBlockThreads / kWave];
   const int m = (int)a.m;
-  const int tid = threadIdx.x;
-  const int nthr = blockDim.x;
-  const int P = nthr * E;  // power of two >= m
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nthr = blockDim.x, nwaves = nthr >> 6;
+  const int P = nthr * E;  // power of two >= m; thread t owns sorted positions t*E .. t*E + E-1
 
   for (int x = tid; x < H; x += nthr) {
     h_key[x] = -1;
     h_maxp[x] = -1;
   }
-  long long key[E];
-  int pay[E];
+  int pay[E], node[E], w[E];
   if constexpr (PRESORTED) {
-    // the sorted order was produced by the chunk-sort + merge kernels
+    // sorted order, nodes and write_pos % B were produced by the chunk-sort + merge kernels
 #pragma unroll
     for (int r = 0; r < E; ++r) {
       const int p = tid * E + r;
-      key[r] = 0;
-      pay[r] = p < m ? a.sorted_j[p] : p;
+      pay[r] = p;
+      node[r] = -1;
+      w[r] = 0;
+      if (p < m) {
+        pay[r] = a.sorted_j[p];
+        node[r] = a.sorted_node[p];
+        w[r] = a.target[p];
+      }
     }
   } else {
-    const int lane = tid & 63, wave = tid >> 6, nwaves = nthr >> 6;
-    long long mx = -0x7fffffffffffffffLL;
-    for (int x = tid; x < a.n; x += nthr) {
-      const long long v = a.ts[x];
-      mx = v > mx ? v : mx;
-    }
+    long long mx = strided_max_ts(a.ts, a.n, tid, nthr);
     for (int off = 32; off > 0; off >>= 1) {
       const long long o = __shfl_xor(mx, off);
       mx = o > mx ? o : mx;
@@ -612,19 +630,20 @@ __global__ __launch_bounds__(kBlockThreads) void ring_update_block_kernel(const 
     if (lane == 0) red[wave] = mx;
     __syncthreads();
     mx = red[0];
-    for (int w = 1; w < nwaves; ++w) mx = red[w] > mx ? red[w] : mx;
+    for (int wv = 1; wv < nwaves; ++wv) mx = red[wv] > mx ? red[wv] : mx;
     const long long span = mx + 1;
 
+    long long key[E];
 #pragma unroll
     for (int r = 0; r < E; ++r) {
       const int j = tid * E + r;
       key[r] = 0x7fffffffffffffffLL;  // padding sorts to the end
       pay[r] = j;
       if (j < m) {
-        int node, nbr;
+        int nd, nbr;
         long long t, i;
-        update_entry(a, j, node, nbr, t, i);
-        key[r] = update_key(node, t, span, a.key_wrap32);
+        update_entry(a, j, nd, nbr, t, i);
+        key[r] = update_key(nd, t, span, a.key_wrap32);
       }
     }
 
@@ -676,92 +695,118 @@ __global__ __launch_bounds__(kBlockThreads) void ring_update_block_kernel(const 
         }
       }
     }
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+      const int p = tid * E + r;
+      node[r] = -1;
+      w[r] = 0;
+      if (p < m) {
+        int nd, nbr;
+        long long t, i;
+        update_entry(a, pay[r], nd, nbr, t, i);
+        const bool valid = nd >= 0 && nd < a.N && nbr >= 0 && nbr < a.N;
+        if (!valid) atomicOr(a.status, TGMX_ST_EDGE_RANGE);
+        if (valid) {
+          node[r] = nd;
+          w[r] = a.write_pos[nd] % a.B;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < E; ++r) s_sn[tid * E + r] = node[r];
+  __syncthreads();
+
+  // run start of every sorted position = last position <= p that opens a run: max-scan, thread -> wave -> block
+  int st[E];
+  {
+    int run = 0;
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+      const int p = tid * E + r;
+      if (p == 0 || s_sn[p - 1] != node[r]) run = p;
+      st[r] = run;
+    }
+    int incl = run;  // positions only grow, so the thread's last value is its maximum
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+      const int o = __shfl_up(incl, off);
+      if (lane >= off) incl = o > incl ? o : incl;
+    }
+    if (lane == kWave - 1) wave_tot[wave] = incl;
+    int before = __shfl_up(incl, 1);
+    if (lane == 0) before = 0;
+    __syncthreads();
+    for (int wv = 0; wv < wave; ++wv) before = wave_tot[wv] > before ? wave_tot[wv] : before;
+#pragma unroll
+    for (int r = 0; r < E; ++r) st[r] = st[r] > before ? st[r] : before;
   }
 #pragma unroll
   for (int r = 0; r < E; ++r) {
     const int p = tid * E + r;
-    s_pay[p] = pay[r];
-    if (p < m) {
-      int node, nbr;
-      long long t, i;
-      update_entry(a, pay[r], node, nbr, t, i);
-      const bool valid = node >= 0 && node < a.N && nbr >= 0 && nbr < a.N;
-      if (!valid) atomicOr(a.status, TGMX_ST_EDGE_RANGE);
-      s_sn[p] = valid ? node : -1;
-    }
+    if (p < m && (p == m - 1 || s_sn[p + 1] != node[r])) s_len[st[r]] = p - st[r] + 1;
   }
   __syncthreads();
 
-  // run start of every sorted position: inclusive max-scan of (p if p opens a run else 0), ping-pong buffers
-  int* cur = reinterpret_cast<int*>(s_key);
-  int* nxt = cur + MAXM;
-  for (int p = tid; p < m; p += nthr) cur[p] = (p > 0 && s_sn[p - 1] == s_sn[p]) ? 0 : p;
-  __syncthreads();
-  for (int off = 1; off < m; off <<= 1) {
-    for (int p = tid; p < m; p += nthr) {
-      const int v = cur[p];
-      const int u = p >= off ? cur[p - off] : 0;
-      nxt[p] = u > v ? u : v;
-    }
-    __syncthreads();
-    int* sw = cur; cur = nxt; nxt = sw;
-  }
-  int* s_start = cur;
-  int* s_len = nxt;  // run length, stored at the run's start
-  for (int p = tid; p < m; p += nthr)
-    if (p == m - 1 || s_sn[p + 1] != s_sn[p]) s_len[s_start[p]] = p - s_start[p] + 1;
-  __syncthreads();
-
-  auto hash_slot = [&](int tgt) -> int {
-    unsigned h = ((unsigned)tgt * 2654435761u) >> (32 - HBITS);
-    for (;;) {
-      const int old = atomicCAS(&h_key[h], -1, tgt);
-      if (old == -1 || old == tgt) return (int)h;
-      h = (h + 1) & (H - 1);
-    }
-  };
-  for (int p = tid; p < m; p += nthr) {
-    const int node = s_sn[p];
-    int tgt = -1;
-    if (node >= 0) {
-      const int lo = s_start[p], cnt = s_len[lo], pos = p - lo;
-      const int drop = cnt > a.B ? cnt - a.B : 0;
+  // placement; collisions between runs of one node resolved by atomicMax of the sorted position
+  int tgt[E], hs[E], cnt[E];
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    const int p = tid * E + r;
+    tgt[r] = -1;
+    hs[r] = 0;
+    cnt[r] = 0;
+    if (p < m && node[r] >= 0) {
+      cnt[r] = s_len[st[r]];
+      const int pos = p - st[r];
+      const int drop = cnt[r] > a.B ? cnt[r] - a.B : 0;
       if (pos >= drop) {
-        tgt = node * a.B + (a.write_pos[node] % a.B + pos - drop) % a.B;
-        atomicMax(&h_maxp[hash_slot(tgt)], p);
+        const int t = node[r] * a.B + (w[r] + pos - drop) % a.B;
+        unsigned h = ((unsigned)t * 2654435761u) >> (32 - HBITS);
+        for (;;) {
+          const int old = atomicCAS(&h_key[h], -1, t);
+          if (old == -1 || old == t) break;
+          h = (h + 1) & (H - 1);
+        }
+        atomicMax(&h_maxp[h], p);
+        tgt[r] = t;
+        hs[r] = (int)h;
       }
     }
-    s_tgt[p] = tgt;
   }
   __syncthreads();
 
-  for (int p = tid; p < m; p += nthr) {
-    const int tgt = s_tgt[p];
-    const int j = s_pay[p];
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    const int p = tid * E + r;
+    if (p >= m) continue;
     int win = -1;
-    if (tgt >= 0) {
-      if (h_maxp[hash_slot(tgt)] == p) {
-        int node, nbr;
-        long long t, i;
-        update_entry(a, j, node, nbr, t, i);
-        Rec r;
-        r.nbr = nbr;
-        r.eid = a.eid0 >= 0 ? (int)(a.eid0 + i) : -1;
-        r.ts = t;
-        a.ring[tgt] = r;
-        win = tgt;
+    if (tgt[r] >= 0) {
+      if (h_maxp[hs[r]] == p) {
+        Rec rec;
+        if constexpr (PRESORTED) {
+          rec = a.sorted_rec[p];
+        } else {
+          int nd, nbr;
+          long long t, i;
+          update_entry(a, pay[r], nd, nbr, t, i);
+          rec.nbr = nbr;
+          rec.eid = a.eid0 >= 0 ? (int)(a.eid0 + i) : -1;
+          rec.ts = t;
+        }
+        a.ring[tgt[r]] = rec;
+        win = tgt[r];
       }
-      const int lo = s_start[p], cnt = s_len[lo];
-      if (p == lo + cnt - 1) {  // the run's last entry commits the run (every write_pos read is behind the barrier)
-        const int kept = cnt > a.B ? a.B : cnt;
-        int32_t* wp = &a.write_pos[s_sn[p]];
+      if (p == st[r] + cnt[r] - 1) {  // the run's last entry commits the run (every write_pos read is behind a barrier)
+        const int kept = cnt[r] > a.B ? a.B : cnt[r];
+        int32_t* wp = &a.write_pos[node[r]];
         const int old = atomicAdd(wp, kept);
         constexpr int kFold = 1 << 30;
         if (old < kFold && old + kept >= kFold) atomicSub(wp, kFold / a.B * a.B);  // stay far from int32 overflow
       }
     }
     a.winner[p] = win;
-    a.sorted_j[p] = j;
+    if constexpr (!PRESORTED) a.sorted_j[p] = pay[r];
   }
 }
 
@@ -778,11 +823,7 @@ __global__ __launch_bounds__(kChunk) void ring_update_chunk_sort_kernel(const Up
   __shared__ int s_pay[kChunk];
   __shared__ long long red[kChunk / kWave];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  long long mx = -0x7fffffffffffffffLL;
-  for (int x = tid; x < a.n; x += kChunk) {
-    const long long v = a.ts[x];
-    mx = v > mx ? v : mx;
-  }
+  long long mx = strided_max_ts(a.ts, a.n, tid, kChunk);
   for (int off = 32; off > 0; off >>= 1) {
     const long long o = __shfl_xor(mx, off);
     mx = o > mx ? o : mx;
@@ -829,10 +870,24 @@ __global__ __launch_bounds__(kChunk) void ring_update_merge_kernel(const UpdateA
   __shared__ int p_all[kBlockMaxM];
   const int m = (int)a.m;
   const int tid = threadIdx.x;
-  for (int x = tid; x < m; x += kChunk) {
-    // chunk c keeps its len_c real entries first (padding sorted last), so [c*256, c*256 + len_c) is dense
-    k_all[x] = a.key[x];
-    p_all[x] = a.node[x];
+  // chunk c keeps its len_c real entries first (padding sorted last), so [c*256, c*256 + len_c) is dense
+  for (int base = tid; base < m; base += 8 * kChunk) {  // 16 independent loads in flight per round
+    long long kv[8];
+    int pv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int x = base + u * kChunk;
+      kv[u] = x < m ? a.key[x] : 0;
+      pv[u] = x < m ? a.node[x] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int x = base + u * kChunk;
+      if (x < m) {
+        k_all[x] = kv[u];
+        p_all[x] = pv[u];
+      }
+    }
   }
   __syncthreads();
   const int c = blockIdx.x;
@@ -842,18 +897,43 @@ __global__ __launch_bounds__(kChunk) void ring_update_merge_kernel(const UpdateA
   const int pay = p_all[e];
   int rank = tid;
   const int chunks = (m + kChunk - 1) / kChunk;
-  for (int o = 0; o < chunks; ++o) {
-    if (o == c) continue;
-    const int base = o * kChunk;
-    int lo = 0, hi = (m - base) < kChunk ? (m - base) : kChunk;  // count of entries of chunk o that sort before mine
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if (pair_after(key, pay, k_all[base + mid], p_all[base + mid])) lo = mid + 1;
-      else hi = mid;
-    }
-    rank += lo;
+  // count of entries of every other chunk that sort before mine: all binary searches advance together, so the
+  // dependent LDS reads of one search hide behind the other chunks' (<= 16 chunks, 9 steps each)
+  constexpr int kMaxChunks = kBlockMaxM / kChunk;
+  int lo[kMaxChunks], hi[kMaxChunks];
+#pragma unroll
+  for (int o = 0; o < kMaxChunks; ++o) {
+    lo[o] = 0;
+    const int len = (m - o * kChunk) < kChunk ? (m - o * kChunk) : kChunk;
+    hi[o] = (o < chunks && o != c) ? len : 0;
   }
+#pragma unroll 1
+  for (int step = 0; step < 9; ++step) {  // 2^9 > kChunk
+#pragma unroll
+    for (int o = 0; o < kMaxChunks; ++o) {
+      if (lo[o] < hi[o]) {
+        const int mid = (lo[o] + hi[o]) >> 1;
+        if (pair_after(key, pay, k_all[o * kChunk + mid], p_all[o * kChunk + mid])) lo[o] = mid + 1;
+        else hi[o] = mid;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < kMaxChunks; ++o) rank += lo[o];
+  // everything the single-workgroup kernel would otherwise gather with dependent loads
+  int node, nbr;
+  long long t, i;
+  update_entry(a, pay, node, nbr, t, i);
+  const bool valid = node >= 0 && node < a.N && nbr >= 0 && nbr < a.N;
+  if (!valid) atomicOr(a.status, TGMX_ST_EDGE_RANGE);
+  Rec rec;
+  rec.nbr = nbr;
+  rec.eid = a.eid0 >= 0 ? (int)(a.eid0 + i) : -1;
+  rec.ts = t;
   a.sorted_j[rank] = pay;
+  a.sorted_node[rank] = valid ? node : -1;
+  a.target[rank] = valid ? a.write_pos[node] % a.B : 0;  // write_pos only moves in the kernel that follows
+  a.sorted_rec[rank] = rec;
 }
 
 static void launch_update_block(UpdateArgs& a, int32_t* scratch, hipStream_t st) {
@@ -862,11 +942,12 @@ static void launch_update_block(UpdateArgs& a, int32_t* scratch, hipStream_t st)
   if (P <= 1024) {
     hipLaunchKernelGGL((ring_update_block_kernel<1, 1024, false>), dim3(1), dim3(P), 0, st, a);
   } else {
-    // chunk-sorted keys (16-byte aligned int64) and entry indices live behind the four int32[m] arrays
+    // chunk-sorted keys (16-byte aligned int64), sorted records and chunk-sorted entry indices live behind the four int32[m] arrays
     const unsigned chunks = (unsigned)((a.m + kChunk - 1) / kChunk);
     long long* s64 = reinterpret_cast<long long*>(((uintptr_t)(scratch + 4 * a.m) + 15) & ~(uintptr_t)15);
     a.key = s64;
-    a.node = reinterpret_cast<int32_t*>(s64 + (long long)chunks * kChunk);
+    a.sorted_rec = reinterpret_cast<Rec*>(s64 + (long long)chunks * kChunk);
+    a.node = reinterpret_cast<int32_t*>(a.sorted_rec + a.m);
     hipLaunchKernelGGL(ring_update_chunk_sort_kernel, dim3(chunks), dim3(kChunk), 0, st, a);
     hipLaunchKernelGGL(ring_update_merge_kernel, dim3(chunks), dim3(kChunk), 0, st, a);
     if (P == 2048) hipLaunchKernelGGL((ring_update_block_kernel<2, 2048, true>), dim3(1), dim3(1024), 0, st, a);
