@@ -232,6 +232,229 @@ __global__ __launch_bounds__(256) void ln_residual_concat_kernel(const float* __
 }
 
 // ---------------------------------------------------------------------------
+// Everything behind the attention reduce of one layer, for a tile of 32 rows, in ONE kernel:
+//   oattn = [zbar_h . W_V,h^T]_h   ->   y = oattn . W_O^T + b_O   ->   LayerNorm(y + [x | 0 | cos(tb)])
+//   ->   cat [ . | z0 ]   ->   relu(fc1)   ->   fc2                     (attention.py:119-127, tgat.py:36-38)
+// Every stage is row-local, so the intermediates never leave LDS: five launches (each ~5 us of fixed cost at these
+// sizes) and four HBM round trips of [R, ~O] activations collapse into one.  A stage is a 32 x N x K GEMM: the A
+// operand comes from LDS (row stride = 4 mod 32 floats: conflict-free 16-byte reads) or, for the first stage,
+// straight from global memory; the weights (B, K-contiguous rows) are read from L2 in the MFMA register layout;
+// the 4 waves split the 32-column blocks of N.
+// ---------------------------------------------------------------------------
+struct ChainArgs {
+  const float* zbar;  // [R, H, Cp]
+  const float* x;     // [R, >= d] layer input rows (the residual's feature part)
+  const float* tb;    // [T] Time2Vec bias: the residual's time part is cos(tb) (attention.py:93-95)
+  const float* z0;    // [R, d0] skip features for the merge layer
+  const float *W_V, *W_O, *b_O, *ln_g, *ln_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+  float* out;         // [R, ldo]
+  long long R, ld_zbar, ldx, ldo;
+  int d, T, d0, O, H, C, emb, emb_out;
+  int Cp, Op, Kc, Ep;  // row strides of the padded weight copies
+  int LD;              // LDS row stride in floats
+  float eps;
+};
+
+template <bool A_LDS>
+__device__ __forceinline__ void chain_load_a(const float* __restrict__ row, int kb, int K, float (&v)[8]) {
+  if (kb + 8 <= K) {
+    const float4 x = *reinterpret_cast<const float4*>(row + kb);
+    const float4 y = *reinterpret_cast<const float4*>(row + kb + 4);
+    v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+    v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
+  } else {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = kb + u < K ? row[kb + u] : 0.f;  // LDS columns >= K may hold an older stage
+  }
+}
+
+__device__ __forceinline__ void load8(const float* __restrict__ p, float (&v)[8]) {
+  const float4 x = *reinterpret_cast<const float4*>(p);
+  const float4 y = *reinterpret_cast<const float4*>(p + 4);
+  v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+  v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
+}
+
+// one 32 x 32 output block: out[:, col_off + n0 .. +32) = A[32, K] . B[n0 .. n0+32, K]^T (+ bias, relu).
+// The weights come from L2 (~1 us away) and a 16-wide k-step is only 8 MFMAs (0.2 us), so the k-loop runs in
+// groups of 4 steps with 4 register buffers: straight-line code, every buffer is refilled for the next group right
+// after its MFMAs issue (no branch between a load and its use, so the compiler's waitcnt stays exact).  The
+// < 4 leftover steps (and the ragged tail of K) are loaded up front with guards and consumed last.
+template <bool A_LDS, bool OUT_LDS>
+__device__ __forceinline__ void chain_block(const float* __restrict__ A, long long lda, int rows_valid,
+                                            const float* __restrict__ B, long long ldb, int N, int n0, int K,
+                                            const float* __restrict__ bias, int relu, float* __restrict__ out,
+                                            long long ldo, int col_off, int lane) {
+  const int i = lane & 31, half = lane >> 5;
+  const int cb = n0 + i < N ? n0 + i : N - 1;
+  const float* __restrict__ pb = B + (long long)cb * ldb + half * 8;
+  const float* __restrict__ pa = A + (long long)((A_LDS || i < rows_valid) ? i : rows_valid - 1) * lda + half * 8;
+  floatx16 acc = {0};
+  constexpr int GA = A_LDS ? 1 : 8;  // a global A operand rides along with B; an LDS one is read at use
+  const int nfull = K > 0 ? K / 16 : 0, ngrp = nfull / 4;
+  const int rem0 = ngrp * 4;  // first leftover step
+  float r0[8], r1[8], r2[8], r3[8], s0[GA], s1[GA], s2[GA], s3[GA];
+  auto tail_fetch = [&](float (&bd)[8], float (&ad)[GA], int st) {
+    const int kb = st * 16 + half * 8;  // kb is relative to pa / pb, which already include half * 8
+    if (st * 16 < K) {
+      load_kn<true, 8>(pb - half * 8, kb, K, bd);
+      if constexpr (!A_LDS) chain_load_a<false>(pa - half * 8, kb, K, ad);
+    }
+  };
+  tail_fetch(r0, s0, rem0);
+  tail_fetch(r1, s1, rem0 + 1);
+  tail_fetch(r2, s2, rem0 + 2);
+  tail_fetch(r3, s3, rem0 + 3);
+  auto mfma8 = [&](const float (&a)[8], const float (&b)[8]) {
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], b[kk], acc, 0, 0, 0);
+  };
+  if (ngrp > 0) {
+    float b0[8], b1[8], b2[8], b3[8], a0[8], a1[8], a2[8], a3[8];
+    load8(pb, b0);
+    load8(pb + 16, b1);
+    load8(pb + 32, b2);
+    load8(pb + 48, b3);
+    if constexpr (!A_LDS) {
+      load8(pa, a0);
+      load8(pa + 16, a1);
+      load8(pa + 32, a2);
+      load8(pa + 48, a3);
+    }
+    for (int gi = 0; gi < ngrp; ++gi) {
+      const int cur = gi * 64;
+      const int nxt = (gi + 1 < ngrp ? gi + 1 : gi) * 64;  // the last group refills itself: harmless, keeps the body branch-free
+      if constexpr (A_LDS) load8(pa + cur, a0);
+      mfma8(a0, b0);
+      load8(pb + nxt, b0);
+      if constexpr (!A_LDS) load8(pa + nxt, a0);
+      if constexpr (A_LDS) load8(pa + cur + 16, a1);
+      mfma8(a1, b1);
+      load8(pb + nxt + 16, b1);
+      if constexpr (!A_LDS) load8(pa + nxt + 16, a1);
+      if constexpr (A_LDS) load8(pa + cur + 32, a2);
+      mfma8(a2, b2);
+      load8(pb + nxt + 32, b2);
+      if constexpr (!A_LDS) load8(pa + nxt + 32, a2);
+      if constexpr (A_LDS) load8(pa + cur + 48, a3);
+      mfma8(a3, b3);
+      load8(pb + nxt + 48, b3);
+      if constexpr (!A_LDS) load8(pa + nxt + 48, a3);
+    }
+  }
+  auto tail_step = [&](const float (&bd)[8], const float (&ad)[GA], int st) {
+    if (st * 16 < K) {
+      if constexpr (A_LDS) {
+        float a[8];
+        chain_load_a<true>(pa - half * 8, st * 16 + half * 8, K, a);
+        mfma8(a, bd);
+      } else {
+        mfma8(ad, bd);
+      }
+    }
+  };
+  tail_step(r0, s0, rem0);
+  tail_step(r1, s1, rem0 + 1);
+  tail_step(r2, s2, rem0 + 2);
+  tail_step(r3, s3, rem0 + 3);
+  const int col = n0 + i;
+  if (col < N) {
+    const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+      float v = acc[r] + bv;
+      if (relu) v = v > 0.f ? v : 0.f;
+      if (OUT_LDS || row < rows_valid) out[(long long)row * ldo + col_off + col] = v;
+    }
+  }
+}
+
+constexpr int kChainWaves = 4;
+constexpr int kChainThreads = kChainWaves * kWave;
+
+__global__ __launch_bounds__(kChainThreads) void tgat_post_chain_kernel(const ChainArgs g) {
+  // LDS: two [32, LD] activation buffers, then the row-constant vectors and this tile's residual / skip inputs,
+  // all staged up front so that no stage waits on a dependent global load
+  extern __shared__ __attribute__((aligned(16))) float chain_lds[];
+  const int O = g.O, dh = O / g.H, LD = g.LD;
+  float* buf0 = chain_lds;
+  float* buf1 = buf0 + 32 * LD;
+  float* ct = buf1 + 32 * LD;  // [T]  cos(tb)
+  float* lg = ct + g.T;        // [O]  LayerNorm weight
+  float* lb = lg + O;          // [O]  LayerNorm bias
+  float* xs = lb + O;          // [32, d]  residual feature part
+  float* zs = xs + 32 * g.d;   // [32, d0] skip features
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long long m0 = (long long)blockIdx.x * 32;
+  const int rows = (g.R - m0) < 32 ? (int)(g.R - m0) : 32;
+  for (int t = tid; t < g.T; t += kChainThreads) ct[t] = cos_t2v(g.tb[t]);
+  for (int c = tid; c < O; c += kChainThreads) {
+    lg[c] = g.ln_g[c];
+    lb[c] = g.ln_b[c];
+  }
+  for (int e = tid; e < rows * g.d; e += kChainThreads) {
+    const int r = e / g.d, c = e - r * g.d;
+    xs[e] = g.x[(m0 + r) * g.ldx + c];
+  }
+  for (int e = tid; e < rows * g.d0; e += kChainThreads) zs[e] = g.z0[m0 * g.d0 + e];
+
+  // stage 1: oattn (buf0) -- per head, zbar rows straight from global.  K = C is the long dimension here and there
+  // are only H * ceil(dh / 32) column blocks, so two waves share a block: the upper half of K lands in buf1 and is
+  // added by the owner of the lower half (fixed order: deterministic).
+  const int nb_h = (dh + 31) / 32;
+  const int nblk = g.H * nb_h;
+  const int Kh = ((g.C + 31) / 32) * 16;  // lower half of K, a multiple of the 16-wide k-step
+  for (int idx = wave; idx < 2 * nblk; idx += kChainWaves) {
+    const int part = idx / nblk, blk = idx - part * nblk;
+    const int h = blk / nb_h, nb = blk - h * nb_h;
+    const float* A = g.zbar + m0 * g.ld_zbar + (long long)h * g.Cp + part * Kh;
+    const float* B = g.W_V + (long long)h * dh * g.Cp + part * Kh;
+    const int Kp = part ? g.C - Kh : (Kh < g.C ? Kh : g.C);
+    chain_block<false, true>(A, g.ld_zbar, rows, B, g.Cp, dh, nb * 32, Kp, nullptr, 0, part ? buf1 : buf0, LD, h * dh, lane);
+  }
+  __syncthreads();
+  for (int e = tid; e < 32 * O; e += kChainThreads) {
+    const int r = e / O, c = e - r * O;
+    buf0[r * LD + c] += buf1[r * LD + c];
+  }
+  __syncthreads();
+  // stage 2: y (buf1) = oattn . W_O^T + b_O
+  for (int nb = wave; nb < (O + 31) / 32; nb += kChainWaves)
+    chain_block<true, true>(buf0, LD, 32, g.W_O, g.Op, O, nb * 32, O, g.b_O, 0, buf1, LD, 0, lane);
+  __syncthreads();
+  // stage 3: cat (buf0) = [LayerNorm(y + residual) | z0]; same arithmetic as ln_residual_concat_kernel
+  const int t0 = O - g.T;
+  for (int r = wave; r < rows; r += kChainWaves) {
+    const float* yr = buf1 + r * LD;
+    const float* xr = xs + r * g.d;
+    auto res = [&](int c) -> float { return c < g.d ? xr[c] : (c >= t0 ? ct[c - t0] : 0.f); };
+    float s = 0.f;
+    for (int c = lane; c < O; c += kWave) s += yr[c] + res(c);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)O;
+    float v = 0.f;
+    for (int c = lane; c < O; c += kWave) {
+      const float t = yr[c] + res(c) - mean;
+      v += t * t;
+    }
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const float rstd = 1.0f / sqrtf(v / (float)O + g.eps);
+    float* orow = buf0 + r * LD;
+    for (int c = lane; c < O; c += kWave) orow[c] = (yr[c] + res(c) - mean) * rstd * lg[c] + lb[c];
+    for (int c = lane; c < g.d0; c += kWave) orow[O + c] = zs[r * g.d0 + c];
+  }
+  __syncthreads();
+  // stage 4: h1 (buf1) = relu(cat . fc1^T + b1)
+  for (int nb = wave; nb < (g.emb + 31) / 32; nb += kChainWaves)
+    chain_block<true, true>(buf0, LD, 32, g.fc1_w, g.Kc, g.emb, nb * 32, O + g.d0, g.fc1_b, 1, buf1, LD, 0, lane);
+  __syncthreads();
+  // stage 5: out = h1 . fc2^T + b2  -> global
+  for (int nb = wave; nb < (g.emb_out + 31) / 32; nb += kChainWaves)
+    chain_block<true, false>(buf1, LD, rows, g.fc2_w, g.Ep, g.emb_out, nb * 32, g.emb, g.fc2_b, 0, g.out + m0 * g.ldo, g.ldo, 0, lane);
+}
+
+// ---------------------------------------------------------------------------
 // Per-row attention over the k sampled neighbor slots (one wave per row).
 // ---------------------------------------------------------------------------
 struct AttnArgs {
@@ -800,6 +1023,39 @@ extern "C" size_t tgmx_tgat_workspace_bytes(const tgmx_tgat_model_t* m, int64_t 
   return tgmx_tgat_layout(m, S0, hops, 0, &lay) == TGMX_OK ? (size_t)lay.total_bytes : 0;
 }
 
+static int launch_post_chain(const tgmx_tgat_layer_t& ly, const tgmx_tgat_layer_layout_t& lo, const float* zbar, const float* x,
+                             long long ldx, const float* tb, const float* z0, int d0, long long R, float* out, long long ldo,
+                             hipStream_t st) {
+  ChainArgs g{};
+  g.zbar = zbar; g.x = x; g.tb = tb; g.z0 = z0;
+  g.W_V = ly.W_V; g.W_O = ly.W_O; g.b_O = ly.b_O; g.ln_g = ly.ln_g; g.ln_b = ly.ln_b;
+  g.fc1_w = ly.fc1_w; g.fc1_b = ly.fc1_b; g.fc2_w = ly.fc2_w; g.fc2_b = ly.fc2_b;
+  g.out = out; g.R = R; g.ld_zbar = (long long)ly.H * lo.Cp; g.ldx = ldx; g.ldo = ldo;
+  g.d = ly.d; g.T = ly.T; g.d0 = d0; g.O = ly.O; g.H = ly.H; g.C = ly.d + ly.D + ly.T; g.emb = ly.emb; g.emb_out = ly.emb_out;
+  g.Cp = lo.Cp; g.Op = lo.Op; g.Kc = lo.Kc; g.Ep = lo.Ep; g.eps = ly.ln_eps;
+  int kmax = ly.O + d0;
+  if (ly.emb > kmax) kmax = ly.emb;
+  g.LD = (kmax + 31) / 32 * 32 + 4;
+  const size_t lds = ((size_t)64 * g.LD + ly.T + 2 * ly.O + 32 * ly.d + 32 * d0) * sizeof(float);
+  if (lds > 160 * 1024) {
+    set_error("tgat_forward: layer too wide for the fused chain (%zu bytes of LDS)", lds);
+    return TGMX_E_UNSUPPORTED;
+  }
+  static size_t lds_limit = 0;
+  if (lds > lds_limit) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tgat_post_chain_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      set_error("tgat_forward: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+      return TGMX_E_LAUNCH;
+    }
+    lds_limit = lds;
+  }
+  hipLaunchKernelGGL(tgat_post_chain_kernel, dim3((unsigned)((R + 31) / 32)), dim3(kChainThreads), lds, st, g);
+  TGMX_CHECK_LAUNCH("tgat_post_chain");
+  return TGMX_OK;
+}
+
 extern "C" int tgmx_tgat_forward(const tgmx_tgat_model_t* m, const float* node_x, int64_t num_nodes, const int32_t* seed_ids,
                                  int64_t S0, const tgmx_tgat_hop_t* hops, float* workspace, size_t workspace_bytes, int32_t save,
                                  float* out, tgmx_stream_t stream) {
@@ -850,6 +1106,13 @@ extern "C" int tgmx_tgat_forward(const tgmx_tgat_model_t* m, const float* node_x
                                       hops[i].nbr_id, m->tw, m->tb, nullptr, nullptr, ly.T, H, k, rows[i], 1.0f / sqrtf((float)dh), Cp,
                                       zbar + off[i] * (long long)H * Cp, probs ? probs + off[i] * (long long)H * k : nullptr, stream)))
         return rc;
+    }
+    if (!save && R >= 2048) {  // inference, enough row tiles to fill the chip: the whole tail of the layer is one
+                               // row-tile kernel, intermediates stay in LDS
+      if ((rc = launch_post_chain(ly, lo, zbar, prev, ld_prev, m->tb, z0, d0, R, nxt, ld_nxt, (hipStream_t)stream))) return rc;
+      prev = nxt;
+      ld_prev = ld_nxt;
+      continue;
     }
     // Oattn[:, head h] = zbar[:, h, :] @ W_V[head h]^T   (W_V padded copy [O, Cp])
     if ((rc = tgmx_sgemm_nt(zbar, (long long)H * Cp, ly.W_V, Cp, oattn, Op, R, dh, C, nullptr, 0, H, Cp, (long long)dh * Cp, dh, stream))) return rc;
