@@ -44,18 +44,16 @@ inline FastDiv make_fastdiv(uint32_t div) {
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
 
-// cos(x) for Time2Vec arguments (float32 x up to ~2^31 * w): the argument is reduced in DOUBLE
-// precision (x - k*pi/2 with a two-term pi/2: exact to ~1e-16 * k, far below float resolution for
-// every float32 input), then a float minimax polynomial on [-pi/4, pi/4].  ~35 instructions and no
-// divergence, vs ~130 for the library cosf whose large-argument (Payne-Hanek) path every wave takes
-// here because a row's 100 frequencies span 9 decades.  Max error ~1.5 ulp (< 2e-7 absolute).
-__device__ __forceinline__ float cos_t2v(float x) {
-  const double xd = (double)x;
-  const double kd = __builtin_rint(xd * 0.63661977236758134308);
-  double r = __builtin_fma(-kd, 1.57079632679489655800e+00, xd);
-  r = __builtin_fma(-kd, 6.12323399573676603587e-17, r);
-  const float rf = (float)r;
-  const int q = (int)((long long)kd & 3);
+// cos(x) for Time2Vec arguments (float32 x up to ~2^31 * w).  A row's 100 frequencies span 9 decades, so the
+// library cosf would take its large-argument (Payne-Hanek) path on every wave (~130 instructions).  Instead:
+//   * polynomial: float minimax sin / cos on [-pi/4, pi/4], quadrant from the reduction's integer;
+//   * reduction, |x| < 8e6 (k < 2^23): three float FMAs x - k*c1 - k*c2 - k*c3 with a three-term pi/2 -- the FMA
+//     forms k*c exactly, so each step rounds once (<= 6e-8 absolute on a result of order 1);
+//   * reduction, larger |x|: the same in double with a two-term pi/2 (exact to ~1e-16 * k for every float32 input).
+// The choice is made per WAVE (__all), not per lane: no divergence, and at dataset scale the high-frequency columns
+// sit in one half of the lanes' column pairs, so the other half always takes the cheap path.
+// Max error < 2.5e-7 absolute.  Must be called from wave-uniform control flow.
+__device__ __forceinline__ float cos_t2v_poly(float rf, int q) {
   const float r2 = rf * rf;
   float sp = -1.9515295891e-4f;
   sp = __fmaf_rn(sp, r2, 8.3321608736e-3f);
@@ -67,6 +65,21 @@ __device__ __forceinline__ float cos_t2v(float x) {
   const float cs = __fmaf_rn(cp * r2, r2, __fmaf_rn(-0.5f, r2, 1.0f));
   const float v = (q & 1) ? sn : cs;  // q: 0 -> cos r, 1 -> -sin r, 2 -> -cos r, 3 -> sin r
   return (q == 1 || q == 2) ? -v : v;
+}
+
+__device__ __forceinline__ float cos_t2v(float x) {
+  if (__all(fabsf(x) < 8.0e6f)) {
+    const float k = __builtin_rintf(x * 0.636619772367581343f);
+    float r = __fmaf_rn(-k, 1.57079637050628662109375f, x);
+    r = __fmaf_rn(-k, -4.37113900018624283e-8f, r);
+    r = __fmaf_rn(-k, -1.71512449e-15f, r);
+    return cos_t2v_poly(r, (int)k & 3);
+  }
+  const double xd = (double)x;
+  const double kd = __builtin_rint(xd * 0.63661977236758134308);
+  double r = __builtin_fma(-kd, 1.57079632679489655800e+00, xd);
+  r = __builtin_fma(-kd, 6.12323399573676603587e-17, r);
+  return cos_t2v_poly((float)r, (int)((long long)kd & 3));
 }
 
 }  // namespace tgmx
