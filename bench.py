@@ -119,6 +119,23 @@ def cpu_baseline(stream, bs, num_nbrs, n_batches, seed):
     )
 
 
+def pmc_traffic(args, grid_slots):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+    of this very command, separate runs; tools/gpu_round.sh writes profiles/pmc_hop1.json).  FETCH_SIZE is doubled: the
+    gfx950 correction of MI355X_MICROARCH.md for wide coalesced reads.  None when no profile of this configuration exists."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_hop1.json')
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        p = json.load(f)
+    same = (p.get('workload'), p.get('mode'), p.get('batch_size'), p.get('num_nbrs')) == (
+        args.workload, args.mode, args.batch_size or DEFAULTS[args.workload][0], args.num_nbrs or DEFAULTS[args.workload][1])
+    if not same or p.get('slots_per_launch') != grid_slots:
+        return None
+    return {'bytes': 2 * 1024 * p['fetch_kb'] + 1024 * p['write_kb'], 'fetch_kb_x2': 2 * p['fetch_kb'], 'write_kb': p['write_kb'],
+            'source': 'profiles/pmc_hop1.json (rocprofv3 --pmc, separate passes)'}
+
+
 def main():
     args = parse_args()
     from tgm_amd.dist import init_process_group
@@ -226,7 +243,7 @@ def main():
             'peak': HBM_PEAK_GBS,
             'unit': 'GB/s',
             'frac': achieved / HBM_PEAK_GBS,
-            'traffic': None,
+            'traffic': pmc_traffic(args, seeds_l * k_l),
             'avg_kernel_ms': avg_ms,
             'launches_timed': len(ker_ms),
             'algorithmic_bytes_per_launch': algo_bytes,

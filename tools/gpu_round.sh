@@ -28,5 +28,8 @@ cd $ROOT
   echo "# rocprofv3 --pmc WRITE_SIZE -- python bench.py --steps 200 --cpu-batches 0   (KB per dispatch)"
   python tools/rocpd_summary.py $OUT/prof_write/write_results.db --md | sed -n '/counter/,$p'
 } > $OUT/rocprof_summary.md
+python tools/pmc_extract.py $OUT/prof_fetch/fetch_results.db $OUT/prof_write/write_results.db $OUT/pmc_hop1.json
+python tools/bench_tgat.py 200 > $OUT/bench_tgat.json 2> $OUT/bench_tgat.err; cat $OUT/bench_tgat.json
+python tools/time_update.py > $OUT/time_update.json 2>/dev/null; cat $OUT/time_update.json
 rm -f $OUT/prof_*/*.db   # the raw SQLite traces are tens of MB; the summary is what is kept
 head -30 $OUT/rocprof_summary.md
