@@ -248,6 +248,11 @@ typedef struct tgmx_tgat_layer {
   const float* fc1_b; /* [emb]                                                                         */
   const float* fc2_w; /* [emb_out, p4(emb)]                                                            */
   const float* fc2_b; /* [emb_out]                                                                     */
+  /* optional (inference): the query side folded onto the layer input -- qf[r, h, c] = qf_v[h*p4(C) + c] +
+   * sum_j x[r, j] * qf_U[(h*p4(C) + c) * p4(d) + j], with U_h = W_K,h^T W_Q,h[:, :d] and v_h = W_K,h^T W_Q,h[:, O-T:]
+   * cos(tb) (the residual's time part is Time2Vec(0), attention.py:93-95).  NULL: Q and qf are computed per call. */
+  const float* qf_U;  /* [H * p4(C), p4(d)] */
+  const float* qf_v;  /* [H * p4(C)]        */
   int32_t d, D, T, O, H, emb, emb_out;
   float ln_eps;
 } tgmx_tgat_layer_t;

@@ -83,7 +83,7 @@ TGAT_MAX_LAYERS = 4
 
 
 class TgatLayer(ctypes.Structure):
-    _fields_ = [(n, c_void_p) for n in ('W_Q', 'W_K_t', 'W_V', 'W_O', 'b_O', 'ln_g', 'ln_b', 'fc1_w', 'fc1_b', 'fc2_w', 'fc2_b')] + [
+    _fields_ = [(n, c_void_p) for n in ('W_Q', 'W_K_t', 'W_V', 'W_O', 'b_O', 'ln_g', 'ln_b', 'fc1_w', 'fc1_b', 'fc2_w', 'fc2_b', 'qf_U', 'qf_v')] + [
         (n, c_int32) for n in ('d', 'D', 'T', 'O', 'H', 'emb', 'emb_out')
     ] + [('ln_eps', ctypes.c_float)]
 

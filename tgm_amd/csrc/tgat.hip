@@ -474,6 +474,13 @@ struct AttnArgs {
   float scale;        // dh^-1/2
   int Cs;             // stride (floats) between consecutive heads of qf / zbar rows (>= C; padded layouts)
   float* probs;       // optional [R, H, k]: the attention weights, saved for the backward pass
+  // optional (register kernel only): queries folded all the way onto the row's input, qf[r, h, c] = qv[h*Cs + c]
+  // + sum_j qx[r, j] * qU[(h*Cs + c) * qld + j], j < qd <= 4 -- then qf is never materialised (qf == nullptr)
+  const float* qU;
+  const float* qv;
+  const float* qx;
+  long long ld_qx;
+  int qd, qld;
 };
 
 // sum over the 64 lanes of P[j], delivered to lane j: 63 shuffles instead of 64 * 6.
@@ -693,14 +700,29 @@ __global__ __launch_bounds__(256) void tgat_attn_reduce_reg_kernel(const AttnArg
   float4 qe[H], qn4[H];
   float qn[H], qt0[H], qt1[H];
   const bool t0_on = lane < T, t1_on = lane + kWave < T;
+  float xq[4] = {0.f, 0.f, 0.f, 0.f};
+  if (a.qU) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xq[j] = j < a.qd ? a.qx[r * a.ld_qx + j] : 0.f;
+  }
 #pragma unroll
   for (int h = 0; h < H; ++h) {
-    const float* qh = q + h * a.Cs;
-    qe[h] = e_on ? make_float4(qh[d + 4 * lane], qh[d + 4 * lane + 1], qh[d + 4 * lane + 2], qh[d + 4 * lane + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
-    if (NBV) qn4[h] = lane < d4 ? make_float4(qh[4 * lane], qh[4 * lane + 1], qh[4 * lane + 2], qh[4 * lane + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
-    else qn[h] = lane < d ? qh[lane] : 0.f;
-    qt0[h] = t0_on ? qh[d + D + lane] : 0.f;
-    qt1[h] = t1_on ? qh[d + D + lane + kWave] : 0.f;
+    const float* qh = a.qU ? nullptr : q + h * a.Cs;
+    // column c of head h: straight from qf, or v[c] + U[c, :] . x[r, :] when the fold reaches the row input
+    auto qcol = [&](int c) -> float {
+      if (!a.qU) return qh[c];
+      const long long g = (long long)h * a.Cs + c;
+      float v = a.qv[g];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j < a.qd) v = __fmaf_rn(xq[j], a.qU[g * a.qld + j], v);
+      return v;
+    };
+    qe[h] = e_on ? make_float4(qcol(d + 4 * lane), qcol(d + 4 * lane + 1), qcol(d + 4 * lane + 2), qcol(d + 4 * lane + 3)) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (NBV) qn4[h] = lane < d4 ? make_float4(qcol(4 * lane), qcol(4 * lane + 1), qcol(4 * lane + 2), qcol(4 * lane + 3)) : make_float4(0.f, 0.f, 0.f, 0.f);
+    else qn[h] = lane < d ? qcol(lane) : 0.f;
+    qt0[h] = t0_on ? qcol(d + D + lane) : 0.f;
+    qt1[h] = t1_on ? qcol(d + D + lane + kWave) : 0.f;
   }
   const float w0 = t0_on ? a.tw[lane] : 0.f, b0 = t0_on ? a.tb[lane] : 0.f;
   const float w1 = t1_on ? a.tw[lane + kWave] : 0.f, b1 = t1_on ? a.tb[lane + kWave] : 0.f;
@@ -787,12 +809,22 @@ static void launch_attn(dim3 grid, dim3 block, size_t lds, hipStream_t st, const
   if constexpr (G * H <= 64) hipLaunchKernelGGL((tgat_attn_reduce_kernel<H, G>), grid, block, lds, st, a);
 }
 
+// shapes the register-resident kernel covers (checked before anything is launched)
+static bool attn_reg_covers(int H, const AttnArgs& a) {
+  const bool edge_ok = a.D > 0 && a.D % 4 == 0 && a.D / 4 <= 64 && ((uintptr_t)a.ex & 15) == 0;
+  const bool nbv = a.d % 4 == 0 && a.d / 4 <= 64 && ((uintptr_t)a.nbrf & 15) == 0;
+  if (!edge_ok || a.tfeat || a.T > 128 || !(nbv || a.d <= 64)) return false;
+  if (a.qU && a.qd > 4) return false;
+  return (H == 1 || H == 2) && a.k <= 20 && a.k * H <= 64;
+}
+
 // register-resident fast path; returns false when the shape does not qualify
 template <int H>
 static bool launch_attn_reg(hipStream_t st, const AttnArgs& a) {
   const bool edge_ok = a.D > 0 && a.D % 4 == 0 && a.D / 4 <= 64 && ((uintptr_t)a.ex & 15) == 0;
   const bool nbv = a.d % 4 == 0 && a.d / 4 <= 64 && ((uintptr_t)a.nbrf & 15) == 0;
   if (!edge_ok || a.tfeat || a.T > 128 || !(nbv || a.d <= 64)) return false;
+  if (a.qU && a.qd > 4) return false;
   const dim3 grid((unsigned)((a.R + 3) / 4)), block(256);
 #define TGMX_REG(G_)                                                                                        \
   if constexpr (G_ * H <= 64) {                                                                             \
@@ -888,31 +920,21 @@ extern "C" int tgmx_ln_residual_concat(const float* y, int64_t ldy, const float*
   return TGMX_OK;
 }
 
-extern "C" int tgmx_tgat_attn_reduce(const float* qf, const float* nbrf, int32_t d, const float* ex, int32_t D,
-                                     const int64_t* seed_t, const int64_t* nbr_t, const int32_t* nbr_id, const float* tw,
-                                     const float* tb, const float* nbr_time_feat, const uint8_t* mask, int32_t T, int32_t H,
-                                     int32_t k, int64_t R, float scale, int32_t head_stride, float* zbar, float* attn_probs,
-                                     tgmx_stream_t stream) {
-  TGMX_REQUIRE(d > 0 && D >= 0 && T > 0 && k > 0 && R >= 0, "tgat_attn_reduce: bad sizes d=%d D=%d T=%d k=%d", d, D, T, k);
-  TGMX_REQUIRE(H == 1 || H == 2 || H == 4 || H == 8, "tgat_attn_reduce: n_heads=%d unsupported (1, 2, 4 or 8)", H);
-  if (R == 0) return TGMX_OK;
-  TGMX_REQUIRE(qf && nbrf && (D == 0 || ex) && zbar, "tgat_attn_reduce: null pointer");
-  TGMX_REQUIRE(nbr_time_feat || (seed_t && nbr_t && tw && tb), "tgat_attn_reduce: need times + Time2Vec params or nbr_time_feat");
-  TGMX_REQUIRE(mask || nbr_id, "tgat_attn_reduce: need nbr_id or mask");
-  TGMX_REQUIRE(head_stride == 0 || head_stride >= d + D + T, "tgat_attn_reduce: head_stride smaller than d + D + T");
-  AttnArgs a{qf, nbrf, ex, seed_t, nbr_t, nbr_id, tw, tb, nbr_time_feat, mask, zbar, R, d, D, T, k, d + D + T, scale,
-             head_stride ? head_stride : d + D + T, attn_probs};
+// shared by the C entry point and the forward driver (which may pass queries folded onto the row input)
+static int attn_reduce_impl(const AttnArgs& a, int H, hipStream_t st) {
+  const int k = a.k, T = a.T;
+  const long long R = a.R;
   const size_t per_wave = ((size_t)k * T + (size_t)k * (H + 2)) * sizeof(float);
   int waves = 4;
   while (waves > 1 && per_wave * waves > 64 * 1024) waves >>= 1;
   TGMX_REQUIRE(per_wave * waves <= 64 * 1024, "tgat_attn_reduce: k*T=%d too large for the LDS time-encoding cache", k * T);
   const dim3 grid((unsigned)((R + waves - 1) / waves)), block(waves * kWave);
   const size_t lds = per_wave * waves;
-  hipStream_t st = (hipStream_t)stream;
   if ((H == 1 && launch_attn_reg<1>(st, a)) || (H == 2 && launch_attn_reg<2>(st, a))) {
     TGMX_CHECK_LAUNCH("tgat_attn_reduce(reg)");
     return TGMX_OK;
   }
+  TGMX_REQUIRE(!a.qU, "tgat_attn_reduce: folded queries need the register kernel (shape not covered)");
   // slots per score group: the smallest instantiated G >= min(k, 64 / H)
   const int want = k < 64 / H ? k : 64 / H;
 #define TGMX_ATTN(H_, G_) launch_attn<H_, G_>(grid, block, lds, st, a)
@@ -935,6 +957,23 @@ extern "C" int tgmx_tgat_attn_reduce(const float* qf, const float* nbrf, int32_t
 #undef TGMX_ATTN
   TGMX_CHECK_LAUNCH("tgat_attn_reduce");
   return TGMX_OK;
+}
+
+extern "C" int tgmx_tgat_attn_reduce(const float* qf, const float* nbrf, int32_t d, const float* ex, int32_t D,
+                                     const int64_t* seed_t, const int64_t* nbr_t, const int32_t* nbr_id, const float* tw,
+                                     const float* tb, const float* nbr_time_feat, const uint8_t* mask, int32_t T, int32_t H,
+                                     int32_t k, int64_t R, float scale, int32_t head_stride, float* zbar, float* attn_probs,
+                                     tgmx_stream_t stream) {
+  TGMX_REQUIRE(d > 0 && D >= 0 && T > 0 && k > 0 && R >= 0, "tgat_attn_reduce: bad sizes d=%d D=%d T=%d k=%d", d, D, T, k);
+  TGMX_REQUIRE(H == 1 || H == 2 || H == 4 || H == 8, "tgat_attn_reduce: n_heads=%d unsupported (1, 2, 4 or 8)", H);
+  if (R == 0) return TGMX_OK;
+  TGMX_REQUIRE(qf && nbrf && (D == 0 || ex) && zbar, "tgat_attn_reduce: null pointer");
+  TGMX_REQUIRE(nbr_time_feat || (seed_t && nbr_t && tw && tb), "tgat_attn_reduce: need times + Time2Vec params or nbr_time_feat");
+  TGMX_REQUIRE(mask || nbr_id, "tgat_attn_reduce: need nbr_id or mask");
+  TGMX_REQUIRE(head_stride == 0 || head_stride >= d + D + T, "tgat_attn_reduce: head_stride smaller than d + D + T");
+  AttnArgs a{qf, nbrf, ex, seed_t, nbr_t, nbr_id, tw, tb, nbr_time_feat, mask, zbar, R, d, D, T, k, d + D + T, scale,
+             head_stride ? head_stride : d + D + T, attn_probs};
+  return attn_reduce_impl(a, H, (hipStream_t)stream);
 }
 
 extern "C" int tgmx_time2vec(const void* x, int32_t x_is_int64, const float* w, const float* b, int32_t T, int64_t n,
@@ -1092,23 +1131,46 @@ extern "C" int tgmx_tgat_forward(const tgmx_tgat_model_t* m, const float* node_x
     float* probs = lo.probs >= 0 ? base + lo.probs : nullptr;
     float* nxt = (j == L) ? out : base + lo.out;
     const long long ld_nxt = ly.emb_out;  // layer outputs stay densely packed: they are the next layer's neighbor features
-    if ((rc = tgmx_tgat_rres(prev, ld_prev, ly.d, m->tb, nullptr, ly.T, O, R, rres, Op, stream))) return rc;
-    // Q[:, head h] = rres @ W_Q[head h rows]^T     (heads written dhp apart)
-    if ((rc = tgmx_sgemm_nt(rres, Op, ly.W_Q, Op, Q, (long long)H * dhp, R, dh, O, nullptr, 0, H, 0, (long long)dh * Op, dhp, stream))) return rc;
-    // qf[:, h, :] = Q[:, head h] @ W_K[head h]  via the transposed padded copy W_K_t [C, H*dhp]
-    if ((rc = tgmx_sgemm_nt(Q, (long long)H * dhp, ly.W_K_t, (long long)H * dhp, qf, (long long)H * Cp, R, C, dh, nullptr, 0, H, dhp, dhp, Cp, stream)))
-      return rc;
+    const bool chain = !save && R >= 2048;     // the fused tail rebuilds the residual itself
+    const bool folded = !save && ly.qf_U != nullptr;  // inference: qf = x . U^T + v, no Q / rres round trip
+    const int dp = (ly.d + 3) / 4 * 4;
+    bool onfly = folded && ly.d <= 4;  // ... and for narrow inputs not even qf: the attention kernel forms it per row
+    for (int i = 0; onfly && i < n_lvl; ++i) {
+      if (rows[i] == 0) continue;
+      AttnArgs probe{};
+      probe.nbrf = prev + off[i + 1] * ld_prev; probe.ex = hops[i].edge_x; probe.d = ly.d; probe.D = ly.D; probe.T = ly.T;
+      probe.k = hops[i].k; probe.qU = ly.qf_U; probe.qd = ly.d;
+      onfly = attn_reg_covers(H, probe);
+    }
+    if (!folded || !chain)
+      if ((rc = tgmx_tgat_rres(prev, ld_prev, ly.d, m->tb, nullptr, ly.T, O, R, rres, Op, stream))) return rc;
+    if (!folded) {
+      // Q[:, head h] = rres @ W_Q[head h rows]^T     (heads written dhp apart)
+      if ((rc = tgmx_sgemm_nt(rres, Op, ly.W_Q, Op, Q, (long long)H * dhp, R, dh, O, nullptr, 0, H, 0, (long long)dh * Op, dhp, stream))) return rc;
+      // qf[:, h, :] = Q[:, head h] @ W_K[head h]  via the transposed padded copy W_K_t [C, H*dhp]
+      if ((rc = tgmx_sgemm_nt(Q, (long long)H * dhp, ly.W_K_t, (long long)H * dhp, qf, (long long)H * Cp, R, C, dh, nullptr, 0, H, dhp, dhp, Cp, stream)))
+        return rc;
+    } else if (!onfly) {
+      if ((rc = tgmx_sgemm_nt(prev, ld_prev, ly.qf_U, dp, qf, (long long)H * Cp, R, H * Cp, ly.d, ly.qf_v, 0, 1, 0, 0, 0, stream))) return rc;
+    }
     for (int i = 0; i < n_lvl; ++i) {
       if (rows[i] == 0) continue;
       TGMX_REQUIRE(hops[i].k == k, "tgat_forward: layer %d needs the same k at every hop it aggregates", j);
       const float* nbrf = prev + off[i + 1] * ld_prev;
-      if ((rc = tgmx_tgat_attn_reduce(qf + off[i] * (long long)H * Cp, nbrf, ly.d, hops[i].edge_x, ly.D, hops[i].seed_t, hops[i].nbr_t,
-                                      hops[i].nbr_id, m->tw, m->tb, nullptr, nullptr, ly.T, H, k, rows[i], 1.0f / sqrtf((float)dh), Cp,
-                                      zbar + off[i] * (long long)H * Cp, probs ? probs + off[i] * (long long)H * k : nullptr, stream)))
-        return rc;
+      AttnArgs a{};
+      a.qf = onfly ? nullptr : qf + off[i] * (long long)H * Cp;
+      a.nbrf = nbrf; a.ex = hops[i].edge_x; a.seed_t = hops[i].seed_t; a.nbr_t = hops[i].nbr_t; a.nbr_id = hops[i].nbr_id;
+      a.tw = m->tw; a.tb = m->tb; a.zbar = zbar + off[i] * (long long)H * Cp; a.R = rows[i];
+      a.d = ly.d; a.D = ly.D; a.T = ly.T; a.k = k; a.C = C; a.scale = 1.0f / sqrtf((float)dh); a.Cs = Cp;
+      a.probs = probs ? probs + off[i] * (long long)H * k : nullptr;
+      if (onfly) {
+        a.qU = ly.qf_U; a.qv = ly.qf_v; a.qx = prev + off[i] * ld_prev; a.ld_qx = ld_prev; a.qd = ly.d; a.qld = dp;
+      }
+      TGMX_REQUIRE(ly.D == 0 || a.ex, "tgat_forward: hop %d has no edge features", i);
+      if ((rc = attn_reduce_impl(a, H, (hipStream_t)stream))) return rc;
     }
-    if (!save && R >= 2048) {  // inference, enough row tiles to fill the chip: the whole tail of the layer is one
-                               // row-tile kernel, intermediates stay in LDS
+    if (chain) {  // inference, enough row tiles to fill the chip: the whole tail of the layer is one row-tile kernel,
+                  // intermediates stay in LDS
       if ((rc = launch_post_chain(ly, lo, zbar, prev, ld_prev, m->tb, z0, d0, R, nxt, ld_nxt, (hipStream_t)stream))) return rc;
       prev = nxt;
       ld_prev = ld_nxt;

@@ -108,7 +108,39 @@ class TGAT(nn.Module):
             ly.d, ly.D, ly.T, ly.O, ly.H = attn.node_dim, attn.edge_dim, attn.time_dim, O, H
             ly.emb, ly.emb_out = merge.fc1.out_features, merge.fc2.out_features
         self._desc_cache = (key, (m, keep))
+        self._desc_folded = False
         return m, keep
+
+    def _ensure_fold(self, m, keep) -> None:
+        """Inference only: fold the query side of every layer onto the layer input (weights only; lives and dies
+        with the parameter cache of ``_model_desc``).  M_h = W_K,h^T W_Q,h [C, O]; U_h = M_h[:, :d];
+        v_h = M_h[:, O-T:] cos(tb) -- computed with the native GEMM."""
+        if self._desc_folded:
+            return
+        p4 = lambda x: (x + 3) // 4 * 4
+        for l, attn in enumerate(self.attn):
+            ly = m.layers[l]
+            O, H, dh = attn.out_dim, attn.n_heads, attn.head_dim
+            C = attn.node_dim + attn.edge_dim + attn.time_dim
+            d_in, T_ = attn.node_dim, attn.time_dim
+            Cp, dp = p4(C), p4(d_in)
+            WKV = attn.W_KV.weight.detach().float()
+            WQ = attn.W_Q.weight.detach().float()
+            dev = WKV.device
+            ct = _ops.time2vec(torch.zeros(1, device=dev), self.time_encoder.w.weight.detach().reshape(-1).float().contiguous(),
+                               self.time_encoder.w.bias.detach().float().contiguous())  # [1, T] = cos(tb)
+            U = torch.zeros((H * Cp, dp), dtype=torch.float32, device=dev)
+            v = torch.zeros((H * Cp, 1), dtype=torch.float32, device=dev)
+            for h in range(H):
+                wk_t = WKV[h * dh : (h + 1) * dh].t().contiguous()  # [C, dh]
+                wq_t = WQ[h * dh : (h + 1) * dh].t().contiguous()  # [O, dh]
+                M = torch.empty((C, O), dtype=torch.float32, device=dev)
+                _ops.sgemm_nt(wk_t, wq_t, M)
+                U[h * Cp : h * Cp + C, :d_in] = M[:, :d_in]
+                _ops.sgemm_nt(M[:, O - T_ :], ct, v[h * Cp : h * Cp + C])
+            keep += [U, v]
+            ly.qf_U, ly.qf_v = U.data_ptr(), v.data_ptr()
+        self._desc_folded = True
 
     def forward(self, node_x: Tensor, seed_nids: List[Tensor], seed_times: List[Tensor], nbr_nids: List[Tensor],
                 nbr_edge_x: List[Tensor], nbr_edge_time: List[Tensor]) -> Tensor:  # fmt: skip
@@ -148,6 +180,7 @@ class TGAT(nn.Module):
         out = torch.empty((S0, self.embed_dim), dtype=torch.float32, device=dev)
         if S0 == 0:
             return out
+        self._ensure_fold(model, _keep)
         need = lib.tgmx_tgat_workspace_bytes(model, S0, hops)
         ws = getattr(self, '_workspace', None)
         if ws is None or ws.device != dev or ws.numel() < need:
