@@ -474,13 +474,6 @@ struct AttnArgs {
   float scale;        // dh^-1/2
   int Cs;             // stride (floats) between consecutive heads of qf / zbar rows (>= C; padded layouts)
   float* probs;       // optional [R, H, k]: the attention weights, saved for the backward pass
-  // optional (register kernel only): queries folded all the way onto the row's input, qf[r, h, c] = qv[h*Cs + c]
-  // + sum_j qx[r, j] * qU[(h*Cs + c) * qld + j], j < qd <= 4 -- then qf is never materialised (qf == nullptr)
-  const float* qU;
-  const float* qv;
-  const float* qx;
-  long long ld_qx;
-  int qd, qld;
 };
 
 // sum over the 64 lanes of P[j], delivered to lane j: 63 shuffles instead of 64 * 6.
@@ -700,29 +693,14 @@ __global__ __launch_bounds__(256) void tgat_attn_reduce_reg_kernel(const AttnArg
   float4 qe[H], qn4[H];
   float qn[H], qt0[H], qt1[H];
   const bool t0_on = lane < T, t1_on = lane + kWave < T;
-  float xq[4] = {0.f, 0.f, 0.f, 0.f};
-  if (a.qU) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) xq[j] = j < a.qd ? a.qx[r * a.ld_qx + j] : 0.f;
-  }
 #pragma unroll
   for (int h = 0; h < H; ++h) {
-    const float* qh = a.qU ? nullptr : q + h * a.Cs;
-    // column c of head h: straight from qf, or v[c] + U[c, :] . x[r, :] when the fold reaches the row input
-    auto qcol = [&](int c) -> float {
-      if (!a.qU) return qh[c];
-      const long long g = (long long)h * a.Cs + c;
-      float v = a.qv[g];
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (j < a.qd) v = __fmaf_rn(xq[j], a.qU[g * a.qld + j], v);
-      return v;
-    };
-    qe[h] = e_on ? make_float4(qcol(d + 4 * lane), qcol(d + 4 * lane + 1), qcol(d + 4 * lane + 2), qcol(d + 4 * lane + 3)) : make_float4(0.f, 0.f, 0.f, 0.f);
-    if (NBV) qn4[h] = lane < d4 ? make_float4(qcol(4 * lane), qcol(4 * lane + 1), qcol(4 * lane + 2), qcol(4 * lane + 3)) : make_float4(0.f, 0.f, 0.f, 0.f);
-    else qn[h] = lane < d ? qcol(lane) : 0.f;
-    qt0[h] = t0_on ? qcol(d + D + lane) : 0.f;
-    qt1[h] = t1_on ? qcol(d + D + lane + kWave) : 0.f;
+    const float* qh = q + h * a.Cs;
+    qe[h] = e_on ? make_float4(qh[d + 4 * lane], qh[d + 4 * lane + 1], qh[d + 4 * lane + 2], qh[d + 4 * lane + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (NBV) qn4[h] = lane < d4 ? make_float4(qh[4 * lane], qh[4 * lane + 1], qh[4 * lane + 2], qh[4 * lane + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    else qn[h] = lane < d ? qh[lane] : 0.f;
+    qt0[h] = t0_on ? qh[d + D + lane] : 0.f;
+    qt1[h] = t1_on ? qh[d + D + lane + kWave] : 0.f;
   }
   const float w0 = t0_on ? a.tw[lane] : 0.f, b0 = t0_on ? a.tb[lane] : 0.f;
   const float w1 = t1_on ? a.tw[lane + kWave] : 0.f, b1 = t1_on ? a.tb[lane + kWave] : 0.f;
@@ -809,22 +787,12 @@ static void launch_attn(dim3 grid, dim3 block, size_t lds, hipStream_t st, const
   if constexpr (G * H <= 64) hipLaunchKernelGGL((tgat_attn_reduce_kernel<H, G>), grid, block, lds, st, a);
 }
 
-// shapes the register-resident kernel covers (checked before anything is launched)
-static bool attn_reg_covers(int H, const AttnArgs& a) {
-  const bool edge_ok = a.D > 0 && a.D % 4 == 0 && a.D / 4 <= 64 && ((uintptr_t)a.ex & 15) == 0;
-  const bool nbv = a.d % 4 == 0 && a.d / 4 <= 64 && ((uintptr_t)a.nbrf & 15) == 0;
-  if (!edge_ok || a.tfeat || a.T > 128 || !(nbv || a.d <= 64)) return false;
-  if (a.qU && a.qd > 4) return false;
-  return (H == 1 || H == 2) && a.k <= 20 && a.k * H <= 64;
-}
-
 // register-resident fast path; returns false when the shape does not qualify
 template <int H>
 static bool launch_attn_reg(hipStream_t st, const AttnArgs& a) {
   const bool edge_ok = a.D > 0 && a.D % 4 == 0 && a.D / 4 <= 64 && ((uintptr_t)a.ex & 15) == 0;
   const bool nbv = a.d % 4 == 0 && a.d / 4 <= 64 && ((uintptr_t)a.nbrf & 15) == 0;
   if (!edge_ok || a.tfeat || a.T > 128 || !(nbv || a.d <= 64)) return false;
-  if (a.qU && a.qd > 4) return false;
   const dim3 grid((unsigned)((a.R + 3) / 4)), block(256);
 #define TGMX_REG(G_)                                                                                        \
   if constexpr (G_ * H <= 64) {                                                                             \
@@ -934,7 +902,6 @@ static int attn_reduce_impl(const AttnArgs& a, int H, hipStream_t st) {
     TGMX_CHECK_LAUNCH("tgat_attn_reduce(reg)");
     return TGMX_OK;
   }
-  TGMX_REQUIRE(!a.qU, "tgat_attn_reduce: folded queries need the register kernel (shape not covered)");
   // slots per score group: the smallest instantiated G >= min(k, 64 / H)
   const int want = k < 64 / H ? k : 64 / H;
 #define TGMX_ATTN(H_, G_) launch_attn<H_, G_>(grid, block, lds, st, a)
@@ -1132,16 +1099,8 @@ extern "C" int tgmx_tgat_forward(const tgmx_tgat_model_t* m, const float* node_x
     float* nxt = (j == L) ? out : base + lo.out;
     const long long ld_nxt = ly.emb_out;  // layer outputs stay densely packed: they are the next layer's neighbor features
     const bool chain = !save && R >= 2048;     // the fused tail rebuilds the residual itself
-    const bool folded = !save && ly.qf_U != nullptr;  // inference: qf = x . U^T + v, no Q / rres round trip
+    const bool folded = !save && ly.qf_U != nullptr;  // inference: qf = x . U^T + v in one GEMM, no Q / rres round trip
     const int dp = (ly.d + 3) / 4 * 4;
-    bool onfly = folded && ly.d <= 4;  // ... and for narrow inputs not even qf: the attention kernel forms it per row
-    for (int i = 0; onfly && i < n_lvl; ++i) {
-      if (rows[i] == 0) continue;
-      AttnArgs probe{};
-      probe.nbrf = prev + off[i + 1] * ld_prev; probe.ex = hops[i].edge_x; probe.d = ly.d; probe.D = ly.D; probe.T = ly.T;
-      probe.k = hops[i].k; probe.qU = ly.qf_U; probe.qd = ly.d;
-      onfly = attn_reg_covers(H, probe);
-    }
     if (!folded || !chain)
       if ((rc = tgmx_tgat_rres(prev, ld_prev, ly.d, m->tb, nullptr, ly.T, O, R, rres, Op, stream))) return rc;
     if (!folded) {
@@ -1150,7 +1109,7 @@ extern "C" int tgmx_tgat_forward(const tgmx_tgat_model_t* m, const float* node_x
       // qf[:, h, :] = Q[:, head h] @ W_K[head h]  via the transposed padded copy W_K_t [C, H*dhp]
       if ((rc = tgmx_sgemm_nt(Q, (long long)H * dhp, ly.W_K_t, (long long)H * dhp, qf, (long long)H * Cp, R, C, dh, nullptr, 0, H, dhp, dhp, Cp, stream)))
         return rc;
-    } else if (!onfly) {
+    } else {
       if ((rc = tgmx_sgemm_nt(prev, ld_prev, ly.qf_U, dp, qf, (long long)H * Cp, R, H * Cp, ly.d, ly.qf_v, 0, 1, 0, 0, 0, stream))) return rc;
     }
     for (int i = 0; i < n_lvl; ++i) {
@@ -1158,14 +1117,11 @@ extern "C" int tgmx_tgat_forward(const tgmx_tgat_model_t* m, const float* node_x
       TGMX_REQUIRE(hops[i].k == k, "tgat_forward: layer %d needs the same k at every hop it aggregates", j);
       const float* nbrf = prev + off[i + 1] * ld_prev;
       AttnArgs a{};
-      a.qf = onfly ? nullptr : qf + off[i] * (long long)H * Cp;
+      a.qf = qf + off[i] * (long long)H * Cp;
       a.nbrf = nbrf; a.ex = hops[i].edge_x; a.seed_t = hops[i].seed_t; a.nbr_t = hops[i].nbr_t; a.nbr_id = hops[i].nbr_id;
       a.tw = m->tw; a.tb = m->tb; a.zbar = zbar + off[i] * (long long)H * Cp; a.R = rows[i];
       a.d = ly.d; a.D = ly.D; a.T = ly.T; a.k = k; a.C = C; a.scale = 1.0f / sqrtf((float)dh); a.Cs = Cp;
       a.probs = probs ? probs + off[i] * (long long)H * k : nullptr;
-      if (onfly) {
-        a.qU = ly.qf_U; a.qv = ly.qf_v; a.qx = prev + off[i] * ld_prev; a.ld_qx = ld_prev; a.qd = ly.d; a.qld = dp;
-      }
       TGMX_REQUIRE(ly.D == 0 || a.ex, "tgat_forward: hop %d has no edge features", i);
       if ((rc = attn_reduce_impl(a, H, (hipStream_t)stream))) return rc;
     }
