@@ -169,6 +169,37 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
   }
 }
 
+// the leaf features of every level of the hop tree in one launch: out rows [end[i-1], end[i]) = table[idx_i[...]]
+struct LeafGatherArgs {
+  const int32_t* idx[TGMX_TGAT_MAX_LAYERS + 1];
+  long long end[TGMX_TGAT_MAX_LAYERS + 1];  // exclusive end row of level i in the output
+  const float* table;
+  float* out;
+  long long rows;
+  int levels, dim;
+};
+
+__global__ __launch_bounds__(256) void gather_leaves_kernel(const LeafGatherArgs g) {
+  const long long total = g.end[g.levels - 1] * g.dim;
+  const long long step = (long long)gridDim.x * blockDim.x;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += step) {
+    const long long i = e / g.dim;
+    const int c = (int)(e - i * g.dim);
+    const int32_t* idx = g.idx[0];
+    long long base = 0;
+#pragma unroll
+    for (int l = 1; l <= TGMX_TGAT_MAX_LAYERS; ++l) {
+      if (l < g.levels && i >= g.end[l - 1]) {
+        idx = g.idx[l];
+        base = g.end[l - 1];
+      }
+    }
+    long long r = idx[i - base];
+    if (r < 0) r += g.rows;  // pad id -1 reads the LAST row of node_x (tgat.py:128-130)
+    g.out[e] = g.table[r * g.dim + c];
+  }
+}
+
 // Rres[r] = [x[r, :d] | 0 (pad) | cos(tb)]  -- the residual == query input (attention.py:93-95);
 // Time2Vec of the zero vector is cos(fma(0, w, b)) = cos(b).
 __global__ __launch_bounds__(256) void tgat_rres_kernel(const float* __restrict__ x, long long ldx, int d,
@@ -1079,9 +1110,21 @@ extern "C" int tgmx_tgat_forward(const tgmx_tgat_model_t* m, const float* node_x
   float* z0 = base + lay.z0;
 
   // leaves: z0[level i] = node_x[V_i], V_0 = seeds, V_i = hop (i-1) neighbor ids (pad -1 -> last row)
-  if ((rc = tgmx_gather_rows(node_x, num_nodes, d0, seed_ids, rows[0], z0, d0, stream))) return rc;
-  for (int i = 1; i <= L; ++i)
-    if ((rc = tgmx_gather_rows(node_x, num_nodes, d0, hops[i - 1].nbr_id, rows[i], z0 + off[i] * d0, d0, stream))) return rc;
+  {
+    LeafGatherArgs lg{};
+    lg.idx[0] = seed_ids;
+    lg.end[0] = off[1];
+    for (int i = 1; i <= L; ++i) {
+      TGMX_REQUIRE(rows[i] == 0 || hops[i - 1].nbr_id, "tgat_forward: hop %d has no neighbor ids", i - 1);
+      lg.idx[i] = hops[i - 1].nbr_id;
+      lg.end[i] = off[i + 1];
+    }
+    lg.table = node_x; lg.out = z0; lg.rows = num_nodes; lg.levels = L + 1; lg.dim = d0;
+    const long long total = off[L + 1] * d0;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (total > 0) hipLaunchKernelGGL(gather_leaves_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, lg);
+  }
 
   const float* prev = z0;
   long long ld_prev = d0;
