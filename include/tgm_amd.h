@@ -84,6 +84,20 @@ int tgmx_recency_lookup_csr(const int64_t* indptr, const tgmx_adj_t* adj,
                             int32_t* status, tgmx_stream_t stream,
                             tgmx_event_t ev_start, tgmx_event_t ev_stop);
 
+/* Uniform neighbor sampling, NeighborSamplerHook (tgm/hooks/neighbors/uniform.py:87-142) over
+ * DGStorageArrayBackend.get_nbrs (tgm/core/_storage/backends/array_backend.py:108-171), against the static index built
+ * with num_batches = -1.  Candidates of node n = its entries with eid < ev_hi (the hook passes the first edge whose time
+ * reaches the batch's earliest timestamp: "strictly before this batch").  At most k candidates: all of them, in event
+ * order, left aligned, padded with (-1, 0, 0.0) -- bit-exact with the reference.  More than k: a uniformly random
+ * k-permutation without replacement (virtual Fisher-Yates), a deterministic function of (rng_seed, rng_stream, node) so
+ * that every occurrence of a node in one call gets the same row, as in the reference.  The reference draws with
+ * Python's Mersenne Twister (random.sample), so parity there is distributional.  k <= 64. */
+int tgmx_uniform_lookup_csr(const int64_t* indptr, const tgmx_adj_t* adj, const float* edge_x, int32_t D,
+                            const int32_t* seeds, int64_t S, int32_t k, int64_t ev_hi, int32_t num_nodes,
+                            int32_t allow_pad, uint64_t rng_seed, uint64_t rng_stream,
+                            int32_t* out_nid, int64_t* out_ts, float* out_x, int32_t* status,
+                            tgmx_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Streaming mode: per-node rings of B records, the exact state machine of the
  * reference hook (recency.py:93-102 state, :239-321 lookup, :323-399 update).
@@ -168,7 +182,8 @@ int tgmx_ring_reset(tgmx_adj_t* ring, int32_t* write_pos, int32_t B, int32_t num
  * n is the source -- with one device radix sort and writes indptr[num_nodes + 1] and the 16-byte records.
  *   src/dst/ts   the time-sorted stream (the store DGData normalises, tgm/data/dg_data.py:350-394)
  *   batch_starts [num_batches] increasing first-edge indices of the loader's batches (tgm/data/loader.py:158-170);
- *                edges before batch_starts[0] form one leading batch
+ *                edges before batch_starts[0] form one leading batch; num_batches = -1: every edge is its own batch,
+ *                i.e. plain (eid, role) order -- the candidate order of the uniform sampler (array_backend.py:127-135)
  *   directed     index source-role entries only (recency.py:332-343)
  *   workspace    >= tgmx_csr_build_workspace_bytes(num_edges, num_nodes, directed)
  *   status       TGMX_ST_EDGE_RANGE is raised for endpoints outside [0, num_nodes)

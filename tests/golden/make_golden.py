@@ -20,6 +20,7 @@ Fixture families:
   g9_*   DGData.discretize
   g10_*  TGCN cell (gate wiring; GCNConv = placeholder restatement, third-party)
   g8_*   TGNMemory (in-tree arithmetic: messages, Last/Mean aggregation, GRU, store semantics)
+  g11_*  NeighborSamplerHook (uniform sampling; Python's `random` seeded so the sampled rows are reproducible)
 """
 from __future__ import annotations
 
@@ -435,11 +436,60 @@ def g10_case():
     print('g10_tgcn: ok')
 
 
+def g11_cases():
+    """Uniform neighbor sampler (tgm/hooks/neighbors/uniform.py + array_backend.get_nbrs).  `sparse`: every node has at
+    most k candidates (deterministic: all neighbors, event order, left aligned).  `dense`: hubs with more candidates than
+    k -- the reference calls random.sample, so the generator seeds Python's `random` once before the loader loop."""
+    import random
+
+    from tgm.hooks import NeighborSamplerHook
+
+    rng = np.random.default_rng(11)
+    cases = {
+        'sparse': dict(N=60, E=90, k=[6, 4], bs=9, directed=False, D=3, tmax=40),
+        'dense': dict(N=12, E=160, k=[4, 3], bs=16, directed=False, D=2, tmax=60),
+        'dense_directed': dict(N=10, E=120, k=[5], bs=12, directed=True, D=0, tmax=30),
+    }
+    for tag, c in cases.items():
+        N, E = c['N'], c['E']
+        src = rng.integers(0, N, E).astype(np.int32)
+        dst = rng.integers(0, N, E).astype(np.int32)
+        ts = np.sort(rng.integers(1, c['tmax'], E)).astype(np.int64)  # heavy ties
+        edge_x = rng.random((E, c['D']), dtype=np.float32) if c['D'] else None
+        neg = rng.integers(0, N, E).astype(np.int32)
+        hook = NeighborSamplerHook(num_nbrs=list(c['k']), seed_nodes_keys=['edge_src', 'edge_dst', 'neg'],
+                                   seed_times_keys=['edge_time', 'edge_time', 'neg_time'], directed=c['directed'])  # fmt: skip
+        hm = HookManager(keys=['k'])
+        hm.register('k', ReplayNegatives(torch.as_tensor(neg)))
+        hm.register('k', hook)
+        d = DGData.from_raw(torch.as_tensor(ts), torch.stack([torch.as_tensor(src), torch.as_tensor(dst)], 1),
+                            None if edge_x is None else torch.as_tensor(edge_x))  # fmt: skip
+        dg = DGraph(d)
+        arrays = dict(src=src, dst=dst, ts=ts, neg=neg)
+        if edge_x is not None:
+            arrays['edge_x'] = edge_x
+        random.seed(4242)
+        nb = 0
+        with hm.activate('k'):
+            for b, batch in enumerate(DGDataLoader(dg, batch_size=c['bs'], hook_manager=hm)):
+                nb += 1
+                for h in range(len(c['k'])):
+                    arrays[f'b{b}_h{h}_seed_nids'] = batch.seed_nids[h].numpy().copy()
+                    arrays[f'b{b}_h{h}_nbr_nids'] = batch.nbr_nids[h].numpy().copy()
+                    arrays[f'b{b}_h{h}_nbr_edge_time'] = batch.nbr_edge_time[h].numpy().copy()
+                    arrays[f'b{b}_h{h}_nbr_edge_x'] = batch.nbr_edge_x[h].numpy().copy()
+        meta = dict(name=f'g11_uniform_{tag}', num_nodes=N, num_nbrs=list(c['k']), batch_size=c['bs'], directed=c['directed'],
+                    num_batches=nb, edge_dim=c['D'], random_seed=4242)  # fmt: skip
+        arrays['meta'] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+        np.savez_compressed(os.path.join(HERE, f'g11_uniform_{tag}.npz'), **arrays)
+        print(f'g11_uniform_{tag}: {nb} batches')
+
+
 if __name__ == '__main__':
     import warnings
 
     warnings.filterwarnings('ignore')
     only = sys.argv[1:]
-    for fam, fn in [('g1', g1_cases), ('g2', g2_cases), ('g3', g3_case), ('g4', g4_case), ('g5', g5_cases), ('g6', g6_case), ('g7', g7_case), ('g8', g8_cases), ('g9', g9_case), ('g10', g10_case)]:
+    for fam, fn in [('g1', g1_cases), ('g2', g2_cases), ('g3', g3_case), ('g4', g4_case), ('g5', g5_cases), ('g6', g6_case), ('g7', g7_case), ('g8', g8_cases), ('g9', g9_case), ('g10', g10_case), ('g11', g11_cases)]:
         if not only or fam in only:
             fn()

@@ -44,32 +44,35 @@ __global__ __launch_bounds__(256) void csr_keys_kernel(const CsrKeyArgs a) {
     a.vals[e] = (unsigned)e;
     return;
   }
-  // batch of e: number of starts <= e
-  long long lo = 0, hi = a.nb;
-  while (lo < hi) {
-    const long long mid = (lo + hi) >> 1;
-    if (a.starts[mid] <= e) lo = mid + 1;
-    else hi = mid;
+  long long run_lo = e, run_hi = e + 1;  // nb < 0: every edge is its own batch -> plain (eid, role) order
+  if (a.nb >= 0) {
+    // batch of e: number of starts <= e
+    long long lo = 0, hi = a.nb;
+    while (lo < hi) {
+      const long long mid = (lo + hi) >> 1;
+      if (a.starts[mid] <= e) lo = mid + 1;
+      else hi = mid;
+    }
+    const long long b_lo = lo > 0 ? a.starts[lo - 1] : 0;
+    const long long b_hi = lo < a.nb ? a.starts[lo] : a.E;
+    // run of equal timestamps around e, clamped to the batch (ts is sorted)
+    const long long t = a.ts[e];
+    long long l = b_lo, h = e;  // first index in [b_lo, e] with ts == t
+    while (l < h) {
+      const long long mid = (l + h) >> 1;
+      if (a.ts[mid] < t) l = mid + 1;
+      else h = mid;
+    }
+    run_lo = l;
+    l = e + 1;
+    h = b_hi;  // first index in (e, b_hi] with ts > t
+    while (l < h) {
+      const long long mid = (l + h) >> 1;
+      if (a.ts[mid] <= t) l = mid + 1;
+      else h = mid;
+    }
+    run_hi = l;
   }
-  const long long b_lo = lo > 0 ? a.starts[lo - 1] : 0;
-  const long long b_hi = lo < a.nb ? a.starts[lo] : a.E;
-  // run of equal timestamps around e, clamped to the batch (ts is sorted)
-  const long long t = a.ts[e];
-  long long l = b_lo, h = e;  // first index in [b_lo, e] with ts == t
-  while (l < h) {
-    const long long mid = (l + h) >> 1;
-    if (a.ts[mid] < t) l = mid + 1;
-    else h = mid;
-  }
-  const long long run_lo = l;
-  l = e + 1;
-  h = b_hi;  // first index in (e, b_hi] with ts > t
-  while (l < h) {
-    const long long mid = (l + h) >> 1;
-    if (a.ts[mid] <= t) l = mid + 1;
-    else h = mid;
-  }
-  const long long run_hi = l;
   a.keys[e] = ((unsigned long long)(unsigned)s << 32) | (unsigned long long)(run_lo + e);
   a.vals[e] = (unsigned)e;
   a.keys[a.E + e] = ((unsigned long long)(unsigned)d << 32) | (unsigned long long)(run_hi + e);
@@ -152,7 +155,7 @@ extern "C" int tgmx_csr_build(const int32_t* src, const int32_t* dst, const int6
                               const int64_t* batch_starts, int64_t num_batches, int32_t directed, int64_t* indptr,
                               tgmx_adj_t* adj, void* workspace, size_t workspace_bytes, int32_t* status,
                               tgmx_stream_t stream) {
-  TGMX_REQUIRE(num_edges >= 0 && num_nodes > 0 && num_batches >= 0, "csr_build: bad sizes E=%lld N=%d nb=%lld", (long long)num_edges,
+  TGMX_REQUIRE(num_edges >= 0 && num_nodes > 0 && num_batches >= -1, "csr_build: bad sizes E=%lld N=%d nb=%lld", (long long)num_edges,
                num_nodes, (long long)num_batches);
   TGMX_REQUIRE(indptr && status, "csr_build: null pointer");
   TGMX_REQUIRE(2 * num_edges < 2147483647LL, "csr_build: more than 2^30 edges need 64-bit positions");
@@ -163,7 +166,7 @@ extern "C" int tgmx_csr_build(const int32_t* src, const int32_t* dst, const int6
     return TGMX_OK;
   }
   TGMX_REQUIRE(src && dst && ts && adj && workspace, "csr_build: null pointer");
-  TGMX_REQUIRE(directed || num_batches == 0 || batch_starts, "csr_build: null batch_starts");
+  TGMX_REQUIRE(directed || num_batches <= 0 || batch_starts, "csr_build: null batch_starts");
   TGMX_REQUIRE(((uintptr_t)adj & 15) == 0, "csr_build: adj must be 16-byte aligned");
   CsrWorkspace w;
   const int rc = csr_layout(num_edges, num_nodes, directed, w);

@@ -969,6 +969,125 @@ __global__ __launch_bounds__(256) void ring_reset_kernel(Rec* ring, int32_t* wri
 
 using namespace tgmx;
 
+namespace tgmx {
+
+struct UniformArgs {
+  const int64_t* indptr;
+  const Rec* recs;
+  const float* edge_x;
+  const int32_t* seeds;
+  int32_t* out_nid;
+  int64_t* out_ts;
+  float* out_x;
+  int32_t* status;
+  long long S, ev_hi;
+  unsigned long long rng_seed, rng_stream;
+  int D, k, N, allow_pad;
+};
+
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+// One wave per seed.  c = #candidates (prefix of the node's (eid, role)-ordered entries below ev_hi).
+// c <= k: lane j takes candidate j.  c > k: k steps of a virtual Fisher-Yates shuffle of [0, c) -- the array is the
+// identity except for <= k overrides, kept one per lane (position, value) and searched by ballot -- so lane i ends up
+// with the i-th element of a uniformly random k-permutation.  All lanes run the same scalar recurrence.
+__global__ __launch_bounds__(256) void uniform_lookup_kernel(const UniformArgs a) {
+  const int lane = lane_id();
+  const long long waves_total = (long long)gridDim.x * (blockDim.x >> 6);
+  const int k = a.k;
+  for (long long s = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); s < a.S; s += waves_total) {
+    const int n = a.seeds[s];
+    const bool live = n >= 0 && n < a.N;
+    if (lane == 0 && (n >= a.N || n < -1 || (n == -1 && !a.allow_pad))) atomicOr(a.status, TGMX_ST_SEED_RANGE);
+    long long ra = 0, c = 0;
+    if (live) {
+      ra = a.indptr[n];
+      c = wave_prefix_count(a.recs, ra, a.indptr[n + 1], a.ev_hi, lane);
+    }
+    long long pick = lane;  // candidate index of output slot `lane`
+    if (c > k) {
+      const unsigned long long base = splitmix64(a.rng_seed ^ splitmix64(a.rng_stream ^ ((unsigned long long)(unsigned)n << 32)));
+      long long ov_pos = -1, ov_val = 0;  // this lane's override of the virtual array
+      int n_ov = 0;
+      for (int i = 0; i < k; ++i) {
+        const unsigned long long r = splitmix64(base + (unsigned long long)i);
+        const long long j = i + (long long)__umul64hi(r, (unsigned long long)(c - i));  // uniform in [i, c)
+        // a[j] and a[i] before the swap
+        const unsigned long long mj = __ballot(ov_pos == j);
+        const long long vj = mj ? __shfl(ov_val, __ffsll((long long)mj) - 1) : j;
+        const unsigned long long mi = __ballot(ov_pos == i);
+        const long long vi = mi ? __shfl(ov_val, __ffsll((long long)mi) - 1) : (long long)i;
+        if (lane == i) pick = vj;  // output slot i
+        if (j != i) {              // a[j] = old a[i] (a[i] itself is never read again)
+          if (mj) {
+            if (ov_pos == j) ov_val = vi;
+          } else {
+            if (lane == n_ov) {
+              ov_pos = j;
+              ov_val = vi;
+            }
+            ++n_ov;
+          }
+        }
+      }
+    }
+    const long long m = c < k ? c : k;  // valid slots
+    // ---- ids / times: lane j < k owns slot j ----
+    int eid = -1;
+    if (lane < k) {
+      int nid = -1;
+      long long ts = 0;
+      if (lane < m) {
+        const Rec r = a.recs[ra + pick];
+        nid = r.nbr;
+        ts = r.ts;
+        eid = r.eid;
+      }
+      a.out_nid[s * k + lane] = nid;
+      a.out_ts[s * k + lane] = ts;
+    }
+    // ---- features: the wave copies slot after slot (rows of edge_x addressed by eid) ----
+    if (a.D > 0) {
+      float* __restrict__ o = a.out_x + s * (long long)k * a.D;
+      for (int j = 0; j < k; ++j) {
+        const int e = __shfl(eid, j);
+        if (e >= 0) {
+          const float* __restrict__ x = a.edge_x + (long long)e * a.D;
+          for (int col = lane; col < a.D; col += kWave) o[(long long)j * a.D + col] = x[col];
+        } else {
+          for (int col = lane; col < a.D; col += kWave) o[(long long)j * a.D + col] = 0.f;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace tgmx
+
+extern "C" int tgmx_uniform_lookup_csr(const int64_t* indptr, const tgmx_adj_t* adj, const float* edge_x, int32_t D,
+                                       const int32_t* seeds, int64_t S, int32_t k, int64_t ev_hi, int32_t num_nodes,
+                                       int32_t allow_pad, uint64_t rng_seed, uint64_t rng_stream, int32_t* out_nid,
+                                       int64_t* out_ts, float* out_x, int32_t* status, tgmx_stream_t stream) {
+  TGMX_REQUIRE(S >= 0 && k > 0 && k <= 64 && D >= 0 && num_nodes > 0 && ev_hi >= 0, "uniform_lookup: bad sizes S=%lld k=%d D=%d N=%d",
+               (long long)S, k, D, num_nodes);
+  if (S == 0) return TGMX_OK;
+  TGMX_REQUIRE(indptr && adj && seeds && out_nid && out_ts && status, "uniform_lookup: null pointer");
+  TGMX_REQUIRE(D == 0 || (edge_x && out_x), "uniform_lookup: D=%d but edge_x/out_x is null", D);
+  TGMX_REQUIRE(((uintptr_t)adj & 15) == 0, "uniform_lookup: adj must be 16-byte aligned");
+  UniformArgs a{indptr, reinterpret_cast<const Rec*>(adj), edge_x, seeds, out_nid, out_ts, out_x, status, S, ev_hi,
+                (unsigned long long)rng_seed, (unsigned long long)rng_stream, D, k, num_nodes, allow_pad};
+  long long blocks = (S + 3) / 4;
+  if (blocks > (1 << 20)) blocks = 1 << 20;
+  hipLaunchKernelGGL(uniform_lookup_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  TGMX_CHECK_LAUNCH("uniform_lookup");
+  return TGMX_OK;
+}
+
 extern "C" int tgmx_recency_lookup_csr(const int64_t* indptr, const tgmx_adj_t* adj, const float* edge_x, int32_t D,
                                        const int32_t* seeds, const int64_t* qtimes, int64_t S, int32_t k, int32_t B,
                                        int64_t ev_lo, int64_t ev_hi, int32_t num_nodes, int32_t allow_pad,

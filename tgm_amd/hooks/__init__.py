@@ -3,6 +3,7 @@ from .dedup import DeduplicationHook
 from .hook_manager import HookManager
 from .negatives import RandomNegativeEdgeSamplerHook
 from .recency import RecencyNeighborHook
+from .uniform import NeighborSamplerHook
 from .registry import hook, list_hooks
 
 __all__ = [
@@ -10,6 +11,7 @@ __all__ = [
     'DGHook',
     'DeduplicationHook',
     'HookManager',
+    'NeighborSamplerHook',
     'RandomNegativeEdgeSamplerHook',
     'RecencyNeighborHook',
     'SeedableHook',

@@ -56,18 +56,24 @@ def build_csr(
     batch_size: Optional[int] = None,
     first_edge: int = 0,
     directed: bool = False,
+    order: str = 'batch',
 ) -> TemporalCSR:
     """Index the stream ``(src, dst, ts)`` (device tensors, time-sorted).
 
     Batch boundaries are given either explicitly (``batch_starts``: increasing
     edge indices, the first batch starts at ``batch_starts[0]``) or as a fixed
     ``batch_size`` counted from ``first_edge``.  Edges before the first boundary
-    form one leading batch.
+    form one leading batch.  ``order='event'`` ignores the batch schedule and orders a node's entries
+    by ``(eid, role)`` -- the candidate order of the uniform sampler.
     """
     _native.require_device(src, 'edge stream')
     dev = src.device
     E = int(src.numel())
-    if batch_starts is None:
+    if order not in ('batch', 'event'):
+        raise ValueError(f"order must be 'batch' or 'event', got {order!r}")
+    if order == 'event':
+        starts = torch.empty(0, dtype=torch.int64, device=dev)
+    elif batch_starts is None:
         if batch_size is None or batch_size <= 0:
             raise ValueError('build_csr needs batch_starts or a positive batch_size')
         starts = torch.arange(first_edge, max(E, first_edge + 1), batch_size, device=dev, dtype=torch.int64)
@@ -87,7 +93,8 @@ def build_csr(
     with torch.cuda.device(dev):
         _native.check(
             lib.tgmx_csr_build(
-                src.data_ptr(), dst.data_ptr(), ts.data_ptr(), E, num_nodes, starts.data_ptr(), int(starts.numel()),
+                src.data_ptr(), dst.data_ptr(), ts.data_ptr(), E, num_nodes, starts.data_ptr() if starts.numel() else None,
+                -1 if order == 'event' else int(starts.numel()),
                 1 if directed else 0, indptr.data_ptr(), adj.data_ptr(), workspace.data_ptr(), ws_bytes, status.data_ptr(),
                 _native.stream_ptr(dev.index),
             ),
