@@ -122,7 +122,8 @@ int tgmx_ring_lookup(const tgmx_adj_t* ring, const int32_t* write_pos,
  * it); key_wrap32 = 0 uses int64 (the intended per-node chronological order).
  * edge_x may be NULL (rows of zeros, recency.py:325-328).  eid0 = store index of
  * the batch's first edge or -1 (recorded in the slot, informational).
- * scratch: >= 12 * m + 16 int32, m = (directed ? n : 2n).  */
+ * scratch: 256-byte aligned, >= tgmx_ring_update_scratch_bytes(n, directed) bytes.  */
+size_t tgmx_ring_update_scratch_bytes(int64_t n, int32_t directed);
 int tgmx_ring_update(tgmx_adj_t* ring, int32_t* write_pos, float* ring_x, int32_t D, int32_t B,
                      int32_t num_nodes, const int32_t* src, const int32_t* dst, const int64_t* ts,
                      const float* edge_x, int64_t n, int64_t eid0, int32_t directed, int32_t key_wrap32,
@@ -164,7 +165,7 @@ typedef struct tgmx_recency_step {
   const float* edge_x;         /* [n, D] or NULL */
   int64_t n, eid0;
   int32_t directed, key_wrap32;
-  int32_t* scratch;            /* >= 12 * m + 16 int32 */
+  int32_t* scratch;            /* 256-byte aligned, >= tgmx_ring_update_scratch_bytes(n, directed) bytes */
   int32_t* status;
   int32_t timed_hop;           /* -1: none */
   tgmx_event_t ev_start, ev_stop;

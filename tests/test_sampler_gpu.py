@@ -159,10 +159,11 @@ def _random_stream(seed, N, E, D, tmax):
         (200, 4000, 6, 400, [3, 8, 2], 50, False, 'int32'),  # k < B on some hops, heavy ties
         (100, 3000, 0, 300, [4, 4], 37, False, 'int32'),  # no edge features
         (50, 3000, 5, 200, [20], 1000, False, 'int32'),  # runs longer than B inside one batch (mid-size single-workgroup update, m=2000)
-        (60, 9000, 5, 300, [20], 2500, False, 'int32'),  # m=5000 entries: multi-kernel update path
+        (60, 9000, 5, 300, [20], 2500, False, 'int32'),  # m=5000 entries: radix-sort update path
         (4000, 9000, 3, 2_000_000, [6, 2], 1500, False, 'int32'),  # mid-size update (m=3000) with wrapping keys
         (9000, 12800, 4, 2_600_000, [20, 3], 1600, False, 'int32'),  # 8-rank global wiki batch: m=3200, wrapping keys
-        (4000, 15000, 3, 2_000_000, [6, 2], 2500, False, 'int32'),  # m=5000: multi-kernel path with wrapping keys
+        (4000, 15000, 3, 2_000_000, [6, 2], 2500, False, 'int32'),  # m=5000: radix-sort path with wrapping keys
+        (30, 24000, 2, 500, [8], 6000, False, 'int32'),  # m=12000: radix-sort path, hub runs far longer than B, heavy ties
         (400, 3000, 7, 2000, [6], 60, False, 'int32'),  # D not a multiple of 4 (scalar gather path)
         (400, 3000, 6, 2000, [6], 60, False, 'int32'),  # D % 2 == 0 (float2 path)
     ],

@@ -132,6 +132,7 @@ class RecencyStep(ctypes.Structure):
 
 SIGNATURES['tgmx_uniform_lookup_csr'] = (c_int32, [_P, _P, _P, c_int32, _P, c_int64, c_int32, c_int64, c_int32, c_int32, ctypes.c_uint64, ctypes.c_uint64,
                                                    _P, _P, _P, _P, _P])
+SIGNATURES['tgmx_ring_update_scratch_bytes'] = (c_size_t, [c_int64, c_int32])
 SIGNATURES['tgmx_csr_build_workspace_bytes'] = (c_size_t, [c_int64, c_int32, c_int32])
 SIGNATURES['tgmx_csr_build'] = (c_int32, [_P, _P, _P, c_int64, c_int32, _P, c_int64, c_int32, _P, _P, _P, c_size_t, _P, _P])
 SIGNATURES['tgmx_recency_step'] = (c_int32, [ctypes.POINTER(RecencyStep), _P])

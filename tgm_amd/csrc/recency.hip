@@ -13,6 +13,11 @@
 //     The [S, B, D] intermediate the reference materialises
 //     (tgm/hooks/neighbors/recency.py:258) never exists.
 // Rows are copied, never recomputed, so features are bit-exact by construction.
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
 #include "common.h"
 
 namespace tgmx {
@@ -318,13 +323,19 @@ struct UpdateArgs {
   int32_t* target;       // scratch [m]: ring row it is placed at (-1 = dropped)
   int32_t* winner;       // scratch [m]: ring row it finally owns (-1 = none)
   Rec* sorted_rec;       // scratch [m] (chunked path): the record of the entry at sorted position p
-  // large-batch path only:
-  long long* span;       // scratch: max(ts) + 1
-  long long* key;        // scratch [m]: sort key of entry j
-  int32_t* node;         // scratch [m]: node of entry j (-1 invalid)
-  int32_t* rank;         // scratch [m]: sorted position of entry j
-  int32_t* kept;         // scratch [m]
-  int32_t* flags;        // scratch [m]
+  // chunked path (1024 < m <= 4096):
+  long long* key;        // scratch: chunk-sorted keys
+  int32_t* node;         // scratch: chunk-sorted entry indices
+  // large-batch path (m > 4096):
+  long long* span;             // scratch: max(ts) + 1
+  unsigned long long* keys_in; // scratch [m]: radix keys of the entries
+  unsigned int* vals_in;       // scratch [m]: entry indices
+  int32_t* hash_key;           // scratch [2^hash_bits]: ring rows placed on (-1 empty)
+  int32_t* hash_maxp;          // scratch [2^hash_bits]: last sorted position placed there
+  int32_t* run_flag;           // scratch [m]
+  int32_t* run_start;          // scratch [m]: first sorted position of p's run
+  int32_t* run_len;            // scratch [m]: run length, at the run's first position
+  int hash_bits;
   int32_t* status;
   long long n, m, eid0;
   int B, N, D, key_wrap32;
@@ -348,10 +359,10 @@ __device__ __forceinline__ void update_entry(const UpdateArgs& a, long long j, i
   t = a.ts[i];
 }
 
-// ---- large batches (m > kBlockMaxM): exact all-pairs passes, tiled in 2-D over (entry, other)
-// so that the O(m^2) compares spread over the whole chip; partial counts meet in global atomics.
-constexpr int kTile = 256;  // "other" entries staged in LDS per block: (m/256)^2 blocks fill the chip
-
+// ---- large batches (m > kBlockMaxM, e.g. the replicated update of an 8-rank global batch of 8 x 4096 edges): O(m)
+// passes around one rocPRIM radix sort of the (sign-flipped) 64-bit keys -- LSD radix sort is stable, which is the
+// reference's `argsort(stable=True)`.  Slot collisions are resolved through an open-addressing hash in the scratch
+// (atomicMax of the sorted position: the last one wins); write_pos moves by one atomicAdd per run.
 __global__ __launch_bounds__(256) void ring_update_span_kernel(const UpdateArgs a) {
   __shared__ long long red[256];
   long long mx = -0x7fffffffffffffffLL;
@@ -374,151 +385,85 @@ __global__ __launch_bounds__(256) void ring_update_keys_kernel(const UpdateArgs 
   int node, nbr;
   long long t, i;
   update_entry(a, j, node, nbr, t, i);
-  const bool valid = node >= 0 && node < a.N && nbr >= 0 && nbr < a.N;
-  if (!valid) atomicOr(a.status, TGMX_ST_EDGE_RANGE);
-  a.key[j] = update_key(node, t, *a.span, a.key_wrap32);
-  a.node[j] = valid ? node : -1;
-  a.rank[j] = 0;
-}
-
-// rank[j] += #{x in tile : (key_x, x) < (key_j, j)}
-__global__ __launch_bounds__(256) void ring_update_rank_kernel(const UpdateArgs a) {
-  __shared__ long long t_key[kTile];
-  const long long x0 = (long long)blockIdx.y * kTile;
-  const int lim = (a.m - x0) < kTile ? (int)(a.m - x0) : kTile;
-  for (int x = threadIdx.x; x < kTile; x += 256) t_key[x] = x < lim ? a.key[x0 + x] : 0x7fffffffffffffffLL;
-  __syncthreads();
-  const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= a.m) return;
-  const long long kj = a.key[j];
-  int cnt = 0;
-  for (int x = 0; x < kTile; x += 8) {
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const long long kx = t_key[x + u];
-      cnt += (kx < kj) || (kx == kj && x0 + x + u < j);
-    }
-  }
-  if (cnt) atomicAdd(&a.rank[j], cnt);
+  a.keys_in[j] = (unsigned long long)update_key(node, t, *a.span, a.key_wrap32) ^ 0x8000000000000000ull;  // signed -> radix order
+  a.vals_in[j] = (unsigned)j;
 }
 
 __global__ __launch_bounds__(256) void ring_update_scatter_kernel(const UpdateArgs a) {
-  const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= a.m) return;
-  const int r = a.rank[j];
-  a.sorted_j[r] = (int)j;
-  a.sorted_node[r] = a.node[j];
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= a.m) return;
+  int node, nbr;
+  long long t, i;
+  update_entry(a, a.sorted_j[p], node, nbr, t, i);
+  const bool valid = node >= 0 && node < a.N && nbr >= 0 && nbr < a.N;
+  if (!valid) atomicOr(a.status, TGMX_ST_EDGE_RANGE);
+  a.sorted_node[p] = valid ? node : -1;
+}
+
+__device__ __forceinline__ int global_hash_slot(int* keys, int hash_bits, int tgt, bool insert) {
+  unsigned h = ((unsigned)tgt * 2654435761u) >> (32 - hash_bits);
+  const unsigned mask = (1u << hash_bits) - 1u;
+  for (;;) {
+    const int old = insert ? atomicCAS(&keys[h], -1, tgt) : keys[h];
+    if (old == tgt || (insert && old == -1)) return (int)h;
+    h = (h + 1) & mask;
+  }
+}
+
+// run analysis of the sorted order: run_start by an inclusive max-scan (rocPRIM) of "p if p opens a run else 0",
+// run length scattered to the run's first position by the run's last one -- O(m) however long the hub runs are
+__global__ __launch_bounds__(256) void ring_update_flags_kernel(const UpdateArgs a) {
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= a.m) return;
+  a.run_flag[p] = (p > 0 && a.sorted_node[p - 1] == a.sorted_node[p]) ? 0 : (int)p;
+}
+
+__global__ __launch_bounds__(256) void ring_update_ends_kernel(const UpdateArgs a) {
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= a.m) return;
+  if (p == a.m - 1 || a.sorted_node[p + 1] != a.sorted_node[p]) a.run_len[a.run_start[p]] = (int)p - a.run_start[p] + 1;
 }
 
 __global__ __launch_bounds__(256) void ring_update_place_kernel(const UpdateArgs a) {
-  // Runs of equal node ids are found through a bitmask of run starts over an LDS window
-  // [p0 - 256, p0 + 512) of the sorted node ids (O(1) words per lookup even for hub nodes);
-  // only runs that leave the window continue with a scan through global memory.
-  __shared__ int win[768];
-  __shared__ unsigned long long starts[12];
-  const long long p0 = (long long)blockIdx.x * blockDim.x;
-  const long long w0 = p0 - 256;
-  for (int x = threadIdx.x; x < 768; x += 256) {
-    const long long q = w0 + x;
-    win[x] = (q >= 0 && q < a.m) ? a.sorted_node[q] : -7;
-  }
-  __syncthreads();
-  for (int x = threadIdx.x; x < 768; x += 256) {
-    const bool st = x > 0 && win[x] != win[x - 1];
-    const unsigned long long m = __ballot(st);
-    if ((threadIdx.x & 63) == 0) starts[x >> 6] = m;
-  }
-  __syncthreads();
-  const long long p = p0 + threadIdx.x;
-  if (p >= a.m) return;
-  const int x = 256 + threadIdx.x;
-  const int node = win[x];
-  int tgt = -1;
-  if (node >= 0) {
-    // run start: nearest start bit at or left of x
-    long long lo = -1;
-    {
-      int w = x >> 6;
-      unsigned long long m = starts[w] & (~0ull >> (63 - (x & 63)));
-      while (!m && w > 0) m = starts[--w];
-      if (m) lo = w0 + w * 64 + 63 - __clzll((long long)m);
-    }
-    if (lo < 0) {  // run began before the window
-      lo = w0 > 0 ? w0 : 0;
-      while (lo > 0 && a.sorted_node[lo - 1] == node) --lo;
-    }
-    // run end: nearest start bit right of x
-    long long hi = -1;
-    {
-      int w = x >> 6;
-      unsigned long long m = (x & 63) == 63 ? 0ull : starts[w] & (~0ull << ((x & 63) + 1));
-      while (!m && w < 11) m = starts[++w];
-      if (m) hi = w0 + w * 64 + __ffsll((long long)m) - 1;
-    }
-    if (hi < 0) {  // run continues past the window
-      hi = w0 + 768;
-      while (hi < a.m && a.sorted_node[hi] == node) ++hi;
-    }
-    if (hi > a.m) hi = a.m;
-    const int cnt = (int)(hi - lo), pos = (int)(p - lo);
-    const int drop = cnt > a.B ? cnt - a.B : 0;
-    if (pos >= drop) tgt = node * a.B + (a.write_pos[node] % a.B + pos - drop) % a.B;
-  }
-  a.target[p] = tgt;
-  a.kept[p] = 0;
-  a.flags[p] = 0;
-}
-
-// per sorted position p (placed entries only), against one tile of the others:
-//   kept[p]  += #{x : same node, placed}       flags[p] |= 1 if a LATER placed entry has the same node
-//                                              flags[p] |= 2 if a LATER entry is placed on the same ring slot
-__global__ __launch_bounds__(256) void ring_update_resolve_kernel(const UpdateArgs a) {
-  __shared__ int2 t_pl[kTile];
-  const long long x0 = (long long)blockIdx.y * kTile;
-  const int lim = (a.m - x0) < kTile ? (int)(a.m - x0) : kTile;
-  for (int x = threadIdx.x; x < kTile; x += 256) t_pl[x] = x < lim ? make_int2(a.sorted_node[x0 + x], a.target[x0 + x]) : make_int2(-3, -2);
-  __syncthreads();
   const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= a.m) return;
-  const int tgt = a.target[p];
-  if (tgt < 0) return;
   const int node = a.sorted_node[p];
-  int kept = 0, fl = 0;
-  for (int x = 0; x < kTile; x += 8) {
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int2 o = t_pl[x + u];
-      const bool same_kept = o.x == node && o.y >= 0;
-      const bool later = x0 + x + u > p;
-      kept += same_kept;
-      fl |= (later && same_kept) ? 1 : 0;
-      fl |= (later && o.y == tgt) ? 2 : 0;
+  int tgt = -1, kept_at_end = 0;
+  if (node >= 0) {
+    const int lo = a.run_start[p], cnt = a.run_len[lo], pos = (int)p - lo;
+    const int drop = cnt > a.B ? cnt - a.B : 0;
+    if (pos >= drop) {
+      tgt = node * a.B + (a.write_pos[node] % a.B + pos - drop) % a.B;
+      atomicMax(&a.hash_maxp[global_hash_slot(a.hash_key, a.hash_bits, tgt, true)], (int)p);
     }
+    if (pos == cnt - 1) kept_at_end = cnt - drop;
   }
-  if (kept) atomicAdd(&a.kept[p], kept);
-  if (fl) atomicOr(&a.flags[p], fl);
+  a.target[p] = tgt;
+  a.winner[p] = kept_at_end;  // #kept of the run, parked at the run's last position until the write pass
 }
 
 __global__ __launch_bounds__(256) void ring_update_write_kernel(const UpdateArgs a) {
   const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= a.m) return;
   const int tgt = a.target[p];
+  const int kept = a.winner[p];
   int win = -1;
-  if (tgt >= 0) {
-    const int fl = a.flags[p];
-    const int node = a.sorted_node[p];
-    if (!(fl & 2)) {
-      int nd, nbr;
-      long long t, i;
-      update_entry(a, a.sorted_j[p], nd, nbr, t, i);
-      Rec r;
-      r.nbr = nbr;
-      r.eid = a.eid0 >= 0 ? (int)(a.eid0 + i) : -1;
-      r.ts = t;
-      a.ring[tgt] = r;
-      win = tgt;
-    }
-    if (!(fl & 1)) a.write_pos[node] = (a.write_pos[node] % a.B + a.kept[p]) % a.B;  // one committer per node
+  if (tgt >= 0 && a.hash_maxp[global_hash_slot(a.hash_key, a.hash_bits, tgt, false)] == (int)p) {
+    int nd, nbr;
+    long long t, i;
+    update_entry(a, a.sorted_j[p], nd, nbr, t, i);
+    Rec r;
+    r.nbr = nbr;
+    r.eid = a.eid0 >= 0 ? (int)(a.eid0 + i) : -1;
+    r.ts = t;
+    a.ring[tgt] = r;
+    win = tgt;
+  }
+  if (kept > 0) {  // every write_pos read happened in the placement launch
+    int32_t* wp = &a.write_pos[a.sorted_node[p]];
+    const int old = atomicAdd(wp, kept);
+    constexpr int kFold = 1 << 30;
+    if (old < kFold && old + kept >= kFold) atomicSub(wp, kFold / a.B * a.B);
   }
   a.winner[p] = win;
 }
@@ -1135,6 +1080,7 @@ static int fill_update_args(UpdateArgs& a, tgmx_adj_t* ring, int32_t* write_pos,
   TGMX_REQUIRE(eid0 < 0 || eid0 + n <= 2147483647LL, "ring_update: edge ids overflow int32");
   TGMX_REQUIRE((long long)B * num_nodes < 2147483647LL, "ring_update: num_nodes*B overflows int32");
   TGMX_REQUIRE(2 * n < 2147483647LL, "ring_update: batch too large");
+  TGMX_REQUIRE(((uintptr_t)scratch & 255) == 0, "ring_update: scratch must be 256-byte aligned");
   a = UpdateArgs{};
   a.ring = reinterpret_cast<Rec*>(ring); a.write_pos = write_pos; a.ring_x = ring_x; a.edge_x = edge_x;
   a.src = src; a.dst = dst; a.ts = ts; a.status = status;
@@ -1143,24 +1089,94 @@ static int fill_update_args(UpdateArgs& a, tgmx_adj_t* ring, int32_t* write_pos,
   return TGMX_OK;
 }
 
-static void launch_update_large(UpdateArgs& a, int32_t* scratch, hipStream_t st) {
+// scratch layout of the large-batch path (byte offsets from a 256-byte aligned base)
+struct LargeScratch {
+  size_t span, keys_in, keys_out, vals_in, hash_key, hash_maxp, run_flag, run_start, run_len, temp, temp_bytes, total;
+  int hash_bits;
+};
+
+static int large_scratch_layout(long long m, LargeScratch& w) {
+  auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  size_t off = up((size_t)4 * m * sizeof(int32_t));  // sorted_j, sorted_node, target, winner
+  w.span = off; off = up(off + 16);
+  w.keys_in = off; off = up(off + (size_t)m * 8);
+  w.keys_out = off; off = up(off + (size_t)m * 8);
+  w.vals_in = off; off = up(off + (size_t)m * 4);
+  w.hash_bits = 8;
+  while ((1ll << w.hash_bits) < 2 * m) ++w.hash_bits;  // load factor <= 0.5
+  w.hash_key = off; off = up(off + ((size_t)4 << w.hash_bits));
+  w.hash_maxp = off; off = up(off + ((size_t)4 << w.hash_bits));
+  w.run_flag = off; off = up(off + (size_t)m * 4);
+  w.run_start = off; off = up(off + (size_t)m * 4);
+  w.run_len = off; off = up(off + (size_t)m * 4);
+  size_t tb = 0;
+  const hipError_t err = rocprim::radix_sort_pairs(nullptr, tb, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
+                                                   (const unsigned int*)nullptr, (unsigned int*)nullptr, (size_t)m, 0u, 64u);
+  if (err != hipSuccess) {
+    set_error("ring_update: radix sort workspace query failed: %s", hipGetErrorString(err));
+    return TGMX_E_LAUNCH;
+  }
+  size_t sb = 0;
+  const hipError_t err2 = rocprim::inclusive_scan(nullptr, sb, (const int*)nullptr, (int*)nullptr, (size_t)m, rocprim::maximum<int>());
+  if (err2 != hipSuccess) {
+    set_error("ring_update: scan workspace query failed: %s", hipGetErrorString(err2));
+    return TGMX_E_LAUNCH;
+  }
+  w.temp = off;
+  w.temp_bytes = tb > sb ? tb : sb;
+  w.total = up(off + w.temp_bytes) + 256;
+  return TGMX_OK;
+}
+
+static int launch_update_large(UpdateArgs& a, int32_t* scratch, hipStream_t st) {
+  LargeScratch w;
+  const int rc = large_scratch_layout(a.m, w);
+  if (rc) return rc;
+  char* base = reinterpret_cast<char*>(scratch);  // the caller's buffer is 256-byte aligned (checked by the entry points)
+  a.span = reinterpret_cast<long long*>(base + w.span);
+  a.keys_in = reinterpret_cast<unsigned long long*>(base + w.keys_in);
+  auto* keys_out = reinterpret_cast<unsigned long long*>(base + w.keys_out);
+  a.vals_in = reinterpret_cast<unsigned int*>(base + w.vals_in);
+  a.hash_key = reinterpret_cast<int32_t*>(base + w.hash_key);
+  a.hash_maxp = reinterpret_cast<int32_t*>(base + w.hash_maxp);
+  a.hash_bits = w.hash_bits;
+  a.run_flag = reinterpret_cast<int32_t*>(base + w.run_flag);
+  a.run_start = reinterpret_cast<int32_t*>(base + w.run_start);
+  a.run_len = reinterpret_cast<int32_t*>(base + w.run_len);
   const unsigned blocks = (unsigned)((a.m + 255) / 256);
-  // 16-byte aligned int64 scratch first, then the int32 arrays
-  long long* s64 = reinterpret_cast<long long*>(scratch + 4 * a.m + ((4 * a.m) & 1));
-  s64 = reinterpret_cast<long long*>(((uintptr_t)s64 + 15) & ~(uintptr_t)15);
-  a.span = s64;
-  a.key = s64 + 2;
-  int32_t* s32 = reinterpret_cast<int32_t*>(a.key + a.m);
-  a.node = s32; a.rank = s32 + a.m; a.kept = s32 + 2 * a.m; a.flags = s32 + 3 * a.m;
-  const dim3 grid2((unsigned)blocks, (unsigned)((a.m + kTile - 1) / kTile));
+  (void)hipMemsetAsync(a.hash_key, 0xFF, (size_t)8 << w.hash_bits, st);  // keys and max positions (adjacent): all -1
   hipLaunchKernelGGL(ring_update_span_kernel, dim3(1), dim3(256), 0, st, a);
   hipLaunchKernelGGL(ring_update_keys_kernel, dim3(blocks), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(ring_update_rank_kernel, grid2, dim3(256), 0, st, a);
+  size_t tb = w.temp_bytes;
+  const hipError_t err = rocprim::radix_sort_pairs(base + w.temp, tb, (const unsigned long long*)a.keys_in, keys_out,
+                                                   (const unsigned int*)a.vals_in, reinterpret_cast<unsigned int*>(a.sorted_j),
+                                                   (size_t)a.m, 0u, 64u, st);
+  if (err != hipSuccess) {
+    set_error("ring_update: radix sort failed: %s", hipGetErrorString(err));
+    return TGMX_E_LAUNCH;
+  }
   hipLaunchKernelGGL(ring_update_scatter_kernel, dim3(blocks), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(ring_update_flags_kernel, dim3(blocks), dim3(256), 0, st, a);
+  tb = w.temp_bytes;
+  const hipError_t err2 = rocprim::inclusive_scan(base + w.temp, tb, (const int*)a.run_flag, a.run_start, (size_t)a.m, rocprim::maximum<int>(), st);
+  if (err2 != hipSuccess) {
+    set_error("ring_update: scan failed: %s", hipGetErrorString(err2));
+    return TGMX_E_LAUNCH;
+  }
+  hipLaunchKernelGGL(ring_update_ends_kernel, dim3(blocks), dim3(256), 0, st, a);
   hipLaunchKernelGGL(ring_update_place_kernel, dim3(blocks), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(ring_update_resolve_kernel, grid2, dim3(256), 0, st, a);
   hipLaunchKernelGGL(ring_update_write_kernel, dim3(blocks), dim3(256), 0, st, a);
   if (a.D > 0) hipLaunchKernelGGL(ring_update_feat_kernel, dim3((unsigned)((a.m + 3) / 4)), dim3(256), 0, st, a);
+  return TGMX_OK;
+}
+
+extern "C" size_t tgmx_ring_update_scratch_bytes(int64_t n, int32_t directed) {
+  const long long m = directed ? n : 2 * n;
+  if (m <= 0) return 256;
+  if (m <= kBlockMaxM) return ((size_t)12 * m + 16) * sizeof(int32_t) + 256;
+  LargeScratch w;
+  if (large_scratch_layout(m, w)) return 0;
+  return w.total;
 }
 
 extern "C" int tgmx_ring_update(tgmx_adj_t* ring, int32_t* write_pos, float* ring_x, int32_t D, int32_t B,
@@ -1175,7 +1191,7 @@ extern "C" int tgmx_ring_update(tgmx_adj_t* ring, int32_t* write_pos, float* rin
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   if (a.m <= kBlockMaxM) launch_update_block(a, scratch, st);
-  else launch_update_large(a, scratch, st);
+  else if (const int rl = launch_update_large(a, scratch, st)) return rl;
   TGMX_CHECK_LAUNCH("ring_update");
   return TGMX_OK;
 }
@@ -1238,7 +1254,7 @@ extern "C" int tgmx_recency_step(const tgmx_recency_step_t* s, tgmx_stream_t str
                                     s->edge_x, s->n, s->eid0, s->directed, s->key_wrap32, s->scratch, s->status);
     if (rc) return rc;
     if (u.m <= kBlockMaxM) launch_update_block(u, s->scratch, st);
-    else launch_update_large(u, s->scratch, st);
+    else if (const int rl = launch_update_large(u, s->scratch, st)) return rl;
   }
   TGMX_CHECK_LAUNCH("recency_step");
   return TGMX_OK;

@@ -135,6 +135,7 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
         self._ring_x: Optional[Tensor] = None  # [N*B, D] float32
         self._write_pos: Optional[Tensor] = None  # [N] int32
         self._scratch: Optional[Tensor] = None
+        self._scratch_edges = 0  # batch size the scratch was sized for
         self._status: Optional[Tensor] = None  # [1] int32 device status word
         # csr state
         self._csr: Optional[TemporalCSR] = None
@@ -225,6 +226,7 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
                 self._ring_x = None if self._ring_x is None else self._ring_x.to(device)
                 self._write_pos = self._write_pos.to(device)
                 self._scratch = None
+                self._scratch_edges = 0
         st = _native.RecencyStep()
         if self._mode == 'ring':
             st.ring, st.write_pos, st.ring_x = self._ring.data_ptr(), self._write_pos.data_ptr(), _native.ptr(self._ring_x)
@@ -348,9 +350,12 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
             n_edges = batch.edge_src.shape[0] if ring_mode else 0
             keep = None
             if n_edges:
-                m = n_edges if self._directed else 2 * n_edges
-                if self._scratch is None or self._scratch.shape[0] < 12 * m + 16:
-                    self._scratch = empty(12 * m + 16, dtype=torch.int32, device=device)
+                if n_edges > self._scratch_edges:
+                    need = int(lib.tgmx_ring_update_scratch_bytes(n_edges, 1 if self._directed else 0))
+                    if need == 0:
+                        _native.check(-2, 'tgmx_ring_update_scratch_bytes')
+                    self._scratch = empty(need, dtype=torch.uint8, device=device)  # torch allocations are 256-byte aligned
+                    self._scratch_edges = n_edges
                     st.scratch = self._scratch.data_ptr()
                 ex = batch.edge_x
                 if ex is not None and D:

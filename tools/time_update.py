@@ -10,7 +10,7 @@ lib = _native.load()
 N, B, D = 9227, 20, 172
 g = torch.Generator().manual_seed(0)
 out = {}
-for n in [200, 400, 512, 800, 1600, 2048, 4096]:
+for n in [200, 400, 512, 800, 1600, 2048, 4096, 32768]:
     m = 2 * n
     src = torch.randint(0, 8227, (n,), generator=g).int().to(dev)
     dst = (8227 + (torch.rand(n, generator=g) ** 3 * 1000).long().clamp(max=999)).int().to(dev)
@@ -19,7 +19,7 @@ for n in [200, 400, 512, 800, 1600, 2048, 4096]:
     ring = torch.zeros(N * B, 2, dtype=torch.int64, device=dev)
     wpos = torch.zeros(N, dtype=torch.int32, device=dev)
     ring_x = torch.zeros(N * B, D, device=dev)
-    scratch = torch.empty(12 * m + 16, dtype=torch.int32, device=dev)
+    scratch = torch.empty(int(lib.tgmx_ring_update_scratch_bytes(n, 0)), dtype=torch.uint8, device=dev)
     status = torch.zeros(1, dtype=torch.int32, device=dev)
     st = _native.stream_ptr()
     def call():
