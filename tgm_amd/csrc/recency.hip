@@ -250,6 +250,88 @@ __global__ __launch_bounds__(256) void recency_lookup_kernel(const LookupArgs a)
   }
 }
 
+// Narrow feature rows (k * D small, e.g. D = 16): one wave per seed moves ~1 KB behind a three-deep chain of dependent
+// loads, so the launch is latency-bound.  The packed variant gives every seed a GROUP of GL lanes (B, k <= GL): 64 / GL
+// seeds per wave, the same ballot / shuffle logic inside the group's slice of the wave, 2-4x the loads in flight.
+// Streaming rings only (the static index's prefix search is wave-wide), plain seed arrays only.
+template <int VEC, int GL>
+__global__ __launch_bounds__(256) void ring_lookup_packed_kernel(const LookupArgs a) {
+  using V = typename VecOf<VEC>::type;
+  constexpr int kGroups = kWave / GL;
+  extern __shared__ __attribute__((aligned(16))) int lds_eid_all[];
+  const int lane = lane_id();
+  const int sub = lane / GL, gl = lane - sub * GL;
+  const int wave_in_block = threadIdx.x >> 6;
+  const int k = a.k, B = a.B;
+  int* lds_eid = lds_eid_all + (wave_in_block * kGroups + sub) * k;
+  const long long waves_total = (long long)gridDim.x * (blockDim.x >> 6);
+  const long long n_rounds = (a.S + kGroups - 1) / kGroups;
+  for (long long w = (long long)blockIdx.x * (blockDim.x >> 6) + wave_in_block; w < n_rounds; w += waves_total) {
+    const long long s = w * kGroups + sub;
+    const bool act = s < a.S;
+    const int n = act ? a.seeds[s] : -1;
+    const long long q = act ? a.qtimes[s] : 0;
+    const bool live = n >= 0 && n < a.N;
+    if (act && gl == 0) {
+      int st = 0;
+      if (n >= a.N || n < -1 || (n == -1 && !a.allow_pad)) st |= TGMX_ST_SEED_RANGE;
+      if (q < 0 && !a.allow_pad) st |= TGMX_ST_SEED_TIME;
+      if (st) atomicOr(a.status, st);
+    }
+    const long long w0 = (long long)(live ? n : 0) * B;
+    const int wrot = live ? a.write_pos[n] % B : 0;
+    auto slot_of = [&](int i) -> long long {
+      int sl = wrot + i;
+      if (sl >= B) sl -= B;
+      return w0 + sl;
+    };
+    Rec r;
+    r.nbr = -1; r.eid = 0; r.ts = 0;
+    if (live && gl < B) r = a.recs[slot_of(gl)];
+    const bool ok = live && gl < B && r.nbr >= 0 && r.ts < q;
+    const unsigned long long m = (__ballot(ok) >> (sub * GL)) & ((GL == 64) ? ~0ull : ((1ull << GL) - 1));
+    const int cnt = m ? 64 - __clzll((long long)m) : 0;  // 1 + position of the rightmost valid entry, inside the group
+    const int i = cnt - k + gl;
+    const int from = i > 0 ? i : 0;
+    const int g_nbr = __shfl(r.nbr, sub * GL + from);
+    const long long g_ts = __shfl(r.ts, sub * GL + from);
+    if (act && gl < k) {
+      const bool has = i >= 0 && g_nbr >= 0;
+      a.out_nid[s * k + gl] = has ? g_nbr : -1;
+      a.out_ts[s * k + gl] = has ? g_ts : 0;
+      lds_eid[gl] = has ? (int)slot_of(from) : -1;
+    }
+    if (a.D == 0) continue;
+    __builtin_amdgcn_wave_barrier();
+    if (act) {
+      const V* __restrict__ X = reinterpret_cast<const V*>(a.edge_x);
+      V* __restrict__ O = reinterpret_cast<V*>(a.out_x + s * (long long)k * a.D);
+      const int total = k * a.row_vecs;
+      constexpr int U = 4;
+      for (int f0 = gl; f0 < total; f0 += GL * U) {
+        V v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int f = f0 + u * GL;
+          v[u] = zero_vec<V>();
+          if (f < total) {
+            const int slot = (int)a.dv.div((uint32_t)f);
+            const int col = f - slot * a.row_vecs;
+            const int e = lds_eid[slot];
+            if (e >= 0) v[u] = X[(long long)e * a.row_vecs + col];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int f = f0 + u * GL;
+          if (f < total) O[f] = v[u];
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 template <bool RING>
 static int launch_lookup(LookupArgs a, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
   if (a.S == 0) return TGMX_OK;
@@ -275,7 +357,24 @@ static int launch_lookup(LookupArgs a, hipStream_t stream, hipEvent_t ev_start, 
 #define TGMX_LAUNCH(VEC_, SMALL_) \
   hipLaunchKernelGGL((recency_lookup_kernel<RING, VEC_, SMALL_>), grid, block, lds, stream, a)
   if (ev_start) (void)hipEventRecord(ev_start, stream);
-  if (small) {
+  // narrow rows: several seeds per wave (streaming rings, plain seed arrays)
+  const int gl = (a.B <= 16 && a.k <= 16) ? 16 : ((a.B <= 32 && a.k <= 32) ? 32 : 64);
+  if (RING && a.grp.groups == 0 && gl < 64 && (long long)a.k * a.row_vecs <= 8 * gl) {
+    const int per_wave = 64 / gl;
+    long long pblocks = ((a.S + per_wave - 1) / per_wave + waves_per_block - 1) / waves_per_block;
+    if (pblocks > (1 << 20)) pblocks = 1 << 20;
+    const dim3 pgrid((unsigned)pblocks);
+    const size_t plds = (size_t)waves_per_block * per_wave * a.k * sizeof(int);
+#define TGMX_PACKED(VEC_)                                                                              \
+  do {                                                                                                 \
+    if (gl == 16) hipLaunchKernelGGL((ring_lookup_packed_kernel<VEC_, 16>), pgrid, block, plds, stream, a); \
+    else hipLaunchKernelGGL((ring_lookup_packed_kernel<VEC_, 32>), pgrid, block, plds, stream, a);          \
+  } while (0)
+    if (vec == 4) TGMX_PACKED(4);
+    else if (vec == 2) TGMX_PACKED(2);
+    else TGMX_PACKED(1);
+#undef TGMX_PACKED
+  } else if (small) {
     if (vec == 4) TGMX_LAUNCH(4, true);
     else if (vec == 2) TGMX_LAUNCH(2, true);
     else TGMX_LAUNCH(1, true);
