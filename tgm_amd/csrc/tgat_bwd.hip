@@ -104,7 +104,13 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   if (e >= MN) return;
   const float* p = partial + (long long)blockIdx.y * splits * MN + e;
   float acc = 0.f;
-  for (int s = 0; s < splits; ++s) acc += p[(long long)s * MN];
+  for (int s = 0; s < splits; s += 8) {  // 8 independent loads in flight; the summation order stays 0, 1, 2, ...
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = s + u < splits ? p[(long long)(s + u) * MN] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += v[u];
+  }
   const int m = (int)(e / N), n = (int)(e - (long long)m * N);
   float* o = out + (long long)blockIdx.y * s_out + (long long)m * ldo + n;
   *o = accumulate ? *o + acc : acc;
@@ -119,7 +125,13 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
   long long r1 = r0 + rows_per_split;
   if (r1 > R) r1 = R;
   float acc = 0.f;
-  for (long long r = r0; r < r1; ++r) acc += in[r * ld + c];
+  for (long long r = r0; r < r1; r += 8) {  // 8 independent loads in flight; summation order stays r0, r0+1, ...
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = r + u < r1 ? in[(r + u) * ld + c] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += v[u];
+  }
   partial[(long long)blockIdx.y * C + c] = acc;
 }
 
@@ -306,19 +318,28 @@ __global__ __launch_bounds__(256) void tgat_attn_backward_kernel(const AttnBwdAr
         qv[h] = q[h * Cs + col0 + c];
       }
       float dw = 0.f, db = 0.f;
-      for (int s = 0; s < k; ++s) {
-        const float z = base[(long long)s * slot_stride + c];
-        float dzs = 0.f;
+      float zs[G];  // the column of every slot first: G independent loads in flight instead of one per iteration
+#pragma clang loop unroll(full)
+      for (int s = 0; s < G; ++s) {
+        const int sl = s < k ? s : k - 1;
+        zs[s] = base[(long long)sl * slot_stride + c];
+      }
+#pragma clang loop unroll(full)
+      for (int s = 0; s < G; ++s) {
+        if (s < k) {
+          const float z = zs[s];
+          float dzs = 0.f;
 #pragma unroll
-        for (int h = 0; h < H; ++h) {
-          acc[h] = __fmaf_rn(s_ds[h * k + s], z, acc[h]);
-          dzs += s_A[h * k + s] * gv[h] + a.scale * s_ds[h * k + s] * qv[h];
-        }
-        if (part == 0 && a.dnbr) a.dnbr[(r * k + s) * (long long)d + c] += dzs;
-        if (part == 2) {
-          const float g = -s_sin[s * T + c] * dzs;  // d cos(arg) / d arg
-          dw = __fmaf_rn(g, s_dt[s], dw);
-          db += g;
+          for (int h = 0; h < H; ++h) {
+            acc[h] = __fmaf_rn(s_ds[h * k + s], z, acc[h]);
+            dzs += s_A[h * k + s] * gv[h] + a.scale * s_ds[h * k + s] * qv[h];
+          }
+          if (part == 0 && a.dnbr) a.dnbr[(r * k + s) * (long long)d + c] += dzs;
+          if (part == 2) {
+            const float g = -s_sin[s * T + c] * dzs;  // d cos(arg) / d arg
+            dw = __fmaf_rn(g, s_dt[s], dw);
+            db += g;
+          }
         }
       }
 #pragma unroll
@@ -375,7 +396,7 @@ extern "C" int tgmx_colsum(const float* in, int64_t ld, int64_t R, int32_t C, fl
                            tgmx_stream_t stream) {
   TGMX_REQUIRE(R >= 0 && C > 0 && ld >= C, "colsum: bad sizes");
   TGMX_REQUIRE(in && out && workspace, "colsum: null pointer");
-  int splits = (int)((R + 255) / 256);
+  int splits = (int)((R + 63) / 64);
   if (splits > 256) splits = 256;
   if (splits < 1) splits = 1;
   const long long rps = (R + splits - 1) / splits;
