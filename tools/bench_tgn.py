@@ -1,0 +1,74 @@
+#!/usr/bin/env python
+"""BASELINE config 3: review-shaped synthetic stream (N=350k, E=4.8M, D=16), TGN memory + graph attention embedding,
+recency sampler k=[10,10] (the model consumes hop 0, like examples/linkproppred/tgn.py:74-95), bs=512.
+Times the whole per-batch pipeline (negatives -> sampler -> dedup -> memory -> embedding -> update_state) on the GPU
+box and prints one JSON line.   python tools/bench_tgn.py [n_batches]"""
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tgm_amd import DGData, DGDataLoader, DGraph  # noqa: E402
+from tgm_amd.hooks import DeduplicationHook, HookManager, RandomNegativeEdgeSamplerHook, RecencyNeighborHook  # noqa: E402
+from tgm_amd.nn import GraphAttentionEmbedding, IdentityMessage, LastAggregator, TGNMemory  # noqa: E402
+from tgm_amd.synth import make_stream  # noqa: E402
+
+dev = torch.device('cuda', 0)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+st = make_stream('review', seed=1337, device=dev)
+N, D, M, T_, bs, ks = st.num_nodes, st.edge_dim, 100, 100, 512, [10, 10]
+dg = DGraph(DGData.from_raw(st.ts, torch.stack([st.src, st.dst], 1), st.edge_x), device=dev)
+hm = HookManager(keys=['k'])
+lo_dst = int(st.dst.min())
+hm.register('k', RandomNegativeEdgeSamplerHook(lo_dst, N))
+hook = RecencyNeighborHook(N, ks, ['edge_src', 'edge_dst', 'neg'], ['edge_time', 'edge_time', 'neg_time'], validate='deferred')
+hm.register('k', hook)
+hm.register('k', DeduplicationHook(seed_nodes_keys=['neg', 'nbr_nids']))
+mem = TGNMemory(N, D, M, T_, IdentityMessage(D, M, T_), LastAggregator()).to(dev).train()
+enc = GraphAttentionEmbedding(M, 100, D, mem.time_enc).to(dev).eval()
+loader = DGDataLoader(dg, batch_size=bs, hook_manager=hm)
+starts = loader._starts
+k = ks[0]
+
+
+def step(i):
+    batch = loader(starts[i])
+    nbr = batch.nbr_nids[0].flatten()
+    keep = nbr != -1
+    seeds = torch.cat([batch.edge_src, batch.edge_dst, batch.neg]).repeat_interleave(k)
+    edge_index = torch.stack([batch.global_to_local(seeds[keep]), batch.global_to_local(nbr[keep])]).long()
+    e_t = batch.nbr_edge_time[0].flatten()[keep]
+    e_x = batch.nbr_edge_x[0].flatten(0, -2)[keep]
+    z, lu = mem(batch.unique_nids)
+    z2 = enc(z, lu, edge_index, e_t, e_x)
+    mem.update_state(batch.edge_src, batch.edge_dst, batch.edge_time, batch.edge_x)
+    return z2, batch
+
+
+with hm.activate('k'), torch.no_grad():
+    for i in range(100):
+        z2, b = step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(100, 100 + n):
+        z2, b = step(i)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    hook.check()
+    # sampler only, same stream
+    t3 = time.perf_counter()
+    for i in range(100 + n, 100 + 2 * n):
+        loader(starts[i])
+    torch.cuda.synchronize()
+    t4 = time.perf_counter()
+slots = 3 * bs * k + 3 * bs * k * ks[1]
+print(json.dumps({
+    'what': 'BASELINE cfg3: review-shaped synthetic (N=350k, E=4.8M, D=16), TGN memory (Last, GRU, 100) + TransformerConv embedding, k=[10,10], bs=512, 1 GPU',
+    'pipeline_us_per_batch': 1e6 * (t2 - t0) / n, 'host_us_per_batch': 1e6 * (t1 - t0) / n,
+    'events_per_s': bs * n / (t2 - t0), 'sampled_edges_per_s': slots * n / (t2 - t0),
+    'loader_hooks_only_us_per_batch': 1e6 * (t4 - t3) / n, 'unique_nodes_last_batch': int(b.unique_nids.numel()),
+}))
