@@ -144,6 +144,8 @@ def main():
     rank, world, local = init_process_group()
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)'
     assert torch.cuda.is_available(), 'bench.py needs a ROCm device'
+    if os.environ.get('TGMX_SINGLE_DEVICE'):  # functional check only: every rank on device 0 (with TGMX_DIST_BACKEND=gloo)
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
 
