@@ -410,6 +410,33 @@ int tgmx_tgcn_concat(const float* a, int64_t lda, const float* b, const float* g
 int tgmx_tgcn_output(const float* u_pre, const float* c_pre, const float* H, int64_t n, float* out,
                      tgmx_stream_t stream);
 
+/* ---- TGN backward building blocks (training; composed by tgm_amd/nn/_tgn_train.py).  The reference trains through
+ * torch autograd (examples/linkproppred/tgn.py:97-118); memory / last_update are buffers, so the parameters reached are
+ * the shared Time2Vec (tgm/nn/modules/time_encoding.py), the GRU cell and the TransformerConv projections.  The dense
+ * projections differentiate through tgmx_sgemm_nt / tgmx_sgemm_tn / tgmx_colsum. ---- */
+
+/* d(gi), d(gh) [R, 3M] of tgmx_tgn_gru_gate (torch.nn.GRUCell gate arithmetic); h is a buffer row (no dh) */
+int tgmx_tgn_gru_gate_backward(const float* gi, const float* gh, const float* h, const float* dout, int32_t M, int64_t R,
+                               float* dgi, float* dgh, tgmx_stream_t stream);
+/* backward of tgmx_tgn_aggregate w.r.t. the Time2Vec parameters: part[r, :T] = d(tw), part[r, T:2T] = d(tb) contribution
+ * of row r (same event selection as the forward; sum the rows with tgmx_colsum).  d_aggr: [R, 2M + D + T].  The row_*
+ * arrays are per-row snapshots of the node's message windows and last_update taken at forward time: the reference's
+ * training loop calls update_state before loss.backward() (examples/linkproppred/tgn.py:111-116). */
+int tgmx_tgn_aggregate_backward(int64_t R, const int64_t* row_lo_s, const int32_t* row_cnt_s, const int64_t* row_lo_d,
+                                const int32_t* row_cnt_d, const int64_t* row_last_update, const int64_t* log_t, int32_t M,
+                                int32_t D, const float* tw, const float* tb, int32_t T, int32_t mean, const float* d_aggr,
+                                float* part, tgmx_stream_t stream);
+/* backward of tgmx_tconv_edge_attr w.r.t. the Time2Vec parameters: part [E, 2T] (d_attr: [E, T + D]) */
+int tgmx_tconv_edge_attr_backward(const int64_t* last_update_local, const int64_t* src, const int64_t* t, const float* tw,
+                                  const float* tb, const float* d_attr, int32_t T, int32_t D, int64_t E, float* part,
+                                  tgmx_stream_t stream);
+/* backward of tgmx_tconv_attend: dq written, dk / dv zero-initialised by the caller and accumulated (float atomics),
+ * de [E, H*C] written for every edge.  C <= 64. */
+int tgmx_tconv_attend_backward(const float* q, const float* k, const float* v, const float* eproj, const int64_t* order,
+                               const int64_t* src, const int64_t* seg_lo, const int64_t* seg_hi, int64_t U, int32_t H,
+                               int32_t C, float scale, const float* dout, float* dq, float* dk, float* dv, float* de,
+                               tgmx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -82,4 +82,25 @@ __device__ __forceinline__ float cos_t2v(float x) {
   return cos_t2v_poly((float)r, (int)((long long)kd & 3));
 }
 
+// sin counterpart of cos_t2v (backward passes only; always the double-precision range reduction)
+__device__ __forceinline__ float sin_t2v(float x) {
+  const double xd = (double)x;
+  const double kd = __builtin_rint(xd * 0.63661977236758134308);
+  double r = __builtin_fma(-kd, 1.57079632679489655800e+00, xd);
+  r = __builtin_fma(-kd, 6.12323399573676603587e-17, r);
+  const float rf = (float)r;
+  const int q = (int)((long long)kd & 3);
+  const float r2 = rf * rf;
+  float sp = -1.9515295891e-4f;
+  sp = __fmaf_rn(sp, r2, 8.3321608736e-3f);
+  sp = __fmaf_rn(sp, r2, -1.6666654611e-1f);
+  const float sn = __fmaf_rn(sp * r2, rf, rf);
+  float cp = 2.443315711809948e-5f;
+  cp = __fmaf_rn(cp, r2, -1.388731625493765e-3f);
+  cp = __fmaf_rn(cp, r2, 4.166664568298827e-2f);
+  const float cs = __fmaf_rn(cp * r2, r2, __fmaf_rn(-0.5f, r2, 1.0f));
+  const float v = (q & 1) ? cs : sn;  // q: 0 -> sin r, 1 -> cos r, 2 -> -sin r, 3 -> -cos r
+  return (q >= 2) ? -v : v;
+}
+
 }  // namespace tgmx

@@ -124,6 +124,8 @@ class TGNMemory(nn.Module):
         lib = _native.load()
         _native.require_device(nodes, 'n_id')
         self._ensure_store(0)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return self._updated_train(nodes)
         dev, R, M, D, T = nodes.device, nodes.numel(), self.memory_dim, self.raw_msg_dim, self.time_dim
         W = 2 * M + D + T
         stream = _native.stream_ptr()
@@ -149,6 +151,18 @@ class TGNMemory(nn.Module):
         _native.check(lib.tgmx_tgn_gru_gate(gi.data_ptr(), gh.data_ptr(), h.data_ptr(), M, R, out.data_ptr(), stream), 'tgmx_tgn_gru_gate')
         return out, new_lu
 
+    def _updated_train(self, nodes: Tensor) -> Tuple[Tensor, Tensor]:
+        """Same arithmetic with autograd through the hand-written backward kernels (nn/_tgn_train.py)."""
+        from ._tgn_train import AggregateFn, GruGateFn, LinearFn
+
+        aggr, new_lu = AggregateFn.apply(self.time_enc.w.weight, self.time_enc.w.bias, self, nodes)
+        h = _ops.gather_rows(self.memory.detach(), nodes)
+        gru = self.memory_updater
+        gi = LinearFn.apply(aggr, gru.weight_ih, gru.bias_ih)
+        gh = LinearFn.apply(h, gru.weight_hh, gru.bias_hh)
+        return GruGateFn.apply(gi, gh, h), new_lu
+
+    @torch.no_grad()
     def _commit(self, nodes: Tensor, flag: Optional[Tensor]) -> None:
         lib = _native.load()
         CH = 1 << 16  # bounds the [rows, msg_dim] scratch when all N nodes are flushed
@@ -275,6 +289,8 @@ class TransformerConv(nn.Module):
         if self.training and self.dropout > 0:
             raise NotImplementedError('tgm_amd TransformerConv: attention dropout / backward not implemented; call .eval()')
         lib = _native.load()
+        if torch.is_grad_enabled() and (x.requires_grad or edge_attr.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return self._forward_train(x, edge_index, edge_attr)
         x = _ops._f32c(x, 'x')
         dev, U, H, C = x.device, x.shape[0], self.heads, self.out_channels
         HC = H * C
@@ -301,6 +317,33 @@ class TransformerConv(nn.Module):
         return out
 
 
+def _tconv_forward_train(self, x: Tensor, edge_index: Tensor, edge_attr: Tensor) -> Tensor:
+    """TransformerConv forward with autograd (hand-written backward kernels, nn/_tgn_train.py)."""
+    from ._tgn_train import LinearFn, TconvAttendFn
+
+    if self.out_channels > 64:
+        raise NotImplementedError('tgm_amd TransformerConv backward supports out_channels <= 64')
+    x = x.float().contiguous() if (x.dtype != torch.float32 or not x.is_contiguous()) else x
+    dev, U, H, C = x.device, x.shape[0], self.heads, self.out_channels
+    q = LinearFn.apply(x, self.lin_query.weight, self.lin_query.bias)
+    k = LinearFn.apply(x, self.lin_key.weight, self.lin_key.bias)
+    v = LinearFn.apply(x, self.lin_value.weight, self.lin_value.bias)
+    skip = LinearFn.apply(x, self.lin_skip.weight, self.lin_skip.bias)
+    E = edge_index.shape[1]
+    if not E:
+        return skip
+    eproj = LinearFn.apply(edge_attr.float().contiguous(), self.lin_edge.weight, None)
+    src, tgt = edge_index[0].contiguous(), edge_index[1].contiguous()
+    tgt_sorted, order = torch.sort(tgt, stable=True)
+    ids = torch.arange(U, device=dev, dtype=tgt.dtype)
+    seg_lo = torch.searchsorted(tgt_sorted, ids, right=False)
+    seg_hi = torch.searchsorted(tgt_sorted, ids, right=True)
+    return TconvAttendFn.apply(q, k, v, eproj, skip, order, src, seg_lo, seg_hi, H, C)
+
+
+TransformerConv._forward_train = _tconv_forward_train
+
+
 class GraphAttentionEmbedding(nn.Module):
     """tgn.py:14-40: edge_attr = [Time2Vec(last_update[src] - t) | msg], then TransformerConv(heads=2, dropout=0.1)."""
 
@@ -316,6 +359,12 @@ class GraphAttentionEmbedding(nn.Module):
         msg = _ops._f32c(msg, 'msg')
         D = msg.shape[1]
         edge_index = edge_index.to(torch.int64)
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            from ._tgn_train import EdgeAttrFn
+
+            edge_attr = EdgeAttrFn.apply(self.time_enc.w.weight, self.time_enc.w.bias, last_update.to(torch.int64).contiguous(),
+                                         edge_index[0].contiguous(), t.to(torch.int64).contiguous(), msg)  # fmt: skip
+            return self.conv(x, edge_index, edge_attr)
         edge_attr = torch.empty((E, T + D), dtype=torch.float32, device=x.device)
         tw, tb = self.time_enc.w.weight.detach().reshape(-1), self.time_enc.w.bias.detach()
         _native.check(
