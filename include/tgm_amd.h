@@ -410,6 +410,15 @@ int tgmx_tgcn_concat(const float* a, int64_t lda, const float* b, const float* g
 int tgmx_tgcn_output(const float* u_pre, const float* c_pre, const float* H, int64_t n, float* out,
                      tgmx_stream_t stream);
 
+/* DeduplicationHook (tgm/hooks/dedup.py:35-67): the sorted unique ids of up to 16 int32 id arrays (edge endpoints, extra
+ * seed attributes, every hop's neighbor ids); -1 (padded slot) is skipped inside the kernel, ids outside [0, num_nodes)
+ * raise TGMX_ST_SEED_RANGE.  out_ids needs room for min(total ids, num_nodes); *out_count (device) receives the number
+ * written.  `parts` / `part_sizes` are HOST arrays of device pointers / lengths.  workspace: 256-byte aligned,
+ * tgmx_unique_ids_workspace_bytes(num_nodes). */
+size_t tgmx_unique_ids_workspace_bytes(int32_t num_nodes);
+int tgmx_unique_ids(const int32_t* const* parts, const int64_t* part_sizes, int32_t num_parts, int32_t num_nodes,
+                    void* workspace, int32_t* out_ids, int64_t* out_count, int32_t* status, tgmx_stream_t stream);
+
 /* ---- TGN backward building blocks (training; composed by tgm_amd/nn/_tgn_train.py).  The reference trains through
  * torch autograd (examples/linkproppred/tgn.py:97-118); memory / last_update are buffers, so the parameters reached are
  * the shared Time2Vec (tgm/nn/modules/time_encoding.py), the GRU cell and the TransformerConv projections.  The dense

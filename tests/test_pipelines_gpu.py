@@ -110,3 +110,45 @@ def test_cfg5_snapshots_tgcn():
         close(H.cpu(), H_ref, f'snapshot {n_snap}')
         n_snap += 1
     assert n_snap == 12
+
+
+def test_dedup_hook_matches_reference_golden():
+    """recency sampler k=[3,2] + DeduplicationHook on the device against the reference's recorded unique_nids /
+    global_to_local (golden g7)."""
+    import json
+    import os
+
+    from tgm_amd import DGData, DGDataLoader, DGraph
+    from tgm_amd.hooks import DeduplicationHook, HookManager, RecencyNeighborHook
+    from tgm_amd.hooks.base import StatelessHook
+
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'g7_dedup.npz'))
+    meta = json.loads(bytes(z['meta']).decode())
+    neg = torch.from_numpy(z['neg']).to(DEV)
+
+    class Replay(StatelessHook):
+        _cls_requires = {'edge_src', 'edge_dst', 'edge_time'}
+        _cls_produces = {'neg', 'neg_time'}
+
+        def __init__(self):
+            super().__init__()
+            self.__post_init__()
+
+        def __call__(self, dg, batch):
+            batch.neg = neg[batch._edge_lo : batch._edge_lo + batch.edge_src.numel()].clone()
+            batch.neg_time = batch.edge_time.clone()
+            return batch
+
+    dg = DGraph(DGData.from_raw(torch.from_numpy(z['ts']), torch.stack([torch.from_numpy(z['src']), torch.from_numpy(z['dst'])], 1)), device=DEV)
+    hm = HookManager(keys=['k'])
+    hm.register('k', Replay())
+    hm.register('k', RecencyNeighborHook(meta['num_nodes'], meta['num_nbrs'], ['edge_src', 'edge_dst', 'neg'], ['edge_time', 'edge_time', 'neg_time']))
+    hm.register('k', DeduplicationHook(seed_nodes_keys=['neg', 'nbr_nids']))
+    nb = 0
+    with hm.activate('k'):
+        for b, batch in enumerate(DGDataLoader(dg, batch_size=meta['batch_size'], hook_manager=hm)):
+            assert batch.unique_nids.dtype == torch.int32
+            assert np.array_equal(batch.unique_nids.cpu().numpy(), z[f'b{b}_unique_nids']), f'batch {b}'
+            assert np.array_equal(batch.global_to_local(batch.edge_src).cpu().numpy(), z[f'b{b}_local_src']), f'batch {b}'
+            nb += 1
+    assert nb == meta['num_batches']

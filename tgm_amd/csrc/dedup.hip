@@ -1,0 +1,123 @@
+// DeduplicationHook (tgm/hooks/dedup.py:35-67): sorted unique node ids of a batch.  The reference concatenates the id
+// tensors (after boolean-masking the pad slots of every hop) and calls torch.unique (a sort).  Node ids are bounded by
+// num_nodes, so a bitmap does it in O(ids + num_nodes / 32) with the result already sorted: mark (atomicOr, pads
+// skipped in the kernel -- no boolean indexing, no device -> host sync per hop), per-word popcount scanned in one
+// workgroup, then every word scatters its set bits to their final positions.
+#include "common.h"
+
+namespace tgmx {
+
+constexpr int kMaxParts = 16;
+
+struct MarkArgs {
+  const int32_t* part[kMaxParts];
+  long long end[kMaxParts];  // exclusive end offset of part p in the concatenation
+  unsigned int* bitmap;
+  int32_t* status;
+  int parts, N;
+};
+
+__global__ __launch_bounds__(256) void dedup_mark_kernel(const MarkArgs a) {
+  const long long total = a.end[a.parts - 1];
+  const long long step = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
+    const int32_t* p = a.part[0];
+    long long base = 0;
+#pragma unroll
+    for (int q = 1; q < kMaxParts; ++q) {
+      if (q < a.parts && i >= a.end[q - 1]) {
+        p = a.part[q];
+        base = a.end[q - 1];
+      }
+    }
+    const int id = p[i - base];
+    if (id == -1) continue;  // padded neighbor slot
+    if (id < 0 || id >= a.N) {
+      atomicOr(a.status, TGMX_ST_SEED_RANGE);
+      continue;
+    }
+    atomicOr(&a.bitmap[id >> 5], 1u << (id & 31));
+  }
+}
+
+// exclusive prefix sum of popcount(bitmap[w]) over all words, one workgroup (num_nodes / 32 words: tens of thousands)
+__global__ __launch_bounds__(1024) void dedup_scan_kernel(const unsigned int* __restrict__ bitmap, long long words,
+                                                          int32_t* __restrict__ prefix, int64_t* __restrict__ count) {
+  __shared__ int wave_tot[16];
+  __shared__ int carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (long long w0 = 0; w0 < words; w0 += 1024) {
+    const long long w = w0 + tid;
+    const int v = w < words ? __popc(bitmap[w]) : 0;
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_up(incl, off);
+      if (lane >= off) incl += o;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int before = carry_s;
+    for (int q = 0; q < wave; ++q) before += wave_tot[q];
+    if (w < words) prefix[w] = before + incl - v;
+    __syncthreads();
+    if (tid == 1023) carry_s = before + incl;
+    __syncthreads();
+  }
+  if (tid == 0) *count = carry_s;
+}
+
+__global__ __launch_bounds__(256) void dedup_compact_kernel(const unsigned int* __restrict__ bitmap, const int32_t* __restrict__ prefix,
+                                                            long long words, int32_t* __restrict__ out) {
+  const long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= words) return;
+  unsigned int bits = bitmap[w];
+  int pos = prefix[w];
+  while (bits) {
+    const int b = __ffs(bits) - 1;
+    out[pos++] = (int)(w * 32 + b);
+    bits &= bits - 1;
+  }
+}
+
+}  // namespace tgmx
+
+using namespace tgmx;
+
+extern "C" size_t tgmx_unique_ids_workspace_bytes(int32_t num_nodes) {
+  const size_t words = ((size_t)(num_nodes > 0 ? num_nodes : 0) + 31) / 32;
+  return words * 8 + 512;  // bitmap + per-word prefix
+}
+
+extern "C" int tgmx_unique_ids(const int32_t* const* parts, const int64_t* part_sizes, int32_t num_parts, int32_t num_nodes,
+                               void* workspace, int32_t* out_ids, int64_t* out_count, int32_t* status, tgmx_stream_t stream) {
+  TGMX_REQUIRE(num_parts > 0 && num_parts <= kMaxParts && num_nodes > 0, "unique_ids: %d parts (1..%d), num_nodes=%d", num_parts, kMaxParts,
+               num_nodes);
+  TGMX_REQUIRE(parts && part_sizes && workspace && out_ids && out_count && status, "unique_ids: null pointer");
+  TGMX_REQUIRE(((uintptr_t)workspace & 255) == 0, "unique_ids: workspace must be 256-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const long long words = ((long long)num_nodes + 31) / 32;
+  unsigned int* bitmap = reinterpret_cast<unsigned int*>(workspace);
+  int32_t* prefix = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(workspace) + ((words * 4 + 255) & ~255ll));
+  MarkArgs m{};
+  long long total = 0;
+  for (int p = 0; p < num_parts; ++p) {
+    TGMX_REQUIRE(part_sizes[p] >= 0 && (part_sizes[p] == 0 || parts[p]), "unique_ids: part %d", p);
+    total += part_sizes[p];
+    m.part[p] = parts[p];
+    m.end[p] = total;
+  }
+  m.bitmap = bitmap; m.status = status; m.parts = num_parts; m.N = num_nodes;
+  (void)hipMemsetAsync(bitmap, 0, (size_t)words * 4, st);
+  if (total > 0) {
+    long long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(dedup_mark_kernel, dim3((unsigned)blocks), dim3(256), 0, st, m);
+  }
+  hipLaunchKernelGGL(dedup_scan_kernel, dim3(1), dim3(1024), 0, st, bitmap, words, prefix, out_count);
+  hipLaunchKernelGGL(dedup_compact_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, bitmap, prefix, words, out_ids);
+  TGMX_CHECK_LAUNCH("unique_ids");
+  return TGMX_OK;
+}

@@ -3,13 +3,20 @@
 Used by the TGN loop: ``unique_nids`` = sorted unique of edge endpoints, extra
 seed attributes and every valid (non-pad) sampled neighbor id;
 ``global_to_local(x)`` = position of ``x`` in ``unique_nids`` (int32).
+
+On a ROCm device the ids go through ``tgmx_unique_ids`` (bitmap over the node ids: no sort, pads skipped inside the
+kernel instead of one boolean-mask sync per hop; ``csrc/dedup.hip``).  Host tensors keep the reference's own torch
+formulation (``cat`` + ``torch.unique``) -- this hook is data plumbing with no device requirement in the reference.
 """
 from __future__ import annotations
 
 from typing import List, Optional
 
+import ctypes
+
 import torch
 
+from .. import _native
 from ..constants import PADDED_NODE_ID
 from ..core import DGBatch, DGraph
 from .base import SeedableHook, StatelessHook
@@ -35,18 +42,52 @@ class DeduplicationHook(StatelessHook, SeedableHook):
     def __call__(self, dg: DGraph, batch: DGBatch) -> DGBatch:
         device = batch.edge_src.device
         parts = [batch.edge_src, batch.edge_dst]
+        nbr_parts = []
         for attr in self.requires:
             if not hasattr(batch, attr):
                 raise ValueError(f'Missing seed node attribute {attr}')
             if 'nbr_nids' in attr:
-                for hop_ids in getattr(batch, attr):
-                    flat = hop_ids.reshape(-1)
-                    parts.append(flat[flat != PADDED_NODE_ID].to(device))
+                nbr_parts += [hop_ids.reshape(-1) for hop_ids in getattr(batch, attr)]
             else:
                 value = getattr(batch, attr)
                 if value is not None:
                     parts.append(value)
-        unique_nids = torch.unique(torch.cat(parts, dim=0), sorted=True)
+        if device.type == 'cuda':
+            unique_nids = self._unique_device(dg, parts + [p.to(device) for p in nbr_parts], device)
+        else:
+            flat = parts + [p[p != PADDED_NODE_ID] for p in nbr_parts]
+            unique_nids = torch.unique(torch.cat(flat, dim=0), sorted=True)
         self.add_batch_attribute(batch, 'unique_nids', unique_nids)
         self.add_batch_attribute(batch, 'global_to_local', lambda x: torch.searchsorted(unique_nids, x).int())
         return batch
+
+    def _unique_device(self, dg: DGraph, parts: List[torch.Tensor], device: torch.device) -> torch.Tensor:
+        lib = _native.load()
+        parts = [p for p in parts if p.numel()]
+        dtype = parts[0].dtype if parts else torch.int32
+        parts = [p if (p.dtype == torch.int32 and p.is_contiguous()) else p.to(torch.int32).contiguous() for p in parts]
+        if not parts:
+            return torch.empty(0, dtype=dtype, device=device)
+        if len(parts) > 16:
+            parts = parts[:15] + [torch.cat(parts[15:])]
+        N = int(dg._storage.num_nodes_global)
+        total = sum(p.numel() for p in parts)
+        ws = getattr(self, '_ws', None)
+        if ws is None or ws[0] != (device, N):
+            need = int(lib.tgmx_unique_ids_workspace_bytes(N))
+            ws = self._ws = ((device, N), torch.empty(need, dtype=torch.uint8, device=device), torch.zeros(1, dtype=torch.int64, device=device),
+                             torch.zeros(1, dtype=torch.int32, device=device))  # fmt: skip
+        _, work, count, status = ws
+        out = torch.empty(min(total, N), dtype=torch.int32, device=device)
+        n = len(parts)
+        ptrs = (ctypes.c_void_p * n)(*[p.data_ptr() for p in parts])
+        sizes = (ctypes.c_int64 * n)(*[p.numel() for p in parts])
+        with torch.cuda.device(device):
+            _native.check(lib.tgmx_unique_ids(ptrs, sizes, n, N, work.data_ptr(), out.data_ptr(), count.data_ptr(), status.data_ptr(),
+                                              _native.stream_ptr(device.index)), 'tgmx_unique_ids')  # fmt: skip
+        cnt, st = int(count.item()), int(status.item())  # the only sync: the result's size (torch.unique has the same one)
+        if st:
+            status.zero_()
+            raise ValueError(f'node ids must satisfy 0 <= x < {N} (or -1 for a padded neighbor slot)')
+        res = out[:cnt]
+        return res if dtype == torch.int32 else res.to(dtype)
