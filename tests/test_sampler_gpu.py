@@ -241,6 +241,60 @@ def test_csr_mode_equals_ring_int64_random():
                 assert torch.equal(x, y), f'batch {b} hop {h}'
 
 
+def test_full_size_wiki_properties():
+    """BASELINE config 2 at FULL size (N=9227, E=157474, D=172, bs=200, k=[20,20], 788 batches), size-independent
+    properties checked on every batch: the streaming rings (intended key order) and the stateless index agree bit for
+    bit; every row is oldest -> newest, strictly before its query time, pads left-aligned as (-1, 0, 0.0); every valid
+    slot's feature row is a verbatim row of edge_x (found through its stream position); hop h+1 seeds are hop h outputs."""
+    DGData, DGDataLoader, DGraph, HookManager, RecencyNeighborHook, ReplayNegatives = _mk()
+    from tgm_amd.synth import make_stream
+
+    st = make_stream('wiki', seed=1337)
+    N, E, D, bs, ks = st.num_nodes, st.num_edges, st.edge_dim, 200, [20, 20]
+    g = torch.Generator().manual_seed(5)
+    neg = torch.randint(8227, N, (E,), generator=g, dtype=torch.int32)
+    data = DGData.from_raw(st.ts, torch.stack([st.src, st.dst], 1), st.edge_x)
+    edge_x_dev = st.edge_x.to(DEV)
+    ts_dev = st.ts.to(DEV)
+    iters = {}
+    for mode in ('ring', 'csr'):
+        hook = RecencyNeighborHook(N, ks, ['edge_src', 'edge_dst', 'neg'], ['edge_time', 'edge_time', 'neg_time'], mode=mode,
+                                   key_arith='int64', batch_size=bs, validate='deferred')  # fmt: skip
+        hm = HookManager(keys=['k'])
+        hm.register('k', ReplayNegatives(neg.to(DEV)))
+        hm.register('k', hook)
+        iters[mode] = (hm, hook, DGDataLoader(DGraph(data, device=DEV), batch_size=bs, hook_manager=hm))
+    (hm_r, hook_r, ld_r), (hm_c, hook_c, ld_c) = iters['ring'], iters['csr']
+    nb = 0
+    with hm_r.activate('k'), hm_c.activate('k'):
+        for br, bc in zip(ld_r, ld_c):
+            for h, k in enumerate(ks):
+                n, t, x = br.nbr_nids[h], br.nbr_edge_time[h], br.nbr_edge_x[h]
+                assert torch.equal(n, bc.nbr_nids[h]) and torch.equal(t, bc.nbr_edge_time[h]) and torch.equal(x, bc.nbr_edge_x[h]), (nb, h)
+                valid = n >= 0
+                q = br.seed_times[h][:, None]
+                assert bool(((t < q) | ~valid).all()), 'a sampled edge is not strictly before its query time'
+                assert bool((valid[:, 1:] | ~valid[:, :-1]).all()), 'pads must be left-aligned'
+                assert bool(((t[:, 1:] >= t[:, :-1]) | ~valid[:, :-1]).all()), 'rows must run oldest -> newest'
+                assert bool((t[~valid] == 0).all()) and bool((x[~valid] == 0).all())
+                if h + 1 < len(ks):
+                    assert torch.equal(br.seed_nids[h + 1], n.reshape(-1)) and torch.equal(br.seed_times[h + 1], t.reshape(-1))
+            if nb % 97 == 0:  # feature rows are verbatim copies: locate each valid slot's edge by (seed, nbr, time)
+                n, t, x = br.nbr_nids[0], br.nbr_edge_time[0], br.nbr_edge_x[0]
+                seeds = br.seed_nids[0]
+                rows = torch.nonzero(n >= 0)[:200]
+                for r, c in rows.tolist():
+                    a_, b_, tt = int(seeds[r]), int(n[r, c]), int(t[r, c])
+                    lo, hi = int(torch.searchsorted(ts_dev, tt)), int(torch.searchsorted(ts_dev, tt, right=True))
+                    s_, d_ = st.src[lo:hi], st.dst[lo:hi]
+                    cand = torch.nonzero(((s_ == a_) & (d_ == b_)) | ((s_ == b_) & (d_ == a_))).reshape(-1) + lo
+                    assert any(torch.equal(edge_x_dev[e], x[r, c]) for e in cand.tolist()), (nb, r, c)
+            nb += 1
+    hook_r.check()
+    hook_c.check()
+    assert nb == (E + bs - 1) // bs
+
+
 def test_edge_cases_and_errors():
     DGData, DGDataLoader, DGraph, HookManager, RecencyNeighborHook, _ = _mk()
     a = dict(src=np.array([1, 2, 3], np.int32), dst=np.array([2, 3, 4], np.int32), ts=np.array([1, 2, 3], np.int64))
