@@ -410,6 +410,12 @@ int tgmx_tgcn_concat(const float* a, int64_t lda, const float* b, const float* g
 int tgmx_tgcn_output(const float* u_pre, const float* c_pre, const float* H, int64_t n, float* out,
                      tgmx_stream_t stream);
 
+/* RandomNegativeEdgeSamplerHook (tgm/hooks/negatives/sampler.py:45-65): out_neg[i] uniform in [low, high), out_time =
+ * copy of time_in (the reference: torch.randint + edge_time.clone()), one launch.  Counter-based generator keyed by
+ * (seed, call, i): same distribution as the reference, a different stream than torch's. */
+int tgmx_random_negatives(int32_t low, int32_t high, int64_t n, uint64_t seed, uint64_t call, int32_t* out_neg,
+                          const int64_t* time_in, int64_t n_time, int64_t* out_time, tgmx_stream_t stream);
+
 /* DeduplicationHook (tgm/hooks/dedup.py:35-67): the sorted unique ids of up to 16 int32 id arrays (edge endpoints, extra
  * seed attributes, every hop's neighbor ids); -1 (padded slot) is skipped inside the kernel, ids outside [0, num_nodes)
  * raise TGMX_ST_SEED_RANGE.  out_ids needs room for min(total ids, num_nodes); *out_count (device) receives the number

@@ -82,6 +82,24 @@ __global__ __launch_bounds__(256) void dedup_compact_kernel(const unsigned int* 
   }
 }
 
+// RandomNegativeEdgeSamplerHook (tgm/hooks/negatives/sampler.py:45-65): neg[i] uniform in [low, high), neg_time = copy of
+// the batch's edge times -- the reference's randint + clone as one launch, counter-based generator (seed, call, i)
+__global__ __launch_bounds__(256) void random_negatives_kernel(int32_t* __restrict__ neg, long long n, int low, unsigned range,
+                                                               unsigned long long seed, unsigned long long call,
+                                                               const int64_t* __restrict__ t_in, int64_t* __restrict__ t_out,
+                                                               long long nt) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    unsigned long long x = seed ^ (call * 0x9E3779B97F4A7C15ull) ^ ((unsigned long long)i * 0xD1B54A32D192ED03ull);
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    neg[i] = low + (int)__umulhi((unsigned)(x >> 32), range);  // uniform up to 2^-32 * range
+  }
+  if (i < nt) t_out[i] = t_in[i];
+}
+
 }  // namespace tgmx
 
 using namespace tgmx;
@@ -119,5 +137,18 @@ extern "C" int tgmx_unique_ids(const int32_t* const* parts, const int64_t* part_
   hipLaunchKernelGGL(dedup_scan_kernel, dim3(1), dim3(1024), 0, st, bitmap, words, prefix, out_count);
   hipLaunchKernelGGL(dedup_compact_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, bitmap, prefix, words, out_ids);
   TGMX_CHECK_LAUNCH("unique_ids");
+  return TGMX_OK;
+}
+
+extern "C" int tgmx_random_negatives(int32_t low, int32_t high, int64_t n, uint64_t seed, uint64_t call, int32_t* out_neg,
+                                     const int64_t* time_in, int64_t n_time, int64_t* out_time, tgmx_stream_t stream) {
+  TGMX_REQUIRE(low < high && n >= 0 && n_time >= 0, "random_negatives: bad arguments low=%d high=%d n=%lld", low, high, (long long)n);
+  const long long work = n > n_time ? n : n_time;
+  if (work == 0) return TGMX_OK;
+  TGMX_REQUIRE((n == 0 || out_neg) && (n_time == 0 || (time_in && out_time)), "random_negatives: null pointer");
+  hipLaunchKernelGGL(random_negatives_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out_neg, (long long)n,
+                     low, (unsigned)((long long)high - low), (unsigned long long)seed, (unsigned long long)call, time_in, out_time,
+                     (long long)n_time);
+  TGMX_CHECK_LAUNCH("random_negatives");
   return TGMX_OK;
 }

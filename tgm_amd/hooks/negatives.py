@@ -2,8 +2,10 @@
 
 Same contract as tgm/hooks/negatives/sampler.py:15-65: ``neg`` = uniform int32
 ids in ``[low, high)`` (one per positive edge, times ``neg_ratio``), ``neg_time``
-= a copy of the batch's edge times.  This is a single ``randint`` on the batch's
-device; it produces the third seed group the neighbor sampler consumes.
+= a copy of the batch's edge times; it produces the third seed group the neighbor sampler consumes.
+On a ROCm device both outputs come from one ``tgmx_random_negatives`` launch (counter-based generator seeded from
+``seed`` or ``torch.initial_seed()``: reproducible under ``torch.manual_seed``, but not torch's Philox stream); host
+tensors use ``torch.randint`` like the reference.
 """
 from __future__ import annotations
 
@@ -11,6 +13,7 @@ from typing import Optional
 
 import torch
 
+from .. import _native
 from ..core import DGBatch, DGraph
 from .base import StatelessHook
 from .registry import hook
@@ -44,6 +47,8 @@ class RandomNegativeEdgeSamplerHook(StatelessHook):
         self.low, self.high, self.neg_ratio = low, high, neg_ratio
         self._seed = seed
         self._gen: Optional[torch.Generator] = None
+        self._rng_seed: Optional[int] = None  # device generator: (seed, call counter, element index)
+        self._calls = 0
         # extensions (defaults = the reference's behaviour): draw one negative per element of
         # batch.<like> and copy batch.<time_key>; used to sample for a rank's shard of the batch
         self._like, self._time_key = like, time_key
@@ -57,10 +62,23 @@ class RandomNegativeEdgeSamplerHook(StatelessHook):
         if n == 0:
             neg = torch.empty((0,), dtype=torch.int32, device=device)
             neg_time = torch.empty((0,), dtype=torch.int64, device=device)
+        elif device.type == 'cuda':
+            t_in = getattr(batch, self._time_key)
+            if t_in.dtype != torch.int64 or not t_in.is_contiguous():
+                t_in = t_in.to(torch.int64).contiguous()
+            neg = torch.empty(n, dtype=torch.int32, device=device)
+            neg_time = torch.empty(t_in.shape[0], dtype=torch.int64, device=device)
+            if self._rng_seed is None:
+                self._rng_seed = (self._seed if self._seed is not None else torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+            self._calls += 1
+            rc = _native.load().tgmx_random_negatives(self.low, self.high, n, self._rng_seed, self._calls, neg.data_ptr(), t_in.data_ptr(),
+                                                      t_in.shape[0], neg_time.data_ptr(), _native.stream_ptr(device.index))  # fmt: skip
+            if rc:
+                _native.check(rc, 'tgmx_random_negatives')
         else:
             gen = None
             if self._seed is not None:
-                if self._gen is None or self._gen.device != torch.empty(0, device=device).device:
+                if self._gen is None:
                     self._gen = torch.Generator(device=device)
                     self._gen.manual_seed(self._seed)
                 gen = self._gen
