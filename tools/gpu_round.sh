@@ -31,5 +31,11 @@ cd $ROOT
 python tools/pmc_extract.py $OUT/prof_fetch/fetch_results.db $OUT/prof_write/write_results.db $OUT/pmc_hop1.json
 python tools/bench_tgat.py 200 > $OUT/bench_tgat.json 2> $OUT/bench_tgat.err; cat $OUT/bench_tgat.json
 python tools/time_update.py > $OUT/time_update.json 2>/dev/null; cat $OUT/time_update.json
+python tools/bench_tgat_train.py 100 > $OUT/bench_tgat_train.json 2>/dev/null; cat $OUT/bench_tgat_train.json
+python tools/bench_tgn.py 300 > $OUT/bench_tgn.json 2>/dev/null; cat $OUT/bench_tgn.json
+python tools/bench_tgcn.py > $OUT/bench_tgcn.json 2>/dev/null; cat $OUT/bench_tgcn.json
+python bench.py --workload comment --steps 300 --cpu-batches 0 > $OUT/bench_comment_ring.json 2>/dev/null; cut -c1-200 $OUT/bench_comment_ring.json
+python bench.py --workload comment --mode csr --steps 300 --cpu-batches 0 > $OUT/bench_comment_csr.json 2>/dev/null; cut -c1-200 $OUT/bench_comment_csr.json
+python bench.py --workload review --steps 500 --cpu-batches 0 > $OUT/bench_review_ring.json 2>/dev/null; cut -c1-200 $OUT/bench_review_ring.json
 rm -f $OUT/prof_*/*.db   # the raw SQLite traces are tens of MB; the summary is what is kept
 head -30 $OUT/rocprof_summary.md
