@@ -216,7 +216,10 @@ struct TconvArgs {
   float scale;
 };
 
-// one wave per target node; online softmax over its incoming edges, head by head
+// one wave per target node; online softmax over its incoming edges, head by head.  The segment's edge ids and
+// sources are fetched 64 at a time with the lanes in parallel and handed out by shuffles, and the (k, v, e) rows of the
+// NEXT edge are requested before the current edge's reduction -- the loop used to pay three dependent global loads per
+// edge (order -> src -> rows).
 __global__ __launch_bounds__(256) void tconv_attend_kernel(const TconvArgs a) {
   const long long i = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (i >= a.U) return;
@@ -229,22 +232,29 @@ __global__ __launch_bounds__(256) void tconv_attend_kernel(const TconvArgs a) {
       // (C <= 64 in practice: one pass; for larger C the scores are recomputed per column chunk)
       const int c = c0 + lane;
       float m = -__builtin_inff(), l = 0.f, acc = 0.f;
-      for (long long p = lo; p < hi; ++p) {
-        const long long e = a.order[p];
-        const long long j = a.src[e];
-        float part = 0.f;
-        for (int cc = lane; cc < a.C; cc += kWave) {
-          const int col = h * a.C + cc;
-          part = __fmaf_rn(a.q[i * HC + col], a.k[j * HC + col] + a.eproj[e * HC + col], part);
+      for (long long p0 = lo; p0 < hi; p0 += kWave) {
+        const int n_here = (hi - p0) < kWave ? (int)(hi - p0) : kWave;
+        long long my_e = 0, my_j = 0;
+        if (lane < n_here) {
+          my_e = a.order[p0 + lane];
+          my_j = a.src[my_e];
         }
-        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
-        const float s = part * a.scale;
-        const float mn = s > m ? s : m;
-        const float corr = expf(m - mn), w = expf(s - mn);
-        const float val = c < a.C ? a.v[j * HC + h * a.C + c] + a.eproj[e * HC + h * a.C + c] : 0.f;
-        acc = acc * corr + w * val;
-        l = l * corr + w;
-        m = mn;
+        for (int t = 0; t < n_here; ++t) {
+          const long long e = __shfl(my_e, t), j = __shfl(my_j, t);
+          float part = 0.f;
+          for (int cc = lane; cc < a.C; cc += kWave) {
+            const int col = h * a.C + cc;
+            part = __fmaf_rn(a.q[i * HC + col], a.k[j * HC + col] + a.eproj[e * HC + col], part);
+          }
+          const float val = c < a.C ? a.v[j * HC + h * a.C + c] + a.eproj[e * HC + h * a.C + c] : 0.f;
+          for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+          const float s = part * a.scale;
+          const float mn = s > m ? s : m;
+          const float corr = expf(m - mn), w = expf(s - mn);
+          acc = acc * corr + w * val;
+          l = l * corr + w;
+          m = mn;
+        }
       }
       if (c < a.C) a.out[i * HC + h * a.C + c] += acc / l;
     }

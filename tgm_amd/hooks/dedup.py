@@ -75,9 +75,9 @@ class DeduplicationHook(StatelessHook, SeedableHook):
         ws = getattr(self, '_ws', None)
         if ws is None or ws[0] != (device, N):
             need = int(lib.tgmx_unique_ids_workspace_bytes(N))
-            ws = self._ws = ((device, N), torch.empty(need, dtype=torch.uint8, device=device), torch.zeros(1, dtype=torch.int64, device=device),
-                             torch.zeros(1, dtype=torch.int32, device=device))  # fmt: skip
-        _, work, count, status = ws
+            ws = self._ws = ((device, N), torch.empty(need, dtype=torch.uint8, device=device), torch.zeros(2, dtype=torch.int64, device=device))
+        _, work, cs = ws  # cs[0] = count (int64), cs[1] low word = status: ONE device -> host read for both
+        count, status = cs[0:1], cs[1:2].view(torch.int32)[0:1]
         out = torch.empty(min(total, N), dtype=torch.int32, device=device)
         n = len(parts)
         ptrs = (ctypes.c_void_p * n)(*[p.data_ptr() for p in parts])
@@ -85,9 +85,10 @@ class DeduplicationHook(StatelessHook, SeedableHook):
         with torch.cuda.device(device):
             _native.check(lib.tgmx_unique_ids(ptrs, sizes, n, N, work.data_ptr(), out.data_ptr(), count.data_ptr(), status.data_ptr(),
                                               _native.stream_ptr(device.index)), 'tgmx_unique_ids')  # fmt: skip
-        cnt, st = int(count.item()), int(status.item())  # the only sync: the result's size (torch.unique has the same one)
+        cnt, st = cs.tolist()  # the only sync: the result's size (torch.unique has the same one)
+        st &= 0xFFFFFFFF
         if st:
-            status.zero_()
+            cs[1].zero_()
             raise ValueError(f'node ids must satisfy 0 <= x < {N} (or -1 for a padded neighbor slot)')
         res = out[:cnt]
         return res if dtype == torch.int32 else res.to(dtype)

@@ -37,11 +37,11 @@ k = ks[0]
 def step(i):
     batch = loader(starts[i])
     nbr = batch.nbr_nids[0].flatten()
-    keep = nbr != -1
+    sel = (nbr != -1).nonzero().squeeze(1)  # one mask -> one index list (one sync) shared by the four gathers below
     seeds = torch.cat([batch.edge_src, batch.edge_dst, batch.neg]).repeat_interleave(k)
-    edge_index = torch.stack([batch.global_to_local(seeds[keep]), batch.global_to_local(nbr[keep])]).long()
-    e_t = batch.nbr_edge_time[0].flatten()[keep]
-    e_x = batch.nbr_edge_x[0].flatten(0, -2)[keep]
+    edge_index = torch.stack([batch.global_to_local(seeds[sel]), batch.global_to_local(nbr[sel])]).long()
+    e_t = batch.nbr_edge_time[0].flatten()[sel]
+    e_x = batch.nbr_edge_x[0].flatten(0, -2)[sel]
     z, lu = mem(batch.unique_nids)
     z2 = enc(z, lu, edge_index, e_t, e_x)
     mem.update_state(batch.edge_src, batch.edge_dst, batch.edge_time, batch.edge_x)
