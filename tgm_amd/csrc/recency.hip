@@ -615,6 +615,21 @@ __device__ __forceinline__ long long strided_max_ts(const int64_t* __restrict__ 
   return mx;
 }
 
+__device__ __forceinline__ long long strided_min_ts(const int64_t* __restrict__ ts, long long n, int tid, int nthr) {
+  long long mn = 0x7fffffffffffffffLL;
+  for (long long base = tid; base < n; base += 8ll * nthr) {
+    long long v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const long long x = base + (long long)u * nthr;
+      v[u] = x < n ? ts[x] : mn;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) mn = v[u] < mn ? v[u] : mn;
+  }
+  return mn;
+}
+
 __device__ __forceinline__ bool pair_after(long long ka, int pa, long long kb, int pb) {
   return ka > kb || (ka == kb && pa > pb);
 }
@@ -629,6 +644,46 @@ __device__ __forceinline__ void bitonic_select(long long& key, int& pay, long lo
   }
 }
 
+// Bitonic network over P = blockDim.x (key, entry index) pairs, ONE per thread: distances < 64 are lane shuffles, the
+// rest go through LDS.  PK: the entry index rides in the key's low 12 bits (see packed_key) -- one 64-bit compare and
+// two shuffles per step instead of a pair compare and three.
+constexpr int kPackBits = 12;  // entry index < 4096 = kBlockMaxM
+constexpr long long kPackBias = 1ll << 50;
+
+// int32-wrapped keys live in [-2^31 + tmin, 2^31 + tmax]: with |t| < 2^49 the biased key fits 51 bits
+__device__ __forceinline__ bool can_pack(int key_wrap32, long long tmin, long long tmax) {
+  return key_wrap32 != 0 && tmin > -(1ll << 49) && tmax < (1ll << 49);
+}
+__device__ __forceinline__ long long packed_key(long long key, int j) { return ((key + kPackBias) << kPackBits) | (long long)j; }
+
+template <bool PK>
+__device__ __forceinline__ void bitonic_sort_one(long long& key, int& pay, long long* s_key, int* s_pay, int tid, int P) {
+  for (int k = 2; k <= P; k <<= 1) {
+    for (int jj = k >> 1; jj > 0; jj >>= 1) {
+      long long pk;
+      int pp = 0;
+      if (jj < kWave) {
+        pk = __shfl_xor(key, jj);
+        if (!PK) pp = __shfl_xor(pay, jj);
+      } else {
+        s_key[tid] = key;
+        if (!PK) s_pay[tid] = pay;
+        __syncthreads();
+        pk = s_key[tid ^ jj];
+        if (!PK) pp = s_pay[tid ^ jj];
+        __syncthreads();
+      }
+      const bool low = (tid & jj) == 0, asc = (tid & k) == 0;
+      const bool mine_after = PK ? key > pk : pair_after(key, pay, pk, pp);
+      if ((low == asc) == mine_after) {
+        key = pk;
+        if (!PK) pay = pp;
+      }
+    }
+  }
+  if (PK) pay = (int)(key & ((1 << kPackBits) - 1));
+}
+
 template <int E, int MAXM, bool PRESORTED>
 __global__ __launch_bounds__(kBlockThreads) void ring_update_block_kernel(const UpdateArgs a) {
   constexpr int H = 2 * MAXM;  // hash load factor <= 0.5
@@ -639,7 +694,7 @@ __global__ __launch_bounds__(kBlockThreads) void ring_update_block_kernel(const 
   __shared__ int s_sn[MAXM];         // node at sorted position p (-1 invalid)
   __shared__ int s_len[MAXM];        // run length, stored at the run's first position
   __shared__ int h_key[H], h_maxp[H];
-  __shared__ long long red[kBlockThreads / kWave];
+  __shared__ long long red[kBlockThreads / kWave], red2[kBlockThreads / kWave];
   __shared__ int wave_tot[kBlockThreads / kWave];
   const int m = (int)a.m;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -666,79 +721,38 @@ __global__ __launch_bounds__(kBlockThreads) void ring_update_block_kernel(const 
       }
     }
   } else {
-    long long mx = strided_max_ts(a.ts, a.n, tid, nthr);
+    static_assert(PRESORTED || E == 1, "the in-kernel sort holds one element per thread");
+    long long mx = strided_max_ts(a.ts, a.n, tid, nthr), mn = strided_min_ts(a.ts, a.n, tid, nthr);
     for (int off = 32; off > 0; off >>= 1) {
-      const long long o = __shfl_xor(mx, off);
+      const long long o = __shfl_xor(mx, off), o2 = __shfl_xor(mn, off);
       mx = o > mx ? o : mx;
+      mn = o2 < mn ? o2 : mn;
     }
-    if (lane == 0) red[wave] = mx;
+    if (lane == 0) {
+      red[wave] = mx;
+      red2[wave] = mn;
+    }
     __syncthreads();
     mx = red[0];
-    for (int wv = 1; wv < nwaves; ++wv) mx = red[wv] > mx ? red[wv] : mx;
+    mn = red2[0];
+    for (int wv = 1; wv < nwaves; ++wv) {
+      mx = red[wv] > mx ? red[wv] : mx;
+      mn = red2[wv] < mn ? red2[wv] : mn;
+    }
     const long long span = mx + 1;
+    const bool packed = can_pack(a.key_wrap32, mn, mx);
 
-    long long key[E];
-#pragma unroll
-    for (int r = 0; r < E; ++r) {
-      const int j = tid * E + r;
-      key[r] = 0x7fffffffffffffffLL;  // padding sorts to the end
-      pay[r] = j;
-      if (j < m) {
-        int nd, nbr;
-        long long t, i;
-        update_entry(a, j, nd, nbr, t, i);
-        key[r] = update_key(nd, t, span, a.key_wrap32);
-      }
+    long long key = 0x7fffffffffffffffLL;  // padding sorts to the end
+    pay[0] = tid;
+    if (tid < m) {
+      int nd, nbr;
+      long long t, i;
+      update_entry(a, tid, nd, nbr, t, i);
+      key = update_key(nd, t, span, a.key_wrap32);
+      if (packed) key = packed_key(key, tid);
     }
-
-    for (int k = 2; k <= P; k <<= 1) {
-      for (int jj = k >> 1; jj > 0; jj >>= 1) {
-        if (jj < E) {  // both elements live in this thread
-          if constexpr (E >= 2) {
-            const int e0 = tid * E;
-            auto cswap = [&](int r, int r2) {
-              const bool asc = ((e0 + r) & k) == 0;
-              if (pair_after(key[r], pay[r], key[r2], pay[r2]) == asc) {
-                const long long tk = key[r]; key[r] = key[r2]; key[r2] = tk;
-                const int tp = pay[r]; pay[r] = pay[r2]; pay[r2] = tp;
-              }
-            };
-            if (jj == 1) {
-              cswap(0, 1);
-              if constexpr (E == 4) cswap(2, 3);
-            } else {
-              if constexpr (E == 4) {
-                cswap(0, 2);
-                cswap(1, 3);
-              }
-            }
-          }
-        } else if (jj < kWave * E) {  // partner is another lane of this wave
-          const int lm = jj / E;
-#pragma unroll
-          for (int r = 0; r < E; ++r) {
-            const long long pk = __shfl_xor(key[r], lm);
-            const int pp = __shfl_xor(pay[r], lm);
-            bitonic_select(key[r], pay[r], pk, pp, tid * E + r, jj, k);
-          }
-        } else {  // partner is in another wave: exchange through LDS
-#pragma unroll
-          for (int r = 0; r < E; ++r) {
-            s_key[tid * E + r] = key[r];
-            s_pay[tid * E + r] = pay[r];
-          }
-          __syncthreads();
-#pragma unroll
-          for (int r = 0; r < E; ++r) {
-            const int e = tid * E + r;
-            const long long pk = s_key[e ^ jj];
-            const int pp = s_pay[e ^ jj];
-            bitonic_select(key[r], pay[r], pk, pp, e, jj, k);
-          }
-          __syncthreads();
-        }
-      }
-    }
+    if (packed) bitonic_sort_one<true>(key, pay[0], s_key, s_pay, tid, P);
+    else bitonic_sort_one<false>(key, pay[0], s_key, s_pay, tid, P);
 #pragma unroll
     for (int r = 0; r < E; ++r) {
       const int p = tid * E + r;
@@ -865,18 +879,27 @@ constexpr int kChunk = 256;
 __global__ __launch_bounds__(kChunk) void ring_update_chunk_sort_kernel(const UpdateArgs a) {
   __shared__ long long s_key[kChunk];
   __shared__ int s_pay[kChunk];
-  __shared__ long long red[kChunk / kWave];
+  __shared__ long long red[kChunk / kWave], red2[kChunk / kWave];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  long long mx = strided_max_ts(a.ts, a.n, tid, kChunk);
+  long long mx = strided_max_ts(a.ts, a.n, tid, kChunk), mn = strided_min_ts(a.ts, a.n, tid, kChunk);
   for (int off = 32; off > 0; off >>= 1) {
-    const long long o = __shfl_xor(mx, off);
+    const long long o = __shfl_xor(mx, off), o2 = __shfl_xor(mn, off);
     mx = o > mx ? o : mx;
+    mn = o2 < mn ? o2 : mn;
   }
-  if (lane == 0) red[wave] = mx;
+  if (lane == 0) {
+    red[wave] = mx;
+    red2[wave] = mn;
+  }
   __syncthreads();
   mx = red[0];
-  for (int w = 1; w < kChunk / kWave; ++w) mx = red[w] > mx ? red[w] : mx;
+  mn = red2[0];
+  for (int w = 1; w < kChunk / kWave; ++w) {
+    mx = red[w] > mx ? red[w] : mx;
+    mn = red2[w] < mn ? red2[w] : mn;
+  }
   const long long span = mx + 1;
+  const bool packed = can_pack(a.key_wrap32, mn, mx);  // the same verdict in every chunk: keys stay comparable
 
   const long long j = (long long)blockIdx.x * kChunk + tid;
   long long key = 0x7fffffffffffffffLL;  // padding of the last chunk sorts to its end
@@ -886,25 +909,10 @@ __global__ __launch_bounds__(kChunk) void ring_update_chunk_sort_kernel(const Up
     long long t, i;
     update_entry(a, j, node, nbr, t, i);
     key = update_key(node, t, span, a.key_wrap32);
+    if (packed) key = packed_key(key, (int)j);
   }
-  for (int k = 2; k <= kChunk; k <<= 1) {
-    for (int jj = k >> 1; jj > 0; jj >>= 1) {
-      long long pk;
-      int pp;
-      if (jj < kWave) {
-        pk = __shfl_xor(key, jj);
-        pp = __shfl_xor(pay, jj);
-      } else {
-        s_key[tid] = key;
-        s_pay[tid] = pay;
-        __syncthreads();
-        pk = s_key[tid ^ jj];
-        pp = s_pay[tid ^ jj];
-        __syncthreads();
-      }
-      bitonic_select(key, pay, pk, pp, tid, jj, k);
-    }
-  }
+  if (packed) bitonic_sort_one<true>(key, pay, s_key, s_pay, tid, kChunk);
+  else bitonic_sort_one<false>(key, pay, s_key, s_pay, tid, kChunk);
   a.key[j] = key;
   a.node[j] = pay;  // chunk-sorted entry index
 }
