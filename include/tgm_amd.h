@@ -425,6 +425,12 @@ size_t tgmx_unique_ids_workspace_bytes(int32_t num_nodes);
 int tgmx_unique_ids(const int32_t* const* parts, const int64_t* part_sizes, int32_t num_parts, int32_t num_nodes,
                     void* workspace, int32_t* out_ids, int64_t* out_count, int32_t* status, tgmx_stream_t stream);
 
+/* Group n <= 1024 int32 ids in one launch: stable sort by id, the permutation (sorted position -> input index), every
+ * position's run [run_lo, run_hi) and a first-of-run flag; any output may be NULL.  Replaces the torch.sort +
+ * searchsorted glue around the TGN message store and commit (tgm/nn/encoder/tgn.py:165-177, 218-229). */
+int tgmx_group_ids(const int32_t* ids, int32_t n, int32_t* sorted, int64_t* perm, int64_t* run_lo, int64_t* run_hi,
+                   uint8_t* first, tgmx_stream_t stream);
+
 /* ---- TGN backward building blocks (training; composed by tgm_amd/nn/_tgn_train.py).  The reference trains through
  * torch autograd (examples/linkproppred/tgn.py:97-118); memory / last_update are buffers, so the parameters reached are
  * the shared Time2Vec (tgm/nn/modules/time_encoding.py), the GRU cell and the TransformerConv projections.  The dense

@@ -630,10 +630,6 @@ __device__ __forceinline__ long long strided_min_ts(const int64_t* __restrict__ 
   return mn;
 }
 
-__device__ __forceinline__ bool pair_after(long long ka, int pa, long long kb, int pb) {
-  return ka > kb || (ka == kb && pa > pb);
-}
-
 // element e (mine) against its partner at distance jj in the step of bitonic stage k: keep min or max
 __device__ __forceinline__ void bitonic_select(long long& key, int& pay, long long pk, int pp, int e, int jj, int k) {
   const bool low = (e & jj) == 0, asc = (e & k) == 0;
@@ -642,46 +638,6 @@ __device__ __forceinline__ void bitonic_select(long long& key, int& pay, long lo
     key = pk;
     pay = pp;
   }
-}
-
-// Bitonic network over P = blockDim.x (key, entry index) pairs, ONE per thread: distances < 64 are lane shuffles, the
-// rest go through LDS.  PK: the entry index rides in the key's low 12 bits (see packed_key) -- one 64-bit compare and
-// two shuffles per step instead of a pair compare and three.
-constexpr int kPackBits = 12;  // entry index < 4096 = kBlockMaxM
-constexpr long long kPackBias = 1ll << 50;
-
-// int32-wrapped keys live in [-2^31 + tmin, 2^31 + tmax]: with |t| < 2^49 the biased key fits 51 bits
-__device__ __forceinline__ bool can_pack(int key_wrap32, long long tmin, long long tmax) {
-  return key_wrap32 != 0 && tmin > -(1ll << 49) && tmax < (1ll << 49);
-}
-__device__ __forceinline__ long long packed_key(long long key, int j) { return ((key + kPackBias) << kPackBits) | (long long)j; }
-
-template <bool PK>
-__device__ __forceinline__ void bitonic_sort_one(long long& key, int& pay, long long* s_key, int* s_pay, int tid, int P) {
-  for (int k = 2; k <= P; k <<= 1) {
-    for (int jj = k >> 1; jj > 0; jj >>= 1) {
-      long long pk;
-      int pp = 0;
-      if (jj < kWave) {
-        pk = __shfl_xor(key, jj);
-        if (!PK) pp = __shfl_xor(pay, jj);
-      } else {
-        s_key[tid] = key;
-        if (!PK) s_pay[tid] = pay;
-        __syncthreads();
-        pk = s_key[tid ^ jj];
-        if (!PK) pp = s_pay[tid ^ jj];
-        __syncthreads();
-      }
-      const bool low = (tid & jj) == 0, asc = (tid & k) == 0;
-      const bool mine_after = PK ? key > pk : pair_after(key, pay, pk, pp);
-      if ((low == asc) == mine_after) {
-        key = pk;
-        if (!PK) pay = pp;
-      }
-    }
-  }
-  if (PK) pay = (int)(key & ((1 << kPackBits) - 1));
 }
 
 template <int E, int MAXM, bool PRESORTED>

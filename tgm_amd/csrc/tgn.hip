@@ -261,6 +261,49 @@ __global__ __launch_bounds__(256) void tconv_attend_kernel(const TconvArgs a) {
   }
 }
 
+// Group a small id array (n <= 1024) in ONE launch: stable sort by id (the entry index rides in the key's low bits),
+// the permutation, every position's run bounds and a first-of-run flag -- what the host otherwise assembles from
+// torch.sort + 2 x searchsorted (message store, tgn.py:218-229) or sort + compare (unique commit rows, tgn.py:165-177).
+__global__ __launch_bounds__(1024) void group_ids_kernel(const int32_t* __restrict__ ids, int n, int32_t* __restrict__ sorted,
+                                                         int64_t* __restrict__ perm, int64_t* __restrict__ run_lo,
+                                                         int64_t* __restrict__ run_hi, unsigned char* __restrict__ first) {
+  __shared__ long long s_key[1024];
+  __shared__ int s_pay[1024];
+  __shared__ int s_id[1024];
+  __shared__ int s_start[1024];
+  __shared__ int wave_tot[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, P = blockDim.x;
+  long long key = 0x7fffffffffffffffLL;
+  int pay = tid;
+  if (tid < n) key = (((long long)ids[tid] + (1ll << 31)) << kPackBits) | (long long)tid;  // ids may be negative (pads)
+  bitonic_sort_one<true>(key, pay, s_key, s_pay, tid, P);
+  const int id = tid < n ? (int)((key >> kPackBits) - (1ll << 31)) : 0x7fffffff;
+  s_id[tid] = id;
+  __syncthreads();
+  // run start = last position <= tid that opens a run (max-scan thread -> wave -> block)
+  const bool opens = tid == 0 || s_id[tid - 1] != id;
+  int incl = opens ? tid : 0;
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    const int o = __shfl_up(incl, off);
+    if (lane >= off) incl = o > incl ? o : incl;
+  }
+  if (lane == kWave - 1) wave_tot[wave] = incl;
+  __syncthreads();
+  for (int w = 0; w < wave; ++w) incl = wave_tot[w] > incl ? wave_tot[w] : incl;
+  s_start[tid] = incl;
+  __syncthreads();
+  if (tid >= n) return;
+  // run end: first later position that opens a run (walk is short: runs are per-node event counts of one batch)
+  int hi = tid + 1;
+  while (hi < n && s_start[hi] == incl) ++hi;
+  if (sorted) sorted[tid] = id;
+  if (perm) perm[tid] = pay;
+  if (run_lo) run_lo[tid] = incl;
+  if (run_hi) run_hi[tid] = hi;
+  if (first) first[tid] = opens ? 1 : 0;
+}
+
 }  // namespace tgmx
 
 using namespace tgmx;
@@ -344,5 +387,17 @@ extern "C" int tgmx_tconv_attend(const float* q, const float* k, const float* v,
   TconvArgs a{q, k, v, eproj, order, src, seg_lo, seg_hi, out, U, H, C, scale};
   hipLaunchKernelGGL(tconv_attend_kernel, dim3((unsigned)((U + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
   TGMX_CHECK_LAUNCH("tconv_attend");
+  return TGMX_OK;
+}
+
+extern "C" int tgmx_group_ids(const int32_t* ids, int32_t n, int32_t* sorted, int64_t* perm, int64_t* run_lo, int64_t* run_hi,
+                              uint8_t* first, tgmx_stream_t stream) {
+  TGMX_REQUIRE(n >= 0 && n <= 1024, "group_ids: n=%d (at most 1024 ids per call)", n);
+  if (n == 0) return TGMX_OK;
+  TGMX_REQUIRE(ids, "group_ids: null pointer");
+  int P = 64;
+  while (P < n) P <<= 1;
+  hipLaunchKernelGGL(group_ids_kernel, dim3(1), dim3(P), 0, (hipStream_t)stream, ids, n, sorted, perm, run_lo, run_hi, first);
+  TGMX_CHECK_LAUNCH("group_ids");
   return TGMX_OK;
 }

@@ -221,9 +221,16 @@ class TGNMemory(nn.Module):
         lib = _native.load()
         n = node.numel()
         self._ensure_store(n)
-        node_sorted, perm = torch.sort(node, stable=True)
-        left = torch.searchsorted(node_sorted, node_sorted, right=False)
-        right = torch.searchsorted(node_sorted, node_sorted, right=True)
+        if n <= 1024:  # one launch: stable sort by node + run bounds (csrc/tgn.hip group_ids_kernel)
+            dev = node.device
+            node_sorted = torch.empty(n, dtype=torch.int32, device=dev)
+            perm, left, right = (torch.empty(n, dtype=torch.int64, device=dev) for _ in range(3))
+            _native.check(lib.tgmx_group_ids(node.data_ptr(), n, node_sorted.data_ptr(), perm.data_ptr(), left.data_ptr(), right.data_ptr(),
+                                             None, _native.stream_ptr()), 'tgmx_group_ids')  # fmt: skip
+        else:
+            node_sorted, perm = torch.sort(node, stable=True)
+            left = torch.searchsorted(node_sorted, node_sorted, right=False)
+            right = torch.searchsorted(node_sorted, node_sorted, right=True)
         _native.check(
             lib.tgmx_tgn_store(perm.data_ptr(), node_sorted.data_ptr(), left.data_ptr(), right.data_ptr(), other.data_ptr(), t.data_ptr(),
                                _native.ptr(raw), self.raw_msg_dim, n, self._log_len, self._log_other.data_ptr(), self._log_t.data_ptr(),
@@ -249,9 +256,15 @@ class TGNMemory(nn.Module):
         t = t.to(torch.int64).contiguous()
         raw = _ops._f32c(raw_msg, 'raw_msg') if self.raw_msg_dim else None
         both = torch.cat([src32, dst32])
-        srt, _ = torch.sort(both)
-        first = torch.ones(srt.numel(), dtype=torch.uint8, device=srt.device)
-        first[1:] = (srt[1:] != srt[:-1]).to(torch.uint8)
+        if both.numel() <= 1024:
+            srt = torch.empty_like(both)
+            first = torch.empty(both.numel(), dtype=torch.uint8, device=both.device)
+            _native.check(_native.load().tgmx_group_ids(both.data_ptr(), both.numel(), srt.data_ptr(), None, None, None, first.data_ptr(),
+                                                        _native.stream_ptr()), 'tgmx_group_ids')  # fmt: skip
+        else:
+            srt, _ = torch.sort(both)
+            first = torch.ones(srt.numel(), dtype=torch.uint8, device=srt.device)
+            first[1:] = (srt[1:] != srt[:-1]).to(torch.uint8)
         if self.training:
             self._commit(srt, first)
             self._store_role(0, src32, dst32, t, raw)
