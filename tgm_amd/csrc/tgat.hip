@@ -740,11 +740,19 @@ __global__ __launch_bounds__(256) void tgat_attn_reduce_reg_kernel(const AttnArg
   float tz0[G], tz1[G], P[64];
 #pragma unroll
   for (int j = 0; j < 64; ++j) P[j] = 0.f;
+  // rows whose k slots all carry the same time delta (every padded seed of a deeper hop: nbr_t = 0 in all slots) need
+  // ONE Time2Vec evaluation per column, not k -- identical arithmetic, ~3/4 of the layer-1 rows at the headline shape
+  const bool same_dt = __all(lane >= k || my_dt == __shfl(my_dt, 0));
 #pragma unroll
   for (int s = 0; s < G; ++s) {
     const float dt = __shfl(my_dt, s);  // compile-time lane: v_readlane
-    tz0[s] = t0_on ? cos_t2v(__fmaf_rn(dt, w0, b0)) : 0.f;
-    tz1[s] = t1_on ? cos_t2v(__fmaf_rn(dt, w1, b1)) : 0.f;
+    if (s > 0 && same_dt) {
+      tz0[s] = tz0[0];
+      tz1[s] = tz1[0];
+    } else {
+      tz0[s] = t0_on ? cos_t2v(__fmaf_rn(dt, w0, b0)) : 0.f;
+      tz1[s] = t1_on ? cos_t2v(__fmaf_rn(dt, w1, b1)) : 0.f;
+    }
 #pragma unroll
     for (int h = 0; h < H; ++h) {
       float p = qe[h].x * ze[s].x;
