@@ -295,6 +295,73 @@ def test_full_size_wiki_properties():
     assert nb == (E + bs - 1) // bs
 
 
+def test_direct_entry_points_match_the_step_call():
+    """tgmx_ring_lookup / tgmx_ring_update / tgmx_recency_lookup_csr called one by one (what INTEGRATION.md's ctypes stub
+    does) give exactly what the hooks get from tgmx_recency_step."""
+    DGData, DGDataLoader, DGraph, HookManager, RecencyNeighborHook, ReplayNegatives = _mk()
+    from tgm_amd import _native
+    from tgm_amd.index import build_csr
+
+    lib = _native.load()
+    N, E, D, bs, ks = 500, 6000, 8, 150, [6, 4]
+    a, edge_x = _random_stream(31, N, E, D, 4000)
+    B = max(ks)
+    # reference path: the hooks (one step call per batch)
+    outs = {}
+    for mode in ('ring', 'csr'):
+        hook = RecencyNeighborHook(N, ks, ['edge_src', 'edge_dst', 'neg'], ['edge_time', 'edge_time', 'neg_time'], mode=mode, key_arith='int64', batch_size=bs)
+        hm = HookManager(keys=['k'])
+        hm.register('k', ReplayNegatives(torch.from_numpy(a['neg']).to(DEV)))
+        hm.register('k', hook)
+        with hm.activate('k'):
+            outs[mode] = [[(b.nbr_nids[h].clone(), b.nbr_edge_time[h].clone(), b.nbr_edge_x[h].clone()) for h in range(2)]
+                          for b in DGDataLoader(_graph(a, 0, E, edge_x), batch_size=bs, hook_manager=hm)]  # fmt: skip
+    # direct path
+    T = lambda x: torch.from_numpy(x).to(DEV)
+    src, dst, ts, neg, ex = T(a['src']), T(a['dst']), T(a['ts']), T(a['neg']), edge_x.to(DEV)
+    ring = torch.empty((N * B, 2), dtype=torch.int64, device=DEV)
+    wpos = torch.empty(N, dtype=torch.int32, device=DEV)
+    ring_x = torch.empty((N * B, D), dtype=torch.float32, device=DEV)
+    status = torch.zeros(1, dtype=torch.int32, device=DEV)
+    st = _native.stream_ptr(0)
+    assert lib.tgmx_ring_reset(ring.data_ptr(), wpos.data_ptr(), B, N, st) == 0
+    scratch = torch.empty(int(lib.tgmx_ring_update_scratch_bytes(bs, 0)), dtype=torch.uint8, device=DEV)
+    csr = build_csr(src, dst, ts, N, batch_size=bs)
+    for b in range(E // bs):
+        lo, hi = b * bs, (b + 1) * bs
+        seeds = torch.cat([src[lo:hi], dst[lo:hi], neg[lo:hi]])
+        times = torch.cat([ts[lo:hi]] * 3)
+        for mode in ('ring', 'csr'):
+            cur_n, cur_t = seeds, times
+            for h, k in enumerate(ks):
+                S = cur_n.numel()
+                nid = torch.empty((S, k), dtype=torch.int32, device=DEV)
+                nts = torch.empty((S, k), dtype=torch.int64, device=DEV)
+                nx = torch.empty((S, k, D), dtype=torch.float32, device=DEV)
+                if mode == 'ring':
+                    rc = lib.tgmx_ring_lookup(ring.data_ptr(), wpos.data_ptr(), ring_x.data_ptr(), D, cur_n.data_ptr(), cur_t.data_ptr(), S, k, B, N,
+                                              1 if h else 0, nid.data_ptr(), nts.data_ptr(), nx.data_ptr(), status.data_ptr(), st, None, None)
+                else:
+                    rc = lib.tgmx_recency_lookup_csr(csr.indptr.data_ptr(), csr.adj.data_ptr(), ex.data_ptr(), D, cur_n.data_ptr(), cur_t.data_ptr(), S, k,
+                                                     B, 0, lo, N, 1 if h else 0, nid.data_ptr(), nts.data_ptr(), nx.data_ptr(), status.data_ptr(), st, None, None)
+                assert rc == 0
+                r_n, r_t, r_x = outs[mode][b][h]
+                assert torch.equal(nid, r_n) and torch.equal(nts, r_t) and torch.equal(nx, r_x), (mode, b, h)
+                cur_n, cur_t = nid.view(-1), nts.view(-1)
+        rc = lib.tgmx_ring_update(ring.data_ptr(), wpos.data_ptr(), ring_x.data_ptr(), D, B, N, src[lo:hi].data_ptr(), dst[lo:hi].data_ptr(),
+                                  ts[lo:hi].data_ptr(), ex[lo:hi].data_ptr(), bs, lo, 0, 0, scratch.data_ptr(), status.data_ptr(), st)
+        assert rc == 0
+    assert int(status.item()) == 0
+    # timing events of the ABI
+    t = _native.KernelTimer()
+    S = 64
+    nid = torch.empty((S, 4), dtype=torch.int32, device=DEV); nts = torch.empty((S, 4), dtype=torch.int64, device=DEV); nx = torch.empty((S, 4, D), device=DEV)
+    assert lib.tgmx_ring_lookup(ring.data_ptr(), wpos.data_ptr(), ring_x.data_ptr(), D, seeds.data_ptr(), times.data_ptr(), S, 4, B, N, 0, nid.data_ptr(),
+                                nts.data_ptr(), nx.data_ptr(), status.data_ptr(), st, t.start, t.stop) == 0
+    torch.cuda.synchronize()
+    assert 0.0 < t.elapsed_ms() < 50.0
+
+
 def test_edge_cases_and_errors():
     DGData, DGDataLoader, DGraph, HookManager, RecencyNeighborHook, _ = _mk()
     a = dict(src=np.array([1, 2, 3], np.int32), dst=np.array([2, 3, 4], np.int32), ts=np.array([1, 2, 3], np.int64))
