@@ -38,6 +38,23 @@ def test_time2vec_matches_reference():
     close(enc2(t.float().view(4, 5)), torch.from_numpy(z['out_jitter']).view(4, 5, 16), 'time2vec float 2-D')
 
 
+def test_device_cosine_accuracy_by_range():
+    """cos_t2v against float64 cos, range by range (separate launches: whole waves take the float reduction below 8e6
+    or the double one above) -- including the edge of the float path, where the quotient needs its correction step."""
+    from tgm_amd.nn import _ops
+
+    g = torch.Generator().manual_seed(0)
+    w, b = torch.ones(1, device=DEV), torch.zeros(1, device=DEV)
+    r = lambda n: torch.rand(n, generator=g)
+    for name, x in [('[0,10)', r(200000) * 10), ('[0,3e6)', r(200000) * 3e6), ('[3e6,8e6)', 3e6 + r(400000) * 4.999e6),
+                    ('(-8e6,0]', -r(400000) * 7.999e6), ('[8e6,2.1e9)', 8e6 + r(200000) * 2.1e9),
+                    ('specials', torch.tensor([0.0, 1e-30, 3.14159265, 1.5707963, 7999999.5, -7999999.5, 8000000.0, 2147483648.0]))]:  # fmt: skip
+        x = x.float().to(DEV)
+        got = _ops.time2vec(x, w, b)[:, 0].cpu().double()
+        err = (got - torch.cos(x.cpu().double())).abs().max().item()
+        assert err < 2.5e-7, f'{name}: max abs error {err:.3e}'
+
+
 @pytest.mark.parametrize('case', gu.ATTN_CASES)
 def test_temporal_attention_matches_reference(case):
     from tgm_amd.nn import TemporalAttention
