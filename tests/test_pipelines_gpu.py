@@ -177,3 +177,30 @@ def test_random_negatives_on_device():
     counts = torch.bincount(outs[0][0] - 100, minlength=64).double()
     sigma = (E / 64 * (1 - 1 / 64)) ** 0.5
     assert bool(((counts - E / 64).abs() < 5 * sigma).all()), counts
+
+
+@pytest.mark.parametrize('N,n_ids', [(31, 100), (1024 * 32, 5000), (200_003, 170_000), (1_000_000, 600_000)])
+def test_unique_ids_matches_torch_unique(N, n_ids):
+    """tgmx_unique_ids (bitmap + multi-round popcount scan) against torch.unique, with pads and several parts."""
+    import ctypes
+
+    from tgm_amd import _native
+
+    lib = _native.load()
+    g = torch.Generator().manual_seed(N)
+    parts = [torch.randint(0, N, (n_ids // 3,), generator=g, dtype=torch.int32), torch.randint(0, max(N // 7, 1), (n_ids // 3,), generator=g, dtype=torch.int32),
+             torch.randint(-1, N, (n_ids - 2 * (n_ids // 3),), generator=g, dtype=torch.int32), torch.tensor([N - 1, 0, -1], dtype=torch.int32)]  # fmt: skip
+    dev_parts = [p.to(DEV) for p in parts]
+    allv = torch.cat(parts)
+    exp = torch.unique(allv[allv >= 0])
+    ws = torch.empty(int(lib.tgmx_unique_ids_workspace_bytes(N)), dtype=torch.uint8, device=DEV)
+    out = torch.empty(min(allv.numel(), N), dtype=torch.int32, device=DEV)
+    cs = torch.zeros(2, dtype=torch.int64, device=DEV)
+    ptrs = (ctypes.c_void_p * 4)(*[p.data_ptr() for p in dev_parts])
+    sizes = (ctypes.c_int64 * 4)(*[p.numel() for p in dev_parts])
+    rc = lib.tgmx_unique_ids(ptrs, sizes, 4, N, ws.data_ptr(), out.data_ptr(), cs[0:1].data_ptr(), cs[1:2].view(torch.int32)[0:1].data_ptr(),
+                             _native.stream_ptr(0))
+    assert rc == 0
+    cnt, st = cs.tolist()
+    assert st == 0 and cnt == exp.numel()
+    assert torch.equal(out[:cnt].cpu(), exp)
