@@ -295,6 +295,34 @@ def test_full_size_wiki_properties():
     assert nb == (E + bs - 1) // bs
 
 
+def test_csr_mode_with_irregular_batch_starts():
+    """Static index built from explicit, irregular batch boundaries (time-unit batching gives such schedules) against
+    the streaming rings fed the same batches; also a directed stream."""
+    DGData, DGDataLoader, DGraph, HookManager, RecencyNeighborHook, ReplayNegatives = _mk()
+    N, E, D, ks = 300, 5000, 4, [7, 3]
+    a, edge_x = _random_stream(5, N, E, D, 2500)  # ~2 edges per timestamp
+    rng = np.random.default_rng(9)
+    cuts = np.unique(np.concatenate([[0], np.sort(rng.integers(1, E, 60)), [E]]))
+    starts = cuts[:-1].tolist()
+    for directed in (False, True):
+        hooks = {
+            'ring': RecencyNeighborHook(N, ks, ['edge_src', 'edge_dst', 'neg'], ['edge_time', 'edge_time', 'neg_time'], mode='ring', key_arith='int64', directed=directed),
+            'csr': RecencyNeighborHook(N, ks, ['edge_src', 'edge_dst', 'neg'], ['edge_time', 'edge_time', 'neg_time'], mode='csr', batch_starts=starts, directed=directed),
+        }
+        dg = _graph(a, 0, E, edge_x)
+        neg = torch.from_numpy(a['neg']).to(DEV)
+        for lo, hi in zip(cuts[:-1].tolist(), cuts[1:].tolist()):
+            outs = {}
+            for mode, hook in hooks.items():
+                batch = dg.slice_events(lo, hi).materialize()
+                batch.neg, batch.neg_time = neg[lo:hi].clone(), batch.edge_time.clone()
+                b = hook(dg, batch)
+                outs[mode] = [(b.nbr_nids[h], b.nbr_edge_time[h], b.nbr_edge_x[h]) for h in range(2)]
+            for h in range(2):
+                for x, y in zip(outs['ring'][h], outs['csr'][h]):
+                    assert torch.equal(x, y), (directed, lo, hi, h)
+
+
 def test_direct_entry_points_match_the_step_call():
     """tgmx_ring_lookup / tgmx_ring_update / tgmx_recency_lookup_csr called one by one (what INTEGRATION.md's ctypes stub
     does) give exactly what the hooks get from tgmx_recency_step."""
