@@ -72,6 +72,32 @@ def test_temporal_attention_matches_reference(case):
           nbr_time_feat=T('nbr_time_feat'), valid_nbr_mask=T('mask'))  # fmt: skip
 
 
+@pytest.mark.parametrize('H,k,nd,ed,td', [(1, 3, 2, 4, 5), (1, 64, 4, 8, 6), (2, 33, 3, 4, 7), (4, 20, 8, 12, 16), (8, 10, 8, 4, 12),
+                                          (8, 20, 16, 2, 24), (2, 20, 4, 172, 100), (4, 1, 5, 3, 3)])
+def test_temporal_attention_shape_sweep_vs_oracle(H, k, nd, ed, td):
+    """Head counts 1..8, k from 1 to 64 (several score groups when k * H > 64), fully masked rows:
+    TemporalAttention (the module-level entry: Time2Vec'd inputs given) against the torch-fp32 oracle."""
+    from oracle import tgat_ref
+    from tgm_amd.nn import TemporalAttention
+
+    torch.manual_seed(H * 100 + k)
+    R = 37
+    m = TemporalAttention(H, nd, ed, td, dropout=0.0).to(DEV).eval()
+    with torch.no_grad():
+        for p in m.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    node_x, time_feat = torch.randn(R, nd), torch.randn(R, td)
+    edge_feat, nbr_x, nbr_t = torch.randn(R, k, ed), torch.randn(R, k, nd), torch.randn(R, k, td)
+    mask = torch.rand(R, k) < 0.6
+    mask[0] = False  # a fully masked row: uniform attention over the masked slots, like the reference
+    mask[1] = True
+    params = {'a.' + n: v.detach().cpu() for n, v in m.state_dict().items()}
+    ref = tgat_ref.temporal_attention(params, 'a.', H, node_x, time_feat, edge_feat, nbr_x, nbr_t, mask)
+    out = m(node_x=node_x.to(DEV), time_feat=time_feat.to(DEV), edge_feat=edge_feat.to(DEV), nbr_node_feat=nbr_x.to(DEV),
+            nbr_time_feat=nbr_t.to(DEV), valid_nbr_mask=mask.to(DEV))  # fmt: skip
+    close(out, ref, f'H={H} k={k}')
+
+
 @pytest.mark.parametrize('case', gu.TGAT_CASES)
 def test_tgat_forward_matches_reference(case):
     from tgm_amd.nn import TGAT
