@@ -141,3 +141,37 @@ def test_tgat_headline_shape_vs_oracle():
                                   cpu(batch.nbr_edge_x), cpu(batch.nbr_edge_time))  # fmt: skip
     assert z.shape == (600, 172)
     close(z, z_ref, 'headline shape')
+
+
+@pytest.mark.parametrize('nd,ed,td,emb,H,ks,S0,L', [(8, 12, 16, 32, 4, [16, 16], 144, 2), (3, 8, 10, 20, 1, [30], 2100, 1), (16, 4, 6, 24, 2, [8, 8, 8], 40, 3),
+                                                   (1, 16, 12, 16, 8, [20, 20], 110, 2)])
+def test_tgat_fused_inference_paths_vs_oracle(nd, ed, td, emb, H, ks, S0, L):
+    """Shapes that take the fused row-tile chain (>= 2048 rows in a layer) and the folded-query GEMM with other head
+    counts, widths, depths and k than the example dims; random hop trees with pads (-1 ids, zero times / features)."""
+    from oracle import tgat_ref
+    from tgm_amd.nn import TGAT
+
+    torch.manual_seed(nd * 7 + H)
+    N = 500
+    enc = TGAT(node_dim=nd, edge_dim=ed, time_dim=td, embed_dim=emb, num_layers=L, n_heads=H).to(DEV).eval()
+    with torch.no_grad():
+        for p in enc.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    node_x = torch.randn(N, nd)
+    seed_n, seed_t, nbr_n, nbr_t, nbr_x = [], [], [], [], []
+    cur_n = torch.randint(0, N, (S0,), dtype=torch.int32)
+    cur_t = torch.randint(1000, 2000, (S0,), dtype=torch.int64)
+    for k in ks:
+        S = cur_n.numel()
+        n = torch.randint(0, N, (S, k), dtype=torch.int32)
+        t = cur_t[:, None] - torch.randint(1, 900, (S, k), dtype=torch.int64)
+        x = torch.randn(S, k, ed)
+        pad = (torch.rand(S, k) < 0.4) | (cur_n[:, None] < 0)
+        n[pad], t[pad], x[pad] = -1, 0, 0.0
+        seed_n.append(cur_n); seed_t.append(cur_t); nbr_n.append(n); nbr_t.append(t); nbr_x.append(x)
+        cur_n, cur_t = n.reshape(-1), t.reshape(-1)
+    params = {k_: v.detach().cpu() for k_, v in enc.state_dict().items()}
+    dev = lambda v: [t.to(DEV) for t in v]
+    z = enc(node_x.to(DEV), dev(seed_n), dev(seed_t), dev(nbr_n), dev(nbr_x), dev(nbr_t))
+    z_ref = tgat_ref.tgat_forward(params, H, node_x, seed_n, seed_t, nbr_n, nbr_x, nbr_t)
+    close(z, z_ref, f'nd={nd} H={H} ks={ks}')
