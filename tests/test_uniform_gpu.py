@@ -138,3 +138,33 @@ def test_uniform_draw_is_uniform():
     lib.tgmx_uniform_lookup_csr(csr.indptr.data_ptr(), csr.adj.data_ptr(), None, 0, seeds.data_ptr(), 1, k, E, N, 0, 99, 5 << 8,
                                 again.data_ptr(), nts[0].data_ptr(), None, status.data_ptr(), _native.stream_ptr(0))
     assert np.array_equal(again.cpu().numpy()[0], got[5])
+
+
+def test_uniform_draw_large_hub_k64():
+    """A hub with 5000 candidates, k = 64 (the maximum), 300 calls: rows are 64 distinct candidates before ev_hi and the
+    draws spread evenly over the candidate range."""
+    from tgm_amd import _native
+    from tgm_amd.index import build_csr
+
+    E, N, k, ev_hi = 6000, 7000, 64, 5000
+    src = torch.zeros(E, dtype=torch.int32, device=DEV)
+    dst = torch.arange(1, E + 1, dtype=torch.int32, device=DEV)
+    ts = torch.arange(1, E + 1, dtype=torch.int64, device=DEV)
+    csr = build_csr(src, dst, ts, N, order='event', directed=True)
+    lib = _native.load()
+    calls = 300
+    seeds = torch.zeros(1, dtype=torch.int32, device=DEV)
+    nid = torch.empty((calls, k), dtype=torch.int32, device=DEV)
+    nts = torch.empty((calls, k), dtype=torch.int64, device=DEV)
+    status = torch.zeros(1, dtype=torch.int32, device=DEV)
+    for c in range(calls):
+        assert lib.tgmx_uniform_lookup_csr(csr.indptr.data_ptr(), csr.adj.data_ptr(), None, 0, seeds.data_ptr(), 1, k, ev_hi, N, 0, 1234, c << 8,
+                                           nid[c].data_ptr(), nts[c].data_ptr(), None, status.data_ptr(), _native.stream_ptr(0)) == 0
+    got, t = nid.cpu().numpy(), nts.cpu().numpy()
+    assert int(status.item()) == 0
+    assert got.min() >= 1 and got.max() <= ev_hi  # only edges before ev_hi (dst = eid + 1)
+    assert np.array_equal(t, got.astype(np.int64))  # times belong to the drawn edges
+    assert all(len(set(row)) == k for row in got.tolist())
+    counts = np.bincount((got.reshape(-1) - 1) * 10 // ev_hi, minlength=10)
+    exp = calls * k / 10
+    assert np.all(np.abs(counts - exp) < 5 * np.sqrt(exp * 0.9)), counts
