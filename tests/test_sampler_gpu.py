@@ -166,6 +166,9 @@ def _random_stream(seed, N, E, D, tmax):
         (30, 24000, 2, 500, [8], 6000, False, 'int32'),  # m=12000: radix-sort path, hub runs far longer than B, heavy ties
         (400, 3000, 7, 2000, [6], 60, False, 'int32'),  # D not a multiple of 4 (scalar gather path)
         (400, 3000, 6, 2000, [6], 60, False, 'int32'),  # D % 2 == 0 (float2 path)
+        (150, 4000, 4, 600, [64], 80, False, 'int32'),  # k = B = 64: the widest single-wave window
+        (300, 2000, 5, 900, [1, 1, 1], 40, False, 'int32'),  # k = 1 on three hops
+        (120, 3000, 8, 500, [32, 2], 64, True, 'int32'),  # B = 32: packed kernel group boundary, directed
     ],
 )
 def test_ring_mode_matches_oracle_random(N, E, D, tmax, num_nbrs, bs, directed, key_arith):
