@@ -47,7 +47,7 @@ def parse_args():
     p.add_argument('--batch-size', type=int, default=None, help='edges per rank per step (default: 200 wiki, 512 review, 4096 comment)')
     p.add_argument('--num-nbrs', type=int, nargs='+', default=None)
     p.add_argument('--mode', default='ring', choices=['ring', 'csr'])
-    p.add_argument('--cpu-batches', type=int, default=150, help='batches of the CPU-baseline sample (0 = skip)')
+    p.add_argument('--cpu-batches', type=int, default=100, help='batches of the CPU-baseline sample (0 = skip); ~0.25 s each on the GPU box host')
     p.add_argument('--profile-every', type=int, default=8, help='bracket the dominant kernel with HIP events every n-th step')
     p.add_argument('--seed', type=int, default=1337)
     return p.parse_args()
