@@ -20,7 +20,7 @@ throughout; only the association of the sums differs.
 """
 from __future__ import annotations
 
-from typing import Dict, List
+from typing import Dict
 
 import torch
 import torch.nn.functional as F

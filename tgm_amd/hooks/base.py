@@ -7,7 +7,7 @@ is.  Seedable hooks add their ``seed_keys`` to ``requires``.
 """
 from __future__ import annotations
 
-from typing import Any, Iterable, List, Optional, Protocol, Set, runtime_checkable
+from typing import Any, List, Optional, Protocol, Set, runtime_checkable
 
 from ..core import DGBatch, DGraph
 

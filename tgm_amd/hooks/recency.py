@@ -24,13 +24,12 @@ raises ``ValueError`` like the reference; ``'deferred'`` only raises when
 from __future__ import annotations
 
 import warnings
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Dict, List, Optional, Sequence
 
 import torch
 from torch import Tensor
 
 from .. import _native
-from ..constants import PADDED_NODE_ID
 from ..core import DGBatch, DGraph
 from ..index import TemporalCSR, build_csr
 from .base import SeedableHook, StatefulHook

@@ -4,7 +4,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tgm_amd import _native
 DEV='cuda'
 torch.manual_seed(0)
-import ctypes
 libpath=os.environ.get('TGMX_LIB')
 if libpath:
     _native._lib=None; lib=_native.load(libpath)
