@@ -4,6 +4,7 @@ the golden vectors recorded from the reference and against the CPU oracle.
 Bit-exact bar: neighbor ids, timestamps and the copied feature rows.
 """
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -434,3 +435,29 @@ def test_edge_cases_and_errors():
     with pytest.warns(UserWarning):
         out = hook(dg, batch)
     assert out.nbr_nids[0].numel() == 0 and out.nbr_edge_x[0].shape == (0, 0)
+
+
+def _fuzz_config(seed):
+    """One random sampler configuration per seed: sizes chosen to land on every update plan (one workgroup, chunk sort +
+    merge, radix sort), every lookup specialisation (packed groups, one wave, chunked B > 64) and both key arithmetics."""
+    r = np.random.default_rng(10_000 + seed)
+    N = int(r.choice([7, 40, 300, 2500, 9000]))
+    bs = int(r.choice([1, 17, 64, 200, 513, 900, 1600, 2300]))
+    E = int(min(max(bs * r.integers(3, 9), 200), 14_000))
+    D = int(r.choice([0, 1, 2, 3, 4, 6, 8, 16, 33]))
+    tmax = int(r.choice([5, 300, 40_000, 3_000_000]))
+    L = int(r.integers(1, 4))
+    num_nbrs = [int(r.choice([1, 2, 3, 5, 8, 16, 20, 32, 64, 70])) for _ in range(L)]
+    while int(np.prod(num_nbrs)) * 3 * bs > 400_000:  # keep the deepest hop small enough for the CPU oracle
+        num_nbrs[int(np.argmax(num_nbrs))] = max(1, max(num_nbrs) // 2)
+    directed = bool(r.integers(0, 2))
+    key_arith = str(r.choice(['int32', 'int64']))
+    validate = str(r.choice(['deferred', 'off', 'sync']))
+    return N, E, D, tmax, num_nbrs, bs, directed, key_arith, validate
+
+
+@pytest.mark.parametrize('seed', range(int(os.environ.get('TGMX_FUZZ', '16'))))
+def test_ring_mode_fuzz(seed):
+    """Seeded random configurations against the oracle (TGMX_FUZZ=<n> widens the sweep; the default keeps the suite short)."""
+    N, E, D, tmax, num_nbrs, bs, directed, key_arith, validate = _fuzz_config(seed)
+    _check_ring_against_oracle(N, E, D, tmax, num_nbrs, bs, directed, key_arith, validate=validate)
