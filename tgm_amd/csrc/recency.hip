@@ -13,6 +13,7 @@
 //     The [S, B, D] intermediate the reference materialises
 //     (tgm/hooks/neighbors/recency.py:258) never exists.
 // Rows are copied, never recomputed, so features are bit-exact by construction.
+#include <cstdlib>
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -57,6 +58,10 @@ struct LookupArgs {
   int D, k, B, N, allow_pad;
   int row_vecs;  // D / VEC
   FastDiv dv;    // division by row_vecs
+  // ring update work riding along (tgmx_recency_step): the first side_blocks workgroups run side_stage on the
+  // launch's second argument instead of looking anything up
+  unsigned side_blocks;
+  int side_stage;
 };
 
 template <int VEC>
@@ -108,17 +113,322 @@ __device__ __forceinline__ long long wave_prefix_count(const Rec* recs, long lon
   return lo + __popcll(__ballot(less)) - a;
 }
 
+// ---------------------------------------------------------------------------
+// Streaming rings: batched append -- a faithful restatement of
+// tgm/hooks/neighbors/recency.py:323-399 INCLUDING its key arithmetic.
+//
+// Entry j < n is (src[j] -> dst[j]), entry n + j is (dst[j] -> src[j]).  The
+// reference stably argsorts key = node * (max_t + 1) + t, where the product is
+// evaluated in int32 (an int32 tensor times a 0-dim int64 tensor stays int32) and
+// therefore wraps at dataset scale; it then treats every RUN of equal node ids
+// in that order as one group: keeps the run's last B entries, scatters them at
+// (write_pos[node] + rank_in_run) % B (runs of one node collide: the later one in
+// sorted order wins) and advances write_pos by the number of kept entries.
+// key_wrap32 = 0 evaluates the key in int64 (the intended (node, time) order).
+//
+// The sort of the m = 2 * batch_size entries is an all-pairs rank: exact, stable,
+// deterministic, no atomics; O(m^2 / lanes), microseconds for m <= ~10^4.
+//   k1 sort : rank every entry, scatter (entry, node) to its sorted position
+//   k2 place: run boundaries -> keep / ring slot per sorted position
+//   k3 write: resolve slot collisions (last wins), write records, commit write_pos
+//   k4 feat : one wave per written record copies its D-float feature row
+// ---------------------------------------------------------------------------
+struct UpdateArgs {
+  Rec* ring;
+  int32_t* write_pos;
+  float* ring_x;        // [N*B, D] feature row of every ring slot
+  const float* edge_x;  // [n, D] rows of this batch (null -> zeros)
+  const int32_t* src;
+  const int32_t* dst;
+  const int64_t* ts;
+  int32_t* sorted_j;     // scratch [m]: entry index at sorted position p
+  int32_t* sorted_node;  // scratch [m]: its node (-1 = invalid entry)
+  int32_t* target;       // scratch [m]: ring row it is placed at (-1 = dropped)
+  int32_t* winner;       // scratch [m]: ring row it finally owns (-1 = none)
+  Rec* sorted_rec;       // scratch [m] (chunked path): the record of the entry at sorted position p
+  // chunked path (1024 < m <= 4096):
+  long long* key;        // scratch: chunk-sorted keys
+  int32_t* node;         // scratch: chunk-sorted entry indices
+  // large-batch path (m > 4096):
+  long long* span;             // scratch: max(ts) + 1
+  unsigned long long* keys_in; // scratch [m]: radix keys of the entries
+  unsigned int* vals_in;       // scratch [m]: entry indices
+  int32_t* hash_key;           // scratch [2^hash_bits]: ring rows placed on (-1 empty)
+  int32_t* hash_maxp;          // scratch [2^hash_bits]: last sorted position placed there
+  int32_t* run_flag;           // scratch [m]
+  int32_t* run_start;          // scratch [m]: first sorted position of p's run
+  int32_t* run_len;            // scratch [m]: run length, at the run's first position
+  int hash_bits;
+  int32_t* status;
+  long long n, m, eid0;
+  int B, N, D, key_wrap32;
+};
+
+__device__ __forceinline__ long long update_key(int node, long long t, long long span, int wrap32) {
+  if (wrap32) {
+    const unsigned int prod = (unsigned int)node * (unsigned int)(int)span;  // int32 multiply, two's complement wrap
+    return (long long)(int)prod + t;
+  }
+  return (long long)node * span + t;
+}
+
+__device__ __forceinline__ void update_entry(const UpdateArgs& a, long long j, int& node, int& nbr, long long& t,
+                                             long long& i) {
+  const bool rev = j >= a.n;
+  i = rev ? j - a.n : j;
+  const int s = a.src[i], d = a.dst[i];
+  node = rev ? d : s;
+  nbr = rev ? s : d;
+  t = a.ts[i];
+}
+
+constexpr int kBlockMaxM = 4096;  // largest batch (entries) of the single-workgroup placement kernel
+constexpr int kChunk = 256;       // entries per workgroup of the spread sort
+
+// max over ts[0, n) of this thread's strided share, 8 independent loads in flight per round
+__device__ __forceinline__ long long strided_max_ts(const int64_t* __restrict__ ts, long long n, int tid, int nthr) {
+  long long mx = -0x7fffffffffffffffLL;
+  for (long long base = tid; base < n; base += 8ll * nthr) {
+    long long v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const long long x = base + (long long)u * nthr;
+      v[u] = x < n ? ts[x] : mx;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) mx = v[u] > mx ? v[u] : mx;
+  }
+  return mx;
+}
+
+__device__ __forceinline__ long long strided_min_ts(const int64_t* __restrict__ ts, long long n, int tid, int nthr) {
+  long long mn = 0x7fffffffffffffffLL;
+  for (long long base = tid; base < n; base += 8ll * nthr) {
+    long long v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const long long x = base + (long long)u * nthr;
+      v[u] = x < n ? ts[x] : mn;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) mn = v[u] < mn ? v[u] : mn;
+  }
+  return mn;
+}
+
+// ---- the state-independent half of the ring update, as workgroup-sized pieces -------------------------------------
+// The order of a batch's entries depends on the batch alone, not on the rings, so `tgmx_recency_step` lets it ride
+// along with the lookups: the first `side_blocks` workgroups of the hop-0 launch chunk-sort the entries, the first
+// `side_blocks` workgroups of the hop-1 launch merge the chunks (and pre-gather node / write_pos % B / record of every
+// sorted position: the rings do not move while lookups run).  What is left after the lookups is the placement kernel
+// (PRESORTED) and the feature copy.  The same pieces are the chunked path of the stand-alone `tgmx_ring_update`.
+
+// one 256-thread workgroup sorts entries [chunk * 256, chunk * 256 + 256) by (key, entry index)
+__device__ __forceinline__ void update_chunk_sort(const UpdateArgs& a, int chunk) {
+  __shared__ long long s_key[kChunk];
+  __shared__ int s_pay[kChunk];
+  __shared__ long long red[kChunk / kWave], red2[kChunk / kWave];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  long long mx = strided_max_ts(a.ts, a.n, tid, kChunk), mn = strided_min_ts(a.ts, a.n, tid, kChunk);
+  for (int off = 32; off > 0; off >>= 1) {
+    const long long o = __shfl_xor(mx, off), o2 = __shfl_xor(mn, off);
+    mx = o > mx ? o : mx;
+    mn = o2 < mn ? o2 : mn;
+  }
+  if (lane == 0) {
+    red[wave] = mx;
+    red2[wave] = mn;
+  }
+  __syncthreads();
+  mx = red[0];
+  mn = red2[0];
+  for (int w = 1; w < kChunk / kWave; ++w) {
+    mx = red[w] > mx ? red[w] : mx;
+    mn = red2[w] < mn ? red2[w] : mn;
+  }
+  const long long span = mx + 1;
+  const bool packed = can_pack(a.key_wrap32, mn, mx);  // the same verdict in every chunk: keys stay comparable
+
+  const long long j = (long long)chunk * kChunk + tid;
+  long long key = 0x7fffffffffffffffLL;  // padding of the last chunk sorts to its end
+  int pay = (int)j;
+  if (j < a.m) {
+    int node, nbr;
+    long long t, i;
+    update_entry(a, j, node, nbr, t, i);
+    key = update_key(node, t, span, a.key_wrap32);
+    if (packed) key = packed_key(key, (int)j);
+  }
+  if (packed) bitonic_sort_one<true>(key, pay, s_key, s_pay, tid, kChunk);
+  else bitonic_sort_one<false>(key, pay, s_key, s_pay, tid, kChunk);
+  a.key[j] = key;
+  a.node[j] = pay;  // chunk-sorted entry index
+}
+
+// global rank of entry `tid` of chunk c = its rank in its chunk + sum over the other chunks of a binary search
+// (pairs are unique, so the ranks are a permutation); k_all / p_all = the chunk-sorted (key, entry) arrays, in LDS
+// (stand-alone kernel) or in global memory (riding along with a lookup launch: L2 hits, nobody waits for them).
+// Chunk c keeps its len_c real entries first (padding sorted last), so [c*256, c*256 + len_c) is dense.
+template <int GROUP>
+__device__ __forceinline__ void update_merge_entry(const UpdateArgs& a, const long long* __restrict__ k_all,
+                                                   const int* __restrict__ p_all, int c, int tid) {
+  const int m = (int)a.m;
+  const int e = c * kChunk + tid;
+  if (e >= m) return;
+  const long long key = k_all[e];
+  const int pay = p_all[e];
+  int rank = tid;
+  const int chunks = (m + kChunk - 1) / kChunk;
+  // GROUP binary searches advance together, so the dependent reads of one search hide behind the others' (9 steps each)
+  constexpr int kMaxChunks = kBlockMaxM / kChunk;
+  static_assert(kMaxChunks % GROUP == 0, "chunk groups");
+#pragma unroll 1
+  for (int g0 = 0; g0 < chunks; g0 += GROUP) {
+    int lo[GROUP], hi[GROUP];
+#pragma unroll
+    for (int o = 0; o < GROUP; ++o) {
+      const int oc = g0 + o;
+      lo[o] = 0;
+      const int len = (m - oc * kChunk) < kChunk ? (m - oc * kChunk) : kChunk;
+      hi[o] = (oc < chunks && oc != c) ? len : 0;
+    }
+#pragma unroll 1
+    for (int step = 0; step < 9; ++step) {  // 2^9 > kChunk
+#pragma unroll
+      for (int o = 0; o < GROUP; ++o) {
+        if (lo[o] < hi[o]) {
+          const int mid = (lo[o] + hi[o]) >> 1;
+          if (pair_after(key, pay, k_all[(g0 + o) * kChunk + mid], p_all[(g0 + o) * kChunk + mid])) lo[o] = mid + 1;
+          else hi[o] = mid;
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < GROUP; ++o) rank += lo[o];
+  }
+  // everything the placement kernel would otherwise gather with dependent loads
+  int node, nbr;
+  long long t, i;
+  update_entry(a, pay, node, nbr, t, i);
+  const bool valid = node >= 0 && node < a.N && nbr >= 0 && nbr < a.N;
+  if (!valid) atomicOr(a.status, TGMX_ST_EDGE_RANGE);
+  Rec rec;
+  rec.nbr = nbr;
+  rec.eid = a.eid0 >= 0 ? (int)(a.eid0 + i) : -1;
+  rec.ts = t;
+  a.sorted_j[rank] = pay;
+  a.sorted_node[rank] = valid ? node : -1;
+  a.target[rank] = valid ? a.write_pos[node] % a.B : 0;  // write_pos only moves in the placement kernel
+  a.sorted_rec[rank] = rec;
+}
+
+// The merge as it rides along with a lookup launch.  The lookups keep the memory pipeline full, so every DEPENDENT
+// global read of a rider costs microseconds: the binary searches above (9 rounds per group of chunks) would outlast the
+// launch.  Two levels instead: every 8th pair of every chunk is staged in LDS (one coalesced round, 6 KB at m = 4096),
+// the search among a chunk's 32 samples runs in LDS, and only the last three steps (7 unknown pairs) read global
+// memory -- for all other chunks at once, so three dependent rounds in all.  Chunks are padded to 256 pairs with keys
+// that sort last (chunk sort), so no length bookkeeping is needed.
+constexpr int kSampleEvery = 8, kSamplesPerChunk = kChunk / kSampleEvery;
+
+__device__ __forceinline__ void update_merge_riding(const UpdateArgs& a, int c) {
+  constexpr int kMaxChunks = kBlockMaxM / kChunk;
+  __shared__ long long smp_key[kMaxChunks * kSamplesPerChunk];
+  __shared__ int smp_pay[kMaxChunks * kSamplesPerChunk];
+  const int m = (int)a.m;
+  const int tid = threadIdx.x;
+  const int chunks = (m + kChunk - 1) / kChunk;
+  const long long* __restrict__ gk = a.key;
+  const int* __restrict__ gp = a.node;
+  for (int x = tid; x < chunks * kSamplesPerChunk; x += kChunk) {  // <= 2 rounds
+    smp_key[x] = gk[x * kSampleEvery];
+    smp_pay[x] = gp[x * kSampleEvery];
+  }
+  const int e = c * kChunk + tid;
+  const bool act = e < m;
+  const long long key = act ? gk[e] : 0;
+  const int pay = act ? gp[e] : 0;
+  __syncthreads();
+  if (!act) return;
+
+  // pos[o] = number of pairs of chunk o known to sort before mine; after the sample search it is 8 * (#samples before
+  // mine - 1) + 1 (the sample itself is before mine, the next sample is not), or 0 when no sample is
+  int pos[kMaxChunks];
+#pragma unroll
+  for (int o = 0; o < kMaxChunks; ++o) {
+    int cnt = 0;  // samples of chunk o before mine, 0..32
+    if (o < chunks && o != c) {
+      const long long* sk = smp_key + o * kSamplesPerChunk;
+      const int* sp = smp_pay + o * kSamplesPerChunk;
+      if (pair_after(key, pay, sk[kSamplesPerChunk - 1], sp[kSamplesPerChunk - 1])) {
+        cnt = kSamplesPerChunk;
+      } else {
+#pragma unroll
+        for (int st = kSamplesPerChunk / 2; st > 0; st >>= 1)
+          if (pair_after(key, pay, sk[cnt + st - 1], sp[cnt + st - 1])) cnt += st;
+      }
+    }
+    pos[o] = cnt > 0 ? (cnt - 1) * kSampleEvery + 1 : -1;  // -1: nothing of this chunk is before mine (or no chunk)
+  }
+#pragma unroll
+  for (int st = kSampleEvery / 2; st > 0; st >>= 1) {  // 3 dependent global rounds, all chunks in flight
+    long long k2[kMaxChunks];
+#pragma unroll
+    for (int o = 0; o < kMaxChunks; ++o) k2[o] = pos[o] >= 0 ? gk[o * kChunk + pos[o] + st - 1] : 0;
+#pragma unroll
+    for (int o = 0; o < kMaxChunks; ++o) {
+      if (pos[o] < 0) continue;
+      bool after = key > k2[o];
+      if (key == k2[o]) after = pay > gp[o * kChunk + pos[o] + st - 1];  // equal unpacked keys only: the entry index decides
+      if (after) pos[o] += st;
+    }
+  }
+  int rank = tid;
+#pragma unroll
+  for (int o = 0; o < kMaxChunks; ++o) rank += pos[o] >= 0 ? pos[o] : 0;
+
+  int node, nbr;
+  long long t, i;
+  update_entry(a, pay, node, nbr, t, i);
+  const bool valid = node >= 0 && node < a.N && nbr >= 0 && nbr < a.N;
+  if (!valid) atomicOr(a.status, TGMX_ST_EDGE_RANGE);
+  Rec rec;
+  rec.nbr = nbr;
+  rec.eid = a.eid0 >= 0 ? (int)(a.eid0 + i) : -1;
+  rec.ts = t;
+  a.sorted_j[rank] = pay;
+  a.sorted_node[rank] = valid ? node : -1;
+  a.target[rank] = valid ? a.write_pos[node] % a.B : 0;  // write_pos only moves in the placement kernel
+  a.sorted_rec[rank] = rec;
+}
+
+constexpr int kSideSort = 1, kSideMerge = 2;
+
+__device__ __forceinline__ void update_side_work(const UpdateArgs& u, int stage, int block) {
+  if (stage == kSideSort) update_chunk_sort(u, block);
+  else update_merge_riding(u, block);
+}
+
+
 template <bool RING, int VEC, bool SMALL>
-__global__ __launch_bounds__(256) void recency_lookup_kernel(const LookupArgs a) {
+__global__ __launch_bounds__(256) void recency_lookup_kernel(const LookupArgs a, const UpdateArgs u) {
   using V = typename VecOf<VEC>::type;
   extern __shared__ __attribute__((aligned(16))) int lds_eid_all[];
+  unsigned bid = blockIdx.x, nblk = gridDim.x;
+  if constexpr (RING) {
+    if (bid < a.side_blocks) {
+      update_side_work(u, a.side_stage, (int)bid);
+      return;
+    }
+    bid -= a.side_blocks;
+    nblk -= a.side_blocks;
+  }
   const int lane = lane_id();
   const int wave_in_block = threadIdx.x >> 6;
   int* lds_eid = lds_eid_all + wave_in_block * a.k;
-  const long long waves_total = (long long)gridDim.x * (blockDim.x >> 6);
+  const long long waves_total = (long long)nblk * (blockDim.x >> 6);
   const int k = a.k, B = a.B;
 
-  for (long long s = (long long)blockIdx.x * (blockDim.x >> 6) + wave_in_block; s < a.S; s += waves_total) {
+  for (long long s = (long long)bid * (blockDim.x >> 6) + wave_in_block; s < a.S; s += waves_total) {
     int n;
     long long q;
     if (a.grp.groups > 0) {
@@ -181,7 +491,17 @@ __global__ __launch_bounds__(256) void recency_lookup_kernel(const LookupArgs a)
     if (SMALL) {
       Rec r;
       r.nbr = -1; r.eid = 0; r.ts = 0;
-      if (lane < wlen) r = a.recs[slot_of(lane)];
+      if (RING) {
+        // the row is read in slot order (no wait for write_pos) and rotated into time order by a shuffle
+        if (live && lane < B) r = a.recs[w0 + lane];
+        int from_slot = wrot + lane;
+        if (from_slot >= B) from_slot -= B;
+        if (lane >= B) from_slot = lane;
+        r.nbr = __shfl(r.nbr, from_slot);
+        r.ts = __shfl(r.ts, from_slot);
+      } else if (lane < wlen) {
+        r = a.recs[slot_of(lane)];
+      }
       const bool ok = lane < wlen && r.nbr >= 0 && r.ts < q;
       const unsigned long long m = __ballot(ok);
       cnt = m ? 64 - __clzll((long long)m) : 0;
@@ -255,18 +575,25 @@ __global__ __launch_bounds__(256) void recency_lookup_kernel(const LookupArgs a)
 // seeds per wave, the same ballot / shuffle logic inside the group's slice of the wave, 2-4x the loads in flight.
 // Streaming rings only (the static index's prefix search is wave-wide), plain seed arrays only.
 template <int VEC, int GL>
-__global__ __launch_bounds__(256) void ring_lookup_packed_kernel(const LookupArgs a) {
+__global__ __launch_bounds__(256) void ring_lookup_packed_kernel(const LookupArgs a, const UpdateArgs u) {
   using V = typename VecOf<VEC>::type;
   constexpr int kGroups = kWave / GL;
   extern __shared__ __attribute__((aligned(16))) int lds_eid_all[];
+  unsigned bid = blockIdx.x, nblk = gridDim.x;
+  if (bid < a.side_blocks) {
+    update_side_work(u, a.side_stage, (int)bid);
+    return;
+  }
+  bid -= a.side_blocks;
+  nblk -= a.side_blocks;
   const int lane = lane_id();
   const int sub = lane / GL, gl = lane - sub * GL;
   const int wave_in_block = threadIdx.x >> 6;
   const int k = a.k, B = a.B;
   int* lds_eid = lds_eid_all + (wave_in_block * kGroups + sub) * k;
-  const long long waves_total = (long long)gridDim.x * (blockDim.x >> 6);
+  const long long waves_total = (long long)nblk * (blockDim.x >> 6);
   const long long n_rounds = (a.S + kGroups - 1) / kGroups;
-  for (long long w = (long long)blockIdx.x * (blockDim.x >> 6) + wave_in_block; w < n_rounds; w += waves_total) {
+  for (long long w = (long long)bid * (blockDim.x >> 6) + wave_in_block; w < n_rounds; w += waves_total) {
     const long long s = w * kGroups + sub;
     const bool act = s < a.S;
     const int n = act ? a.seeds[s] : -1;
@@ -287,7 +614,14 @@ __global__ __launch_bounds__(256) void ring_lookup_packed_kernel(const LookupArg
     };
     Rec r;
     r.nbr = -1; r.eid = 0; r.ts = 0;
-    if (live && gl < B) r = a.recs[slot_of(gl)];
+    if (live && gl < B) r = a.recs[w0 + gl];  // slot order (no wait for write_pos), rotated into time order below
+    {
+      int from_slot = wrot + gl;
+      if (from_slot >= B) from_slot -= B;
+      if (gl >= B) from_slot = gl;
+      r.nbr = __shfl(r.nbr, sub * GL + from_slot);
+      r.ts = __shfl(r.ts, sub * GL + from_slot);
+    }
     const bool ok = live && gl < B && r.nbr >= 0 && r.ts < q;
     const unsigned long long m = (__ballot(ok) >> (sub * GL)) & ((GL == 64) ? ~0ull : ((1ull << GL) - 1));
     const int cnt = m ? 64 - __clzll((long long)m) : 0;  // 1 + position of the rightmost valid entry, inside the group
@@ -333,8 +667,12 @@ __global__ __launch_bounds__(256) void ring_lookup_packed_kernel(const LookupArg
 }
 
 template <bool RING>
-static int launch_lookup(LookupArgs a, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
+static int launch_lookup(LookupArgs a, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop,
+                         const UpdateArgs* side = nullptr, int side_stage = 0, unsigned side_blocks = 0) {
   if (a.S == 0) return TGMX_OK;
+  const UpdateArgs u = side ? *side : UpdateArgs{};
+  a.side_blocks = (RING && side) ? side_blocks : 0;
+  a.side_stage = side_stage;
   const bool small = a.B <= kWave && a.k <= kWave;
   int vec = 1;
   if (a.D > 0) {
@@ -352,10 +690,10 @@ static int launch_lookup(LookupArgs a, hipStream_t stream, hipEvent_t ev_start, 
   const int waves_per_block = 4;
   long long blocks = (a.S + waves_per_block - 1) / waves_per_block;
   if (blocks > (1 << 20)) blocks = 1 << 20;
-  const dim3 grid((unsigned)blocks), block(waves_per_block * kWave);
+  const dim3 grid((unsigned)blocks + a.side_blocks), block(waves_per_block * kWave);
   const size_t lds = (size_t)waves_per_block * a.k * sizeof(int);
 #define TGMX_LAUNCH(VEC_, SMALL_) \
-  hipLaunchKernelGGL((recency_lookup_kernel<RING, VEC_, SMALL_>), grid, block, lds, stream, a)
+  hipLaunchKernelGGL((recency_lookup_kernel<RING, VEC_, SMALL_>), grid, block, lds, stream, a, u)
   if (ev_start) (void)hipEventRecord(ev_start, stream);
   // narrow rows: several seeds per wave (streaming rings, plain seed arrays)
   const int gl = (a.B <= 16 && a.k <= 16) ? 16 : ((a.B <= 32 && a.k <= 32) ? 32 : 64);
@@ -363,12 +701,12 @@ static int launch_lookup(LookupArgs a, hipStream_t stream, hipEvent_t ev_start, 
     const int per_wave = 64 / gl;
     long long pblocks = ((a.S + per_wave - 1) / per_wave + waves_per_block - 1) / waves_per_block;
     if (pblocks > (1 << 20)) pblocks = 1 << 20;
-    const dim3 pgrid((unsigned)pblocks);
+    const dim3 pgrid((unsigned)pblocks + a.side_blocks);
     const size_t plds = (size_t)waves_per_block * per_wave * a.k * sizeof(int);
 #define TGMX_PACKED(VEC_)                                                                              \
   do {                                                                                                 \
-    if (gl == 16) hipLaunchKernelGGL((ring_lookup_packed_kernel<VEC_, 16>), pgrid, block, plds, stream, a); \
-    else hipLaunchKernelGGL((ring_lookup_packed_kernel<VEC_, 32>), pgrid, block, plds, stream, a);          \
+    if (gl == 16) hipLaunchKernelGGL((ring_lookup_packed_kernel<VEC_, 16>), pgrid, block, plds, stream, a, u); \
+    else hipLaunchKernelGGL((ring_lookup_packed_kernel<VEC_, 32>), pgrid, block, plds, stream, a, u);          \
   } while (0)
     if (vec == 4) TGMX_PACKED(4);
     else if (vec == 2) TGMX_PACKED(2);
@@ -389,74 +727,6 @@ static int launch_lookup(LookupArgs a, hipStream_t stream, hipEvent_t ev_start, 
   return TGMX_OK;
 }
 
-// ---------------------------------------------------------------------------
-// Streaming rings: batched append -- a faithful restatement of
-// tgm/hooks/neighbors/recency.py:323-399 INCLUDING its key arithmetic.
-//
-// Entry j < n is (src[j] -> dst[j]), entry n + j is (dst[j] -> src[j]).  The
-// reference stably argsorts key = node * (max_t + 1) + t, where the product is
-// evaluated in int32 (an int32 tensor times a 0-dim int64 tensor stays int32) and
-// therefore wraps at dataset scale; it then treats every RUN of equal node ids
-// in that order as one group: keeps the run's last B entries, scatters them at
-// (write_pos[node] + rank_in_run) % B (runs of one node collide: the later one in
-// sorted order wins) and advances write_pos by the number of kept entries.
-// key_wrap32 = 0 evaluates the key in int64 (the intended (node, time) order).
-//
-// The sort of the m = 2 * batch_size entries is an all-pairs rank: exact, stable,
-// deterministic, no atomics; O(m^2 / lanes), microseconds for m <= ~10^4.
-//   k1 sort : rank every entry, scatter (entry, node) to its sorted position
-//   k2 place: run boundaries -> keep / ring slot per sorted position
-//   k3 write: resolve slot collisions (last wins), write records, commit write_pos
-//   k4 feat : one wave per written record copies its D-float feature row
-// ---------------------------------------------------------------------------
-struct UpdateArgs {
-  Rec* ring;
-  int32_t* write_pos;
-  float* ring_x;        // [N*B, D] feature row of every ring slot
-  const float* edge_x;  // [n, D] rows of this batch (null -> zeros)
-  const int32_t* src;
-  const int32_t* dst;
-  const int64_t* ts;
-  int32_t* sorted_j;     // scratch [m]: entry index at sorted position p
-  int32_t* sorted_node;  // scratch [m]: its node (-1 = invalid entry)
-  int32_t* target;       // scratch [m]: ring row it is placed at (-1 = dropped)
-  int32_t* winner;       // scratch [m]: ring row it finally owns (-1 = none)
-  Rec* sorted_rec;       // scratch [m] (chunked path): the record of the entry at sorted position p
-  // chunked path (1024 < m <= 4096):
-  long long* key;        // scratch: chunk-sorted keys
-  int32_t* node;         // scratch: chunk-sorted entry indices
-  // large-batch path (m > 4096):
-  long long* span;             // scratch: max(ts) + 1
-  unsigned long long* keys_in; // scratch [m]: radix keys of the entries
-  unsigned int* vals_in;       // scratch [m]: entry indices
-  int32_t* hash_key;           // scratch [2^hash_bits]: ring rows placed on (-1 empty)
-  int32_t* hash_maxp;          // scratch [2^hash_bits]: last sorted position placed there
-  int32_t* run_flag;           // scratch [m]
-  int32_t* run_start;          // scratch [m]: first sorted position of p's run
-  int32_t* run_len;            // scratch [m]: run length, at the run's first position
-  int hash_bits;
-  int32_t* status;
-  long long n, m, eid0;
-  int B, N, D, key_wrap32;
-};
-
-__device__ __forceinline__ long long update_key(int node, long long t, long long span, int wrap32) {
-  if (wrap32) {
-    const unsigned int prod = (unsigned int)node * (unsigned int)(int)span;  // int32 multiply, two's complement wrap
-    return (long long)(int)prod + t;
-  }
-  return (long long)node * span + t;
-}
-
-__device__ __forceinline__ void update_entry(const UpdateArgs& a, long long j, int& node, int& nbr, long long& t,
-                                             long long& i) {
-  const bool rev = j >= a.n;
-  i = rev ? j - a.n : j;
-  const int s = a.src[i], d = a.dst[i];
-  node = rev ? d : s;
-  nbr = rev ? s : d;
-  t = a.ts[i];
-}
 
 // ---- large batches (m > kBlockMaxM, e.g. the replicated update of an 8-rank global batch of 8 x 4096 edges): O(m)
 // passes around one rocPRIM radix sort of the (sign-flipped) 64-bit keys -- LSD radix sort is stable, which is the
@@ -596,39 +866,8 @@ __global__ __launch_bounds__(256) void ring_update_feat_kernel(const UpdateArgs 
 //           the last one wins).
 //   write : winners write their record; the last entry of every run advances write_pos by #kept with one
 //           atomicAdd (every reader takes write_pos % B).
-constexpr int kBlockMaxM = 4096;
 constexpr int kBlockThreads = 1024;
 
-// max over ts[0, n) of this thread's strided share, 8 independent loads in flight per round
-__device__ __forceinline__ long long strided_max_ts(const int64_t* __restrict__ ts, long long n, int tid, int nthr) {
-  long long mx = -0x7fffffffffffffffLL;
-  for (long long base = tid; base < n; base += 8ll * nthr) {
-    long long v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const long long x = base + (long long)u * nthr;
-      v[u] = x < n ? ts[x] : mx;
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) mx = v[u] > mx ? v[u] : mx;
-  }
-  return mx;
-}
-
-__device__ __forceinline__ long long strided_min_ts(const int64_t* __restrict__ ts, long long n, int tid, int nthr) {
-  long long mn = 0x7fffffffffffffffLL;
-  for (long long base = tid; base < n; base += 8ll * nthr) {
-    long long v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const long long x = base + (long long)u * nthr;
-      v[u] = x < n ? ts[x] : mn;
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) mn = v[u] < mn ? v[u] : mn;
-  }
-  return mn;
-}
 
 // element e (mine) against its partner at distance jj in the step of bitonic stage k: keep min or max
 __device__ __forceinline__ void bitonic_select(long long& key, int& pay, long long pk, int pp, int e, int jj, int k) {
@@ -824,61 +1063,17 @@ __global__ __launch_bounds__(kBlockThreads) void ring_update_block_kernel(const 
   }
 }
 
-// 1024 < m <= kBlockMaxM (the replicated update of a 4- or 8-rank global batch): one workgroup is VALU-bound on
-// the sorting network (37 us at m = 3200), so the sort is spread over the chip:
-//   chunk sort : one 256-thread workgroup per 256 entries -- the same register / shuffle bitonic network
-//   merge      : every entry's global rank = its rank in its chunk + sum over the other chunks of a binary search
-//                (all chunk-sorted keys staged in LDS; pairs are unique, so the ranks are a permutation)
-// and the single-workgroup kernel above runs with PRESORTED = true (runs, placement, collisions, writes).
-constexpr int kChunk = 256;
-
-__global__ __launch_bounds__(kChunk) void ring_update_chunk_sort_kernel(const UpdateArgs a) {
-  __shared__ long long s_key[kChunk];
-  __shared__ int s_pay[kChunk];
-  __shared__ long long red[kChunk / kWave], red2[kChunk / kWave];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  long long mx = strided_max_ts(a.ts, a.n, tid, kChunk), mn = strided_min_ts(a.ts, a.n, tid, kChunk);
-  for (int off = 32; off > 0; off >>= 1) {
-    const long long o = __shfl_xor(mx, off), o2 = __shfl_xor(mn, off);
-    mx = o > mx ? o : mx;
-    mn = o2 < mn ? o2 : mn;
-  }
-  if (lane == 0) {
-    red[wave] = mx;
-    red2[wave] = mn;
-  }
-  __syncthreads();
-  mx = red[0];
-  mn = red2[0];
-  for (int w = 1; w < kChunk / kWave; ++w) {
-    mx = red[w] > mx ? red[w] : mx;
-    mn = red2[w] < mn ? red2[w] : mn;
-  }
-  const long long span = mx + 1;
-  const bool packed = can_pack(a.key_wrap32, mn, mx);  // the same verdict in every chunk: keys stay comparable
-
-  const long long j = (long long)blockIdx.x * kChunk + tid;
-  long long key = 0x7fffffffffffffffLL;  // padding of the last chunk sorts to its end
-  int pay = (int)j;
-  if (j < a.m) {
-    int node, nbr;
-    long long t, i;
-    update_entry(a, j, node, nbr, t, i);
-    key = update_key(node, t, span, a.key_wrap32);
-    if (packed) key = packed_key(key, (int)j);
-  }
-  if (packed) bitonic_sort_one<true>(key, pay, s_key, s_pay, tid, kChunk);
-  else bitonic_sort_one<false>(key, pay, s_key, s_pay, tid, kChunk);
-  a.key[j] = key;
-  a.node[j] = pay;  // chunk-sorted entry index
-}
+// 1024 < m <= kBlockMaxM stand-alone (the replicated update of a 4- or 8-rank global batch through `tgmx_ring_update`):
+// one workgroup is VALU-bound on the sorting network (37 us at m = 3200), so the sort is spread over the chip with the
+// pieces above (chunk sort, then merge with all chunk-sorted keys staged in LDS) and the single-workgroup kernel runs
+// with PRESORTED = true (runs, placement, collisions, writes).
+__global__ __launch_bounds__(kChunk) void ring_update_chunk_sort_kernel(const UpdateArgs a) { update_chunk_sort(a, blockIdx.x); }
 
 __global__ __launch_bounds__(kChunk) void ring_update_merge_kernel(const UpdateArgs a) {
   __shared__ long long k_all[kBlockMaxM];
   __shared__ int p_all[kBlockMaxM];
   const int m = (int)a.m;
   const int tid = threadIdx.x;
-  // chunk c keeps its len_c real entries first (padding sorted last), so [c*256, c*256 + len_c) is dense
   for (int base = tid; base < m; base += 8 * kChunk) {  // 16 independent loads in flight per round
     long long kv[8];
     int pv[8];
@@ -898,50 +1093,28 @@ __global__ __launch_bounds__(kChunk) void ring_update_merge_kernel(const UpdateA
     }
   }
   __syncthreads();
-  const int c = blockIdx.x;
-  const int e = c * kChunk + tid;
-  if (e >= m) return;
-  const long long key = k_all[e];
-  const int pay = p_all[e];
-  int rank = tid;
-  const int chunks = (m + kChunk - 1) / kChunk;
-  // count of entries of every other chunk that sort before mine: all binary searches advance together, so the
-  // dependent LDS reads of one search hide behind the other chunks' (<= 16 chunks, 9 steps each)
-  constexpr int kMaxChunks = kBlockMaxM / kChunk;
-  int lo[kMaxChunks], hi[kMaxChunks];
-#pragma unroll
-  for (int o = 0; o < kMaxChunks; ++o) {
-    lo[o] = 0;
-    const int len = (m - o * kChunk) < kChunk ? (m - o * kChunk) : kChunk;
-    hi[o] = (o < chunks && o != c) ? len : 0;
-  }
-#pragma unroll 1
-  for (int step = 0; step < 9; ++step) {  // 2^9 > kChunk
-#pragma unroll
-    for (int o = 0; o < kMaxChunks; ++o) {
-      if (lo[o] < hi[o]) {
-        const int mid = (lo[o] + hi[o]) >> 1;
-        if (pair_after(key, pay, k_all[o * kChunk + mid], p_all[o * kChunk + mid])) lo[o] = mid + 1;
-        else hi[o] = mid;
-      }
-    }
-  }
-#pragma unroll
-  for (int o = 0; o < kMaxChunks; ++o) rank += lo[o];
-  // everything the single-workgroup kernel would otherwise gather with dependent loads
-  int node, nbr;
-  long long t, i;
-  update_entry(a, pay, node, nbr, t, i);
-  const bool valid = node >= 0 && node < a.N && nbr >= 0 && nbr < a.N;
-  if (!valid) atomicOr(a.status, TGMX_ST_EDGE_RANGE);
-  Rec rec;
-  rec.nbr = nbr;
-  rec.eid = a.eid0 >= 0 ? (int)(a.eid0 + i) : -1;
-  rec.ts = t;
-  a.sorted_j[rank] = pay;
-  a.sorted_node[rank] = valid ? node : -1;
-  a.target[rank] = valid ? a.write_pos[node] % a.B : 0;  // write_pos only moves in the kernel that follows
-  a.sorted_rec[rank] = rec;
+  update_merge_entry<16>(a, k_all, p_all, blockIdx.x, tid);
+}
+
+// scratch of the spread sort: chunk-sorted keys (16-byte aligned int64), sorted records and chunk-sorted entry indices
+// live behind the four int32[m] arrays
+static unsigned set_chunk_scratch(UpdateArgs& a, int32_t* scratch) {
+  const unsigned chunks = (unsigned)((a.m + kChunk - 1) / kChunk);
+  long long* s64 = reinterpret_cast<long long*>(((uintptr_t)(scratch + 4 * a.m) + 15) & ~(uintptr_t)15);
+  a.key = s64;
+  a.sorted_rec = reinterpret_cast<Rec*>(s64 + (long long)chunks * kChunk);
+  a.node = reinterpret_cast<int32_t*>(a.sorted_rec + a.m);
+  return chunks;
+}
+
+// placement of a batch whose sorted order is already in the scratch, then the feature rows
+static void launch_update_presorted(const UpdateArgs& a, hipStream_t st) {
+  int P = 64;
+  while (P < a.m) P <<= 1;
+  if (P <= 1024) hipLaunchKernelGGL((ring_update_block_kernel<1, 1024, true>), dim3(1), dim3(P), 0, st, a);
+  else if (P == 2048) hipLaunchKernelGGL((ring_update_block_kernel<2, 2048, true>), dim3(1), dim3(1024), 0, st, a);
+  else hipLaunchKernelGGL((ring_update_block_kernel<4, 4096, true>), dim3(1), dim3(1024), 0, st, a);
+  if (a.D > 0) hipLaunchKernelGGL(ring_update_feat_kernel, dim3((unsigned)((a.m + 3) / 4)), dim3(256), 0, st, a);
 }
 
 static void launch_update_block(UpdateArgs& a, int32_t* scratch, hipStream_t st) {
@@ -949,19 +1122,13 @@ static void launch_update_block(UpdateArgs& a, int32_t* scratch, hipStream_t st)
   while (P < a.m) P <<= 1;
   if (P <= 1024) {
     hipLaunchKernelGGL((ring_update_block_kernel<1, 1024, false>), dim3(1), dim3(P), 0, st, a);
-  } else {
-    // chunk-sorted keys (16-byte aligned int64), sorted records and chunk-sorted entry indices live behind the four int32[m] arrays
-    const unsigned chunks = (unsigned)((a.m + kChunk - 1) / kChunk);
-    long long* s64 = reinterpret_cast<long long*>(((uintptr_t)(scratch + 4 * a.m) + 15) & ~(uintptr_t)15);
-    a.key = s64;
-    a.sorted_rec = reinterpret_cast<Rec*>(s64 + (long long)chunks * kChunk);
-    a.node = reinterpret_cast<int32_t*>(a.sorted_rec + a.m);
-    hipLaunchKernelGGL(ring_update_chunk_sort_kernel, dim3(chunks), dim3(kChunk), 0, st, a);
-    hipLaunchKernelGGL(ring_update_merge_kernel, dim3(chunks), dim3(kChunk), 0, st, a);
-    if (P == 2048) hipLaunchKernelGGL((ring_update_block_kernel<2, 2048, true>), dim3(1), dim3(1024), 0, st, a);
-    else hipLaunchKernelGGL((ring_update_block_kernel<4, 4096, true>), dim3(1), dim3(1024), 0, st, a);
+    if (a.D > 0) hipLaunchKernelGGL(ring_update_feat_kernel, dim3((unsigned)((a.m + 3) / 4)), dim3(256), 0, st, a);
+    return;
   }
-  if (a.D > 0) hipLaunchKernelGGL(ring_update_feat_kernel, dim3((unsigned)((a.m + 3) / 4)), dim3(256), 0, st, a);
+  const unsigned chunks = set_chunk_scratch(a, scratch);
+  hipLaunchKernelGGL(ring_update_chunk_sort_kernel, dim3(chunks), dim3(kChunk), 0, st, a);
+  hipLaunchKernelGGL(ring_update_merge_kernel, dim3(chunks), dim3(kChunk), 0, st, a);
+  launch_update_presorted(a, st);
 }
 
 __global__ __launch_bounds__(256) void ring_reset_kernel(Rec* ring, int32_t* write_pos, long long nrec, int N) {
@@ -1236,7 +1403,7 @@ static int launch_update_large(UpdateArgs& a, int32_t* scratch, hipStream_t st) 
 extern "C" size_t tgmx_ring_update_scratch_bytes(int64_t n, int32_t directed) {
   const long long m = directed ? n : 2 * n;
   if (m <= 0) return 256;
-  if (m <= kBlockMaxM) return ((size_t)12 * m + 16) * sizeof(int32_t) + 256;
+  if (m <= kBlockMaxM) return ((size_t)12 * m + 16) * sizeof(int32_t) + 256 + 12 * kChunk;  // + chunk padding of the spread sort
   LargeScratch w;
   if (large_scratch_layout(m, w)) return 0;
   return w.total;
@@ -1287,6 +1454,18 @@ extern "C" int tgmx_recency_step(const tgmx_recency_step_t* s, tgmx_stream_t str
     grp.out_nid = s->seed_nid0; grp.out_ts = s->seed_ts0; grp.groups = s->n_groups;
   }
 
+  // ---- ring update, front half: batches of up to kBlockMaxM entries are sorted by workgroups riding along with the
+  // lookup launches (chunk sort with hop 0, merge with hop 1); only the placement runs after the lookups
+  UpdateArgs u{};
+  unsigned side_chunks = 0;
+  if (s->n > 0) {
+    const int rc = fill_update_args(u, s->ring, s->write_pos, s->ring_x, s->D, s->B, s->num_nodes, s->src, s->dst, s->ts,
+                                    s->edge_x, s->n, s->eid0, s->directed, s->key_wrap32, s->scratch, s->status);
+    if (rc) return rc;
+    static const bool no_ride = getenv("TGMX_NO_RIDE") != nullptr;  // A/B knob: the update as its own launches
+    if (u.m <= kBlockMaxM && s->n_hops > 0 && S > 0 && !no_ride) side_chunks = set_chunk_scratch(u, s->scratch);
+  }
+
   // ---- lookups, hop by hop (hop h + 1 consumes hop h's outputs in place)
   const int32_t* cur_n = s->seed_nid0;
   const int64_t* cur_t = s->seed_ts0;
@@ -1303,7 +1482,9 @@ extern "C" int tgmx_recency_step(const tgmx_recency_step_t* s, tgmx_stream_t str
     a.ev_lo = s->ev_lo; a.ev_hi = s->ev_hi;
     const bool timed = h == s->timed_hop;
     hipEvent_t e0 = timed ? (hipEvent_t)s->ev_start : nullptr, e1 = timed ? (hipEvent_t)s->ev_stop : nullptr;
-    const int rc = csr ? launch_lookup<false>(a, st, e0, e1) : launch_lookup<true>(a, st, e0, e1);
+    const bool ride = side_chunks > 0 && h < 2;
+    const int rc = csr ? launch_lookup<false>(a, st, e0, e1)
+                       : launch_lookup<true>(a, st, e0, e1, ride ? &u : nullptr, h == 0 ? kSideSort : kSideMerge, side_chunks);
     if (rc) return rc;
     cur_n = s->out_nid[h];
     cur_t = s->out_ts[h];
@@ -1312,12 +1493,14 @@ extern "C" int tgmx_recency_step(const tgmx_recency_step_t* s, tgmx_stream_t str
 
   // ---- ring update (after every lookup, recency.py:161-163)
   if (s->n > 0) {
-    UpdateArgs u;
-    const int rc = fill_update_args(u, s->ring, s->write_pos, s->ring_x, s->D, s->B, s->num_nodes, s->src, s->dst, s->ts,
-                                    s->edge_x, s->n, s->eid0, s->directed, s->key_wrap32, s->scratch, s->status);
-    if (rc) return rc;
-    if (u.m <= kBlockMaxM) launch_update_block(u, s->scratch, st);
-    else if (const int rl = launch_update_large(u, s->scratch, st)) return rl;
+    if (side_chunks > 0) {
+      if (s->n_hops < 2) hipLaunchKernelGGL(ring_update_merge_kernel, dim3(side_chunks), dim3(kChunk), 0, st, u);
+      launch_update_presorted(u, st);
+    } else if (u.m <= kBlockMaxM) {
+      launch_update_block(u, s->scratch, st);
+    } else if (const int rl = launch_update_large(u, s->scratch, st)) {
+      return rl;
+    }
   }
   TGMX_CHECK_LAUNCH("recency_step");
   return TGMX_OK;
