@@ -216,6 +216,247 @@ __device__ __forceinline__ long long strided_min_ts(const int64_t* __restrict__ 
   return mn;
 }
 
+// Batches of up to kBlockMaxM entries (every TGB-style batch size, and the replicated update of an 8-rank
+// global batch): ONE workgroup with the working set in LDS (gfx950: 160 KiB per CU).
+//   sort  : bitonic network over (key, entry index) pairs -- unique, so the order is the stable one.  Thread t
+//           holds E consecutive elements in registers: compare distances < E are in-register, distances < 64 E
+//           are lane shuffles inside the wave (no barrier, no LDS), only distances >= 64 E go through LDS
+//           (6 of the 45 steps at m = 400; 10 of 78 at m = 4096).
+//   runs  : maximal runs of equal node in sorted order by an inclusive max-scan (hub runs are long).
+//   place : ring slot = (write_pos[node] % B + offset inside the kept part of the run) % B; collisions between
+//           runs of one node are resolved through an LDS open-addressing hash (atomicMax of the sorted position:
+//           the last one wins).
+//   write : winners write their record; the last entry of every run advances write_pos by #kept with one
+//           atomicAdd (every reader takes write_pos % B).
+constexpr int kBlockThreads = 1024;
+
+
+// element e (mine) against its partner at distance jj in the step of bitonic stage k: keep min or max
+__device__ __forceinline__ void bitonic_select(long long& key, int& pay, long long pk, int pp, int e, int jj, int k) {
+  const bool low = (e & jj) == 0, asc = (e & k) == 0;
+  const bool mine_after = pair_after(key, pay, pk, pp);
+  if ((low == asc) == mine_after) {  // keep-min and mine is larger, or keep-max and mine is smaller
+    key = pk;
+    pay = pp;
+  }
+}
+
+__device__ __forceinline__ void commit_write_pos(int32_t* wp, int kept, int B) {
+  const int old = atomicAdd(wp, kept);
+  constexpr int kFold = 1 << 30;
+  if (old < kFold && old + kept >= kFold) atomicSub(wp, kFold / B * B);  // stay far from int32 overflow
+}
+
+// LDS of the placement (and, stand-alone, of the sort); the riders of the lookup launches carve theirs from a union
+template <int MAXM>
+struct PlaceLds {
+  int sn[MAXM];   // node at sorted position p (-1 invalid)
+  int len[MAXM];  // run length, stored at the run's first position
+  int h_key[2 * MAXM], h_maxp[2 * MAXM];  // hash load factor <= 0.5
+  long long red[kBlockThreads / kWave], red2[kBlockThreads / kWave];
+  int wave_tot[kBlockThreads / kWave];
+};
+template <int MAXM>
+struct SortLds {
+  long long key[MAXM];
+  int pay[MAXM];
+};
+
+// DEFER: decide everything, write nothing to the rings -- winner[p] = the ring row position p finally owns (-1 none),
+// target[p] = the write_pos increment position p commits (0 none); `ring_update_commit_kernel` applies them.
+template <int E, int MAXM, bool PRESORTED, bool DEFER>
+__device__ __forceinline__ void update_block_body(const UpdateArgs& a, PlaceLds<MAXM>& L, SortLds<PRESORTED ? 1 : MAXM>& S) {
+  constexpr int H = 2 * MAXM;
+  constexpr int HBITS = MAXM == 1024 ? 11 : (MAXM == 2048 ? 12 : 13);
+  static_assert((1 << HBITS) == H, "hash size");
+  long long* s_key = S.key;
+  int* s_pay = S.pay;
+  int* s_sn = L.sn;
+  int* s_len = L.len;
+  int* h_key = L.h_key;
+  int* h_maxp = L.h_maxp;
+  long long* red = L.red;
+  long long* red2 = L.red2;
+  int* wave_tot = L.wave_tot;
+  const int m = (int)a.m;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nthr = blockDim.x, nwaves = nthr >> 6;
+  const int P = nthr * E;  // power of two >= m; thread t owns sorted positions t*E .. t*E + E-1
+
+  for (int x = tid; x < H; x += nthr) {
+    h_key[x] = -1;
+    h_maxp[x] = -1;
+  }
+  int pay[E], node[E], w[E];
+  if constexpr (PRESORTED) {
+    // sorted order, nodes and write_pos % B were produced by the chunk-sort + merge kernels
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+      const int p = tid * E + r;
+      pay[r] = p;
+      node[r] = -1;
+      w[r] = 0;
+      if (p < m) {
+        pay[r] = a.sorted_j[p];
+        node[r] = a.sorted_node[p];
+        w[r] = a.target[p];
+      }
+    }
+  } else {
+    static_assert(PRESORTED || E == 1, "the in-kernel sort holds one element per thread");
+    long long mx = strided_max_ts(a.ts, a.n, tid, nthr), mn = strided_min_ts(a.ts, a.n, tid, nthr);
+    for (int off = 32; off > 0; off >>= 1) {
+      const long long o = __shfl_xor(mx, off), o2 = __shfl_xor(mn, off);
+      mx = o > mx ? o : mx;
+      mn = o2 < mn ? o2 : mn;
+    }
+    if (lane == 0) {
+      red[wave] = mx;
+      red2[wave] = mn;
+    }
+    __syncthreads();
+    mx = red[0];
+    mn = red2[0];
+    for (int wv = 1; wv < nwaves; ++wv) {
+      mx = red[wv] > mx ? red[wv] : mx;
+      mn = red2[wv] < mn ? red2[wv] : mn;
+    }
+    const long long span = mx + 1;
+    const bool packed = can_pack(a.key_wrap32, mn, mx);
+
+    long long key = 0x7fffffffffffffffLL;  // padding sorts to the end
+    pay[0] = tid;
+    if (tid < m) {
+      int nd, nbr;
+      long long t, i;
+      update_entry(a, tid, nd, nbr, t, i);
+      key = update_key(nd, t, span, a.key_wrap32);
+      if (packed) key = packed_key(key, tid);
+    }
+    if (packed) bitonic_sort_one<true>(key, pay[0], s_key, s_pay, tid, P);
+    else bitonic_sort_one<false>(key, pay[0], s_key, s_pay, tid, P);
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+      const int p = tid * E + r;
+      node[r] = -1;
+      w[r] = 0;
+      if (p < m) {
+        int nd, nbr;
+        long long t, i;
+        update_entry(a, pay[r], nd, nbr, t, i);
+        const bool valid = nd >= 0 && nd < a.N && nbr >= 0 && nbr < a.N;
+        if (!valid) atomicOr(a.status, TGMX_ST_EDGE_RANGE);
+        if (valid) {
+          node[r] = nd;
+          w[r] = a.write_pos[nd] % a.B;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < E; ++r) s_sn[tid * E + r] = node[r];
+  __syncthreads();
+
+  // run start of every sorted position = last position <= p that opens a run: max-scan, thread -> wave -> block
+  int st[E];
+  {
+    int run = 0;
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+      const int p = tid * E + r;
+      if (p == 0 || s_sn[p - 1] != node[r]) run = p;
+      st[r] = run;
+    }
+    int incl = run;  // positions only grow, so the thread's last value is its maximum
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+      const int o = __shfl_up(incl, off);
+      if (lane >= off) incl = o > incl ? o : incl;
+    }
+    if (lane == kWave - 1) wave_tot[wave] = incl;
+    int before = __shfl_up(incl, 1);
+    if (lane == 0) before = 0;
+    __syncthreads();
+    for (int wv = 0; wv < wave; ++wv) before = wave_tot[wv] > before ? wave_tot[wv] : before;
+#pragma unroll
+    for (int r = 0; r < E; ++r) st[r] = st[r] > before ? st[r] : before;
+  }
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    const int p = tid * E + r;
+    if (p < m && (p == m - 1 || s_sn[p + 1] != node[r])) s_len[st[r]] = p - st[r] + 1;
+  }
+  __syncthreads();
+
+  // placement; collisions between runs of one node resolved by atomicMax of the sorted position
+  int tgt[E], hs[E], cnt[E];
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    const int p = tid * E + r;
+    tgt[r] = -1;
+    hs[r] = 0;
+    cnt[r] = 0;
+    if (p < m && node[r] >= 0) {
+      cnt[r] = s_len[st[r]];
+      const int pos = p - st[r];
+      const int drop = cnt[r] > a.B ? cnt[r] - a.B : 0;
+      if (pos >= drop) {
+        const int t = node[r] * a.B + (w[r] + pos - drop) % a.B;
+        unsigned h = ((unsigned)t * 2654435761u) >> (32 - HBITS);
+        for (;;) {
+          const int old = atomicCAS(&h_key[h], -1, t);
+          if (old == -1 || old == t) break;
+          h = (h + 1) & (H - 1);
+        }
+        atomicMax(&h_maxp[h], p);
+        tgt[r] = t;
+        hs[r] = (int)h;
+      }
+    }
+  }
+  __syncthreads();
+
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    const int p = tid * E + r;
+    if (p >= m) continue;
+    int win = -1, kept = 0;
+    if (tgt[r] >= 0) {
+      if (h_maxp[hs[r]] == p) {
+        Rec rec;
+        if constexpr (DEFER) {
+          // the commit kernel reads sorted_rec[p] itself
+        } else if constexpr (PRESORTED) {
+          rec = a.sorted_rec[p];
+        } else {
+          int nd, nbr;
+          long long t, i;
+          update_entry(a, pay[r], nd, nbr, t, i);
+          rec.nbr = nbr;
+          rec.eid = a.eid0 >= 0 ? (int)(a.eid0 + i) : -1;
+          rec.ts = t;
+        }
+        if constexpr (!DEFER) a.ring[tgt[r]] = rec;
+        win = tgt[r];
+      }
+      if (p == st[r] + cnt[r] - 1) {  // the run's last entry commits the run (every write_pos read is behind a barrier)
+        kept = cnt[r] > a.B ? a.B : cnt[r];
+        if constexpr (!DEFER) commit_write_pos(&a.write_pos[node[r]], kept, a.B);
+      }
+    }
+    a.winner[p] = win;
+    if constexpr (DEFER) a.target[p] = kept;
+    if constexpr (!PRESORTED) a.sorted_j[p] = pay[r];
+  }
+}
+
+template <int E, int MAXM, bool PRESORTED>
+__global__ __launch_bounds__(kBlockThreads) void ring_update_block_kernel(const UpdateArgs a) {
+  __shared__ PlaceLds<MAXM> L;
+  __shared__ SortLds<PRESORTED ? 1 : MAXM> S;
+  update_block_body<E, MAXM, PRESORTED, false>(a, L, S);
+}
+
 // ---- the state-independent half of the ring update, as workgroup-sized pieces -------------------------------------
 // The order of a batch's entries depends on the batch alone, not on the rings, so `tgmx_recency_step` lets it ride
 // along with the lookups: the first `side_blocks` workgroups of the hop-0 launch chunk-sort the entries, the first
@@ -224,10 +465,17 @@ __device__ __forceinline__ long long strided_min_ts(const int64_t* __restrict__ 
 // (PRESORTED) and the feature copy.  The same pieces are the chunked path of the stand-alone `tgmx_ring_update`.
 
 // one 256-thread workgroup sorts entries [chunk * 256, chunk * 256 + 256) by (key, entry index)
-__device__ __forceinline__ void update_chunk_sort(const UpdateArgs& a, int chunk) {
-  __shared__ long long s_key[kChunk];
-  __shared__ int s_pay[kChunk];
-  __shared__ long long red[kChunk / kWave], red2[kChunk / kWave];
+struct ChunkSortLds {
+  long long key[kChunk];
+  int pay[kChunk];
+  long long red[kChunk / kWave], red2[kChunk / kWave];
+};
+
+__device__ __forceinline__ void update_chunk_sort(const UpdateArgs& a, int chunk, ChunkSortLds& W) {
+  long long* s_key = W.key;
+  int* s_pay = W.pay;
+  long long* red = W.red;
+  long long* red2 = W.red2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   long long mx = strided_max_ts(a.ts, a.n, tid, kChunk), mn = strided_min_ts(a.ts, a.n, tid, kChunk);
   for (int off = 32; off > 0; off >>= 1) {
@@ -330,82 +578,138 @@ __device__ __forceinline__ void update_merge_entry(const UpdateArgs& a, const lo
 // that sort last (chunk sort), so no length bookkeeping is needed.
 constexpr int kSampleEvery = 8, kSamplesPerChunk = kChunk / kSampleEvery;
 
-__device__ __forceinline__ void update_merge_riding(const UpdateArgs& a, int c) {
-  constexpr int kMaxChunks = kBlockMaxM / kChunk;
-  __shared__ long long smp_key[kMaxChunks * kSamplesPerChunk];
-  __shared__ int smp_pay[kMaxChunks * kSamplesPerChunk];
+struct SampleLds {
+  long long key[(kBlockMaxM / kChunk) * kSamplesPerChunk];
+  int pay[(kBlockMaxM / kChunk) * kSamplesPerChunk];
+};
+
+// NE entries per thread (entry `tid` of chunks c0 .. c0 + NE - 1), each searched in up to NC chunks; NE * NC
+// searches advance together.  <1, 16>: one workgroup per chunk, any m <= 4096.  <4, 4>: ONE workgroup merges a whole
+// batch of m <= 1024 entries (and goes on to place it, see below).
+template <int NE, int NC>
+__device__ __forceinline__ void update_merge_riding(const UpdateArgs& a, int c0, SampleLds& W) {
   const int m = (int)a.m;
   const int tid = threadIdx.x;
   const int chunks = (m + kChunk - 1) / kChunk;
   const long long* __restrict__ gk = a.key;
   const int* __restrict__ gp = a.node;
   for (int x = tid; x < chunks * kSamplesPerChunk; x += kChunk) {  // <= 2 rounds
-    smp_key[x] = gk[x * kSampleEvery];
-    smp_pay[x] = gp[x * kSampleEvery];
+    W.key[x] = gk[x * kSampleEvery];
+    W.pay[x] = gp[x * kSampleEvery];
   }
-  const int e = c * kChunk + tid;
-  const bool act = e < m;
-  const long long key = act ? gk[e] : 0;
-  const int pay = act ? gp[e] : 0;
+  long long key[NE];
+  int pay[NE];
+  bool act[NE];
+#pragma unroll
+  for (int q = 0; q < NE; ++q) {
+    const int e = (c0 + q) * kChunk + tid;
+    act[q] = e < m;
+    key[q] = act[q] ? gk[e] : 0;
+    pay[q] = act[q] ? gp[e] : 0;
+  }
   __syncthreads();
-  if (!act) return;
 
-  // pos[o] = number of pairs of chunk o known to sort before mine; after the sample search it is 8 * (#samples before
-  // mine - 1) + 1 (the sample itself is before mine, the next sample is not), or 0 when no sample is
-  int pos[kMaxChunks];
+  // pos[q][o] = number of pairs of chunk o known to sort before entry q; after the sample search it is
+  // 8 * (#samples before mine - 1) + 1 (that sample is before mine, the next one is not), -1 when nothing of the chunk
+  // is before mine (or there is no such search)
+  int pos[NE][NC];
 #pragma unroll
-  for (int o = 0; o < kMaxChunks; ++o) {
-    int cnt = 0;  // samples of chunk o before mine, 0..32
-    if (o < chunks && o != c) {
-      const long long* sk = smp_key + o * kSamplesPerChunk;
-      const int* sp = smp_pay + o * kSamplesPerChunk;
-      if (pair_after(key, pay, sk[kSamplesPerChunk - 1], sp[kSamplesPerChunk - 1])) {
-        cnt = kSamplesPerChunk;
-      } else {
+  for (int q = 0; q < NE; ++q) {
 #pragma unroll
-        for (int st = kSamplesPerChunk / 2; st > 0; st >>= 1)
-          if (pair_after(key, pay, sk[cnt + st - 1], sp[cnt + st - 1])) cnt += st;
+    for (int o = 0; o < NC; ++o) {
+      int cnt = 0;  // samples of chunk o before mine, 0..32
+      if (act[q] && o < chunks && o != c0 + q) {
+        const long long* sk = W.key + o * kSamplesPerChunk;
+        const int* sp = W.pay + o * kSamplesPerChunk;
+        if (pair_after(key[q], pay[q], sk[kSamplesPerChunk - 1], sp[kSamplesPerChunk - 1])) {
+          cnt = kSamplesPerChunk;
+        } else {
+#pragma unroll
+          for (int st = kSamplesPerChunk / 2; st > 0; st >>= 1)
+            if (pair_after(key[q], pay[q], sk[cnt + st - 1], sp[cnt + st - 1])) cnt += st;
+        }
+      }
+      pos[q][o] = cnt > 0 ? (cnt - 1) * kSampleEvery + 1 : -1;
+    }
+  }
+#pragma unroll
+  for (int st = kSampleEvery / 2; st > 0; st >>= 1) {  // 3 dependent global rounds, every search in flight
+    long long k2[NE][NC];
+#pragma unroll
+    for (int q = 0; q < NE; ++q)
+#pragma unroll
+      for (int o = 0; o < NC; ++o) k2[q][o] = pos[q][o] >= 0 ? gk[o * kChunk + pos[q][o] + st - 1] : 0;
+#pragma unroll
+    for (int q = 0; q < NE; ++q) {
+#pragma unroll
+      for (int o = 0; o < NC; ++o) {
+        if (pos[q][o] < 0) continue;
+        bool after = key[q] > k2[q][o];
+        if (key[q] == k2[q][o]) after = pay[q] > gp[o * kChunk + pos[q][o] + st - 1];  // equal unpacked keys only
+        if (after) pos[q][o] += st;
       }
     }
-    pos[o] = cnt > 0 ? (cnt - 1) * kSampleEvery + 1 : -1;  // -1: nothing of this chunk is before mine (or no chunk)
+  }
+  // everything the placement would otherwise gather with dependent loads
+  int node[NE], nbr[NE];
+  long long t[NE], i[NE];
+#pragma unroll
+  for (int q = 0; q < NE; ++q) {
+    node[q] = nbr[q] = -1;
+    t[q] = i[q] = 0;
+    if (act[q]) update_entry(a, pay[q], node[q], nbr[q], t[q], i[q]);
+  }
+  int w[NE];
+  bool valid[NE];
+#pragma unroll
+  for (int q = 0; q < NE; ++q) {
+    valid[q] = act[q] && node[q] >= 0 && node[q] < a.N && nbr[q] >= 0 && nbr[q] < a.N;
+    w[q] = valid[q] ? a.write_pos[node[q]] : 0;  // write_pos only moves after the lookups
   }
 #pragma unroll
-  for (int st = kSampleEvery / 2; st > 0; st >>= 1) {  // 3 dependent global rounds, all chunks in flight
-    long long k2[kMaxChunks];
+  for (int q = 0; q < NE; ++q) {
+    if (!act[q]) continue;
+    int rank = tid;
 #pragma unroll
-    for (int o = 0; o < kMaxChunks; ++o) k2[o] = pos[o] >= 0 ? gk[o * kChunk + pos[o] + st - 1] : 0;
-#pragma unroll
-    for (int o = 0; o < kMaxChunks; ++o) {
-      if (pos[o] < 0) continue;
-      bool after = key > k2[o];
-      if (key == k2[o]) after = pay > gp[o * kChunk + pos[o] + st - 1];  // equal unpacked keys only: the entry index decides
-      if (after) pos[o] += st;
-    }
+    for (int o = 0; o < NC; ++o) rank += pos[q][o] >= 0 ? pos[q][o] : 0;
+    if (!valid[q]) atomicOr(a.status, TGMX_ST_EDGE_RANGE);
+    Rec rec;
+    rec.nbr = nbr[q];
+    rec.eid = a.eid0 >= 0 ? (int)(a.eid0 + i[q]) : -1;
+    rec.ts = t[q];
+    a.sorted_j[rank] = pay[q];
+    a.sorted_node[rank] = valid[q] ? node[q] : -1;
+    a.target[rank] = w[q] % a.B;
+    a.sorted_rec[rank] = rec;
   }
-  int rank = tid;
-#pragma unroll
-  for (int o = 0; o < kMaxChunks; ++o) rank += pos[o] >= 0 ? pos[o] : 0;
-
-  int node, nbr;
-  long long t, i;
-  update_entry(a, pay, node, nbr, t, i);
-  const bool valid = node >= 0 && node < a.N && nbr >= 0 && nbr < a.N;
-  if (!valid) atomicOr(a.status, TGMX_ST_EDGE_RANGE);
-  Rec rec;
-  rec.nbr = nbr;
-  rec.eid = a.eid0 >= 0 ? (int)(a.eid0 + i) : -1;
-  rec.ts = t;
-  a.sorted_j[rank] = pay;
-  a.sorted_node[rank] = valid ? node : -1;
-  a.target[rank] = valid ? a.write_pos[node] % a.B : 0;  // write_pos only moves in the placement kernel
-  a.sorted_rec[rank] = rec;
 }
 
-constexpr int kSideSort = 1, kSideMerge = 2;
+// What rides along with which launch (tgmx_recency_step):
+//   kSideSort  (hop 0): workgroup c chunk-sorts entries [256 c, 256 c + 256)
+//   kSideMerge (hop 1, 1024 < m <= 4096): workgroup c ranks chunk c's entries; the placement is its own launch
+//   kSidePlace (hop 1, m <= 1024): ONE workgroup merges the whole batch and decides the placement (DEFER): after the
+//              lookups a single launch commits records, write_pos and feature rows
+constexpr int kSideSort = 1, kSideMerge = 2, kSidePlace = 3;
+constexpr int kRidePlaceMaxM = 1024;
+
+union RiderLds {
+  ChunkSortLds sort;
+  SampleLds smp;
+  PlaceLds<kRidePlaceMaxM> place;
+};
 
 __device__ __forceinline__ void update_side_work(const UpdateArgs& u, int stage, int block) {
-  if (stage == kSideSort) update_chunk_sort(u, block);
-  else update_merge_riding(u, block);
+  __shared__ RiderLds W;
+  if (stage == kSideSort) {
+    update_chunk_sort(u, block, W.sort);
+  } else if (stage == kSideMerge) {
+    update_merge_riding<1, kBlockMaxM / kChunk>(u, block, W.smp);
+  } else {
+    update_merge_riding<4, 4>(u, 0, W.smp);
+    __syncthreads();  // the sorted arrays written above are read below by other threads of this workgroup
+    SortLds<1> none;
+    update_block_body<4, kRidePlaceMaxM, true, true>(u, W.place, none);
+  }
 }
 
 
@@ -837,12 +1141,21 @@ __global__ __launch_bounds__(256) void ring_update_write_kernel(const UpdateArgs
   a.winner[p] = win;
 }
 
-// one wave per sorted position: copy the winning entry's D-float feature row
+// one wave per sorted position: copy the winning entry's D-float feature row.  COMMIT (after a riding placement, which
+// only decided): lane 0 also writes the winner's record and the run's write_pos increment
+template <bool COMMIT>
 __global__ __launch_bounds__(256) void ring_update_feat_kernel(const UpdateArgs a) {
   const long long p = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (p >= a.m) return;
   const int row = a.winner[p];
-  if (row < 0) return;
+  if constexpr (COMMIT) {
+    if (lane_id() == 0) {
+      const int kept = a.target[p];
+      if (row >= 0) a.ring[row] = a.sorted_rec[p];
+      if (kept > 0) commit_write_pos(&a.write_pos[a.sorted_node[p]], kept, a.B);
+    }
+  }
+  if (row < 0 || a.D == 0) return;
   const long long j = a.sorted_j[p];
   const long long i = j >= a.n ? j - a.n : j;
   float* __restrict__ o = a.ring_x + (long long)row * a.D;
@@ -854,220 +1167,14 @@ __global__ __launch_bounds__(256) void ring_update_feat_kernel(const UpdateArgs 
   }
 }
 
-// Batches of up to kBlockMaxM entries (every TGB-style batch size, and the replicated update of an 8-rank
-// global batch): ONE workgroup with the working set in LDS (gfx950: 160 KiB per CU).
-//   sort  : bitonic network over (key, entry index) pairs -- unique, so the order is the stable one.  Thread t
-//           holds E consecutive elements in registers: compare distances < E are in-register, distances < 64 E
-//           are lane shuffles inside the wave (no barrier, no LDS), only distances >= 64 E go through LDS
-//           (6 of the 45 steps at m = 400; 10 of 78 at m = 4096).
-//   runs  : maximal runs of equal node in sorted order by an inclusive max-scan (hub runs are long).
-//   place : ring slot = (write_pos[node] % B + offset inside the kept part of the run) % B; collisions between
-//           runs of one node are resolved through an LDS open-addressing hash (atomicMax of the sorted position:
-//           the last one wins).
-//   write : winners write their record; the last entry of every run advances write_pos by #kept with one
-//           atomicAdd (every reader takes write_pos % B).
-constexpr int kBlockThreads = 1024;
-
-
-// element e (mine) against its partner at distance jj in the step of bitonic stage k: keep min or max
-__device__ __forceinline__ void bitonic_select(long long& key, int& pay, long long pk, int pp, int e, int jj, int k) {
-  const bool low = (e & jj) == 0, asc = (e & k) == 0;
-  const bool mine_after = pair_after(key, pay, pk, pp);
-  if ((low == asc) == mine_after) {  // keep-min and mine is larger, or keep-max and mine is smaller
-    key = pk;
-    pay = pp;
-  }
-}
-
-template <int E, int MAXM, bool PRESORTED>
-__global__ __launch_bounds__(kBlockThreads) void ring_update_block_kernel(const UpdateArgs a) {
-  constexpr int H = 2 * MAXM;  // hash load factor <= 0.5
-  constexpr int HBITS = MAXM == 1024 ? 11 : (MAXM == 2048 ? 12 : 13);
-  static_assert((1 << HBITS) == H, "hash size");
-  __shared__ long long s_key[MAXM];  // LDS leg of the sort
-  __shared__ int s_pay[MAXM];        // LDS leg of the sort
-  __shared__ int s_sn[MAXM];         // node at sorted position p (-1 invalid)
-  __shared__ int s_len[MAXM];        // run length, stored at the run's first position
-  __shared__ int h_key[H], h_maxp[H];
-  __shared__ long long red[kBlockThreads / kWave], red2[kBlockThreads / kWave];
-  __shared__ int wave_tot[kBlockThreads / kWave];
-  const int m = (int)a.m;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nthr = blockDim.x, nwaves = nthr >> 6;
-  const int P = nthr * E;  // power of two >= m; thread t owns sorted positions t*E .. t*E + E-1
-
-  for (int x = tid; x < H; x += nthr) {
-    h_key[x] = -1;
-    h_maxp[x] = -1;
-  }
-  int pay[E], node[E], w[E];
-  if constexpr (PRESORTED) {
-    // sorted order, nodes and write_pos % B were produced by the chunk-sort + merge kernels
-#pragma unroll
-    for (int r = 0; r < E; ++r) {
-      const int p = tid * E + r;
-      pay[r] = p;
-      node[r] = -1;
-      w[r] = 0;
-      if (p < m) {
-        pay[r] = a.sorted_j[p];
-        node[r] = a.sorted_node[p];
-        w[r] = a.target[p];
-      }
-    }
-  } else {
-    static_assert(PRESORTED || E == 1, "the in-kernel sort holds one element per thread");
-    long long mx = strided_max_ts(a.ts, a.n, tid, nthr), mn = strided_min_ts(a.ts, a.n, tid, nthr);
-    for (int off = 32; off > 0; off >>= 1) {
-      const long long o = __shfl_xor(mx, off), o2 = __shfl_xor(mn, off);
-      mx = o > mx ? o : mx;
-      mn = o2 < mn ? o2 : mn;
-    }
-    if (lane == 0) {
-      red[wave] = mx;
-      red2[wave] = mn;
-    }
-    __syncthreads();
-    mx = red[0];
-    mn = red2[0];
-    for (int wv = 1; wv < nwaves; ++wv) {
-      mx = red[wv] > mx ? red[wv] : mx;
-      mn = red2[wv] < mn ? red2[wv] : mn;
-    }
-    const long long span = mx + 1;
-    const bool packed = can_pack(a.key_wrap32, mn, mx);
-
-    long long key = 0x7fffffffffffffffLL;  // padding sorts to the end
-    pay[0] = tid;
-    if (tid < m) {
-      int nd, nbr;
-      long long t, i;
-      update_entry(a, tid, nd, nbr, t, i);
-      key = update_key(nd, t, span, a.key_wrap32);
-      if (packed) key = packed_key(key, tid);
-    }
-    if (packed) bitonic_sort_one<true>(key, pay[0], s_key, s_pay, tid, P);
-    else bitonic_sort_one<false>(key, pay[0], s_key, s_pay, tid, P);
-#pragma unroll
-    for (int r = 0; r < E; ++r) {
-      const int p = tid * E + r;
-      node[r] = -1;
-      w[r] = 0;
-      if (p < m) {
-        int nd, nbr;
-        long long t, i;
-        update_entry(a, pay[r], nd, nbr, t, i);
-        const bool valid = nd >= 0 && nd < a.N && nbr >= 0 && nbr < a.N;
-        if (!valid) atomicOr(a.status, TGMX_ST_EDGE_RANGE);
-        if (valid) {
-          node[r] = nd;
-          w[r] = a.write_pos[nd] % a.B;
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < E; ++r) s_sn[tid * E + r] = node[r];
-  __syncthreads();
-
-  // run start of every sorted position = last position <= p that opens a run: max-scan, thread -> wave -> block
-  int st[E];
-  {
-    int run = 0;
-#pragma unroll
-    for (int r = 0; r < E; ++r) {
-      const int p = tid * E + r;
-      if (p == 0 || s_sn[p - 1] != node[r]) run = p;
-      st[r] = run;
-    }
-    int incl = run;  // positions only grow, so the thread's last value is its maximum
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-      const int o = __shfl_up(incl, off);
-      if (lane >= off) incl = o > incl ? o : incl;
-    }
-    if (lane == kWave - 1) wave_tot[wave] = incl;
-    int before = __shfl_up(incl, 1);
-    if (lane == 0) before = 0;
-    __syncthreads();
-    for (int wv = 0; wv < wave; ++wv) before = wave_tot[wv] > before ? wave_tot[wv] : before;
-#pragma unroll
-    for (int r = 0; r < E; ++r) st[r] = st[r] > before ? st[r] : before;
-  }
-#pragma unroll
-  for (int r = 0; r < E; ++r) {
-    const int p = tid * E + r;
-    if (p < m && (p == m - 1 || s_sn[p + 1] != node[r])) s_len[st[r]] = p - st[r] + 1;
-  }
-  __syncthreads();
-
-  // placement; collisions between runs of one node resolved by atomicMax of the sorted position
-  int tgt[E], hs[E], cnt[E];
-#pragma unroll
-  for (int r = 0; r < E; ++r) {
-    const int p = tid * E + r;
-    tgt[r] = -1;
-    hs[r] = 0;
-    cnt[r] = 0;
-    if (p < m && node[r] >= 0) {
-      cnt[r] = s_len[st[r]];
-      const int pos = p - st[r];
-      const int drop = cnt[r] > a.B ? cnt[r] - a.B : 0;
-      if (pos >= drop) {
-        const int t = node[r] * a.B + (w[r] + pos - drop) % a.B;
-        unsigned h = ((unsigned)t * 2654435761u) >> (32 - HBITS);
-        for (;;) {
-          const int old = atomicCAS(&h_key[h], -1, t);
-          if (old == -1 || old == t) break;
-          h = (h + 1) & (H - 1);
-        }
-        atomicMax(&h_maxp[h], p);
-        tgt[r] = t;
-        hs[r] = (int)h;
-      }
-    }
-  }
-  __syncthreads();
-
-#pragma unroll
-  for (int r = 0; r < E; ++r) {
-    const int p = tid * E + r;
-    if (p >= m) continue;
-    int win = -1;
-    if (tgt[r] >= 0) {
-      if (h_maxp[hs[r]] == p) {
-        Rec rec;
-        if constexpr (PRESORTED) {
-          rec = a.sorted_rec[p];
-        } else {
-          int nd, nbr;
-          long long t, i;
-          update_entry(a, pay[r], nd, nbr, t, i);
-          rec.nbr = nbr;
-          rec.eid = a.eid0 >= 0 ? (int)(a.eid0 + i) : -1;
-          rec.ts = t;
-        }
-        a.ring[tgt[r]] = rec;
-        win = tgt[r];
-      }
-      if (p == st[r] + cnt[r] - 1) {  // the run's last entry commits the run (every write_pos read is behind a barrier)
-        const int kept = cnt[r] > a.B ? a.B : cnt[r];
-        int32_t* wp = &a.write_pos[node[r]];
-        const int old = atomicAdd(wp, kept);
-        constexpr int kFold = 1 << 30;
-        if (old < kFold && old + kept >= kFold) atomicSub(wp, kFold / a.B * a.B);  // stay far from int32 overflow
-      }
-    }
-    a.winner[p] = win;
-    if constexpr (!PRESORTED) a.sorted_j[p] = pay[r];
-  }
-}
-
 // 1024 < m <= kBlockMaxM stand-alone (the replicated update of a 4- or 8-rank global batch through `tgmx_ring_update`):
 // one workgroup is VALU-bound on the sorting network (37 us at m = 3200), so the sort is spread over the chip with the
 // pieces above (chunk sort, then merge with all chunk-sorted keys staged in LDS) and the single-workgroup kernel runs
 // with PRESORTED = true (runs, placement, collisions, writes).
-__global__ __launch_bounds__(kChunk) void ring_update_chunk_sort_kernel(const UpdateArgs a) { update_chunk_sort(a, blockIdx.x); }
+__global__ __launch_bounds__(kChunk) void ring_update_chunk_sort_kernel(const UpdateArgs a) {
+  __shared__ ChunkSortLds W;
+  update_chunk_sort(a, blockIdx.x, W);
+}
 
 __global__ __launch_bounds__(kChunk) void ring_update_merge_kernel(const UpdateArgs a) {
   __shared__ long long k_all[kBlockMaxM];
@@ -1114,7 +1221,7 @@ static void launch_update_presorted(const UpdateArgs& a, hipStream_t st) {
   if (P <= 1024) hipLaunchKernelGGL((ring_update_block_kernel<1, 1024, true>), dim3(1), dim3(P), 0, st, a);
   else if (P == 2048) hipLaunchKernelGGL((ring_update_block_kernel<2, 2048, true>), dim3(1), dim3(1024), 0, st, a);
   else hipLaunchKernelGGL((ring_update_block_kernel<4, 4096, true>), dim3(1), dim3(1024), 0, st, a);
-  if (a.D > 0) hipLaunchKernelGGL(ring_update_feat_kernel, dim3((unsigned)((a.m + 3) / 4)), dim3(256), 0, st, a);
+  if (a.D > 0) hipLaunchKernelGGL(ring_update_feat_kernel<false>, dim3((unsigned)((a.m + 3) / 4)), dim3(256), 0, st, a);
 }
 
 static void launch_update_block(UpdateArgs& a, int32_t* scratch, hipStream_t st) {
@@ -1122,7 +1229,7 @@ static void launch_update_block(UpdateArgs& a, int32_t* scratch, hipStream_t st)
   while (P < a.m) P <<= 1;
   if (P <= 1024) {
     hipLaunchKernelGGL((ring_update_block_kernel<1, 1024, false>), dim3(1), dim3(P), 0, st, a);
-    if (a.D > 0) hipLaunchKernelGGL(ring_update_feat_kernel, dim3((unsigned)((a.m + 3) / 4)), dim3(256), 0, st, a);
+    if (a.D > 0) hipLaunchKernelGGL(ring_update_feat_kernel<false>, dim3((unsigned)((a.m + 3) / 4)), dim3(256), 0, st, a);
     return;
   }
   const unsigned chunks = set_chunk_scratch(a, scratch);
@@ -1396,7 +1503,7 @@ static int launch_update_large(UpdateArgs& a, int32_t* scratch, hipStream_t st) 
   hipLaunchKernelGGL(ring_update_ends_kernel, dim3(blocks), dim3(256), 0, st, a);
   hipLaunchKernelGGL(ring_update_place_kernel, dim3(blocks), dim3(256), 0, st, a);
   hipLaunchKernelGGL(ring_update_write_kernel, dim3(blocks), dim3(256), 0, st, a);
-  if (a.D > 0) hipLaunchKernelGGL(ring_update_feat_kernel, dim3((unsigned)((a.m + 3) / 4)), dim3(256), 0, st, a);
+  if (a.D > 0) hipLaunchKernelGGL(ring_update_feat_kernel<false>, dim3((unsigned)((a.m + 3) / 4)), dim3(256), 0, st, a);
   return TGMX_OK;
 }
 
@@ -1458,12 +1565,14 @@ extern "C" int tgmx_recency_step(const tgmx_recency_step_t* s, tgmx_stream_t str
   // lookup launches (chunk sort with hop 0, merge with hop 1); only the placement runs after the lookups
   UpdateArgs u{};
   unsigned side_chunks = 0;
+  bool ride_place = false;  // m <= 1024: hop 1 carries the merge AND the placement decisions
   if (s->n > 0) {
     const int rc = fill_update_args(u, s->ring, s->write_pos, s->ring_x, s->D, s->B, s->num_nodes, s->src, s->dst, s->ts,
                                     s->edge_x, s->n, s->eid0, s->directed, s->key_wrap32, s->scratch, s->status);
     if (rc) return rc;
     static const bool no_ride = getenv("TGMX_NO_RIDE") != nullptr;  // A/B knob: the update as its own launches
     if (u.m <= kBlockMaxM && s->n_hops > 0 && S > 0 && !no_ride) side_chunks = set_chunk_scratch(u, s->scratch);
+    ride_place = side_chunks > 0 && u.m <= kRidePlaceMaxM && s->n_hops >= 2;
   }
 
   // ---- lookups, hop by hop (hop h + 1 consumes hop h's outputs in place)
@@ -1484,7 +1593,9 @@ extern "C" int tgmx_recency_step(const tgmx_recency_step_t* s, tgmx_stream_t str
     hipEvent_t e0 = timed ? (hipEvent_t)s->ev_start : nullptr, e1 = timed ? (hipEvent_t)s->ev_stop : nullptr;
     const bool ride = side_chunks > 0 && h < 2;
     const int rc = csr ? launch_lookup<false>(a, st, e0, e1)
-                       : launch_lookup<true>(a, st, e0, e1, ride ? &u : nullptr, h == 0 ? kSideSort : kSideMerge, side_chunks);
+                       : launch_lookup<true>(a, st, e0, e1, ride ? &u : nullptr,
+                                             h == 0 ? kSideSort : (ride_place ? kSidePlace : kSideMerge),
+                                             (h == 1 && ride_place) ? 1u : side_chunks);
     if (rc) return rc;
     cur_n = s->out_nid[h];
     cur_t = s->out_ts[h];
@@ -1493,7 +1604,9 @@ extern "C" int tgmx_recency_step(const tgmx_recency_step_t* s, tgmx_stream_t str
 
   // ---- ring update (after every lookup, recency.py:161-163)
   if (s->n > 0) {
-    if (side_chunks > 0) {
+    if (ride_place) {
+      hipLaunchKernelGGL(ring_update_feat_kernel<true>, dim3((unsigned)((u.m + 3) / 4)), dim3(256), 0, st, u);
+    } else if (side_chunks > 0) {
       if (s->n_hops < 2) hipLaunchKernelGGL(ring_update_merge_kernel, dim3(side_chunks), dim3(kChunk), 0, st, u);
       launch_update_presorted(u, st);
     } else if (u.m <= kBlockMaxM) {

@@ -31,6 +31,7 @@ cd $ROOT
 python tools/pmc_extract.py $OUT/prof_fetch/fetch_results.db $OUT/prof_write/write_results.db $OUT/pmc_hop1.json
 python tools/bench_tgat.py 200 > $OUT/bench_tgat.json 2> $OUT/bench_tgat.err; cat $OUT/bench_tgat.json
 python tools/time_update.py > $OUT/time_update.json 2>/dev/null; cat $OUT/time_update.json
+python tools/time_step_world.py wiki ring > $OUT/step_by_world.json 2>/dev/null; tail -1 $OUT/step_by_world.json
 python tools/bench_tgat_train.py 100 > $OUT/bench_tgat_train.json 2>/dev/null; cat $OUT/bench_tgat_train.json
 python tools/bench_tgn.py 300 > $OUT/bench_tgn.json 2>/dev/null; cat $OUT/bench_tgn.json
 python tools/bench_tgcn.py > $OUT/bench_tgcn.json 2>/dev/null; cat $OUT/bench_tgcn.json
