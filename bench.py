@@ -205,16 +205,20 @@ def main():
     # ---- roofline of the dominant kernel (last hop's lookup + gather launch) -----------
     log = hook.profile_log
     hook.profile_hop = None
-    ker_ms = [t.elapsed_ms() for t, *_ in log]
+    ker_ms = [t.elapsed_ms() for t, _ in log]
     avg_ms = sum(ker_ms) / max(len(ker_ms), 1)
-    seeds_l = log[0][1] if log else 0
-    k_l = log[0][2] if log else 0
-    valid = sum(int((nid >= 0).sum().item()) for *_, nid in log) / max(len(log), 1)
-    total_slots = seeds_l * k_l
+    # the timed launch covers one hop, or hop 0 + hop 1 when tgmx_recency_step runs them as one launch
+    shape = [(seeds, k) for seeds, k, _ in log[0][1]] if log else []
+    seeds_l = sum(seeds for seeds, _ in shape)
+    total_slots = sum(seeds * k for seeds, k in shape)
+    valid = sum(int((nid >= 0).sum().item()) for _, hops in log for *_, nid in hops) / max(len(log), 1)
     # algorithmic bytes per launch: every slot is written (id 4 + ts 8 + 4D),
     # valid slots also read their 16-byte record and 4D-byte feature row; 68 B of index traffic per seed
     algo_bytes = total_slots * (12 + 4 * D) + valid * (16 + 4 * D) + seeds_l * 68
     achieved = algo_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    fused = len(shape) > 1
+    kernel_name = ('recency_lookup_fused01_kernel (hop 0 + hop 1 in one launch: ' if fused else f'recency_lookup_kernel (hop {last_hop}: ') + \
+        ' + '.join(f'{seeds} seeds x k={k}' for seeds, k in shape) + ')'
 
     total_units = args.steps * slots_per_step * world
     out = {
@@ -240,12 +244,12 @@ def main():
         },
         'roofline': {
             'bound': 'hbm',
-            'kernel': f'recency_lookup_kernel (hop {last_hop}: {seeds_l} seeds x k={k_l})',
+            'kernel': kernel_name,
             'achieved': achieved,
             'peak': HBM_PEAK_GBS,
             'unit': 'GB/s',
             'frac': achieved / HBM_PEAK_GBS,
-            'traffic': pmc_traffic(args, seeds_l * k_l),
+            'traffic': pmc_traffic(args, total_slots),
             'avg_kernel_ms': avg_ms,
             'launches_timed': len(ker_ms),
             'algorithmic_bytes_per_launch': algo_bytes,

@@ -135,6 +135,12 @@ int tgmx_ring_update(tgmx_adj_t* ring, int32_t* write_pos, float* ring_x, int32_
  * Semantics are exactly tgmx_ring_lookup x n_hops followed by tgmx_ring_update (or, with indptr set,
  * tgmx_recency_lookup_csr x n_hops against the static index); the seed concatenation rides
  * on the hop-0 lookup launch (its wave of seed s reads group g's arrays and publishes seed_nid0[s] / seed_ts0[s]).
+ * Scheduling (results identical): for batches of up to 4096 ring entries (2 per edge, 1 if directed) the update's
+ * sort -- and up to 1024 entries also its placement decisions, which read write_pos but write only the scratch -- run
+ * in extra workgroups of the hop-0 / hop-1 lookup launches; the rings themselves are written by the launch(es) that
+ * follow the last lookup.  Hop 0 and hop 1 are one launch when tgmx_recency_step_plan says so (hop 1's waves re-derive
+ * their seed from the unchanged rings instead of waiting for hop 0's output).
+ *   timed_hop = 0 or 1 then times that one launch.
  *   n_groups = 0: hop-0 seeds are already in seed_nid0 / seed_ts0 (S0 of them).
  *   n_hops   = 0: update only.          n = 0: lookups only.
  *   timed_hop >= 0: ev_start / ev_stop are recorded around that hop's lookup launch. */
@@ -172,6 +178,10 @@ typedef struct tgmx_recency_step {
 } tgmx_recency_step_t;
 
 int tgmx_recency_step(const tgmx_recency_step_t* step, tgmx_stream_t stream);
+/* How tgmx_recency_step would schedule this argument block: bit 0 = hop 0 and hop 1 run as ONE launch (B <= 64, hop 1
+ * not served by the narrow-row kernel, update absent / <= 1024 entries / > 4096 entries).  Informational (bench.py
+ * attributes the timed launch's bytes with it); results never depend on it. */
+int tgmx_recency_step_plan(const tgmx_recency_step_t* step);
 
 /* ring.fill(pad), write_pos.zero_()  (recency.py:111-117) */
 int tgmx_ring_reset(tgmx_adj_t* ring, int32_t* write_pos, int32_t B, int32_t num_nodes,

@@ -184,6 +184,12 @@ def test_ring_mode_matches_oracle_random(N, E, D, tmax, num_nbrs, bs, directed, 
         (9000, 9600, 4, 2_600_000, [20, 3], 1600),  # 8-rank global wiki batch (m=3200: 4 elements per thread)
         (5000, 8000, 4, 2_600_000, [10, 2], 800),  # m=1600: 2 elements per thread
         (50, 3000, 5, 200, [20], 700),  # hub runs longer than B (m=1400)
+        (2000, 4096, 4, 2_600_000, [8, 3], 512),  # m=1024: the largest batch whose placement rides with hop 1
+        (2000, 4104, 4, 2_600_000, [8, 3], 513),  # m=1026: merge riders + placement launch
+        (6000, 8192, 2, 2_600_000, [4, 2], 2048),  # m=4096: the largest batch of the chunked sort
+        (6000, 8196, 2, 2_600_000, [4, 2], 2049),  # m=4098: radix-sort path
+        (700, 3000, 6, 900, [12], 300),  # single hop: chunk sort rides hop 0, the merge is its own launch
+        (700, 3000, 0, 900, [12, 4], 300),  # no edge features: the commit launch still writes records and write_pos
     ],
 )
 def test_ring_step_variants(N, E, D, tmax, num_nbrs, bs, validate):

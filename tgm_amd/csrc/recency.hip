@@ -62,6 +62,11 @@ struct LookupArgs {
   // launch's second argument instead of looking anything up
   unsigned side_blocks;
   int side_stage;
+  // fused hop 0 + hop 1 launch: hop 1's k and outputs (rows of hop 1 = S * k)
+  int k1;
+  int32_t* out_nid1;
+  int64_t* out_ts1;
+  float* out_x1;
 };
 
 template <int VEC>
@@ -693,7 +698,9 @@ __device__ __forceinline__ void update_merge_riding(const UpdateArgs& a, int c0,
 //   kSideMerge (hop 1, 1024 < m <= 4096): workgroup c ranks chunk c's entries; the placement is its own launch
 //   kSidePlace (hop 1, m <= 1024): ONE workgroup merges the whole batch and decides the placement (DEFER): after the
 //              lookups a single launch commits records, write_pos and feature rows
-constexpr int kSideSort = 1, kSideMerge = 2, kSidePlace = 3;
+//   kSideAll   (fused hop 0 + 1 launch, m <= 1024): ONE workgroup does all of it -- chunk sorts one after the other,
+//              merge, placement decisions -- inside the single lookup launch
+constexpr int kSideSort = 1, kSideMerge = 2, kSidePlace = 3, kSideAll = 4;
 constexpr int kRidePlaceMaxM = 1024;
 
 union RiderLds {
@@ -709,6 +716,14 @@ __device__ __forceinline__ void update_side_work(const UpdateArgs& u, int stage,
   } else if (stage == kSideMerge) {
     update_merge_riding<1, kBlockMaxM / kChunk>(u, block, W.smp);
   } else {
+    if (stage == kSideAll) {
+      const int chunks = (int)((u.m + kChunk - 1) / kChunk);
+#pragma unroll 1
+      for (int c = 0; c < kRidePlaceMaxM / kChunk; ++c) {
+        if (c < chunks) update_chunk_sort(u, c, W.sort);
+        __syncthreads();  // W.sort is reused; the chunk-sorted pairs written above are read below by other threads
+      }
+    }
     update_merge_riding<4, 4>(u, 0, W.smp);
     __syncthreads();  // the sorted arrays written above are read below by other threads of this workgroup
     SortLds<1> none;
@@ -717,9 +732,196 @@ __device__ __forceinline__ void update_side_work(const UpdateArgs& u, int stage,
 }
 
 
+// ---- one seed's lookup, in pieces (shared by the per-hop kernel and the fused hop-0 + hop-1 kernel) -----------------
+// hop-0 seed s: from the seed groups (publishing the concatenated arrays when `publish`) or the plain arrays
+__device__ __forceinline__ void fetch_seed(const LookupArgs& a, long long s, int lane, bool publish, int& n, long long& q) {
+  if (a.grp.groups > 0) {
+    const int32_t* pn = a.grp.nid[0];
+    const int64_t* pt = a.grp.ts[0];
+    long long base = 0;
+#pragma unroll
+    for (int g = 1; g < TGMX_MAX_SEED_GROUPS; ++g) {
+      if (g < a.grp.groups && s >= a.grp.end[g - 1]) {
+        pn = a.grp.nid[g];
+        pt = a.grp.ts[g];
+        base = a.grp.end[g - 1];
+      }
+    }
+    n = pn[s - base];
+    q = pt[s - base];
+    if (publish && lane == 0) {
+      a.grp.out_nid[s] = n;
+      a.grp.out_ts[s] = q;
+    }
+  } else {
+    n = a.seeds[s];
+    q = a.qtimes[s];
+  }
+}
+
+__device__ __forceinline__ void check_seed(const LookupArgs& a, int n, long long q, int allow_pad, int lane) {
+  if (lane == 0) {
+    int st = 0;
+    if (n >= a.N || n < -1 || (n == -1 && !allow_pad)) st |= TGMX_ST_SEED_RANGE;
+    if (q < 0 && !allow_pad) st |= TGMX_ST_SEED_TIME;
+    if (st) atomicOr(a.status, st);
+  }
+}
+
+// window [w0, w0 + wlen) of node n in "oldest -> newest" order
+struct Window {
+  long long w0;  // CSR: absolute record index; RING: row base
+  int wlen, wrot;
+};
+
+template <bool RING>
+__device__ __forceinline__ Window find_window(const LookupArgs& a, int n, bool live, int lane) {
+  Window w;
+  w.w0 = 0;
+  w.wlen = 0;
+  w.wrot = 0;
+  if (live) {
+    if (RING) {
+      w.w0 = (long long)n * a.B;
+      w.wrot = a.write_pos[n] % a.B;  // unrolled position i lives in slot (wrot + i) % B
+      w.wlen = a.B;
+    } else {
+      const long long ra = a.indptr[n], rz = a.indptr[n + 1];
+      const long long p_hi = ra + wave_prefix_count(a.recs, ra, rz, a.ev_hi, lane);
+      const long long p_lo = a.ev_lo <= 0 ? ra : ra + wave_prefix_count(a.recs, ra, rz, a.ev_lo, lane);
+      w.w0 = p_hi - a.B > p_lo ? p_hi - a.B : p_lo;
+      w.wlen = (int)(p_hi - w.w0);
+    }
+  }
+  return w;
+}
+
+template <bool RING>
+__device__ __forceinline__ long long slot_of(const Window& w, int B, int i) {
+  if (RING) {
+    int sl = w.wrot + i;
+    if (sl >= B) sl -= B;
+    return w.w0 + sl;
+  }
+  return w.w0 + i;
+}
+
+// B, k <= 64: the whole window in one wave.  Lane c < k gets output slot c of the k-wide row: (has, nbr, ts) and the
+// feature row it gathers from (ring slot / edge id; -1 for a pad)
+struct SmallPick {
+  bool has;
+  int nbr, src;
+  long long ts;
+};
+
+template <bool RING>
+__device__ __forceinline__ SmallPick small_pick(const LookupArgs& a, int n, long long q, int k, bool live, int lane) {
+  const int B = a.B;
+  const Window w = find_window<RING>(a, n, live, lane);
+  Rec r;
+  r.nbr = -1; r.eid = 0; r.ts = 0;
+  if (RING) {
+    // the row is read in slot order (no wait for write_pos) and rotated into time order by a shuffle
+    if (live && lane < B) r = a.recs[(long long)n * B + lane];
+    int from_slot = w.wrot + lane;
+    if (from_slot >= B) from_slot -= B;
+    if (lane >= B) from_slot = lane;
+    r.nbr = __shfl(r.nbr, from_slot);
+    r.ts = __shfl(r.ts, from_slot);
+  } else if (lane < w.wlen) {
+    r = a.recs[slot_of<RING>(w, B, lane)];
+  }
+  const bool ok = lane < w.wlen && r.nbr >= 0 && r.ts < q;
+  const unsigned long long m = __ballot(ok);
+  const int cnt = m ? 64 - __clzll((long long)m) : 0;  // 1 + unrolled position of the rightmost entry with ts < q
+  const int i = cnt - k + lane;                        // unrolled position feeding output slot `lane`
+  const int from = i > 0 ? i : 0;
+  const int g_nbr = __shfl(r.nbr, from);
+  const int g_eid = __shfl(r.eid, from);
+  const long long g_ts = __shfl(r.ts, from);
+  SmallPick o;
+  o.has = i >= 0 && g_nbr >= 0;
+  o.nbr = o.has ? g_nbr : -1;
+  o.ts = o.has ? g_ts : 0;
+  o.src = o.has ? (RING ? (int)slot_of<RING>(w, B, from) : g_eid) : -1;
+  return o;
+}
+
+// phase B: stream the [k, D] block of row s; lds_eid[c] = feature row of output slot c (-1: zeros)
+template <int VEC>
+__device__ __forceinline__ void gather_rows(const LookupArgs& a, long long s, int k, int lane, const int* lds_eid, float* out_x) {
+  using V = typename VecOf<VEC>::type;
+  const V* __restrict__ X = reinterpret_cast<const V*>(a.edge_x);
+  V* __restrict__ O = reinterpret_cast<V*>(out_x + s * (long long)k * a.D);
+  const int total = k * a.row_vecs;
+  constexpr int U = 4;
+  for (int f0 = lane; f0 < total; f0 += kWave * U) {
+    V v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int f = f0 + u * kWave;
+      v[u] = zero_vec<V>();
+      if (f < total) {
+        const int slot = (int)a.dv.div((uint32_t)f);
+        const int col = f - slot * a.row_vecs;
+        const int e = lds_eid[slot];
+        if (e >= 0) v[u] = X[(long long)e * a.row_vecs + col];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int f = f0 + u * kWave;
+      if (f < total) O[f] = v[u];
+    }
+  }
+}
+
+// the k most recent neighbors of (n, q) into row s of (out_nid, out_ts, out_x)
+template <bool RING, int VEC, bool SMALL>
+__device__ __forceinline__ void lookup_seed(const LookupArgs& a, long long s, int n, long long q, int k, int lane, int* lds_eid,
+                                            int32_t* out_nid, int64_t* out_ts, float* out_x) {
+  const bool live = n >= 0 && n < a.N;
+  if (SMALL) {
+    const SmallPick o = small_pick<RING>(a, n, q, k, live, lane);
+    if (lane < k) {
+      out_nid[s * k + lane] = o.nbr;
+      out_ts[s * k + lane] = o.ts;
+      lds_eid[lane] = o.src;
+    }
+  } else {
+    const int B = a.B;
+    const Window w = find_window<RING>(a, n, live, lane);
+    int cnt = 0;  // 1 + unrolled position of the rightmost entry with ts < q
+    for (int top = w.wlen; top > 0 && cnt == 0; top -= kWave) {
+      const int lo = top > kWave ? top - kWave : 0;
+      const int i = lo + lane;
+      bool ok = false;
+      if (i < top) {
+        const Rec r = a.recs[slot_of<RING>(w, B, i)];
+        ok = r.nbr >= 0 && r.ts < q;
+      }
+      const unsigned long long m = __ballot(ok);
+      if (m) cnt = lo + 64 - __clzll((long long)m);
+    }
+    for (int c = lane; c < k; c += kWave) {
+      const int i = cnt - k + c;
+      Rec r;
+      r.nbr = -1; r.eid = 0; r.ts = 0;
+      if (i >= 0) r = a.recs[slot_of<RING>(w, B, i)];
+      const bool has = r.nbr >= 0;
+      out_nid[s * k + c] = has ? r.nbr : -1;
+      out_ts[s * k + c] = has ? r.ts : 0;
+      lds_eid[c] = has ? (RING ? (int)slot_of<RING>(w, B, i) : r.eid) : -1;
+    }
+  }
+  if (a.D == 0) return;
+  __builtin_amdgcn_wave_barrier();  // lds_eid written above is read cross-lane below
+  gather_rows<VEC>(a, s, k, lane, lds_eid, out_x);
+  __builtin_amdgcn_wave_barrier();  // the next seed reuses lds_eid
+}
+
 template <bool RING, int VEC, bool SMALL>
 __global__ __launch_bounds__(256) void recency_lookup_kernel(const LookupArgs a, const UpdateArgs u) {
-  using V = typename VecOf<VEC>::type;
   extern __shared__ __attribute__((aligned(16))) int lds_eid_all[];
   unsigned bid = blockIdx.x, nblk = gridDim.x;
   if constexpr (RING) {
@@ -734,147 +936,58 @@ __global__ __launch_bounds__(256) void recency_lookup_kernel(const LookupArgs a,
   const int wave_in_block = threadIdx.x >> 6;
   int* lds_eid = lds_eid_all + wave_in_block * a.k;
   const long long waves_total = (long long)nblk * (blockDim.x >> 6);
-  const int k = a.k, B = a.B;
-
   for (long long s = (long long)bid * (blockDim.x >> 6) + wave_in_block; s < a.S; s += waves_total) {
     int n;
     long long q;
-    if (a.grp.groups > 0) {
-      const int32_t* pn = a.grp.nid[0];
-      const int64_t* pt = a.grp.ts[0];
-      long long base = 0;
-#pragma unroll
-      for (int g = 1; g < TGMX_MAX_SEED_GROUPS; ++g) {
-        if (g < a.grp.groups && s >= a.grp.end[g - 1]) {
-          pn = a.grp.nid[g];
-          pt = a.grp.ts[g];
-          base = a.grp.end[g - 1];
-        }
-      }
-      n = pn[s - base];
-      q = pt[s - base];
-      if (lane == 0) {
-        a.grp.out_nid[s] = n;
-        a.grp.out_ts[s] = q;
-      }
+    fetch_seed(a, s, lane, true, n, q);
+    check_seed(a, n, q, a.allow_pad, lane);
+    lookup_seed<RING, VEC, SMALL>(a, s, n, q, a.k, lane, lds_eid, a.out_nid, a.out_ts, a.out_x);
+  }
+}
+
+// Hop 0 and hop 1 in ONE launch (B, k0, k1 <= 64).  Hop 1's seeds are hop 0's outputs, but the rings do not move
+// between the two, so the wave of hop-1 row (s0, j) re-derives its seed itself: it repeats hop 0's window search for
+// seed s0 (one 16-byte read per lane of a row that 1 + k0 waves share: L2 hits) and takes output slot j.  That removes
+// the dependency between the launches: the few hundred hop-0 seeds -- a launch bound by its three dependent reads, not
+// by bandwidth -- run inside the big hop-1 launch instead of in front of it.  Waves [0, S0) are hop 0 (they also
+// publish the concatenated seeds), waves [S0, S0 + S0 k0) are hop 1; results are identical to the two launches.
+template <bool RING, int VEC>
+__global__ __launch_bounds__(256) void recency_lookup_fused01_kernel(const LookupArgs a, const UpdateArgs u) {
+  extern __shared__ __attribute__((aligned(16))) int lds_eid_all[];
+  unsigned bid = blockIdx.x, nblk = gridDim.x;
+  if constexpr (RING) {
+    if (bid < a.side_blocks) {
+      update_side_work(u, a.side_stage, (int)bid);
+      return;
+    }
+    bid -= a.side_blocks;
+    nblk -= a.side_blocks;
+  }
+  const int lane = lane_id();
+  const int wave_in_block = threadIdx.x >> 6;
+  const int k0 = a.k, k1 = a.k1;
+  int* lds_eid = lds_eid_all + wave_in_block * (k0 > k1 ? k0 : k1);
+  const long long waves_total = (long long)nblk * (blockDim.x >> 6);
+  const long long S0 = a.S, S1 = a.S * k0;
+  for (long long w = (long long)bid * (blockDim.x >> 6) + wave_in_block; w < S0 + S1; w += waves_total) {
+    int n;
+    long long q;
+    if (w < S0) {
+      fetch_seed(a, w, lane, true, n, q);
+      check_seed(a, n, q, 0, lane);
+      lookup_seed<RING, VEC, true>(a, w, n, q, k0, lane, lds_eid, a.out_nid, a.out_ts, a.out_x);
     } else {
-      n = a.seeds[s];
-      q = a.qtimes[s];
+      const long long idx = w - S0;
+      const long long s0 = idx / k0;
+      const int j = (int)(idx - s0 * k0);
+      int n0;
+      long long q0;
+      fetch_seed(a, s0, lane, false, n0, q0);
+      const SmallPick o = small_pick<RING>(a, n0, q0, k0, n0 >= 0 && n0 < a.N, lane);
+      n = __shfl(o.nbr, j);
+      q = __shfl(o.ts, j);
+      lookup_seed<RING, VEC, true>(a, idx, n, q, k1, lane, lds_eid, a.out_nid1, a.out_ts1, a.out_x1);
     }
-
-    bool live = n >= 0 && n < a.N;
-    if (lane == 0) {
-      int st = 0;
-      if (n >= a.N || n < -1 || (n == -1 && !a.allow_pad)) st |= TGMX_ST_SEED_RANGE;
-      if (q < 0 && !a.allow_pad) st |= TGMX_ST_SEED_TIME;
-      if (st) atomicOr(a.status, st);
-    }
-
-    // ---- phase A: window [w0, w0 + wlen) in "oldest -> newest" order ---------
-    long long w0 = 0;  // CSR: absolute record index; RING: row base
-    int wlen = 0, wrot = 0;
-    if (live) {
-      if (RING) {
-        w0 = (long long)n * B;
-        wrot = a.write_pos[n] % B;  // unrolled position i lives in slot (wrot + i) % B
-        wlen = B;
-      } else {
-        const long long ra = a.indptr[n], rz = a.indptr[n + 1];
-        const long long p_hi = ra + wave_prefix_count(a.recs, ra, rz, a.ev_hi, lane);
-        const long long p_lo = a.ev_lo <= 0 ? ra : ra + wave_prefix_count(a.recs, ra, rz, a.ev_lo, lane);
-        w0 = p_hi - B > p_lo ? p_hi - B : p_lo;
-        wlen = (int)(p_hi - w0);
-      }
-    }
-    auto slot_of = [&](int i) -> long long {
-      if (RING) {
-        int sl = wrot + i;
-        if (sl >= B) sl -= B;
-        return w0 + sl;
-      }
-      return w0 + i;
-    };
-
-    int cnt = 0;  // 1 + unrolled position of the rightmost entry with ts < q
-    if (SMALL) {
-      Rec r;
-      r.nbr = -1; r.eid = 0; r.ts = 0;
-      if (RING) {
-        // the row is read in slot order (no wait for write_pos) and rotated into time order by a shuffle
-        if (live && lane < B) r = a.recs[w0 + lane];
-        int from_slot = wrot + lane;
-        if (from_slot >= B) from_slot -= B;
-        if (lane >= B) from_slot = lane;
-        r.nbr = __shfl(r.nbr, from_slot);
-        r.ts = __shfl(r.ts, from_slot);
-      } else if (lane < wlen) {
-        r = a.recs[slot_of(lane)];
-      }
-      const bool ok = lane < wlen && r.nbr >= 0 && r.ts < q;
-      const unsigned long long m = __ballot(ok);
-      cnt = m ? 64 - __clzll((long long)m) : 0;
-      const int i = cnt - k + lane;  // unrolled position feeding output slot `lane`
-      const int from = i > 0 ? i : 0;
-      const int g_nbr = __shfl(r.nbr, from);
-      const int g_eid = __shfl(r.eid, from);
-      const long long g_ts = __shfl(r.ts, from);
-      if (lane < k) {
-        const bool has = i >= 0 && g_nbr >= 0;
-        a.out_nid[s * k + lane] = has ? g_nbr : -1;
-        a.out_ts[s * k + lane] = has ? g_ts : 0;
-        lds_eid[lane] = has ? (RING ? (int)slot_of(from) : g_eid) : -1;
-      }
-    } else {
-      for (int top = wlen; top > 0 && cnt == 0; top -= kWave) {
-        const int lo = top > kWave ? top - kWave : 0;
-        const int i = lo + lane;
-        bool ok = false;
-        if (i < top) {
-          const Rec r = a.recs[slot_of(i)];
-          ok = r.nbr >= 0 && r.ts < q;
-        }
-        const unsigned long long m = __ballot(ok);
-        if (m) cnt = lo + 64 - __clzll((long long)m);
-      }
-      for (int c = lane; c < k; c += kWave) {
-        const int i = cnt - k + c;
-        Rec r;
-        r.nbr = -1; r.eid = 0; r.ts = 0;
-        if (i >= 0) r = a.recs[slot_of(i)];
-        const bool has = r.nbr >= 0;
-        a.out_nid[s * k + c] = has ? r.nbr : -1;
-        a.out_ts[s * k + c] = has ? r.ts : 0;
-        lds_eid[c] = has ? (RING ? (int)slot_of(i) : r.eid) : -1;
-      }
-    }
-    if (a.D == 0) continue;
-    __builtin_amdgcn_wave_barrier();  // lds_eid written above is read cross-lane below
-
-    // ---- phase B: stream the [k, D] block ------------------------------------
-    const V* __restrict__ X = reinterpret_cast<const V*>(a.edge_x);
-    V* __restrict__ O = reinterpret_cast<V*>(a.out_x + s * (long long)k * a.D);
-    const int total = k * a.row_vecs;
-    constexpr int U = 4;
-    for (int f0 = lane; f0 < total; f0 += kWave * U) {
-      V v[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int f = f0 + u * kWave;
-        v[u] = zero_vec<V>();
-        if (f < total) {
-          const int slot = (int)a.dv.div((uint32_t)f);
-          const int col = f - slot * a.row_vecs;
-          const int e = lds_eid[slot];
-          if (e >= 0) v[u] = X[(long long)e * a.row_vecs + col];
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int f = f0 + u * kWave;
-        if (f < total) O[f] = v[u];
-      }
-    }
-    __builtin_amdgcn_wave_barrier();  // next seed reuses lds_eid
   }
 }
 
@@ -974,6 +1087,29 @@ __global__ __launch_bounds__(256) void ring_lookup_packed_kernel(const LookupArg
   }
 }
 
+// gather width (floats per load) for this launch's alignment; fills row_vecs and the slot divider
+static int prepare_lookup(LookupArgs& a, const float* out_x, int kmax) {
+  int vec = 1;
+  if (a.D > 0) {
+    const uintptr_t bits = (uintptr_t)a.edge_x | (uintptr_t)out_x | (uintptr_t)a.out_x;
+    if (a.D % 4 == 0 && (bits & 15) == 0) vec = 4;
+    else if (a.D % 2 == 0 && (bits & 7) == 0) vec = 2;
+  }
+  a.row_vecs = a.D > 0 ? a.D / vec : 1;
+  a.dv = make_fastdiv((uint32_t)a.row_vecs);
+  if ((unsigned long long)kmax * a.row_vecs * (unsigned long long)a.row_vecs >= (1ull << 32)) {
+    set_error("recency_lookup: k*D^2 too large for the slot divider (k=%d, D=%d)", kmax, a.D);
+    return TGMX_E_UNSUPPORTED;
+  }
+  return vec;
+}
+
+// lanes per seed of the packed kernel for (B, k); 64 = the packed kernel does not apply
+static int packed_group_lanes(const LookupArgs& a, int k, bool ring) {
+  const int gl = (a.B <= 16 && k <= 16) ? 16 : ((a.B <= 32 && k <= 32) ? 32 : 64);
+  return (ring && gl < 64 && (long long)k * a.row_vecs <= 8 * gl) ? gl : 64;
+}
+
 template <bool RING>
 static int launch_lookup(LookupArgs a, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop,
                          const UpdateArgs* side = nullptr, int side_stage = 0, unsigned side_blocks = 0) {
@@ -982,19 +1118,8 @@ static int launch_lookup(LookupArgs a, hipStream_t stream, hipEvent_t ev_start, 
   a.side_blocks = (RING && side) ? side_blocks : 0;
   a.side_stage = side_stage;
   const bool small = a.B <= kWave && a.k <= kWave;
-  int vec = 1;
-  if (a.D > 0) {
-    const bool al16 = (((uintptr_t)a.edge_x | (uintptr_t)a.out_x) & 15) == 0;
-    const bool al8 = (((uintptr_t)a.edge_x | (uintptr_t)a.out_x) & 7) == 0;
-    if (a.D % 4 == 0 && al16) vec = 4;
-    else if (a.D % 2 == 0 && al8) vec = 2;
-  }
-  a.row_vecs = a.D > 0 ? a.D / vec : 1;
-  a.dv = make_fastdiv((uint32_t)a.row_vecs);
-  if ((unsigned long long)a.k * a.row_vecs * (unsigned long long)a.row_vecs >= (1ull << 32)) {
-    set_error("recency_lookup: k*D^2 too large for the slot divider (k=%d, D=%d)", a.k, a.D);
-    return TGMX_E_UNSUPPORTED;
-  }
+  const int vec = prepare_lookup(a, a.out_x, a.k);
+  if (vec < 0) return vec;
   const int waves_per_block = 4;
   long long blocks = (a.S + waves_per_block - 1) / waves_per_block;
   if (blocks > (1 << 20)) blocks = 1 << 20;
@@ -1004,8 +1129,8 @@ static int launch_lookup(LookupArgs a, hipStream_t stream, hipEvent_t ev_start, 
   hipLaunchKernelGGL((recency_lookup_kernel<RING, VEC_, SMALL_>), grid, block, lds, stream, a, u)
   if (ev_start) (void)hipEventRecord(ev_start, stream);
   // narrow rows: several seeds per wave (streaming rings, plain seed arrays)
-  const int gl = (a.B <= 16 && a.k <= 16) ? 16 : ((a.B <= 32 && a.k <= 32) ? 32 : 64);
-  if (RING && a.grp.groups == 0 && gl < 64 && (long long)a.k * a.row_vecs <= 8 * gl) {
+  const int gl = a.grp.groups == 0 ? packed_group_lanes(a, a.k, RING) : 64;
+  if (gl < 64) {
     const int per_wave = 64 / gl;
     long long pblocks = ((a.S + per_wave - 1) / per_wave + waves_per_block - 1) / waves_per_block;
     if (pblocks > (1 << 20)) pblocks = 1 << 20;
@@ -1032,6 +1157,32 @@ static int launch_lookup(LookupArgs a, hipStream_t stream, hipEvent_t ev_start, 
 #undef TGMX_LAUNCH
   if (ev_stop) (void)hipEventRecord(ev_stop, stream);
   TGMX_CHECK_LAUNCH("recency_lookup");
+  return TGMX_OK;
+}
+
+
+// hop 0 (a: seeds / groups, k, outputs) and hop 1 (k1, out_*1) as one launch; the caller checked can_fuse01
+template <bool RING>
+static int launch_fused01(LookupArgs a, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop, const UpdateArgs* side,
+                          int side_stage, unsigned side_blocks) {
+  const UpdateArgs u = side ? *side : UpdateArgs{};
+  a.side_blocks = (RING && side) ? side_blocks : 0;
+  a.side_stage = side_stage;
+  const int kmax = a.k > a.k1 ? a.k : a.k1;
+  const int vec = prepare_lookup(a, a.out_x1, kmax);
+  if (vec < 0) return vec;
+  const int waves_per_block = 4;
+  const long long waves = a.S + a.S * a.k;
+  long long blocks = (waves + waves_per_block - 1) / waves_per_block;
+  if (blocks > (1 << 20)) blocks = 1 << 20;
+  const dim3 grid((unsigned)blocks + a.side_blocks), block(waves_per_block * kWave);
+  const size_t lds = (size_t)waves_per_block * kmax * sizeof(int);
+  if (ev_start) (void)hipEventRecord(ev_start, stream);
+  if (vec == 4) hipLaunchKernelGGL((recency_lookup_fused01_kernel<RING, 4>), grid, block, lds, stream, a, u);
+  else if (vec == 2) hipLaunchKernelGGL((recency_lookup_fused01_kernel<RING, 2>), grid, block, lds, stream, a, u);
+  else hipLaunchKernelGGL((recency_lookup_fused01_kernel<RING, 1>), grid, block, lds, stream, a, u);
+  if (ev_stop) (void)hipEventRecord(ev_stop, stream);
+  TGMX_CHECK_LAUNCH("recency_lookup_fused01");
   return TGMX_OK;
 }
 
@@ -1538,6 +1689,33 @@ extern "C" int tgmx_ring_update(tgmx_adj_t* ring, int32_t* write_pos, float* rin
   return TGMX_OK;
 }
 
+// Can hop 0 and hop 1 of this step be one launch?  (B <= 64; hop 1 not better served by the packed narrow-row kernel;
+// an update either absent, small enough for ONE rider workgroup (m <= 1024), or not riding at all.)
+static bool plan_fuse01(const tgmx_recency_step_t* s, long long S0) {
+  static const bool no_fuse = getenv("TGMX_NO_FUSE") != nullptr;  // A/B knob
+  static const bool no_ride = getenv("TGMX_NO_RIDE") != nullptr;
+  if (no_fuse || s->n_hops < 2 || S0 <= 0 || s->B > kWave || s->k[0] <= 0 || s->k[1] <= 0) return false;
+  if (s->indptr == nullptr) {  // streaming rings: the packed kernel takes narrow hop-1 rows
+    LookupArgs a{};
+    a.B = s->B; a.D = s->D; a.edge_x = s->ring_x; a.out_x = s->out_x[0];
+    if (prepare_lookup(a, s->out_x[1], s->k[1]) < 0) return false;
+    if (packed_group_lanes(a, s->k[1], true) < 64) return false;
+  }
+  const long long m = s->directed ? s->n : 2 * s->n;
+  if (s->n > 0 && !no_ride && m > kRidePlaceMaxM && m <= kBlockMaxM) return false;  // the riders need two launches
+  return true;
+}
+
+extern "C" int tgmx_recency_step_plan(const tgmx_recency_step_t* s) {
+  if (!s) return 0;
+  long long S0 = s->S0;
+  if (s->n_groups > 0) {
+    S0 = 0;
+    for (int g = 0; g < s->n_groups && g < TGMX_MAX_SEED_GROUPS; ++g) S0 += s->grp_n[g];
+  }
+  return plan_fuse01(s, S0) ? 1 : 0;
+}
+
 extern "C" int tgmx_recency_step(const tgmx_recency_step_t* s, tgmx_stream_t stream) {
   TGMX_REQUIRE(s, "recency_step: null argument block");
   TGMX_REQUIRE(s->n_groups >= 0 && s->n_groups <= TGMX_MAX_SEED_GROUPS && s->n_hops >= 0 && s->n_hops <= TGMX_MAX_HOPS,
@@ -1580,10 +1758,34 @@ extern "C" int tgmx_recency_step(const tgmx_recency_step_t* s, tgmx_stream_t str
     ride_place = side_chunks > 0 && u.m <= kRidePlaceMaxM && s->n_hops >= 2;
   }
 
-  // ---- lookups, hop by hop (hop h + 1 consumes hop h's outputs in place)
+  // ---- lookups, hop by hop (hop h + 1 consumes hop h's outputs in place); hops 0 and 1 as one launch when possible
   const int32_t* cur_n = s->seed_nid0;
   const int64_t* cur_t = s->seed_ts0;
-  for (int h = 0; h < s->n_hops && S > 0; ++h) {
+  int h = 0;
+  if (plan_fuse01(s, S)) {
+    const int k0 = s->k[0], k1 = s->k[1];
+    TGMX_REQUIRE(s->B >= k0 && s->B >= k1, "recency_step: k=[%d, %d] but B=%d", k0, k1, s->B);
+    TGMX_REQUIRE(cur_n && cur_t && s->out_nid[0] && s->out_ts[0] && s->out_nid[1] && s->out_ts[1] &&
+                     (s->D == 0 || (s->ring_x && s->out_x[0] && s->out_x[1])), "recency_step: null pointer at hop 0 / 1");
+    LookupArgs a{};
+    a.grp = grp;
+    a.indptr = s->indptr; a.recs = reinterpret_cast<const Rec*>(s->ring); a.write_pos = s->write_pos; a.edge_x = s->ring_x;
+    a.seeds = cur_n; a.qtimes = cur_t; a.out_nid = s->out_nid[0]; a.out_ts = s->out_ts[0]; a.out_x = s->out_x[0];
+    a.k1 = k1; a.out_nid1 = s->out_nid[1]; a.out_ts1 = s->out_ts[1]; a.out_x1 = s->out_x[1];
+    a.status = s->status; a.S = S; a.D = s->D; a.k = k0; a.B = s->B; a.N = s->num_nodes; a.allow_pad = 0;
+    a.ev_lo = s->ev_lo; a.ev_hi = s->ev_hi;
+    const bool timed = s->timed_hop == 0 || s->timed_hop == 1;
+    hipEvent_t e0 = timed ? (hipEvent_t)s->ev_start : nullptr, e1 = timed ? (hipEvent_t)s->ev_stop : nullptr;
+    ride_place = side_chunks > 0;  // plan_fuse01: m <= 1024 whenever the riders are on
+    const int rc = csr ? launch_fused01<false>(a, st, e0, e1, nullptr, 0, 0)
+                       : launch_fused01<true>(a, st, e0, e1, ride_place ? &u : nullptr, kSideAll, 1u);
+    if (rc) return rc;
+    cur_n = s->out_nid[1];
+    cur_t = s->out_ts[1];
+    S *= (long long)k0 * k1;
+    h = 2;
+  }
+  for (; h < s->n_hops && S > 0; ++h) {
     const int k = s->k[h];
     TGMX_REQUIRE(k > 0 && s->B >= k, "recency_step: hop %d has k=%d, B=%d", h, k, s->B);
     TGMX_REQUIRE(cur_n && cur_t && s->out_nid[h] && s->out_ts[h] && (s->D == 0 || (s->ring_x && s->out_x[h])),

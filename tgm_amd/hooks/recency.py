@@ -179,6 +179,13 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
         else:
             self._epoch_lo = None  # re-anchored at the next batch's first edge
 
+    def fuses_first_hops(self) -> bool:
+        """Did the last call run hop 0 and hop 1 as one launch?  (``tgmx_recency_step_plan`` on the argument block of
+        that call; informational -- ``bench.py`` attributes the timed launch's bytes with it.)"""
+        if self._step is None:
+            return False
+        return bool(_native.load().tgmx_recency_step_plan(self._step) & 1)
+
     def check(self) -> None:
         """Raise the ``ValueError`` the reference would have raised for bad seeds
         seen since the last check (one device->host read)."""
@@ -389,7 +396,9 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
                     _native.check(rc, 'tgmx_recency_step')
             del keep
             if timer is not None:
-                self.profile_log.append((timer, out_seed_n[self.profile_hop].shape[0], self._num_nbrs[self.profile_hop], out_n[self.profile_hop]))
+                # every hop the timed launch covers: (seed rows, k, neighbor ids written)
+                hops = [0, 1] if self.profile_hop in (0, 1) and self.fuses_first_hops() else [self.profile_hop]
+                self.profile_log.append((timer, [(out_seed_n[h].shape[0], self._num_nbrs[h], out_n[h]) for h in hops]))
         return self._publish(batch, out_seed_n, out_seed_t, out_n, out_t, out_x, seed_mask)
 
     # ------------------------------------------------------------------
