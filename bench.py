@@ -48,7 +48,7 @@ def parse_args():
     p.add_argument('--num-nbrs', type=int, nargs='+', default=None)
     p.add_argument('--mode', default='ring', choices=['ring', 'csr'])
     p.add_argument('--cpu-batches', type=int, default=100, help='batches of the CPU-baseline sample (0 = skip); ~0.25 s each on the GPU box host')
-    p.add_argument('--profile-every', type=int, default=8, help='bracket the dominant kernel with HIP events every n-th step')
+    p.add_argument('--profile-every', type=int, default=16, help='bracket the dominant kernel with HIP events every n-th step')
     p.add_argument('--seed', type=int, default=1337)
     return p.parse_args()
 
@@ -179,13 +179,17 @@ def main():
         return it
 
     with hm.activate('bench'):
-        pos = run(args.warmup, 0)
-        hook.check()
         from tgm_amd._native import KernelTimer
 
         every = max(1, args.profile_every)
+        # the warm-up runs with the same instrumentation as the timed steps (first-use costs of the counting ops land there)
         hook.profile_hop, hook.profile_every, hook.profile_log = last_hop, every, []
-        hook.profile_pool = [KernelTimer() for _ in range(min(256, args.steps // every + 1))]
+        hook.profile_pool = [KernelTimer() for _ in range(args.warmup // every + 1)]
+        pos = run(args.warmup, 0)
+        hook.check()
+        hook.profile_log = []
+        # at most 48 timed launches: ~100 HIP events awaiting their timestamps is where the runtime starts to stall
+        hook.profile_pool = [KernelTimer() for _ in range(min(48, args.steps // every + 1))]
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
@@ -205,13 +209,13 @@ def main():
     # ---- roofline of the dominant kernel (last hop's lookup + gather launch) -----------
     log = hook.profile_log
     hook.profile_hop = None
-    ker_ms = [t.elapsed_ms() for t, _ in log]
+    ker_ms = [t.elapsed_ms() for t, *_ in log]
     avg_ms = sum(ker_ms) / max(len(ker_ms), 1)
     # the timed launch covers one hop, or hop 0 + hop 1 when tgmx_recency_step runs them as one launch
-    shape = [(seeds, k) for seeds, k, _ in log[0][1]] if log else []
+    shape = log[0][1] if log else []
     seeds_l = sum(seeds for seeds, _ in shape)
     total_slots = sum(seeds * k for seeds, k in shape)
-    valid = sum(int((nid >= 0).sum().item()) for _, hops in log for *_, nid in hops) / max(len(log), 1)
+    valid = sum(int(counts.sum().item()) for *_, counts in log) / max(len(log), 1)
     # algorithmic bytes per launch: every slot is written (id 4 + ts 8 + 4D),
     # valid slots also read their 16-byte record and 4D-byte feature row; 68 B of index traffic per seed
     algo_bytes = total_slots * (12 + 4 * D) + valid * (16 + 4 * D) + seeds_l * 68

@@ -396,9 +396,13 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
                     _native.check(rc, 'tgmx_recency_step')
             del keep
             if timer is not None:
-                # every hop the timed launch covers: (seed rows, k, neighbor ids written)
+                # every hop the timed launch covers: (seed rows, k) and the number of valid neighbor slots per hop as a
+                # small device tensor -- holding the outputs themselves would pin allocator blocks and slow later steps
                 hops = [0, 1] if self.profile_hop in (0, 1) and self.fuses_first_hops() else [self.profile_hop]
-                self.profile_log.append((timer, [(out_seed_n[h].shape[0], self._num_nbrs[h], out_n[h]) for h in hops]))
+                counts = torch.empty(len(hops), dtype=torch.int64, device=device)
+                for i, h in enumerate(hops):
+                    torch.sum((out_n[h] != -1).view(-1), dim=0, dtype=torch.int64, out=counts[i])  # asynchronous, unlike count_nonzero
+                self.profile_log.append((timer, [(out_seed_n[h].shape[0], self._num_nbrs[h]) for h in hops], counts))
         return self._publish(batch, out_seed_n, out_seed_t, out_n, out_t, out_x, seed_mask)
 
     # ------------------------------------------------------------------
