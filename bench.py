@@ -48,7 +48,7 @@ def parse_args():
     p.add_argument('--num-nbrs', type=int, nargs='+', default=None)
     p.add_argument('--mode', default='ring', choices=['ring', 'csr'])
     p.add_argument('--cpu-batches', type=int, default=100, help='batches of the CPU-baseline sample (0 = skip); ~0.25 s each on the GPU box host')
-    p.add_argument('--profile-every', type=int, default=16, help='bracket the dominant kernel with HIP events every n-th step')
+    p.add_argument('--profile-every', type=int, default=32, help='bracket the dominant kernel with HIP events every n-th step')
     p.add_argument('--seed', type=int, default=1337)
     return p.parse_args()
 
@@ -183,11 +183,12 @@ def main():
 
         every = max(1, args.profile_every)
         # the warm-up runs with the same instrumentation as the timed steps (first-use costs of the counting ops land there)
-        hook.profile_hop, hook.profile_every, hook.profile_log = last_hop, every, []
-        hook.profile_pool = [KernelTimer() for _ in range(args.warmup // every + 1)]
+        warm_every = max(1, min(every, args.warmup // 2))  # at least two instrumented warm-up steps
+        hook.profile_hop, hook.profile_every, hook.profile_log = last_hop, warm_every, []
+        hook.profile_pool = [KernelTimer() for _ in range(args.warmup // warm_every + 1)]
         pos = run(args.warmup, 0)
         hook.check()
-        hook.profile_log = []
+        hook.profile_every, hook.profile_log = every, []
         # at most 48 timed launches: ~100 HIP events awaiting their timestamps is where the runtime starts to stall
         hook.profile_pool = [KernelTimer() for _ in range(min(48, args.steps // every + 1))]
         if world > 1:

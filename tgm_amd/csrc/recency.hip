@@ -1695,6 +1695,9 @@ static bool plan_fuse01(const tgmx_recency_step_t* s, long long S0) {
   static const bool no_fuse = getenv("TGMX_NO_FUSE") != nullptr;  // A/B knob
   static const bool no_ride = getenv("TGMX_NO_RIDE") != nullptr;
   if (no_fuse || s->n_hops < 2 || S0 <= 0 || s->B > kWave || s->k[0] <= 0 || s->k[1] <= 0) return false;
+  // static index: a hop-1 wave would repeat hop 0's two prefix searches (dependent reads); that only pays when its own
+  // gather is long (comment-shaped, D = 16: 26.9 -> 19.2 G sampled-edges/s fused; wiki-shaped, D = 172: 4.8 -> 5.1)
+  if (s->indptr != nullptr && (long long)s->k[1] * s->D * 4 < 4096) return false;
   if (s->indptr == nullptr) {  // streaming rings: the packed kernel takes narrow hop-1 rows
     LookupArgs a{};
     a.B = s->B; a.D = s->D; a.edge_x = s->ring_x; a.out_x = s->out_x[0];
