@@ -38,6 +38,7 @@ extern "C" {
 #define TGMX_ST_SEED_RANGE 1 /* a hop-0 seed id outside [0, num_nodes)        */
 #define TGMX_ST_SEED_TIME 2  /* a hop-0 seed time < 0                         */
 #define TGMX_ST_EDGE_RANGE 4 /* an edge endpoint outside [0, num_nodes)       */
+#define TGMX_ST_SCRATCH 8    /* the head of the update scratch was not zero at first use */
 
 typedef void* tgmx_stream_t;
 typedef void* tgmx_event_t; /* hipEvent_t */
@@ -122,7 +123,9 @@ int tgmx_ring_lookup(const tgmx_adj_t* ring, const int32_t* write_pos,
  * it); key_wrap32 = 0 uses int64 (the intended per-node chronological order).
  * edge_x may be NULL (rows of zeros, recency.py:325-328).  eid0 = store index of
  * the batch's first edge or -1 (recorded in the slot, informational).
- * scratch: 256-byte aligned, >= tgmx_ring_update_scratch_bytes(n, directed) bytes.  */
+ * scratch: 256-byte aligned, >= tgmx_ring_update_scratch_bytes(n, directed) bytes; its first 256 bytes must be ZERO
+ * when the buffer is first handed to the library (a self-resetting barrier of tgmx_recency_step's update workgroups
+ * lives there; the library leaves it zero) -- everything behind them is plain scratch.  */
 size_t tgmx_ring_update_scratch_bytes(int64_t n, int32_t directed);
 int tgmx_ring_update(tgmx_adj_t* ring, int32_t* write_pos, float* ring_x, int32_t D, int32_t B,
                      int32_t num_nodes, const int32_t* src, const int32_t* dst, const int64_t* ts,
@@ -179,7 +182,7 @@ typedef struct tgmx_recency_step {
 
 int tgmx_recency_step(const tgmx_recency_step_t* step, tgmx_stream_t stream);
 /* How tgmx_recency_step would schedule this argument block: bit 0 = hop 0 and hop 1 run as ONE launch (B <= 64, hop 1
- * not served by the narrow-row kernel, update absent / <= 1024 entries / > 4096 entries).  Informational (bench.py
+ * not served by the narrow-row kernel; static index: wide rows only).  Informational (bench.py
  * attributes the timed launch's bytes with it); results never depend on it. */
 int tgmx_recency_step_plan(const tgmx_recency_step_t* step);
 

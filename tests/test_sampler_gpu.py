@@ -363,7 +363,7 @@ def test_direct_entry_points_match_the_step_call():
     status = torch.zeros(1, dtype=torch.int32, device=DEV)
     st = _native.stream_ptr(0)
     assert lib.tgmx_ring_reset(ring.data_ptr(), wpos.data_ptr(), B, N, st) == 0
-    scratch = torch.empty(int(lib.tgmx_ring_update_scratch_bytes(bs, 0)), dtype=torch.uint8, device=DEV)
+    scratch = torch.zeros(int(lib.tgmx_ring_update_scratch_bytes(bs, 0)), dtype=torch.uint8, device=DEV)
     csr = build_csr(src, dst, ts, N, batch_size=bs)
     for b in range(E // bs):
         lo, hi = b * bs, (b + 1) * bs

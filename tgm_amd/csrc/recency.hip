@@ -164,6 +164,7 @@ struct UpdateArgs {
   int32_t* run_start;          // scratch [m]: first sorted position of p's run
   int32_t* run_len;            // scratch [m]: run length, at the run's first position
   int hash_bits;
+  int32_t* barrier;  // 2 ints at the head of the caller's scratch: the riders' self-resetting barrier (count, generation)
   int32_t* status;
   long long n, m, eid0;
   int B, N, D, key_wrap32;
@@ -700,7 +701,39 @@ __device__ __forceinline__ void update_merge_riding(const UpdateArgs& a, int c0,
 //              lookups a single launch commits records, write_pos and feature rows
 //   kSideAll   (fused hop 0 + 1 launch, m <= 1024): ONE workgroup does all of it -- chunk sorts one after the other,
 //              merge, placement decisions -- inside the single lookup launch
-constexpr int kSideSort = 1, kSideMerge = 2, kSidePlace = 3, kSideAll = 4;
+//   kSideSortMerge (fused hop 0 + 1 launch, 1024 < m <= 4096): workgroup c chunk-sorts, all riders meet at a barrier of
+//              their own (they are the launch's first <= 16 workgroups: resident together), then workgroup c merges
+constexpr int kSideSort = 1, kSideMerge = 2, kSidePlace = 3, kSideAll = 4, kSideSortMerge = 5;
+
+// Barrier between the `parts` rider workgroups of one launch: bar[0] counts arrivals, bar[1] is the generation.  It
+// resets itself, so the words only have to be zero when the scratch buffer is first used.  Device-scope release before
+// arriving and acquire after leaving make the chunk-sorted pairs of the other workgroups (other CUs, other XCDs: other
+// L2s) visible.  A barrier that never opens (non-zero scratch head) gives up after ~1 s and reports it.
+__device__ __forceinline__ bool rider_barrier(int32_t* bar, int parts) {
+  __syncthreads();
+  bool ok = true;
+  if (threadIdx.x == 0) {
+    __threadfence();
+    const int gen = __hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int prev = __hip_atomic_fetch_add(&bar[0], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev == parts - 1) {
+      __hip_atomic_store(&bar[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(&bar[1], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      int spins = 0;
+      while (__hip_atomic_load(&bar[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > (1 << 22)) {
+          ok = false;
+          break;
+        }
+      }
+    }
+    __threadfence();
+  }
+  __syncthreads();
+  return ok;
+}
 constexpr int kRidePlaceMaxM = 1024;
 
 union RiderLds {
@@ -714,6 +747,10 @@ __device__ __forceinline__ void update_side_work(const UpdateArgs& u, int stage,
   if (stage == kSideSort) {
     update_chunk_sort(u, block, W.sort);
   } else if (stage == kSideMerge) {
+    update_merge_riding<1, kBlockMaxM / kChunk>(u, block, W.smp);
+  } else if (stage == kSideSortMerge) {
+    update_chunk_sort(u, block, W.sort);
+    if (!rider_barrier(u.barrier, (int)((u.m + kChunk - 1) / kChunk)) && threadIdx.x == 0) atomicOr(u.status, TGMX_ST_SCRATCH);
     update_merge_riding<1, kBlockMaxM / kChunk>(u, block, W.smp);
   } else {
     if (stage == kSideAll) {
@@ -1562,6 +1599,8 @@ extern "C" int tgmx_ring_lookup(const tgmx_adj_t* ring, const int32_t* write_pos
   return launch_lookup<true>(a, (hipStream_t)stream, (hipEvent_t)ev_start, (hipEvent_t)ev_stop);
 }
 
+constexpr int kScratchHead = 64;  // ints (256 bytes: the layouts behind it stay 256-byte aligned)
+
 static int fill_update_args(UpdateArgs& a, tgmx_adj_t* ring, int32_t* write_pos, float* ring_x, int32_t D, int32_t B,
                             int32_t num_nodes, const int32_t* src, const int32_t* dst, const int64_t* ts,
                             const float* edge_x, int64_t n, int64_t eid0, int32_t directed, int32_t key_wrap32,
@@ -1578,6 +1617,8 @@ static int fill_update_args(UpdateArgs& a, tgmx_adj_t* ring, int32_t* write_pos,
   a.ring = reinterpret_cast<Rec*>(ring); a.write_pos = write_pos; a.ring_x = ring_x; a.edge_x = edge_x;
   a.src = src; a.dst = dst; a.ts = ts; a.status = status;
   a.n = n; a.m = directed ? n : 2 * n; a.eid0 = eid0; a.B = B; a.N = num_nodes; a.D = D; a.key_wrap32 = key_wrap32;
+  a.barrier = scratch;      // first kScratchHead ints: the riders' barrier words (zero when the buffer is first used)
+  scratch += kScratchHead;  // everything else lives behind them, in every path
   a.sorted_j = scratch; a.sorted_node = scratch + a.m; a.target = scratch + 2 * a.m; a.winner = scratch + 3 * a.m;
   return TGMX_OK;
 }
@@ -1665,11 +1706,12 @@ static int launch_update_large(UpdateArgs& a, int32_t* scratch, hipStream_t st) 
 
 extern "C" size_t tgmx_ring_update_scratch_bytes(int64_t n, int32_t directed) {
   const long long m = directed ? n : 2 * n;
-  if (m <= 0) return 256;
-  if (m <= kBlockMaxM) return ((size_t)12 * m + 16) * sizeof(int32_t) + 256 + 12 * kChunk;  // + chunk padding of the spread sort
+  constexpr size_t head = kScratchHead * sizeof(int32_t);
+  if (m <= 0) return head + 256;
+  if (m <= kBlockMaxM) return head + ((size_t)12 * m + 16) * sizeof(int32_t) + 256 + 12 * kChunk;  // + chunk padding of the spread sort
   LargeScratch w;
   if (large_scratch_layout(m, w)) return 0;
-  return w.total;
+  return head + w.total;
 }
 
 extern "C" int tgmx_ring_update(tgmx_adj_t* ring, int32_t* write_pos, float* ring_x, int32_t D, int32_t B,
@@ -1683,14 +1725,13 @@ extern "C" int tgmx_ring_update(tgmx_adj_t* ring, int32_t* write_pos, float* rin
                                   key_wrap32, scratch, status);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
-  if (a.m <= kBlockMaxM) launch_update_block(a, scratch, st);
-  else if (const int rl = launch_update_large(a, scratch, st)) return rl;
+  if (a.m <= kBlockMaxM) launch_update_block(a, scratch + kScratchHead, st);
+  else if (const int rl = launch_update_large(a, scratch + kScratchHead, st)) return rl;
   TGMX_CHECK_LAUNCH("ring_update");
   return TGMX_OK;
 }
 
-// Can hop 0 and hop 1 of this step be one launch?  (B <= 64; hop 1 not better served by the packed narrow-row kernel;
-// an update either absent, small enough for ONE rider workgroup (m <= 1024), or not riding at all.)
+// Can hop 0 and hop 1 of this step be one launch?  (B <= 64; hop 1 not better served by the packed narrow-row kernel.)
 static bool plan_fuse01(const tgmx_recency_step_t* s, long long S0) {
   static const bool no_fuse = getenv("TGMX_NO_FUSE") != nullptr;  // A/B knob
   static const bool no_ride = getenv("TGMX_NO_RIDE") != nullptr;
@@ -1705,7 +1746,8 @@ static bool plan_fuse01(const tgmx_recency_step_t* s, long long S0) {
     if (packed_group_lanes(a, s->k[1], true) < 64) return false;
   }
   const long long m = s->directed ? s->n : 2 * s->n;
-  if (s->n > 0 && !no_ride && m > kRidePlaceMaxM && m <= kBlockMaxM) return false;  // the riders need two launches
+  (void)no_ride;
+  (void)m;
   return true;
 }
 
@@ -1757,7 +1799,7 @@ extern "C" int tgmx_recency_step(const tgmx_recency_step_t* s, tgmx_stream_t str
                                     s->edge_x, s->n, s->eid0, s->directed, s->key_wrap32, s->scratch, s->status);
     if (rc) return rc;
     static const bool no_ride = getenv("TGMX_NO_RIDE") != nullptr;  // A/B knob: the update as its own launches
-    if (u.m <= kBlockMaxM && s->n_hops > 0 && S > 0 && !no_ride) side_chunks = set_chunk_scratch(u, s->scratch);
+    if (u.m <= kBlockMaxM && s->n_hops > 0 && S > 0 && !no_ride) side_chunks = set_chunk_scratch(u, s->scratch + kScratchHead);
     ride_place = side_chunks > 0 && u.m <= kRidePlaceMaxM && s->n_hops >= 2;
   }
 
@@ -1779,9 +1821,10 @@ extern "C" int tgmx_recency_step(const tgmx_recency_step_t* s, tgmx_stream_t str
     a.ev_lo = s->ev_lo; a.ev_hi = s->ev_hi;
     const bool timed = s->timed_hop == 0 || s->timed_hop == 1;
     hipEvent_t e0 = timed ? (hipEvent_t)s->ev_start : nullptr, e1 = timed ? (hipEvent_t)s->ev_stop : nullptr;
-    ride_place = side_chunks > 0;  // plan_fuse01: m <= 1024 whenever the riders are on
+    // riders: m <= 1024 -> one workgroup does it all and only the commit follows; else sort | barrier | merge
     const int rc = csr ? launch_fused01<false>(a, st, e0, e1, nullptr, 0, 0)
-                       : launch_fused01<true>(a, st, e0, e1, ride_place ? &u : nullptr, kSideAll, 1u);
+                       : launch_fused01<true>(a, st, e0, e1, side_chunks > 0 ? &u : nullptr,
+                                              ride_place ? kSideAll : kSideSortMerge, ride_place ? 1u : side_chunks);
     if (rc) return rc;
     cur_n = s->out_nid[1];
     cur_t = s->out_ts[1];
@@ -1820,8 +1863,8 @@ extern "C" int tgmx_recency_step(const tgmx_recency_step_t* s, tgmx_stream_t str
       if (s->n_hops < 2) hipLaunchKernelGGL(ring_update_merge_kernel, dim3(side_chunks), dim3(kChunk), 0, st, u);
       launch_update_presorted(u, st);
     } else if (u.m <= kBlockMaxM) {
-      launch_update_block(u, s->scratch, st);
-    } else if (const int rl = launch_update_large(u, s->scratch, st)) {
+      launch_update_block(u, s->scratch + kScratchHead, st);
+    } else if (const int rl = launch_update_large(u, s->scratch + kScratchHead, st)) {
       return rl;
     }
   }

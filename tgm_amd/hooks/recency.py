@@ -35,7 +35,7 @@ from ..index import TemporalCSR, build_csr
 from .base import SeedableHook, StatefulHook
 from .registry import hook
 
-_ST_SEED_RANGE, _ST_SEED_TIME, _ST_EDGE_RANGE = 1, 2, 4
+_ST_SEED_RANGE, _ST_SEED_TIME, _ST_EDGE_RANGE, _ST_SCRATCH = 1, 2, 4, 8
 
 
 class _NullCtx:
@@ -203,6 +203,8 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
             raise ValueError('Seed times must be >= 0')
         if st & _ST_EDGE_RANGE:
             raise ValueError(f'Batch edge endpoints must satisfy 0 <= x < {self._num_nodes}')
+        if st & _ST_SCRATCH:
+            raise RuntimeError('tgmx_recency_step: the update scratch was not zero-initialised (internal error)')
 
     # ------------------------------------------------------------------
     def _ensure_state(self, dg: DGraph, device: torch.device) -> None:
@@ -360,7 +362,8 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
                     need = int(lib.tgmx_ring_update_scratch_bytes(n_edges, 1 if self._directed else 0))
                     if need == 0:
                         _native.check(-2, 'tgmx_ring_update_scratch_bytes')
-                    self._scratch = empty(need, dtype=torch.uint8, device=device)  # torch allocations are 256-byte aligned
+                    # torch allocations are 256-byte aligned; zeros: the head of the scratch holds a self-resetting barrier
+                    self._scratch = torch.zeros(need, dtype=torch.uint8, device=device)
                     self._scratch_edges = n_edges
                     st.scratch = self._scratch.data_ptr()
                 ex = batch.edge_x

@@ -19,7 +19,7 @@ for n in [200, 400, 512, 800, 1600, 2048, 4096, 32768]:
     ring = torch.zeros(N * B, 2, dtype=torch.int64, device=dev)
     wpos = torch.zeros(N, dtype=torch.int32, device=dev)
     ring_x = torch.zeros(N * B, D, device=dev)
-    scratch = torch.empty(int(lib.tgmx_ring_update_scratch_bytes(n, 0)), dtype=torch.uint8, device=dev)
+    scratch = torch.zeros(int(lib.tgmx_ring_update_scratch_bytes(n, 0)), dtype=torch.uint8, device=dev)
     status = torch.zeros(1, dtype=torch.int32, device=dev)
     st = _native.stream_ptr()
     def call():
