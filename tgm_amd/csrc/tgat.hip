@@ -505,7 +505,38 @@ struct AttnArgs {
   float scale;        // dh^-1/2
   int Cs;             // stride (floats) between consecutive heads of qf / zbar rows (>= C; padded layouts)
   float* probs;       // optional [R, H, k]: the attention weights, saved for the backward pass
+  // Several levels of the hop tree in ONE launch (they share the layer's weights; qf / zbar / probs are contiguous
+  // across levels).  Rows [seg_begin[i], seg_begin[i + 1]) read level i's sampler outputs; the pointers are biased by
+  // the host so that the GLOBAL row index addresses them (ex_i - seg_begin[i] * k * D, ...).  n_seg <= 1: the plain
+  // fields above.
+  int n_seg;
+  long long seg_begin[TGMX_TGAT_MAX_LAYERS];
+  const float* seg_nbrf[TGMX_TGAT_MAX_LAYERS];
+  const float* seg_ex[TGMX_TGAT_MAX_LAYERS];
+  const int64_t* seg_seed_t[TGMX_TGAT_MAX_LAYERS];
+  const int64_t* seg_nbr_t[TGMX_TGAT_MAX_LAYERS];
+  const int32_t* seg_nbr_id[TGMX_TGAT_MAX_LAYERS];
 };
+
+// the level (segment) of row r: wave-uniform, so this is scalar code
+struct AttnLevel {
+  const float* nbrf;
+  const float* ex;
+  const int64_t* seed_t;
+  const int64_t* nbr_t;
+  const int32_t* nbr_id;
+};
+__device__ __forceinline__ AttnLevel attn_level(const AttnArgs& a, long long r) {
+  AttnLevel v{a.nbrf, a.ex, a.seed_t, a.nbr_t, a.nbr_id};
+  if (a.n_seg > 1) {
+    int si = 0;
+#pragma unroll
+    for (int i = 1; i < TGMX_TGAT_MAX_LAYERS; ++i)
+      if (i < a.n_seg && r >= a.seg_begin[i]) si = i;
+    v.nbrf = a.seg_nbrf[si]; v.ex = a.seg_ex[si]; v.seed_t = a.seg_seed_t[si]; v.nbr_t = a.seg_nbr_t[si]; v.nbr_id = a.seg_nbr_id[si];
+  }
+  return v;
+}
 
 // sum over the 64 lanes of P[j], delivered to lane j: 63 shuffles instead of 64 * 6.
 // (template steps: every register index must be a compile-time constant, or P spills to scratch)
@@ -547,14 +578,15 @@ __global__ __launch_bounds__(256) void tgat_attn_reduce_kernel(const AttnArgs a)
   const long long r = (long long)blockIdx.x * (blockDim.x >> 6) + wave;
   if (r >= a.R) return;
   const float* __restrict__ q = a.qf + r * (long long)H * a.Cs;
-  const float* __restrict__ nb = a.nbrf + r * (long long)k * d;
-  const float* __restrict__ ex = a.ex + r * (long long)k * D;
+  const AttnLevel lv = attn_level(a, r);
+  const float* __restrict__ nb = lv.nbrf + r * (long long)k * d;
+  const float* __restrict__ ex = lv.ex + r * (long long)k * D;
 
   // slot metadata + Time2Vec of every slot (computed once, reused by both passes)
-  const long long st = a.tfeat ? 0 : a.seed_t[r];
+  const long long st = a.tfeat ? 0 : lv.seed_t[r];
   for (int s = lane; s < k; s += kWave) {
-    if (!a.tfeat) s_dt[s] = (float)(st - a.nbr_t[r * k + s]);  // int64 subtract, then round-to-nearest f32 (tgat.py:143-145)
-    const bool ok = a.mask ? a.mask[r * k + s] != 0 : a.nbr_id[r * k + s] != -1;
+    if (!a.tfeat) s_dt[s] = (float)(st - lv.nbr_t[r * k + s]);  // int64 subtract, then round-to-nearest f32 (tgat.py:143-145)
+    const bool ok = a.mask ? a.mask[r * k + s] != 0 : lv.nbr_id[r * k + s] != -1;
     s_valid[s] = ok ? 1.f : 0.f;
   }
   __builtin_amdgcn_wave_barrier();
@@ -685,15 +717,16 @@ __global__ __launch_bounds__(256) void tgat_attn_reduce_reg_kernel(const AttnArg
   const int k = a.k, T = a.T, d = a.d, D = a.D;
   const int D4 = D >> 2, d4 = d >> 2;
   const float* __restrict__ q = a.qf + r * (long long)H * a.Cs;
-  const float* __restrict__ nb = a.nbrf + r * (long long)k * d;
-  const float4* __restrict__ ex4 = reinterpret_cast<const float4*>(a.ex + r * (long long)k * D);
+  const AttnLevel lv = attn_level(a, r);
+  const float* __restrict__ nb = lv.nbrf + r * (long long)k * d;
+  const float4* __restrict__ ex4 = reinterpret_cast<const float4*>(lv.ex + r * (long long)k * D);
 
   // slot metadata: lane s holds slot s
   float my_dt = 0.f;
   bool my_ok = false;
   if (lane < k) {
-    my_dt = (float)(a.seed_t[r] - a.nbr_t[r * k + lane]);  // int64 subtract, then round-to-nearest f32
-    my_ok = a.mask ? a.mask[r * k + lane] != 0 : a.nbr_id[r * k + lane] != -1;
+    my_dt = (float)(lv.seed_t[r] - lv.nbr_t[r * k + lane]);  // int64 subtract, then round-to-nearest f32
+    my_ok = a.mask ? a.mask[r * k + lane] != 0 : lv.nbr_id[r * k + lane] != -1;
   }
 
   // ---- the row's features, straight into registers (all loads independent) ----
@@ -829,8 +862,13 @@ static void launch_attn(dim3 grid, dim3 block, size_t lds, hipStream_t st, const
 // register-resident fast path; returns false when the shape does not qualify
 template <int H>
 static bool launch_attn_reg(hipStream_t st, const AttnArgs& a) {
-  const bool edge_ok = a.D > 0 && a.D % 4 == 0 && a.D / 4 <= 64 && ((uintptr_t)a.ex & 15) == 0;
-  const bool nbv = a.d % 4 == 0 && a.d / 4 <= 64 && ((uintptr_t)a.nbrf & 15) == 0;
+  uintptr_t ex_bits = (uintptr_t)a.ex, nb_bits = (uintptr_t)a.nbrf;  // D, d multiples of 4: biased pointers keep their alignment
+  for (int i = 0; i < a.n_seg; ++i) {
+    ex_bits |= (uintptr_t)a.seg_ex[i];
+    nb_bits |= (uintptr_t)a.seg_nbrf[i];
+  }
+  const bool edge_ok = a.D > 0 && a.D % 4 == 0 && a.D / 4 <= 64 && (ex_bits & 15) == 0;
+  const bool nbv = a.d % 4 == 0 && a.d / 4 <= 64 && (nb_bits & 15) == 0;
   if (!edge_ok || a.tfeat || a.T > 128 || !(nbv || a.d <= 64)) return false;
   const dim3 grid((unsigned)((a.R + 3) / 4)), block(256);
 #define TGMX_REG(G_)                                                                                        \
@@ -1163,18 +1201,27 @@ extern "C" int tgmx_tgat_forward(const tgmx_tgat_model_t* m, const float* node_x
     } else {
       if ((rc = tgmx_sgemm_nt(prev, ld_prev, ly.qf_U, dp, qf, (long long)H * Cp, R, H * Cp, ly.d, ly.qf_v, 0, 1, 0, 0, 0, stream))) return rc;
     }
-    for (int i = 0; i < n_lvl; ++i) {
-      if (rows[i] == 0) continue;
-      TGMX_REQUIRE(hops[i].k == k, "tgat_forward: layer %d needs the same k at every hop it aggregates", j);
-      const float* nbrf = prev + off[i + 1] * ld_prev;
+    {
+      // every level this layer aggregates, in ONE launch (same weights, same k; qf / zbar / probs are contiguous)
       AttnArgs a{};
-      a.qf = qf + off[i] * (long long)H * Cp;
-      a.nbrf = nbrf; a.ex = hops[i].edge_x; a.seed_t = hops[i].seed_t; a.nbr_t = hops[i].nbr_t; a.nbr_id = hops[i].nbr_id;
-      a.tw = m->tw; a.tb = m->tb; a.zbar = zbar + off[i] * (long long)H * Cp; a.R = rows[i];
+      a.qf = qf; a.zbar = zbar; a.probs = probs; a.R = off[n_lvl];
+      a.tw = m->tw; a.tb = m->tb;
       a.d = ly.d; a.D = ly.D; a.T = ly.T; a.k = k; a.C = C; a.scale = 1.0f / sqrtf((float)dh); a.Cs = Cp;
-      a.probs = probs ? probs + off[i] * (long long)H * k : nullptr;
-      TGMX_REQUIRE(ly.D == 0 || a.ex, "tgat_forward: hop %d has no edge features", i);
-      if ((rc = attn_reduce_impl(a, H, (hipStream_t)stream))) return rc;
+      a.n_seg = n_lvl;
+      for (int i = 0; i < n_lvl; ++i) {
+        TGMX_REQUIRE(hops[i].k == k, "tgat_forward: layer %d needs the same k at every hop it aggregates", j);
+        TGMX_REQUIRE(rows[i] == 0 || ly.D == 0 || hops[i].edge_x, "tgat_forward: hop %d has no edge features", i);
+        const long long b = off[i];  // the kernel indexes with the global row: bias every level's arrays by its first row
+        a.seg_begin[i] = b;
+        a.seg_nbrf[i] = prev + off[i + 1] * ld_prev - b * (long long)k * ly.d;
+        a.seg_ex[i] = hops[i].edge_x ? hops[i].edge_x - b * (long long)k * ly.D : nullptr;
+        a.seg_seed_t[i] = hops[i].seed_t - b;
+        a.seg_nbr_t[i] = hops[i].nbr_t - b * (long long)k;
+        a.seg_nbr_id[i] = hops[i].nbr_id - b * (long long)k;
+      }
+      a.nbrf = a.seg_nbrf[0]; a.ex = a.seg_ex[0]; a.seed_t = a.seg_seed_t[0]; a.nbr_t = a.seg_nbr_t[0]; a.nbr_id = a.seg_nbr_id[0];
+      TGMX_REQUIRE(ld_prev == ly.d, "tgat_forward: layer %d expects densely packed input rows", j);
+      if (a.R > 0 && (rc = attn_reduce_impl(a, H, (hipStream_t)stream))) return rc;
     }
     if (chain) {  // inference, enough row tiles to fill the chip: the whole tail of the layer is one row-tile kernel,
                   // intermediates stay in LDS
