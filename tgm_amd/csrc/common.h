@@ -67,25 +67,34 @@ __device__ __forceinline__ float cos_t2v_poly(float rf, int q) {
   return (q == 1 || q == 2) ? -v : v;
 }
 
-__device__ __forceinline__ float cos_t2v(float x) {
-  if (__all(fabsf(x) < 8.0e6f)) {
-    float k = __builtin_rintf(x * 0.636619772367581343f);
-    float r = __fmaf_rn(-k, 1.57079637050628662109375f, x);
-    r = __fmaf_rn(-k, -4.37113900018624283e-8f, r);
-    // near 8e6 the float product x * (2/pi) is only good to ~half a unit, so k can be one off: one exact correction
-    // step on the two-term remainder brings r back into [-pi/4, pi/4] (without it: 7.7e-6 worst error in [3e6, 8e6))
-    const float adj = r > 0.78539819f ? 1.f : (r < -0.78539819f ? -1.f : 0.f);
-    k += adj;
-    r = __fmaf_rn(-adj, 1.57079637050628662109375f, r);
-    r = __fmaf_rn(-adj, -4.37113900018624283e-8f, r);
-    r = __fmaf_rn(-k, -1.71512449e-15f, r);
-    return cos_t2v_poly(r, (int)k & 3);
-  }
+// the two reductions on their own (callers that decide once for many arguments: the attention kernel)
+__device__ __forceinline__ float cos_t2v_small(float x) {  // |x| < 8e6
+  float k = __builtin_rintf(x * 0.636619772367581343f);
+  float r = __fmaf_rn(-k, 1.57079637050628662109375f, x);
+  r = __fmaf_rn(-k, -4.37113900018624283e-8f, r);
+  // near 8e6 the float product x * (2/pi) is only good to ~half a unit, so k can be one off: one exact correction
+  // step on the two-term remainder brings r back into [-pi/4, pi/4] (without it: 7.7e-6 worst error in [3e6, 8e6))
+  const float adj = r > 0.78539819f ? 1.f : (r < -0.78539819f ? -1.f : 0.f);
+  k += adj;
+  r = __fmaf_rn(-adj, 1.57079637050628662109375f, r);
+  r = __fmaf_rn(-adj, -4.37113900018624283e-8f, r);
+  r = __fmaf_rn(-k, -1.71512449e-15f, r);
+  return cos_t2v_poly(r, (int)k & 3);
+}
+
+__device__ __forceinline__ float cos_t2v_big(float x) {  // any float32
   const double xd = (double)x;
   const double kd = __builtin_rint(xd * 0.63661977236758134308);
   double r = __builtin_fma(-kd, 1.57079632679489655800e+00, xd);
   r = __builtin_fma(-kd, 6.12323399573676603587e-17, r);
   return cos_t2v_poly((float)r, (int)((long long)kd & 3));
+}
+
+constexpr float kCosSmallLimit = 8.0e6f;
+
+__device__ __forceinline__ float cos_t2v(float x) {
+  if (__all(fabsf(x) < kCosSmallLimit)) return cos_t2v_small(x);
+  return cos_t2v_big(x);
 }
 
 __device__ __forceinline__ bool pair_after(long long ka, int pa, long long kb, int pb) {

@@ -776,16 +776,43 @@ __global__ __launch_bounds__(256) void tgat_attn_reduce_reg_kernel(const AttnArg
   // rows whose k slots all carry the same time delta (every padded seed of a deeper hop: nbr_t = 0 in all slots) need
   // ONE Time2Vec evaluation per column, not k -- identical arithmetic, ~3/4 of the layer-1 rows at the headline shape
   const bool same_dt = __all(lane >= k || my_dt == __shfl(my_dt, 0));
+  // The cosine's reduction path (float for |x| < 8e6, double beyond) is chosen ONCE per row, and the evaluations run
+  // as straight-line code: with the choice (a wave vote and a branch) inside every evaluation the 40 evaluations of a
+  // row cost 23 of the kernel's 73 us.  Lanes past T carry w = b = 0: their cos(0) meets a zero query weight below and
+  // is never stored.
+  bool small = true;
 #pragma unroll
   for (int s = 0; s < G; ++s) {
     const float dt = __shfl(my_dt, s);  // compile-time lane: v_readlane
-    if (s > 0 && same_dt) {
-      tz0[s] = tz0[0];
-      tz1[s] = tz1[0];
-    } else {
-      tz0[s] = t0_on ? cos_t2v(__fmaf_rn(dt, w0, b0)) : 0.f;
-      tz1[s] = t1_on ? cos_t2v(__fmaf_rn(dt, w1, b1)) : 0.f;
+    small = small && fabsf(__fmaf_rn(dt, w0, b0)) < kCosSmallLimit && fabsf(__fmaf_rn(dt, w1, b1)) < kCosSmallLimit;
+  }
+  const bool row_small = __all(small);
+  if (same_dt) {
+    const float dt = __shfl(my_dt, 0);
+    const float c0 = row_small ? cos_t2v_small(__fmaf_rn(dt, w0, b0)) : cos_t2v_big(__fmaf_rn(dt, w0, b0));
+    const float c1 = row_small ? cos_t2v_small(__fmaf_rn(dt, w1, b1)) : cos_t2v_big(__fmaf_rn(dt, w1, b1));
+#pragma unroll
+    for (int s = 0; s < G; ++s) {
+      tz0[s] = c0;
+      tz1[s] = c1;
     }
+  } else if (row_small) {
+#pragma unroll
+    for (int s = 0; s < G; ++s) {
+      const float dt = __shfl(my_dt, s);
+      tz0[s] = cos_t2v_small(__fmaf_rn(dt, w0, b0));
+      tz1[s] = cos_t2v_small(__fmaf_rn(dt, w1, b1));
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < G; ++s) {
+      const float dt = __shfl(my_dt, s);
+      tz0[s] = cos_t2v_big(__fmaf_rn(dt, w0, b0));
+      tz1[s] = cos_t2v_big(__fmaf_rn(dt, w1, b1));
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < G; ++s) {
 #pragma unroll
     for (int h = 0; h < H; ++h) {
       float p = qe[h].x * ze[s].x;

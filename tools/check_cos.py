@@ -3,6 +3,9 @@
 separate launch so that whole waves take the float (|x| < 8e6) or the double reduction path."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tgm_amd import _native
+if os.environ.get("TGMX_LIB"):
+    _native.load(os.environ["TGMX_LIB"])
 from tgm_amd.nn import _ops
 torch.manual_seed(0)
 w = torch.ones(1, device='cuda'); b = torch.zeros(1, device='cuda')
