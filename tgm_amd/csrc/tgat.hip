@@ -551,9 +551,26 @@ __device__ __forceinline__ void reduce_scatter_step(float (&P)[64], int lane) {
     P[i] = keep + recv;
   }
 }
+// the two widest steps as gfx950 lane swaps: v_permlane32_swap exchanges the upper half of one register with the lower
+// half of another (v_permlane16_swap: odd 16-lane rows with even ones), so a' + b' IS keep + recv for both halves --
+// two instructions per pair instead of two selects, a ds_bpermute and an add (same operands: bit-identical sums)
+__device__ __forceinline__ void reduce_scatter_swap32(float (&P)[64]) {
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(P[i]), __float_as_uint(P[i + 32]), false, false);
+    P[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+}
+__device__ __forceinline__ void reduce_scatter_swap16(float (&P)[64]) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(P[i]), __float_as_uint(P[i + 16]), false, false);
+    P[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+}
 __device__ __forceinline__ float reduce_scatter64(float (&P)[64], int lane) {
-  reduce_scatter_step<32>(P, lane);
-  reduce_scatter_step<16>(P, lane);
+  reduce_scatter_swap32(P);
+  reduce_scatter_swap16(P);
   reduce_scatter_step<8>(P, lane);
   reduce_scatter_step<4>(P, lane);
   reduce_scatter_step<2>(P, lane);
@@ -708,6 +725,12 @@ __global__ __launch_bounds__(256) void tgat_attn_reduce_kernel(const AttnArgs a)
 // registers, so the row's [k, C] block is read from memory exactly ONCE, as 16-byte loads issued
 // back to back; no LDS at all (slot metadata and attention weights travel by v_readlane).
 // ---------------------------------------------------------------------------
+// value of lane `src` (a compile-time constant after unrolling) for every lane: one v_readlane_b32 into an SGPR --
+// __shfl would go through the LDS crossbar (ds_bpermute) even for a constant lane
+__device__ __forceinline__ float lane_bcast(float v, int src) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+
 template <int H, int G, bool NBV>
 __global__ __launch_bounds__(256) void tgat_attn_reduce_reg_kernel(const AttnArgs a) {
   static_assert(G * H <= 64, "a score group must fit the 64 lanes");
@@ -775,7 +798,7 @@ __global__ __launch_bounds__(256) void tgat_attn_reduce_reg_kernel(const AttnArg
   for (int j = 0; j < 64; ++j) P[j] = 0.f;
   // rows whose k slots all carry the same time delta (every padded seed of a deeper hop: nbr_t = 0 in all slots) need
   // ONE Time2Vec evaluation per column, not k -- identical arithmetic, ~3/4 of the layer-1 rows at the headline shape
-  const bool same_dt = __all(lane >= k || my_dt == __shfl(my_dt, 0));
+  const bool same_dt = __all(lane >= k || my_dt == lane_bcast(my_dt, 0));
   // The cosine's reduction path (float for |x| < 8e6, double beyond) is chosen ONCE per row, and the evaluations run
   // as straight-line code: with the choice (a wave vote and a branch) inside every evaluation the 40 evaluations of a
   // row cost 23 of the kernel's 73 us.  Lanes past T carry w = b = 0: their cos(0) meets a zero query weight below and
@@ -783,12 +806,12 @@ __global__ __launch_bounds__(256) void tgat_attn_reduce_reg_kernel(const AttnArg
   bool small = true;
 #pragma unroll
   for (int s = 0; s < G; ++s) {
-    const float dt = __shfl(my_dt, s);  // compile-time lane: v_readlane
+    const float dt = lane_bcast(my_dt, s);
     small = small && fabsf(__fmaf_rn(dt, w0, b0)) < kCosSmallLimit && fabsf(__fmaf_rn(dt, w1, b1)) < kCosSmallLimit;
   }
   const bool row_small = __all(small);
   if (same_dt) {
-    const float dt = __shfl(my_dt, 0);
+    const float dt = lane_bcast(my_dt, 0);
     const float c0 = row_small ? cos_t2v_small(__fmaf_rn(dt, w0, b0)) : cos_t2v_big(__fmaf_rn(dt, w0, b0));
     const float c1 = row_small ? cos_t2v_small(__fmaf_rn(dt, w1, b1)) : cos_t2v_big(__fmaf_rn(dt, w1, b1));
 #pragma unroll
@@ -799,14 +822,14 @@ __global__ __launch_bounds__(256) void tgat_attn_reduce_reg_kernel(const AttnArg
   } else if (row_small) {
 #pragma unroll
     for (int s = 0; s < G; ++s) {
-      const float dt = __shfl(my_dt, s);
+      const float dt = lane_bcast(my_dt, s);
       tz0[s] = cos_t2v_small(__fmaf_rn(dt, w0, b0));
       tz1[s] = cos_t2v_small(__fmaf_rn(dt, w1, b1));
     }
   } else {
 #pragma unroll
     for (int s = 0; s < G; ++s) {
-      const float dt = __shfl(my_dt, s);
+      const float dt = lane_bcast(my_dt, s);
       tz0[s] = cos_t2v_big(__fmaf_rn(dt, w0, b0));
       tz1[s] = cos_t2v_big(__fmaf_rn(dt, w1, b1));
     }
@@ -857,7 +880,7 @@ __global__ __launch_bounds__(256) void tgat_attn_reduce_reg_kernel(const AttnArg
     float an = 0.f, at0 = 0.f, at1 = 0.f;
 #pragma unroll
     for (int s = 0; s < G; ++s) {
-      const float w = __shfl(A, s * H + h);  // 0 for s >= k
+      const float w = lane_bcast(A, s * H + h);  // 0 for s >= k
       ae.x = __fmaf_rn(w, ze[s].x, ae.x); ae.y = __fmaf_rn(w, ze[s].y, ae.y);
       ae.z = __fmaf_rn(w, ze[s].z, ae.z); ae.w = __fmaf_rn(w, ze[s].w, ae.w);
       if (NBV) {
