@@ -443,6 +443,28 @@ def test_edge_cases_and_errors():
     assert out.nbr_nids[0].numel() == 0 and out.nbr_edge_x[0].shape == (0, 0)
 
 
+def test_dirty_scratch_head_is_reported_not_hung():
+    """The riders' barrier lives in the first 256 bytes of the update scratch, which must be zero at first use.  A
+    dirty head must not hang the device: the barrier gives up after about a second and raises TGMX_ST_SCRATCH."""
+    DGData, DGDataLoader, DGraph, HookManager, RecencyNeighborHook, ReplayNegatives = _mk()
+    N, E, D, bs = 3000, 4000, 64, 800  # m = 1600, wide rows: hops fused, riders = sort | barrier | merge
+    a, edge_x = _random_stream(5, N, E, D, 100_000)
+    hook = RecencyNeighborHook(N, [4, 20], ['edge_src', 'edge_dst'], ['edge_time', 'edge_time'], validate='deferred')
+    hm = HookManager(keys=['k'])
+    hm.register('k', hook)
+    dg = _graph(a, 0, E, edge_x)
+    loader = DGDataLoader(dg, batch_size=bs, hook_manager=hm)
+    with hm.activate('k'):
+        it = iter(loader)
+        next(it)  # allocates (and zeroes) the scratch
+        hook.check()
+        assert hook.fuses_first_hops()
+        hook._scratch[:8].fill_(0x7F)  # corrupt the barrier words
+        next(it)
+        with pytest.raises(RuntimeError, match='scratch'):
+            hook.check()
+
+
 def _fuzz_config(seed):
     """One random sampler configuration per seed: sizes chosen to land on every update plan (one workgroup, chunk sort +
     merge, radix sort), every lookup specialisation (packed groups, one wave, chunked B > 64) and both key arithmetics."""

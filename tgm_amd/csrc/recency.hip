@@ -743,7 +743,7 @@ __device__ __forceinline__ bool rider_barrier(int32_t* bar, int parts) {
       int spins = 0;
       while (__hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
         __builtin_amdgcn_s_sleep(8);
-        if (++spins > (1 << 22)) {
+        if (++spins > (1 << 19)) {  // ~1 s of polling
           ok = false;
           break;
         }
