@@ -13,6 +13,14 @@
 //     The [S, B, D] intermediate the reference materialises
 //     (tgm/hooks/neighbors/recency.py:258) never exists.
 // Rows are copied, never recomputed, so features are bit-exact by construction.
+//
+// File map (one translation unit: the lookup launches carry pieces of the ring update, so both live here):
+//   UpdateArgs, keys, the single-workgroup sort / placement body (update_block_body)
+//   riders: update_chunk_sort, update_merge_riding, rider_barrier, update_side_work -- the state-independent half of
+//     the ring update as workgroup-sized pieces that ride inside the lookup launches
+//   lookup pieces (fetch_seed ... lookup_seed) and the kernels built from them: recency_lookup_kernel (one hop),
+//     recency_lookup_fused01_kernel (hop 0 + hop 1 in one launch), ring_lookup_packed_kernel (narrow rows)
+//   the stand-alone update paths (one workgroup / chunk sort + merge / rocPRIM radix sort), uniform sampler, C entry points
 #include <cstdlib>
 #include <cstring>
 
