@@ -41,8 +41,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); ~6300 GB/s achievabl
 def parse_args():
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
-    p.add_argument('--steps', type=int, default=788)  # one pass over the 157 474-edge stream at bs=200
-    p.add_argument('--warmup', type=int, default=20)
+    p.add_argument('--steps', type=int, default=2364)  # three passes over the 157 474-edge stream at bs=200 (788 batches each)
+    p.add_argument('--warmup', type=int, default=100)
     p.add_argument('--workload', default='wiki', choices=['wiki', 'review', 'comment'])
     p.add_argument('--batch-size', type=int, default=None, help='edges per rank per step (default: 200 wiki, 512 review, 4096 comment)')
     p.add_argument('--num-nbrs', type=int, nargs='+', default=None)
