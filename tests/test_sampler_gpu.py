@@ -489,3 +489,41 @@ def test_ring_mode_fuzz(seed):
     """Seeded random configurations against the oracle (TGMX_FUZZ=<n> widens the sweep; the default keeps the suite short)."""
     N, E, D, tmax, num_nbrs, bs, directed, key_arith, validate = _fuzz_config(seed)
     _check_ring_against_oracle(N, E, D, tmax, num_nbrs, bs, directed, key_arith, validate=validate)
+
+
+@pytest.mark.parametrize('seed', range(max(4, int(os.environ.get('TGMX_FUZZ', '16')) // 2)))
+def test_csr_mode_fuzz(seed):
+    """Stateless static-index lookups == streaming rings with the intended (int64) key order, on seeded random
+    configurations (wide and narrow rows, so both the fused hop 0 + hop 1 launch and the per-hop launches run)."""
+    DGData, DGDataLoader, DGraph, HookManager, RecencyNeighborHook, ReplayNegatives = _mk()
+    r = np.random.default_rng(20_000 + seed)
+    N = int(r.choice([9, 120, 2500]))
+    bs = int(r.choice([7, 64, 200, 700]))
+    E = int(min(max(bs * r.integers(4, 10), 300), 6000))
+    D = int(r.choice([0, 3, 8, 64, 172]))
+    tmax = int(r.choice([20, 5000, 2_000_000]))
+    L = int(r.integers(1, 4))
+    num_nbrs = [int(r.choice([1, 3, 8, 20, 32])) for _ in range(L)]
+    while int(np.prod(num_nbrs)) * 3 * bs * max(D, 1) > 40_000_000:
+        num_nbrs[int(np.argmax(num_nbrs))] = max(1, max(num_nbrs) // 2)
+    directed = bool(r.integers(0, 2))
+    a, edge_x = _random_stream(4321 + seed, N, E, D, tmax)
+    outs = {}
+    for mode in ('ring', 'csr'):
+        hook = RecencyNeighborHook(N, num_nbrs, ['edge_src', 'edge_dst', 'neg'], ['edge_time', 'edge_time', 'neg_time'],
+                                   mode=mode, key_arith='int64', batch_size=bs, directed=directed, validate='deferred')  # fmt: skip
+        hm = HookManager(keys=['k'])
+        hm.register('k', ReplayNegatives(torch.from_numpy(a['neg']).to(DEV)))
+        hm.register('k', hook)
+        dg = _graph(a, 0, E, edge_x)
+        res = []
+        with hm.activate('k'):
+            for batch in DGDataLoader(dg, batch_size=bs, hook_manager=hm):
+                res.append([(batch.nbr_nids[h], batch.nbr_edge_time[h], batch.nbr_edge_x[h]) for h in range(L)])
+        hook.check()
+        outs[mode] = res
+    assert len(outs['ring']) == len(outs['csr'])
+    for b, (x, y) in enumerate(zip(outs['ring'], outs['csr'])):
+        for h in range(L):
+            for u, v in zip(x[h], y[h]):
+                assert torch.equal(u, v), f'batch {b} hop {h} ({N=}, {bs=}, {D=}, {num_nbrs=}, {directed=})'
