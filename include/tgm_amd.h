@@ -39,6 +39,7 @@ extern "C" {
 #define TGMX_ST_SEED_TIME 2  /* a hop-0 seed time < 0                         */
 #define TGMX_ST_EDGE_RANGE 4 /* an edge endpoint outside [0, num_nodes)       */
 #define TGMX_ST_SCRATCH 8    /* the head of the update scratch was not zero at first use */
+#define TGMX_ST_TS_BOUND 16  /* a batch timestamp outside [0, ts_bound] (tgmx_recency_step_t) */
 
 typedef void* tgmx_stream_t;
 typedef void* tgmx_event_t; /* hipEvent_t */
@@ -178,6 +179,9 @@ typedef struct tgmx_recency_step {
   int32_t* status;
   int32_t timed_hop;           /* -1: none */
   tgmx_event_t ev_start, ev_stop;
+  int64_t ts_bound;            /* 0 = unknown; else a promise: every timestamp of every batch satisfies 0 <= t <= ts_bound
+                                  (lets the large-batch update sort only the key bits that can be set; a violation is
+                                  reported as TGMX_ST_TS_BOUND and the order of that batch is unspecified) */
 } tgmx_recency_step_t;
 
 int tgmx_recency_step(const tgmx_recency_step_t* step, tgmx_stream_t stream);

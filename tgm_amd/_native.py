@@ -127,6 +127,7 @@ class RecencyStep(ctypes.Structure):
         ('n', c_int64), ('eid0', c_int64), ('directed', c_int32), ('key_wrap32', c_int32),
         ('scratch', c_void_p), ('status', c_void_p),
         ('timed_hop', c_int32), ('ev_start', c_void_p), ('ev_stop', c_void_p),
+        ('ts_bound', c_int64),
     ]  # fmt: skip
 
 

@@ -172,6 +172,8 @@ struct UpdateArgs {
   int32_t* run_start;          // scratch [m]: first sorted position of p's run
   int32_t* run_len;            // scratch [m]: run length, at the run's first position
   int hash_bits;
+  long long ts_bound;   // > 0: every timestamp is promised to lie in [0, ts_bound] (bounded-bit radix sort)
+  int sort_bits;        // large path: number of low key bits the radix sort looks at (64 = all)
   int32_t* barrier;  // 2 ints at the head of the caller's scratch: the riders' self-resetting barrier (count, generation)
   int32_t* status;
   long long n, m, eid0;
@@ -1255,20 +1257,24 @@ static int launch_fused01(LookupArgs a, hipStream_t stream, hipEvent_t ev_start,
 // passes around one rocPRIM radix sort of the (sign-flipped) 64-bit keys -- LSD radix sort is stable, which is the
 // reference's `argsort(stable=True)`.  Slot collisions are resolved through an open-addressing hash in the scratch
 // (atomicMax of the sorted position: the last one wins); write_pos moves by one atomicAdd per run.
+// span = max(ts) + 1, by gridDim.x workgroups meeting in one atomicMax (the word is preset to a very negative value);
+// a single workgroup walking 32 768 timestamps took 56 us
 __global__ __launch_bounds__(256) void ring_update_span_kernel(const UpdateArgs a) {
-  __shared__ long long red[256];
+  __shared__ long long red[256 / kWave];
+  const long long per = (a.n + gridDim.x - 1) / gridDim.x;
+  const long long lo = (long long)blockIdx.x * per, hi = lo + per < a.n ? lo + per : a.n;
   long long mx = -0x7fffffffffffffffLL;
-  for (long long x = threadIdx.x; x < a.n; x += 256) {
-    const long long v = a.ts[x];
-    mx = v > mx ? v : mx;
+  if (lo < hi) mx = strided_max_ts(a.ts + lo, hi - lo, threadIdx.x, 256);
+  for (int off = 32; off > 0; off >>= 1) {
+    const long long o = __shfl_xor(mx, off);
+    mx = o > mx ? o : mx;
   }
-  red[threadIdx.x] = mx;
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
   __syncthreads();
-  for (int w = 128; w > 0; w >>= 1) {
-    if ((int)threadIdx.x < w) red[threadIdx.x] = red[threadIdx.x + w] > red[threadIdx.x] ? red[threadIdx.x + w] : red[threadIdx.x];
-    __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 256 / kWave; ++w) mx = red[w] > mx ? red[w] : mx;
+    if (lo < hi) atomicMax(a.span, mx + 1);
   }
-  if (threadIdx.x == 0) *a.span = red[0] + 1;
 }
 
 __global__ __launch_bounds__(256) void ring_update_keys_kernel(const UpdateArgs a) {
@@ -1277,7 +1283,15 @@ __global__ __launch_bounds__(256) void ring_update_keys_kernel(const UpdateArgs 
   int node, nbr;
   long long t, i;
   update_entry(a, j, node, nbr, t, i);
-  a.keys_in[j] = (unsigned long long)update_key(node, t, *a.span, a.key_wrap32) ^ 0x8000000000000000ull;  // signed -> radix order
+  const long long key = update_key(node, t, *a.span, a.key_wrap32);
+  if (a.sort_bits < 64) {
+    // bounded sort: t in [0, ts_bound] makes key + 2^31 (int32-wrapped product) resp. key (int64 product, valid node)
+    // non-negative and narrower than sort_bits
+    if (t < 0 || t > a.ts_bound) atomicOr(a.status, TGMX_ST_TS_BOUND);
+    a.keys_in[j] = (unsigned long long)(a.key_wrap32 ? key + 2147483648LL : key);
+  } else {
+    a.keys_in[j] = (unsigned long long)key ^ 0x8000000000000000ull;  // signed -> radix order
+  }
   a.vals_in[j] = (unsigned)j;
 }
 
@@ -1689,7 +1703,9 @@ static int large_scratch_layout(long long m, LargeScratch& w) {
   return TGMX_OK;
 }
 
-static int launch_update_large(UpdateArgs& a, int32_t* scratch, hipStream_t st) {
+// front: everything up to the placement decisions -- nothing there writes ring state, so it may run next to the lookups
+// of the same batch on another stream; back: the writes (ring records, write_pos, feature rows)
+static int launch_update_large_front(UpdateArgs& a, int32_t* scratch, hipStream_t st) {
   LargeScratch w;
   const int rc = large_scratch_layout(a.m, w);
   if (rc) return rc;
@@ -1706,12 +1722,29 @@ static int launch_update_large(UpdateArgs& a, int32_t* scratch, hipStream_t st) 
   a.run_len = reinterpret_cast<int32_t*>(base + w.run_len);
   const unsigned blocks = (unsigned)((a.m + 255) / 256);
   (void)hipMemsetAsync(a.hash_key, 0xFF, (size_t)8 << w.hash_bits, st);  // keys and max positions (adjacent): all -1
-  hipLaunchKernelGGL(ring_update_span_kernel, dim3(1), dim3(256), 0, st, a);
+  (void)hipMemsetAsync(a.span, 0x80, sizeof(long long), st);  // 0x8080...: far below any timestamp
+  const unsigned span_blocks = (unsigned)((a.n + 2047) / 2048 < 64 ? (a.n + 2047) / 2048 : 64);
+  hipLaunchKernelGGL(ring_update_span_kernel, dim3(span_blocks), dim3(256), 0, st, a);
+  // how many key bits can be set?  (only with the caller's promise 0 <= t <= ts_bound)
+  a.sort_bits = 64;
+  if (a.ts_bound > 0) {
+    int bits = 64;
+    if (a.key_wrap32) {
+      if (a.ts_bound < (1ll << 61)) {
+        const unsigned long long top = (1ull << 32) + (unsigned long long)a.ts_bound;  // key + 2^31 < 2^32 + ts_bound
+        bits = 64 - __builtin_clzll(top);
+      }
+    } else {
+      const __int128 top = (__int128)a.N * ((__int128)a.ts_bound + 1);  // node * span + t < N * (ts_bound + 1)
+      if (top < ((__int128)1 << 62)) bits = 64 - __builtin_clzll((unsigned long long)top);
+    }
+    a.sort_bits = bits;
+  }
   hipLaunchKernelGGL(ring_update_keys_kernel, dim3(blocks), dim3(256), 0, st, a);
   size_t tb = w.temp_bytes;
   const hipError_t err = rocprim::radix_sort_pairs(base + w.temp, tb, (const unsigned long long*)a.keys_in, keys_out,
                                                    (const unsigned int*)a.vals_in, reinterpret_cast<unsigned int*>(a.sorted_j),
-                                                   (size_t)a.m, 0u, 64u, st);
+                                                   (size_t)a.m, 0u, (unsigned)a.sort_bits, st);
   if (err != hipSuccess) {
     set_error("ring_update: radix sort failed: %s", hipGetErrorString(err));
     return TGMX_E_LAUNCH;
@@ -1726,8 +1759,18 @@ static int launch_update_large(UpdateArgs& a, int32_t* scratch, hipStream_t st) 
   }
   hipLaunchKernelGGL(ring_update_ends_kernel, dim3(blocks), dim3(256), 0, st, a);
   hipLaunchKernelGGL(ring_update_place_kernel, dim3(blocks), dim3(256), 0, st, a);
+  return TGMX_OK;
+}
+
+static void launch_update_large_back(const UpdateArgs& a, hipStream_t st) {
+  const unsigned blocks = (unsigned)((a.m + 255) / 256);
   hipLaunchKernelGGL(ring_update_write_kernel, dim3(blocks), dim3(256), 0, st, a);
   if (a.D > 0) hipLaunchKernelGGL(ring_update_feat_kernel<false>, dim3((unsigned)((a.m + 3) / 4)), dim3(256), 0, st, a);
+}
+
+static int launch_update_large(UpdateArgs& a, int32_t* scratch, hipStream_t st) {
+  if (const int rc = launch_update_large_front(a, scratch, st)) return rc;
+  launch_update_large_back(a, st);
   return TGMX_OK;
 }
 
@@ -1756,6 +1799,32 @@ extern "C" int tgmx_ring_update(tgmx_adj_t* ring, int32_t* write_pos, float* rin
   else if (const int rl = launch_update_large(a, scratch + kScratchHead, st)) return rl;
   TGMX_CHECK_LAUNCH("ring_update");
   return TGMX_OK;
+}
+
+// Large batches (m > kBlockMaxM: the rocPRIM path) inside tgmx_recency_step: sort, run analysis and placement
+// decisions read no ring state that the lookups of the same batch change, so they run on a library-owned side stream
+// next to the lookups; only the writes wait for both.  (For small batches the riders do the same inside the lookup
+// launches without any stream traffic -- four extra runtime calls per batch only pay when the batch is big: the
+// comment-shaped step is 220 us of kernels against 60 us of host.)
+struct SideStream {
+  hipStream_t stream = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+};
+static SideStream* side_stream_for_current_device() {
+  static SideStream side[64];
+  static const bool off = getenv("TGMX_NO_SIDE_STREAM") != nullptr;  // A/B knob
+  int dev = 0;
+  if (off || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  SideStream& s = side[dev];
+  if (!s.stream) {
+    if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess) {
+      s.stream = nullptr;
+      return nullptr;
+    }
+  }
+  return &s;
 }
 
 // Can hop 0 and hop 1 of this step be one launch?  (B <= 64; hop 1 not better served by the packed narrow-row kernel.)
@@ -1825,9 +1894,17 @@ extern "C" int tgmx_recency_step(const tgmx_recency_step_t* s, tgmx_stream_t str
     const int rc = fill_update_args(u, s->ring, s->write_pos, s->ring_x, s->D, s->B, s->num_nodes, s->src, s->dst, s->ts,
                                     s->edge_x, s->n, s->eid0, s->directed, s->key_wrap32, s->scratch, s->status);
     if (rc) return rc;
+    u.ts_bound = s->ts_bound;
     static const bool no_ride = getenv("TGMX_NO_RIDE") != nullptr;  // A/B knob: the update as its own launches
     if (u.m <= kBlockMaxM && s->n_hops > 0 && S > 0 && !no_ride) side_chunks = set_chunk_scratch(u, s->scratch + kScratchHead);
     ride_place = side_chunks > 0 && u.m <= kRidePlaceMaxM && s->n_hops >= 2;
+  }
+  SideStream* side = nullptr;  // set: the large update's front half runs on the side stream next to the lookups
+  if (s->n > 0 && u.m > kBlockMaxM && s->n_hops > 0 && S > 0 && (side = side_stream_for_current_device()) != nullptr) {
+    (void)hipEventRecord(side->fork, st);  // the batch's inputs and the previous batch's ring writes are complete
+    (void)hipStreamWaitEvent(side->stream, side->fork, 0);
+    if (const int rl = launch_update_large_front(u, s->scratch + kScratchHead, side->stream)) return rl;
+    (void)hipEventRecord(side->join, side->stream);
   }
 
   // ---- lookups, hop by hop (hop h + 1 consumes hop h's outputs in place); hops 0 and 1 as one launch when possible
@@ -1891,6 +1968,9 @@ extern "C" int tgmx_recency_step(const tgmx_recency_step_t* s, tgmx_stream_t str
       launch_update_presorted(u, st);
     } else if (u.m <= kBlockMaxM) {
       launch_update_block(u, s->scratch + kScratchHead, st);
+    } else if (side) {
+      (void)hipStreamWaitEvent(st, side->join, 0);
+      launch_update_large_back(u, st);
     } else if (const int rl = launch_update_large(u, s->scratch + kScratchHead, st)) {
       return rl;
     }

@@ -35,7 +35,7 @@ from ..index import TemporalCSR, build_csr
 from .base import SeedableHook, StatefulHook
 from .registry import hook
 
-_ST_SEED_RANGE, _ST_SEED_TIME, _ST_EDGE_RANGE, _ST_SCRATCH = 1, 2, 4, 8
+_ST_SEED_RANGE, _ST_SEED_TIME, _ST_EDGE_RANGE, _ST_SCRATCH, _ST_TS_BOUND = 1, 2, 4, 8, 16
 
 
 class _NullCtx:
@@ -203,6 +203,8 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
             raise ValueError('Seed times must be >= 0')
         if st & _ST_EDGE_RANGE:
             raise ValueError(f'Batch edge endpoints must satisfy 0 <= x < {self._num_nodes}')
+        if st & _ST_TS_BOUND:
+            raise RuntimeError('tgmx_recency_step: a batch timestamp lies outside [0, ts_bound] (the bound comes from the graph store)')
         if st & _ST_SCRATCH:
             raise RuntimeError('tgmx_recency_step: the update scratch was not zero-initialised (internal error)')
 
@@ -246,6 +248,12 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
         st.directed, st.key_wrap32 = (1 if self._directed else 0), self._key_wrap32
         st.status = self._status.data_ptr()
         st.timed_hop = -1
+        # the store is time-sorted and keeps a host copy of the timestamps: [0, last] bounds every batch of this graph
+        # (lets the large-batch update sort only the key bits that can be set); unknown / negative times: no promise
+        st.ts_bound = 0
+        times = getattr(dg._storage, '_time_np', None)
+        if times is not None and len(times) and int(times[0]) >= 0:
+            st.ts_bound = int(times[-1])
         self._step = st
 
     def _ensure_csr(self, dg: DGraph, batch: DGBatch) -> TemporalCSR:
