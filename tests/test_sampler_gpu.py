@@ -465,6 +465,26 @@ def test_dirty_scratch_head_is_reported_not_hung():
             hook.check()
 
 
+def test_violated_timestamp_bound_is_reported():
+    """Large batches sort only the key bits that `ts_bound` allows; a timestamp beyond the promise must be reported."""
+    DGData, DGDataLoader, DGraph, HookManager, RecencyNeighborHook, ReplayNegatives = _mk()
+    N, E, D, bs = 500, 6000, 2, 3000  # m = 6000: the rocPRIM path
+    a, edge_x = _random_stream(9, N, E, D, 50_000)
+    hook = RecencyNeighborHook(N, [4], ['edge_src', 'edge_dst'], ['edge_time', 'edge_time'], validate='deferred')
+    hm = HookManager(keys=['k'])
+    hm.register('k', hook)
+    loader = DGDataLoader(_graph(a, 0, E, edge_x), batch_size=bs, hook_manager=hm)
+    with hm.activate('k'):
+        it = iter(loader)
+        next(it)
+        hook.check()  # the bound taken from the store holds
+        assert hook._step.ts_bound == int(a['ts'][-1])
+        hook._step.ts_bound = 10  # a promise the second batch breaks
+        next(it)
+        with pytest.raises(RuntimeError, match='ts_bound'):
+            hook.check()
+
+
 def _fuzz_config(seed):
     """One random sampler configuration per seed: sizes chosen to land on every update plan (one workgroup, chunk sort +
     merge, radix sort), every lookup specialisation (packed groups, one wave, chunked B > 64) and both key arithmetics."""
