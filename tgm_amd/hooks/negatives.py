@@ -66,8 +66,12 @@ class RandomNegativeEdgeSamplerHook(StatelessHook):
             t_in = getattr(batch, self._time_key)
             if t_in.dtype != torch.int64 or not t_in.is_contiguous():
                 t_in = t_in.to(torch.int64).contiguous()
-            neg = torch.empty(n, dtype=torch.int32, device=device)
-            neg_time = torch.empty(t_in.shape[0], dtype=torch.int64, device=device)
+            ne = getattr(self, '_new_empty', None)
+            if ne is None or ne[0] != device:  # bound new_empty of per-dtype prototypes: cheaper than torch.empty(dtype=, device=)
+                ne = self._new_empty = (device, torch.empty(0, dtype=torch.int32, device=device).new_empty,
+                                        torch.empty(0, dtype=torch.int64, device=device).new_empty)
+            neg = ne[1](n)
+            neg_time = ne[2](t_in.shape[0])
             if self._rng_seed is None:
                 self._rng_seed = (self._seed if self._seed is not None else torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
             self._calls += 1

@@ -248,6 +248,7 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
         st.directed, st.key_wrap32 = (1 if self._directed else 0), self._key_wrap32
         st.status = self._status.data_ptr()
         st.timed_hop = -1
+        self._new_empty = tuple(torch.empty(0, dtype=t, device=device).new_empty for t in (torch.int32, torch.int64, torch.float32))
         # the store is time-sorted and keeps a host copy of the timestamps: [0, last] bounds every batch of this graph
         # (lets the large-batch update sort only the key bits that can be set); unknown / negative times: no promise
         st.ts_bound = 0
@@ -328,8 +329,10 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
                     self._epoch_lo = ev_hi
                 st.ev_lo, st.ev_hi = self._epoch_lo, ev_hi
             # hop-0 seeds (fresh tensors owned by the batch, like the reference's torch.cat)
-            seeds = empty(S0, dtype=torch.int32, device=device)
-            seed_times = empty(S0, dtype=torch.int64, device=device)
+            # bound new_empty of per-dtype prototypes: ~0.5 us less per tensor than torch.empty(..., dtype=, device=)
+            ne32, ne64, nef = self._new_empty
+            seeds = ne32(S0)
+            seed_times = ne64(S0)
             for g, (a, t) in enumerate(zip(groups, group_times)):
                 if not a.is_contiguous():
                     a = a.contiguous()
@@ -344,9 +347,9 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
             out_seed_n, out_seed_t, out_n, out_t, out_x = [], [], [], [], []
             cur_n, cur_t, S = seeds, seed_times, S0
             for hop, k in enumerate(self._num_nbrs):
-                nid = empty((S, k), dtype=torch.int32, device=device)
-                nts = empty((S, k), dtype=torch.int64, device=device)
-                nx = empty((S, k, D), dtype=torch.float32, device=device)
+                nid = ne32((S, k))
+                nts = ne64((S, k))
+                nx = nef((S, k, D))
                 st.out_nid[hop], st.out_ts[hop], st.out_x[hop] = nid.data_ptr(), nts.data_ptr(), nx.data_ptr()
                 out_seed_n.append(cur_n)
                 out_seed_t.append(cur_t)
