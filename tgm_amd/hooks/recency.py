@@ -52,7 +52,8 @@ _NULL = _NullCtx()
 def _on_device(device: torch.device):
     """Device guard that costs nothing when ``device`` is already current."""
     idx = device.index
-    if idx is None or idx == torch.cuda.current_device():
+    cur = _native._cuda_get_device  # the C accessor: torch.cuda.current_device() walks through _lazy_init (~2 us)
+    if idx is None or idx == (cur() if cur is not None else torch.cuda.current_device()):
         return _NULL
     return torch.cuda.device(device)
 
