@@ -53,6 +53,9 @@ typedef struct tgmx_adj {
 } tgmx_adj_t;
 
 int tgmx_version(void);
+/* sizeof of the argument structs as this library was compiled (a binding checks its own mirror against it):
+ * 0 tgmx_adj_t, 1 tgmx_recency_step_t, 2 tgmx_tgat_layer_t, 3 tgmx_tgat_model_t, 4 tgmx_tgat_hop_t, 5 tgmx_tgat_layout_t */
+size_t tgmx_abi_sizeof(int32_t which);
 const char* tgmx_last_error(void);
 
 /* HIP timing events.  The lookup entry points accept an optional (ev_start,

@@ -65,3 +65,16 @@ def test_product_never_imports_the_oracle():
             if f.endswith('.py'):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), f'{f} imports oracle/'
+
+
+def test_struct_mirrors_have_the_library_s_sizes():
+    """The ctypes mirrors of the argument structs must match what the library was compiled with."""
+    import ctypes
+
+    from tgm_amd import _native
+
+    lib = _native.load()
+    mirrors = {1: _native.RecencyStep, 2: _native.TgatLayer, 3: _native.TgatModel, 4: _native.TgatHop, 5: _native.TgatLayout}
+    assert lib.tgmx_abi_sizeof(0) == 16
+    for which, cls in mirrors.items():
+        assert lib.tgmx_abi_sizeof(which) == ctypes.sizeof(cls), cls.__name__

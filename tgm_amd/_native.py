@@ -23,6 +23,7 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libtgm_amd.so')
 _P = c_void_p
 SIGNATURES = {
     'tgmx_version': (c_int32, []),
+    'tgmx_abi_sizeof': (c_size_t, [c_int32]),
     'tgmx_last_error': (c_char_p, []),
     'tgmx_event_create': (c_int32, [ctypes.POINTER(c_void_p)]),
     'tgmx_event_destroy': (c_int32, [_P]),

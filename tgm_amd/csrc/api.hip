@@ -16,6 +16,18 @@ void set_error(const char* fmt, ...) {
 }  // namespace tgmx
 
 extern "C" int tgmx_version(void) { return TGMX_ABI_VERSION; }
+
+extern "C" size_t tgmx_abi_sizeof(int32_t which) {
+  switch (which) {
+    case 0: return sizeof(tgmx_adj_t);
+    case 1: return sizeof(tgmx_recency_step_t);
+    case 2: return sizeof(tgmx_tgat_layer_t);
+    case 3: return sizeof(tgmx_tgat_model_t);
+    case 4: return sizeof(tgmx_tgat_hop_t);
+    case 5: return sizeof(tgmx_tgat_layout_t);
+    default: return 0;
+  }
+}
 extern "C" const char* tgmx_last_error(void) { return tgmx::g_err; }
 
 extern "C" int tgmx_event_create(tgmx_event_t* ev) {
