@@ -180,6 +180,17 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
         else:
             self._epoch_lo = None  # re-anchored at the next batch's first edge
 
+    def _refresh_ts_bound(self, dg: DGraph) -> None:
+        """The store is time-sorted and keeps a host copy of the timestamps: [0, last] bounds every batch of this graph
+        (lets the large-batch update sort only the key bits that can be set); unknown / negative times: no promise."""
+        store = dg._storage
+        self._bound_store = store
+        bound = 0
+        times = getattr(store, '_time_np', None)
+        if times is not None and len(times) and int(times[0]) >= 0:
+            bound = int(times[-1])
+        self._step.ts_bound = bound
+
     def fuses_first_hops(self) -> bool:
         """Did the last call run hop 0 and hop 1 as one launch?  (``tgmx_recency_step_plan`` on the argument block of
         that call; informational -- ``bench.py`` attributes the timed launch's bytes with it.)"""
@@ -250,13 +261,9 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
         st.status = self._status.data_ptr()
         st.timed_hop = -1
         self._new_empty = tuple(torch.empty(0, dtype=t, device=device).new_empty for t in (torch.int32, torch.int64, torch.float32))
-        # the store is time-sorted and keeps a host copy of the timestamps: [0, last] bounds every batch of this graph
-        # (lets the large-batch update sort only the key bits that can be set); unknown / negative times: no promise
-        st.ts_bound = 0
-        times = getattr(dg._storage, '_time_np', None)
-        if times is not None and len(times) and int(times[0]) >= 0:
-            st.ts_bound = int(times[-1])
         self._step = st
+        self._bound_store = None
+        self._refresh_ts_bound(dg)
 
     def _ensure_csr(self, dg: DGraph, batch: DGBatch) -> TemporalCSR:
         store = dg._storage
@@ -314,6 +321,8 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
         if len(groups) > _native.MAX_SEED_GROUPS or L > _native.MAX_HOPS:
             raise ValueError(f'at most {_native.MAX_SEED_GROUPS} seed groups and {_native.MAX_HOPS} hops are supported')
         self._ensure_state(dg, device)
+        if dg._storage is not self._bound_store:  # another graph: its timestamps may be larger
+            self._refresh_ts_bound(dg)
         D = self._edge_x_dim
         st = self._step
         lib = _native.load()
