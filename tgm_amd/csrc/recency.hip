@@ -19,7 +19,7 @@
 //   riders: update_chunk_sort, update_merge_riding, rider_barrier, update_side_work -- the state-independent half of
 //     the ring update as workgroup-sized pieces that ride inside the lookup launches
 //   lookup pieces (fetch_seed ... lookup_seed) and the kernels built from them: recency_lookup_kernel (one hop),
-//     recency_lookup_fused01_kernel (hop 0 + hop 1 in one launch), ring_lookup_packed_kernel (narrow rows)
+//     recency_lookup_fused01_kernel (hop 0 + hop 1 in one launch), lookup_packed_kernel (narrow rows)
 //   the stand-alone update paths (one workgroup / chunk sort + merge / rocPRIM radix sort), uniform sampler, C entry points
 #include <cstdlib>
 #include <cstring>
@@ -798,6 +798,41 @@ __device__ __forceinline__ void update_side_work(const UpdateArgs& u, int stage,
 }
 
 
+// wave_prefix_count for a GROUP of GL lanes (64 / GL groups per wave, each with its own [a, z)): GL probes per round.
+// The loop runs while ANY group of the wave still has more than GL candidates (finished groups idle through it).
+template <int GL>
+__device__ __forceinline__ long long group_prefix_count(const Rec* recs, long long a, long long z, long long bound, int gl, int sub) {
+  constexpr unsigned long long kMask = GL == 64 ? ~0ull : ((1ull << GL) - 1);
+  long long lo = a, hi = z;
+  while (__any(hi - lo > GL)) {
+    const bool busy = hi - lo > GL;
+    const long long len = hi - lo;
+    const long long stride = (len + GL - 1) / GL;
+    long long idx = lo + (long long)(gl + 1) * stride - 1;
+    if (idx > hi - 1) idx = hi - 1;
+    const bool less = busy && (long long)recs[idx].eid < bound;
+    const int c = __popcll((__ballot(less) >> (sub * GL)) & kMask);
+    if (busy) {
+      long long nlo = lo, nhi = hi;
+      if (c > 0) {
+        long long p = lo + (long long)c * stride - 1;
+        if (p > hi - 1) p = hi - 1;
+        nlo = p + 1;
+      }
+      if (c < GL) {
+        long long p = lo + (long long)(c + 1) * stride - 1;
+        if (p > hi - 1) p = hi - 1;
+        nhi = p;  // recs[p] is >= bound: the answer is <= p
+      }
+      lo = nlo;
+      hi = nhi < nlo ? nlo : nhi;
+    }
+  }
+  const long long idx = lo + gl;
+  const bool less = idx < hi && (long long)recs[idx].eid < bound;
+  return lo + __popcll((__ballot(less) >> (sub * GL)) & kMask) - a;
+}
+
 // ---- one seed's lookup, in pieces (shared by the per-hop kernel and the fused hop-0 + hop-1 kernel) -----------------
 // hop-0 seed s: from the seed groups (publishing the concatenated arrays when `publish`) or the plain arrays
 __device__ __forceinline__ void fetch_seed(const LookupArgs& a, long long s, int lane, bool publish, int& n, long long& q) {
@@ -1057,22 +1092,25 @@ __global__ __launch_bounds__(256) void recency_lookup_fused01_kernel(const Looku
   }
 }
 
-// Narrow feature rows (k * D small, e.g. D = 16): one wave per seed moves ~1 KB behind a three-deep chain of dependent
-// loads, so the launch is latency-bound.  The packed variant gives every seed a GROUP of GL lanes (B, k <= GL): 64 / GL
-// seeds per wave, the same ballot / shuffle logic inside the group's slice of the wave, 2-4x the loads in flight.
-// Streaming rings only (the static index's prefix search is wave-wide), plain seed arrays only.
-template <int VEC, int GL>
-__global__ __launch_bounds__(256) void ring_lookup_packed_kernel(const LookupArgs a, const UpdateArgs u) {
+// Narrow feature rows (k * D small, e.g. D = 16): one wave per seed moves ~1 KB behind a chain of dependent loads, so
+// the launch is latency-bound.  The packed variant gives every seed a GROUP of GL lanes (B, k <= GL): 64 / GL seeds per
+// wave, the same ballot / shuffle logic inside the group's slice of the wave, 2-4x the loads in flight.  Plain seed
+// arrays only (hops >= 1).  RING: streaming rings (and the riders of the ring update); else the static index, with
+// the batch-boundary prefix searches done per group.
+template <bool RING, int VEC, int GL>
+__global__ __launch_bounds__(256) void lookup_packed_kernel(const LookupArgs a, const UpdateArgs u) {
   using V = typename VecOf<VEC>::type;
   constexpr int kGroups = kWave / GL;
   extern __shared__ __attribute__((aligned(16))) int lds_eid_all[];
   unsigned bid = blockIdx.x, nblk = gridDim.x;
-  if (bid < a.side_blocks) {
-    update_side_work(u, a.side_stage, (int)bid);
-    return;
+  if constexpr (RING) {
+    if (bid < a.side_blocks) {
+      update_side_work(u, a.side_stage, (int)bid);
+      return;
+    }
+    bid -= a.side_blocks;
+    nblk -= a.side_blocks;
   }
-  bid -= a.side_blocks;
-  nblk -= a.side_blocks;
   const int lane = lane_id();
   const int sub = lane / GL, gl = lane - sub * GL;
   const int wave_in_block = threadIdx.x >> 6;
@@ -1092,8 +1130,20 @@ __global__ __launch_bounds__(256) void ring_lookup_packed_kernel(const LookupArg
       if (q < 0 && !a.allow_pad) st |= TGMX_ST_SEED_TIME;
       if (st) atomicOr(a.status, st);
     }
-    const long long w0 = (long long)(live ? n : 0) * B;
-    const int wrot = live ? a.write_pos[n] % B : 0;
+    // window of <= B records in time order: the ring row rotated by write_pos, or the last B visible index entries
+    long long w0 = 0;
+    int wrot = 0, wlen = 0;
+    if constexpr (RING) {
+      w0 = (long long)(live ? n : 0) * B;
+      wrot = live ? a.write_pos[n] % B : 0;
+      wlen = live ? B : 0;
+    } else {
+      const long long ra = live ? a.indptr[n] : 0, rz = live ? a.indptr[n + 1] : 0;
+      const long long p_hi = ra + group_prefix_count<GL>(a.recs, ra, rz, a.ev_hi, gl, sub);
+      const long long p_lo = a.ev_lo <= 0 ? ra : ra + group_prefix_count<GL>(a.recs, ra, rz, a.ev_lo, gl, sub);
+      w0 = p_hi - B > p_lo ? p_hi - B : p_lo;
+      wlen = (int)(p_hi - w0);
+    }
     auto slot_of = [&](int i) -> long long {
       int sl = wrot + i;
       if (sl >= B) sl -= B;
@@ -1101,26 +1151,27 @@ __global__ __launch_bounds__(256) void ring_lookup_packed_kernel(const LookupArg
     };
     Rec r;
     r.nbr = -1; r.eid = 0; r.ts = 0;
-    if (live && gl < B) r = a.recs[w0 + gl];  // slot order (no wait for write_pos), rotated into time order below
-    {
+    if (gl < wlen) r = a.recs[w0 + gl];  // RING: slot order (no wait for write_pos), rotated into time order below
+    if constexpr (RING) {
       int from_slot = wrot + gl;
       if (from_slot >= B) from_slot -= B;
       if (gl >= B) from_slot = gl;
       r.nbr = __shfl(r.nbr, sub * GL + from_slot);
       r.ts = __shfl(r.ts, sub * GL + from_slot);
     }
-    const bool ok = live && gl < B && r.nbr >= 0 && r.ts < q;
+    const bool ok = gl < wlen && r.nbr >= 0 && r.ts < q;
     const unsigned long long m = (__ballot(ok) >> (sub * GL)) & ((GL == 64) ? ~0ull : ((1ull << GL) - 1));
     const int cnt = m ? 64 - __clzll((long long)m) : 0;  // 1 + position of the rightmost valid entry, inside the group
     const int i = cnt - k + gl;
     const int from = i > 0 ? i : 0;
     const int g_nbr = __shfl(r.nbr, sub * GL + from);
+    const int g_eid = __shfl(r.eid, sub * GL + from);
     const long long g_ts = __shfl(r.ts, sub * GL + from);
     if (act && gl < k) {
       const bool has = i >= 0 && g_nbr >= 0;
       a.out_nid[s * k + gl] = has ? g_nbr : -1;
       a.out_ts[s * k + gl] = has ? g_ts : 0;
-      lds_eid[gl] = has ? (int)slot_of(from) : -1;
+      lds_eid[gl] = has ? (RING ? (int)slot_of(from) : g_eid) : -1;
     }
     if (a.D == 0) continue;
     __builtin_amdgcn_wave_barrier();
@@ -1195,7 +1246,7 @@ static int launch_lookup(LookupArgs a, hipStream_t stream, hipEvent_t ev_start, 
   hipLaunchKernelGGL((recency_lookup_kernel<RING, VEC_, SMALL_>), grid, block, lds, stream, a, u)
   if (ev_start) (void)hipEventRecord(ev_start, stream);
   // narrow rows: several seeds per wave (streaming rings, plain seed arrays)
-  const int gl = a.grp.groups == 0 ? packed_group_lanes(a, a.k, RING) : 64;
+  const int gl = a.grp.groups == 0 ? packed_group_lanes(a, a.k, true) : 64;
   if (gl < 64) {
     const int per_wave = 64 / gl;
     long long pblocks = ((a.S + per_wave - 1) / per_wave + waves_per_block - 1) / waves_per_block;
@@ -1204,8 +1255,8 @@ static int launch_lookup(LookupArgs a, hipStream_t stream, hipEvent_t ev_start, 
     const size_t plds = (size_t)waves_per_block * per_wave * a.k * sizeof(int);
 #define TGMX_PACKED(VEC_)                                                                              \
   do {                                                                                                 \
-    if (gl == 16) hipLaunchKernelGGL((ring_lookup_packed_kernel<VEC_, 16>), pgrid, block, plds, stream, a, u); \
-    else hipLaunchKernelGGL((ring_lookup_packed_kernel<VEC_, 32>), pgrid, block, plds, stream, a, u);          \
+    if (gl == 16) hipLaunchKernelGGL((lookup_packed_kernel<RING, VEC_, 16>), pgrid, block, plds, stream, a, u); \
+    else hipLaunchKernelGGL((lookup_packed_kernel<RING, VEC_, 32>), pgrid, block, plds, stream, a, u);          \
   } while (0)
     if (vec == 4) TGMX_PACKED(4);
     else if (vec == 2) TGMX_PACKED(2);
