@@ -107,7 +107,7 @@ class HookManager:
     # -- module requirement validation ----------------------------------------
     def validate_requirement(self, module: Any, key: Optional[str] = None) -> None:
         """Check that ``module.requires`` is covered by the hooks under ``key`` (or every key)."""
-        from ..nn.base import EncoderModule
+        from ..nn.base import EncoderModule, missing_attributes
 
         if not isinstance(module, EncoderModule):
             raise BadEncoderProtocolError(
@@ -116,7 +116,9 @@ class HookManager:
         if key is not None:
             self._check_key(key)
         for k in [key] if key is not None else list(self._key_to_hooks):
-            self._explain_missing(set(module.requires), self._key_to_hooks[k] + self._shared_hooks, k)
+            hooks = self._key_to_hooks[k] + self._shared_hooks
+            if missing_attributes(module, CORE_ATTRIBUTE.union(*(h.produces for h in hooks))):
+                self._explain_missing(set(module.requires), hooks, k)
 
     def _explain_missing(self, needed: Set[str], hooks: List[DGHook], key: str) -> None:
         available = CORE_ATTRIBUTE.union(*(h.produces for h in hooks))
