@@ -183,7 +183,7 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
     def _refresh_ts_bound(self, dg: DGraph) -> None:
         """The store is time-sorted and keeps a host copy of the timestamps: [0, last] bounds every batch of this graph
         (lets the large-batch update sort only the key bits that can be set); unknown / negative times: no promise."""
-        store = dg._storage
+        store = getattr(dg, '_storage', None)  # a foreign DGraph (the reference's) may keep its store elsewhere: no promise then
         self._bound_store = store
         bound = 0
         times = getattr(store, '_time_np', None)
@@ -321,7 +321,7 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
         if len(groups) > _native.MAX_SEED_GROUPS or L > _native.MAX_HOPS:
             raise ValueError(f'at most {_native.MAX_SEED_GROUPS} seed groups and {_native.MAX_HOPS} hops are supported')
         self._ensure_state(dg, device)
-        if dg._storage is not self._bound_store:  # another graph: its timestamps may be larger
+        if getattr(dg, '_storage', None) is not self._bound_store:  # another graph: its timestamps may be larger
             self._refresh_ts_bound(dg)
         D = self._edge_x_dim
         st = self._step
