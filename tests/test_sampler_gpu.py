@@ -443,6 +443,7 @@ def test_edge_cases_and_errors():
     assert out.nbr_nids[0].numel() == 0 and out.nbr_edge_x[0].shape == (0, 0)
 
 
+@pytest.mark.skipif(any(os.environ.get(k) for k in ('TGMX_NO_RIDE', 'TGMX_NO_FUSE')), reason='the A/B knob removes the barrier')
 def test_dirty_scratch_head_is_reported_not_hung():
     """The riders' barrier lives in the first 256 bytes of the update scratch, which must be zero at first use.  A
     dirty head must not hang the device: the barrier gives up after about a second and raises TGMX_ST_SCRATCH."""
