@@ -136,6 +136,27 @@ def pmc_traffic(args, grid_slots):
             'source': 'profiles/pmc_hop1.json (rocprofv3 --pmc, separate passes)'}
 
 
+def rocprof_kernel_us(fused: bool):
+    """Average duration of the dominant kernel in the committed rocprofv3 --kernel-trace --stats summary of this very
+    command (profiles/r01_sampler_rocprof_summary.md; tools/gpu_round.sh writes it) -- the cross-check of the HIP-event
+    figure (events bracket the launch from outside: ~2-3 us more than the kernel's own duration)."""
+    path = os.path.join(ROOT, 'profiles', 'r01_sampler_rocprof_summary.md')
+    if not os.path.exists(path):
+        return None
+    want = 'recency_lookup_fused01_kernel' if fused else 'recency_lookup_kernel'
+    best = None
+    for line in open(path):
+        cells = [c.strip() for c in line.split('|')]
+        if len(cells) > 5 and want in cells[1]:
+            try:
+                calls, avg = int(cells[2]), float(cells[4])
+            except ValueError:
+                continue
+            if best is None or calls > best[0]:
+                best = (calls, avg)
+    return None if best is None else best[1]
+
+
 def main():
     args = parse_args()
     from tgm_amd.dist import init_process_group
@@ -256,6 +277,7 @@ def main():
             'frac': achieved / HBM_PEAK_GBS,
             'traffic': pmc_traffic(args, total_slots),
             'avg_kernel_ms': avg_ms,
+            'rocprof_avg_kernel_us': rocprof_kernel_us(fused) if (args.workload == 'wiki' and args.mode == 'ring' and world == 1) else None,
             'launches_timed': len(ker_ms),
             'algorithmic_bytes_per_launch': algo_bytes,
             'valid_slot_fraction': valid / max(total_slots, 1),
