@@ -238,8 +238,8 @@ int tgmx_tgat_rres(const float* x, int64_t ldx, int32_t d, const float* tb, cons
                    int32_t T, int32_t O, int64_t R, float* out, int64_t ldo /* 0 = O; columns [O, ldo) zeroed */,
                    tgmx_stream_t stream);
 
-/* C[b] = act(A[b] (M x K, lda) * B[b]^T (B is N x K, ldb) + bias), b < batch with
- * element strides; exact-fp32 MFMA.  Replaces the nn.Linear calls of
+/* C[b] = act(A[b] (M x K, lda) * B[b]^T (B is N x K, ldb) + bias[b]), b < batch with
+ * element strides (bias: [batch, N], i.e. [N] when batch = 1); exact-fp32 MFMA.  Replaces the nn.Linear calls of
  * attention.py:96,125 and tgat.py:36-38 and the folded W_K / W_V contractions. */
 int tgmx_sgemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
                   int64_t M, int32_t N, int32_t K, const float* bias, int32_t relu, int32_t batch,

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void sgemm_nt_kernel(const GemmArgs g) {
       const long long row = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
       const int col = n0 + t * 32 + i;
       if (row < g.M && col < g.N) {
-        if (g.bias) v += g.bias[col];
+        if (g.bias) v += g.bias[(long long)blockIdx.z * g.N + col];  // batch b adds row b of a [batch, N] bias
         if (g.relu) v = v > 0.f ? v : 0.f;
         C[row * g.ldc + col] = v;
       }
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void sgemm_nt_kernel(const GemmArgs g) {
       const int col = n0 + t * 32 + i;
       if (col < g.N) {
         float v = t ? acc1[r] : acc0[r];
-        if (g.bias) v += g.bias[col];
+        if (g.bias) v += g.bias[(long long)blockIdx.z * g.N + col];  // batch b adds row b of a [batch, N] bias
         if (g.relu) v = v > 0.f ? v : 0.f;
         C[row * g.ldc + col] = v;
       }

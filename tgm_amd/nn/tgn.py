@@ -298,6 +298,18 @@ class TransformerConv(nn.Module):
         self.lin_edge = nn.Linear(edge_dim, hc, bias=False)
         self.lin_skip = nn.Linear(in_channels, hc, bias=True)
 
+    def _stacked_projections(self) -> Tuple[Tensor, Tensor]:
+        """[4, HC, in] weights and [4, HC] biases of lin_query / lin_key / lin_value / lin_skip, rebuilt only when a
+        parameter was reallocated or modified in place (optimizer step, load_state_dict)."""
+        lins = (self.lin_query, self.lin_key, self.lin_value, self.lin_skip)
+        key = tuple((p.data_ptr(), p._version) for lin in lins for p in (lin.weight, lin.bias))
+        cached = getattr(self, '_stacked', None)
+        if cached is None or cached[0] != key:
+            W4 = torch.stack([lin.weight.detach().float() for lin in lins]).contiguous()
+            b4 = torch.stack([lin.bias.detach().float() for lin in lins]).contiguous()
+            cached = self._stacked = (key, W4, b4)
+        return cached[1], cached[2]
+
     def forward(self, x: Tensor, edge_index: Tensor, edge_attr: Tensor) -> Tensor:
         if self.training and self.dropout > 0:
             raise NotImplementedError('tgm_amd TransformerConv: attention dropout / backward not implemented; call .eval()')
@@ -308,11 +320,11 @@ class TransformerConv(nn.Module):
         dev, U, H, C = x.device, x.shape[0], self.heads, self.out_channels
         HC = H * C
         f32 = dict(dtype=torch.float32, device=dev)
-        q, k, v, out = (torch.empty((U, HC), **f32) for _ in range(4))
-        _ops.sgemm_nt(x, self.lin_query.weight.detach(), q, bias=self.lin_query.bias.detach())
-        _ops.sgemm_nt(x, self.lin_key.weight.detach(), k, bias=self.lin_key.bias.detach())
-        _ops.sgemm_nt(x, self.lin_value.weight.detach(), v, bias=self.lin_value.bias.detach())
-        _ops.sgemm_nt(x, self.lin_skip.weight.detach(), out, bias=self.lin_skip.bias.detach())
+        # query / key / value / skip projections of the same x: ONE batched launch over the stacked weights
+        W4, b4 = self._stacked_projections()
+        qkvs = torch.empty((4, U, HC), **f32)
+        _ops.sgemm_nt(x, W4[0], qkvs[0], bias=b4, batch=4, sA=0, sB=W4.stride(0), sC=U * HC)
+        q, k, v, out = qkvs[0], qkvs[1], qkvs[2], qkvs[3]
         E = edge_index.shape[1]
         if E:
             eproj = torch.empty((E, HC), **f32)
