@@ -402,6 +402,14 @@ int tgmx_tconv_edge_attr(const int64_t* last_update_local, const int64_t* src, c
                          const float* msg, const float* tw, const float* tb, int32_t T, int32_t D,
                          int64_t E, float* out, tgmx_stream_t stream);
 
+/* Group n items by key[i] in [0, num_keys): order[] = the item ids stably sorted by key (what
+ * argsort(stable=True) gives), seg_lo[k] / seg_hi[k] = the range of order[] holding key k.  Used for the incoming-edge
+ * segments of TransformerConv (PyG scatter-softmax over edge_index[1]); replaces torch.sort + 2 x searchsorted.
+ * Keys outside the range raise TGMX_ST_EDGE_RANGE in *status (and are clamped). */
+size_t tgmx_segment_sort_workspace_bytes(int64_t n);
+int tgmx_segment_sort(const int64_t* key, int64_t n, int32_t num_keys, int64_t* order, int64_t* seg_lo, int64_t* seg_hi,
+                      void* workspace, size_t workspace_bytes, int32_t* status, tgmx_stream_t stream);
+
 /* TransformerConv attention (third-party definition, PyG 2.6.1): for every target i,
  * out[i] += sum_j softmax_j(q_i.(k_j + e_ij)/sqrt(C)) (v_j + e_ij) per head; edges of target i are
  * order[seg_lo[i] .. seg_hi[i]) (edge ids sorted by target), src[e] = source j. */

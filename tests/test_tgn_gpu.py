@@ -95,3 +95,18 @@ def test_graph_attention_embedding_matches_restatement():
     ref = graph_attention_embedding_ref({k: v.cpu() for k, v in enc.state_dict().items()}, x, last_update, edge_index, t, msg)
     assert out.shape == (U, emb)
     close(out.cpu(), ref, 'graph attention embedding')
+
+
+@pytest.mark.parametrize('U,E', [(1, 1), (5, 0), (300, 40), (7000, 15000), (40_000, 3)])
+def test_segment_sort_matches_stable_argsort(U, E):
+    """``tgmx_segment_sort`` (TransformerConv's incoming-edge grouping) == torch's stable argsort + searchsorted bounds."""
+    from tgm_amd.nn.tgn import TransformerConv
+
+    conv = TransformerConv(8, 4, heads=1, dropout=0.0, edge_dim=2).to(DEV).eval()
+    g = torch.Generator().manual_seed(U + E)
+    tgt = torch.randint(0, U, (E,), generator=g).to(DEV)
+    order, lo, hi = conv._incoming_segments(tgt, U)
+    srt, ref_order = torch.sort(tgt, stable=True)
+    ids = torch.arange(U, device=DEV)
+    assert torch.equal(order, ref_order)
+    assert torch.equal(lo, torch.searchsorted(srt, ids, right=False)) and torch.equal(hi, torch.searchsorted(srt, ids, right=True))

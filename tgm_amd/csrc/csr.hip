@@ -195,3 +195,102 @@ extern "C" int tgmx_csr_build(const int32_t* src, const int32_t* dst, const int6
   TGMX_CHECK_LAUNCH("csr_build");
   return TGMX_OK;
 }
+
+// ---------------------------------------------------------------------------
+// Group edges by a small integer key (TransformerConv: incoming edges per target node).  The reference stack gets
+// there with a stable 64-bit argsort plus two searchsorted calls (~10 launches); here: iota, ONE stable LSD radix sort
+// over the ceil(log2 num_keys) bits that can be set, and a binary search per key for the segment bounds.
+// ---------------------------------------------------------------------------
+namespace tgmx {
+
+__global__ __launch_bounds__(256) void segsort_keys_kernel(const int64_t* __restrict__ key, long long n, int num_keys,
+                                                           unsigned int* __restrict__ k32, int64_t* __restrict__ iota,
+                                                           int32_t* status) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const long long k = key[i];
+  if (k < 0 || k >= num_keys) atomicOr(status, TGMX_ST_EDGE_RANGE);
+  k32[i] = (unsigned int)(k < 0 ? 0 : (k >= num_keys ? num_keys - 1 : k));
+  iota[i] = i;
+}
+
+__global__ __launch_bounds__(256) void segsort_bounds_kernel(const unsigned int* __restrict__ sorted, long long n, int num_keys,
+                                                             int64_t* __restrict__ seg_lo, int64_t* __restrict__ seg_hi) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= num_keys) return;
+  auto lower = [&](unsigned int v) {  // first position with sorted[p] >= v
+    long long lo = 0, hi = n;
+    while (lo < hi) {
+      const long long mid = (lo + hi) >> 1;
+      if (sorted[mid] < v) lo = mid + 1;
+      else hi = mid;
+    }
+    return lo;
+  };
+  seg_lo[k] = lower((unsigned int)k);
+  seg_hi[k] = lower((unsigned int)k + 1u);
+}
+
+struct SegSortLayout {
+  size_t k_in, k_out, v_in, temp, temp_bytes, total;
+};
+static int segsort_layout(long long n, SegSortLayout& w) {
+  auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  size_t off = 0;
+  w.k_in = off; off = up(off + (size_t)n * 4);
+  w.k_out = off; off = up(off + (size_t)n * 4);
+  w.v_in = off; off = up(off + (size_t)n * 8);
+  size_t tb = 0;
+  if (rocprim::radix_sort_pairs(nullptr, tb, (const unsigned int*)nullptr, (unsigned int*)nullptr, (const int64_t*)nullptr,
+                                (int64_t*)nullptr, (size_t)n, 0u, 32u) != hipSuccess)
+    return TGMX_E_LAUNCH;
+  w.temp = off; w.temp_bytes = tb; off = up(off + tb);
+  w.total = off + 256;
+  return TGMX_OK;
+}
+
+}  // namespace tgmx
+
+extern "C" size_t tgmx_segment_sort_workspace_bytes(int64_t n) {
+  tgmx::SegSortLayout w;
+  if (n <= 0) return 256;
+  return tgmx::segsort_layout(n, w) == TGMX_OK ? w.total : 0;
+}
+
+extern "C" int tgmx_segment_sort(const int64_t* key, int64_t n, int32_t num_keys, int64_t* order, int64_t* seg_lo, int64_t* seg_hi,
+                                 void* workspace, size_t workspace_bytes, int32_t* status, tgmx_stream_t stream) {
+  using namespace tgmx;
+  TGMX_REQUIRE(n >= 0 && num_keys > 0, "segment_sort: bad sizes n=%lld num_keys=%d", (long long)n, num_keys);
+  TGMX_REQUIRE(seg_lo && seg_hi && status, "segment_sort: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  if (n == 0) {
+    (void)hipMemsetAsync(seg_lo, 0, (size_t)num_keys * 8, st);
+    (void)hipMemsetAsync(seg_hi, 0, (size_t)num_keys * 8, st);
+    return TGMX_OK;
+  }
+  TGMX_REQUIRE(key && order && workspace, "segment_sort: null pointer");
+  SegSortLayout w;
+  if (segsort_layout(n, w) != TGMX_OK || workspace_bytes < w.total) {
+    set_error("segment_sort: workspace too small (%zu bytes)", workspace_bytes);
+    return TGMX_E_INVALID;
+  }
+  char* base = reinterpret_cast<char*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  auto* k_in = reinterpret_cast<unsigned int*>(base + w.k_in);
+  auto* k_out = reinterpret_cast<unsigned int*>(base + w.k_out);
+  auto* v_in = reinterpret_cast<int64_t*>(base + w.v_in);
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(segsort_keys_kernel, dim3(blocks), dim3(256), 0, st, key, (long long)n, num_keys, k_in, v_in, status);
+  unsigned bits = 1;
+  while ((1ll << bits) < num_keys) ++bits;
+  size_t tb = w.temp_bytes;
+  if (rocprim::radix_sort_pairs(base + w.temp, tb, (const unsigned int*)k_in, k_out, (const int64_t*)v_in, order, (size_t)n,
+                                0u, bits, st) != hipSuccess) {
+    set_error("segment_sort: radix sort failed");
+    return TGMX_E_LAUNCH;
+  }
+  hipLaunchKernelGGL(segsort_bounds_kernel, dim3((unsigned)((num_keys + 255) / 256)), dim3(256), 0, st, k_out, (long long)n, num_keys,
+                     seg_lo, seg_hi);
+  TGMX_CHECK_LAUNCH("segment_sort");
+  return TGMX_OK;
+}
+

@@ -298,6 +298,24 @@ class TransformerConv(nn.Module):
         self.lin_edge = nn.Linear(edge_dim, hc, bias=False)
         self.lin_skip = nn.Linear(in_channels, hc, bias=True)
 
+    def _incoming_segments(self, tgt: Tensor, U: int) -> Tuple[Tensor, Tensor, Tensor]:
+        """Edge ids stably grouped by target node and every node's [lo, hi) range in that order (one bounded-bit radix
+        sort + a binary search per node: ``tgmx_segment_sort``; the stack it replaces was a 64-bit stable argsort and two
+        ``searchsorted`` calls).  Targets outside [0, U) are clamped and flagged in a device status word (no host sync)."""
+        lib = _native.load()
+        dev, E = tgt.device, tgt.numel()
+        if tgt.dtype != torch.int64:
+            tgt = tgt.long()
+        need = int(lib.tgmx_segment_sort_workspace_bytes(E))
+        ws = getattr(self, '_seg_ws', None)
+        if ws is None or ws[0].device != dev or ws[0].numel() < need:
+            ws = self._seg_ws = (torch.empty(need, dtype=torch.uint8, device=dev), torch.zeros(1, dtype=torch.int32, device=dev))
+        order = torch.empty(E, dtype=torch.int64, device=dev)
+        seg = torch.empty((2, U), dtype=torch.int64, device=dev)
+        _native.check(lib.tgmx_segment_sort(tgt.data_ptr(), E, U, order.data_ptr(), seg[0].data_ptr(), seg[1].data_ptr(), ws[0].data_ptr(),
+                                            ws[0].numel(), ws[1].data_ptr(), _native.stream_ptr()), 'tgmx_segment_sort')  # fmt: skip
+        return order, seg[0], seg[1]
+
     def _stacked_projections(self) -> Tuple[Tensor, Tensor]:
         """[4, HC, in] weights and [4, HC] biases of lin_query / lin_key / lin_value / lin_skip, rebuilt only when a
         parameter was reallocated or modified in place (optimizer step, load_state_dict)."""
@@ -330,10 +348,7 @@ class TransformerConv(nn.Module):
             eproj = torch.empty((E, HC), **f32)
             _ops.sgemm_nt(_ops._f32c(edge_attr, 'edge_attr'), self.lin_edge.weight.detach(), eproj)
             src, tgt = edge_index[0].contiguous(), edge_index[1].contiguous()  # flow: source_to_target
-            tgt_sorted, order = torch.sort(tgt, stable=True)
-            ids = torch.arange(U, device=dev, dtype=tgt.dtype)
-            seg_lo = torch.searchsorted(tgt_sorted, ids, right=False)
-            seg_hi = torch.searchsorted(tgt_sorted, ids, right=True)
+            order, seg_lo, seg_hi = self._incoming_segments(tgt, U)
             _native.check(
                 lib.tgmx_tconv_attend(q.data_ptr(), k.data_ptr(), v.data_ptr(), eproj.data_ptr(), order.data_ptr(), src.data_ptr(),
                                       seg_lo.data_ptr(), seg_hi.data_ptr(), U, H, C, float(C) ** -0.5, out.data_ptr(), _native.stream_ptr()),
@@ -359,10 +374,7 @@ def _tconv_forward_train(self, x: Tensor, edge_index: Tensor, edge_attr: Tensor)
         return skip
     eproj = LinearFn.apply(edge_attr.float().contiguous(), self.lin_edge.weight, None)
     src, tgt = edge_index[0].contiguous(), edge_index[1].contiguous()
-    tgt_sorted, order = torch.sort(tgt, stable=True)
-    ids = torch.arange(U, device=dev, dtype=tgt.dtype)
-    seg_lo = torch.searchsorted(tgt_sorted, ids, right=False)
-    seg_hi = torch.searchsorted(tgt_sorted, ids, right=True)
+    order, seg_lo, seg_hi = self._incoming_segments(tgt, U)
     return TconvAttendFn.apply(q, k, v, eproj, skip, order, src, seg_lo, seg_hi, H, C)
 
 
