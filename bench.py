@@ -263,7 +263,8 @@ def main():
         'data': 'synthetic',
         'config': {
             'workload': f'tgbl-{args.workload}-shaped synthetic stream: N={stream.num_nodes}, E={stream.num_edges}, D={D}; '
-            f'seeds = src|dst|neg, num_nbrs={num_nbrs}, batch_size={bs_rank} edges per rank ({bs_rank * world} global), mode={args.mode}',
+            f'seeds = src|dst|neg, num_nbrs={num_nbrs}, batch_size={bs_rank} edges per rank ({bs_rank * world} global), mode={args.mode}, '
+            "seed validation on the device, read back once after the timed steps (validate='deferred')",
             'slots_per_step_per_rank': slots_per_step,
             'events_per_s': args.steps * bs_rank * world / elapsed,
             'parallelism': f'edge-batch sharding x{world}, replicated stream, no data-path collective',
