@@ -9,11 +9,19 @@ resident COO store, draw negatives, sample 2 hops for [src | dst | neg] seeds
 (hand-written HIP lookup kernels), append the batch to the per-node rings.  All
 inputs are resident in HBM before the timed region.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling -- the
-global batch is N x 200 edges; every rank holds a replica of the stream, samples
-for its own contiguous 200-edge slice and applies the whole batch's (tiny) ring
-update.  No collective on the data path; barrier + device sync bracket the timed
-region and the reported time is the max over ranks.
+N > 1 (launched by torch.distributed.run, one rank per GPU): edge-batch sharding.
+``--scaling weak`` (default): the global batch is N x 200 edges; ``--scaling strong``:
+the global batch stays at the single-GPU size and rank r seeds from edges
+[r * bs / N, (r + 1) * bs / N) of it.  Either way every rank
+holds a replica of the stream and applies the whole batch's (tiny) ring update.
+No collective on the data path; barrier + device sync bracket the timed region and
+the reported time is the max over ranks.
+
+Steady state: before the warm-up the stream is replayed UNTIMED up to ``--start-frac``
+(default half) of its batches, so the timed steps run on filled rings (a fresh stream
+would be measured on almost-empty rings: nearly all-pad output).  If the timed steps
+reach the end of the stream the state is reset and the stream restarts (an epoch
+boundary); the default step count stops before that.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra
 objects: "roofline" (dominant kernel = the hop-1 lookup/gather launch, timed with
@@ -41,13 +49,18 @@ HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); ~6300 GB/s achievabl
 def parse_args():
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
-    p.add_argument('--steps', type=int, default=2364)  # three passes over the 157 474-edge stream at bs=200 (788 batches each)
-    p.add_argument('--warmup', type=int, default=100)
+    p.add_argument('--steps', type=int, default=None, help='timed batches (default: up to the end of the stream from --start-frac, at most 2000)')
+    p.add_argument('--warmup', type=int, default=20)
     p.add_argument('--workload', default='wiki', choices=['wiki', 'review', 'comment'])
     p.add_argument('--batch-size', type=int, default=None, help='edges per rank per step (default: 200 wiki, 512 review, 4096 comment)')
     p.add_argument('--num-nbrs', type=int, nargs='+', default=None)
     p.add_argument('--mode', default='ring', choices=['ring', 'csr'])
-    p.add_argument('--cpu-batches', type=int, default=100, help='batches of the CPU-baseline sample (0 = skip); ~0.25 s each on the GPU box host')
+    p.add_argument('--cpu-batches', type=int, default=8, help='batches of the CPU-baseline sample PER thread setting (0 = skip); ~0.1-0.3 s each')
+    p.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
+    p.add_argument('--pool', type=int, default=4, help='DGDataLoader(output_pool=): ring of preallocated output sets, one native call per batch; '
+                   '0 = hook-by-hook path with fresh tensors per batch (the reference-semantics default of the library)')
+    p.add_argument('--validate', default='deferred', choices=['deferred', 'sync', 'off'], help="seed validation mode of the hook ('sync' = its default: a device->host read per batch)")
+    p.add_argument('--start-frac', type=float, default=0.5, help='fraction of the stream replayed untimed before the warm-up (ring fill)')
     p.add_argument('--profile-every', type=int, default=32, help='bracket the dominant kernel with HIP events every n-th step')
     p.add_argument('--seed', type=int, default=1337)
     return p.parse_args()
@@ -56,14 +69,13 @@ def parse_args():
 DEFAULTS = {'wiki': (200, [20, 20]), 'review': (512, [10, 10]), 'comment': (4096, [20, 20])}
 
 
-def build_pipeline(stream, rank, world, bs_rank, num_nbrs, mode, device):
+def build_pipeline(stream, rank, world, global_bs, num_nbrs, mode, device, pool=0, validate='deferred'):
     from tgm_amd import DGData, DGDataLoader, DGraph
     from tgm_amd.dist import EdgeShardHook
     from tgm_amd.hooks import HookManager, RandomNegativeEdgeSamplerHook, RecencyNeighborHook
 
     data = DGData.from_raw(stream.ts, torch.stack([stream.src, stream.dst], 1), stream.edge_x, static_node_x=stream.node_x)
     dg = DGraph(data, device=device)
-    global_bs = bs_rank * world
     hm = HookManager(keys=['bench'])
     lo_dst = int(stream.dst.min())
     if world > 1:
@@ -74,15 +86,17 @@ def build_pipeline(stream, rank, world, bs_rank, num_nbrs, mode, device):
         keys, tkeys = ['edge_src', 'edge_dst', 'neg'], ['edge_time', 'edge_time', 'neg_time']
         hm.register('bench', RandomNegativeEdgeSamplerHook(lo_dst, stream.num_nodes))
     hook = RecencyNeighborHook(
-        stream.num_nodes, num_nbrs, keys, tkeys, mode=mode, validate='deferred', batch_size=global_bs if mode == 'csr' else None
+        stream.num_nodes, num_nbrs, keys, tkeys, mode=mode, validate=validate, batch_size=global_bs if mode == 'csr' else None
     )
     hm.register('bench', hook)
-    loader = DGDataLoader(dg, batch_size=global_bs, hook_manager=hm)
+    loader = DGDataLoader(dg, batch_size=global_bs, hook_manager=hm, output_pool=pool if validate != 'sync' else 0)
     return dg, hm, hook, loader
 
 
-def cpu_baseline(stream, bs, num_nbrs, n_batches, seed):
-    """Reference algorithm (torch-CPU tensor program, oracle/ring_port.py) on the host cores."""
+def cpu_baseline(stream, bs, num_nbrs, n_batches, seed, first_batch):
+    """Reference algorithm (torch-CPU tensor program, oracle/ring_port.py) on the host cores: the same region of the same
+    stream as the timed GPU steps (the rings are brought there with update-only calls, untimed), best of a few thread counts
+    (small tensor ops oversubscribe a 128-core host: all cores is rarely the fastest)."""
     from oracle.ring_port import RingSamplerCPU
 
     src, dst, ts, x = stream.src.cpu(), stream.dst.cpu(), stream.ts.cpu(), None if stream.edge_x is None else stream.edge_x.cpu()
@@ -91,31 +105,49 @@ def cpu_baseline(stream, bs, num_nbrs, n_batches, seed):
     g = torch.Generator().manual_seed(seed)
     lo_dst = int(dst.min())
     E = src.numel()
-    slots = 0
-    t_total = 0.0
-    done = 0
-    for b in range(n_batches + 1):
+    all_threads = torch.get_num_threads()
+    for b in range(max(0, first_batch - 400), first_batch):  # fill the rings: update only (the 400 batches before the sample)
         lo, hi = b * bs, min((b + 1) * bs, E)
-        if lo >= E:
-            break
-        neg = torch.randint(lo_dst, stream.num_nodes, (hi - lo,), dtype=torch.int32, generator=g)
-        seeds = torch.cat([src[lo:hi], dst[lo:hi], neg])
-        times = torch.cat([ts[lo:hi]] * 3)
-        t0 = time.perf_counter()
-        hops = model.step(seeds, times, src[lo:hi], dst[lo:hi], ts[lo:hi], None if x is None else x[lo:hi])
-        dt = time.perf_counter() - t0
-        if b == 0:
-            continue  # first batch warms the allocator
-        t_total += dt
-        slots += sum(h[2].numel() for h in hops)
-        done += 1
+        model.update(src[lo:hi], dst[lo:hi], ts[lo:hi], None if x is None else x[lo:hi])
+    b = first_batch
+    results = {}
+    t_all = 0.0
+    try:
+        for threads in sorted({t for t in (8, 16, 32, all_threads) if t <= all_threads}):
+            torch.set_num_threads(threads)
+            slots, t_total, done = 0, 0.0, 0
+            for i in range(n_batches + 1):
+                lo, hi = b * bs, min((b + 1) * bs, E)
+                if lo >= E:
+                    break
+                b += 1
+                neg = torch.randint(lo_dst, stream.num_nodes, (hi - lo,), dtype=torch.int32, generator=g)
+                seeds = torch.cat([src[lo:hi], dst[lo:hi], neg])
+                times = torch.cat([ts[lo:hi]] * 3)
+                t0 = time.perf_counter()
+                hops = model.step(seeds, times, src[lo:hi], dst[lo:hi], ts[lo:hi], None if x is None else x[lo:hi])
+                dt = time.perf_counter() - t0
+                if i == 0:
+                    continue  # first batch at this thread count warms the pool / allocator
+                t_total += dt
+                slots += sum(h[2].numel() for h in hops)
+                done += 1
+            if done:
+                results[threads] = (slots / t_total, 1e3 * t_total / done, done)
+                t_all += t_total
+    finally:
+        torch.set_num_threads(all_threads)
+    best = max(results, key=lambda t: results[t][0])
     return dict(
-        value=slots / t_total,
+        value=results[best][0],
         unit='sampled-edges/s',
-        cores=torch.get_num_threads(),
+        cores=best,
         kind='port',
-        sample=f'batches 1..{done} of the same stream (bs={bs}, k={num_nbrs}), sampler stage only, {t_total:.1f} s',
-        ms_per_step=1e3 * t_total / max(done, 1),
+        sample=f'{results[best][2]} batches per thread setting from batch {first_batch} of the same stream (bs={bs}, k={num_nbrs}, rings filled by '
+        f'the preceding batches), sampler stage only, {t_all:.1f} s of timed CPU work in total; best of threads={sorted(results)}',
+        ms_per_step=results[best][1],
+        by_threads={str(t): {'sampled_edges_per_s': v[0], 'ms_per_step': v[1]} for t, v in results.items()},
+        host_cores=os.cpu_count(),
     )
 
 
@@ -138,10 +170,10 @@ def pmc_traffic(args, grid_slots):
 
 def rocprof_kernel_us(fused: bool):
     """Average duration of the dominant kernel in the committed rocprofv3 --kernel-trace --stats summary of this very
-    command (profiles/r01_sampler_rocprof_summary.md; tools/gpu_round.sh writes it) -- the cross-check of the HIP-event
+    command (profiles/rNN_sampler_rocprof_summary.md, latest round; tools/gpu_round.sh writes it) -- the cross-check of the HIP-event
     figure (events bracket the launch from outside: ~2-3 us more than the kernel's own duration)."""
-    path = os.path.join(ROOT, 'profiles', 'r01_sampler_rocprof_summary.md')
-    if not os.path.exists(path):
+    path = next((p for p in (os.path.join(ROOT, 'profiles', f'r{r:02d}_sampler_rocprof_summary.md') for r in (2, 1)) if os.path.exists(p)), None)
+    if path is None:
         return None
     want = 'recency_lookup_fused01_kernel' if fused else 'recency_lookup_kernel'
     best = None
@@ -170,53 +202,70 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
 
-    bs_rank, num_nbrs = DEFAULTS[args.workload]
-    bs_rank = args.batch_size or bs_rank
+    bs, num_nbrs = DEFAULTS[args.workload]
+    bs = args.batch_size or bs
     num_nbrs = args.num_nbrs or num_nbrs
+    # weak: every rank seeds from bs edges of a (world x bs)-edge global batch; strong: the global batch stays bs edges
+    global_bs = bs * world if args.scaling == 'weak' else bs
+    lo_r, hi_r = (global_bs * rank) // world, (global_bs * (rank + 1)) // world
+    bs_rank = hi_r - lo_r  # this rank's seeds edges per full batch
     # small shapes are generated on the host (bit-stable stream shared with the fixtures), big ones on the device
     gen_dev = 'cpu' if args.workload == 'wiki' else device
     stream = make_stream(args.workload, seed=args.seed, device=gen_dev)
-    dg, hm, hook, loader = build_pipeline(stream, rank, world, bs_rank, num_nbrs, args.mode, device)
+    dg, hm, hook, loader = build_pipeline(stream, rank, world, global_bs, num_nbrs, args.mode, device, pool=args.pool, validate=args.validate)
     D = stream.edge_dim
     n_batches = len(loader)
-    S0 = 3 * bs_rank
-    slots_per_step = 0
-    S = S0
-    for k in num_nbrs:
-        slots_per_step += S * k
-        S *= k
     last_hop = len(num_nbrs) - 1
 
-    def run(n_steps, start):
+    def slots_of(edges):
+        total, S = 0, 3 * edges
+        for k in num_nbrs:
+            total += S * k
+            S *= k
+        return total
+
+    # ---- schedule: [0, first) untimed ring fill, then the warm-up, then the timed steps -----------------
+    first_timed = min(max(int(args.start_frac * n_batches), args.warmup), n_batches - 1)
+    steps = args.steps if args.steps is not None else max(1, min(2000, n_batches - 1 - first_timed))  # stop before the ragged last batch
+    fill = first_timed - args.warmup
+    starts = loader._starts
+    state = {'it': 0, 'edges': 0}
+
+    def run(n_steps, count=False):
         """n_steps consecutive batches, wrapping around the stream (epoch boundary = reset_state)."""
-        it = start
-        starts = loader._starts
+        it = state['it']
+        edges = 0
         for _ in range(n_steps):
             if it == n_batches:
                 hm.reset_state()
                 it = 0
             loader(starts[it])
+            if count:
+                e_lo = starts[it]
+                edges += min(global_bs, stream.num_edges - e_lo)
             it += 1
-        return it
+        state['it'] = it
+        return edges
 
     with hm.activate('bench'):
         from tgm_amd._native import KernelTimer
 
-        every = max(1, args.profile_every)
+        run(fill)  # untimed: brings the rings to their state at `first_timed - warmup`
+        every = max(1, min(args.profile_every, steps // 4))  # at least four timed launches, however short the run
         # the warm-up runs with the same instrumentation as the timed steps (first-use costs of the counting ops land there)
         warm_every = max(1, min(every, args.warmup // 2))  # at least two instrumented warm-up steps
         hook.profile_hop, hook.profile_every, hook.profile_log = last_hop, warm_every, []
         hook.profile_pool = [KernelTimer() for _ in range(args.warmup // warm_every + 1)]
-        pos = run(args.warmup, 0)
+        run(args.warmup)
         hook.check()
-        hook.profile_every, hook.profile_log = every, []
+        hook.profile_every, hook.profile_log, hook._calls = every, [], 0
         # at most 48 timed launches: ~100 HIP events awaiting their timestamps is where the runtime starts to stall
-        hook.profile_pool = [KernelTimer() for _ in range(min(48, args.steps // every + 1))]
+        hook.profile_pool = [KernelTimer() for _ in range(min(48, steps // every + 1))]
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        run(args.steps, pos)
+        run(steps)
         torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
@@ -228,46 +277,65 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # units actually processed by the timed steps (the ragged last batch of an epoch is smaller), all ranks together
+    total_units, total_events, it = 0, 0, first_timed
+    for _ in range(steps):
+        if it == n_batches:
+            it = 0
+        n_e = min(global_bs, stream.num_edges - starts[it])
+        total_events += n_e
+        for r in range(world):
+            total_units += slots_of((n_e * (r + 1)) // world - (n_e * r) // world)
+        it += 1
+
     # ---- roofline of the dominant kernel (last hop's lookup + gather launch) -----------
     log = hook.profile_log
     hook.profile_hop = None
+    if not log:
+        raise SystemExit('bench.py: no launch of the dominant kernel was timed (steps too small for --profile-every?)')
     ker_ms = [t.elapsed_ms() for t, *_ in log]
-    avg_ms = sum(ker_ms) / max(len(ker_ms), 1)
-    # the timed launch covers one hop, or hop 0 + hop 1 when tgmx_recency_step runs them as one launch
-    shape = log[0][1] if log else []
-    seeds_l = sum(seeds for seeds, _ in shape)
-    total_slots = sum(seeds * k for seeds, k in shape)
-    valid = sum(int(counts.sum().item()) for *_, counts in log) / max(len(log), 1)
-    # algorithmic bytes per launch: every slot is written (id 4 + ts 8 + 4D),
-    # valid slots also read their 16-byte record and 4D-byte feature row; 68 B of index traffic per seed
+    avg_ms = sum(ker_ms) / len(ker_ms)
+    # the timed launch covers one hop, or hop 0 + hop 1 when tgmx_recency_step runs them as one launch; average the
+    # per-launch figures over the timed launches (shapes only differ for the ragged last batch of an epoch)
+    seeds_l = sum(sum(seeds for seeds, _ in shape) for _, shape, _ in log) / len(log)
+    total_slots = sum(sum(seeds * k for seeds, k in shape) for _, shape, _ in log) / len(log)
+    valid = sum(int(counts.sum().item()) for *_, counts in log) / len(log)
+    # algorithmic bytes per launch, VALID-AWARE: every slot is written (id 4 + ts 8 + 4D); only
+    # valid slots read their 16-byte record and 4D-byte feature row (pads are written as zeros without reading anything --
+    # charging SURVEY 8(d)'s 28 + 8D per slot to pad slots too would report more than the HBM peak); 68 B of index traffic per seed
     algo_bytes = total_slots * (12 + 4 * D) + valid * (16 + 4 * D) + seeds_l * 68
-    achieved = algo_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
+    shape = log[0][1]
     fused = len(shape) > 1
     kernel_name = ('recency_lookup_fused01_kernel (hop 0 + hop 1 in one launch: ' if fused else f'recency_lookup_kernel (hop {last_hop}: ') + \
         ' + '.join(f'{seeds} seeds x k={k}' for seeds, k in shape) + ')'
 
-    total_units = args.steps * slots_per_step * world
+    lowered = args.pool > 0 and args.validate != 'sync'
     out = {
         'metric': 'sampled-edges/sec (TGAT 2-hop k=20 recency sampler, tgbl-wiki synthetic)' if args.workload == 'wiki'
         else f'sampled-edges/sec (recency sampler, tgbl-{args.workload} synthetic)',
         'value': total_units / elapsed,
         'unit': 'sampled-edges/s',
         'n_gpus': world,
-        'steps': args.steps,
+        'steps': steps,
         'warmup': args.warmup,
-        'ms_per_step': 1e3 * elapsed / args.steps,
+        'ms_per_step': 1e3 * elapsed / steps,
         'higher_is_better': True,
-        'scaling': 'weak',
+        'scaling': args.scaling,
         'vs_baseline': None,
         'dtype': 'int32/int64 indices + f32 feature rows (copied, no arithmetic)',
         'data': 'synthetic',
         'config': {
             'workload': f'tgbl-{args.workload}-shaped synthetic stream: N={stream.num_nodes}, E={stream.num_edges}, D={D}; '
-            f'seeds = src|dst|neg, num_nbrs={num_nbrs}, batch_size={bs_rank} edges per rank ({bs_rank * world} global), mode={args.mode}, '
-            "seed validation on the device, read back once after the timed steps (validate='deferred')",
-            'slots_per_step_per_rank': slots_per_step,
-            'events_per_s': args.steps * bs_rank * world / elapsed,
-            'parallelism': f'edge-batch sharding x{world}, replicated stream, no data-path collective',
+            f'seeds = src|dst|neg, num_nbrs={num_nbrs}, global batch {global_bs} edges, {bs_rank} seed edges per rank, mode={args.mode}; '
+            f'timed batches {first_timed}..{first_timed + steps - 1} of {n_batches} (batches before them replayed untimed: rings in steady state); '
+            + (f'loader output_pool={args.pool}: one tgmx_pipeline_step per batch into a ring of preallocated outputs; ' if lowered
+               else 'hook-by-hook path, fresh output tensors per batch; ')
+            + f"seed validation on the device, validate='{args.validate}'"
+            + (' (status word read back once after the timed steps)' if args.validate == 'deferred' else ''),
+            'slots_per_step_per_rank': slots_of(bs_rank),
+            'events_per_s': total_events / elapsed,
+            'parallelism': f'edge-batch sharding x{world} ({args.scaling} scaling), replicated stream, no data-path collective',
         },
         'roofline': {
             'bound': 'hbm',
@@ -276,17 +344,18 @@ def main():
             'peak': HBM_PEAK_GBS,
             'unit': 'GB/s',
             'frac': achieved / HBM_PEAK_GBS,
-            'traffic': pmc_traffic(args, total_slots),
+            'traffic': pmc_traffic(args, int(total_slots)),
             'avg_kernel_ms': avg_ms,
             'rocprof_avg_kernel_us': rocprof_kernel_us(fused) if (args.workload == 'wiki' and args.mode == 'ring' and world == 1) else None,
             'launches_timed': len(ker_ms),
             'algorithmic_bytes_per_launch': algo_bytes,
             'valid_slot_fraction': valid / max(total_slots, 1),
+            'bytes_model': 'valid-aware: slots x (12 + 4D) written + valid slots x (16 + 4D) read + 68 B per seed',
         },
     }
     if rank == 0:
         if world == 1 and args.cpu_batches > 0:
-            out['cpu_baseline'] = cpu_baseline(stream, bs_rank, num_nbrs, args.cpu_batches, args.seed)
+            out['cpu_baseline'] = cpu_baseline(stream, bs, num_nbrs, args.cpu_batches, args.seed, first_timed)
         else:
             out['cpu_baseline'] = None
         print(json.dumps(out), flush=True)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TGMX_ABI_VERSION 1
+#define TGMX_ABI_VERSION 2
 
 #define TGMX_OK 0
 #define TGMX_E_INVALID (-1)  /* bad argument (null pointer, size, alignment) */
@@ -54,7 +54,8 @@ typedef struct tgmx_adj {
 
 int tgmx_version(void);
 /* sizeof of the argument structs as this library was compiled (a binding checks its own mirror against it):
- * 0 tgmx_adj_t, 1 tgmx_recency_step_t, 2 tgmx_tgat_layer_t, 3 tgmx_tgat_model_t, 4 tgmx_tgat_hop_t, 5 tgmx_tgat_layout_t */
+ * 0 tgmx_adj_t, 1 tgmx_recency_step_t, 2 tgmx_tgat_layer_t, 3 tgmx_tgat_model_t, 4 tgmx_tgat_hop_t, 5 tgmx_tgat_layout_t,
+ * 6 tgmx_pipeline_t, 7 tgmx_pipeline_out_t */
 size_t tgmx_abi_sizeof(int32_t which);
 const char* tgmx_last_error(void);
 
@@ -185,6 +186,15 @@ typedef struct tgmx_recency_step {
   int64_t ts_bound;            /* 0 = unknown; else a promise: every timestamp of every batch satisfies 0 <= t <= ts_bound
                                   (lets the large-batch update sort only the key bits that can be set; a violation is
                                   reported as TGMX_ST_TS_BOUND and the order of that batch is unspecified) */
+  /* ABI v2.  Negatives generated in place: RandomNegativeEdgeSamplerHook.__call__ (tgm/hooks/negatives/sampler.py:45-65)
+   * folded into the seed fetch.  With neg_out set, seed group `neg_group` takes no id array (grp_nid[neg_group] is
+   * ignored): its i-th id is the i-th draw of tgmx_random_negatives(neg_low, neg_high, ., neg_seed, neg_call) -- the
+   * same counter-based generator -- its times are grp_ts[neg_group], and the hop-0 lookup also writes the group to
+   * neg_out[grp_n] / neg_time_out[grp_n] (the hook's `neg` / `neg_time`).  neg_out = NULL: off (v1 behaviour). */
+  int32_t neg_group, neg_low, neg_high;
+  uint64_t neg_seed, neg_call;
+  int32_t* neg_out;
+  int64_t* neg_time_out;
 } tgmx_recency_step_t;
 
 int tgmx_recency_step(const tgmx_recency_step_t* step, tgmx_stream_t stream);
@@ -192,6 +202,61 @@ int tgmx_recency_step(const tgmx_recency_step_t* step, tgmx_stream_t stream);
  * not served by the narrow-row kernel; static index: wide rows only).  Informational (bench.py
  * attributes the timed launch's bytes with it); results never depend on it. */
 int tgmx_recency_step_plan(const tgmx_recency_step_t* step);
+
+/* ------------------------------------------------------------------------
+ * The loader's per-batch call as ONE entry point: DGDataLoader.__call__ (tgm/data/loader.py:158-170: slice,
+ * materialize) -> HookManager.execute_active_hooks (tgm/hooks/hook_manager.py:139-168) for the hook chain
+ *   [EdgeShardHook (ours: a rank's contiguous share of the batch)] -> RandomNegativeEdgeSamplerHook
+ *   (tgm/hooks/negatives/sampler.py:45-65) -> RecencyNeighborHook (tgm/hooks/neighbors/recency.py:119-171)
+ * over the device-resident stream.  A batch is the edge range [edge_lo, edge_lo + n_edges) of the store; the seeds are
+ * the roles listed in seed_role (in the order of the hook's seed_nodes_keys), every role over this rank's share
+ * [n * rank / world, n * (rank + 1) / world) of the batch, all with the share's edge times as query times;
+ * negatives are generated inside the seed fetch (tgmx_recency_step_t.neg_out).  Streaming mode (step.indptr == NULL,
+ * update != 0) appends the WHOLE batch to the rings after the lookups (every rank replays the global batch).
+ * The caller owns the outputs (a pool of preallocated buffers): nothing is allocated, nothing synchronises.
+ * Results are identical to running the three hooks one by one. */
+#define TGMX_SEED_SRC 0
+#define TGMX_SEED_DST 1
+#define TGMX_SEED_NEG 2
+typedef struct tgmx_pipeline {
+  const int32_t* src;          /* resident stream, time-sorted (DGData, tgm/data/dg_data.py:350-394) */
+  const int32_t* dst;
+  const int64_t* ts;
+  const float* edge_x;         /* [num_edges, D] or NULL */
+  int64_t num_edges;
+  int32_t rank, world;         /* seeds come from this rank's share of every batch (world = 1: the whole batch) */
+  int32_t n_roles;
+  int32_t seed_role[TGMX_MAX_SEED_GROUPS]; /* TGMX_SEED_* per seed group */
+  int32_t neg_low, neg_high;   /* negatives: uniform ids in [neg_low, neg_high) */
+  uint64_t neg_seed;
+  int32_t update;              /* streaming mode: append the batch to the rings after the lookups */
+  int32_t reserved0;
+  tgmx_recency_step_t step;    /* static fields filled by the caller: state pointers, D, B, num_nodes, n_hops, k[],
+                                  directed, key_wrap32, scratch, status, ts_bound; static index: indptr, ev_lo
+                                  (first edge visible in this epoch; ev_hi is set to edge_lo by the call) */
+} tgmx_pipeline_t;
+
+typedef struct tgmx_pipeline_out {
+  int32_t* neg;                /* [share]  (NULL unless a TGMX_SEED_NEG role exists) */
+  int64_t* neg_time;           /* [share] */
+  int32_t* seed_nid0;          /* [n_roles * share] concatenated hop-0 seeds */
+  int64_t* seed_ts0;
+  int32_t* out_nid[TGMX_MAX_HOPS];
+  int64_t* out_ts[TGMX_MAX_HOPS];
+  float* out_x[TGMX_MAX_HOPS];
+  int32_t timed_hop;           /* -1: none; else ev_start / ev_stop bracket that hop's lookup launch */
+  tgmx_event_t ev_start, ev_stop;
+} tgmx_pipeline_out_t;
+
+int tgmx_pipeline_step(const tgmx_pipeline_t* pipe, int64_t edge_lo, int64_t n_edges, uint64_t neg_call,
+                       const tgmx_pipeline_out_t* out, tgmx_stream_t stream);
+
+/* DGStorageArrayBackend._binary_search (tgm/core/_storage/backends/array_backend.py:301-321): event index range
+ * [*lb, *ub) of the slice {start_time <= t <= end_time (inclusive; has_* = 0: unbounded), start_idx <= i < end_idx
+ * (negative: unbounded)} over the time-sorted timeline.  `host_time` is a HOST array (the one exception to the
+ * device-pointer convention: slicing is host arithmetic, O(log n), no device work). */
+int tgmx_slice(const int64_t* host_time, int64_t n, int32_t has_start_time, int64_t start_time, int32_t has_end_time,
+               int64_t end_time, int64_t start_idx, int64_t end_idx, int64_t* lb, int64_t* ub);
 
 /* ring.fill(pad), write_pos.zero_()  (recency.py:111-117) */
 int tgmx_ring_reset(tgmx_adj_t* ring, int32_t* write_pos, int32_t B, int32_t num_nodes,

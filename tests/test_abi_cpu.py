@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f'{name} declared in tgm_amd.h but not exported by libtgm_amd.so'
     # and the ctypes signature table covers the same set
     assert sorted(_native.SIGNATURES) == declared_symbols()
-    assert _native.load().tgmx_version() == 1
+    assert _native.load().tgmx_version() == 2
 
 
 def test_no_cpu_fallback():
@@ -74,7 +74,8 @@ def test_struct_mirrors_have_the_library_s_sizes():
     from tgm_amd import _native
 
     lib = _native.load()
-    mirrors = {1: _native.RecencyStep, 2: _native.TgatLayer, 3: _native.TgatModel, 4: _native.TgatHop, 5: _native.TgatLayout}
+    mirrors = {1: _native.RecencyStep, 2: _native.TgatLayer, 3: _native.TgatModel, 4: _native.TgatHop, 5: _native.TgatLayout,
+               6: _native.Pipeline, 7: _native.PipelineOut}
     assert lib.tgmx_abi_sizeof(0) == 16
     for which, cls in mirrors.items():
         assert lib.tgmx_abi_sizeof(which) == ctypes.sizeof(cls), cls.__name__

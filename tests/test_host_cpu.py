@@ -207,3 +207,35 @@ def test_discretize_matches_reference_golden():
     dg = DGraph(d.discretize('h'))
     sizes = [b.edge_src.numel() for b in DGDataLoader(dg, batch_unit='h')]
     assert sum(sizes) == dg.num_edge_events and len(sizes) >= 5
+
+
+def test_tgmx_slice_matches_the_store_s_event_range():
+    """tgmx_slice (host arithmetic in the C ABI) == EdgeStore.event_range == the reference's _binary_search
+    (array_backend.py:301-321) on a tie-heavy timeline, every bound combination."""
+    import ctypes
+
+    import numpy as np
+
+    from tgm_amd import _native
+    from tgm_amd.core.store import SliceBounds
+
+    lib = _native.load()
+    rng = np.random.default_rng(3)
+    t = np.sort(rng.integers(0, 40, 300)).astype(np.int64)
+    lb, ub = ctypes.c_int64(), ctypes.c_int64()
+
+    class FakeStore:
+        _time_np = t
+        num_events = len(t)
+
+    from tgm_amd.core.store import EdgeStore
+
+    for _ in range(400):
+        st_ = None if rng.random() < 0.3 else int(rng.integers(-3, 45))
+        et_ = None if rng.random() < 0.3 else int(rng.integers(-3, 45))
+        si_ = None if rng.random() < 0.5 else int(rng.integers(0, 300))
+        ei_ = None if rng.random() < 0.5 else int(rng.integers(1, 301))
+        want = EdgeStore.event_range(FakeStore, SliceBounds(st_, et_, si_, ei_))
+        rc = lib.tgmx_slice(t.ctypes.data, len(t), st_ is not None, st_ or 0, et_ is not None, et_ or 0, si_ or 0, ei_ if ei_ else -1,
+                            ctypes.byref(lb), ctypes.byref(ub))
+        assert rc == 0 and (lb.value, ub.value) == want, (st_, et_, si_, ei_)

@@ -1,0 +1,210 @@
+"""The lowered hook chain (DGDataLoader(output_pool=R) -> tgmx_pipeline_step: shard -> negatives generated in the seed
+fetch -> recency sampler, pooled outputs) against (a) the same chain run hook by hook -- every produced tensor
+bit-identical, negatives included -- and (b) the CPU oracle.  Reference behaviour restated:
+tgm/data/loader.py:158-170 + tgm/hooks/hook_manager.py:139-168 + tgm/hooks/negatives/sampler.py:45-65 +
+tgm/hooks/neighbors/recency.py:119-171."""
+import logging
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _stream(E=5000, D=12, shape='wiki', **kw):
+    from tgm_amd.synth import make_stream
+
+    return make_stream(shape, seed=11, num_edges=E, edge_dim=D, **kw)
+
+
+def _build(st, bs, num_nbrs, mode, pool, world=1, rank=0, neg=True, extra=None, directed=False):
+    from tgm_amd import DGData, DGDataLoader, DGraph
+    from tgm_amd.dist import EdgeShardHook
+    from tgm_amd.hooks import HookManager, RandomNegativeEdgeSamplerHook, RecencyNeighborHook
+
+    dg = DGraph(DGData.from_raw(st.ts, torch.stack([st.src, st.dst], 1), st.edge_x), device=DEV)
+    hm = HookManager(keys=['k'])
+    lo_dst = int(st.dst.min())
+    if world > 1:
+        hm.register('k', EdgeShardHook(rank, world))
+        keys, tkeys = ['shard_src', 'shard_dst'], ['shard_time', 'shard_time']
+        if neg:
+            hm.register('k', RandomNegativeEdgeSamplerHook(lo_dst, st.num_nodes, seed=5, like='shard_dst', time_key='shard_time'))
+    else:
+        keys, tkeys = ['edge_src', 'edge_dst'], ['edge_time', 'edge_time']
+        if neg:
+            hm.register('k', RandomNegativeEdgeSamplerHook(lo_dst, st.num_nodes, seed=5))
+    if neg:
+        keys, tkeys = keys + ['neg'], tkeys + ['neg_time']
+    hook = RecencyNeighborHook(st.num_nodes, num_nbrs, keys, tkeys, mode=mode, validate='deferred', directed=directed,
+                               batch_size=bs if mode == 'csr' else None)  # fmt: skip
+    hm.register('k', hook)
+    for h in extra or []:
+        hm.register('k', h)
+    return hm, hook, DGDataLoader(dg, batch_size=bs, hook_manager=hm, output_pool=pool)
+
+
+def _same(a, b, tag):
+    if isinstance(a, torch.Tensor):
+        assert isinstance(b, torch.Tensor) and a.dtype == b.dtype and a.shape == b.shape, f'{tag}: {a.dtype}{tuple(a.shape)} vs {b.dtype}{tuple(b.shape)}'
+        assert torch.equal(a, b), tag
+    elif isinstance(a, (list, tuple)):
+        assert len(a) == len(b), tag
+        for i, (x, y) in enumerate(zip(a, b)):
+            _same(x, y, f'{tag}[{i}]')
+    elif isinstance(a, dict):
+        assert sorted(a) == sorted(b), tag
+        for k in a:
+            _same(a[k], b[k], f'{tag}[{k}]')
+    else:
+        assert a == b, tag
+
+
+ATTRS = ['edge_src', 'edge_dst', 'edge_time', 'edge_x', 'seed_nids', 'seed_times', 'nbr_nids', 'nbr_edge_time', 'nbr_edge_x', 'seed_node_nbr_mask']
+
+
+@pytest.mark.parametrize('mode', ['ring', 'csr'])
+@pytest.mark.parametrize('world,rank', [(1, 0), (2, 0), (2, 1), (3, 1)])
+@pytest.mark.parametrize('neg', [True, False])
+def test_lowered_chain_equals_hook_by_hook(mode, world, rank, neg):
+    st = _stream()
+    bs, k = 96, [4, 3]  # 5000 % 96 = 8: a ragged last batch
+    hm_a, hook_a, plain = _build(st, bs, k, mode, 0, world, rank, neg)
+    hm_b, hook_b, pooled = _build(st, bs, k, mode, 3, world, rank, neg)
+    attrs = ATTRS + (['neg', 'neg_time'] if neg else []) + (['shard_src', 'shard_dst', 'shard_time', 'shard_lo'] if world > 1 else [])
+    with hm_a.activate('k'), hm_b.activate('k'):
+        for epoch in range(2):
+            n = 0
+            for ba, bb in zip(plain, pooled):
+                for name in attrs:
+                    _same(getattr(ba, name), getattr(bb, name), f'epoch {epoch} batch {n} {name}')
+                assert ba._edge_lo == bb._edge_lo
+                n += 1
+            assert n == len(plain) == len(pooled)
+            hm_a.reset_state()
+            hm_b.reset_state()
+        assert pooled._compiled[1] is not None and pooled._compiled[1].n_lowered == (1 if world > 1 else 0) + (1 if neg else 0) + 1
+    hook_a.check()
+    hook_b.check()
+
+
+def test_lowered_chain_vs_oracle_and_pool_recycling():
+    """Pooled outputs against the CPU restatement of the reference (oracle/ring_port.py), with the comment-like
+    non-bipartite shape (timestamp ties inside batches, self loops possible); the tensors of batch i are recycled by
+    batch i + R and not before."""
+    from oracle.ring_port import RingSamplerCPU
+
+    st = _stream(E=6000, D=16, shape='comment', n_src=300, t_hi=1_100_000_500)
+    bs, k, R = 256, [5, 5], 2
+    hm, hook, loader = _build(st, bs, k, 'ring', R)
+    ref = RingSamplerCPU(st.num_nodes, k, 16)
+    held = []
+    with hm.activate('k'):
+        for b, batch in enumerate(loader):
+            lo, hi = b * bs, min((b + 1) * bs, st.num_edges)
+            neg = batch.neg.cpu()
+            hops = ref.step(torch.cat([st.src[lo:hi], st.dst[lo:hi], neg]), torch.cat([st.ts[lo:hi]] * 3), st.src[lo:hi], st.dst[lo:hi],
+                            st.ts[lo:hi], st.edge_x[lo:hi])  # fmt: skip
+            for h, (s_n, s_t, o_i, o_t, o_x) in enumerate(hops):
+                assert torch.equal(batch.seed_nids[h].cpu(), s_n) and torch.equal(batch.seed_times[h].cpu(), s_t)
+                assert torch.equal(batch.nbr_nids[h].cpu(), o_i), f'batch {b} hop {h}'
+                assert torch.equal(batch.nbr_edge_time[h].cpu(), o_t) and torch.equal(batch.nbr_edge_x[h].cpu(), o_x)
+            held.append((batch.nbr_nids[1], batch.nbr_nids[1].clone()))
+            if hi - lo == bs and b >= 1 and held[b - 1][0].shape == held[b][0].shape:
+                assert torch.equal(*held[b - 1]), 'a pooled tensor changed before R more batches were produced'
+                if b >= R and held[b - R][0].shape == held[b][0].shape:
+                    assert held[b - R][0].data_ptr() == held[b][0].data_ptr()  # recycled after exactly R batches
+    hook.check()
+
+
+def test_hooks_behind_the_lowered_prefix_still_run():
+    from tgm_amd.hooks import DeduplicationHook
+
+    st = _stream(E=3000, D=8)
+    hm_a, _, plain = _build(st, 128, [5], 'ring', 0, extra=[DeduplicationHook(seed_nodes_keys=['neg', 'nbr_nids'])])
+    hm_b, _, pooled = _build(st, 128, [5], 'ring', 2, extra=[DeduplicationHook(seed_nodes_keys=['neg', 'nbr_nids'])])
+    with hm_a.activate('k'), hm_b.activate('k'):
+        for ba, bb in zip(plain, pooled):
+            _same(ba.unique_nids, bb.unique_nids, 'unique_nids')
+            _same(ba.global_to_local(ba.edge_src), bb.global_to_local(bb.edge_src), 'global_to_local')
+        assert pooled._compiled[1].n_lowered == 2
+
+
+def test_sync_validation_is_not_lowered_and_bad_seeds_raise_in_deferred_mode():
+    from tgm_amd import DGData, DGDataLoader, DGraph
+    from tgm_amd.hooks import HookManager, RecencyNeighborHook
+
+    st = _stream(E=600, D=4)
+    dg = DGraph(DGData.from_raw(st.ts, torch.stack([st.src, st.dst], 1), st.edge_x), device=DEV)
+    hm = HookManager(keys=['k'])
+    hm.register('k', RecencyNeighborHook(st.num_nodes, [3], ['edge_src', 'edge_dst'], ['edge_time', 'edge_time']))  # validate='sync'
+    loader = DGDataLoader(dg, batch_size=100, hook_manager=hm, output_pool=2)
+    with hm.activate('k'):
+        next(iter(loader))
+        assert loader._compiled[1] is None  # the default mode keeps the reference's raise-per-call behaviour
+    # deferred validation through the lowered path: num_nodes too small for the stream's ids
+    hm2 = HookManager(keys=['k'])
+    bad = RecencyNeighborHook(10, [3], ['edge_src', 'edge_dst'], ['edge_time', 'edge_time'], validate='deferred', mode='csr', batch_size=100)
+    hm2.register('k', bad)
+    # (the static index build itself validates endpoints)
+    with hm2.activate('k'), pytest.raises(ValueError):
+        for _ in DGDataLoader(dg, batch_size=100, hook_manager=hm2, output_pool=2):
+            pass
+        bad.check()
+
+
+def test_csr_mode_refuses_batches_off_the_indexed_schedule():
+    """a batch that does not start on a boundary of the schedule the index was built for must not silently
+    return wrong neighbours."""
+    from tgm_amd import DGData, DGDataLoader, DGraph
+    from tgm_amd.hooks import HookManager, RecencyNeighborHook
+
+    st = _stream(E=2000, D=4)
+    dg = DGraph(DGData.from_raw(st.ts, torch.stack([st.src, st.dst], 1), st.edge_x), device=DEV)
+    for pool in (0, 2):
+        hook = RecencyNeighborHook(st.num_nodes, [3], ['edge_src', 'edge_dst'], ['edge_time', 'edge_time'], mode='csr', batch_size=128,
+                                   validate='deferred')  # fmt: skip
+        hm = HookManager(keys=['k'])
+        hm.register('k', hook)
+        with hm.activate('k'):
+            it = iter(DGDataLoader(dg, batch_size=128, hook_manager=hm, output_pool=pool))
+            next(it), next(it)
+            with pytest.raises(ValueError, match='not a boundary'):
+                next(iter(DGDataLoader(dg.slice_events(300, 2000), batch_size=128, hook_manager=hm, output_pool=pool)))
+            # an aligned split is fine
+            next(iter(DGDataLoader(dg.slice_events(384, 2000), batch_size=128, hook_manager=hm, output_pool=pool)))
+
+
+def test_out_of_order_batches_warn_once(caplog):
+    from tgm_amd import DGData, DGDataLoader, DGraph
+    from tgm_amd.hooks import HookManager, RecencyNeighborHook
+
+    st = _stream(E=1000, D=4)
+    dg = DGraph(DGData.from_raw(st.ts, torch.stack([st.src, st.dst], 1), st.edge_x), device=DEV)
+    hm = HookManager(keys=['k'])
+    hm.register('k', RecencyNeighborHook(st.num_nodes, [3], ['edge_src', 'edge_dst'], ['edge_time', 'edge_time']))
+    loader = DGDataLoader(dg, batch_size=100, hook_manager=hm)
+    with hm.activate('k'), caplog.at_level(logging.WARNING, logger='tgm_amd.hooks.recency'):
+        loader(500)
+        loader(600)
+        assert not caplog.records
+        loader(100)  # behind the previous batch, state not reset
+        loader(0)
+        assert len([r for r in caplog.records if 'chronological' in r.getMessage()]) == 1
+        hm.reset_state()
+        loader(0)
+        assert len(caplog.records) == 1
+
+
+def test_masks_are_fresh_tensors_per_batch():
+    """recency.py:221-224 hands out new index tensors per batch: an in-place edit must not leak into the next batch."""
+    st = _stream(E=600, D=4)
+    hm, _, loader = _build(st, 100, [3], 'ring', 0)
+    with hm.activate('k'):
+        it = iter(loader)
+        b0 = next(it)
+        b0.seed_node_nbr_mask['edge_dst'].fill_(-7)
+        b1 = next(it)
+        assert torch.equal(b1.seed_node_nbr_mask['edge_dst'].cpu(), torch.arange(100, 200))
+        assert torch.equal(b1.seed_node_nbr_mask['neg'].cpu(), torch.arange(200, 300))

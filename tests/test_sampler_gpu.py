@@ -548,3 +548,100 @@ def test_csr_mode_fuzz(seed):
         for h in range(L):
             for u, v in zip(x[h], y[h]):
                 assert torch.equal(u, v), f'batch {b} hop {h} ({N=}, {bs=}, {D=}, {num_nbrs=}, {directed=})'
+
+
+# ---- the BASELINE.json configurations at their own shapes (close the gaps) -----------------------------------
+def _pooled_pipeline(st, bs, ks, mode='ring', pool=3, key_arith='int32', neg_seed=3, dg=None):
+    """negatives -> recency sampler through DGDataLoader(output_pool=): the path bench.py times."""
+    from tgm_amd import DGData, DGDataLoader, DGraph
+    from tgm_amd.hooks import HookManager, RandomNegativeEdgeSamplerHook, RecencyNeighborHook
+
+    if dg is None:
+        dg = DGraph(DGData.from_raw(st.ts, torch.stack([st.src, st.dst], 1), st.edge_x), device=DEV)
+    hm = HookManager(keys=['k'])
+    hm.register('k', RandomNegativeEdgeSamplerHook(int(st.dst.min()), st.num_nodes, seed=neg_seed))
+    hook = RecencyNeighborHook(st.num_nodes, ks, ['edge_src', 'edge_dst', 'neg'], ['edge_time', 'edge_time', 'neg_time'], mode=mode,
+                               key_arith=key_arith, validate='deferred', batch_size=bs if mode == 'csr' else None)  # fmt: skip
+    hm.register('k', hook)
+    return dg, hm, hook, DGDataLoader(dg, batch_size=bs, hook_manager=hm, output_pool=pool)
+
+
+def _against_oracle(st, bs, ks, n_batches, pool=3):
+    from oracle.ring_port import RingSamplerCPU
+
+    _, hm, hook, loader = _pooled_pipeline(st, bs, ks, pool=pool)
+    ref = RingSamplerCPU(st.num_nodes, ks, st.edge_dim)
+    src, dst, ts, x = st.src.cpu(), st.dst.cpu(), st.ts.cpu(), st.edge_x.cpu()
+    with hm.activate('k'):
+        for b, batch in enumerate(loader):
+            if b == n_batches:
+                break
+            lo, hi = b * bs, min((b + 1) * bs, st.num_edges)
+            hops = ref.step(torch.cat([src[lo:hi], dst[lo:hi], batch.neg.cpu()]), torch.cat([ts[lo:hi]] * 3), src[lo:hi], dst[lo:hi], ts[lo:hi], x[lo:hi])
+            for h, (_, _, o_i, o_t, o_x) in enumerate(hops):
+                assert torch.equal(batch.nbr_nids[h].cpu(), o_i), f'b{b} h{h} ids'
+                assert torch.equal(batch.nbr_edge_time[h].cpu(), o_t), f'b{b} h{h} times'
+                assert torch.equal(batch.nbr_edge_x[h].cpu(), o_x), f'b{b} h{h} feats'
+    hook.check()
+    assert loader._compiled[1] is not None
+
+
+def test_cfg2_benched_mode_full_size_vs_oracle():
+    """BASELINE cfg 2 exactly as bench.py runs it -- full N = 9227, D = 172, bs = 200, k = [20, 20], the reference's
+    wrapping int32 key arithmetic (recency.py:347), pooled outputs, negatives generated in the seed fetch -- against the
+    CPU restatement of the reference for the first 160 batches (32 000 edges: rings of the hubs wrap several times)."""
+    from tgm_amd.synth import make_stream
+
+    _against_oracle(make_stream('wiki', seed=1337), 200, [20, 20], 160)
+
+
+def test_cfg3_review_shape_two_hops_vs_oracle():
+    """BASELINE cfg 3's sampler at its own shape: bipartite, unix-scale timestamps, D = 16, bs = 512, k = [10, 10]
+    (hop 1 runs the packed narrow-row kernel with 16-lane groups, the update's placement rides as m = 1024)."""
+    from tgm_amd.synth import make_stream
+
+    _against_oracle(make_stream('review', seed=21, num_edges=30_000, n_src=30_000, n_dst=5_000), 512, [10, 10], 1000)
+
+
+def test_cfg4_comment_shape_reduced_vs_oracle():
+    """BASELINE cfg 4 reduced in N and E only: non-bipartite (a node meets itself in both roles, timestamp ties inside a
+    batch), unix-scale timestamps with wrapping int32 keys, D = 16, bs = 4096 (m = 8192: the rocPRIM radix-sort update
+    with its front half on the side stream), k = [20, 20] (packed narrow-row kernel, 32-lane groups)."""
+    from tgm_amd.synth import make_stream
+
+    _against_oracle(make_stream('comment', seed=4, num_edges=9 * 4096 + 77, n_src=50_000), 4096, [20, 20], 1000)
+
+
+def test_cfg4_comment_full_size_midstream_properties():
+    """BASELINE cfg 4 at FULL size (N = 1 M, E = 44 M, D = 16, bs = 4096, k = [20, 20]), an epoch opened mid-stream at
+    edge 22 M and followed for 120 batches: the streaming rings (intended key order) and the static index over the
+    whole 44 M-edge store agree bit for bit on every batch, and every row satisfies the sampler's invariants."""
+    from tgm_amd import DGData, DGraph
+    from tgm_amd.synth import make_stream
+
+    st = make_stream('comment', seed=1337, device=DEV)
+    bs, ks, first, nb = 4096, [20, 20], 22_000_000 // 4096 * 4096, 120
+    dg = DGraph(DGData.from_raw(st.ts, torch.stack([st.src, st.dst], 1), st.edge_x), device=DEV)
+    view = dg.slice_events(first, first + nb * bs)
+    _, hm_r, hook_r, ld_r = _pooled_pipeline(st, bs, ks, mode='ring', key_arith='int64', dg=view)
+    _, hm_c, hook_c, ld_c = _pooled_pipeline(st, bs, ks, mode='csr', dg=view)
+    n_seen, n_valid = 0, 0
+    with hm_r.activate('k'), hm_c.activate('k'):
+        for br, bc in zip(ld_r, ld_c):
+            assert br._edge_lo == bc._edge_lo == first + n_seen * bs
+            assert torch.equal(br.neg, bc.neg)
+            for h in range(2):
+                n, t, x = br.nbr_nids[h], br.nbr_edge_time[h], br.nbr_edge_x[h]
+                assert torch.equal(n, bc.nbr_nids[h]) and torch.equal(t, bc.nbr_edge_time[h]) and torch.equal(x, bc.nbr_edge_x[h]), (n_seen, h)
+                valid = n >= 0
+                q = br.seed_times[h][:, None]
+                assert bool(((t < q) | ~valid).all()) and bool((valid[:, 1:] | ~valid[:, :-1]).all())
+                assert bool(((t[:, 1:] >= t[:, :-1]) | ~valid[:, :-1]).all())
+                assert bool((t[~valid] == 0).all()) and bool((x[~valid] == 0).all())
+                if h == 1:
+                    n_valid += int(valid.sum())
+            assert torch.equal(br.seed_nids[1], br.nbr_nids[0].reshape(-1))
+            n_seen += 1
+    hook_r.check()
+    hook_c.check()
+    assert n_seen == nb and n_valid > 0

@@ -129,6 +129,32 @@ class RecencyStep(ctypes.Structure):
         ('scratch', c_void_p), ('status', c_void_p),
         ('timed_hop', c_int32), ('ev_start', c_void_p), ('ev_stop', c_void_p),
         ('ts_bound', c_int64),
+        ('neg_group', c_int32), ('neg_low', c_int32), ('neg_high', c_int32),
+        ('neg_seed', ctypes.c_uint64), ('neg_call', ctypes.c_uint64), ('neg_out', c_void_p), ('neg_time_out', c_void_p),
+    ]  # fmt: skip
+
+
+SEED_SRC, SEED_DST, SEED_NEG = 0, 1, 2
+
+
+class Pipeline(ctypes.Structure):
+    """tgmx_pipeline_t (include/tgm_amd.h)."""
+
+    _fields_ = [
+        ('src', c_void_p), ('dst', c_void_p), ('ts', c_void_p), ('edge_x', c_void_p), ('num_edges', c_int64),
+        ('rank', c_int32), ('world', c_int32), ('n_roles', c_int32), ('seed_role', c_int32 * MAX_SEED_GROUPS),
+        ('neg_low', c_int32), ('neg_high', c_int32), ('neg_seed', ctypes.c_uint64),
+        ('update', c_int32), ('reserved0', c_int32), ('step', RecencyStep),
+    ]  # fmt: skip
+
+
+class PipelineOut(ctypes.Structure):
+    """tgmx_pipeline_out_t (include/tgm_amd.h)."""
+
+    _fields_ = [
+        ('neg', c_void_p), ('neg_time', c_void_p), ('seed_nid0', c_void_p), ('seed_ts0', c_void_p),
+        ('out_nid', c_void_p * MAX_HOPS), ('out_ts', c_void_p * MAX_HOPS), ('out_x', c_void_p * MAX_HOPS),
+        ('timed_hop', c_int32), ('ev_start', c_void_p), ('ev_stop', c_void_p),
     ]  # fmt: skip
 
 
@@ -147,6 +173,8 @@ SIGNATURES['tgmx_csr_build_workspace_bytes'] = (c_size_t, [c_int64, c_int32, c_i
 SIGNATURES['tgmx_csr_build'] = (c_int32, [_P, _P, _P, c_int64, c_int32, _P, c_int64, c_int32, _P, _P, _P, c_size_t, _P, _P])
 SIGNATURES['tgmx_recency_step'] = (c_int32, [ctypes.POINTER(RecencyStep), _P])
 SIGNATURES['tgmx_recency_step_plan'] = (c_int32, [ctypes.POINTER(RecencyStep)])
+SIGNATURES['tgmx_pipeline_step'] = (c_int32, [ctypes.POINTER(Pipeline), c_int64, c_int64, ctypes.c_uint64, ctypes.POINTER(PipelineOut), _P])
+SIGNATURES['tgmx_slice'] = (c_int32, [_P, c_int64, c_int32, c_int64, c_int32, c_int64, c_int64, c_int64, ctypes.POINTER(c_int64), ctypes.POINTER(c_int64)])
 SIGNATURES['tgmx_segment_sort_workspace_bytes'] = (c_size_t, [c_int64])
 SIGNATURES['tgmx_segment_sort'] = (c_int32, [_P, c_int64, c_int32, _P, _P, _P, _P, c_size_t, _P, _P])
 SIGNATURES['tgmx_tgat_layout'] = (c_int32, [ctypes.POINTER(TgatModel), c_int64, ctypes.POINTER(TgatHop), c_int32, ctypes.POINTER(TgatLayout)])

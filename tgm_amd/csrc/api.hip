@@ -25,6 +25,8 @@ extern "C" size_t tgmx_abi_sizeof(int32_t which) {
     case 3: return sizeof(tgmx_tgat_model_t);
     case 4: return sizeof(tgmx_tgat_hop_t);
     case 5: return sizeof(tgmx_tgat_layout_t);
+    case 6: return sizeof(tgmx_pipeline_t);
+    case 7: return sizeof(tgmx_pipeline_out_t);
     default: return 0;
   }
 }

@@ -44,6 +44,18 @@ inline FastDiv make_fastdiv(uint32_t div) {
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
 
+// RandomNegativeEdgeSamplerHook's draw i of call `call` (tgm/hooks/negatives/sampler.py:45-65: uniform ids in [low, low + range)):
+// a counter-based generator, so the stand-alone kernel (dedup.hip) and the seed fetch of the lookup kernels (recency.hip,
+// negatives generated in place) produce the same ids
+__device__ __forceinline__ int negative_draw(unsigned long long seed, unsigned long long call, unsigned long long i, int low, unsigned range) {
+  unsigned long long x = seed ^ (call * 0x9E3779B97F4A7C15ull) ^ (i * 0xD1B54A32D192ED03ull);
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return low + (int)__umulhi((unsigned)(x >> 32), range);  // uniform up to 2^-32 * range
+}
+
 // cos(x) for Time2Vec arguments (float32 x up to ~2^31 * w).  A row's 100 frequencies span 9 decades, so the
 // library cosf would take its large-argument (Payne-Hanek) path on every wave (~130 instructions).  Instead:
 //   * polynomial: float minimax sin / cos on [-pi/4, pi/4], quadrant from the reduction's integer;

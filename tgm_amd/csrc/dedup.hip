@@ -89,14 +89,7 @@ __global__ __launch_bounds__(256) void random_negatives_kernel(int32_t* __restri
                                                                const int64_t* __restrict__ t_in, int64_t* __restrict__ t_out,
                                                                long long nt) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) {
-    unsigned long long x = seed ^ (call * 0x9E3779B97F4A7C15ull) ^ ((unsigned long long)i * 0xD1B54A32D192ED03ull);
-    x += 0x9E3779B97F4A7C15ull;
-    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-    x ^= x >> 31;
-    neg[i] = low + (int)__umulhi((unsigned)(x >> 32), range);  // uniform up to 2^-32 * range
-  }
+  if (i < n) neg[i] = negative_draw(seed, call, (unsigned long long)i, low, range);
   if (i < nt) t_out[i] = t_in[i];
 }
 

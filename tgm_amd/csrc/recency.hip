@@ -47,6 +47,15 @@ struct SeedGroups {
   int32_t* out_nid;
   int64_t* out_ts;
   int groups;  // 0: seeds / qtimes are read instead
+  // group `gen` (-1: none) has no id array: its ids are RandomNegativeEdgeSamplerHook's draws (negative_draw), generated
+  // where they are needed -- every wave that fetches seed s re-derives the same id -- and published to gen_out /
+  // gen_out_ts (the hook's `neg` / `neg_time`) by the hop-0 wave of that seed
+  int gen;
+  int gen_low;
+  unsigned gen_range;
+  unsigned long long gen_seed, gen_call;
+  int32_t* gen_out;
+  int64_t* gen_out_ts;
 };
 
 struct LookupArgs {
@@ -840,19 +849,26 @@ __device__ __forceinline__ void fetch_seed(const LookupArgs& a, long long s, int
     const int32_t* pn = a.grp.nid[0];
     const int64_t* pt = a.grp.ts[0];
     long long base = 0;
+    int sel = 0;
 #pragma unroll
     for (int g = 1; g < TGMX_MAX_SEED_GROUPS; ++g) {
       if (g < a.grp.groups && s >= a.grp.end[g - 1]) {
         pn = a.grp.nid[g];
         pt = a.grp.ts[g];
         base = a.grp.end[g - 1];
+        sel = g;
       }
     }
-    n = pn[s - base];
+    const bool gen = sel == a.grp.gen;  // wave-uniform
+    n = gen ? negative_draw(a.grp.gen_seed, a.grp.gen_call, (unsigned long long)(s - base), a.grp.gen_low, a.grp.gen_range) : pn[s - base];
     q = pt[s - base];
     if (publish && lane == 0) {
       a.grp.out_nid[s] = n;
       a.grp.out_ts[s] = q;
+      if (gen) {
+        a.grp.gen_out[s - base] = n;
+        a.grp.gen_out_ts[s - base] = q;
+      }
     }
   } else {
     n = a.seeds[s];
@@ -1923,11 +1939,19 @@ extern "C" int tgmx_recency_step(const tgmx_recency_step_t* s, tgmx_stream_t str
 
   // ---- hop-0 seeds: groups are concatenated by the hop-0 lookup itself (or by nothing when there is no hop)
   SeedGroups grp{};
+  grp.gen = -1;
   long long S = s->S0;
   if (s->n_groups > 0) {
     S = 0;
+    const int gen = s->neg_out ? s->neg_group : -1;  // negatives generated in place of seed group neg_group
+    TGMX_REQUIRE(gen < s->n_groups, "recency_step: neg_group=%d but %d seed groups", gen, s->n_groups);
+    if (gen >= 0) {
+      TGMX_REQUIRE(s->neg_low < s->neg_high && s->neg_time_out, "recency_step: generated negatives need low < high and neg_time_out");
+      grp.gen = gen; grp.gen_low = s->neg_low; grp.gen_range = (unsigned)((long long)s->neg_high - s->neg_low);
+      grp.gen_seed = s->neg_seed; grp.gen_call = s->neg_call; grp.gen_out = s->neg_out; grp.gen_out_ts = s->neg_time_out;
+    }
     for (int g = 0; g < s->n_groups; ++g) {
-      TGMX_REQUIRE(s->grp_n[g] >= 0 && (s->grp_n[g] == 0 || (s->grp_nid[g] && s->grp_ts[g])), "recency_step: seed group %d", g);
+      TGMX_REQUIRE(s->grp_n[g] >= 0 && (s->grp_n[g] == 0 || ((g == gen || s->grp_nid[g]) && s->grp_ts[g])), "recency_step: seed group %d", g);
       S += s->grp_n[g];
       grp.nid[g] = s->grp_nid[g]; grp.ts[g] = s->grp_ts[g]; grp.end[g] = S;
     }

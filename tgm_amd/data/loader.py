@@ -6,6 +6,12 @@ iterator instead of a ``torch.utils.data.DataLoader`` subclass: a batch here is
 two integers plus zero-copy views, so the DataLoader machinery (sampler,
 fetcher, collate indirection) would be the dominant per-batch cost.  Like the
 reference it always runs in the caller's process (hook state must not fork).
+
+``output_pool=R`` (ours, default 0 = off): run the lowerable prefix of the hook
+chain -- [shard] -> [negatives] -> recency sampler -- as one native call per
+batch writing into a ring of ``R`` preallocated output sets
+(``tgm_amd/pipeline.py``).  Same tensors as the hook-by-hook path; they are
+recycled after ``R`` further batches instead of being freshly allocated.
 """
 from __future__ import annotations
 
@@ -23,6 +29,7 @@ class DGDataLoader:
         batch_unit: str = 'r',
         on_empty: Literal['skip', 'raise', None] = 'skip',
         hook_manager: Optional[Any] = None,
+        output_pool: int = 0,
         **kwargs: Any,
     ) -> None:
         if batch_size <= 0:
@@ -47,6 +54,9 @@ class DGDataLoader:
         self._batch_size = batch_size
         self._hook_manager = hook_manager
         self._on_empty = on_empty
+        self._output_pool = int(output_pool)
+        self._compiled = None  # (hook list identity, CompiledPipeline or None)
+        self._event_fast = False
 
         if unit.is_event_ordered:
             self._slice_op = dg.slice_events
@@ -54,6 +64,10 @@ class DGDataLoader:
             # an event-ordered view over a sub-range starts at its own first event
             lb, _ = dg._event_range
             start, stop = lb, lb + dg.num_events
+            # every event is an edge and the view has no time bounds: a batch is the edge range [s, min(s + bs, stop))
+            st, sl = dg._storage, dg._slice
+            self._event_fast = st.num_edges == st.num_events and sl.start_time is None and sl.end_time is None
+            self._stop = stop
         else:
             self._slice_op = dg.slice_time
             start, stop = dg.start_time, dg.end_time + 1
@@ -71,10 +85,57 @@ class DGDataLoader:
     def __call__(self, slice_start) -> DGBatch:
         """Materialize the batch beginning at ``slice_start`` and run the active hooks."""
         s = slice_start[0] if isinstance(slice_start, (list, tuple)) else slice_start
+        if self._output_pool > 0 and self._hook_manager is not None:
+            batch = self._call_compiled(s)
+            if batch is not None:
+                return batch
         view = self._slice_op(s, s + self._batch_size)
         batch = view.materialize()
         if self._hook_manager is not None:
             batch = self._hook_manager.execute_active_hooks(view, batch)
+        return batch
+
+    def _call_compiled(self, s: int) -> Optional[DGBatch]:
+        """The batch through the lowered hook chain (None: nothing lowerable / this batch is left to the hooks)."""
+        hm = self._hook_manager
+        hooks = hm.active_hooks()
+        cached = self._compiled
+        if cached is None or cached[0] is not hooks:
+            from ..pipeline import CompiledPipeline
+
+            cached = self._compiled = (hooks, CompiledPipeline.lower(self._dg, hooks, self._output_pool))
+        pipe = cached[1]
+        if pipe is None:
+            return None
+        dg = self._dg
+        view = None
+        if self._event_fast:
+            lo, hi = s, min(s + self._batch_size, self._stop)
+            lb = lo
+        else:
+            view = self._slice_op(s, s + self._batch_size)
+            lo, hi = view._edge_range
+            lb = view._event_range[0]
+        n = hi - lo
+        arr = dg._storage.on(dg._device)
+        if view is None or (arr.node_x is None and arr.node_y is None):
+            batch = DGBatch(arr.src.narrow(0, lo, n), arr.dst.narrow(0, lo, n), arr.ts.narrow(0, lo, n))
+            batch._edge_lo, batch._event_lo = lo, lb
+            if n > 0:
+                if arr.edge_x is not None:
+                    batch.edge_x = arr.edge_x.narrow(0, lo, n)
+                if arr.edge_type is not None:
+                    batch.edge_type = arr.edge_type.narrow(0, lo, n)
+        else:
+            batch = view.materialize()
+        if not pipe.step(lo, n, batch):
+            return None
+        rest = hooks[pipe.n_lowered :] if pipe.n_lowered < len(hooks) else None
+        if rest:
+            if view is None:
+                view = self._slice_op(s, s + self._batch_size)
+            for h in rest:
+                batch = h(view, batch)
         return batch
 
     @staticmethod

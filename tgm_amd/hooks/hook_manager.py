@@ -87,6 +87,16 @@ class HookManager:
             batch = h(dg, batch)
         return batch
 
+    def active_hooks(self) -> List[DGHook]:
+        """The resolved (dependency-ordered) hook list of the active key.  The list object is replaced, not edited, when
+        hooks are registered, so callers may cache on its identity."""
+        key = self._active_key
+        if key is None:
+            raise RuntimeError('No active key set. Use activate() context manager.')
+        if self._dirty[key]:
+            self.resolve_hooks(key)
+        return self._key_to_hooks[key]
+
     def reset_state(self, key: Optional[str] = None) -> None:
         if key is not None:
             self._check_key(key)

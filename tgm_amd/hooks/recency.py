@@ -23,6 +23,7 @@ raises ``ValueError`` like the reference; ``'deferred'`` only raises when
 """
 from __future__ import annotations
 
+import logging
 import warnings
 from typing import Dict, List, Optional, Sequence
 
@@ -34,6 +35,8 @@ from ..core import DGBatch, DGraph
 from ..index import TemporalCSR, build_csr
 from .base import SeedableHook, StatefulHook
 from .registry import hook
+
+logger = logging.getLogger('tgm_amd.hooks.recency')
 
 _ST_SEED_RANGE, _ST_SEED_TIME, _ST_EDGE_RANGE, _ST_SCRATCH, _ST_TS_BOUND = 1, 2, 4, 8, 16
 
@@ -127,6 +130,8 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
         self._batch_size = batch_size
         self._batch_starts = batch_starts
         self._warned_seed_None = False
+        self._warned_order = False
+        self._last_batch_t = -(1 << 62)
 
         self._device: Optional[torch.device] = None
         self._edge_x_dim: Optional[int] = None
@@ -140,11 +145,12 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
         # csr state
         self._csr: Optional[TemporalCSR] = None
         self._csr_store = None
+        self._csr_first = 0
+        self._csr_bounds = None
         self._epoch_lo: Optional[int] = None  # first edge index visible in this epoch
 
         # optional kernel timing (bench.py): every `profile_every`-th call brackets the
         # lookup launch of hop `profile_hop` with HIP events on the launch stream
-        self._mask_cache: Dict[tuple, Dict[str, Tensor]] = {}
         self._step: Optional[_native.RecencyStep] = None  # argument block of tgmx_recency_step (static fields pre-filled)
         self.profile_hop: Optional[int] = None
         self.profile_every: int = 1
@@ -167,6 +173,8 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
 
     def reset_state(self) -> None:
         """Forget all history (recency.py:111-117)."""
+        self._last_batch_t = -(1 << 62)
+        self._warned_order = False
         if self._mode == 'ring':
             if self._ring is not None:
                 lib = _native.load()
@@ -265,11 +273,13 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
         self._bound_store = None
         self._refresh_ts_bound(dg)
 
-    def _ensure_csr(self, dg: DGraph, batch: DGBatch) -> TemporalCSR:
+    def _ensure_csr(self, dg: DGraph, first_edge: int) -> TemporalCSR:
         store = dg._storage
         if self._csr is None or self._csr_store is not store or self._csr.device != self._device:
             arr = store.on(self._device)
-            first = batch._edge_lo or 0
+            first = first_edge or 0
+            self._csr_first = first
+            self._csr_bounds = None if self._batch_starts is None else frozenset(int(b) for b in self._batch_starts)
             self._csr = build_csr(
                 arr.src,
                 arr.dst,
@@ -284,6 +294,55 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
             st = self._step
             st.indptr, st.ring, st.ring_x = self._csr.indptr.data_ptr(), self._csr.adj.data_ptr(), _native.ptr(arr.edge_x)
         return self._csr
+
+    def _check_csr_boundary(self, ev_hi: int) -> None:
+        """The static index orders a node's entries by (batch, time, role, eid): the entries before edge ``ev_hi`` form
+        a prefix -- which is what the lookup kernel assumes -- only when ``ev_hi`` is a boundary of the schedule the index
+        was built for.  Anything else (another batch size, a split that starts inside a batch, time-unit
+        batching with a size-based index) would silently return wrong neighbours: refuse it."""
+        if self._csr_bounds is not None:
+            ok = ev_hi in self._csr_bounds or ev_hi >= self._csr.num_edges
+        else:
+            ok = ev_hi >= self._csr_first and (ev_hi - self._csr_first) % self._batch_size == 0 or ev_hi >= self._csr.num_edges
+        if not ok:
+            raise ValueError(
+                f"mode='csr': the batch starts at edge {ev_hi}, which is not a boundary of the schedule the index was built for "
+                f'(first edge {self._csr_first}, ' + (f'batch_size {self._batch_size}' if self._csr_bounds is None else 'explicit batch_starts')
+                + "). Build the hook with this loader's batch_size / batch_starts, or use mode='ring'."
+            )
+
+    def _ensure_scratch(self, n_edges: int, device: torch.device) -> None:
+        """Ring-update scratch for batches of up to ``n_edges`` edges (grown, never shrunk)."""
+        if n_edges > self._scratch_edges:
+            need = int(_native.load().tgmx_ring_update_scratch_bytes(n_edges, 1 if self._directed else 0))
+            if need == 0:
+                _native.check(-2, 'tgmx_ring_update_scratch_bytes')
+            # torch allocations are 256-byte aligned; zeros: the head of the scratch holds a self-resetting barrier
+            self._scratch = torch.zeros(need, dtype=torch.uint8, device=device)
+            self._scratch_edges = n_edges
+            self._step.scratch = self._scratch.data_ptr()
+
+    def _note_batch_time(self, dg: DGraph, batch: DGBatch) -> None:
+        """The reference warns when a query is older than everything the buffers hold (recency.py:242-251:
+        ``query_times.min() < self._nbr_times.min()``, a scan of the whole [N, B] buffer per hop -- whose minimum is 0 until
+        every slot of every node has been written, so it practically never fires).  What it guards against is batches
+        arriving out of chronological order; that is tracked here in O(1) from the store's host timeline: warn (once per
+        epoch) when a batch starts before the previous one did."""
+        lo = batch._event_lo
+        store = getattr(dg, '_storage', None)
+        times = getattr(store, '_time_np', None)
+        if lo is None or times is None or lo >= len(times):
+            return
+        t0 = int(times[lo])
+        if t0 < self._last_batch_t and not self._warned_order:
+            self._warned_order = True
+            logger.warning(
+                f'RecencyNeighborHook: this batch starts at t={t0}, behind the previous batch (t={self._last_batch_t}). '
+                'Results may be incomplete or incorrect. This hook assumes queries are processed in chronological order: '
+                '(1) the dataloader must return batches sorted by timestamp, (2) batches must not be shuffled, '
+                '(3) reset the hook state between datasets / epochs / evaluation runs.'
+            )
+        self._last_batch_t = t0
 
     # ------------------------------------------------------------------
     def __call__(self, dg: DGraph, batch: DGBatch) -> DGBatch:
@@ -321,6 +380,7 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
         if len(groups) > _native.MAX_SEED_GROUPS or L > _native.MAX_HOPS:
             raise ValueError(f'at most {_native.MAX_SEED_GROUPS} seed groups and {_native.MAX_HOPS} hops are supported')
         self._ensure_state(dg, device)
+        self._note_batch_time(dg, batch)
         if getattr(dg, '_storage', None) is not self._bound_store:  # another graph: its timestamps may be larger
             self._refresh_ts_bound(dg)
         D = self._edge_x_dim
@@ -333,8 +393,9 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
             if not ring_mode:
                 if batch._edge_lo is None:
                     raise ValueError("mode='csr' needs batches materialized by tgm_amd.DGraph (batch._edge_lo is unset)")
-                self._ensure_csr(dg, batch)
                 ev_hi = int(batch._edge_lo)
+                self._ensure_csr(dg, ev_hi)
+                self._check_csr_boundary(ev_hi)
                 if self._epoch_lo is None:
                     self._epoch_lo = ev_hi
                 st.ev_lo, st.ev_hi = self._epoch_lo, ev_hi
@@ -379,14 +440,7 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
             n_edges = batch.edge_src.shape[0] if ring_mode else 0
             keep = None
             if n_edges:
-                if n_edges > self._scratch_edges:
-                    need = int(lib.tgmx_ring_update_scratch_bytes(n_edges, 1 if self._directed else 0))
-                    if need == 0:
-                        _native.check(-2, 'tgmx_ring_update_scratch_bytes')
-                    # torch allocations are 256-byte aligned; zeros: the head of the scratch holds a self-resetting barrier
-                    self._scratch = torch.zeros(need, dtype=torch.uint8, device=device)
-                    self._scratch_edges = n_edges
-                    st.scratch = self._scratch.data_ptr()
+                self._ensure_scratch(n_edges, device)
                 ex = batch.edge_x
                 if ex is not None and D:
                     if ex.dtype != torch.float32 or not ex.is_contiguous():
@@ -479,15 +533,12 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
             n = seed.shape[0]
             mask[node_attr] = (offset, n)
             offset += n
-        # the index ranges only depend on the group sizes: build them once per layout
-        layout = (device, tuple(mask.items()))
-        cached = self._mask_cache.get(layout)
-        if cached is None:
-            cached = {k: torch.arange(o, o + n, device=device) for k, (o, n) in mask.items()}
-            if len(self._mask_cache) > 64:
-                self._mask_cache.clear()
-            self._mask_cache[layout] = cached
-        mask = dict(cached)
+        # fresh per batch, like the reference (recency.py:221-224): ONE arange (one launch) and a window of it per key
+        if offset and device.type == 'cuda':
+            whole = torch.arange(offset, device=device)
+            mask = {k: whole.narrow(0, o, n) for k, (o, n) in mask.items()}
+        else:
+            mask = {k: torch.arange(o, o + n, device=device) for k, (o, n) in mask.items()}
         if not concat:
             return seeds, times, mask  # ring mode: the groups are concatenated by the step call itself
         if seeds:
