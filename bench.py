@@ -57,7 +57,7 @@ def parse_args():
     p.add_argument('--mode', default='ring', choices=['ring', 'csr'])
     p.add_argument('--cpu-batches', type=int, default=8, help='batches of the CPU-baseline sample PER thread setting (0 = skip); ~0.1-0.3 s each')
     p.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
-    p.add_argument('--pool', type=int, default=4, help='DGDataLoader(output_pool=): ring of preallocated output sets, one native call per batch; '
+    p.add_argument('--pool', type=int, default=1, help='DGDataLoader(output_pool=): ring of preallocated output sets, one native call per batch; '
                    '0 = hook-by-hook path with fresh tensors per batch (the reference-semantics default of the library)')
     p.add_argument('--validate', default='deferred', choices=['deferred', 'sync', 'off'], help="seed validation mode of the hook ('sync' = its default: a device->host read per batch)")
     p.add_argument('--start-frac', type=float, default=0.5, help='fraction of the stream replayed untimed before the warm-up (ring fill)')

@@ -55,7 +55,7 @@ typedef struct tgmx_adj {
 int tgmx_version(void);
 /* sizeof of the argument structs as this library was compiled (a binding checks its own mirror against it):
  * 0 tgmx_adj_t, 1 tgmx_recency_step_t, 2 tgmx_tgat_layer_t, 3 tgmx_tgat_model_t, 4 tgmx_tgat_hop_t, 5 tgmx_tgat_layout_t,
- * 6 tgmx_pipeline_t, 7 tgmx_pipeline_out_t */
+ * 6 tgmx_pipeline_t, 7 tgmx_pipeline_out_t, 8 tgmx_dropout_t */
 size_t tgmx_abi_sizeof(int32_t which);
 const char* tgmx_last_error(void);
 
@@ -286,6 +286,21 @@ int tgmx_csr_build(const int32_t* src, const int32_t* dst, const int64_t* ts, in
  * tgm_amd/nn/tgat.py in the order of tgm/nn/encoder/tgat.py:95-149.
  * ------------------------------------------------------------------------ */
 
+/* nn.Dropout(p) in training mode as a counter-based mask (attention.py:119,126; PyG TransformerConv's dropout on the
+ * attention weights): element i of the tensor a site covers is kept iff the 32 random bits of (seed, stream, row0 * width
+ * + i) are >= floor(p * 2^32), and scaled by 1 / (1 - p).  Nothing is stored: the backward entry points regenerate the
+ * mask from the same descriptor.  p = 0 (or a NULL descriptor): dropout off. */
+typedef struct tgmx_dropout {
+  float p;
+  uint64_t seed;
+  uint64_t stream; /* one value per (forward call, site) */
+  int64_t row0;    /* index of the first row this call covers within the site's tensor (level-by-level calls) */
+} tgmx_dropout_t;
+
+/* out[r, c] = x[r, c] * mask(r, c) / (1 - p), c < C  (in place when out == x; forward on a tensor, backward on its gradient) */
+int tgmx_dropout(const float* x, int64_t ldx, int64_t R, int32_t C, const tgmx_dropout_t* drop, float* out, int64_t ldo,
+                 tgmx_stream_t stream);
+
 /* out[n, T] = cos(fma(float(x[i]), w[t], b[t]))        Time2Vec.forward
  * (tgm/nn/modules/time_encoding.py:22-24); x is int64 (x_is_int64) or float32. */
 int tgmx_time2vec(const void* x, int32_t x_is_int64, const float* w, const float* b, int32_t T,
@@ -321,7 +336,8 @@ int tgmx_tgat_attn_reduce(const float* qf, const float* nbrf, int32_t d, const f
                           const float* tw, const float* tb, const float* nbr_time_feat,
                           const uint8_t* mask, int32_t T, int32_t H, int32_t k, int64_t R,
                           float scale, int32_t head_stride /* floats between heads in qf / zbar rows, 0 = C */,
-                          float* zbar, float* attn_probs /* optional [R,H,k]: softmax weights, for backward */,
+                          float* zbar, float* attn_probs /* optional [R,H,k]: softmax weights BEFORE dropout, for backward */,
+                          const tgmx_dropout_t* drop /* NULL = off; element (r, h, s) of [R, H, k], attention.py:119 */,
                           tgmx_stream_t stream);
 
 /* out[R, O + d0] = [LayerNorm(y + res) * gamma + beta | z0]
@@ -362,6 +378,9 @@ typedef struct tgmx_tgat_model {
   const float* tb; /* [T] time_encoder.w.bias   */
   int32_t num_layers, d0;
   tgmx_tgat_layer_t layers[TGMX_TGAT_MAX_LAYERS];
+  /* training (save != 0) with dropout: p and seed; `stream` = the forward call's counter -- layer j (1-based) uses
+   * stream * 64 + 2 j for the attention weights and stream * 64 + 2 j + 1 for the W_O output (attention.py:119,126) */
+  tgmx_dropout_t drop;
 } tgmx_tgat_model_t;
 typedef struct tgmx_tgat_hop {
   const int64_t* seed_t; /* [rows_i]        seed_times[i]    */
@@ -426,7 +445,8 @@ int tgmx_tgat_attn_backward(const float* qf, const float* probs, const float* dz
                             int32_t d, const float* ex, int32_t D, const int64_t* seed_t,
                             const int64_t* nbr_t, const float* tw, const float* tb, int32_t T, int32_t H,
                             int32_t k, int64_t R, float scale, int32_t head_stride, float* dqf,
-                            float* dnbr, float* dtime_rows, tgmx_stream_t stream);
+                            float* dnbr, float* dtime_rows, const tgmx_dropout_t* drop /* the forward's, NULL = off */,
+                            tgmx_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * TGN memory module (tgm/nn/encoder/tgn.py:80-251), forward arithmetic.
@@ -481,6 +501,8 @@ int tgmx_segment_sort(const int64_t* key, int64_t n, int32_t num_keys, int64_t* 
 int tgmx_tconv_attend(const float* q, const float* k, const float* v, const float* eproj,
                       const int64_t* order, const int64_t* src, const int64_t* seg_lo,
                       const int64_t* seg_hi, int64_t U, int32_t H, int32_t C, float scale, float* out,
+                      const tgmx_dropout_t* drop /* training: dropout on the coefficients after the softmax, element
+                                                    e * H + h (PyG TransformerConv dropout=; tgn.py:25-27 uses 0.1); NULL = off */,
                       tgmx_stream_t stream);
 
 /* ------------------------------------------------------------------------
@@ -549,7 +571,7 @@ int tgmx_tconv_edge_attr_backward(const int64_t* last_update_local, const int64_
 int tgmx_tconv_attend_backward(const float* q, const float* k, const float* v, const float* eproj, const int64_t* order,
                                const int64_t* src, const int64_t* seg_lo, const int64_t* seg_hi, int64_t U, int32_t H,
                                int32_t C, float scale, const float* dout, float* dq, float* dk, float* dv, float* de,
-                               tgmx_stream_t stream);
+                               const tgmx_dropout_t* drop /* the forward's, NULL = off */, tgmx_stream_t stream);
 
 #ifdef __cplusplus
 }

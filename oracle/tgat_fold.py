@@ -26,10 +26,10 @@ import torch
 import torch.nn.functional as F
 from torch import Tensor
 
-from .tgat_ref import PAD_ID, merge, time2vec
+from .tgat_ref import PAD_ID, layer_dropout, merge, time2vec
 
 
-def temporal_attention_folded(p: Dict[str, Tensor], prefix: str, n_heads: int, node_x, time_feat, edge_feat, nbr_node_feat, nbr_time_feat, mask):
+def temporal_attention_folded(p: Dict[str, Tensor], prefix: str, n_heads: int, node_x, time_feat, edge_feat, nbr_node_feat, nbr_time_feat, mask, drop=None):
     WQ, WKV, WO, bO = p[prefix + 'W_Q.weight'], p[prefix + 'W_KV.weight'], p[prefix + 'W_O.weight'], p[prefix + 'W_O.bias']
     g, be = p[prefix + 'layer_norm.weight'], p[prefix + 'layer_norm.bias']
     O = WQ.shape[0]
@@ -47,13 +47,17 @@ def temporal_attention_folded(p: Dict[str, Tensor], prefix: str, n_heads: int, n
     A = torch.einsum('bhc,bkc->bhk', qf, Z) * dh**-0.5
     A = A.masked_fill(~mask[:, None, :], -1e10)
     A = torch.softmax(A, dim=-1)
+    if drop is not None:
+        A = A * drop[0].to(A.dtype)
     zbar = torch.einsum('bhk,bkc->bhc', A, Z)  # [B, H, C]
     Oattn = torch.cat([zbar[:, h] @ WV[h * dh : (h + 1) * dh].T for h in range(H)], dim=1)  # [B, O]
     out = Oattn @ WO.T + bO
+    if drop is not None:
+        out = out * drop[1].to(out.dtype)
     return F.layer_norm(out + R, (O,), g, be, 1e-5)
 
 
-def tgat_forward_folded(p, n_heads, node_x, seed_nids, seed_times, nbr_nids, nbr_edge_x, nbr_edge_time) -> Tensor:
+def tgat_forward_folded(p, n_heads, node_x, seed_nids, seed_times, nbr_nids, nbr_edge_x, nbr_edge_time, dropout=None) -> Tensor:
     L = len(nbr_nids)
     tw, tb = p['time_encoder.w.weight'], p['time_encoder.w.bias']
     z = {0: {0: node_x[seed_nids[0].long()]}}
@@ -68,6 +72,7 @@ def tgat_forward_folded(p, n_heads, node_x, seed_nids, seed_times, nbr_nids, nbr
                 p, f'attn.{j - 1}.', n_heads, node_x=x, time_feat=time2vec(torch.zeros(n), tw, tb), edge_feat=nbr_edge_x[i],
                 nbr_node_feat=z[j - 1][i + 1].reshape(n, k, -1),
                 nbr_time_feat=time2vec(seed_times[i][:, None] - nbr_edge_time[i], tw, tb), mask=nbr_nids[i] != PAD_ID,
+                drop=layer_dropout(dropout, j, i, [z[0][q].shape[0] for q in range(i)], n, n_heads, k, p[f'attn.{j - 1}.W_Q.weight'].shape[0]),
             )  # fmt: skip
             z[j][i] = merge(p, f'merge_layers.{j - 1}.', out, z[0][i])
     return z[L][0]

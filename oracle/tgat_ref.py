@@ -40,7 +40,8 @@ def time2vec(t: Tensor, w: Tensor, b: Tensor) -> Tensor:
     return torch.cos(arg)
 
 
-def temporal_attention(p: Dict[str, Tensor], prefix: str, n_heads: int, node_x, time_feat, edge_feat, nbr_node_feat, nbr_time_feat, mask):
+def temporal_attention(p: Dict[str, Tensor], prefix: str, n_heads: int, node_x, time_feat, edge_feat, nbr_node_feat, nbr_time_feat, mask, drop=None):
+    """``drop`` = (scale_attn [B, H, k], scale_out [B, O]): train-mode dropout with explicit masks (attention.py:119,126)."""
     WQ, WKV, WO, bO = p[prefix + 'W_Q.weight'], p[prefix + 'W_KV.weight'], p[prefix + 'W_O.weight'], p[prefix + 'W_O.bias']
     g, be = p[prefix + 'layer_norm.weight'], p[prefix + 'layer_norm.bias']
     O = WQ.shape[0]
@@ -58,9 +59,25 @@ def temporal_attention(p: Dict[str, Tensor], prefix: str, n_heads: int, node_x, 
     A = torch.einsum('bhd,bkhd->bhk', Qh, Kh) * dh**-0.5
     A = A.masked_fill(~mask[:, None, :], -1e10)
     A = torch.softmax(A, dim=-1)
+    if drop is not None:
+        A = A * drop[0].to(A.dtype)
     Oattn = torch.einsum('bhk,bkhd->bhd', A, Vh).reshape(B, O)
     out = Oattn @ WO.T + bO
+    if drop is not None:
+        out = out * drop[1].to(out.dtype)
     return F.layer_norm(out + R, (O,), g, be, 1e-5)
+
+
+def layer_dropout(dropout, j: int, level: int, rows_before, n: int, H: int, k: int, O: int):
+    """The two dropout scales of layer j (1-based) for the rows of `level` (tgmx_tgat_model_t.drop: layer j uses stream
+    call * 64 + 2 j for the attention weights and + 1 for the W_O output; a level's rows follow the earlier levels')."""
+    if dropout is None or not dropout[0]:
+        return None
+    from .dropout_ref import dropout_scale
+
+    p_, seed, call = dropout
+    row0 = int(sum(rows_before))
+    return dropout_scale(p_, seed, call * 64 + 2 * j, (n, H, k), row0), dropout_scale(p_, seed, call * 64 + 2 * j + 1, (n, O), row0)
 
 
 def merge(p: Dict[str, Tensor], prefix: str, x1: Tensor, x2: Tensor) -> Tensor:
@@ -77,7 +94,9 @@ def tgat_forward(
     nbr_nids: List[Tensor],
     nbr_edge_x: List[Tensor],
     nbr_edge_time: List[Tensor],
+    dropout=None,
 ) -> Tensor:
+    """``dropout`` = (p, seed, call): train mode with the kernels' counter-based masks (oracle/dropout_ref.py)."""
     L = len(nbr_nids)
     tw, tb = p['time_encoder.w.weight'], p['time_encoder.w.bias']
     # leaves: node_x[ids]; pad id -1 indexes the LAST row, exactly like the reference's fancy indexing
@@ -98,6 +117,7 @@ def tgat_forward(
                 nbr_node_feat=z[j - 1][i + 1].reshape(n, k, -1),
                 nbr_time_feat=time2vec(seed_times[i][:, None] - nbr_edge_time[i], tw, tb),
                 mask=nbr_nids[i] != PAD_ID,
+                drop=layer_dropout(dropout, j, i, [z[0][q].shape[0] for q in range(i)], n, n_heads, k, p[f'attn.{j - 1}.W_Q.weight'].shape[0]),
             )  # fmt: skip
             z[j][i] = merge(p, f'merge_layers.{j - 1}.', out, z[0][i])
     return z[L][0]

@@ -113,11 +113,13 @@ class TGNMemoryRef:
         self.training = True
 
 
-def transformer_conv_ref(p: Dict[str, Tensor], prefix: str, heads: int, x: Tensor, edge_index: Tensor, edge_attr: Tensor) -> Tensor:
+def transformer_conv_ref(p: Dict[str, Tensor], prefix: str, heads: int, x: Tensor, edge_index: Tensor, edge_attr: Tensor, dropout=None) -> Tensor:
     """torch_geometric.nn.TransformerConv (2.6.1) from its published definition -- concat heads,
     root_weight=True, beta=False, eval mode:  out_i = W_skip x_i + b + ||_h sum_j alpha^h_ij (W_v x_j + b_v + W_e e_ij),
     alpha^h_ij = softmax over the edges j->i of (W_q x_i + b_q)^h . (W_k x_j + b_k + W_e e_ij)^h / sqrt(C).
-    UNPINNED: PyG is not installable here, the reference's own tests only check shapes."""
+    UNPINNED: PyG is not installable here, the reference's own tests only check shapes.
+    ``dropout`` = (p, seed, stream): train mode -- PyG applies F.dropout to alpha after the softmax; the mask is the
+    kernels' counter-based one, element (edge e, head h) -> e * heads + h (oracle/dropout_ref.py)."""
     lin = lambda name, v: v @ p[prefix + name + '.weight'].T + (p[prefix + name + '.bias'] if prefix + name + '.bias' in p else 0)
     HC = p[prefix + 'lin_query.weight'].shape[0]
     C = HC // heads
@@ -128,14 +130,21 @@ def transformer_conv_ref(p: Dict[str, Tensor], prefix: str, heads: int, x: Tenso
     val = (v[src] + e).view(-1, heads, C)
     score = (q[tgt].view(-1, heads, C) * key).sum(-1) / C**0.5  # [E, H]
     out = lin('lin_skip', x).clone()
+    keep = None
+    if dropout is not None and dropout[0]:
+        from .dropout_ref import dropout_scale
+
+        keep = dropout_scale(dropout[0], dropout[1], dropout[2], (score.shape[0], heads)).to(score.dtype)
     for i in torch.unique(tgt).tolist():
         m = tgt == i
         a = torch.softmax(score[m], dim=0)  # over the incoming edges of i
+        if keep is not None:
+            a = a * keep[m]
         out[i] += (a[:, :, None] * val[m]).sum(0).reshape(-1)
     return out
 
 
-def graph_attention_embedding_ref(p: Dict[str, Tensor], x, last_update, edge_index, t, msg) -> Tensor:
+def graph_attention_embedding_ref(p: Dict[str, Tensor], x, last_update, edge_index, t, msg, dropout=None) -> Tensor:
     rel_t = last_update[edge_index[0].long()] - t
     enc = time2vec(rel_t, p['time_enc.w.weight'], p['time_enc.w.bias'])
-    return transformer_conv_ref(p, 'conv.', 2, x, edge_index, torch.cat([enc, msg], dim=-1))
+    return transformer_conv_ref(p, 'conv.', 2, x, edge_index, torch.cat([enc, msg], dim=-1), dropout=dropout)

@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda'
 
 
-def _ref_grads(params, n_heads, inputs, dz, dtype):
+def _ref_grads(params, n_heads, inputs, dz, dtype, dropout=None, want_z=False):
     """torch autograd (CPU) through the folded restatement in `dtype`.  Time2Vec is evaluated at the float32
     argument the model uses (float32(dt), one fma rounded to float32; straight-through for the roundings):
     at unix-scale timestamps cos / sin are only meaningful there."""
@@ -27,11 +27,12 @@ def _ref_grads(params, n_heads, inputs, dz, dtype):
     tr.time2vec = tgat_fold.time2vec = t2v
     try:
         z = tgat_fold.tgat_forward_folded(p, n_heads, f(inputs['node_x']), inputs['seed_nids'], inputs['seed_times'], inputs['nbr_nids'],
-                                          [f(x) for x in inputs['nbr_edge_x']], inputs['nbr_edge_time'])  # fmt: skip
+                                          [f(x) for x in inputs['nbr_edge_x']], inputs['nbr_edge_time'], dropout=dropout)  # fmt: skip
     finally:
         tr.time2vec = tgat_fold.time2vec = old
     (z * dz.to(dtype)).sum().backward()
-    return {k: v.grad.float() for k, v in p.items()}
+    grads = {k: v.grad.float() for k, v in p.items()}
+    return (grads, z.detach().float()) if want_z else grads
 
 
 def _worst(enc, g_ref):
@@ -87,5 +88,80 @@ def test_tgat_training_step_reduces_loss():
         opt.step()
         losses.append(float(loss.detach()))
     assert losses[-1] < 0.8 * losses[0] and all(b < a * 1.05 for a, b in zip(losses, losses[1:])), losses
-    with pytest.raises(NotImplementedError):
-        TGAT(edge_dim=meta['edge_dim'], num_layers=2, dropout=0.1, **meta['dims']).to(DEV).train()(**args)
+
+
+@pytest.mark.parametrize('case', ['g5_tgat_small_nd8', 'g5_tgat_example_dims'])
+def test_tgat_train_mode_dropout_forward_and_gradients(case):
+    """The reference's DEFAULT training configuration (dropout = 0.1 on the attention weights and on the W_O output,
+    attention.py:119,126; tgat.py:67): forward and every parameter gradient against torch autograd through the oracle
+    run with exactly the masks the device drew (oracle/dropout_ref.py restates the counter-based generator)."""
+    from tgm_amd.nn import TGAT
+
+    meta, params, inputs, z_eval = gu.tgat_case(case)
+    enc = TGAT(edge_dim=meta['edge_dim'], num_layers=len(meta['num_nbrs']), **meta['dims']).to(DEV).train()  # dropout: the default 0.1
+    assert enc.attn[0].dropout.p == pytest.approx(0.1)
+    enc.load_state_dict(params)
+    dev = lambda v: [t.to(DEV) for t in v] if isinstance(v, list) else v.to(DEV)
+    args = {k: dev(v) for k, v in inputs.items()}
+    torch.manual_seed(0)
+    dz = torch.randn(z_eval.shape)
+    for call in (1, 2):  # a fresh mask per call
+        enc.zero_grad()
+        z = enc(**args)
+        z.backward(dz.to(DEV))
+        assert enc._drop_calls == call
+        drop = (0.1, enc._drop_seed, call)
+        g64, z64 = _ref_grads(params, meta['dims']['n_heads'], inputs, dz, torch.float64, dropout=drop, want_z=True)
+        assert ((z.detach().cpu() - z64).abs() <= 1e-5 * z64.abs().clamp(min=1)).all(), 'train-mode forward'
+        assert not torch.allclose(z.detach().cpu(), z_eval, atol=1e-3), 'dropout had no effect'
+        w64 = _worst(enc, g64)
+        w32 = _worst(enc, _ref_grads(params, meta['dims']['n_heads'], inputs, dz, torch.float32, dropout=drop)) if w64[1] > 1e-4 else w64
+        assert min(w64[1], w32[1]) <= 1e-4, f'{case} call {call}: worst rel err vs fp64 {w64}, vs fp32 {w32}'
+    # eval mode is untouched by all of this
+    z_e = enc.eval()(**args)
+    assert ((z_e.detach().cpu() - z_eval).abs() <= 1e-5 * z_eval.abs().clamp(min=1)).all()
+
+
+def test_dropout_mask_statistics_and_determinism():
+    """tgmx_dropout: kept fraction ~ 1 - p, kept values scaled by 1 / (1 - p), same (seed, stream) -> same mask, another
+    stream -> another mask; bit-identical to the numpy restatement."""
+    from oracle.dropout_ref import dropout_scale
+    from tgm_amd import _native
+
+    lib = _native.load()
+    R, C, p = 4096, 77, 0.1
+    x = torch.ones((R, C), device=DEV)
+    outs = []
+    for stream in (5, 5, 6):
+        y = torch.empty_like(x)
+        _native.check(lib.tgmx_dropout(x.data_ptr(), C, R, C, _native.dropout_desc(p, 1234, stream), y.data_ptr(), C, _native.stream_ptr()), 'tgmx_dropout')
+        outs.append(y.cpu())
+    assert torch.equal(outs[0], outs[1]) and not torch.equal(outs[0], outs[2])
+    assert torch.equal(outs[0], dropout_scale(p, 1234, 5, (R, C)))
+    kept = (outs[0] != 0).float().mean().item()
+    assert abs(kept - 0.9) < 0.005 and torch.allclose(outs[0][outs[0] != 0], torch.tensor(1 / 0.9))
+
+
+def test_tgat_default_constructor_trains():
+    """the reference-default constructor arguments (dropout 0.1) must train, not raise."""
+    from tgm_amd.nn import TGAT
+
+    meta, params, inputs, _ = gu.tgat_case('g5_tgat_small_nd8')
+    enc = TGAT(edge_dim=meta['edge_dim'], num_layers=2, **meta['dims']).to(DEV).train()
+    enc.load_state_dict(params)
+    dev = lambda v: [t.to(DEV) for t in v] if isinstance(v, list) else v.to(DEV)
+    args = {k: dev(v) for k, v in inputs.items()}
+    torch.manual_seed(1)
+    target = torch.randn(30, meta['dims']['embed_dim'], device=DEV)
+    opt = torch.optim.Adam(enc.parameters(), lr=1e-2)
+    losses = []
+    for _ in range(60):
+        opt.zero_grad()
+        loss = ((enc(**args) - target) ** 2).mean()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert sum(losses[-10:]) < 0.8 * sum(losses[:10]), losses
+    with torch.no_grad():  # train mode under no_grad still applies dropout, like nn.Dropout
+        a, b = enc(**args), enc(**args)
+    assert not torch.equal(a, b)

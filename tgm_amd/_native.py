@@ -50,7 +50,7 @@ SIGNATURES = {
     ),
     'tgmx_tgat_attn_reduce': (
         c_int32,
-        [_P, _P, c_int32, _P, c_int32, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int64, ctypes.c_float, c_int32, _P, _P, _P],
+        [_P, _P, c_int32, _P, c_int32, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int64, ctypes.c_float, c_int32, _P, _P, _P, _P],
     ),
     'tgmx_tgn_store': (c_int32, [_P, _P, _P, _P, _P, _P, _P, c_int32, c_int64, c_int64, _P, _P, _P, _P, _P, _P]),
     'tgmx_tgn_aggregate': (
@@ -60,7 +60,7 @@ SIGNATURES = {
     'tgmx_tgn_gru_gate': (c_int32, [_P, _P, _P, c_int32, c_int64, _P, _P]),
     'tgmx_tgn_commit': (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int64, _P, _P, _P]),
     'tgmx_tconv_edge_attr': (c_int32, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int64, _P, _P]),
-    'tgmx_tconv_attend': (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, ctypes.c_float, _P, _P]),
+    'tgmx_tconv_attend': (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, ctypes.c_float, _P, _P, _P]),
     'tgmx_gcn_norm_dense': (c_int32, [_P, _P, _P, c_int64, c_int64, ctypes.c_float, c_int32, _P, c_int64, _P, _P]),
     'tgmx_tgcn_concat': (c_int32, [_P, c_int64, _P, _P, c_int32, c_int64, _P, _P]),
     'tgmx_tgcn_output': (c_int32, [_P, _P, _P, c_int64, _P, _P]),
@@ -75,12 +75,27 @@ SIGNATURES = {
     'tgmx_ln_backward': (c_int32, [_P, c_int64, _P, c_int64, _P, c_int64, _P, c_int32, ctypes.c_float, c_int64, _P, c_int64, _P, c_int64, _P]),
     'tgmx_tgat_attn_backward': (
         c_int32,
-        [_P, _P, _P, _P, c_int32, _P, c_int32, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int64, ctypes.c_float, c_int32, _P, _P, _P, _P],
+        [_P, _P, _P, _P, c_int32, _P, c_int32, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int64, ctypes.c_float, c_int32, _P, _P, _P, _P, _P],
     ),
+    'tgmx_dropout': (c_int32, [_P, c_int64, c_int64, c_int32, _P, _P, c_int64, _P]),
     'tgmx_ln_residual_concat': (c_int32, [_P, c_int64, _P, c_int64, _P, _P, c_int32, ctypes.c_float, _P, c_int32, c_int64, _P, c_int64, _P]),
 }
 
 TGAT_MAX_LAYERS = 4
+
+
+class Dropout(ctypes.Structure):
+    """tgmx_dropout_t (include/tgm_amd.h)."""
+
+    _fields_ = [('p', ctypes.c_float), ('seed', ctypes.c_uint64), ('stream', ctypes.c_uint64), ('row0', c_int64)]
+
+
+def dropout_desc(p: float, seed: int, stream: int, row0: int = 0):
+    """byref(tgmx_dropout_t) for an active dropout site, None (NULL) when p == 0."""
+    if not p:
+        return None
+    d = Dropout(float(p), seed & 0xFFFFFFFFFFFFFFFF, stream & 0xFFFFFFFFFFFFFFFF, row0)
+    return ctypes.byref(d)
 
 
 class TgatLayer(ctypes.Structure):
@@ -90,7 +105,7 @@ class TgatLayer(ctypes.Structure):
 
 
 class TgatModel(ctypes.Structure):
-    _fields_ = [('tw', c_void_p), ('tb', c_void_p), ('num_layers', c_int32), ('d0', c_int32), ('layers', TgatLayer * TGAT_MAX_LAYERS)]
+    _fields_ = [('tw', c_void_p), ('tb', c_void_p), ('num_layers', c_int32), ('d0', c_int32), ('layers', TgatLayer * TGAT_MAX_LAYERS), ('drop', Dropout)]
 
 
 class TgatHop(ctypes.Structure):
@@ -164,7 +179,7 @@ SIGNATURES['tgmx_ring_update_scratch_bytes'] = (c_size_t, [c_int64, c_int32])
 SIGNATURES['tgmx_tgn_gru_gate_backward'] = (c_int32, [_P, _P, _P, _P, c_int32, c_int64, _P, _P, _P])
 SIGNATURES['tgmx_tgn_aggregate_backward'] = (c_int32, [c_int64, _P, _P, _P, _P, _P, _P, c_int32, c_int32, _P, _P, c_int32, c_int32, _P, _P, _P])
 SIGNATURES['tgmx_tconv_edge_attr_backward'] = (c_int32, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int64, _P, _P])
-SIGNATURES['tgmx_tconv_attend_backward'] = (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, ctypes.c_float, _P, _P, _P, _P, _P, _P])
+SIGNATURES['tgmx_tconv_attend_backward'] = (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, ctypes.c_float, _P, _P, _P, _P, _P, _P, _P])
 SIGNATURES['tgmx_group_ids'] = (c_int32, [_P, c_int32, _P, _P, _P, _P, _P, _P])
 SIGNATURES['tgmx_random_negatives'] = (c_int32, [c_int32, c_int32, c_int64, ctypes.c_uint64, ctypes.c_uint64, _P, _P, c_int64, _P, _P])
 SIGNATURES['tgmx_unique_ids_workspace_bytes'] = (c_size_t, [c_int32])

@@ -84,19 +84,22 @@ class DGraph:
         lo, hi = self._storage.edge_range(self._slice)
         return lo, max(lo, hi)
 
+    # (the reference writes the derived bound back into its slice tracker, graph.py:160-176; here the slice keeps only the
+    # bounds the caller asked for -- the derived ones are implied by the index range, and a slice without time bounds is
+    # what lets the loader address batches as plain edge ranges)
     @cached_property
     def start_time(self) -> Optional[int]:
-        if self._slice.start_time is None:
-            lb, ub = self._event_range
-            self._slice.start_time = None if lb >= ub else self._storage.time_at(lb)
-        return self._slice.start_time
+        if self._slice.start_time is not None:
+            return self._slice.start_time
+        lb, ub = self._event_range
+        return None if lb >= ub else self._storage.time_at(lb)
 
     @cached_property
     def end_time(self) -> Optional[int]:
-        if self._slice.end_time is None:
-            lb, ub = self._event_range
-            self._slice.end_time = None if lb >= ub else self._storage.time_at(ub - 1)
-        return self._slice.end_time
+        if self._slice.end_time is not None:
+            return self._slice.end_time
+        lb, ub = self._event_range
+        return None if lb >= ub else self._storage.time_at(ub - 1)
 
     @cached_property
     def num_events(self) -> int:

@@ -27,6 +27,7 @@ extern "C" size_t tgmx_abi_sizeof(int32_t which) {
     case 5: return sizeof(tgmx_tgat_layout_t);
     case 6: return sizeof(tgmx_pipeline_t);
     case 7: return sizeof(tgmx_pipeline_out_t);
+    case 8: return sizeof(tgmx_dropout_t);
     default: return 0;
   }
 }

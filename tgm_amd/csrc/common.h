@@ -47,13 +47,50 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
 // RandomNegativeEdgeSamplerHook's draw i of call `call` (tgm/hooks/negatives/sampler.py:45-65: uniform ids in [low, low + range)):
 // a counter-based generator, so the stand-alone kernel (dedup.hip) and the seed fetch of the lookup kernels (recency.hip,
 // negatives generated in place) produce the same ids
-__device__ __forceinline__ int negative_draw(unsigned long long seed, unsigned long long call, unsigned long long i, int low, unsigned range) {
-  unsigned long long x = seed ^ (call * 0x9E3779B97F4A7C15ull) ^ (i * 0xD1B54A32D192ED03ull);
+// counter-based generator: 32 uniform bits for (seed, stream, index) -- a splitmix64 finaliser over the mixed counter
+__host__ __device__ __forceinline__ unsigned counter_u32(unsigned long long seed, unsigned long long stream, unsigned long long i) {
+  unsigned long long x = seed ^ (stream * 0x9E3779B97F4A7C15ull) ^ (i * 0xD1B54A32D192ED03ull);
   x += 0x9E3779B97F4A7C15ull;
   x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
   x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
   x ^= x >> 31;
-  return low + (int)__umulhi((unsigned)(x >> 32), range);  // uniform up to 2^-32 * range
+  return (unsigned)(x >> 32);
+}
+__device__ __forceinline__ int negative_draw(unsigned long long seed, unsigned long long call, unsigned long long i, int low, unsigned range) {
+  return low + (int)__umulhi(counter_u32(seed, call, i), range);  // uniform up to 2^-32 * range
+}
+
+// nn.Dropout(p) as a counter-based mask: element i of stream `stream` is kept iff its 32 random bits are >= thresh =
+// floor(p * 2^32); kept elements are scaled by inv = 1 / (1 - p).  The backward passes regenerate the mask from the same
+// (seed, stream, i) instead of storing it.  thresh == 0: dropout off (every element kept, scale 1).
+struct DropoutArgs {
+  unsigned thresh;
+  float inv;
+  unsigned long long seed, stream;
+};
+__device__ __forceinline__ float dropout_scale(const DropoutArgs& d, unsigned long long i) {
+  if (d.thresh == 0) return 1.f;
+  return counter_u32(d.seed, d.stream, i) >= d.thresh ? d.inv : 0.f;
+}
+inline DropoutArgs make_dropout(const tgmx_dropout_t* t) {
+  DropoutArgs d{0u, 1.f, 0ull, 0ull};
+  if (t && t->p > 0.f) {
+    const double th = (double)t->p * 4294967296.0;
+    d.thresh = th >= 4294967295.0 ? 4294967295u : (unsigned)th;
+    d.inv = (float)(1.0 / (1.0 - (double)t->p));
+    d.seed = t->seed;
+    d.stream = t->stream;
+  }
+  return d;
+}
+inline DropoutArgs make_dropout(float p, unsigned long long seed, unsigned long long stream) {
+  DropoutArgs d{0u, 1.f, seed, stream};
+  if (p > 0.f) {
+    const double t = (double)p * 4294967296.0;
+    d.thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+    d.inv = (float)(1.0 / (1.0 - (double)p));
+  }
+  return d;
 }
 
 // cos(x) for Time2Vec arguments (float32 x up to ~2^31 * w).  A row's 100 frequencies span 9 decades, so the

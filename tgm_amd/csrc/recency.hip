@@ -24,6 +24,7 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <hip/hip_ext.h>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 
@@ -1221,6 +1222,15 @@ __global__ __launch_bounds__(256) void lookup_packed_kernel(const LookupArgs a, 
 }
 
 // gather width (floats per load) for this launch's alignment; fills row_vecs and the slot divider
+// A launch that may be timed: with an event pair the kernel goes through hipExtLaunchKernelGGL, whose events carry the
+// dispatch's OWN begin / end timestamps (what rocprofv3 --kernel-trace reports); hipEventRecord before / after the launch
+// brackets it from outside and adds the command processor's event handling (~4-6 us under a full queue)
+#define TGMX_LAUNCH_TIMED(KERNEL, GRID, BLOCK, LDS, STREAM, E0, E1, ...)                          \
+  do {                                                                                           \
+    if ((E0) && (E1)) hipExtLaunchKernelGGL(KERNEL, GRID, BLOCK, (uint32_t)(LDS), STREAM, E0, E1, 0, __VA_ARGS__); \
+    else hipLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, __VA_ARGS__);                      \
+  } while (0)
+
 static int prepare_lookup(LookupArgs& a, const float* out_x, int kmax) {
   int vec = 1;
   if (a.D > 0) {
@@ -1259,8 +1269,7 @@ static int launch_lookup(LookupArgs a, hipStream_t stream, hipEvent_t ev_start, 
   const dim3 grid((unsigned)blocks + a.side_blocks), block(waves_per_block * kWave);
   const size_t lds = (size_t)waves_per_block * a.k * sizeof(int);
 #define TGMX_LAUNCH(VEC_, SMALL_) \
-  hipLaunchKernelGGL((recency_lookup_kernel<RING, VEC_, SMALL_>), grid, block, lds, stream, a, u)
-  if (ev_start) (void)hipEventRecord(ev_start, stream);
+  TGMX_LAUNCH_TIMED((recency_lookup_kernel<RING, VEC_, SMALL_>), grid, block, lds, stream, ev_start, ev_stop, a, u)
   // narrow rows: several seeds per wave (streaming rings, plain seed arrays)
   const int gl = a.grp.groups == 0 ? packed_group_lanes(a, a.k, true) : 64;
   if (gl < 64) {
@@ -1271,8 +1280,8 @@ static int launch_lookup(LookupArgs a, hipStream_t stream, hipEvent_t ev_start, 
     const size_t plds = (size_t)waves_per_block * per_wave * a.k * sizeof(int);
 #define TGMX_PACKED(VEC_)                                                                              \
   do {                                                                                                 \
-    if (gl == 16) hipLaunchKernelGGL((lookup_packed_kernel<RING, VEC_, 16>), pgrid, block, plds, stream, a, u); \
-    else hipLaunchKernelGGL((lookup_packed_kernel<RING, VEC_, 32>), pgrid, block, plds, stream, a, u);          \
+    if (gl == 16) TGMX_LAUNCH_TIMED((lookup_packed_kernel<RING, VEC_, 16>), pgrid, block, plds, stream, ev_start, ev_stop, a, u); \
+    else TGMX_LAUNCH_TIMED((lookup_packed_kernel<RING, VEC_, 32>), pgrid, block, plds, stream, ev_start, ev_stop, a, u);          \
   } while (0)
     if (vec == 4) TGMX_PACKED(4);
     else if (vec == 2) TGMX_PACKED(2);
@@ -1288,7 +1297,6 @@ static int launch_lookup(LookupArgs a, hipStream_t stream, hipEvent_t ev_start, 
     else TGMX_LAUNCH(1, false);
   }
 #undef TGMX_LAUNCH
-  if (ev_stop) (void)hipEventRecord(ev_stop, stream);
   TGMX_CHECK_LAUNCH("recency_lookup");
   return TGMX_OK;
 }
@@ -1310,11 +1318,9 @@ static int launch_fused01(LookupArgs a, hipStream_t stream, hipEvent_t ev_start,
   if (blocks > (1 << 20)) blocks = 1 << 20;
   const dim3 grid((unsigned)blocks + a.side_blocks), block(waves_per_block * kWave);
   const size_t lds = (size_t)waves_per_block * kmax * sizeof(int);
-  if (ev_start) (void)hipEventRecord(ev_start, stream);
-  if (vec == 4) hipLaunchKernelGGL((recency_lookup_fused01_kernel<RING, 4>), grid, block, lds, stream, a, u);
-  else if (vec == 2) hipLaunchKernelGGL((recency_lookup_fused01_kernel<RING, 2>), grid, block, lds, stream, a, u);
-  else hipLaunchKernelGGL((recency_lookup_fused01_kernel<RING, 1>), grid, block, lds, stream, a, u);
-  if (ev_stop) (void)hipEventRecord(ev_stop, stream);
+  if (vec == 4) TGMX_LAUNCH_TIMED((recency_lookup_fused01_kernel<RING, 4>), grid, block, lds, stream, ev_start, ev_stop, a, u);
+  else if (vec == 2) TGMX_LAUNCH_TIMED((recency_lookup_fused01_kernel<RING, 2>), grid, block, lds, stream, ev_start, ev_stop, a, u);
+  else TGMX_LAUNCH_TIMED((recency_lookup_fused01_kernel<RING, 1>), grid, block, lds, stream, ev_start, ev_stop, a, u);
   TGMX_CHECK_LAUNCH("recency_lookup_fused01");
   return TGMX_OK;
 }

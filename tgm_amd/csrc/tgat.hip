@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void sgemm_nt_kernel(const GemmArgs g) {
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ table, long long rows, int dim,
                                                           const int32_t* __restrict__ idx, long long n,
-                                                          float* __restrict__ out, long long ldo) {
+                                                          float* out, long long ldo) {
   const long long total = n * dim;
   const long long step = (long long)gridDim.x * blockDim.x;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += step) {
@@ -504,7 +504,9 @@ struct AttnArgs {
   int d, D, T, k, C;
   float scale;        // dh^-1/2
   int Cs;             // stride (floats) between consecutive heads of qf / zbar rows (>= C; padded layouts)
-  float* probs;       // optional [R, H, k]: the attention weights, saved for the backward pass
+  float* probs;       // optional [R, H, k]: the attention weights (BEFORE dropout), saved for the backward pass
+  DropoutArgs drop;   // training: dropout on the attention weights (attention.py:119), element index ((row0 + r) * H + h) * k + s
+  long long drop_row0;
   // Several levels of the hop tree in ONE launch (they share the layer's weights; qf / zbar / probs are contiguous
   // across levels).  Rows [seg_begin[i], seg_begin[i + 1]) read level i's sampler outputs; the pointers are biased by
   // the host so that the GLOBAL row index addresses them (ex_i - seg_begin[i] * k * D, ...).  n_seg <= 1: the plain
@@ -685,6 +687,10 @@ __global__ __launch_bounds__(256) void tgat_attn_reduce_kernel(const AttnArgs a)
 
   if (a.probs)
     for (int e = lane; e < H * k; e += kWave) a.probs[r * (long long)H * k + e] = s_A[e];
+  if (a.drop.thresh) {
+    for (int e = lane; e < H * k; e += kWave) s_A[e] *= dropout_scale(a.drop, (unsigned long long)(a.drop_row0 + r) * (H * k) + e);
+    __builtin_amdgcn_wave_barrier();
+  }
   // ---- pass 2: zbar[h][c] = sum_s A[h][s] z[s][c]  (features re-read: L1/L2 hits) ----
   // slots are consumed 8 at a time so that 8 independent loads are in flight per lane
   float* __restrict__ zb = a.zbar + r * (long long)H * a.Cs;
@@ -869,8 +875,9 @@ __global__ __launch_bounds__(256) void tgat_attn_reduce_reg_kernel(const AttnArg
   float sum = ev;
 #pragma unroll
   for (int o = H; o < 64; o <<= 1) sum += __shfl_xor(sum, o);
-  const float A = ev / sum;
+  float A = ev / sum;
   if (a.probs && live) a.probs[r * (long long)H * k + (lane - js * H) * k + js] = A;
+  if (a.drop.thresh && live) A *= dropout_scale(a.drop, (unsigned long long)(a.drop_row0 + r) * (H * k) + (lane - js * H) * k + js);
 
   // ---- zbar[h] = sum_s A[h][s] z[s], from registers ----
   float* __restrict__ zb = a.zbar + r * (long long)H * a.Cs;
@@ -1057,7 +1064,7 @@ extern "C" int tgmx_tgat_attn_reduce(const float* qf, const float* nbrf, int32_t
                                      const int64_t* seed_t, const int64_t* nbr_t, const int32_t* nbr_id, const float* tw,
                                      const float* tb, const float* nbr_time_feat, const uint8_t* mask, int32_t T, int32_t H,
                                      int32_t k, int64_t R, float scale, int32_t head_stride, float* zbar, float* attn_probs,
-                                     tgmx_stream_t stream) {
+                                     const tgmx_dropout_t* drop, tgmx_stream_t stream) {
   TGMX_REQUIRE(d > 0 && D >= 0 && T > 0 && k > 0 && R >= 0, "tgat_attn_reduce: bad sizes d=%d D=%d T=%d k=%d", d, D, T, k);
   TGMX_REQUIRE(H == 1 || H == 2 || H == 4 || H == 8, "tgat_attn_reduce: n_heads=%d unsupported (1, 2, 4 or 8)", H);
   if (R == 0) return TGMX_OK;
@@ -1067,7 +1074,35 @@ extern "C" int tgmx_tgat_attn_reduce(const float* qf, const float* nbrf, int32_t
   TGMX_REQUIRE(head_stride == 0 || head_stride >= d + D + T, "tgat_attn_reduce: head_stride smaller than d + D + T");
   AttnArgs a{qf, nbrf, ex, seed_t, nbr_t, nbr_id, tw, tb, nbr_time_feat, mask, zbar, R, d, D, T, k, d + D + T, scale,
              head_stride ? head_stride : d + D + T, attn_probs};
+  a.drop = make_dropout(drop);
+  a.drop_row0 = drop ? drop->row0 : 0;
   return attn_reduce_impl(a, H, (hipStream_t)stream);
+}
+
+namespace tgmx {
+__global__ __launch_bounds__(256) void dropout_kernel(const float* x, long long ldx, long long R, int C, DropoutArgs d, long long row0,
+                                                      float* out, long long ldo) {
+  const long long total = R * C;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long r = e / C;
+    const int c = (int)(e - r * C);
+    out[r * ldo + c] = x[r * ldx + c] * dropout_scale(d, (unsigned long long)(row0 + r) * C + c);
+  }
+}
+}  // namespace tgmx
+
+extern "C" int tgmx_dropout(const float* x, int64_t ldx, int64_t R, int32_t C, const tgmx_dropout_t* drop, float* out, int64_t ldo,
+                            tgmx_stream_t stream) {
+  TGMX_REQUIRE(R >= 0 && C > 0 && ldx >= C && ldo >= C, "dropout: bad sizes R=%lld C=%d", (long long)R, C);
+  if (R == 0) return TGMX_OK;
+  TGMX_REQUIRE(x && out, "dropout: null pointer");
+  TGMX_REQUIRE(!drop || (drop->p >= 0.f && drop->p < 1.f), "dropout: p must be in [0, 1)");
+  long long blocks = (R * C + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (long long)ldx, (long long)R, C, make_dropout(drop),
+                     drop ? (long long)drop->row0 : 0ll, out, (long long)ldo);
+  TGMX_CHECK_LAUNCH("dropout");
+  return TGMX_OK;
 }
 
 extern "C" int tgmx_time2vec(const void* x, int32_t x_is_int64, const float* w, const float* b, int32_t T, int64_t n,
@@ -1258,6 +1293,7 @@ extern "C" int tgmx_tgat_forward(const tgmx_tgat_model_t* m, const float* node_x
       a.tw = m->tw; a.tb = m->tb;
       a.d = ly.d; a.D = ly.D; a.T = ly.T; a.k = k; a.C = C; a.scale = 1.0f / sqrtf((float)dh); a.Cs = Cp;
       a.n_seg = n_lvl;
+      if (save && m->drop.p > 0.f) a.drop = make_dropout(m->drop.p, m->drop.seed, m->drop.stream * 64 + 2 * (unsigned long long)j);
       for (int i = 0; i < n_lvl; ++i) {
         TGMX_REQUIRE(hops[i].k == k, "tgat_forward: layer %d needs the same k at every hop it aggregates", j);
         TGMX_REQUIRE(rows[i] == 0 || ly.D == 0 || hops[i].edge_x, "tgat_forward: hop %d has no edge features", i);
@@ -1283,6 +1319,10 @@ extern "C" int tgmx_tgat_forward(const tgmx_tgat_model_t* m, const float* node_x
     // Oattn[:, head h] = zbar[:, h, :] @ W_V[head h]^T   (W_V padded copy [O, Cp])
     if ((rc = tgmx_sgemm_nt(zbar, (long long)H * Cp, ly.W_V, Cp, oattn, Op, R, dh, C, nullptr, 0, H, Cp, (long long)dh * Cp, dh, stream))) return rc;
     if ((rc = tgmx_sgemm_nt(oattn, Op, ly.W_O, Op, y, Op, R, O, O, ly.b_O, 0, 1, 0, 0, 0, stream))) return rc;
+    if (save && m->drop.p > 0.f) {  // dropout(W_O(O)) (attention.py:126), in place: the saved y is what the LayerNorm saw
+      const tgmx_dropout_t dy{m->drop.p, m->drop.seed, m->drop.stream * 64 + 2 * (uint64_t)j + 1, 0};
+      if ((rc = tgmx_dropout(y, Op, R, O, &dy, y, Op, stream))) return rc;
+    }
     if ((rc = tgmx_ln_residual_concat(y, Op, rres, Op, ly.ln_g, ly.ln_b, O, ly.ln_eps, z0, d0, R, cat, Kc, stream))) return rc;
     if ((rc = tgmx_sgemm_nt(cat, Kc, ly.fc1_w, Kc, h1, Ep, R, ly.emb, O + d0, ly.fc1_b, 1, 1, 0, 0, 0, stream))) return rc;
     if ((rc = tgmx_sgemm_nt(h1, Ep, ly.fc2_w, Ep, nxt, ld_nxt, R, ly.emb_out, ly.emb, ly.fc2_b, 0, 1, 0, 0, 0, stream))) return rc;

@@ -201,6 +201,8 @@ struct AttnBwdArgs {
   long long R;
   int d, D, T, k, C, Cs;
   float scale;
+  DropoutArgs drop;  // the forward's attention dropout: regenerated, element ((row0 + r) * H + h) * k + s
+  long long drop_row0;
 };
 
 template <int HALF>
@@ -271,16 +273,18 @@ __global__ __launch_bounds__(256) void tgat_attn_backward_kernel(const AttnBwdAr
   bwd_reduce_scatter_step<4>(P, lane);
   bwd_reduce_scatter_step<2>(P, lane);
   bwd_reduce_scatter_step<1>(P, lane);
-  const float dA = P[0];  // lane j = s*H + h
   const int js = lane / H, jh = lane - js * H;
   const bool live = js < k;
+  // zbar used A' = A * mk (dropout on the softmax output, attention.py:119): dA = dA' * mk, and the slot gradients below take A'
+  const float mk = live ? dropout_scale(a.drop, (unsigned long long)(a.drop_row0 + r) * (H * k) + jh * k + js) : 0.f;
+  const float dA = P[0] * mk;  // lane j = s*H + h
   const float A = live ? a.probs[r * (long long)H * k + jh * k + js] : 0.f;
   float dot = A * dA;
 #pragma unroll
   for (int o = H; o < 64; o <<= 1) dot += __shfl_xor(dot, o);
   const float ds = A * (dA - dot);  // softmax backward; masked slots have A == 0
   if (live) {
-    s_A[jh * k + js] = A;
+    s_A[jh * k + js] = A * mk;
     s_ds[jh * k + js] = ds;
   }
   __builtin_amdgcn_wave_barrier();
@@ -428,13 +432,15 @@ extern "C" int tgmx_ln_backward(const float* dout, int64_t ldd, const float* y, 
 extern "C" int tgmx_tgat_attn_backward(const float* qf, const float* probs, const float* dzbar, const float* nbrf, int32_t d,
                                        const float* ex, int32_t D, const int64_t* seed_t, const int64_t* nbr_t, const float* tw,
                                        const float* tb, int32_t T, int32_t H, int32_t k, int64_t R, float scale, int32_t head_stride,
-                                       float* dqf, float* dnbr, float* dtime_rows, tgmx_stream_t stream) {
+                                       float* dqf, float* dnbr, float* dtime_rows, const tgmx_dropout_t* drop, tgmx_stream_t stream) {
   TGMX_REQUIRE(d > 0 && D >= 0 && T > 0 && k > 0 && R >= 0, "tgat_attn_backward: bad sizes");
   TGMX_REQUIRE((H == 1 || H == 2 || H == 4 || H == 8) && k * H <= 64, "tgat_attn_backward: needs n_heads in {1,2,4,8} and k * n_heads <= 64 (k=%d, H=%d)", k, H);
   if (R == 0) return TGMX_OK;
   TGMX_REQUIRE(qf && probs && dzbar && nbrf && (D == 0 || ex) && seed_t && nbr_t && tw && tb && dqf && dtime_rows, "tgat_attn_backward: null pointer");
   const int C = d + D + T;
   AttnBwdArgs a{qf, probs, dzbar, nbrf, ex, seed_t, nbr_t, tw, tb, dqf, dnbr, dtime_rows, R, d, D, T, k, C, head_stride ? head_stride : C, scale};
+  a.drop = make_dropout(drop);
+  a.drop_row0 = drop ? drop->row0 : 0;
   const size_t per_wave = ((size_t)2 * k * T + k + 2 * (size_t)H * k) * sizeof(float);
   int waves = 4;
   while (waves > 1 && per_wave * waves > 64 * 1024) waves >>= 1;

@@ -214,6 +214,7 @@ struct TconvArgs {
   long long U;
   int H, C;
   float scale;
+  DropoutArgs drop;  // training: dropout on the attention coefficients after the softmax (PyG TransformerConv), element e * H + h
 };
 
 // one wave per target node; online softmax over its incoming edges, head by head.  The segment's edge ids and
@@ -251,7 +252,8 @@ __global__ __launch_bounds__(256) void tconv_attend_kernel(const TconvArgs a) {
           const float s = part * a.scale;
           const float mn = s > m ? s : m;
           const float corr = expf(m - mn), w = expf(s - mn);
-          acc = acc * corr + w * val;
+          // the softmax normalises over every incoming edge; dropout then zeroes / rescales single coefficients
+          acc = acc * corr + w * dropout_scale(a.drop, (unsigned long long)e * a.H + h) * val;
           l = l * corr + w;
           m = mn;
         }
@@ -380,11 +382,12 @@ extern "C" int tgmx_tconv_edge_attr(const int64_t* last_update_local, const int6
 
 extern "C" int tgmx_tconv_attend(const float* q, const float* k, const float* v, const float* eproj, const int64_t* order,
                                  const int64_t* src, const int64_t* seg_lo, const int64_t* seg_hi, int64_t U, int32_t H, int32_t C,
-                                 float scale, float* out, tgmx_stream_t stream) {
+                                 float scale, float* out, const tgmx_dropout_t* drop, tgmx_stream_t stream) {
   TGMX_REQUIRE(U >= 0 && H > 0 && C > 0, "tconv_attend: bad sizes");
   if (U == 0) return TGMX_OK;
   TGMX_REQUIRE(q && k && v && eproj && order && src && seg_lo && seg_hi && out, "tconv_attend: null pointer");
   TconvArgs a{q, k, v, eproj, order, src, seg_lo, seg_hi, out, U, H, C, scale};
+  a.drop = make_dropout(drop);
   hipLaunchKernelGGL(tconv_attend_kernel, dim3((unsigned)((U + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
   TGMX_CHECK_LAUNCH("tconv_attend");
   return TGMX_OK;

@@ -155,6 +155,7 @@ struct TconvBwdArgs {
   long long U;
   int H, C;
   float scale;
+  DropoutArgs drop;  // the forward's dropout on the attention coefficients, regenerated: element e * H + h
 };
 
 __global__ __launch_bounds__(256) void tconv_attend_backward_kernel(const TconvBwdArgs a) {
@@ -182,11 +183,11 @@ __global__ __launch_bounds__(256) void tconv_attend_backward_kernel(const TconvB
       const float mn = s > m ? s : m;
       const float corr = expf(m - mn), w = expf(s - mn);
       const float val = on ? a.v[j * HC + col] + a.eproj[e * HC + col] : 0.f;
-      acc = acc * corr + w * val;
+      acc = acc * corr + w * dropout_scale(a.drop, (unsigned long long)e * a.H + h) * val;
       l = l * corr + w;
       m = mn;
     }
-    float delta = go * (acc / l);
+    float delta = go * (acc / l);  // sum_e alpha_e d alpha_e with d alpha_e = mk_e (go . val_e): the dropped output, again
     for (int o = 32; o > 0; o >>= 1) delta += __shfl_xor(delta, o);
     float dqi = 0.f;
     for (long long p = lo; p < hi; ++p) {
@@ -200,12 +201,14 @@ __global__ __launch_bounds__(256) void tconv_attend_backward_kernel(const TconvB
         dal += __shfl_xor(dal, o);
       }
       const float alpha = expf(part * a.scale - m) / l;
-      const float ds = alpha * (dal - delta) * a.scale;
+      const float mk = dropout_scale(a.drop, (unsigned long long)e * a.H + h);
+      const float ds = alpha * (dal * mk - delta) * a.scale;  // softmax backward on the pre-dropout coefficients
       dqi = __fmaf_rn(ds, ke, dqi);
       if (on) {
+        const float ad = alpha * mk;  // the coefficient the value actually got
         atomicAdd(&a.dk[j * HC + col], ds * qi);
-        atomicAdd(&a.dv[j * HC + col], alpha * go);
-        a.de[e * HC + col] = ds * qi + alpha * go;
+        atomicAdd(&a.dv[j * HC + col], ad * go);
+        a.de[e * HC + col] = ds * qi + ad * go;
       }
     }
     if (on) a.dq[i * HC + col] = dqi;
@@ -263,11 +266,12 @@ extern "C" int tgmx_tconv_edge_attr_backward(const int64_t* last_update_local, c
 extern "C" int tgmx_tconv_attend_backward(const float* q, const float* k, const float* v, const float* eproj, const int64_t* order,
                                           const int64_t* src, const int64_t* seg_lo, const int64_t* seg_hi, int64_t U, int32_t H,
                                           int32_t C, float scale, const float* dout, float* dq, float* dk, float* dv, float* de,
-                                          tgmx_stream_t stream) {
+                                          const tgmx_dropout_t* drop, tgmx_stream_t stream) {
   TGMX_REQUIRE(U >= 0 && H > 0 && C > 0 && C <= 64, "tconv_attend_backward: bad sizes (C <= 64)");
   if (U == 0) return TGMX_OK;
   TGMX_REQUIRE(q && k && v && eproj && order && src && seg_lo && seg_hi && dout && dq && dk && dv && de, "tconv_attend_backward: null pointer");
   TconvBwdArgs a{q, k, v, eproj, order, src, seg_lo, seg_hi, dout, dq, dk, dv, de, U, H, C, scale};
+  a.drop = make_dropout(drop);
   hipLaunchKernelGGL(tconv_attend_backward_kernel, dim3((unsigned)((U + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
   TGMX_CHECK_LAUNCH("tconv_attend_backward");
   return TGMX_OK;

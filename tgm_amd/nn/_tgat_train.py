@@ -9,7 +9,8 @@ attention (``oracle/tgat_fold.py``), composed from the kernels of ``csrc/tgat_bw
     LayerNorm, ReLU, per-row attention backward -> dedicated kernels
 
 Gradients are produced for every parameter of the module (not for ``node_x`` or the sampled edge
-features, which are data).  Dropout must be inactive (p == 0 or eval mode).
+features, which are data).  Dropout (train mode): the forward call's ``tgmx_dropout_t`` (p, seed,
+stream) is kept on the context and the backward regenerates both masks of every layer from it.
 """
 from __future__ import annotations
 
@@ -49,6 +50,7 @@ class TGATFunction(torch.autograd.Function):
         )  # fmt: skip
         ctx.module, ctx.lay, ctx.ws, ctx.hop_tensors, ctx.ks, ctx.keep, ctx.S0 = module, lay, ws, hop_tensors, ks, keep, S0
         ctx.n_params = len(params)
+        ctx.drop = (float(model.drop.p), int(model.drop.seed), int(model.drop.stream))  # the model block is shared: copy
         return out
 
     @staticmethod
@@ -60,6 +62,7 @@ class TGATFunction(torch.autograd.Function):
 def _backward(ctx, dz: Tensor) -> List[Tensor]:
     lib = _native.load()
     module, lay, ws, ks = ctx.module, ctx.lay, ctx.ws, ctx.ks
+    drop_p, drop_seed, drop_stream = ctx.drop
     dev = dz.device
     L, d0 = module.num_layers, module.node_dim
     stream = _native.stream_ptr()
@@ -144,12 +147,18 @@ def _backward(ctx, dz: Tensor) -> List[Tensor]:
         g_ln_w, g_ln_b = torch.empty(O, **f32), torch.empty(O, **f32)
         colsum(dgx, R, O, g_ln_w)
         colsum(dcat, R, O, g_ln_b)
-        # ---- W_O ----
+        # ---- W_O (its output went through dropout, attention.py:126: the gradient takes the same mask; the residual
+        # branch below keeps the unmasked du) ----
+        du_y = du
+        if drop_p > 0:
+            du_y = torch.empty((R, Op), **f32)
+            _native.check(lib.tgmx_dropout(du.data_ptr(), Op, R, O, _native.dropout_desc(drop_p, drop_seed, drop_stream * 64 + 2 * j + 1),
+                                           du_y.data_ptr(), Op, stream), 'tgmx_dropout')  # fmt: skip
         g_WO, g_bO = torch.empty_like(W_O), torch.empty(O, **f32)
-        tn(du, oattn, g_WO, R, O, O)
-        colsum(du, R, O, g_bO)
+        tn(du_y, oattn, g_WO, R, O, O)
+        colsum(du_y, R, O, g_bO)
         doattn = torch.empty((R, Op), **f32)
-        nt(du, W_O.t().contiguous(), doattn, R, O, O)
+        nt(du_y, W_O.t().contiguous(), doattn, R, O, O)
         # ---- W_V fold: oattn[:, head h] = zbar[:, h, :] @ W_V[head h]^T ----
         g_WKV = torch.empty_like(WKV)
         g_WK, g_WV = g_WKV[:O], g_WKV[O:]
@@ -176,7 +185,8 @@ def _backward(ctx, dz: Tensor) -> List[Tensor]:
                 lib.tgmx_tgat_attn_backward(
                     qf[o].data_ptr(), probs[o].data_ptr(), dzbar[o].data_ptr(), nbrf.data_ptr(), d, _native.ptr(ex_i), D, st_i.data_ptr(),
                     nt_i.data_ptr(), tw.data_ptr(), tb.data_ptr(), T, H, k, Ri, float(dh) ** -0.5, Cp, dqf[o].data_ptr(),
-                    dprev[level_off[i + 1]].data_ptr() if need_dprev else 0, dtime[o].data_ptr(), stream,
+                    dprev[level_off[i + 1]].data_ptr() if need_dprev else 0, dtime[o].data_ptr(),
+                    _native.dropout_desc(drop_p, drop_seed, drop_stream * 64 + 2 * j, row0=o), stream,
                 ),
                 'tgmx_tgat_attn_backward',
             )  # fmt: skip

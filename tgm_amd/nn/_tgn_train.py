@@ -174,15 +174,16 @@ class TconvAttendFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, q: Tensor, k: Tensor, v: Tensor, eproj: Tensor, skip: Tensor, order: Tensor, src: Tensor, seg_lo: Tensor,
-                seg_hi: Tensor, H: int, C: int) -> Tensor:  # fmt: skip
+                seg_hi: Tensor, H: int, C: int, drop: tuple = (0.0, 0, 0)) -> Tensor:  # fmt: skip
         lib = _native.load()
         out = skip.clone()
         U = q.shape[0]
         _native.check(lib.tgmx_tconv_attend(q.data_ptr(), k.data_ptr(), v.data_ptr(), eproj.data_ptr(), order.data_ptr(), src.data_ptr(),
-                                            seg_lo.data_ptr(), seg_hi.data_ptr(), U, H, C, float(C) ** -0.5, out.data_ptr(), _native.stream_ptr()),
+                                            seg_lo.data_ptr(), seg_hi.data_ptr(), U, H, C, float(C) ** -0.5, out.data_ptr(),
+                                            _native.dropout_desc(*drop), _native.stream_ptr()),
                       'tgmx_tconv_attend')  # fmt: skip
         ctx.save_for_backward(q, k, v, eproj, order, src, seg_lo, seg_hi)
-        ctx.H, ctx.C = H, C
+        ctx.H, ctx.C, ctx.drop = H, C, drop
         return out
 
     @staticmethod
@@ -196,5 +197,5 @@ class TconvAttendFn(torch.autograd.Function):
         _native.check(lib.tgmx_tconv_attend_backward(q.data_ptr(), k.data_ptr(), v.data_ptr(), eproj.data_ptr(), order.data_ptr(), src.data_ptr(),
                                                      seg_lo.data_ptr(), seg_hi.data_ptr(), q.shape[0], ctx.H, ctx.C, float(ctx.C) ** -0.5,
                                                      dout.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), de.data_ptr(),
-                                                     _native.stream_ptr()), 'tgmx_tconv_attend_backward')  # fmt: skip
-        return dq, dk, dv, de, dout, None, None, None, None, None, None
+                                                     _native.dropout_desc(*ctx.drop), _native.stream_ptr()), 'tgmx_tconv_attend_backward')  # fmt: skip
+        return dq, dk, dv, de, dout, None, None, None, None, None, None, None

@@ -4,8 +4,11 @@ Same constructor, parameters (``W_Q``, ``W_KV``, ``W_O``, ``layer_norm``) and fo
 signature as tgm/nn/modules/attention.py:5-128, so state_dicts interchange.  The forward
 runs on the HIP kernels of ``csrc/tgat.hip`` with the W_KV projection folded onto the
 query / output side (q-length 1; see ``oracle/tgat_fold.py`` for the algebra).
-Forward / eval only for now: dropout must be inactive (``.eval()`` or p == 0) and no
-autograd graph is recorded (backward is a SURVEY.md section 8(f) "next" row).
+Used stand-alone the module is forward-only (no autograd graph is recorded; training goes
+through ``TGAT``, whose hand-written backward covers this layer).  In ``.train()`` mode the two
+dropout sites of the reference (attention.py:119 on the attention weights, :126 on the W_O
+output) are applied with counter-based masks (``tgmx_dropout_t``): seeded from
+``torch.initial_seed()``, a fresh stream per call.
 """
 from __future__ import annotations
 
@@ -39,9 +42,12 @@ class TemporalAttention(nn.Module):
         self.layer_norm = nn.LayerNorm(out_dim)
 
     # ------------------------------------------------------------------
-    def _check_mode(self) -> None:
-        if self.training and self.dropout.p > 0:
-            raise NotImplementedError('tgm_amd TemporalAttention: dropout is not implemented; build the model with dropout=0 (training) or call .eval()')
+    def _dropout_site(self, site: int):
+        """tgmx_dropout_t of this call's dropout site (0: attention weights, 1: W_O output); None when inactive."""
+        p = self.dropout.p if self.training else 0.0
+        if not p:
+            return None
+        return _native.dropout_desc(p, torch.initial_seed(), self._drop_calls * 64 + site)
 
     def attend(
         self,
@@ -63,6 +69,7 @@ class TemporalAttention(nn.Module):
         (the merge layer's concat) -> [R, O (+ d0)]."""
         lib = _native.load()
         dev = rres.device
+        self._drop_calls = getattr(self, '_drop_calls', 0) + 1
         R, O, H, dh = rres.shape[0], self.out_dim, self.n_heads, self.head_dim
         d, D, T = self.node_dim, self.edge_dim, self.time_dim
         C = d + D + T
@@ -81,7 +88,7 @@ class TemporalAttention(nn.Module):
             lib.tgmx_tgat_attn_reduce(
                 qf.data_ptr(), nbrf.data_ptr(), d, _native.ptr(ex), D, _native.ptr(seed_t), _native.ptr(nbr_t), _native.ptr(nbr_id),
                 _native.ptr(tw), _native.ptr(tb), _native.ptr(nbr_time_feat), _native.ptr(mask), T, H, k, R, float(dh) ** -0.5, 0,
-                zbar.data_ptr(), 0, stream,
+                zbar.data_ptr(), 0, self._dropout_site(0), stream,
             ),
             'tgmx_tgat_attn_reduce',
         )  # fmt: skip
@@ -90,6 +97,9 @@ class TemporalAttention(nn.Module):
         _ops.sgemm_nt(zbar.view(R, H * C), WV, oattn, M=R, N=dh, K=C, batch=H, sA=C, sB=dh * C, sC=dh)
         y = torch.empty((R, O), **f32)
         _ops.sgemm_nt(oattn, self.W_O.weight.detach(), y, bias=self.W_O.bias.detach())
+        drop_y = self._dropout_site(1)
+        if drop_y is not None:
+            _native.check(lib.tgmx_dropout(y.data_ptr(), O, R, O, drop_y, y.data_ptr(), O, stream), 'tgmx_dropout')
         d0 = 0 if z0 is None else z0.shape[1]
         out = torch.empty((R, O + d0), **f32)
         ln = self.layer_norm
@@ -103,7 +113,6 @@ class TemporalAttention(nn.Module):
     def forward(self, node_x: Tensor, time_feat: Tensor, edge_feat: Tensor, nbr_node_feat: Tensor, nbr_time_feat: Tensor,
                 valid_nbr_mask: Tensor) -> Tensor:  # fmt: skip
         """Reference signature (attention.py:58-66): explicit time features and mask."""
-        self._check_mode()
         lib = _native.load()
         node_x = _ops._f32c(node_x, 'node_x')
         R, k = valid_nbr_mask.shape

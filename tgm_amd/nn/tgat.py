@@ -11,8 +11,10 @@ Parameter names match the reference (``time_encoder.w.*``, ``attn.{l}.*``,
   raw outputs (timestamps, ids): the [R, k, C] key tensor never exists.
 
 With gradients enabled the forward keeps its intermediates and a hand-written backward
-(``nn/_tgat_train.py``, ``csrc/tgat_bwd.hip``) produces the parameter gradients; dropout must be
-inactive (p == 0 or ``.eval()``).
+(``nn/_tgat_train.py``, ``csrc/tgat_bwd.hip``) produces the parameter gradients.  In ``.train()``
+mode the reference's two dropout sites per layer (attention.py:119,126; default p = 0.1,
+tgat.py:67) are active: counter-based masks (``tgmx_dropout_t``) seeded from
+``torch.initial_seed()``, one stream per forward call, regenerated -- not stored -- by the backward.
 """
 from __future__ import annotations
 
@@ -148,8 +150,6 @@ class TGAT(nn.Module):
         Returns the seeds' embeddings [len(seed_nids[0]), embed_dim].  One native call enqueues the
         whole forward (``tgmx_tgat_forward``)."""
         L = self.num_layers
-        for m_ in self.attn:
-            m_._check_mode()
         lib = _native.load()
         node_x = _ops._f32c(node_x, 'node_x')
         if node_x.shape[1] != self.node_dim:
@@ -170,9 +170,18 @@ class TGAT(nn.Module):
             h = hops[i]
             h.seed_t, h.nbr_id, h.nbr_t, h.edge_x, h.k = st.data_ptr(), nid.data_ptr(), nt.data_ptr(), _native.ptr(ex), nid.shape[-1]
             rows *= nid.shape[-1]
-        if S0 and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            # training: same native forward with every intermediate kept, hand-written backward (nn/_tgat_train.py)
+        drop_p = float(self.attn[0].dropout.p) if self.training else 0.0
+        if S0 and (drop_p > 0 or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()))):
+            # training: same native forward with every intermediate kept, hand-written backward (nn/_tgat_train.py);
+            # also the path that applies dropout (train mode under no_grad included, like the reference)
             from ._tgat_train import TGATFunction
+
+            if any(float(a.dropout.p) != float(self.attn[0].dropout.p) for a in self.attn):
+                raise NotImplementedError('tgm_amd TGAT: every attention layer must use the same dropout probability')
+            self._drop_calls = getattr(self, '_drop_calls', 0) + 1
+            if getattr(self, '_drop_seed', None) is None:
+                self._drop_seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
+            model.drop.p, model.drop.seed, model.drop.stream, model.drop.row0 = drop_p, self._drop_seed, self._drop_calls, 0
 
             flat = [t for i in range(L) for t in hold[4 * i : 4 * i + 4]]
             flat = [flat[4 * i + j] for i in range(L) for j in (3, 0, 1, 2)]  # (seed_t, nbr_id, nbr_t, edge_x) per hop

@@ -286,7 +286,9 @@ class TGNMemory(nn.Module):
 class TransformerConv(nn.Module):
     """Graph transformer operator with edge features -- parameters named like
     ``torch_geometric.nn.TransformerConv`` (2.6.1; third-party to the reference, parity unpinned):
-    concat=True, root_weight=True, beta=False, bias=True; attention dropout must be inactive."""
+    concat=True, root_weight=True, beta=False, bias=True.  In ``.train()`` mode the attention coefficients go through
+    dropout after the softmax like PyG's (``F.dropout(alpha, p=self.dropout)``): a counter-based mask per (edge, head),
+    seeded from ``torch.initial_seed()``, a fresh stream per forward call, regenerated by the backward."""
 
     def __init__(self, in_channels: int, out_channels: int, heads: int = 1, dropout: float = 0.0, edge_dim: Optional[int] = None) -> None:
         super().__init__()
@@ -328,9 +330,16 @@ class TransformerConv(nn.Module):
             cached = self._stacked = (key, W4, b4)
         return cached[1], cached[2]
 
+    def _dropout_site(self) -> tuple:
+        """(p, seed, stream) of this forward call's attention dropout; p = 0 outside train mode."""
+        if not (self.training and self.dropout > 0):
+            return (0.0, 0, 0)
+        self._drop_calls = getattr(self, '_drop_calls', 0) + 1
+        if getattr(self, '_drop_seed', None) is None:
+            self._drop_seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
+        return (float(self.dropout), self._drop_seed, self._drop_calls)
+
     def forward(self, x: Tensor, edge_index: Tensor, edge_attr: Tensor) -> Tensor:
-        if self.training and self.dropout > 0:
-            raise NotImplementedError('tgm_amd TransformerConv: attention dropout / backward not implemented; call .eval()')
         lib = _native.load()
         if torch.is_grad_enabled() and (x.requires_grad or edge_attr.requires_grad or any(p.requires_grad for p in self.parameters())):
             return self._forward_train(x, edge_index, edge_attr)
@@ -351,7 +360,8 @@ class TransformerConv(nn.Module):
             order, seg_lo, seg_hi = self._incoming_segments(tgt, U)
             _native.check(
                 lib.tgmx_tconv_attend(q.data_ptr(), k.data_ptr(), v.data_ptr(), eproj.data_ptr(), order.data_ptr(), src.data_ptr(),
-                                      seg_lo.data_ptr(), seg_hi.data_ptr(), U, H, C, float(C) ** -0.5, out.data_ptr(), _native.stream_ptr()),
+                                      seg_lo.data_ptr(), seg_hi.data_ptr(), U, H, C, float(C) ** -0.5, out.data_ptr(),
+                                      _native.dropout_desc(*self._dropout_site()), _native.stream_ptr()),
                 'tgmx_tconv_attend',
             )  # fmt: skip
         return out
@@ -375,7 +385,7 @@ def _tconv_forward_train(self, x: Tensor, edge_index: Tensor, edge_attr: Tensor)
     eproj = LinearFn.apply(edge_attr.float().contiguous(), self.lin_edge.weight, None)
     src, tgt = edge_index[0].contiguous(), edge_index[1].contiguous()
     order, seg_lo, seg_hi = self._incoming_segments(tgt, U)
-    return TconvAttendFn.apply(q, k, v, eproj, skip, order, src, seg_lo, seg_hi, H, C)
+    return TconvAttendFn.apply(q, k, v, eproj, skip, order, src, seg_lo, seg_hi, H, C, self._dropout_site())
 
 
 TransformerConv._forward_train = _tconv_forward_train

@@ -56,8 +56,8 @@ class CompiledPipeline:
         self._pipe: Optional[_native.Pipeline] = None
         self._step_ref = None  # the hook's argument block this pipeline was bound to
         self._lib = _native.load()
-        self._device = dg.device
         self._arr = dg._storage.on(dg.device)
+        self._device = self._arr.src.device  # with its index ('cuda' -> 'cuda:0'): what the hooks see on batch tensors
         self._roles = [_ROLE_KEYS[shard is not None][k][0] for k in nbr._seed_nodes_keys]
 
     # -- lowering ---------------------------------------------------------------

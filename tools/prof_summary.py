@@ -1,0 +1,85 @@
+#!/usr/bin/env python
+"""Summarise rocprofv3 output (the rocpd SQLite database this image's rocprofv3 writes) as markdown / JSON.
+
+    python tools/prof_summary.py trace <dir-or-db> [--title "..."]      per-kernel table of a --kernel-trace --stats run
+    python tools/prof_summary.py gaps  <dir-or-db> --kernel <substr>    launch-to-launch gaps on the stream around one kernel
+    python tools/prof_summary.py pmc   <dir-or-db> [--kernel <substr>]  per-kernel average of every collected counter
+
+Used by tools/gpu_profile.sh; the tables under profiles/ are its output, unedited.
+"""
+import argparse
+import glob
+import json
+import os
+import sqlite3
+import sys
+
+
+def open_db(path):
+    if os.path.isdir(path):
+        dbs = sorted(glob.glob(os.path.join(path, '**', '*.db'), recursive=True))
+        if not dbs:
+            sys.exit(f'no .db under {path}')
+        path = dbs[-1]
+    return sqlite3.connect(path)
+
+
+def short(name, n=70):
+    return name if len(name) <= n else name[: n - 3] + '...'
+
+
+def trace(db, title):
+    rows = db.execute('select name, grid_x, count(*), sum(duration), avg(duration), min(duration), max(duration), max(vgpr_count), max(lds_size) '
+                      'from kernels group by name, grid_x order by sum(duration) desc').fetchall()
+    total = sum(r[3] for r in rows) or 1
+    print(f'# {title}')
+    print('| kernel | grid | calls | total ms | avg us | min us | max us | VGPR | LDS B | % |')
+    print('|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|')
+    for name, grid, n, tot, avg, mn, mx, vg, lds in rows[:30]:
+        print(f'| `{short(name)}` | {grid} | {n} | {tot / 1e6:.3f} | {avg / 1e3:.2f} | {mn / 1e3:.2f} | {mx / 1e3:.2f} | {vg} | {lds} | {100 * tot / total:.1f} |')
+
+
+def gaps(db, kernel):
+    rows = db.execute('select name, start, end from kernels order by start').fetchall()
+    idle, busy, n = 0, 0, 0
+    first = last = None
+    for i, (name, s, e) in enumerate(rows):
+        if kernel in name:
+            if first is None:
+                first = i
+            last = i
+    if first is None:
+        sys.exit(f'no kernel matching {kernel}')
+    # the timed steps are the second half of the run (bench.py replays the first half untimed): launches 55 % .. 95 %
+    idx = [i for i, r in enumerate(rows) if kernel in r[0]]
+    lo, hi = idx[int(0.55 * len(idx))], idx[int(0.95 * len(idx))]
+    for i in range(lo, hi):
+        busy += rows[i][2] - rows[i][1]
+        idle += max(0, rows[i + 1][1] - rows[i][2])
+        n += 1
+    steps = sum(1 for i in idx if lo <= i < hi)
+    print(json.dumps({'kernel': kernel, 'launches_in_window': n, 'steps_in_window': steps, 'busy_us_per_step': busy / steps / 1e3,
+                      'idle_us_per_step': idle / steps / 1e3, 'wall_us_per_step': (rows[hi][1] - rows[lo][1]) / steps / 1e3}))
+
+
+def pmc(db, kernel):
+    rows = db.execute('select k.name, k.grid_x, p.counter_name, count(*), avg(p.counter_value), min(p.counter_value), max(p.counter_value) '
+                      'from pmc_events p join kernels k on k.dispatch_id = p.dispatch_id group by k.name, k.grid_x, p.counter_name '
+                      'order by avg(p.counter_value) desc').fetchall()
+    print('| kernel | counter | grid | n | avg | min | max |')
+    print('|---|---|---:|---:|---:|---:|---:|')
+    for name, grid, cn, n, avg, mn, mx in rows:
+        if kernel and kernel not in name:
+            continue
+        print(f'| `{short(name, 60)}` | {cn} | {grid} | {n} | {avg:.1f} | {mn:.1f} | {mx:.1f} |')
+
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('what', choices=['trace', 'gaps', 'pmc'])
+    ap.add_argument('path')
+    ap.add_argument('--title', default='rocprofv3 --kernel-trace --stats')
+    ap.add_argument('--kernel', default='')
+    a = ap.parse_args()
+    db = open_db(a.path)
+    {'trace': lambda: trace(db, a.title), 'gaps': lambda: gaps(db, a.kernel), 'pmc': lambda: pmc(db, a.kernel)}[a.what]()
