@@ -495,6 +495,17 @@ size_t tgmx_segment_sort_workspace_bytes(int64_t n);
 int tgmx_segment_sort(const int64_t* key, int64_t n, int32_t num_keys, int64_t* order, int64_t* seg_lo, int64_t* seg_hi,
                       void* workspace, size_t workspace_bytes, int32_t* status, tgmx_stream_t stream);
 
+/* DGData.discretize's grouping, `_get_keep_indices` (tgm/data/dg_data.py:471-500), for one event group of n events:
+ *   bucket[i]  = int32(floor(float64(time[i]) * factor))                                  (dg_data.py:469)
+ *   key[i]     = bucket[i] * (max(id_key) + 1) + id_key[i],  id_key = id0 * (max(id0, id1) + 1) + id1 (or id0 when id1 is
+ *                NULL) -- int32 arithmetic that wraps exactly like the reference's int32 tensors
+ *   keep_pos   = positions of the first event of every distinct key in a STABLE sort of the keys, ascending
+ *                (`reduce_op='first'`), *keep_count of them (device int64; keep_pos must hold n entries).
+ * Ids must be >= 0.  workspace >= tgmx_discretize_workspace_bytes(n). */
+size_t tgmx_discretize_workspace_bytes(int64_t n);
+int tgmx_discretize_keep(const int64_t* time, const int32_t* id0, const int32_t* id1, int64_t n, double factor, int32_t* bucket,
+                         int64_t* keep_pos, int64_t* keep_count, void* workspace, size_t workspace_bytes, tgmx_stream_t stream);
+
 /* TransformerConv attention (third-party definition, PyG 2.6.1): for every target i,
  * out[i] += sum_j softmax_j(q_i.(k_j + e_ij)/sqrt(C)) (v_j + e_ij) per head; edges of target i are
  * order[seg_lo[i] .. seg_hi[i]) (edge ids sorted by target), src[e] = source j. */

@@ -95,7 +95,7 @@ def test_cfg5_snapshots_tgcn():
     N, E, year = 255, 30_000, 365 * 24 * 3600
     ts = torch.from_numpy(np.sort(rng.integers(0, 12 * year, E)))
     ei = torch.from_numpy(rng.integers(0, N, (E, 2)).astype(np.int32))
-    data = DGData.from_raw(ts, ei, torch.rand(E, 1), static_node_x=torch.randn(N, 16), time_delta='s').discretize('Y')
+    data = DGData.from_raw(ts, ei, torch.rand(E, 1), static_node_x=torch.randn(N, 16), time_delta='s').discretize('Y', device=DEV)
     assert data.time_delta.unit == 'Y' and int(data.time.max()) == 11
     dg = DGraph(data, device=DEV)
     torch.manual_seed(0)

@@ -43,3 +43,50 @@ def test_tgcn_trade_shaped_vs_oracle():
     conv = GCNConv(Fin, C, add_self_loops=False).to(DEV)
     out = conv(x.to(DEV), ei.to(DEV))
     close(out.cpu(), gcn_conv_ref(x, ei, None, conv.lin.weight.detach().cpu(), conv.bias.detach().cpu(), add_self_loops=False), 'gcn no loops')
+
+
+def test_discretize_on_device_matches_reference_golden_and_host_path():
+    """DGData.discretize(device='cuda') -- every event group's grouping in tgmx_discretize_keep (csrc/discretize.hip) --
+    against golden g9 (the reference's output; tgm/data/dg_data.py:423-564) and, bit for bit, against the host torch
+    formulation on a trade-shaped stream (255 nodes, 468 k edges, seconds -> years) and on a stream whose int32 radix key
+    wraps (ids ~ 1e6: src * base + dst overflows int32 exactly as in the reference)."""
+    import os
+
+    import numpy as np
+
+    from tgm_amd import DGData
+
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'g9_discretize.npz'))
+    T = torch.from_numpy
+    d = DGData.from_raw(T(z['ts']), T(z['ei']), T(z['ex']), node_x_time=T(z['nt']), node_x_nids=T(z['nn']), node_x=T(z['nx']),
+                        node_y_time=T(z['yt']), node_y_nids=T(z['yn']), node_y=T(z['yv']), time_delta='s')  # fmt: skip
+    fields = ('time', 'edge_mask', 'edge_index', 'edge_x', 'node_x_mask', 'node_x_nids', 'node_x', 'node_y_mask', 'node_y_nids', 'node_y')
+
+    def canon(times, *cols):  # events sharing a discretized timestamp: the reference's final argsort is not stable (dg_data.py:360)
+        rows = np.concatenate([np.asarray(times, np.float64)[:, None]] + [np.asarray(c, np.float64).reshape(len(times), -1) for c in cols], 1)
+        return rows[np.lexsort(rows.T[::-1])]
+
+    for unit in ('m', 'h'):
+        with pytest.warns(UserWarning):
+            c = d.discretize(unit, device=DEV)
+            h = d.discretize(unit)
+        for f in fields:  # device path == host path, bit for bit
+            assert torch.equal(getattr(c, f), getattr(h, f)), (unit, f)
+        assert np.array_equal(c.time.numpy(), z[f'{unit}_time'])
+        for mask, cols in (('edge_mask', ('edge_index', 'edge_x')), ('node_x_mask', ('node_x_nids', 'node_x')), ('node_y_mask', ('node_y_nids', 'node_y'))):
+            got = canon(c.time[getattr(c, mask).long()].numpy(), *[getattr(c, f).numpy() for f in cols])
+            exp = canon(z[f'{unit}_time'][z[f'{unit}_{mask}']], *[z[f'{unit}_{f}'] for f in cols])
+            assert got.shape == exp.shape and np.array_equal(got, exp), f'{unit} {mask}'
+
+    rng = np.random.default_rng(0)
+    year = 365 * 24 * 3600
+    for N, E, span in ((255, 468_000, 30 * year), (1_000_000, 300_000, 40 * year)):
+        ts = torch.from_numpy(np.sort(rng.integers(0, span, E)))
+        ei = torch.from_numpy(rng.integers(0, N, (E, 2)).astype(np.int32))
+        if N > 100_000:
+            ei[: E // 2] = ei[E // 2 : E // 2 * 2]  # repeated (src, dst) pairs so that groups exist despite the large id range
+        data = DGData.from_raw(ts, ei, torch.rand(E, 1), time_delta='s')
+        a, b = data.discretize('Y', device=DEV), data.discretize('Y')
+        assert a.time.numel() < E
+        for f in ('time', 'edge_mask', 'edge_index', 'edge_x'):
+            assert torch.equal(getattr(a, f), getattr(b, f)), (N, f)

@@ -83,7 +83,7 @@ def test_tgn_parameter_gradients(aggr, dropout):
         r = refs[name].grad
         assert p.grad is not None and r is not None, name
         # lin_key.bias has a mathematically zero gradient (softmax is shift invariant per target): floor the scale
-        err = ((p.grad.cpu() - r).abs().max() / r.abs().max().clamp(min=1e-3)).item()
+        err = ((p.grad.cpu() - r).abs().max() / r.abs().max().clamp(min=2e-3)).item()
         report.append((name, err, float(r.abs().max())))
         if err > worst[1]:
             worst = (name, err)

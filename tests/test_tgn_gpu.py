@@ -42,10 +42,13 @@ def test_tgn_memory_matches_reference(case):
             assert torch.equal(mem.last_update.cpu(), T(a['flush_last_update']))
 
 
-@pytest.mark.parametrize('aggr,bs', [('last', 512), ('mean', 512), ('last', 700), ('mean', 100)])
-def test_tgn_memory_matches_oracle_review_shaped(aggr, bs):
+@pytest.mark.parametrize('aggr,bs,log_cap', [('last', 512, None), ('mean', 512, None), ('last', 700, None), ('mean', 100, None), ('last', 512, 64),
+                                             ('mean', 100, 256)])
+def test_tgn_memory_matches_oracle_review_shaped(aggr, bs, log_cap):
     """Example dims (memory/time 100, msg 16) on a review-shaped stream with hubs; bs=512 is the BASELINE batch (one-launch
-    id grouping: 2*bs <= 1024), bs=700 takes the torch.sort fallback of the message store / commit."""
+    id grouping: 2*bs <= 1024), bs=700 takes the torch.sort fallback of the message store / commit.  log_cap: a tiny
+    message-log capacity, so the store is compacted every few batches (the log must not grow with the events
+    seen) -- results must not change and the log must stay within a small multiple of the live windows."""
     from oracle.tgn_ref import TGNMemoryRef
     from tgm_amd.nn import IdentityMessage, LastAggregator, MeanAggregator, TGNMemory
     from tgm_amd.synth import make_stream
@@ -58,6 +61,8 @@ def test_tgn_memory_matches_oracle_review_shaped(aggr, bs):
     mem = TGNMemory(N, D, M, T_, IdentityMessage(D, M, T_), LastAggregator() if aggr == 'last' else MeanAggregator()).to(DEV).train()
     params = {k: v.detach().cpu().clone() for k, v in mem.state_dict().items() if k not in ('memory', 'last_update', '_assoc')}
     ref = TGNMemoryRef(N, D, M, T_, params, aggr)
+    if log_cap:
+        mem._log_cap_min = log_cap
     g = torch.Generator().manual_seed(9)
     for b, lo in enumerate(range(0, st.num_edges, bs)):
         hi = min(lo + bs, st.num_edges)
@@ -74,6 +79,9 @@ def test_tgn_memory_matches_oracle_review_shaped(aggr, bs):
         assert torch.equal(lu.cpu(), lu_ref)
         mem.update_state(src.to(DEV), dst.to(DEV), t.to(DEV), raw.to(DEV))
         ref.update_state(src, dst, t, raw)
+        if log_cap and mem.training:
+            live = int(mem._st_cnt[0].sum()) + int(mem._st_cnt[1].sum())
+            assert mem._log_other.numel() <= max(log_cap, 4 * (live + 2 * bs)), (mem._log_other.numel(), live)
     close(mem.memory.cpu(), ref.memory, 'final memory')
     assert torch.equal(mem.last_update.cpu(), ref.last_update)
 

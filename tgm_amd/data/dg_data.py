@@ -217,11 +217,15 @@ class DGData:
         vals = {f.name: getattr(self, f.name) for f in fields(self)}
         return DGData(**{k: (v.clone() if isinstance(v, Tensor) else copy.deepcopy(v)) for k, v in vals.items()})
 
-    def discretize(self, time_delta: 'TimeDeltaDG | str | None', reduce_op: str = 'first') -> 'DGData':
+    def discretize(self, time_delta: 'TimeDeltaDG | str | None', reduce_op: str = 'first', device=None) -> 'DGData':
         """Coarsen the time granularity (tgm/data/dg_data.py:423-564): timestamps become bucket indices
         ``floor(t * self.time_delta / time_delta)`` and, per bucket, only the FIRST event of every
-        (src, dst) edge / node id is kept, in chronological order.  Sort-bound one-shot work: it runs as
-        torch ops on whatever device the tensors live on (stable sort of a radix key)."""
+        (src, dst) edge / node id is kept, in chronological order.
+
+        The grouping is sort-bound.  With ``device=`` a ROCm device (ours; or when the tensors already live on one) every
+        event group goes through ``tgmx_discretize_keep`` (``csrc/discretize.hip``: the reference's int32 radix key, one
+        stable rocPRIM radix sort, first-of-group marks compacted in event order); host tensors without ``device=`` keep
+        the reference's torch formulation (host data plumbing, like the reference).  Both give identical results."""
         from ..exceptions import EventOrderedConversionError, InvalidDiscretizationError
 
         if isinstance(time_delta, str):
@@ -237,6 +241,10 @@ class DGData:
 
         factor = self.time_delta.convert(time_delta)
         buckets = (self.time.to(torch.float64) * factor).floor().int()  # float64: exact for every int32 timestamp
+
+        dev = torch.device(device) if device is not None else self.time.device
+        if dev.type == 'cuda':
+            return self._discretize_on_device(time_delta, factor, dev)
 
         def first_per_bucket(event_pos: Tensor, ids: Tensor) -> Tensor:
             """positions (within this event group) of the first event of every (bucket, id) pair, ascending"""
@@ -268,6 +276,55 @@ class DGData:
                 kw[f'{pre}_nids'] = getattr(self, f'{pre}_nids')[kp]
                 vals = getattr(self, pre)
                 kw[pre] = None if vals is None else vals[kp]
+        return DGData.from_raw(**kw)
+
+    def _discretize_on_device(self, time_delta: 'TimeDeltaDG', factor: float, dev: torch.device) -> 'DGData':
+        """``discretize`` with every event group's grouping in ``tgmx_discretize_keep``; the result lives where ``self`` does."""
+        from .. import _native
+
+        lib = _native.load()
+        home = self.time.device
+        up = lambda t: t.to(dev).contiguous()
+        time_d = up(self.time)
+
+        def group(event_pos: Tensor, ids: Tensor):
+            """(kept positions within the group, their buckets), both on the device"""
+            n = int(event_pos.numel())
+            t = time_d[up(event_pos).long()].contiguous()
+            ids = up(ids).to(torch.int32)
+            id0 = ids[:, 0].contiguous() if ids.ndim == 2 else ids
+            id1 = ids[:, 1].contiguous() if ids.ndim == 2 else None
+            if n and int(ids.min()) < 0:
+                raise ValueError('discretize: ids must be >= 0')
+            bucket = torch.empty(n, dtype=torch.int32, device=dev)
+            keep = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+            count = torch.zeros(1, dtype=torch.int64, device=dev)
+            need = int(lib.tgmx_discretize_workspace_bytes(n))
+            if need == 0:
+                _native.check(-2, 'tgmx_discretize_workspace_bytes')
+            ws = torch.empty(need, dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev):
+                _native.check(lib.tgmx_discretize_keep(t.data_ptr(), id0.data_ptr(), _native.ptr(id1), n, float(factor), bucket.data_ptr(),
+                                                       keep.data_ptr(), count.data_ptr(), ws.data_ptr(), need, _native.stream_ptr(dev.index)),
+                              'tgmx_discretize_keep')  # fmt: skip
+            keep = keep[: int(count.item())]
+            return keep, bucket[keep]
+
+        back = lambda t: t.to(home)
+        keep, b_keep = group(self.edge_mask, self.edge_index)
+        pick = lambda t, kp: None if t is None else back(up(t)[kp])
+        kw = dict(
+            time_delta=time_delta, edge_time=back(b_keep), edge_index=pick(self.edge_index, keep), edge_x=pick(self.edge_x, keep),
+            edge_type=pick(self.edge_type, keep), static_node_x=None if self.static_node_x is None else self.static_node_x.clone(),
+            node_type=None if self.node_type is None else self.node_type.clone(),
+        )  # fmt: skip
+        for pre in ('node_x', 'node_y'):
+            mask = getattr(self, f'{pre}_mask')
+            if mask is not None:
+                kp, bk = group(mask, getattr(self, f'{pre}_nids'))
+                kw[f'{pre}_time'] = back(bk)
+                kw[f'{pre}_nids'] = pick(getattr(self, f'{pre}_nids'), kp)
+                kw[pre] = pick(getattr(self, pre), kp)
         return DGData.from_raw(**kw)
 
     @property

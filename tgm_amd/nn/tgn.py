@@ -73,6 +73,7 @@ class TGNMemory(nn.Module):
         self._log_t: Optional[Tensor] = None
         self._log_raw: Optional[Tensor] = None
         self._log_len = 0
+        self._log_cap_min = 1 << 16  # rows; tests shrink it to exercise the compaction
         self.shard_commits = True  # under torch.distributed (world > 1): shard update_state's commit across ranks
         self.memory_updater.reset_parameters()
 
@@ -101,6 +102,11 @@ class TGNMemory(nn.Module):
         self._log_len = 0
 
     def _ensure_store(self, extra: int) -> None:
+        """Room for ``extra`` more log rows.  The log is append-only between compactions; a node's window is dead as soon
+        as the node shows up again in that role (``_update_msg_store`` REPLACES a node's events, tgn.py:218-229), so when
+        the log is full the live windows are copied -- packed -- into FRESH tensors (autograd contexts that snapshotted
+        windows of the old tensors keep them alive and stay valid) and the capacity only grows when the live rows need it.
+        Memory is bounded by the live windows (what the reference's per-node store holds), not by the events seen."""
         dev = self.memory.device
         if self._st_lo[0] is None or self._st_lo[0].device != dev:
             self._reset_message_store()
@@ -108,15 +114,35 @@ class TGNMemory(nn.Module):
         need = self._log_len + extra
         cap = 0 if self._log_other is None else self._log_other.numel()
         if need > cap or (self._log_other is not None and self._log_other.device != dev):
-            new_cap = max(need, 2 * cap, 1 << 16)
-            other = torch.empty(new_cap, dtype=torch.int32, device=dev)
-            t = torch.empty(new_cap, dtype=torch.int64, device=dev)
-            raw = torch.empty((new_cap, max(self.raw_msg_dim, 1)), dtype=torch.float32, device=dev)
+            live = 0
             if self._log_len:
-                other[: self._log_len] = self._log_other[: self._log_len]
-                t[: self._log_len] = self._log_t[: self._log_len]
-                raw[: self._log_len] = self._log_raw[: self._log_len]
-            self._log_other, self._log_t, self._log_raw = other, t, raw
+                live = int(self._st_cnt[0].sum()) + int(self._st_cnt[1].sum())  # one host read per compaction (rare)
+            new_cap = max(2 * (live + extra), self._log_cap_min)
+            self._compact_into(new_cap, dev)
+
+    def _compact_into(self, new_cap: int, dev: torch.device) -> None:
+        """Pack every live window into new log tensors of ``new_cap`` rows and re-point the windows."""
+        other = torch.empty(new_cap, dtype=torch.int32, device=dev)
+        t = torch.empty(new_cap, dtype=torch.int64, device=dev)
+        raw = torch.empty((new_cap, max(self.raw_msg_dim, 1)), dtype=torch.float32, device=dev)
+        base = 0
+        if self._log_len:
+            N = self.num_nodes
+            ids = torch.arange(N, device=dev)
+            for r in (0, 1):
+                cnt, lo = self._st_cnt[r].long(), self._st_lo[r]
+                total = int(cnt.sum())
+                new_lo = torch.cumsum(cnt, 0) - cnt + base
+                if total:
+                    node_of = torch.repeat_interleave(ids, cnt, output_size=total)
+                    rows = lo[node_of] + (torch.arange(base, base + total, device=dev) - new_lo[node_of])
+                    other[base : base + total] = self._log_other[rows]
+                    t[base : base + total] = self._log_t[rows]
+                    raw[base : base + total] = self._log_raw[rows]
+                self._st_lo[r] = torch.where(cnt > 0, new_lo, torch.zeros_like(new_lo))
+                base += total
+        self._log_other, self._log_t, self._log_raw = other, t, raw
+        self._log_len = base
 
     # -- kernels ----------------------------------------------------------------
     def _updated(self, nodes: Tensor) -> Tuple[Tensor, Tensor]:

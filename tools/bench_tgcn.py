@@ -22,7 +22,7 @@ raw = DGData.from_raw(ts, ei, torch.rand(E, 1), static_node_x=torch.randn(N, 16)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 data = raw.clone().to(dev) if hasattr(raw, 'to') else raw
-data = raw.discretize('Y')
+data = raw.discretize('Y', device=dev)
 torch.cuda.synchronize()
 t_disc = time.perf_counter() - t0
 dg = DGraph(data, device=dev)
