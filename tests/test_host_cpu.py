@@ -239,3 +239,19 @@ def test_tgmx_slice_matches_the_store_s_event_range():
         rc = lib.tgmx_slice(t.ctypes.data, len(t), st_ is not None, st_ or 0, et_ is not None, et_ or 0, si_ or 0, ei_ if ei_ else -1,
                             ctypes.byref(lb), ctypes.byref(ub))
         assert rc == 0 and (lb.value, ub.value) == want, (st_, et_, si_, ei_)
+
+
+def test_reference_side_binding_script():
+    """INTEGRATION.md section 2 as an executed check: our hooks inside the REFERENCE's HookManager (protocol, registration,
+    neg -> nbr ordering edge), identical requires / produces, DGBatch fields, TGAT state_dict interchange.  Needs the
+    reference checkout, so it only runs in the build container (skipped elsewhere; nothing on the GPU box reads it)."""
+    import os
+    import subprocess
+    import sys
+
+    if not os.path.isdir('/root/reference/tgm'):
+        pytest.skip('reference checkout not present')
+    script = os.path.join(os.path.dirname(__file__), 'golden', 'check_reference_binding.py')
+    r = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count('[binding] ok') == 5
