@@ -63,6 +63,8 @@ def parse_args():
     p.add_argument('--start-frac', type=float, default=0.5, help='fraction of the stream replayed untimed before the warm-up (ring fill)')
     p.add_argument('--profile-every', type=int, default=32, help='bracket the dominant kernel with HIP events every n-th step')
     p.add_argument('--seed', type=int, default=1337)
+    p.add_argument('--emulate-world', type=int, default=0, help='single process: run the step of rank --emulate-rank of a W-rank job (there is no data-path collective, so nothing is missing from it); modelling aid, n_gpus stays 1')
+    p.add_argument('--emulate-rank', type=int, default=0)
     return p.parse_args()
 
 
@@ -196,6 +198,10 @@ def main():
 
     rank, world, local = init_process_group()
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)'
+    real_world = world
+    if args.emulate_world:
+        assert world == 1, '--emulate-world is a single-process modelling aid'
+        rank, world = args.emulate_rank, args.emulate_world
     assert torch.cuda.is_available(), 'bench.py needs a ROCm device'
     if os.environ.get('TGMX_SINGLE_DEVICE'):  # functional check only: every rank on device 0 (with TGMX_DIST_BACKEND=gloo)
         local = 0
@@ -261,18 +267,18 @@ def main():
         hook.profile_every, hook.profile_log, hook._calls = every, [], 0
         # at most 48 timed launches: ~100 HIP events awaiting their timestamps is where the runtime starts to stall
         hook.profile_pool = [KernelTimer() for _ in range(min(48, steps // every + 1))]
-        if world > 1:
+        if real_world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         run(steps)
         torch.cuda.synchronize()
-        if world > 1:
+        if real_world > 1:
             torch.distributed.barrier()
         elapsed = time.perf_counter() - t0
         hook.check()
 
-    if world > 1:
+    if real_world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -284,7 +290,7 @@ def main():
             it = 0
         n_e = min(global_bs, stream.num_edges - starts[it])
         total_events += n_e
-        for r in range(world):
+        for r in (range(world) if not args.emulate_world else [rank]):
             total_units += slots_of((n_e * (r + 1)) // world - (n_e * r) // world)
         it += 1
 
@@ -316,7 +322,7 @@ def main():
         else f'sampled-edges/sec (recency sampler, tgbl-{args.workload} synthetic)',
         'value': total_units / elapsed,
         'unit': 'sampled-edges/s',
-        'n_gpus': world,
+        'n_gpus': real_world,
         'steps': steps,
         'warmup': args.warmup,
         'ms_per_step': 1e3 * elapsed / steps,
@@ -335,7 +341,8 @@ def main():
             + (' (status word read back once after the timed steps)' if args.validate == 'deferred' else ''),
             'slots_per_step_per_rank': slots_of(bs_rank),
             'events_per_s': total_events / elapsed,
-            'parallelism': f'edge-batch sharding x{world} ({args.scaling} scaling), replicated stream, no data-path collective',
+            'parallelism': f'edge-batch sharding x{world} ({args.scaling} scaling), replicated stream, no data-path collective'
+            + (f' -- EMULATED: this is rank {rank} of {world} alone on one GPU (value = that rank\'s units only)' if args.emulate_world else ''),
         },
         'roofline': {
             'bound': 'hbm',
@@ -353,13 +360,13 @@ def main():
             'bytes_model': 'valid-aware: slots x (12 + 4D) written + valid slots x (16 + 4D) read + 68 B per seed',
         },
     }
-    if rank == 0:
-        if world == 1 and args.cpu_batches > 0:
+    if rank == 0 or args.emulate_world:
+        if world == 1 and real_world == 1 and args.cpu_batches > 0:
             out['cpu_baseline'] = cpu_baseline(stream, bs, num_nbrs, args.cpu_batches, args.seed, first_timed)
         else:
             out['cpu_baseline'] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if real_world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

@@ -128,7 +128,7 @@ int tgmx_ring_lookup(const tgmx_adj_t* ring, const int32_t* write_pos,
  * it); key_wrap32 = 0 uses int64 (the intended per-node chronological order).
  * edge_x may be NULL (rows of zeros, recency.py:325-328).  eid0 = store index of
  * the batch's first edge or -1 (recorded in the slot, informational).
- * scratch: 256-byte aligned, >= tgmx_ring_update_scratch_bytes(n, directed) bytes; its first 256 bytes must be ZERO
+ * scratch: 256-byte aligned, >= tgmx_ring_update_scratch_bytes(n, directed) bytes; its first 4096 bytes must be ZERO
  * when the buffer is first handed to the library (a self-resetting barrier of tgmx_recency_step's update workgroups
  * lives there; the library leaves it zero) -- everything behind them is plain scratch.  */
 size_t tgmx_ring_update_scratch_bytes(int64_t n, int32_t directed);

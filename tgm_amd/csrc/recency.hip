@@ -80,6 +80,10 @@ struct LookupArgs {
   // launch's second argument instead of looking anything up
   unsigned side_blocks;
   int side_stage;
+  // tail commit (tgmx_recency_step, placement decided by the rider): the LAST tail_blocks workgroups wait until every
+  // lookup workgroup and the rider have finished, then write the batch into the rings -- the update's write-back as the
+  // tail of the lookup launch instead of a launch of its own
+  unsigned tail_blocks;
   // fused hop 0 + hop 1 launch: hop 1's k and outputs (rows of hop 1 = S * k)
   int k1;
   int32_t* out_nid1;
@@ -775,6 +779,124 @@ __device__ __forceinline__ bool rider_barrier(int32_t* bar, int parts) {
 }
 constexpr int kRidePlaceMaxM = 1024;
 
+// ---- tail commit -----------------------------------------------------------------------------------------------------
+// bar[2] counts finished workgroups (lookups + rider), bar[3] finished tail workgroups; the last tail workgroup zeroes
+// both, so the words only have to be zero when the scratch is first used (like the riders' barrier).
+// Counting is two-level: 3000 same-address device-scope atomics serialise at the memory side (measured: the launch took
+// 117 instead of 39 us with one counter), so workgroup b adds to group counter b % kTailGroups (own 64-byte lines:
+// bar[16 + 16 g]) and only the workgroup that completes a group (it knows the group's size) moves the global word.
+constexpr int kTailGroups = 32;
+__device__ __forceinline__ void tail_signal(int32_t* bar, bool publish, unsigned bid, unsigned nblk) {
+  __syncthreads();  // every thread's loads have returned and its stores have been issued and counted
+  if (threadIdx.x == 0) {
+    if (publish) {
+      // the rider's placement decisions must be visible to tail workgroups on other XCDs (their L2s are not coherent
+      // with this one): one write-back of this L2, once per launch; lookup workgroups publish nothing (relaxed)
+      __threadfence();
+      __hip_atomic_store(&bar[4], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // decisions readable
+      __hip_atomic_fetch_add(&bar[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      const unsigned g = bid % kTailGroups;
+      const unsigned size = (nblk - g + kTailGroups - 1) / kTailGroups;  // workgroups b < nblk with b % kTailGroups == g
+      int32_t* cnt = &bar[16 + 16 * g];
+      const int prev = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (prev == (int)size - 1) {
+        __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+        __hip_atomic_fetch_add(&bar[2], (int)size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+}
+
+// Workgroup `tb` of `tail_blocks`, positions [4 tb, 4 tb + 4), one wave each (the body of ring_update_feat_kernel<COMMIT>).
+// Everything is READ before the launch-wide wait and only written after it: as soon as the rider has published its
+// placement decisions (bar[4], set behind its write-back) the wave fetches its position's decision, record and feature
+// row into registers; once every lookup workgroup has finished (bar[2] == need) what is left is stores.
+__device__ __forceinline__ bool tail_wait(const int32_t* word, unsigned need) {
+  int spins = 0;
+  while ((unsigned)__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+    __builtin_amdgcn_s_sleep(8);
+    if (++spins > (1 << 22)) return false;  // seconds: the count can only be short if the scratch head was not zero at first use
+  }
+  return true;
+}
+
+__device__ __forceinline__ void tail_commit(const UpdateArgs& a, unsigned tb, unsigned tail_blocks, unsigned need) {
+  __shared__ int ok_s;
+  const int lane = lane_id();
+  const long long p = (long long)tb * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (threadIdx.x == 0) ok_s = tail_wait(&a.barrier[4], 1u) ? 1 : 0;
+  __syncthreads();
+  bool ok = ok_s != 0;
+  // ---- reads (the rider's scratch device-coherently: it was written through another XCD's L2) ----
+  int row = -1, kept = 0, node = 0;
+  long long rec_lo = 0, rec_hi = 0;
+  constexpr int kMaxCols = 8;  // feature columns per lane held in registers: D <= 512, wider rows are copied after the wait
+  float xv[kMaxCols];
+  const float* x = nullptr;
+  const bool wide = a.D > kMaxCols * kWave;
+  if (ok && p < a.m) {
+    row = ld_agent(&a.winner[p]);
+    kept = ld_agent(&a.target[p]);
+    if (row >= 0) {
+      const long long* src = reinterpret_cast<const long long*>(&a.sorted_rec[p]);
+      rec_lo = ld_agent(&src[0]);
+      rec_hi = ld_agent(&src[1]);
+    }
+    if (kept > 0) node = ld_agent(&a.sorted_node[p]);
+    if (row >= 0 && a.D > 0 && a.edge_x) {
+      const long long j = ld_agent(&a.sorted_j[p]);
+      x = a.edge_x + (j >= a.n ? j - a.n : j) * a.D;
+      if (!wide) {
+#pragma unroll
+        for (int u = 0; u < kMaxCols; ++u) {
+          const int c = lane + u * kWave;
+          xv[u] = c < a.D ? x[c] : 0.f;
+        }
+      }
+    }
+  }
+  // ---- every lookup workgroup and the rider done: nobody reads the rings any more ----
+  if (threadIdx.x == 0) ok_s = (ok && tail_wait(&a.barrier[2], need)) ? 1 : 0;
+  __syncthreads();
+  ok = ok_s != 0;
+  if (!ok) {
+    if (threadIdx.x == 0) atomicOr(a.status, TGMX_ST_SCRATCH);
+  } else if (p < a.m) {
+    if (lane == 0) {
+      if (row >= 0) {
+        long long* dst = reinterpret_cast<long long*>(&a.ring[row]);
+        dst[0] = rec_lo;
+        dst[1] = rec_hi;
+      }
+      if (kept > 0) commit_write_pos(&a.write_pos[node], kept, a.B);
+    }
+    if (row >= 0 && a.D > 0) {
+      float* __restrict__ o = a.ring_x + (long long)row * a.D;
+      if (!x) {
+        for (int c = lane; c < a.D; c += kWave) o[c] = 0.f;
+      } else if (wide) {
+        for (int c = lane; c < a.D; c += kWave) o[c] = x[c];
+      } else {
+#pragma unroll
+        for (int u = 0; u < kMaxCols; ++u) {
+          const int c = lane + u * kWave;
+          if (c < a.D) o[c] = xv[u];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int prev = __hip_atomic_fetch_add(&a.barrier[3], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev == (int)tail_blocks - 1) {  // last one out: leave the words zero for the next launch
+      __hip_atomic_store(&a.barrier[2], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&a.barrier[3], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&a.barrier[4], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 union RiderLds {
   ChunkSortLds sort;
   SampleLds smp;
@@ -1038,17 +1160,22 @@ __device__ __forceinline__ void lookup_seed(const LookupArgs& a, long long s, in
   __builtin_amdgcn_wave_barrier();  // the next seed reuses lds_eid
 }
 
-template <bool RING, int VEC, bool SMALL>
+template <bool RING, int VEC, bool SMALL, bool RIDE>
 __global__ __launch_bounds__(256) void recency_lookup_kernel(const LookupArgs a, const UpdateArgs u) {
   extern __shared__ __attribute__((aligned(16))) int lds_eid_all[];
   unsigned bid = blockIdx.x, nblk = gridDim.x;
-  if constexpr (RING) {
+  if constexpr (RING && RIDE) {
     if (bid < a.side_blocks) {
       update_side_work(u, a.side_stage, (int)bid);
+      if (a.tail_blocks) tail_signal(u.barrier, true, 0, 0);
       return;
     }
     bid -= a.side_blocks;
-    nblk -= a.side_blocks;
+    nblk -= a.side_blocks + a.tail_blocks;
+    if (bid >= nblk) {  // the launch's last workgroups: the update's write-back, once everyone else is done
+      tail_commit(u, bid - nblk, a.tail_blocks, nblk + a.side_blocks);
+      return;
+    }
   }
   const int lane = lane_id();
   const int wave_in_block = threadIdx.x >> 6;
@@ -1060,6 +1187,9 @@ __global__ __launch_bounds__(256) void recency_lookup_kernel(const LookupArgs a,
     fetch_seed(a, s, lane, true, n, q);
     check_seed(a, n, q, a.allow_pad, lane);
     lookup_seed<RING, VEC, SMALL>(a, s, n, q, a.k, lane, lds_eid, a.out_nid, a.out_ts, a.out_x);
+  }
+  if constexpr (RING && RIDE) {
+    if (a.tail_blocks) tail_signal(u.barrier, false, bid, nblk);
   }
 }
 
@@ -1076,10 +1206,15 @@ __global__ __launch_bounds__(256) void recency_lookup_fused01_kernel(const Looku
   if constexpr (RING) {
     if (bid < a.side_blocks) {
       update_side_work(u, a.side_stage, (int)bid);
+      if (a.tail_blocks) tail_signal(u.barrier, true, 0, 0);
       return;
     }
     bid -= a.side_blocks;
-    nblk -= a.side_blocks;
+    nblk -= a.side_blocks + a.tail_blocks;
+    if (bid >= nblk) {  // the launch's last workgroups: the update's write-back, once everyone else is done
+      tail_commit(u, bid - nblk, a.tail_blocks, nblk + a.side_blocks);
+      return;
+    }
   }
   const int lane = lane_id();
   const int wave_in_block = threadIdx.x >> 6;
@@ -1107,6 +1242,9 @@ __global__ __launch_bounds__(256) void recency_lookup_fused01_kernel(const Looku
       lookup_seed<RING, VEC, true>(a, idx, n, q, k1, lane, lds_eid, a.out_nid1, a.out_ts1, a.out_x1);
     }
   }
+  if constexpr (RING) {
+    if (a.tail_blocks) tail_signal(u.barrier, false, bid, nblk);
+  }
 }
 
 // Narrow feature rows (k * D small, e.g. D = 16): one wave per seed moves ~1 KB behind a chain of dependent loads, so
@@ -1114,19 +1252,27 @@ __global__ __launch_bounds__(256) void recency_lookup_fused01_kernel(const Looku
 // wave, the same ballot / shuffle logic inside the group's slice of the wave, 2-4x the loads in flight.  Plain seed
 // arrays only (hops >= 1).  RING: streaming rings (and the riders of the ring update); else the static index, with
 // the batch-boundary prefix searches done per group.
-template <bool RING, int VEC, int GL>
+// RIDE = false: no rider workgroups in this launch (large batches take the radix-sort update on the side stream, the
+// static index has no update) -- the instantiation then carries no rider LDS (24.9 KB static, i.e. 6 workgroups per CU)
+// and the launch runs at twice the occupancy, which is what this latency-bound kernel lives on.
+template <bool RING, int VEC, int GL, bool RIDE>
 __global__ __launch_bounds__(256) void lookup_packed_kernel(const LookupArgs a, const UpdateArgs u) {
   using V = typename VecOf<VEC>::type;
   constexpr int kGroups = kWave / GL;
   extern __shared__ __attribute__((aligned(16))) int lds_eid_all[];
   unsigned bid = blockIdx.x, nblk = gridDim.x;
-  if constexpr (RING) {
+  if constexpr (RING && RIDE) {
     if (bid < a.side_blocks) {
       update_side_work(u, a.side_stage, (int)bid);
+      if (a.tail_blocks) tail_signal(u.barrier, true, 0, 0);
       return;
     }
     bid -= a.side_blocks;
-    nblk -= a.side_blocks;
+    nblk -= a.side_blocks + a.tail_blocks;
+    if (bid >= nblk) {  // the launch's last workgroups: the update's write-back, once everyone else is done
+      tail_commit(u, bid - nblk, a.tail_blocks, nblk + a.side_blocks);
+      return;
+    }
   }
   const int lane = lane_id();
   const int sub = lane / GL, gl = lane - sub * GL;
@@ -1219,6 +1365,9 @@ __global__ __launch_bounds__(256) void lookup_packed_kernel(const LookupArgs a, 
     }
     __builtin_amdgcn_wave_barrier();
   }
+  if constexpr (RING && RIDE) {
+    if (a.tail_blocks) tail_signal(u.barrier, false, bid, nblk);
+  }
 }
 
 // gather width (floats per load) for this launch's alignment; fills row_vecs and the slot divider
@@ -1255,33 +1404,40 @@ static int packed_group_lanes(const LookupArgs& a, int k, bool ring) {
 
 template <bool RING>
 static int launch_lookup(LookupArgs a, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop,
-                         const UpdateArgs* side = nullptr, int side_stage = 0, unsigned side_blocks = 0) {
+                         const UpdateArgs* side = nullptr, int side_stage = 0, unsigned side_blocks = 0, unsigned tail_blocks = 0) {
   if (a.S == 0) return TGMX_OK;
   const UpdateArgs u = side ? *side : UpdateArgs{};
   a.side_blocks = (RING && side) ? side_blocks : 0;
   a.side_stage = side_stage;
+  a.tail_blocks = a.side_blocks ? tail_blocks : 0;
   const bool small = a.B <= kWave && a.k <= kWave;
   const int vec = prepare_lookup(a, a.out_x, a.k);
   if (vec < 0) return vec;
   const int waves_per_block = 4;
   long long blocks = (a.S + waves_per_block - 1) / waves_per_block;
   if (blocks > (1 << 20)) blocks = 1 << 20;
-  const dim3 grid((unsigned)blocks + a.side_blocks), block(waves_per_block * kWave);
+  const dim3 grid((unsigned)blocks + a.side_blocks + a.tail_blocks), block(waves_per_block * kWave);
   const size_t lds = (size_t)waves_per_block * a.k * sizeof(int);
-#define TGMX_LAUNCH(VEC_, SMALL_) \
-  TGMX_LAUNCH_TIMED((recency_lookup_kernel<RING, VEC_, SMALL_>), grid, block, lds, stream, ev_start, ev_stop, a, u)
+  const bool ride = RING && a.side_blocks > 0;
+#define TGMX_LAUNCH(VEC_, SMALL_)                                                                                              \
+  do {                                                                                                                         \
+    if (ride) TGMX_LAUNCH_TIMED((recency_lookup_kernel<RING, VEC_, SMALL_, true>), grid, block, lds, stream, ev_start, ev_stop, a, u); \
+    else TGMX_LAUNCH_TIMED((recency_lookup_kernel<RING, VEC_, SMALL_, false>), grid, block, lds, stream, ev_start, ev_stop, a, u);     \
+  } while (0)
   // narrow rows: several seeds per wave (streaming rings, plain seed arrays)
   const int gl = a.grp.groups == 0 ? packed_group_lanes(a, a.k, true) : 64;
   if (gl < 64) {
     const int per_wave = 64 / gl;
     long long pblocks = ((a.S + per_wave - 1) / per_wave + waves_per_block - 1) / waves_per_block;
     if (pblocks > (1 << 20)) pblocks = 1 << 20;
-    const dim3 pgrid((unsigned)pblocks + a.side_blocks);
+    const dim3 pgrid((unsigned)pblocks + a.side_blocks + a.tail_blocks);
     const size_t plds = (size_t)waves_per_block * per_wave * a.k * sizeof(int);
 #define TGMX_PACKED(VEC_)                                                                              \
   do {                                                                                                 \
-    if (gl == 16) TGMX_LAUNCH_TIMED((lookup_packed_kernel<RING, VEC_, 16>), pgrid, block, plds, stream, ev_start, ev_stop, a, u); \
-    else TGMX_LAUNCH_TIMED((lookup_packed_kernel<RING, VEC_, 32>), pgrid, block, plds, stream, ev_start, ev_stop, a, u);          \
+    if (gl == 16 && ride) TGMX_LAUNCH_TIMED((lookup_packed_kernel<RING, VEC_, 16, true>), pgrid, block, plds, stream, ev_start, ev_stop, a, u); \
+    else if (gl == 16) TGMX_LAUNCH_TIMED((lookup_packed_kernel<RING, VEC_, 16, false>), pgrid, block, plds, stream, ev_start, ev_stop, a, u);  \
+    else if (ride) TGMX_LAUNCH_TIMED((lookup_packed_kernel<RING, VEC_, 32, true>), pgrid, block, plds, stream, ev_start, ev_stop, a, u);       \
+    else TGMX_LAUNCH_TIMED((lookup_packed_kernel<RING, VEC_, 32, false>), pgrid, block, plds, stream, ev_start, ev_stop, a, u);                \
   } while (0)
     if (vec == 4) TGMX_PACKED(4);
     else if (vec == 2) TGMX_PACKED(2);
@@ -1305,10 +1461,11 @@ static int launch_lookup(LookupArgs a, hipStream_t stream, hipEvent_t ev_start, 
 // hop 0 (a: seeds / groups, k, outputs) and hop 1 (k1, out_*1) as one launch; the caller checked can_fuse01
 template <bool RING>
 static int launch_fused01(LookupArgs a, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop, const UpdateArgs* side,
-                          int side_stage, unsigned side_blocks) {
+                          int side_stage, unsigned side_blocks, unsigned tail_blocks = 0) {
   const UpdateArgs u = side ? *side : UpdateArgs{};
   a.side_blocks = (RING && side) ? side_blocks : 0;
   a.side_stage = side_stage;
+  a.tail_blocks = a.side_blocks ? tail_blocks : 0;
   const int kmax = a.k > a.k1 ? a.k : a.k1;
   const int vec = prepare_lookup(a, a.out_x1, kmax);
   if (vec < 0) return vec;
@@ -1316,7 +1473,7 @@ static int launch_fused01(LookupArgs a, hipStream_t stream, hipEvent_t ev_start,
   const long long waves = a.S + a.S * a.k;
   long long blocks = (waves + waves_per_block - 1) / waves_per_block;
   if (blocks > (1 << 20)) blocks = 1 << 20;
-  const dim3 grid((unsigned)blocks + a.side_blocks), block(waves_per_block * kWave);
+  const dim3 grid((unsigned)blocks + a.side_blocks + a.tail_blocks), block(waves_per_block * kWave);
   const size_t lds = (size_t)waves_per_block * kmax * sizeof(int);
   if (vec == 4) TGMX_LAUNCH_TIMED((recency_lookup_fused01_kernel<RING, 4>), grid, block, lds, stream, ev_start, ev_stop, a, u);
   else if (vec == 2) TGMX_LAUNCH_TIMED((recency_lookup_fused01_kernel<RING, 2>), grid, block, lds, stream, ev_start, ev_stop, a, u);
@@ -1713,7 +1870,7 @@ extern "C" int tgmx_ring_lookup(const tgmx_adj_t* ring, const int32_t* write_pos
   return launch_lookup<true>(a, (hipStream_t)stream, (hipEvent_t)ev_start, (hipEvent_t)ev_stop);
 }
 
-constexpr int kScratchHead = 64;  // ints (256 bytes: the layouts behind it stay 256-byte aligned)
+constexpr int kScratchHead = 1024;  // ints (4 KiB, zero at first use: barrier words + the tail commit's grouped counters; the layouts behind it stay 256-byte aligned)
 
 static int fill_update_args(UpdateArgs& a, tgmx_adj_t* ring, int32_t* write_pos, float* ring_x, int32_t D, int32_t B,
                             int32_t num_nodes, const int32_t* src, const int32_t* dst, const int64_t* ts,
@@ -1980,6 +2137,13 @@ extern "C" int tgmx_recency_step(const tgmx_recency_step_t* s, tgmx_stream_t str
     if (u.m <= kBlockMaxM && s->n_hops > 0 && S > 0 && !no_ride) side_chunks = set_chunk_scratch(u, s->scratch + kScratchHead);
     ride_place = side_chunks > 0 && u.m <= kRidePlaceMaxM && s->n_hops >= 2;
   }
+  // m <= 1024 and the placement rides: the write-back (records, write_pos, feature rows) CAN run as the tail of the last
+  // lookup launch -- its last ceil(m / 4) workgroups prefetch their decisions, wait for the others, then store -- instead
+  // of a launch of its own.  Measured on MI355X (wiki shape): lookup 37.9 + commit 5.3 us as two launches, 44.9 us as one
+  // (the launch-wide wait costs more than the launch boundary it replaces), so it is OFF unless TGMX_TAIL=1 (A/B knob;
+  // results identical, covered by the same tests).
+  static const bool use_tail = getenv("TGMX_TAIL") != nullptr;
+  const unsigned tail_blocks = (ride_place && use_tail && s->n_hops == 2) ? (unsigned)((u.m + 3) / 4) : 0u;
   SideStream* side = nullptr;  // set: the large update's front half runs on the side stream next to the lookups
   if (s->n > 0 && u.m > kBlockMaxM && s->n_hops > 0 && S > 0 && (side = side_stream_for_current_device()) != nullptr) {
     (void)hipEventRecord(side->fork, st);  // the batch's inputs and the previous batch's ring writes are complete
@@ -2009,7 +2173,7 @@ extern "C" int tgmx_recency_step(const tgmx_recency_step_t* s, tgmx_stream_t str
     // riders: m <= 1024 -> one workgroup does it all and only the commit follows; else sort | barrier | merge
     const int rc = csr ? launch_fused01<false>(a, st, e0, e1, nullptr, 0, 0)
                        : launch_fused01<true>(a, st, e0, e1, side_chunks > 0 ? &u : nullptr,
-                                              ride_place ? kSideAll : kSideSortMerge, ride_place ? 1u : side_chunks);
+                                              ride_place ? kSideAll : kSideSortMerge, ride_place ? 1u : side_chunks, tail_blocks);
     if (rc) return rc;
     cur_n = s->out_nid[1];
     cur_t = s->out_ts[1];
@@ -2033,7 +2197,7 @@ extern "C" int tgmx_recency_step(const tgmx_recency_step_t* s, tgmx_stream_t str
     const int rc = csr ? launch_lookup<false>(a, st, e0, e1)
                        : launch_lookup<true>(a, st, e0, e1, ride ? &u : nullptr,
                                              h == 0 ? kSideSort : (ride_place ? kSidePlace : kSideMerge),
-                                             (h == 1 && ride_place) ? 1u : side_chunks);
+                                             (h == 1 && ride_place) ? 1u : side_chunks, (h == 1 && ride_place) ? tail_blocks : 0u);
     if (rc) return rc;
     cur_n = s->out_nid[h];
     cur_t = s->out_ts[h];
@@ -2042,7 +2206,9 @@ extern "C" int tgmx_recency_step(const tgmx_recency_step_t* s, tgmx_stream_t str
 
   // ---- ring update (after every lookup, recency.py:161-163)
   if (s->n > 0) {
-    if (ride_place) {
+    if (ride_place && tail_blocks) {
+      // written by the tail of the last lookup launch
+    } else if (ride_place) {
       hipLaunchKernelGGL(ring_update_feat_kernel<true>, dim3((unsigned)((u.m + 3) / 4)), dim3(256), 0, st, u);
     } else if (side_chunks > 0) {
       if (s->n_hops < 2) hipLaunchKernelGGL(ring_update_merge_kernel, dim3(side_chunks), dim3(kChunk), 0, st, u);
