@@ -1252,12 +1252,107 @@ __global__ __launch_bounds__(256) void recency_lookup_fused01_kernel(const Looku
 // wave, the same ballot / shuffle logic inside the group's slice of the wave, 2-4x the loads in flight.  Plain seed
 // arrays only (hops >= 1).  RING: streaming rings (and the riders of the ring update); else the static index, with
 // the batch-boundary prefix searches done per group.
+// ---- narrow rows: one GROUP of GL lanes per seed (64 / GL seeds per wave) ----------------------------------------------
+// the k most recent neighbors of (n, q) inside the group's slice of the wave: lane gl < k gets output slot gl
+struct GroupPick {
+  bool has;
+  int nbr, src;  // src: feature row of the slot (ring slot / edge id), -1 for a pad
+  long long ts;
+};
+
+template <bool RING, int GL>
+__device__ __forceinline__ GroupPick group_pick(const LookupArgs& a, int n, long long q, int k, bool live, int gl, int sub) {
+  const int B = a.B;
+  // window of <= B records in time order: the ring row rotated by write_pos, or the last B visible index entries
+  long long w0 = 0;
+  int wrot = 0, wlen = 0;
+  if constexpr (RING) {
+    w0 = (long long)(live ? n : 0) * B;
+    wrot = live ? a.write_pos[n] % B : 0;
+    wlen = live ? B : 0;
+  } else {
+    const long long ra = live ? a.indptr[n] : 0, rz = live ? a.indptr[n + 1] : 0;
+    const long long p_hi = ra + group_prefix_count<GL>(a.recs, ra, rz, a.ev_hi, gl, sub);
+    const long long p_lo = a.ev_lo <= 0 ? ra : ra + group_prefix_count<GL>(a.recs, ra, rz, a.ev_lo, gl, sub);
+    w0 = p_hi - B > p_lo ? p_hi - B : p_lo;
+    wlen = (int)(p_hi - w0);
+  }
+  Rec r;
+  r.nbr = -1; r.eid = 0; r.ts = 0;
+  if (gl < wlen) r = a.recs[w0 + gl];  // RING: slot order (no wait for write_pos), rotated into time order below
+  if constexpr (RING) {
+    int from_slot = wrot + gl;
+    if (from_slot >= B) from_slot -= B;
+    if (gl >= B) from_slot = gl;
+    r.nbr = __shfl(r.nbr, sub * GL + from_slot);
+    r.ts = __shfl(r.ts, sub * GL + from_slot);
+  }
+  const bool ok = gl < wlen && r.nbr >= 0 && r.ts < q;
+  const unsigned long long m = (__ballot(ok) >> (sub * GL)) & ((GL == 64) ? ~0ull : ((1ull << GL) - 1));
+  const int cnt = m ? 64 - __clzll((long long)m) : 0;  // 1 + position of the rightmost valid entry, inside the group
+  const int i = cnt - k + gl;
+  const int from = i > 0 ? i : 0;
+  const int g_nbr = __shfl(r.nbr, sub * GL + from);
+  const int g_eid = __shfl(r.eid, sub * GL + from);
+  const long long g_ts = __shfl(r.ts, sub * GL + from);
+  GroupPick o;
+  o.has = i >= 0 && g_nbr >= 0;
+  o.nbr = o.has ? g_nbr : -1;
+  o.ts = o.has ? g_ts : 0;
+  int sl = wrot + from;
+  if (sl >= B) sl -= B;
+  o.src = o.has ? (RING ? (int)(w0 + sl) : g_eid) : -1;
+  return o;
+}
+
+// row s of (out_nid, out_ts, out_x) from the group's pick; k is wave-uniform
+template <int VEC, int GL>
+__device__ __forceinline__ void group_emit(const LookupArgs& a, bool act, long long s, int k, const GroupPick& o, int* lds_eid, int gl,
+                                           int32_t* out_nid, int64_t* out_ts, float* out_x) {
+  using V = typename VecOf<VEC>::type;
+  if (act && gl < k) {
+    out_nid[s * k + gl] = o.nbr;
+    out_ts[s * k + gl] = o.ts;
+    lds_eid[gl] = o.src;
+  }
+  if (a.D == 0) return;
+  __builtin_amdgcn_wave_barrier();
+  if (act) {
+    const V* __restrict__ X = reinterpret_cast<const V*>(a.edge_x);
+    V* __restrict__ O = reinterpret_cast<V*>(out_x + s * (long long)k * a.D);
+    const int total = k * a.row_vecs;
+    constexpr int U = 4;
+    for (int f0 = gl; f0 < total; f0 += GL * U) {
+      V v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int f = f0 + u * GL;
+        v[u] = zero_vec<V>();
+        if (f < total) {
+          const int slot = (int)a.dv.div((uint32_t)f);
+          const int col = f - slot * a.row_vecs;
+          const int e = lds_eid[slot];
+          if (e >= 0) v[u] = X[(long long)e * a.row_vecs + col];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int f = f0 + u * GL;
+        if (f < total) O[f] = v[u];
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
 // RIDE = false: no rider workgroups in this launch (large batches take the radix-sort update on the side stream, the
 // static index has no update) -- the instantiation then carries no rider LDS (24.9 KB static, i.e. 6 workgroups per CU)
 // and the launch runs at twice the occupancy, which is what this latency-bound kernel lives on.
+// (Hop 0 inside this launch -- hop-1 groups re-deriving their seed like recency_lookup_fused01_kernel does for wide rows --
+// was measured and dropped: the re-derivation doubles the chain of dependent reads this kernel is bound by; review shape
+// 18.0 + 6.4 us as two launches vs 32.6 us fused, comment shape 123 + 18 vs 186 us.)
 template <bool RING, int VEC, int GL, bool RIDE>
 __global__ __launch_bounds__(256) void lookup_packed_kernel(const LookupArgs a, const UpdateArgs u) {
-  using V = typename VecOf<VEC>::type;
   constexpr int kGroups = kWave / GL;
   extern __shared__ __attribute__((aligned(16))) int lds_eid_all[];
   unsigned bid = blockIdx.x, nblk = gridDim.x;
@@ -1277,7 +1372,7 @@ __global__ __launch_bounds__(256) void lookup_packed_kernel(const LookupArgs a, 
   const int lane = lane_id();
   const int sub = lane / GL, gl = lane - sub * GL;
   const int wave_in_block = threadIdx.x >> 6;
-  const int k = a.k, B = a.B;
+  const int k = a.k;
   int* lds_eid = lds_eid_all + (wave_in_block * kGroups + sub) * k;
   const long long waves_total = (long long)nblk * (blockDim.x >> 6);
   const long long n_rounds = (a.S + kGroups - 1) / kGroups;
@@ -1286,91 +1381,20 @@ __global__ __launch_bounds__(256) void lookup_packed_kernel(const LookupArgs a, 
     const bool act = s < a.S;
     const int n = act ? a.seeds[s] : -1;
     const long long q = act ? a.qtimes[s] : 0;
-    const bool live = n >= 0 && n < a.N;
     if (act && gl == 0) {
       int st = 0;
       if (n >= a.N || n < -1 || (n == -1 && !a.allow_pad)) st |= TGMX_ST_SEED_RANGE;
       if (q < 0 && !a.allow_pad) st |= TGMX_ST_SEED_TIME;
       if (st) atomicOr(a.status, st);
     }
-    // window of <= B records in time order: the ring row rotated by write_pos, or the last B visible index entries
-    long long w0 = 0;
-    int wrot = 0, wlen = 0;
-    if constexpr (RING) {
-      w0 = (long long)(live ? n : 0) * B;
-      wrot = live ? a.write_pos[n] % B : 0;
-      wlen = live ? B : 0;
-    } else {
-      const long long ra = live ? a.indptr[n] : 0, rz = live ? a.indptr[n + 1] : 0;
-      const long long p_hi = ra + group_prefix_count<GL>(a.recs, ra, rz, a.ev_hi, gl, sub);
-      const long long p_lo = a.ev_lo <= 0 ? ra : ra + group_prefix_count<GL>(a.recs, ra, rz, a.ev_lo, gl, sub);
-      w0 = p_hi - B > p_lo ? p_hi - B : p_lo;
-      wlen = (int)(p_hi - w0);
-    }
-    auto slot_of = [&](int i) -> long long {
-      int sl = wrot + i;
-      if (sl >= B) sl -= B;
-      return w0 + sl;
-    };
-    Rec r;
-    r.nbr = -1; r.eid = 0; r.ts = 0;
-    if (gl < wlen) r = a.recs[w0 + gl];  // RING: slot order (no wait for write_pos), rotated into time order below
-    if constexpr (RING) {
-      int from_slot = wrot + gl;
-      if (from_slot >= B) from_slot -= B;
-      if (gl >= B) from_slot = gl;
-      r.nbr = __shfl(r.nbr, sub * GL + from_slot);
-      r.ts = __shfl(r.ts, sub * GL + from_slot);
-    }
-    const bool ok = gl < wlen && r.nbr >= 0 && r.ts < q;
-    const unsigned long long m = (__ballot(ok) >> (sub * GL)) & ((GL == 64) ? ~0ull : ((1ull << GL) - 1));
-    const int cnt = m ? 64 - __clzll((long long)m) : 0;  // 1 + position of the rightmost valid entry, inside the group
-    const int i = cnt - k + gl;
-    const int from = i > 0 ? i : 0;
-    const int g_nbr = __shfl(r.nbr, sub * GL + from);
-    const int g_eid = __shfl(r.eid, sub * GL + from);
-    const long long g_ts = __shfl(r.ts, sub * GL + from);
-    if (act && gl < k) {
-      const bool has = i >= 0 && g_nbr >= 0;
-      a.out_nid[s * k + gl] = has ? g_nbr : -1;
-      a.out_ts[s * k + gl] = has ? g_ts : 0;
-      lds_eid[gl] = has ? (RING ? (int)slot_of(from) : g_eid) : -1;
-    }
-    if (a.D == 0) continue;
-    __builtin_amdgcn_wave_barrier();
-    if (act) {
-      const V* __restrict__ X = reinterpret_cast<const V*>(a.edge_x);
-      V* __restrict__ O = reinterpret_cast<V*>(a.out_x + s * (long long)k * a.D);
-      const int total = k * a.row_vecs;
-      constexpr int U = 4;
-      for (int f0 = gl; f0 < total; f0 += GL * U) {
-        V v[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int f = f0 + u * GL;
-          v[u] = zero_vec<V>();
-          if (f < total) {
-            const int slot = (int)a.dv.div((uint32_t)f);
-            const int col = f - slot * a.row_vecs;
-            const int e = lds_eid[slot];
-            if (e >= 0) v[u] = X[(long long)e * a.row_vecs + col];
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int f = f0 + u * GL;
-          if (f < total) O[f] = v[u];
-        }
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
+    const GroupPick o = group_pick<RING, GL>(a, n, q, k, n >= 0 && n < a.N, gl, sub);
+    group_emit<VEC, GL>(a, act, s, k, o, lds_eid, gl, a.out_nid, a.out_ts, a.out_x);
   }
   if constexpr (RING && RIDE) {
     if (a.tail_blocks) tail_signal(u.barrier, false, bid, nblk);
   }
 }
 
-// gather width (floats per load) for this launch's alignment; fills row_vecs and the slot divider
 // A launch that may be timed: with an event pair the kernel goes through hipExtLaunchKernelGGL, whose events carry the
 // dispatch's OWN begin / end timestamps (what rocprofv3 --kernel-trace reports); hipEventRecord before / after the launch
 // brackets it from outside and adds the command processor's event handling (~4-6 us under a full queue)

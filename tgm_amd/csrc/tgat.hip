@@ -758,8 +758,56 @@ __global__ __launch_bounds__(256) void tgat_attn_reduce_reg_kernel(const AttnArg
     my_ok = a.mask ? a.mask[r * k + lane] != 0 : lv.nbr_id[r * k + lane] != -1;
   }
 
-  // ---- the row's features, straight into registers (all loads independent) ----
+  // The sampler's all-pad row (every seed that is itself a pad slot of the hop above: ~1/3 of the layer-1 rows at the
+  // headline shape): no valid slot, so the reference attends uniformly (attention.py:114-118) over k slots that are all
+  // the same pad entry -- the same neighbor row (node -1), zero edge features (recency.py:287-319 pads with 0.0) and one
+  // time delta.  The uniform average of k identical vectors is that vector: no scores, no softmax, ONE slot read instead
+  // of k.  (Differs from summing k products by (1/k) in the last bit or two: ~1e-7 relative.)  Applies to id-masked
+  // rows only; an explicit mask tensor takes the general path.
   const bool e_on = lane < D4;
+  {
+    const unsigned kmask = k >= 32 ? 0xffffffffu : ((1u << k) - 1u);
+    const bool none = ((unsigned)__ballot(my_ok) & kmask) == 0 && !a.mask;
+    const float dt0 = lane_bcast(my_dt, 0);
+    if (none && __all(lane >= k || my_dt == dt0)) {
+      const float A = 1.0f / (float)k;  // softmax of k equal scores
+      if (a.probs && lane < H * k) a.probs[r * (long long)H * k + lane] = A;
+      float wh[H];
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        wh[h] = 1.f;
+        if (a.drop.thresh) {  // sum over the slots of A * dropout scale
+          float acc = 0.f;
+          for (int s2 = 0; s2 < k; ++s2) acc += A * dropout_scale(a.drop, (unsigned long long)(a.drop_row0 + r) * (H * k) + h * k + s2);
+          wh[h] = acc;
+        }
+      }
+      const bool t0 = lane < T, t1 = lane + kWave < T;
+      const float c0 = cos_t2v(__fmaf_rn(dt0, t0 ? a.tw[lane] : 0.f, t0 ? a.tb[lane] : 0.f));
+      const float c1 = cos_t2v(__fmaf_rn(dt0, t1 ? a.tw[lane + kWave] : 0.f, t1 ? a.tb[lane + kWave] : 0.f));
+      const float4 e = e_on ? ex4[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+      float* __restrict__ zb0 = a.zbar + r * (long long)H * a.Cs;
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        float* zh = zb0 + h * a.Cs;
+        const float w = wh[h];
+        if (NBV) {
+          if (lane < d4) {
+            const float4 v = reinterpret_cast<const float4*>(nb)[lane];
+            zh[4 * lane] = w * v.x; zh[4 * lane + 1] = w * v.y; zh[4 * lane + 2] = w * v.z; zh[4 * lane + 3] = w * v.w;
+          }
+        } else if (lane < d) {
+          zh[lane] = w * nb[lane];
+        }
+        if (e_on) { zh[d + 4 * lane] = w * e.x; zh[d + 4 * lane + 1] = w * e.y; zh[d + 4 * lane + 2] = w * e.z; zh[d + 4 * lane + 3] = w * e.w; }
+        if (t0) zh[d + D + lane] = w * c0;
+        if (t1) zh[d + D + lane + kWave] = w * c1;
+      }
+      return;
+    }
+  }
+
+  // ---- the row's features, straight into registers (all loads independent) ----
   float4 ze[G];
 #pragma unroll
   for (int s = 0; s < G; ++s) {
