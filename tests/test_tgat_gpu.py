@@ -66,10 +66,14 @@ def test_temporal_attention_matches_reference(case):
     out = m(node_x=T('node_x'), time_feat=T('time_feat'), edge_feat=T('edge_feat'), nbr_node_feat=T('nbr_node_feat'),
             nbr_time_feat=T('nbr_time_feat'), valid_nbr_mask=T('mask'))  # fmt: skip
     close(out, torch.from_numpy(a['out']), case)
+    # train mode: the two dropout sites of attention.py:119,126 are active (counter-based masks; the arithmetic given the
+    # masks is pinned in tests/test_tgat_backward_gpu.py) -- a fresh mask per call, eval untouched
+    kw = dict(node_x=T('node_x'), time_feat=T('time_feat'), edge_feat=T('edge_feat'), nbr_node_feat=T('nbr_node_feat'),
+              nbr_time_feat=T('nbr_time_feat'), valid_nbr_mask=T('mask'))  # fmt: skip
     m.train()
-    with pytest.raises(NotImplementedError):
-        m(node_x=T('node_x'), time_feat=T('time_feat'), edge_feat=T('edge_feat'), nbr_node_feat=T('nbr_node_feat'),
-          nbr_time_feat=T('nbr_time_feat'), valid_nbr_mask=T('mask'))  # fmt: skip
+    o1, o2 = m(**kw), m(**kw)
+    assert o1.shape == out.shape and not torch.equal(o1, o2) and not torch.equal(o1, out)
+    assert torch.equal(m.eval()(**kw), out)
 
 
 @pytest.mark.parametrize('H,k,nd,ed,td', [(1, 3, 2, 4, 5), (1, 64, 4, 8, 6), (2, 33, 3, 4, 7), (4, 20, 8, 12, 16), (8, 10, 8, 4, 12),
