@@ -471,7 +471,34 @@ int tgmx_tgn_aggregate(const int32_t* nodes, int64_t R, const float* memory,
                        const int64_t* st_lo_s, const int32_t* st_cnt_s, const int64_t* st_lo_d,
                        const int32_t* st_cnt_d, const int32_t* log_other, const int64_t* log_t,
                        const float* log_raw, int32_t D, const float* tw, const float* tb, int32_t T,
-                       int32_t mean, float* aggr, int64_t* new_lu, tgmx_stream_t stream);
+                       int32_t mean, float* aggr, int64_t* new_lu,
+                       int64_t* assoc /* optional [num_nodes]: assoc[nodes[r]] = (stamp << 32) | r, the reference's
+                                         self._assoc[n_id] = arange (tgn.py:193); NULL = not recorded */,
+                       int64_t stamp, tgmx_stream_t stream);
+
+/* TGNMemory.update_state in train mode (tgn.py:165-177) when the rows of the preceding forward are at hand: the
+ * reference commits _get_updated_memory(unique(src, dst)) -- for an unchanged state exactly the rows that forward produced
+ * -- so the commit is memory[v] = val[row(v)], last_update[v] = lu[row(v)] with row(v) from `assoc` (stamp-checked: a
+ * node that was not part of that forward sets *status to 1 and is skipped).  Duplicate nodes write identical values. */
+int tgmx_tgn_commit_assoc(const int32_t* src, const int32_t* dst, int64_t n, const int64_t* assoc, int64_t stamp,
+                          const float* val, const int64_t* lu, int32_t M, int32_t num_nodes, float* memory,
+                          int64_t* last_update, int32_t* status, tgmx_stream_t stream);
+
+/* TGNMemory._update_msg_store for both roles of one batch of n <= 1024 events (tgn.py:218-229, called at :173,176) in one
+ * launch: log rows [base, base + n) = events grouped by src (stable), [base + n, base + 2n) grouped by dst; every node's
+ * (lo, cnt) window is replaced. */
+int tgmx_tgn_store_batch(const int32_t* src, const int32_t* dst, const int64_t* t, const float* raw, int32_t D, int32_t n,
+                         int64_t base, int32_t* log_other, int64_t* log_t, float* log_raw, int64_t* st_lo_s,
+                         int32_t* st_cnt_s, int64_t* st_lo_d, int32_t* st_cnt_d, tgmx_stream_t stream);
+
+/* The sampled edge list of one hop as the reference's TGN loop assembles it from torch ops
+ * (examples/linkproppred/tgn.py:80-92): for every valid slot (nbr != -1), in slot order,
+ *   edge_index[0][e] = local(seed of the row), edge_index[1][e] = local(nbr), edge_t[e] = nbr_t, edge_x[e] = nbr_x row,
+ * local(v) = position of v in the sorted unique ids `uniq` (DeduplicationHook's global_to_local, tgm/hooks/dedup.py:60-66).
+ * edge_index is [2, cap] (row 1 starts at cap), cap >= S * k; *count = number of edges (device); row_off: scratch [S + 1]. */
+int tgmx_tgn_edge_list(const int32_t* seed, const int32_t* nbr, const int64_t* nbr_t, const float* nbr_x, int64_t S, int32_t k,
+                       int32_t D, const int32_t* uniq, int64_t U, int64_t cap, int64_t* row_off, int64_t* edge_index,
+                       int64_t* edge_t, float* edge_x, int64_t* count, tgmx_stream_t stream);
 
 /* torch.nn.GRUCell gates from gi = x W_ih^T + b_ih and gh = h W_hh^T + b_hh ([R, 3M], r|z|n). */
 int tgmx_tgn_gru_gate(const float* gi, const float* gh, const float* h, int32_t M, int64_t R,

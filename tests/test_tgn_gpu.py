@@ -118,3 +118,76 @@ def test_segment_sort_matches_stable_argsort(U, E):
     ids = torch.arange(U, device=DEV)
     assert torch.equal(order, ref_order)
     assert torch.equal(lo, torch.searchsorted(srt, ids, right=False)) and torch.equal(hi, torch.searchsorted(srt, ids, right=True))
+
+
+def _tgn_stream_pipeline(pool, seed=8):
+    from tgm_amd import DGData, DGDataLoader, DGraph
+    from tgm_amd.hooks import DeduplicationHook, HookManager, RandomNegativeEdgeSamplerHook, RecencyNeighborHook
+    from tgm_amd.synth import make_stream
+
+    st = make_stream('review', seed=seed, num_edges=6144, n_src=700, n_dst=100)
+    ts = st.ts[0] + torch.arange(st.num_edges) * 300
+    dg = DGraph(DGData.from_raw(ts, torch.stack([st.src, st.dst], 1), st.edge_x), device=DEV)
+    hm = HookManager(keys=['k'])
+    hm.register('k', RandomNegativeEdgeSamplerHook(700, st.num_nodes, seed=4))
+    hm.register('k', RecencyNeighborHook(st.num_nodes, [10], ['edge_src', 'edge_dst', 'neg'], ['edge_time', 'edge_time', 'neg_time'], validate='deferred'))
+    hm.register('k', DeduplicationHook(seed_nodes_keys=['neg', 'nbr_nids']))
+    return st, hm, DGDataLoader(dg, batch_size=512, hook_manager=hm, output_pool=pool)
+
+
+def _reference_glue(batch, k):
+    """examples/linkproppred/tgn.py:80-92, verbatim in torch ops"""
+    nbr = batch.nbr_nids[0].flatten()
+    mask = nbr != -1
+    seeds = torch.cat([batch.edge_src, batch.edge_dst, batch.neg]).repeat_interleave(k)
+    edge_index = torch.stack([batch.global_to_local(seeds[mask]), batch.global_to_local(nbr[mask])]).long()
+    return edge_index, batch.nbr_edge_time[0].flatten()[mask], batch.nbr_edge_x[0].flatten(0, -2)[mask]
+
+
+def test_sampled_edge_list_equals_the_reference_loop_s_torch_glue():
+    from tgm_amd.nn import sampled_edge_list
+
+    st, hm, loader = _tgn_stream_pipeline(pool=1)
+    with hm.activate('k'):
+        for b, batch in enumerate(loader):
+            ei, et, ex = sampled_edge_list(batch)
+            ei_ref, et_ref, ex_ref = _reference_glue(batch, 10)
+            assert ei.dtype == torch.int64 and torch.equal(ei, ei_ref), b
+            assert torch.equal(et, et_ref) and torch.equal(ex, ex_ref), b
+    assert b == 11
+
+
+@pytest.mark.parametrize('aggr', ['last', 'mean'])
+def test_reuse_forward_commits_the_same_state(aggr):
+    """TGNMemory.reuse_forward: update_state copies the rows the forward produced (tgn.py:165-177 recomputes them from the
+    same state) -- memory, last_update, the stores and every forward output stay bit-identical to the default path, with
+    fresh and with pooled sampler outputs; a node outside the forward's n_id is reported by check()."""
+    from tgm_amd.nn import GraphAttentionEmbedding, IdentityMessage, LastAggregator, MeanAggregator, TGNMemory, sampled_edge_list
+
+    runs = {}
+    for reuse in (False, True):
+        st, hm, loader = _tgn_stream_pipeline(pool=1 if reuse else 0)
+        N, D, M, T_ = st.num_nodes, 16, 32, 20
+        torch.manual_seed(5)
+        mem = TGNMemory(N, D, M, T_, IdentityMessage(D, M, T_), LastAggregator() if aggr == 'last' else MeanAggregator()).to(DEV).train()
+        enc = GraphAttentionEmbedding(M, 32, D, mem.time_enc).to(DEV).eval()
+        mem.reuse_forward = reuse
+        outs = []
+        with hm.activate('k'), torch.no_grad():
+            for batch in loader:
+                ei, et, ex = sampled_edge_list(batch) if reuse else _reference_glue(batch, 10)
+                z, lu = mem(batch.unique_nids)
+                outs.append((z.clone(), lu.clone(), enc(z, lu, ei, et, ex).clone()))
+                mem.update_state(batch.edge_src, batch.edge_dst, batch.edge_time, batch.edge_x)
+        mem.check()
+        runs[reuse] = (outs, mem.memory.clone(), mem.last_update.clone(), mem)
+    for (a, b) in zip(runs[False][0], runs[True][0]):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    assert torch.equal(runs[False][1], runs[True][1]) and torch.equal(runs[False][2], runs[True][2])
+    mem = runs[True][3]
+    mem(torch.tensor([1, 2, 3], dtype=torch.int32, device=DEV))
+    mem.update_state(torch.tensor([1, 699], dtype=torch.int32, device=DEV), torch.tensor([2, 3], dtype=torch.int32, device=DEV),
+                     torch.tensor([10**9, 10**9 + 1], device=DEV), torch.rand(2, 16, device=DEV))
+    with pytest.raises(RuntimeError, match='not in the preceding forward'):
+        mem.check()

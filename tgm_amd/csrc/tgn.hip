@@ -74,6 +74,8 @@ struct AggrArgs {
   int64_t* new_lu;          // [R]
   long long R;
   int M, D, T, N, mean;
+  int64_t* assoc;           // optional [N]: assoc[node] = (stamp << 32) | row  (tgn.py:193: self._assoc[n_id] = arange)
+  long long stamp;
 };
 
 __device__ __forceinline__ void tgn_message_cols(const AggrArgs& a, int lane, const float* mem_v, long long ev, long long lu_v,
@@ -101,6 +103,7 @@ __global__ __launch_bounds__(256) void tgn_aggregate_kernel(const AggrArgs a) {
   float* out = a.aggr + row * W;
   int v = a.nodes[row];
   if (v < 0) v += a.N;
+  if (a.assoc && lane == 0) a.assoc[v] = (a.stamp << 32) | row;
   const long long lu_v = a.last_update[v];
   const float* mem_v = a.memory + (long long)v * a.M;
   const long long lo0 = a.st_lo[0][v], lo1 = a.st_lo[1][v];
@@ -306,6 +309,188 @@ __global__ __launch_bounds__(1024) void group_ids_kernel(const int32_t* __restri
   if (first) first[tid] = opens ? 1 : 0;
 }
 
+
+// ---- update_state in train mode with the rows of the preceding forward (tgn.py:165-177) ------------------------------
+// The reference commits `_get_updated_memory(unique(src, dst))` -- the same rows its forward just produced for those
+// nodes (same state, same arithmetic).  With `assoc` filled by that forward's aggregation, the commit is a row copy:
+// memory[v] = val[row(v)], last_update[v] = lu[row(v)] for every batch entry (duplicates write the same values, so no
+// unique / first-occurrence pass).  An entry whose node was not part of that forward (stale stamp) raises *status.
+__global__ __launch_bounds__(256) void tgn_commit_assoc_kernel(const int32_t* __restrict__ src, const int32_t* __restrict__ dst, long long n,
+                                                               const int64_t* __restrict__ assoc, long long stamp,
+                                                               const float* __restrict__ val, const int64_t* __restrict__ lu, int M, int N,
+                                                               float* __restrict__ memory, int64_t* __restrict__ last_update,
+                                                               int32_t* __restrict__ status) {
+  const long long e = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (e >= 2 * n) return;
+  int v = e < n ? src[e] : dst[e - n];
+  if (v < 0) v += N;
+  const long long as = assoc[v];
+  if ((as >> 32) != stamp) {
+    if (lane_id() == 0) atomicOr(status, 1);
+    return;
+  }
+  const long long row = as & 0xffffffffll;
+  for (int c = lane_id(); c < M; c += kWave) memory[(long long)v * M + c] = val[row * M + c];
+  if (lane_id() == 0) last_update[v] = lu[row];
+}
+
+// ---- message store of one batch, BOTH roles, one launch (tgn.py:218-229 called twice, :173,176) -----------------------
+// Workgroup `role` (0: events keyed by src, other = dst; 1: keyed by dst, other = src) sorts its n <= 1024 keys stably
+// (the entry index rides in the key), finds every key's run, and writes the log rows [base + role * n, +n) in sorted order
+// plus the node's (lo, cnt) window -- what group_ids_kernel + tgn_store_kernel did as two launches per role.
+struct StoreBatchArgs {
+  const int32_t* src;
+  const int32_t* dst;
+  const int64_t* t;
+  const float* raw;  // [n, D]
+  int32_t* log_other;
+  int64_t* log_t;
+  float* log_raw;
+  int64_t* st_lo[2];
+  int32_t* st_cnt[2];
+  long long base;
+  int n, D;
+};
+
+__global__ __launch_bounds__(1024) void tgn_store_batch_kernel(const StoreBatchArgs a) {
+  __shared__ long long s_key[1024];
+  __shared__ int s_pay[1024];
+  __shared__ int s_id[1024];
+  __shared__ int s_start[1024];
+  __shared__ int s_perm[1024];
+  __shared__ int wave_tot[16];
+  const int role = blockIdx.x;
+  const int32_t* ids = role == 0 ? a.src : a.dst;
+  const int32_t* oth = role == 0 ? a.dst : a.src;
+  const int n = a.n;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, P = blockDim.x;
+  long long key = 0x7fffffffffffffffLL;
+  int pay = tid;
+  if (tid < n) key = (((long long)ids[tid] + (1ll << 31)) << kPackBits) | (long long)tid;
+  bitonic_sort_one<true>(key, pay, s_key, s_pay, tid, P);
+  const int id = tid < n ? (int)((key >> kPackBits) - (1ll << 31)) : 0x7fffffff;
+  s_id[tid] = id;
+  s_perm[tid] = pay;
+  __syncthreads();
+  const bool opens = tid == 0 || s_id[tid - 1] != id;
+  int incl = opens ? tid : 0;
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    const int o = __shfl_up(incl, off);
+    if (lane >= off) incl = o > incl ? o : incl;
+  }
+  if (lane == kWave - 1) wave_tot[wave] = incl;
+  __syncthreads();
+  for (int w = 0; w < wave; ++w) incl = wave_tot[w] > incl ? wave_tot[w] : incl;
+  s_start[tid] = incl;
+  __syncthreads();
+  const long long base = a.base + (long long)role * n;
+  if (tid < n) {
+    if (opens) {  // one writer per node: the run's (lo, cnt)
+      int hi = tid + 1;
+      while (hi < n && s_start[hi] == incl) ++hi;
+      a.st_lo[role][id] = base + incl;
+      a.st_cnt[role][id] = hi - incl;
+    }
+    a.log_other[base + tid] = oth[pay];
+    a.log_t[base + tid] = a.t[pay];
+  }
+  // raw rows: a wave per sorted position, round-robin
+  for (int p = wave; p < n; p += (P >> 6)) {
+    const int e = s_perm[p];
+    for (int c = lane; c < a.D; c += kWave) a.log_raw[(base + p) * a.D + c] = a.raw[(long long)e * a.D + c];
+  }
+}
+
+// ---- the sampled edge list of one hop, as the reference's TGN loop builds it (examples/linkproppred/tgn.py:80-92) ------
+//   mask = nbr != -1;  edge_index = [global_to_local(seed.repeat_interleave(k)[mask]); global_to_local(nbr[mask])]
+//   edge_t = nbr_t[mask];  edge_x = nbr_x[mask]     -- order = slot order, local ids = position in the sorted unique ids
+// Two launches: per-row valid counts + exclusive scan (one workgroup), then a wave per seed row writes its valid slots.
+__global__ __launch_bounds__(1024) void edge_list_scan_kernel(const int32_t* __restrict__ nbr, long long S, int k, int64_t* __restrict__ row_off,
+                                                              int64_t* __restrict__ count) {
+  __shared__ long long wave_tot[16];
+  __shared__ long long carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (long long r0 = 0; r0 < S; r0 += 1024) {
+    const long long r = r0 + tid;
+    long long c = 0;
+    if (r < S)
+      for (int s = 0; s < k; ++s) c += nbr[r * k + s] != -1;
+    long long incl = c;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+      const long long o = __shfl_up(incl, off);
+      if (lane >= off) incl += o;
+    }
+    if (lane == kWave - 1) wave_tot[wave] = incl;
+    __syncthreads();
+    long long before = carry_s;
+    for (int w = 0; w < wave; ++w) before += wave_tot[w];
+    if (r < S) row_off[r] = before + incl - c;
+    __syncthreads();
+    if (tid == 1023) carry_s = before + incl;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    row_off[S] = carry_s;
+    *count = carry_s;
+  }
+}
+
+struct EdgeListArgs {
+  const int32_t* seed;   // [S]
+  const int32_t* nbr;    // [S, k]
+  const int64_t* nbr_t;  // [S, k]
+  const float* nbr_x;    // [S, k, D]
+  const int32_t* uniq;   // [U] sorted unique ids
+  const int64_t* row_off;
+  int64_t* ei;           // [2, cap]
+  int64_t* et;           // [cap]
+  float* ex;             // [cap, D]
+  long long S, U, cap;
+  int k, D;
+};
+
+__device__ __forceinline__ long long local_id(const int32_t* __restrict__ uniq, long long U, int v) {  // searchsorted(left)
+  long long lo = 0, hi = U;
+  while (lo < hi) {
+    const long long mid = (lo + hi) >> 1;
+    if (uniq[mid] < v) lo = mid + 1;
+    else hi = mid;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void edge_list_write_kernel(const EdgeListArgs a) {
+  const long long r = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (r >= a.S) return;
+  const int lane = lane_id();
+  const int k = a.k;
+  const int id = lane < k ? a.nbr[r * k + lane] : -1;
+  const bool ok = id != -1;
+  const unsigned long long m = __ballot(ok);
+  if (!m) return;
+  const long long pos = a.row_off[r] + __popcll(m & ((1ull << lane) - 1ull));
+  const long long seed_local = local_id(a.uniq, a.U, a.seed[r]);
+  if (ok) {
+    a.ei[pos] = seed_local;
+    a.ei[a.cap + pos] = local_id(a.uniq, a.U, id);
+    a.et[pos] = a.nbr_t[r * k + lane];
+  }
+  // feature rows of the valid slots, in slot order
+  unsigned long long rest = m;
+  long long out = a.row_off[r];
+  while (rest) {
+    const int s = __ffsll((long long)rest) - 1;
+    rest &= rest - 1;
+    const float* __restrict__ x = a.nbr_x + (r * k + s) * (long long)a.D;
+    for (int c = lane; c < a.D; c += kWave) a.ex[out * a.D + c] = x[c];
+    ++out;
+  }
+}
+
 }  // namespace tgmx
 
 using namespace tgmx;
@@ -328,7 +513,7 @@ extern "C" int tgmx_tgn_aggregate(const int32_t* nodes, int64_t R, const float* 
                                   int32_t num_nodes, const int64_t* st_lo_s, const int32_t* st_cnt_s, const int64_t* st_lo_d,
                                   const int32_t* st_cnt_d, const int32_t* log_other, const int64_t* log_t, const float* log_raw,
                                   int32_t D, const float* tw, const float* tb, int32_t T, int32_t mean, float* aggr, int64_t* new_lu,
-                                  tgmx_stream_t stream) {
+                                  int64_t* assoc, int64_t stamp, tgmx_stream_t stream) {
   TGMX_REQUIRE(R >= 0 && M > 0 && D >= 0 && T > 0 && num_nodes > 0, "tgn_aggregate: bad sizes");
   if (R == 0) return TGMX_OK;
   TGMX_REQUIRE(nodes && memory && last_update && st_lo_s && st_cnt_s && st_lo_d && st_cnt_d && tw && tb && aggr && new_lu,
@@ -338,6 +523,7 @@ extern "C" int tgmx_tgn_aggregate(const int32_t* nodes, int64_t R, const float* 
   a.st_lo[0] = st_lo_s; a.st_lo[1] = st_lo_d; a.st_cnt[0] = st_cnt_s; a.st_cnt[1] = st_cnt_d;
   a.log_other = log_other; a.log_t = log_t; a.log_raw = log_raw; a.tw = tw; a.tb = tb; a.aggr = aggr; a.new_lu = new_lu;
   a.R = R; a.M = M; a.D = D; a.T = T; a.N = num_nodes; a.mean = mean;
+  a.assoc = assoc; a.stamp = stamp;
   hipLaunchKernelGGL(tgn_aggregate_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
   TGMX_CHECK_LAUNCH("tgn_aggregate");
   return TGMX_OK;
@@ -402,5 +588,51 @@ extern "C" int tgmx_group_ids(const int32_t* ids, int32_t n, int32_t* sorted, in
   while (P < n) P <<= 1;
   hipLaunchKernelGGL(group_ids_kernel, dim3(1), dim3(P), 0, (hipStream_t)stream, ids, n, sorted, perm, run_lo, run_hi, first);
   TGMX_CHECK_LAUNCH("group_ids");
+  return TGMX_OK;
+}
+
+extern "C" int tgmx_tgn_commit_assoc(const int32_t* src, const int32_t* dst, int64_t n, const int64_t* assoc, int64_t stamp, const float* val,
+                                     const int64_t* lu, int32_t M, int32_t num_nodes, float* memory, int64_t* last_update, int32_t* status,
+                                     tgmx_stream_t stream) {
+  TGMX_REQUIRE(n >= 0 && M > 0 && num_nodes > 0, "tgn_commit_assoc: bad sizes");
+  if (n == 0) return TGMX_OK;
+  TGMX_REQUIRE(src && dst && assoc && val && lu && memory && last_update && status, "tgn_commit_assoc: null pointer");
+  hipLaunchKernelGGL(tgn_commit_assoc_kernel, dim3((unsigned)((2 * n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, src, dst, (long long)n, assoc,
+                     (long long)stamp, val, lu, M, num_nodes, memory, last_update, status);
+  TGMX_CHECK_LAUNCH("tgn_commit_assoc");
+  return TGMX_OK;
+}
+
+extern "C" int tgmx_tgn_store_batch(const int32_t* src, const int32_t* dst, const int64_t* t, const float* raw, int32_t D, int32_t n,
+                                    int64_t base, int32_t* log_other, int64_t* log_t, float* log_raw, int64_t* st_lo_s, int32_t* st_cnt_s,
+                                    int64_t* st_lo_d, int32_t* st_cnt_d, tgmx_stream_t stream) {
+  TGMX_REQUIRE(n >= 0 && n <= 1024 && D >= 0 && base >= 0, "tgn_store_batch: n=%d (at most 1024 events per call), D=%d", n, D);
+  if (n == 0) return TGMX_OK;
+  TGMX_REQUIRE(src && dst && t && (D == 0 || (raw && log_raw)) && log_other && log_t && st_lo_s && st_cnt_s && st_lo_d && st_cnt_d,
+               "tgn_store_batch: null pointer");
+  StoreBatchArgs a{src, dst, t, raw, log_other, log_t, log_raw, {st_lo_s, st_lo_d}, {st_cnt_s, st_cnt_d}, base, n, D};
+  int P = 64;
+  while (P < n) P <<= 1;
+  hipLaunchKernelGGL(tgn_store_batch_kernel, dim3(2), dim3(P), 0, (hipStream_t)stream, a);
+  TGMX_CHECK_LAUNCH("tgn_store_batch");
+  return TGMX_OK;
+}
+
+extern "C" int tgmx_tgn_edge_list(const int32_t* seed, const int32_t* nbr, const int64_t* nbr_t, const float* nbr_x, int64_t S, int32_t k,
+                                  int32_t D, const int32_t* uniq, int64_t U, int64_t cap, int64_t* row_off, int64_t* edge_index,
+                                  int64_t* edge_t, float* edge_x, int64_t* count, tgmx_stream_t stream) {
+  TGMX_REQUIRE(S >= 0 && k > 0 && k <= 64 && D >= 0 && U >= 0 && cap >= S * k, "tgn_edge_list: bad sizes S=%lld k=%d cap=%lld", (long long)S, k,
+               (long long)cap);
+  TGMX_REQUIRE(count && row_off, "tgn_edge_list: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  if (S == 0) {
+    (void)hipMemsetAsync(count, 0, sizeof(int64_t), st);
+    return TGMX_OK;
+  }
+  TGMX_REQUIRE(seed && nbr && nbr_t && (D == 0 || (nbr_x && edge_x)) && uniq && edge_index && edge_t, "tgn_edge_list: null pointer");
+  hipLaunchKernelGGL(edge_list_scan_kernel, dim3(1), dim3(1024), 0, st, nbr, (long long)S, k, row_off, count);
+  EdgeListArgs a{seed, nbr, nbr_t, nbr_x, uniq, row_off, edge_index, edge_t, edge_x, S, U, cap, k, D};
+  hipLaunchKernelGGL(edge_list_write_kernel, dim3((unsigned)((S + 3) / 4)), dim3(256), 0, st, a);
+  TGMX_CHECK_LAUNCH("tgn_edge_list");
   return TGMX_OK;
 }

@@ -95,7 +95,7 @@ class AggregateFn(torch.autograd.Function):
     """aggr rows of TGNMemory (tgmx_tgn_aggregate); differentiable w.r.t. the Time2Vec weight / bias."""
 
     @staticmethod
-    def forward(ctx, tw: Tensor, tb: Tensor, mem_module, nodes: Tensor):
+    def forward(ctx, tw: Tensor, tb: Tensor, mem_module, nodes: Tensor, assoc=None, stamp: int = 0):
         m = mem_module
         lib = _native.load()
         dev, R, M, D, T = nodes.device, nodes.numel(), m.memory_dim, m.raw_msg_dim, m.time_dim
@@ -108,7 +108,7 @@ class AggregateFn(torch.autograd.Function):
                 nodes.data_ptr(), R, m.memory.data_ptr(), m.last_update.data_ptr(), M, m.num_nodes, m._st_lo[0].data_ptr(),
                 m._st_cnt[0].data_ptr(), m._st_lo[1].data_ptr(), m._st_cnt[1].data_ptr(), _native.ptr(m._log_other), _native.ptr(m._log_t),
                 _native.ptr(m._log_raw), D, twc.data_ptr(), tbc.data_ptr(), T, m.aggr_module.mean, aggr.data_ptr(), new_lu.data_ptr(),
-                _native.stream_ptr(),
+                _native.ptr(assoc), stamp, _native.stream_ptr(),
             ),
             'tgmx_tgn_aggregate',
         )  # fmt: skip
@@ -129,7 +129,7 @@ class AggregateFn(torch.autograd.Function):
         lib = _native.load()
         dev = ctx.twc.device
         if R == 0:
-            return torch.zeros(ctx.tw_shape, device=dev), torch.zeros(T, device=dev), None, None
+            return torch.zeros(ctx.tw_shape, device=dev), torch.zeros(T, device=dev), None, None, None, None
         part = torch.empty((R, 2 * T), dtype=torch.float32, device=dev)
         _native.check(
             lib.tgmx_tgn_aggregate_backward(R, lo0.data_ptr(), c0.data_ptr(), lo1.data_ptr(), c1.data_ptr(), lu.data_ptr(), _native.ptr(log_t),
@@ -138,7 +138,7 @@ class AggregateFn(torch.autograd.Function):
             'tgmx_tgn_aggregate_backward',
         )  # fmt: skip
         g = _colsum(part, R, 2 * T)
-        return g[:T].reshape(ctx.tw_shape), g[T:], None, None
+        return g[:T].reshape(ctx.tw_shape), g[T:], None, None, None, None
 
 
 class EdgeAttrFn(torch.autograd.Function):

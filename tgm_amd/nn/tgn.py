@@ -74,6 +74,16 @@ class TGNMemory(nn.Module):
         self._log_raw: Optional[Tensor] = None
         self._log_len = 0
         self._log_cap_min = 1 << 16  # rows; tests shrink it to exercise the compaction
+        # reuse_forward (ours, default off = the reference's evaluation order): in train mode update_state commits the rows the
+        # preceding forward() just produced for the batch's nodes instead of recomputing them (same state, same arithmetic,
+        # same values; tgn.py:165-177 calls _get_updated_memory a second time).  Contract: the batch's src / dst nodes are
+        # among that forward's n_id (the reference loop passes batch.unique_nids) -- verified on the device, reported by check().
+        self.reuse_forward = False
+        self._version = 0          # bumped by every mutation of memory / last_update / the message stores
+        self._fwd = None           # (version, stamp, memory rows [R, M], last_update rows [R]) of the last train-mode forward
+        self._assoc64 = None       # [N] int64: (stamp << 32) | row
+        self._stamp = 0
+        self._reuse_status = None  # device int32: 1 = an update_state node was not part of the reused forward
         self.shard_commits = True  # under torch.distributed (world > 1): shard update_state's commit across ranks
         self.memory_updater.reset_parameters()
 
@@ -87,6 +97,7 @@ class TGNMemory(nn.Module):
         self.reset_state()
 
     def reset_state(self) -> None:
+        self._version += 1
         self.memory.zero_()
         self.last_update.zero_()
         self._reset_message_store()
@@ -95,6 +106,7 @@ class TGNMemory(nn.Module):
         self.memory.detach_()
 
     def _reset_message_store(self) -> None:
+        self._version += 1
         dev = self.memory.device
         for r in (0, 1):
             self._st_lo[r] = torch.zeros(self.num_nodes, dtype=torch.int64, device=dev)
@@ -145,13 +157,21 @@ class TGNMemory(nn.Module):
         self._log_len = base
 
     # -- kernels ----------------------------------------------------------------
-    def _updated(self, nodes: Tensor) -> Tuple[Tensor, Tensor]:
-        """Look-ahead memory for int32 node ids ``nodes`` [R] (tgn.py:191-216); writes nothing."""
+    def _updated(self, nodes: Tensor, record: bool = False) -> Tuple[Tensor, Tensor]:
+        """Look-ahead memory for int32 node ids ``nodes`` [R] (tgn.py:191-216); writes nothing (``record``: also node -> row
+        in the private association table, for ``reuse_forward``)."""
         lib = _native.load()
         _native.require_device(nodes, 'n_id')
         self._ensure_store(0)
+        assoc, stamp = None, 0
+        if record:
+            if self._assoc64 is None or self._assoc64.device != nodes.device:
+                self._assoc64 = torch.zeros(self.num_nodes, dtype=torch.int64, device=nodes.device)
+                self._reuse_status = torch.zeros(1, dtype=torch.int32, device=nodes.device)
+            self._stamp += 1
+            assoc, stamp = self._assoc64, self._stamp
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            return self._updated_train(nodes)
+            return self._updated_train(nodes, assoc, stamp)
         dev, R, M, D, T = nodes.device, nodes.numel(), self.memory_dim, self.raw_msg_dim, self.time_dim
         W = 2 * M + D + T
         stream = _native.stream_ptr()
@@ -163,7 +183,7 @@ class TGNMemory(nn.Module):
                 nodes.data_ptr(), R, self.memory.data_ptr(), self.last_update.data_ptr(), M, self.num_nodes,
                 self._st_lo[0].data_ptr(), self._st_cnt[0].data_ptr(), self._st_lo[1].data_ptr(), self._st_cnt[1].data_ptr(),
                 _native.ptr(self._log_other), _native.ptr(self._log_t), _native.ptr(self._log_raw), D, tw.data_ptr(), tb.data_ptr(),
-                T, self.aggr_module.mean, aggr.data_ptr(), new_lu.data_ptr(), stream,
+                T, self.aggr_module.mean, aggr.data_ptr(), new_lu.data_ptr(), _native.ptr(assoc), stamp, stream,
             ),
             'tgmx_tgn_aggregate',
         )  # fmt: skip
@@ -177,19 +197,27 @@ class TGNMemory(nn.Module):
         _native.check(lib.tgmx_tgn_gru_gate(gi.data_ptr(), gh.data_ptr(), h.data_ptr(), M, R, out.data_ptr(), stream), 'tgmx_tgn_gru_gate')
         return out, new_lu
 
-    def _updated_train(self, nodes: Tensor) -> Tuple[Tensor, Tensor]:
+    def _updated_train(self, nodes: Tensor, assoc: Optional[Tensor] = None, stamp: int = 0) -> Tuple[Tensor, Tensor]:
         """Same arithmetic with autograd through the hand-written backward kernels (nn/_tgn_train.py)."""
         from ._tgn_train import AggregateFn, GruGateFn, LinearFn
 
-        aggr, new_lu = AggregateFn.apply(self.time_enc.w.weight, self.time_enc.w.bias, self, nodes)
+        aggr, new_lu = AggregateFn.apply(self.time_enc.w.weight, self.time_enc.w.bias, self, nodes, assoc, stamp)
         h = _ops.gather_rows(self.memory.detach(), nodes)
         gru = self.memory_updater
         gi = LinearFn.apply(aggr, gru.weight_ih, gru.bias_ih)
         gh = LinearFn.apply(h, gru.weight_hh, gru.bias_hh)
         return GruGateFn.apply(gi, gh, h), new_lu
 
+    def check(self) -> None:
+        """Raise if an ``update_state`` under ``reuse_forward`` met a node that the reused forward had not evaluated (one
+        device -> host read; the offending rows were left unchanged)."""
+        if self._reuse_status is not None and int(self._reuse_status.item()):
+            self._reuse_status.zero_()
+            raise RuntimeError('TGNMemory(reuse_forward=True): update_state saw a node that was not in the preceding forward(n_id)')
+
     @torch.no_grad()
     def _commit(self, nodes: Tensor, flag: Optional[Tensor]) -> None:
+        self._version += 1
         lib = _native.load()
         CH = 1 << 16  # bounds the [rows, msg_dim] scratch when all N nodes are flushed
         # every row is computed from the OLD memory first (the reference evaluates all of n_id at once), then written
@@ -243,7 +271,26 @@ class TGNMemory(nn.Module):
             dist.all_gather_into_tensor(lu_g, lu_l)
         return mem_g[:R], lu_g[:R]
 
+    def _store_batch(self, src32: Tensor, dst32: Tensor, t: Tensor, raw: Optional[Tensor]) -> None:
+        """Both roles' message stores of one batch (tgn.py:173,176): one launch for n <= 1024 events."""
+        n = src32.numel()
+        if n > 1024:
+            self._store_role(0, src32, dst32, t, raw)
+            self._store_role(1, dst32, src32, t, raw)
+            return
+        self._version += 1
+        self._ensure_store(2 * n)
+        _native.check(
+            _native.load().tgmx_tgn_store_batch(src32.data_ptr(), dst32.data_ptr(), t.data_ptr(), _native.ptr(raw), self.raw_msg_dim, n, self._log_len,
+                                                self._log_other.data_ptr(), self._log_t.data_ptr(), self._log_raw.data_ptr(),
+                                                self._st_lo[0].data_ptr(), self._st_cnt[0].data_ptr(), self._st_lo[1].data_ptr(),
+                                                self._st_cnt[1].data_ptr(), _native.stream_ptr()),
+            'tgmx_tgn_store_batch',
+        )  # fmt: skip
+        self._log_len += 2 * n
+
     def _store_role(self, role: int, node: Tensor, other: Tensor, t: Tensor, raw: Optional[Tensor]) -> None:
+        self._version += 1
         lib = _native.load()
         n = node.numel()
         self._ensure_store(n)
@@ -271,7 +318,11 @@ class TGNMemory(nn.Module):
         eval mode: the table rows (tgn.py:157-163)."""
         _native.require_device(n_id, 'n_id')
         if self.training:
-            return self._updated(n_id.to(torch.int32).contiguous())
+            if not self.reuse_forward:
+                return self._updated(n_id.to(torch.int32).contiguous())
+            mem, lu = self._updated(n_id.to(torch.int32).contiguous(), record=True)
+            self._fwd = (self._version, self._stamp, mem.detach(), lu)
+            return mem, lu
         idx = n_id.long()
         return self.memory[idx], self.last_update[idx]
 
@@ -281,6 +332,21 @@ class TGNMemory(nn.Module):
         src32, dst32 = src.to(torch.int32).contiguous(), dst.to(torch.int32).contiguous()
         t = t.to(torch.int64).contiguous()
         raw = _ops._f32c(raw_msg, 'raw_msg') if self.raw_msg_dim else None
+        fwd = self._fwd
+        if self.training and self.reuse_forward and fwd is not None and fwd[0] == self._version and not self._sharded(2 * src32.numel()):
+            # the rows this batch's nodes need are the ones the forward just computed: commit by row copy, then store
+            _, stamp, mem_rows, lu_rows = fwd
+            self._version += 1
+            _native.check(
+                _native.load().tgmx_tgn_commit_assoc(src32.data_ptr(), dst32.data_ptr(), src32.numel(), self._assoc64.data_ptr(), stamp,
+                                                     mem_rows.data_ptr(), lu_rows.data_ptr(), self.memory_dim, self.num_nodes,
+                                                     self.memory.data_ptr(), self.last_update.data_ptr(), self._reuse_status.data_ptr(),
+                                                     _native.stream_ptr()),
+                'tgmx_tgn_commit_assoc',
+            )  # fmt: skip
+            self._fwd = None
+            self._store_batch(src32, dst32, t, raw)
+            return
         both = torch.cat([src32, dst32])
         if both.numel() <= 1024:
             srt = torch.empty_like(both)
@@ -293,12 +359,14 @@ class TGNMemory(nn.Module):
             first[1:] = (srt[1:] != srt[:-1]).to(torch.uint8)
         if self.training:
             self._commit(srt, first)
-            self._store_role(0, src32, dst32, t, raw)
-            self._store_role(1, dst32, src32, t, raw)
+            self._store_batch(src32, dst32, t, raw)
         else:
-            self._store_role(0, src32, dst32, t, raw)
-            self._store_role(1, dst32, src32, t, raw)
+            self._store_batch(src32, dst32, t, raw)
             self._commit(srt, first)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._version += 1  # memory / last_update may change under a cached forward
+        return super().load_state_dict(*args, **kwargs)
 
     def train(self, mode: bool = True) -> 'TGNMemory':
         if self.training and not mode and self.memory.device.type == 'cuda':
@@ -307,6 +375,39 @@ class TGNMemory(nn.Module):
             self._reset_message_store()
         super().train(mode)
         return self
+
+
+def sampled_edge_list(batch, hop: int = 0) -> Tuple[Tensor, Tensor, Tensor]:
+    """``(edge_index [2, E] int64, edge_time [E] int64, edge_x [E, D] float32)`` of one sampled hop, exactly what the
+    reference's TGN loop assembles from a dozen torch ops (examples/linkproppred/tgn.py:80-92):
+
+        mask = nbr != -1;  edge_index = stack([global_to_local(seeds.repeat_interleave(k)[mask]), global_to_local(nbr[mask])])
+        edge_time = nbr_edge_time[hop].flatten()[mask];  edge_x = nbr_edge_x[hop].flatten(0, -2)[mask]
+
+    in two launches (``tgmx_tgn_edge_list``) and one device -> host read (E).  Needs ``batch.unique_nids`` (the
+    ``DeduplicationHook``) and the sampler's outputs; bit-identical to the torch formulation (tests/test_tgn_gpu.py)."""
+    lib = _native.load()
+    seeds, nbr = batch.seed_nids[hop], batch.nbr_nids[hop]
+    nbr_t, nbr_x, uniq = batch.nbr_edge_time[hop], batch.nbr_edge_x[hop], batch.unique_nids
+    _native.require_device(nbr, 'nbr_nids')
+    dev = nbr.device
+    S, k = nbr.shape
+    D = nbr_x.shape[-1]
+    c = lambda t, dt: t if (t.dtype == dt and t.is_contiguous()) else t.to(dt).contiguous()
+    seeds, nbr, nbr_t, nbr_x, uniq = c(seeds, torch.int32), c(nbr, torch.int32), c(nbr_t, torch.int64), c(nbr_x, torch.float32), c(uniq, torch.int32)
+    cap = S * k
+    ei = torch.empty((2, max(cap, 1)), dtype=torch.int64, device=dev)
+    et = torch.empty(max(cap, 1), dtype=torch.int64, device=dev)
+    ex = torch.empty((max(cap, 1), D), dtype=torch.float32, device=dev)
+    ws = torch.empty(S + 2, dtype=torch.int64, device=dev)  # row offsets [S + 1] | count
+    _native.check(
+        lib.tgmx_tgn_edge_list(seeds.data_ptr(), nbr.data_ptr(), nbr_t.data_ptr(), nbr_x.data_ptr(), S, k, D, uniq.data_ptr(), uniq.numel(),
+                               max(cap, 1), ws.data_ptr(), ei.data_ptr(), et.data_ptr(), ex.data_ptr(), ws[S + 1 :].data_ptr(),
+                               _native.stream_ptr()),
+        'tgmx_tgn_edge_list',
+    )  # fmt: skip
+    E = int(ws[S + 1].item())
+    return ei[:, :E], et[:E], ex[:E]
 
 
 class TransformerConv(nn.Module):

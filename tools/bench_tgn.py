@@ -13,11 +13,15 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tgm_amd import DGData, DGDataLoader, DGraph  # noqa: E402
 from tgm_amd.hooks import DeduplicationHook, HookManager, RandomNegativeEdgeSamplerHook, RecencyNeighborHook  # noqa: E402
-from tgm_amd.nn import GraphAttentionEmbedding, IdentityMessage, LastAggregator, TGNMemory  # noqa: E402
+from tgm_amd.nn import GraphAttentionEmbedding, IdentityMessage, LastAggregator, TGNMemory, sampled_edge_list  # noqa: E402
 from tgm_amd.synth import make_stream  # noqa: E402
 
 dev = torch.device('cuda', 0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+# 'fast' (default): pooled loader, TGNMemory.reuse_forward, sampled_edge_list (one native call for the loop's edge-list glue);
+# 'reference': fresh tensors, the reference loop's torch glue verbatim, update_state recomputing its rows -- same results
+variant = sys.argv[2] if len(sys.argv) > 2 else 'fast'
+fast = variant == 'fast'
 st = make_stream('review', seed=1337, device=dev)
 N, D, M, T_, bs, ks = st.num_nodes, st.edge_dim, 100, 100, 512, [10, 10]
 dg = DGraph(DGData.from_raw(st.ts, torch.stack([st.src, st.dst], 1), st.edge_x), device=dev)
@@ -28,14 +32,21 @@ hook = RecencyNeighborHook(N, ks, ['edge_src', 'edge_dst', 'neg'], ['edge_time',
 hm.register('k', hook)
 hm.register('k', DeduplicationHook(seed_nodes_keys=['neg', 'nbr_nids']))
 mem = TGNMemory(N, D, M, T_, IdentityMessage(D, M, T_), LastAggregator()).to(dev).train()
+mem.reuse_forward = fast
 enc = GraphAttentionEmbedding(M, 100, D, mem.time_enc).to(dev).eval()
-loader = DGDataLoader(dg, batch_size=bs, hook_manager=hm)
+loader = DGDataLoader(dg, batch_size=bs, hook_manager=hm, output_pool=1 if fast else 0)
 starts = loader._starts
 k = ks[0]
 
 
 def step(i):
     batch = loader(starts[i])
+    if fast:
+        edge_index, e_t, e_x = sampled_edge_list(batch)
+        z, lu = mem(batch.unique_nids)
+        z2 = enc(z, lu, edge_index, e_t, e_x)
+        mem.update_state(batch.edge_src, batch.edge_dst, batch.edge_time, batch.edge_x)
+        return z2, batch
     nbr = batch.nbr_nids[0].flatten()
     sel = (nbr != -1).nonzero().squeeze(1)  # one mask -> one index list (one sync) shared by the four gathers below
     seeds = torch.cat([batch.edge_src, batch.edge_dst, batch.neg]).repeat_interleave(k)
@@ -59,6 +70,7 @@ with hm.activate('k'), torch.no_grad():
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     hook.check()
+    mem.check()
     # sampler only, same stream
     t3 = time.perf_counter()
     for i in range(100 + n, 100 + 2 * n):
@@ -67,6 +79,7 @@ with hm.activate('k'), torch.no_grad():
     t4 = time.perf_counter()
 slots = 3 * bs * k + 3 * bs * k * ks[1]
 print(json.dumps({
+    'variant': variant,
     'what': 'BASELINE cfg3: review-shaped synthetic (N=350k, E=4.8M, D=16), TGN memory (Last, GRU, 100) + TransformerConv embedding, k=[10,10], bs=512, 1 GPU',
     'pipeline_us_per_batch': 1e6 * (t2 - t0) / n, 'host_us_per_batch': 1e6 * (t1 - t0) / n,
     'events_per_s': bs * n / (t2 - t0), 'sampled_edges_per_s': slots * n / (t2 - t0),
