@@ -497,8 +497,9 @@ int tgmx_tgn_store_batch(const int32_t* src, const int32_t* dst, const int64_t* 
  * local(v) = position of v in the sorted unique ids `uniq` (DeduplicationHook's global_to_local, tgm/hooks/dedup.py:60-66).
  * edge_index is [2, cap] (row 1 starts at cap), cap >= S * k; *count = number of edges (device); row_off: scratch [S + 1]. */
 int tgmx_tgn_edge_list(const int32_t* seed, const int32_t* nbr, const int64_t* nbr_t, const float* nbr_x, int64_t S, int32_t k,
-                       int32_t D, const int32_t* uniq, int64_t U, int64_t cap, int64_t* row_off, int64_t* edge_index,
-                       int64_t* edge_t, float* edge_x, int64_t* count, tgmx_stream_t stream);
+                       int32_t D, const int32_t* uniq, int64_t U, const int64_t* uniq_count /* device-side U, NULL = use U */,
+                       int64_t cap, int64_t* row_off, int64_t* edge_index, int64_t* edge_t, float* edge_x, int64_t* count,
+                       tgmx_stream_t stream);
 
 /* torch.nn.GRUCell gates from gi = x W_ih^T + b_ih and gh = h W_hh^T + b_hh ([R, 3M], r|z|n). */
 int tgmx_tgn_gru_gate(const float* gi, const float* gh, const float* h, int32_t M, int64_t R,
@@ -573,7 +574,8 @@ int tgmx_random_negatives(int32_t low, int32_t high, int64_t n, uint64_t seed, u
  * seed attributes, every hop's neighbor ids); -1 (padded slot) is skipped inside the kernel, ids outside [0, num_nodes)
  * raise TGMX_ST_SEED_RANGE.  out_ids needs room for min(total ids, num_nodes); *out_count (device) receives the number
  * written.  `parts` / `part_sizes` are HOST arrays of device pointers / lengths.  workspace: 256-byte aligned,
- * tgmx_unique_ids_workspace_bytes(num_nodes). */
+ * tgmx_unique_ids_workspace_bytes(num_nodes) bytes, ALL ZERO when first handed to the library (the node bitmap: every call
+ * leaves it zero again, so there is no memset per call). */
 size_t tgmx_unique_ids_workspace_bytes(int32_t num_nodes);
 int tgmx_unique_ids(const int32_t* const* parts, const int64_t* part_sizes, int32_t num_parts, int32_t num_nodes,
                     void* workspace, int32_t* out_ids, int64_t* out_count, int32_t* status, tgmx_stream_t stream);

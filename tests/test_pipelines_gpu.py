@@ -193,7 +193,7 @@ def test_unique_ids_matches_torch_unique(N, n_ids):
     dev_parts = [p.to(DEV) for p in parts]
     allv = torch.cat(parts)
     exp = torch.unique(allv[allv >= 0])
-    ws = torch.empty(int(lib.tgmx_unique_ids_workspace_bytes(N)), dtype=torch.uint8, device=DEV)
+    ws = torch.zeros(int(lib.tgmx_unique_ids_workspace_bytes(N)), dtype=torch.uint8, device=DEV)  # zero at first use; every call leaves it zero
     out = torch.empty(min(allv.numel(), N), dtype=torch.int32, device=DEV)
     cs = torch.zeros(2, dtype=torch.int64, device=DEV)
     ptrs = (ctypes.c_void_p * 4)(*[p.data_ptr() for p in dev_parts])
@@ -204,3 +204,4 @@ def test_unique_ids_matches_torch_unique(N, n_ids):
     cnt, st = cs.tolist()
     assert st == 0 and cnt == exp.numel()
     assert torch.equal(out[:cnt].cpu(), exp)
+    assert not bool(ws.any()), 'the bitmap must be clean again after the call'

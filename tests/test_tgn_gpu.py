@@ -191,3 +191,30 @@ def test_reuse_forward_commits_the_same_state(aggr):
                      torch.tensor([10**9, 10**9 + 1], device=DEV), torch.rand(2, 16, device=DEV))
     with pytest.raises(RuntimeError, match='not in the preceding forward'):
         mem.check()
+
+
+def test_prefetching_loader_and_edge_list_hook_yield_the_same_batches():
+    """DGDataLoader(prefetch=1): batch i is handed out after batch i + 1 was enqueued; DeduplicationHook and
+    SampledEdgeListHook learn their output sizes through deferred finalizers.  Every tensor equals the plain loader's
+    (fresh tensors, no prefetch) and the reference loop's torch glue."""
+    from tgm_amd import DGDataLoader
+    from tgm_amd.hooks import SampledEdgeListHook
+
+    st, hm_a, plain = _tgn_stream_pipeline(pool=0)
+    _, hm_b, _ = _tgn_stream_pipeline(pool=0)
+    hm_b.register('k', SampledEdgeListHook(hop=0))
+    ahead = DGDataLoader(plain.dgraph, batch_size=512, hook_manager=hm_b, output_pool=2, prefetch=1)
+    with pytest.raises(ValueError, match='output_pool'):
+        DGDataLoader(plain.dgraph, batch_size=512, hook_manager=hm_b, output_pool=1, prefetch=1)
+    n = 0
+    with hm_a.activate('k'), hm_b.activate('k'):
+        for ba, bb in zip(plain, ahead):
+            assert ba._edge_lo == bb._edge_lo
+            for name in ('edge_src', 'neg', 'unique_nids'):
+                assert torch.equal(getattr(ba, name), getattr(bb, name)), (n, name)
+            assert torch.equal(ba.nbr_nids[0], bb.nbr_nids[0]) and torch.equal(ba.nbr_edge_x[0], bb.nbr_edge_x[0])
+            ei, et, ex = _reference_glue(ba, 10)
+            assert torch.equal(bb.sampled_edge_index, ei) and torch.equal(bb.sampled_edge_time, et) and torch.equal(bb.sampled_edge_x, ex)
+            assert torch.equal(bb.global_to_local(bb.edge_src), ba.global_to_local(ba.edge_src))
+            n += 1
+    assert n == 12

@@ -59,7 +59,7 @@ SIGNATURES = {
     ),
     'tgmx_tgn_commit_assoc': (c_int32, [_P, _P, c_int64, _P, c_int64, _P, _P, c_int32, c_int32, _P, _P, _P, _P]),
     'tgmx_tgn_store_batch': (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int64, _P, _P, _P, _P, _P, _P, _P, _P]),
-    'tgmx_tgn_edge_list': (c_int32, [_P, _P, _P, _P, c_int64, c_int32, c_int32, _P, c_int64, c_int64, _P, _P, _P, _P, _P, _P]),
+    'tgmx_tgn_edge_list': (c_int32, [_P, _P, _P, _P, c_int64, c_int32, c_int32, _P, c_int64, _P, c_int64, _P, _P, _P, _P, _P, _P]),
     'tgmx_tgn_gru_gate': (c_int32, [_P, _P, _P, c_int32, c_int64, _P, _P]),
     'tgmx_tgn_commit': (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int64, _P, _P, _P]),
     'tgmx_tconv_edge_attr': (c_int32, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int64, _P, _P]),

@@ -35,6 +35,23 @@ class DGBatch:
     _edge_lo: Optional[int] = field(default=None, repr=False, compare=False)
     _event_lo: Optional[int] = field(default=None, repr=False, compare=False)
 
+    # Hooks whose output SIZE is only known on the device (unique ids, compacted edge lists) enqueue their kernels, start an
+    # asynchronous copy of the size and register a finalizer here instead of waiting for it; the loader runs the
+    # finalizers right away (default) or one batch later (DGDataLoader(prefetch=1)), when the size arrived long ago.
+    def _defer(self, fn) -> None:
+        if self.__dict__.get('_deferred', False):
+            self.__dict__.setdefault('_pending', []).append(fn)
+        else:
+            fn()
+
+    def _finalize(self) -> 'DGBatch':
+        pending = self.__dict__.pop('_pending', None)
+        self.__dict__['_deferred'] = False
+        if pending:
+            for fn in pending:
+                fn()
+        return self
+
     def __str__(self) -> str:
         def describe(v: Any) -> str:
             if isinstance(v, Tensor):

@@ -40,9 +40,11 @@ __global__ __launch_bounds__(256) void dedup_mark_kernel(const MarkArgs a) {
   }
 }
 
-// exclusive prefix sum of popcount(bitmap[w]) over all words, one workgroup (num_nodes / 32 words: tens of thousands)
-__global__ __launch_bounds__(1024) void dedup_scan_kernel(const unsigned int* __restrict__ bitmap, long long words,
-                                                          int32_t* __restrict__ prefix, int64_t* __restrict__ count) {
+// One workgroup walks the bitmap (num_nodes / 32 words: ~11 k at review scale) 1024 words at a time: exclusive prefix sum
+// of the popcounts, every set bit written to its slot of the ascending output -- and the word cleared again, so the bitmap
+// is all-zero when the call ends (no memset per call; it only has to be zero when the workspace is first used).
+__global__ __launch_bounds__(1024) void dedup_scan_compact_kernel(unsigned int* __restrict__ bitmap, long long words, int32_t* __restrict__ out,
+                                                                  int64_t* __restrict__ count) {
   __shared__ int wave_tot[16];
   __shared__ int carry_s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -50,7 +52,8 @@ __global__ __launch_bounds__(1024) void dedup_scan_kernel(const unsigned int* __
   __syncthreads();
   for (long long w0 = 0; w0 < words; w0 += 1024) {
     const long long w = w0 + tid;
-    const int v = w < words ? __popc(bitmap[w]) : 0;
+    unsigned int bits = w < words ? bitmap[w] : 0u;
+    const int v = __popc(bits);
     int incl = v;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -61,25 +64,20 @@ __global__ __launch_bounds__(1024) void dedup_scan_kernel(const unsigned int* __
     __syncthreads();
     int before = carry_s;
     for (int q = 0; q < wave; ++q) before += wave_tot[q];
-    if (w < words) prefix[w] = before + incl - v;
+    if (bits) {
+      bitmap[w] = 0u;
+      int pos = before + incl - v;
+      while (bits) {
+        const int b = __ffs(bits) - 1;
+        out[pos++] = (int)(w * 32 + b);
+        bits &= bits - 1;
+      }
+    }
     __syncthreads();
     if (tid == 1023) carry_s = before + incl;
     __syncthreads();
   }
   if (tid == 0) *count = carry_s;
-}
-
-__global__ __launch_bounds__(256) void dedup_compact_kernel(const unsigned int* __restrict__ bitmap, const int32_t* __restrict__ prefix,
-                                                            long long words, int32_t* __restrict__ out) {
-  const long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (w >= words) return;
-  unsigned int bits = bitmap[w];
-  int pos = prefix[w];
-  while (bits) {
-    const int b = __ffs(bits) - 1;
-    out[pos++] = (int)(w * 32 + b);
-    bits &= bits - 1;
-  }
 }
 
 // RandomNegativeEdgeSamplerHook (tgm/hooks/negatives/sampler.py:45-65): neg[i] uniform in [low, high), neg_time = copy of
@@ -111,7 +109,6 @@ extern "C" int tgmx_unique_ids(const int32_t* const* parts, const int64_t* part_
   hipStream_t st = (hipStream_t)stream;
   const long long words = ((long long)num_nodes + 31) / 32;
   unsigned int* bitmap = reinterpret_cast<unsigned int*>(workspace);
-  int32_t* prefix = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(workspace) + ((words * 4 + 255) & ~255ll));
   MarkArgs m{};
   long long total = 0;
   for (int p = 0; p < num_parts; ++p) {
@@ -121,14 +118,12 @@ extern "C" int tgmx_unique_ids(const int32_t* const* parts, const int64_t* part_
     m.end[p] = total;
   }
   m.bitmap = bitmap; m.status = status; m.parts = num_parts; m.N = num_nodes;
-  (void)hipMemsetAsync(bitmap, 0, (size_t)words * 4, st);
   if (total > 0) {
     long long blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(dedup_mark_kernel, dim3((unsigned)blocks), dim3(256), 0, st, m);
   }
-  hipLaunchKernelGGL(dedup_scan_kernel, dim3(1), dim3(1024), 0, st, bitmap, words, prefix, out_count);
-  hipLaunchKernelGGL(dedup_compact_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, bitmap, prefix, words, out_ids);
+  hipLaunchKernelGGL(dedup_scan_compact_kernel, dim3(1), dim3(1024), 0, st, bitmap, words, out_ids, out_count);
   TGMX_CHECK_LAUNCH("unique_ids");
   return TGMX_OK;
 }

@@ -220,14 +220,17 @@ struct TconvArgs {
   DropoutArgs drop;  // training: dropout on the attention coefficients after the softmax (PyG TransformerConv), element e * H + h
 };
 
-// one wave per target node; online softmax over its incoming edges, head by head.  The segment's edge ids and
-// sources are fetched 64 at a time with the lanes in parallel and handed out by shuffles, and the (k, v, e) rows of the
-// NEXT edge are requested before the current edge's reduction -- the loop used to pay three dependent global loads per
-// edge (order -> src -> rows).
+// online softmax over a target's incoming edges, head by head
 __global__ __launch_bounds__(256) void tconv_attend_kernel(const TconvArgs a) {
-  const long long i = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  // ONE WORKGROUP (4 waves) per target: wave w takes the target's incoming edges lo + w, lo + w + 4, ... and keeps an online
+  // softmax partial (running max m, normaliser l, weighted sum acc per output column); the four partials meet in LDS and
+  // are merged in wave order (deterministic).  With a wave per target the launch lasted as long as the busiest hub's
+  // edge list walked serially (116 us at the review shape: items with hundreds of incoming edges).
+  constexpr int kWavesPerTarget = 4;
+  __shared__ float s_m[kWavesPerTarget], s_l[kWavesPerTarget], s_acc[kWavesPerTarget][kWave];
+  const long long i = blockIdx.x;
   if (i >= a.U) return;
-  const int lane = lane_id();
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
   const long long lo = a.seg_lo[i], hi = a.seg_hi[i];
   if (hi <= lo) return;  // no incoming edge: only the skip term
   const int HC = a.H * a.C;
@@ -236,32 +239,54 @@ __global__ __launch_bounds__(256) void tconv_attend_kernel(const TconvArgs a) {
       // (C <= 64 in practice: one pass; for larger C the scores are recomputed per column chunk)
       const int c = c0 + lane;
       float m = -__builtin_inff(), l = 0.f, acc = 0.f;
-      for (long long p0 = lo; p0 < hi; p0 += kWave) {
-        const int n_here = (hi - p0) < kWave ? (int)(hi - p0) : kWave;
+      // this wave's edges 64 at a time: lane t fetches (edge id, source) of position p0 + 4 t, handed out by shuffles
+      for (long long p0 = lo + wave; p0 < hi; p0 += (long long)kWavesPerTarget * kWave) {
+        const long long my_p = p0 + (long long)kWavesPerTarget * lane;
         long long my_e = 0, my_j = 0;
-        if (lane < n_here) {
-          my_e = a.order[p0 + lane];
+        if (my_p < hi) {
+          my_e = a.order[my_p];
           my_j = a.src[my_e];
         }
+        const long long left = (hi - p0 + kWavesPerTarget - 1) / kWavesPerTarget;
+        const int n_here = left < kWave ? (int)left : kWave;
         for (int t = 0; t < n_here; ++t) {
-          const long long e = __shfl(my_e, t), j = __shfl(my_j, t);
-          float part = 0.f;
-          for (int cc = lane; cc < a.C; cc += kWave) {
-            const int col = h * a.C + cc;
-            part = __fmaf_rn(a.q[i * HC + col], a.k[j * HC + col] + a.eproj[e * HC + col], part);
-          }
-          const float val = c < a.C ? a.v[j * HC + h * a.C + c] + a.eproj[e * HC + h * a.C + c] : 0.f;
-          for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
-          const float s = part * a.scale;
-          const float mn = s > m ? s : m;
-          const float corr = expf(m - mn), w = expf(s - mn);
-          // the softmax normalises over every incoming edge; dropout then zeroes / rescales single coefficients
-          acc = acc * corr + w * dropout_scale(a.drop, (unsigned long long)e * a.H + h) * val;
-          l = l * corr + w;
-          m = mn;
+        const long long e = __shfl(my_e, t), j = __shfl(my_j, t);
+        float part = 0.f;
+        for (int cc = lane; cc < a.C; cc += kWave) {
+          const int col = h * a.C + cc;
+          part = __fmaf_rn(a.q[i * HC + col], a.k[j * HC + col] + a.eproj[e * HC + col], part);
+        }
+        const float val = c < a.C ? a.v[j * HC + h * a.C + c] + a.eproj[e * HC + h * a.C + c] : 0.f;
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+        const float s = part * a.scale;
+        const float mn = s > m ? s : m;
+        const float corr = expf(m - mn), w = expf(s - mn);
+        // the softmax normalises over every incoming edge; dropout then zeroes / rescales single coefficients
+        acc = acc * corr + w * dropout_scale(a.drop, (unsigned long long)e * a.H + h) * val;
+        l = l * corr + w;
+        m = mn;
         }
       }
-      if (c < a.C) a.out[i * HC + h * a.C + c] += acc / l;
+      __syncthreads();  // the previous (head, column chunk)'s partials have been consumed
+      if (lane == 0) {
+        s_m[wave] = m;
+        s_l[wave] = l;
+      }
+      s_acc[wave][lane] = acc;
+      __syncthreads();
+      if (wave == 0) {
+        float M = s_m[0];
+#pragma unroll
+        for (int w2 = 1; w2 < kWavesPerTarget; ++w2) M = fmaxf(M, s_m[w2]);
+        float L = 0.f, A = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < kWavesPerTarget; ++w2) {
+          const float f = s_l[w2] > 0.f ? expf(s_m[w2] - M) : 0.f;  // a wave without edges has m = -inf, l = 0
+          L += s_l[w2] * f;
+          A += s_acc[w2][lane] * f;
+        }
+        if (c < a.C) a.out[i * HC + h * a.C + c] += A / L;
+      }
     }
   }
 }
@@ -395,10 +420,10 @@ __global__ __launch_bounds__(1024) void tgn_store_batch_kernel(const StoreBatchA
     a.log_other[base + tid] = oth[pay];
     a.log_t[base + tid] = a.t[pay];
   }
-  // raw rows: a wave per sorted position, round-robin
-  for (int p = wave; p < n; p += (P >> 6)) {
-    const int e = s_perm[p];
-    for (int c = lane; c < a.D; c += kWave) a.log_raw[(base + p) * a.D + c] = a.raw[(long long)e * a.D + c];
+  // raw rows in sorted order: one element per thread and step (all independent)
+  for (int x = tid; x < n * a.D; x += P) {
+    const int p = x / a.D, c = x - p * a.D;
+    a.log_raw[(base + p) * a.D + c] = a.raw[(long long)s_perm[p] * a.D + c];
   }
 }
 
@@ -445,6 +470,7 @@ struct EdgeListArgs {
   const int64_t* nbr_t;  // [S, k]
   const float* nbr_x;    // [S, k, D]
   const int32_t* uniq;   // [U] sorted unique ids
+  const int64_t* uniq_count;  // device-side U (overrides the host value when set)
   const int64_t* row_off;
   int64_t* ei;           // [2, cap]
   int64_t* et;           // [cap]
@@ -473,10 +499,11 @@ __global__ __launch_bounds__(256) void edge_list_write_kernel(const EdgeListArgs
   const unsigned long long m = __ballot(ok);
   if (!m) return;
   const long long pos = a.row_off[r] + __popcll(m & ((1ull << lane) - 1ull));
-  const long long seed_local = local_id(a.uniq, a.U, a.seed[r]);
+  const long long U = a.uniq_count ? *a.uniq_count : a.U;
+  const long long seed_local = local_id(a.uniq, U, a.seed[r]);
   if (ok) {
     a.ei[pos] = seed_local;
-    a.ei[a.cap + pos] = local_id(a.uniq, a.U, id);
+    a.ei[a.cap + pos] = local_id(a.uniq, U, id);
     a.et[pos] = a.nbr_t[r * k + lane];
   }
   // feature rows of the valid slots, in slot order
@@ -574,7 +601,7 @@ extern "C" int tgmx_tconv_attend(const float* q, const float* k, const float* v,
   TGMX_REQUIRE(q && k && v && eproj && order && src && seg_lo && seg_hi && out, "tconv_attend: null pointer");
   TconvArgs a{q, k, v, eproj, order, src, seg_lo, seg_hi, out, U, H, C, scale};
   a.drop = make_dropout(drop);
-  hipLaunchKernelGGL(tconv_attend_kernel, dim3((unsigned)((U + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(tconv_attend_kernel, dim3((unsigned)U), dim3(256), 0, (hipStream_t)stream, a);
   TGMX_CHECK_LAUNCH("tconv_attend");
   return TGMX_OK;
 }
@@ -619,8 +646,8 @@ extern "C" int tgmx_tgn_store_batch(const int32_t* src, const int32_t* dst, cons
 }
 
 extern "C" int tgmx_tgn_edge_list(const int32_t* seed, const int32_t* nbr, const int64_t* nbr_t, const float* nbr_x, int64_t S, int32_t k,
-                                  int32_t D, const int32_t* uniq, int64_t U, int64_t cap, int64_t* row_off, int64_t* edge_index,
-                                  int64_t* edge_t, float* edge_x, int64_t* count, tgmx_stream_t stream) {
+                                  int32_t D, const int32_t* uniq, int64_t U, const int64_t* uniq_count, int64_t cap, int64_t* row_off,
+                                  int64_t* edge_index, int64_t* edge_t, float* edge_x, int64_t* count, tgmx_stream_t stream) {
   TGMX_REQUIRE(S >= 0 && k > 0 && k <= 64 && D >= 0 && U >= 0 && cap >= S * k, "tgn_edge_list: bad sizes S=%lld k=%d cap=%lld", (long long)S, k,
                (long long)cap);
   TGMX_REQUIRE(count && row_off, "tgn_edge_list: null pointer");
@@ -631,7 +658,7 @@ extern "C" int tgmx_tgn_edge_list(const int32_t* seed, const int32_t* nbr, const
   }
   TGMX_REQUIRE(seed && nbr && nbr_t && (D == 0 || (nbr_x && edge_x)) && uniq && edge_index && edge_t, "tgn_edge_list: null pointer");
   hipLaunchKernelGGL(edge_list_scan_kernel, dim3(1), dim3(1024), 0, st, nbr, (long long)S, k, row_off, count);
-  EdgeListArgs a{seed, nbr, nbr_t, nbr_x, uniq, row_off, edge_index, edge_t, edge_x, S, U, cap, k, D};
+  EdgeListArgs a{seed, nbr, nbr_t, nbr_x, uniq, uniq_count, row_off, edge_index, edge_t, edge_x, S, U, cap, k, D};
   hipLaunchKernelGGL(edge_list_write_kernel, dim3((unsigned)((S + 3) / 4)), dim3(256), 0, st, a);
   TGMX_CHECK_LAUNCH("tgn_edge_list");
   return TGMX_OK;

@@ -30,6 +30,7 @@ class DGDataLoader:
         on_empty: Literal['skip', 'raise', None] = 'skip',
         hook_manager: Optional[Any] = None,
         output_pool: int = 0,
+        prefetch: int = 0,
         **kwargs: Any,
     ) -> None:
         if batch_size <= 0:
@@ -55,6 +56,12 @@ class DGDataLoader:
         self._hook_manager = hook_manager
         self._on_empty = on_empty
         self._output_pool = int(output_pool)
+        # prefetch=p (ours): iteration runs p batches ahead -- batch i is handed out after batch i + p has been ENQUEUED, so
+        # hooks that must learn an output size from the device (DeduplicationHook, SampledEdgeListHook) find it waiting instead
+        # of stalling the stream.  Hook state (sampler rings) does not depend on what the consumer does with a batch.
+        self._prefetch = int(prefetch)
+        if self._prefetch and 0 < self._output_pool <= self._prefetch:
+            raise ValueError(f'prefetch={prefetch} keeps {prefetch + 1} batches alive: output_pool must be 0 (fresh tensors) or > prefetch')
         self._compiled = None  # (hook list identity, CompiledPipeline or None)
         self._event_fast = False
 
@@ -82,20 +89,22 @@ class DGDataLoader:
     def __len__(self) -> int:
         return len(self._starts)
 
-    def __call__(self, slice_start) -> DGBatch:
+    def __call__(self, slice_start, _deferred: bool = False) -> DGBatch:
         """Materialize the batch beginning at ``slice_start`` and run the active hooks."""
         s = slice_start[0] if isinstance(slice_start, (list, tuple)) else slice_start
         if self._output_pool > 0 and self._hook_manager is not None:
-            batch = self._call_compiled(s)
+            batch = self._call_compiled(s, _deferred)
             if batch is not None:
-                return batch
+                return batch if _deferred else batch._finalize()
         view = self._slice_op(s, s + self._batch_size)
         batch = view.materialize()
         if self._hook_manager is not None:
-            batch = self._hook_manager.execute_active_hooks(view, batch)
-        return batch
+            batch.__dict__['_deferred'] = _deferred
+            for h in self._hook_manager.active_hooks():
+                batch = h(view, batch)
+        return batch if _deferred else batch._finalize()
 
-    def _call_compiled(self, s: int) -> Optional[DGBatch]:
+    def _call_compiled(self, s: int, deferred: bool = False) -> Optional[DGBatch]:
         """The batch through the lowered hook chain (None: nothing lowerable / this batch is left to the hooks)."""
         hm = self._hook_manager
         hooks = hm.active_hooks()
@@ -130,6 +139,7 @@ class DGDataLoader:
             batch = view.materialize()
         if not pipe.step(lo, n, batch):
             return None
+        batch.__dict__['_deferred'] = deferred
         rest = hooks[pipe.n_lowered :] if pipe.n_lowered < len(hooks) else None
         if rest:
             if view is None:
@@ -146,6 +156,9 @@ class DGDataLoader:
         return n == 0
 
     def __iter__(self) -> Iterator[DGBatch]:
+        if self._prefetch > 0:
+            yield from self._iter_prefetch()
+            return
         for s in self._starts:
             batch = self(s)
             if self._on_empty is not None and self._is_batch_empty(batch):
@@ -153,3 +166,20 @@ class DGDataLoader:
                     raise EmptyBatchError('Empty batch encountered')
                 continue
             yield batch
+
+    def _iter_prefetch(self) -> Iterator[DGBatch]:
+        from collections import deque
+
+        ahead: deque = deque()
+        for s in self._starts:
+            batch = self(s, _deferred=True)
+            if self._on_empty is not None and self._is_batch_empty(batch):
+                if self._on_empty == 'raise':
+                    raise EmptyBatchError('Empty batch encountered')
+                batch._finalize()
+                continue
+            ahead.append(batch)
+            if len(ahead) > self._prefetch:
+                yield ahead.popleft()._finalize()
+        while ahead:
+            yield ahead.popleft()._finalize()

@@ -1,5 +1,6 @@
 from .base import BaseDGHook, DGHook, SeedableHook, StatefulHook, StatelessHook
 from .dedup import DeduplicationHook
+from .edge_list import SampledEdgeListHook
 from .hook_manager import HookManager
 from .negatives import RandomNegativeEdgeSamplerHook
 from .recency import RecencyNeighborHook
@@ -14,6 +15,7 @@ __all__ = [
     'NeighborSamplerHook',
     'RandomNegativeEdgeSamplerHook',
     'RecencyNeighborHook',
+    'SampledEdgeListHook',
     'SeedableHook',
     'StatefulHook',
     'StatelessHook',

@@ -53,21 +53,26 @@ class DeduplicationHook(StatelessHook, SeedableHook):
                 if value is not None:
                     parts.append(value)
         if device.type == 'cuda':
-            unique_nids = self._unique_device(dg, parts + [p.to(device) for p in nbr_parts], device)
-        else:
-            flat = parts + [p[p != PADDED_NODE_ID] for p in nbr_parts]
-            unique_nids = torch.unique(torch.cat(flat, dim=0), sorted=True)
-        self.add_batch_attribute(batch, 'unique_nids', unique_nids)
-        self.add_batch_attribute(batch, 'global_to_local', lambda x: torch.searchsorted(unique_nids, x).int())
+            self._unique_device(dg, batch, parts + [p.to(device) for p in nbr_parts], device)
+            return batch
+        flat = parts + [p[p != PADDED_NODE_ID] for p in nbr_parts]
+        self._publish(batch, torch.unique(torch.cat(flat, dim=0), sorted=True))
         return batch
 
-    def _unique_device(self, dg: DGraph, parts: List[torch.Tensor], device: torch.device) -> torch.Tensor:
+    def _publish(self, batch: DGBatch, unique_nids: torch.Tensor) -> None:
+        self.add_batch_attribute(batch, 'unique_nids', unique_nids)
+        self.add_batch_attribute(batch, 'global_to_local', lambda x: torch.searchsorted(unique_nids, x).int())
+
+    def _unique_device(self, dg: DGraph, batch: DGBatch, parts: List[torch.Tensor], device: torch.device) -> None:
+        """Enqueue ``tgmx_unique_ids`` and publish ``unique_nids`` / ``global_to_local`` once the count is on the host: right away
+        (one device -> host wait, like ``torch.unique``), or -- for a batch the loader prefetches -- in the batch's finalizer."""
         lib = _native.load()
         parts = [p for p in parts if p.numel()]
         dtype = parts[0].dtype if parts else torch.int32
         parts = [p if (p.dtype == torch.int32 and p.is_contiguous()) else p.to(torch.int32).contiguous() for p in parts]
         if not parts:
-            return torch.empty(0, dtype=dtype, device=device)
+            self._publish(batch, torch.empty(0, dtype=dtype, device=device))
+            return
         if len(parts) > 16:
             parts = parts[:15] + [torch.cat(parts[15:])]
         N = int(dg._storage.num_nodes_global)
@@ -75,8 +80,13 @@ class DeduplicationHook(StatelessHook, SeedableHook):
         ws = getattr(self, '_ws', None)
         if ws is None or ws[0] != (device, N):
             need = int(lib.tgmx_unique_ids_workspace_bytes(N))
-            ws = self._ws = ((device, N), torch.empty(need, dtype=torch.uint8, device=device), torch.zeros(2, dtype=torch.int64, device=device))
-        _, work, cs = ws  # cs[0] = count (int64), cs[1] low word = status: ONE device -> host read for both
+            ring = [(torch.zeros(2, dtype=torch.int64, device=device), torch.zeros(2, dtype=torch.int64).pin_memory(), torch.cuda.Event())
+                    for _ in range(4)]  # (count | status) on the device, its pinned host mirror, "mirror written" -- one set per batch in flight
+            ws = self._ws = ((device, N), torch.zeros(need, dtype=torch.uint8, device=device), ring)  # zeros: the bitmap cleans itself
+            self._turn = 0
+        _, work, ring = ws
+        cs, pin, ev = ring[self._turn % len(ring)]
+        self._turn += 1
         count, status = cs[0:1], cs[1:2].view(torch.int32)[0:1]
         out = torch.empty(min(total, N), dtype=torch.int32, device=device)
         n = len(parts)
@@ -85,10 +95,18 @@ class DeduplicationHook(StatelessHook, SeedableHook):
         with torch.cuda.device(device):
             _native.check(lib.tgmx_unique_ids(ptrs, sizes, n, N, work.data_ptr(), out.data_ptr(), count.data_ptr(), status.data_ptr(),
                                               _native.stream_ptr(device.index)), 'tgmx_unique_ids')  # fmt: skip
-        cnt, st = cs.tolist()  # the only sync: the result's size (torch.unique has the same one)
-        st &= 0xFFFFFFFF
-        if st:
-            cs[1].zero_()
-            raise ValueError(f'node ids must satisfy 0 <= x < {N} (or -1 for a padded neighbor slot)')
-        res = out[:cnt]
-        return res if dtype == torch.int32 else res.to(dtype)
+            pin.copy_(cs, non_blocking=True)
+            ev.record()
+        # device-side handoff for hooks further down the chain (they need neither the host count nor the finalized slice)
+        batch.__dict__['_unique_dev'] = (out, count)
+
+        def finish() -> None:
+            ev.synchronize()  # the only wait: the result's size (torch.unique has the same one)
+            cnt, st = pin.tolist()
+            if st & 0xFFFFFFFF:
+                cs[1].zero_()
+                raise ValueError(f'node ids must satisfy 0 <= x < {N} (or -1 for a padded neighbor slot)')
+            res = out[:cnt]
+            self._publish(batch, res if dtype == torch.int32 else res.to(dtype))
+
+        batch._defer(finish)

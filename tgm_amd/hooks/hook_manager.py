@@ -85,7 +85,7 @@ class HookManager:
             self.resolve_hooks(key)
         for h in self._key_to_hooks[key]:
             batch = h(dg, batch)
-        return batch
+        return batch._finalize() if hasattr(batch, '_finalize') else batch
 
     def active_hooks(self) -> List[DGHook]:
         """The resolved (dependency-ordered) hook list of the active key.  The list object is replaced, not edited, when

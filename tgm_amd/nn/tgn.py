@@ -377,6 +377,36 @@ class TGNMemory(nn.Module):
         return self
 
 
+def _edge_list_enqueue(batch, hop: int):
+    """Enqueue ``tgmx_tgn_edge_list`` for one hop; returns (edge_index [2, cap], edge_t [cap], edge_x [cap, D], count [1] on the device)."""
+    lib = _native.load()
+    seeds, nbr = batch.seed_nids[hop], batch.nbr_nids[hop]
+    nbr_t, nbr_x = batch.nbr_edge_time[hop], batch.nbr_edge_x[hop]
+    _native.require_device(nbr, 'nbr_nids')
+    dev = nbr.device
+    S, k = nbr.shape
+    D = nbr_x.shape[-1]
+    c = lambda t, dt: t if (t.dtype == dt and t.is_contiguous()) else t.to(dt).contiguous()
+    seeds, nbr, nbr_t, nbr_x = c(seeds, torch.int32), c(nbr, torch.int32), c(nbr_t, torch.int64), c(nbr_x, torch.float32)
+    pending = batch.__dict__.get('_unique_dev')  # DeduplicationHook's device-side result: ids [capacity] + count, no host size needed
+    if pending is not None:
+        uniq, U, ucount = pending[0], 0, pending[1].data_ptr()
+    else:
+        uniq = c(batch.unique_nids, torch.int32)
+        U, ucount = uniq.numel(), None
+    cap = max(S * k, 1)
+    ei = torch.empty((2, cap), dtype=torch.int64, device=dev)
+    et = torch.empty(cap, dtype=torch.int64, device=dev)
+    ex = torch.empty((cap, D), dtype=torch.float32, device=dev)
+    ws = torch.empty(S + 2, dtype=torch.int64, device=dev)  # row offsets [S + 1] | count
+    _native.check(
+        lib.tgmx_tgn_edge_list(seeds.data_ptr(), nbr.data_ptr(), nbr_t.data_ptr(), nbr_x.data_ptr(), S, k, D, uniq.data_ptr(), U, ucount, cap,
+                               ws.data_ptr(), ei.data_ptr(), et.data_ptr(), ex.data_ptr(), ws[S + 1 :].data_ptr(), _native.stream_ptr()),
+        'tgmx_tgn_edge_list',
+    )  # fmt: skip
+    return ei, et, ex, ws[S + 1 :]
+
+
 def sampled_edge_list(batch, hop: int = 0) -> Tuple[Tensor, Tensor, Tensor]:
     """``(edge_index [2, E] int64, edge_time [E] int64, edge_x [E, D] float32)`` of one sampled hop, exactly what the
     reference's TGN loop assembles from a dozen torch ops (examples/linkproppred/tgn.py:80-92):
@@ -385,28 +415,10 @@ def sampled_edge_list(batch, hop: int = 0) -> Tuple[Tensor, Tensor, Tensor]:
         edge_time = nbr_edge_time[hop].flatten()[mask];  edge_x = nbr_edge_x[hop].flatten(0, -2)[mask]
 
     in two launches (``tgmx_tgn_edge_list``) and one device -> host read (E).  Needs ``batch.unique_nids`` (the
-    ``DeduplicationHook``) and the sampler's outputs; bit-identical to the torch formulation (tests/test_tgn_gpu.py)."""
-    lib = _native.load()
-    seeds, nbr = batch.seed_nids[hop], batch.nbr_nids[hop]
-    nbr_t, nbr_x, uniq = batch.nbr_edge_time[hop], batch.nbr_edge_x[hop], batch.unique_nids
-    _native.require_device(nbr, 'nbr_nids')
-    dev = nbr.device
-    S, k = nbr.shape
-    D = nbr_x.shape[-1]
-    c = lambda t, dt: t if (t.dtype == dt and t.is_contiguous()) else t.to(dt).contiguous()
-    seeds, nbr, nbr_t, nbr_x, uniq = c(seeds, torch.int32), c(nbr, torch.int32), c(nbr_t, torch.int64), c(nbr_x, torch.float32), c(uniq, torch.int32)
-    cap = S * k
-    ei = torch.empty((2, max(cap, 1)), dtype=torch.int64, device=dev)
-    et = torch.empty(max(cap, 1), dtype=torch.int64, device=dev)
-    ex = torch.empty((max(cap, 1), D), dtype=torch.float32, device=dev)
-    ws = torch.empty(S + 2, dtype=torch.int64, device=dev)  # row offsets [S + 1] | count
-    _native.check(
-        lib.tgmx_tgn_edge_list(seeds.data_ptr(), nbr.data_ptr(), nbr_t.data_ptr(), nbr_x.data_ptr(), S, k, D, uniq.data_ptr(), uniq.numel(),
-                               max(cap, 1), ws.data_ptr(), ei.data_ptr(), et.data_ptr(), ex.data_ptr(), ws[S + 1 :].data_ptr(),
-                               _native.stream_ptr()),
-        'tgmx_tgn_edge_list',
-    )  # fmt: skip
-    E = int(ws[S + 1].item())
+    ``DeduplicationHook``) and the sampler's outputs; bit-identical to the torch formulation (tests/test_tgn_gpu.py).
+    ``tgm_amd.hooks.SampledEdgeListHook`` is the same as a hook, whose read of E a prefetching loader hides."""
+    ei, et, ex, count = _edge_list_enqueue(batch, hop)
+    E = int(count.item())
     return ei[:, :E], et[:E], ex[:E]
 
 

@@ -12,13 +12,14 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tgm_amd import DGData, DGDataLoader, DGraph  # noqa: E402
-from tgm_amd.hooks import DeduplicationHook, HookManager, RandomNegativeEdgeSamplerHook, RecencyNeighborHook  # noqa: E402
+from tgm_amd.hooks import DeduplicationHook, HookManager, RandomNegativeEdgeSamplerHook, RecencyNeighborHook, SampledEdgeListHook  # noqa: E402
 from tgm_amd.nn import GraphAttentionEmbedding, IdentityMessage, LastAggregator, TGNMemory, sampled_edge_list  # noqa: E402
 from tgm_amd.synth import make_stream  # noqa: E402
 
 dev = torch.device('cuda', 0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-# 'fast' (default): pooled loader, TGNMemory.reuse_forward, sampled_edge_list (one native call for the loop's edge-list glue);
+# 'fast' (default): pooled loader running one batch ahead (prefetch=1), SampledEdgeListHook (the loop's edge-list glue as one
+#   native call inside the hook chain), TGNMemory.reuse_forward;
 # 'reference': fresh tensors, the reference loop's torch glue verbatim, update_state recomputing its rows -- same results
 variant = sys.argv[2] if len(sys.argv) > 2 else 'fast'
 fast = variant == 'fast'
@@ -31,20 +32,23 @@ hm.register('k', RandomNegativeEdgeSamplerHook(lo_dst, N))
 hook = RecencyNeighborHook(N, ks, ['edge_src', 'edge_dst', 'neg'], ['edge_time', 'edge_time', 'neg_time'], validate='deferred')
 hm.register('k', hook)
 hm.register('k', DeduplicationHook(seed_nodes_keys=['neg', 'nbr_nids']))
+if fast:
+    hm.register('k', SampledEdgeListHook(hop=0))
 mem = TGNMemory(N, D, M, T_, IdentityMessage(D, M, T_), LastAggregator()).to(dev).train()
 mem.reuse_forward = fast
 enc = GraphAttentionEmbedding(M, 100, D, mem.time_enc).to(dev).eval()
-loader = DGDataLoader(dg, batch_size=bs, hook_manager=hm, output_pool=1 if fast else 0)
-starts = loader._starts
 k = ks[0]
 
 
-def step(i):
-    batch = loader(starts[i])
+def batches(lo, hi):
+    """batches lo .. hi - 1 of the stream (a view of the resident store; the sampler state carries over)"""
+    return DGDataLoader(dg.slice_events(lo * bs, hi * bs), batch_size=bs, hook_manager=hm, output_pool=2 if fast else 0, prefetch=1 if fast else 0)
+
+
+def step(batch):
     if fast:
-        edge_index, e_t, e_x = sampled_edge_list(batch)
         z, lu = mem(batch.unique_nids)
-        z2 = enc(z, lu, edge_index, e_t, e_x)
+        z2 = enc(z, lu, batch.sampled_edge_index, batch.sampled_edge_time, batch.sampled_edge_x)
         mem.update_state(batch.edge_src, batch.edge_dst, batch.edge_time, batch.edge_x)
         return z2, batch
     nbr = batch.nbr_nids[0].flatten()
@@ -60,21 +64,21 @@ def step(i):
 
 
 with hm.activate('k'), torch.no_grad():
-    for i in range(100):
-        z2, b = step(i)
+    for batch in batches(0, 100):
+        z2, b = step(batch)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(100, 100 + n):
-        z2, b = step(i)
+    for batch in batches(100, 100 + n):
+        z2, b = step(batch)
     t1 = time.perf_counter()
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     hook.check()
     mem.check()
-    # sampler only, same stream
+    # loader + hooks only, same stream
     t3 = time.perf_counter()
-    for i in range(100 + n, 100 + 2 * n):
-        loader(starts[i])
+    for batch in batches(100 + n, 100 + 2 * n):
+        pass
     torch.cuda.synchronize()
     t4 = time.perf_counter()
 slots = 3 * bs * k + 3 * bs * k * ks[1]
