@@ -4,6 +4,9 @@ C ABI, against the reference's outputs (goldens g5 / g6) and the torch-fp32 orac
 Tolerance (fp32 path; BASELINE north_star: 1e-5 relative):
     |got - ref| <= 1e-5 * max(1, |ref|)   element-wise.
 """
+import json
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -21,6 +24,15 @@ def close(got, ref, tag):
     assert torch.isfinite(got).all(), f'{tag}: non-finite output'
     err = (got - ref).abs()
     worst = (err / (RTOL * ref.abs().clamp(min=1.0))).max().item()
+    # The bar is |got - ref| <= 1e-5 * max(1, |ref|): relative for |ref| >= 1, absolute 1e-5 below that (every output here
+    # comes out of a LayerNorm / MLP with O(1) scale, where a pure relative bound on an element that happens to be ~0 is not
+    # meaningful).  TGMX_PARITY_STATS=<file>: also record the worst PURE relative error over the elements with |ref| >= 1e-2.
+    if os.environ.get('TGMX_PARITY_STATS'):
+        big = ref.abs() >= 1e-2
+        rel = (err[big] / ref.abs()[big]).max().item() if bool(big.any()) else 0.0
+        with open(os.environ['TGMX_PARITY_STATS'], 'a') as f:
+            f.write(json.dumps({'case': tag, 'elements': got.numel(), 'max_abs_err': err.max().item(), 'worst_multiple_of_bound': worst,
+                                'worst_relative_err_where_ref_ge_1e-2': rel, 'max_abs_ref': ref.abs().max().item()}) + '\n')
     assert worst <= 1.0, f'{tag}: worst error {worst:.2f}x the 1e-5 bound (max abs err {err.max().item():.3e})'
 
 

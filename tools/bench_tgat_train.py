@@ -16,7 +16,7 @@ from tgm_amd.synth import make_stream  # noqa: E402
 stream = make_stream('wiki', seed=1337)
 dev = torch.device('cuda', 0)
 dg, hm, hook, loader = bench.build_pipeline(stream, 0, 1, 200, [20, 20], 'ring', dev)
-enc = TGAT(node_dim=1, edge_dim=172, time_dim=100, embed_dim=172, num_layers=2, dropout=0.0).to(dev).train()
+enc = TGAT(node_dim=1, edge_dim=172, time_dim=100, embed_dim=172, num_layers=2).to(dev).train()  # the reference default dropout 0.1
 opt = torch.optim.Adam(enc.parameters(), lr=1e-4)
 starts = loader._starts
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
