@@ -491,6 +491,15 @@ __global__ __launch_bounds__(kBlockThreads) void ring_update_block_kernel(const 
   update_block_body<E, MAXM, PRESORTED, false>(a, L, S, (int)blockIdx.x, (int)gridDim.x);
 }
 
+// placement DECISIONS only (PRESORTED, DEFER): reads write_pos, writes winner / target to the scratch -- may run next to the
+// lookups of the same batch; ring_update_feat_kernel<COMMIT> applies them afterwards
+template <int E, int MAXM>
+__global__ __launch_bounds__(kBlockThreads) void ring_update_decide_kernel(const UpdateArgs a) {
+  __shared__ PlaceLds<MAXM> L;
+  __shared__ SortLds<1> S;
+  update_block_body<E, MAXM, true, true>(a, L, S, (int)blockIdx.x, (int)gridDim.x);
+}
+
 // ---- the state-independent half of the ring update, as workgroup-sized pieces -------------------------------------
 // The order of a batch's entries depends on the batch alone, not on the rings, so `tgmx_recency_step` lets it ride
 // along with the lookups: the first `side_blocks` workgroups of the hop-0 launch chunk-sort the entries, the first
@@ -1712,6 +1721,18 @@ static void launch_update_presorted(const UpdateArgs& a, hipStream_t st) {
   if (a.D > 0) hipLaunchKernelGGL(ring_update_feat_kernel<false>, dim3((unsigned)((a.m + 3) / 4)), dim3(256), 0, st, a);
 }
 
+// 1024 < m <= 4096 next to the lookups (side stream): chunk sort, merge (+ pre-gather), placement decisions; nothing here
+// writes ring state.  The commit (ring_update_feat_kernel<true>) follows the lookups on the main stream.
+static void launch_update_mid_front(const UpdateArgs& a, unsigned chunks, hipStream_t st) {
+  hipLaunchKernelGGL(ring_update_chunk_sort_kernel, dim3(chunks), dim3(kChunk), 0, st, a);
+  hipLaunchKernelGGL(ring_update_merge_kernel, dim3(chunks), dim3(kChunk), 0, st, a);
+  int P = 64;
+  while (P < a.m) P <<= 1;
+  constexpr unsigned parts = 8;
+  if (P <= 2048) hipLaunchKernelGGL((ring_update_decide_kernel<2, 2048>), dim3(parts), dim3(1024), 0, st, a);
+  else hipLaunchKernelGGL((ring_update_decide_kernel<4, 4096>), dim3(parts), dim3(1024), 0, st, a);
+}
+
 static void launch_update_block(UpdateArgs& a, int32_t* scratch, hipStream_t st) {
   int P = 64;
   while (P < a.m) P <<= 1;
@@ -2161,6 +2182,19 @@ extern "C" int tgmx_recency_step(const tgmx_recency_step_t* s, tgmx_stream_t str
     if (u.m <= kBlockMaxM && s->n_hops > 0 && S > 0 && !no_ride) side_chunks = set_chunk_scratch(u, s->scratch + kScratchHead);
     ride_place = side_chunks > 0 && u.m <= kRidePlaceMaxM && s->n_hops >= 2;
   }
+  // 1024 < m <= 4096 (the replicated update of a 4- / 8-rank global wiki batch): the whole front half -- sort, merge,
+  // placement decisions -- on the side stream next to the lookups instead of riders + a placement launch behind them; only
+  // the commit follows the lookups.  Costs the host two event records, two stream waits and three launches per batch, which
+  // it has to spare since the loader chain is one native call (wiki, 8 ranks: 62 -> ~47 us per step).  A/B: TGMX_NO_SIDE_MID=1.
+  static const bool no_side_mid = getenv("TGMX_NO_SIDE_MID") != nullptr;
+  SideStream* mid = nullptr;
+  if (side_chunks > 0 && !ride_place && u.m > kRidePlaceMaxM && !no_side_mid && (mid = side_stream_for_current_device()) != nullptr) {
+    (void)hipEventRecord(mid->fork, st);  // the batch's inputs and the previous batch's ring writes are complete
+    (void)hipStreamWaitEvent(mid->stream, mid->fork, 0);
+    launch_update_mid_front(u, side_chunks, mid->stream);
+    (void)hipEventRecord(mid->join, mid->stream);
+    side_chunks = 0;  // no riders in the lookup launches
+  }
   // m <= 1024 and the placement rides: the write-back (records, write_pos, feature rows) CAN run as the tail of the last
   // lookup launch -- its last ceil(m / 4) workgroups prefetch their decisions, wait for the others, then store -- instead
   // of a launch of its own.  Measured on MI355X (wiki shape): lookup 37.9 + commit 5.3 us as two launches, 44.9 us as one
@@ -2230,7 +2264,10 @@ extern "C" int tgmx_recency_step(const tgmx_recency_step_t* s, tgmx_stream_t str
 
   // ---- ring update (after every lookup, recency.py:161-163)
   if (s->n > 0) {
-    if (ride_place && tail_blocks) {
+    if (mid) {
+      (void)hipStreamWaitEvent(st, mid->join, 0);
+      hipLaunchKernelGGL(ring_update_feat_kernel<true>, dim3((unsigned)((u.m + 3) / 4)), dim3(256), 0, st, u);
+    } else if (ride_place && tail_blocks) {
       // written by the tail of the last lookup launch
     } else if (ride_place) {
       hipLaunchKernelGGL(ring_update_feat_kernel<true>, dim3((unsigned)((u.m + 3) / 4)), dim3(256), 0, st, u);
