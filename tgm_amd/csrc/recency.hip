@@ -2182,11 +2182,11 @@ extern "C" int tgmx_recency_step(const tgmx_recency_step_t* s, tgmx_stream_t str
     if (u.m <= kBlockMaxM && s->n_hops > 0 && S > 0 && !no_ride) side_chunks = set_chunk_scratch(u, s->scratch + kScratchHead);
     ride_place = side_chunks > 0 && u.m <= kRidePlaceMaxM && s->n_hops >= 2;
   }
-  // 1024 < m <= 4096 (the replicated update of a 4- / 8-rank global wiki batch): the whole front half -- sort, merge,
-  // placement decisions -- on the side stream next to the lookups instead of riders + a placement launch behind them; only
-  // the commit follows the lookups.  Costs the host two event records, two stream waits and three launches per batch, which
-  // it has to spare since the loader chain is one native call (wiki, 8 ranks: 62 -> ~47 us per step).  A/B: TGMX_NO_SIDE_MID=1.
-  static const bool no_side_mid = getenv("TGMX_NO_SIDE_MID") != nullptr;
+  // 1024 < m <= 4096 (the replicated update of a 4- / 8-rank global wiki batch): the front half -- sort, merge, placement
+  // decisions -- CAN run on the side stream next to the lookups instead of riders + a placement launch behind them.
+  // Measured on MI355X and rejected: the fork / join dependency between the streams costs more than the placement launch it
+  // hides (wiki, rank 7 of 8: 84.1 vs 60.4 us per step; rank 3 of 4: 70.4 vs 53.2).  Off unless TGMX_SIDE_MID=1 (A/B knob).
+  static const bool no_side_mid = getenv("TGMX_SIDE_MID") == nullptr;
   SideStream* mid = nullptr;
   if (side_chunks > 0 && !ride_place && u.m > kRidePlaceMaxM && !no_side_mid && (mid = side_stream_for_current_device()) != nullptr) {
     (void)hipEventRecord(mid->fork, st);  // the batch's inputs and the previous batch's ring writes are complete
