@@ -172,8 +172,9 @@ def pmc_traffic(args, grid_slots):
 
 def rocprof_kernel_us(fused: bool):
     """Average duration of the dominant kernel in the committed rocprofv3 --kernel-trace --stats summary of this very
-    command (profiles/rNN_sampler_rocprof_summary.md, latest round; tools/gpu_round.sh writes it) -- the cross-check of the HIP-event
-    figure (events bracket the launch from outside: ~2-3 us more than the kernel's own duration)."""
+    command (profiles/rNN_sampler_rocprof_summary.md, latest round; tools/gpu_profile.sh writes it): the "timed region" line -- the
+    last 393 launches, i.e. the steady-state steps bench.py times -- when present, else the whole-run average.  Cross-check of the
+    figure measured live (the dispatch's own begin / end timestamps through hipExtLaunchKernelGGL)."""
     path = next((p for p in (os.path.join(ROOT, 'profiles', f'r{r:02d}_sampler_rocprof_summary.md') for r in (2, 1)) if os.path.exists(p)), None)
     if path is None:
         return None
@@ -181,9 +182,14 @@ def rocprof_kernel_us(fused: bool):
     best = None
     for line in open(path):
         cells = [c.strip() for c in line.split('|')]
-        if len(cells) > 5 and want in cells[1]:
+        if len(cells) > 3 and cells[1].startswith('timed region') and want in cells[1]:
             try:
-                calls, avg = int(cells[2]), float(cells[4])
+                return float(cells[2].split()[1])  # "avg 38.12 us": the same steady-state launches bench.py times
+            except (ValueError, IndexError):
+                pass
+        if len(cells) > 6 and want in cells[1]:
+            try:
+                calls, avg = int(cells[3]), float(cells[5])
             except ValueError:
                 continue
             if best is None or calls > best[0]:

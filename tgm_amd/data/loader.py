@@ -92,16 +92,20 @@ class DGDataLoader:
     def __call__(self, slice_start, _deferred: bool = False) -> DGBatch:
         """Materialize the batch beginning at ``slice_start`` and run the active hooks."""
         s = slice_start[0] if isinstance(slice_start, (list, tuple)) else slice_start
-        if self._output_pool > 0 and self._hook_manager is not None:
+        if self._output_pool > 0 and hasattr(self._hook_manager, 'active_hooks'):
             batch = self._call_compiled(s, _deferred)
             if batch is not None:
                 return batch if _deferred else batch._finalize()
         view = self._slice_op(s, s + self._batch_size)
         batch = view.materialize()
-        if self._hook_manager is not None:
+        hm = self._hook_manager
+        if hm is not None:
             batch.__dict__['_deferred'] = _deferred
-            for h in self._hook_manager.active_hooks():
-                batch = h(view, batch)
+            if hasattr(hm, 'active_hooks'):
+                for h in hm.active_hooks():
+                    batch = h(view, batch)
+            else:  # a foreign manager (the reference's): its own entry point
+                batch = hm.execute_active_hooks(view, batch)
         return batch if _deferred else batch._finalize()
 
     def _call_compiled(self, s: int, deferred: bool = False) -> Optional[DGBatch]:

@@ -62,6 +62,15 @@ def gaps(db, kernel):
                       'idle_us_per_step': idle / steps / 1e3, 'wall_us_per_step': (rows[hi][1] - rows[lo][1]) / steps / 1e3}))
 
 
+def tail(db, kernel, last):
+    """average duration of the LAST `last` launches of one kernel: bench.py's timed steps are the end of the run"""
+    rows = [r for r in db.execute('select name, start, end, grid_x from kernels order by start').fetchall() if kernel in r[0]]
+    main_grid = max(set(r[3] for r in rows), key=lambda g: sum(1 for r in rows if r[3] == g))
+    rows = [r for r in rows if r[3] == main_grid][-last:]
+    d = [(e - s_) / 1e3 for _, s_, e, _ in rows]
+    print(f'| timed region: last {len(d)} launches of `{kernel}` | avg {sum(d) / len(d):.2f} us | min {min(d):.2f} | max {max(d):.2f} |')
+
+
 def pmc(db, kernel):
     rows = db.execute('select k.name, k.grid_x, p.counter_name, count(*), avg(p.counter_value), min(p.counter_value), max(p.counter_value) '
                       'from pmc_events p join kernels k on k.dispatch_id = p.dispatch_id group by k.name, k.grid_x, p.counter_name '
@@ -76,10 +85,11 @@ def pmc(db, kernel):
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
-    ap.add_argument('what', choices=['trace', 'gaps', 'pmc'])
+    ap.add_argument('what', choices=['trace', 'gaps', 'pmc', 'tail'])
+    ap.add_argument('--last', type=int, default=393)
     ap.add_argument('path')
     ap.add_argument('--title', default='rocprofv3 --kernel-trace --stats')
     ap.add_argument('--kernel', default='')
     a = ap.parse_args()
     db = open_db(a.path)
-    {'trace': lambda: trace(db, a.title), 'gaps': lambda: gaps(db, a.kernel), 'pmc': lambda: pmc(db, a.kernel)}[a.what]()
+    {'trace': lambda: trace(db, a.title), 'gaps': lambda: gaps(db, a.kernel), 'pmc': lambda: pmc(db, a.kernel), 'tail': lambda: tail(db, a.kernel, a.last)}[a.what]()
