@@ -55,7 +55,7 @@ typedef struct tgmx_adj {
 int tgmx_version(void);
 /* sizeof of the argument structs as this library was compiled (a binding checks its own mirror against it):
  * 0 tgmx_adj_t, 1 tgmx_recency_step_t, 2 tgmx_tgat_layer_t, 3 tgmx_tgat_model_t, 4 tgmx_tgat_hop_t, 5 tgmx_tgat_layout_t,
- * 6 tgmx_pipeline_t, 7 tgmx_pipeline_out_t, 8 tgmx_dropout_t */
+ * 6 tgmx_pipeline_t, 7 tgmx_pipeline_out_t, 8 tgmx_dropout_t, 9 tgmx_tgn_memory_fwd_t, 10 tgmx_tconv_fwd_t */
 size_t tgmx_abi_sizeof(int32_t which);
 const char* tgmx_last_error(void);
 
@@ -490,6 +490,37 @@ int tgmx_tgn_commit_assoc(const int32_t* src, const int32_t* dst, int64_t n, con
 int tgmx_tgn_store_batch(const int32_t* src, const int32_t* dst, const int64_t* t, const float* raw, int32_t D, int32_t n,
                          int64_t base, int32_t* log_other, int64_t* log_t, float* log_raw, int64_t* st_lo_s,
                          int32_t* st_cnt_s, int64_t* st_lo_d, int32_t* st_cnt_d, tgmx_stream_t stream);
+
+/* TGNMemory._get_updated_memory (tgn.py:191-216) and GraphAttentionEmbedding.forward (tgn.py:30-40, PyG TransformerConv) as
+ * ONE call each (inference / no-grad paths): the same launches, in the same order, as the building blocks above composed by
+ * the host -- aggregate, gather, the two GRU GEMMs, gates; four stacked projections, edge encoding, lin_edge GEMM, segment
+ * sort, attention.  Every buffer is the caller's.  qkvs is [4, U, H*C]: query | key | value | skip; the result is its 4th
+ * block (skip + attention). */
+typedef struct tgmx_tgn_memory_fwd {
+  const int32_t* nodes; int64_t R;
+  const float* memory; const int64_t* last_update; int32_t M, num_nodes;
+  const int64_t* st_lo_s; const int32_t* st_cnt_s; const int64_t* st_lo_d; const int32_t* st_cnt_d;
+  const int32_t* log_other; const int64_t* log_t; const float* log_raw; int32_t D;
+  const float* tw; const float* tb; int32_t T, mean;
+  const float *W_ih, *b_ih, *W_hh, *b_hh;              /* GRUCell: [3M, 2M + D + T], [3M], [3M, M], [3M] */
+  float *ws_aggr, *ws_h, *ws_gi, *ws_gh;               /* [R, 2M + D + T], [R, M], [R, 3M], [R, 3M] */
+  float* out_mem; int64_t* out_lu;                     /* [R, M], [R] */
+  int64_t* assoc; int64_t stamp;                       /* optional, as in tgmx_tgn_aggregate */
+} tgmx_tgn_memory_fwd_t;
+int tgmx_tgn_memory_forward(const tgmx_tgn_memory_fwd_t* args, tgmx_stream_t stream);
+
+typedef struct tgmx_tconv_fwd {
+  const float* x; int64_t U; int32_t in_ch;
+  const int64_t* last_update_local;                    /* [U] */
+  const int64_t* src; const int64_t* tgt; const int64_t* t; const float* msg; int64_t E; int32_t D, T;
+  const float* tw; const float* tb;
+  const float* W4; const float* b4; const float* W_edge; /* [4, H*C, in_ch], [4, H*C], [H*C, T + D] */
+  int32_t H, C;
+  float* edge_attr; float* qkvs; float* eproj;         /* [E, T + D], [4, U, H*C], [E, H*C] */
+  int64_t* order; int64_t* seg_lo; int64_t* seg_hi;    /* [E], [U], [U] */
+  void* sort_ws; size_t sort_ws_bytes; int32_t* status;
+} tgmx_tconv_fwd_t;
+int tgmx_tconv_forward(const tgmx_tconv_fwd_t* args, tgmx_stream_t stream);
 
 /* The sampled edge list of one hop as the reference's TGN loop assembles it from torch ops
  * (examples/linkproppred/tgn.py:80-92): for every valid slot (nbr != -1), in slot order,

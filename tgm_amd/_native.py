@@ -152,6 +152,32 @@ class RecencyStep(ctypes.Structure):
     ]  # fmt: skip
 
 
+class TgnMemoryFwd(ctypes.Structure):
+    """tgmx_tgn_memory_fwd_t (include/tgm_amd.h)."""
+
+    _fields_ = [
+        ('nodes', c_void_p), ('R', c_int64), ('memory', c_void_p), ('last_update', c_void_p), ('M', c_int32), ('num_nodes', c_int32),
+        ('st_lo_s', c_void_p), ('st_cnt_s', c_void_p), ('st_lo_d', c_void_p), ('st_cnt_d', c_void_p),
+        ('log_other', c_void_p), ('log_t', c_void_p), ('log_raw', c_void_p), ('D', c_int32),
+        ('tw', c_void_p), ('tb', c_void_p), ('T', c_int32), ('mean', c_int32),
+        ('W_ih', c_void_p), ('b_ih', c_void_p), ('W_hh', c_void_p), ('b_hh', c_void_p),
+        ('ws_aggr', c_void_p), ('ws_h', c_void_p), ('ws_gi', c_void_p), ('ws_gh', c_void_p),
+        ('out_mem', c_void_p), ('out_lu', c_void_p), ('assoc', c_void_p), ('stamp', c_int64),
+    ]  # fmt: skip
+
+
+class TconvFwd(ctypes.Structure):
+    """tgmx_tconv_fwd_t (include/tgm_amd.h)."""
+
+    _fields_ = [
+        ('x', c_void_p), ('U', c_int64), ('in_ch', c_int32), ('last_update_local', c_void_p),
+        ('src', c_void_p), ('tgt', c_void_p), ('t', c_void_p), ('msg', c_void_p), ('E', c_int64), ('D', c_int32), ('T', c_int32),
+        ('tw', c_void_p), ('tb', c_void_p), ('W4', c_void_p), ('b4', c_void_p), ('W_edge', c_void_p), ('H', c_int32), ('C', c_int32),
+        ('edge_attr', c_void_p), ('qkvs', c_void_p), ('eproj', c_void_p), ('order', c_void_p), ('seg_lo', c_void_p), ('seg_hi', c_void_p),
+        ('sort_ws', c_void_p), ('sort_ws_bytes', c_size_t), ('status', c_void_p),
+    ]  # fmt: skip
+
+
 SEED_SRC, SEED_DST, SEED_NEG = 0, 1, 2
 
 
@@ -195,6 +221,8 @@ SIGNATURES['tgmx_pipeline_step'] = (c_int32, [ctypes.POINTER(Pipeline), c_int64,
 SIGNATURES['tgmx_slice'] = (c_int32, [_P, c_int64, c_int32, c_int64, c_int32, c_int64, c_int64, c_int64, ctypes.POINTER(c_int64), ctypes.POINTER(c_int64)])
 SIGNATURES['tgmx_discretize_workspace_bytes'] = (c_size_t, [c_int64])
 SIGNATURES['tgmx_discretize_keep'] = (c_int32, [_P, _P, _P, c_int64, ctypes.c_double, _P, _P, _P, _P, c_size_t, _P])
+SIGNATURES['tgmx_tgn_memory_forward'] = (c_int32, [ctypes.POINTER(TgnMemoryFwd), _P])
+SIGNATURES['tgmx_tconv_forward'] = (c_int32, [ctypes.POINTER(TconvFwd), _P])
 SIGNATURES['tgmx_segment_sort_workspace_bytes'] = (c_size_t, [c_int64])
 SIGNATURES['tgmx_segment_sort'] = (c_int32, [_P, c_int64, c_int32, _P, _P, _P, _P, c_size_t, _P, _P])
 SIGNATURES['tgmx_tgat_layout'] = (c_int32, [ctypes.POINTER(TgatModel), c_int64, ctypes.POINTER(TgatHop), c_int32, ctypes.POINTER(TgatLayout)])

@@ -28,6 +28,8 @@ extern "C" size_t tgmx_abi_sizeof(int32_t which) {
     case 6: return sizeof(tgmx_pipeline_t);
     case 7: return sizeof(tgmx_pipeline_out_t);
     case 8: return sizeof(tgmx_dropout_t);
+    case 9: return sizeof(tgmx_tgn_memory_fwd_t);
+    case 10: return sizeof(tgmx_tconv_fwd_t);
     default: return 0;
   }
 }

@@ -663,3 +663,42 @@ extern "C" int tgmx_tgn_edge_list(const int32_t* seed, const int32_t* nbr, const
   TGMX_CHECK_LAUNCH("tgn_edge_list");
   return TGMX_OK;
 }
+
+// ---- one call per module forward (inference / no-grad paths): the launches of TGNMemory's look-ahead and of
+// GraphAttentionEmbedding as C++ sequences -- the same entry points, in the same order, as tgm_amd/nn/tgn.py composes
+// them one ctypes call at a time (a Python-mediated launch costs the host ~8 us, a C++ one ~4; cfg 3 is host-bound).
+extern "C" int tgmx_tgn_memory_forward(const tgmx_tgn_memory_fwd_t* a, tgmx_stream_t stream) {
+  TGMX_REQUIRE(a, "tgn_memory_forward: null argument block");
+  const int64_t R = a->R;
+  if (R == 0) return TGMX_OK;
+  const int M = a->M, W = 2 * a->M + a->D + a->T;
+  TGMX_REQUIRE(a->ws_aggr && a->ws_h && a->ws_gi && a->ws_gh && a->out_mem && a->out_lu && a->W_ih && a->W_hh, "tgn_memory_forward: null pointer");
+  int rc = tgmx_tgn_aggregate(a->nodes, R, a->memory, a->last_update, M, a->num_nodes, a->st_lo_s, a->st_cnt_s, a->st_lo_d, a->st_cnt_d,
+                              a->log_other, a->log_t, a->log_raw, a->D, a->tw, a->tb, a->T, a->mean, a->ws_aggr, a->out_lu, a->assoc, a->stamp,
+                              stream);
+  if (rc) return rc;
+  if ((rc = tgmx_gather_rows(a->memory, a->num_nodes, M, a->nodes, R, a->ws_h, M, stream))) return rc;
+  // GRUCell: gi = aggr W_ih^T + b_ih, gh = h W_hh^T + b_hh, gates
+  if ((rc = tgmx_sgemm_nt(a->ws_aggr, W, a->W_ih, W, a->ws_gi, 3 * M, R, 3 * M, W, a->b_ih, 0, 1, 0, 0, 0, stream))) return rc;
+  if ((rc = tgmx_sgemm_nt(a->ws_h, M, a->W_hh, M, a->ws_gh, 3 * M, R, 3 * M, M, a->b_hh, 0, 1, 0, 0, 0, stream))) return rc;
+  return tgmx_tgn_gru_gate(a->ws_gi, a->ws_gh, a->ws_h, M, R, a->out_mem, stream);
+}
+
+extern "C" int tgmx_tconv_forward(const tgmx_tconv_fwd_t* a, tgmx_stream_t stream) {
+  TGMX_REQUIRE(a, "tconv_forward: null argument block");
+  const int64_t U = a->U, E = a->E;
+  if (U == 0) return TGMX_OK;
+  const int HC = a->H * a->C, Wd = a->T + a->D;
+  TGMX_REQUIRE(a->x && a->W4 && a->b4 && a->qkvs, "tconv_forward: null pointer");
+  // query / key / value / skip projections of the same x: ONE batched launch over the stacked weights
+  int rc = tgmx_sgemm_nt(a->x, a->in_ch, a->W4, a->in_ch, a->qkvs, HC, U, HC, a->in_ch, a->b4, 0, 4, 0, (int64_t)HC * a->in_ch, U * HC, stream);
+  if (rc || E == 0) return rc;
+  TGMX_REQUIRE(a->src && a->tgt && a->t && a->edge_attr && a->eproj && a->order && a->seg_lo && a->seg_hi && a->sort_ws && a->status,
+               "tconv_forward: null pointer");
+  if ((rc = tgmx_tconv_edge_attr(a->last_update_local, a->src, a->t, a->msg, a->tw, a->tb, a->T, a->D, E, a->edge_attr, stream))) return rc;
+  if ((rc = tgmx_sgemm_nt(a->edge_attr, Wd, a->W_edge, Wd, a->eproj, HC, E, HC, Wd, nullptr, 0, 1, 0, 0, 0, stream))) return rc;
+  if ((rc = tgmx_segment_sort(a->tgt, E, (int32_t)U, a->order, a->seg_lo, a->seg_hi, a->sort_ws, a->sort_ws_bytes, a->status, stream))) return rc;
+  float* out = a->qkvs + 3 * U * HC;  // the skip projection; the attention output is added to it
+  return tgmx_tconv_attend(a->qkvs, a->qkvs + U * HC, a->qkvs + 2 * U * HC, a->eproj, a->order, a->src, a->seg_lo, a->seg_hi, U, a->H, a->C,
+                           1.0f / sqrtf((float)a->C), out, nullptr, stream);
+}

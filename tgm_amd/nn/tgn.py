@@ -18,6 +18,7 @@ unspecified there; here it is the earlier edge of the batch.
 from __future__ import annotations
 
 import copy
+import os
 from typing import Callable, Optional, Tuple
 
 import torch
@@ -27,6 +28,8 @@ from torch import Tensor
 from .. import _native
 from . import _ops
 from .time_encoding import Time2Vec
+
+_COMPOSE_IN_PYTHON = bool(os.environ.get('TGMX_TGN_PY'))  # A/B knob: module forwards as sequences of ctypes calls instead of one C driver call
 
 
 class LastAggregator(nn.Module):
@@ -84,6 +87,7 @@ class TGNMemory(nn.Module):
         self._assoc64 = None       # [N] int64: (stamp << 32) | row
         self._stamp = 0
         self._reuse_status = None  # device int32: 1 = an update_state node was not part of the reused forward
+        self._fwd_args = None      # tgmx_tgn_memory_fwd_t, reused
         self.shard_commits = True  # under torch.distributed (world > 1): shard update_state's commit across ranks
         self.memory_updater.reset_parameters()
 
@@ -174,27 +178,49 @@ class TGNMemory(nn.Module):
             return self._updated_train(nodes, assoc, stamp)
         dev, R, M, D, T = nodes.device, nodes.numel(), self.memory_dim, self.raw_msg_dim, self.time_dim
         W = 2 * M + D + T
-        stream = _native.stream_ptr()
-        aggr = torch.empty((R, W), dtype=torch.float32, device=dev)
-        new_lu = torch.empty(R, dtype=torch.int64, device=dev)
-        tw, tb = self.time_enc.w.weight.detach().reshape(-1), self.time_enc.w.bias.detach()
-        _native.check(
-            lib.tgmx_tgn_aggregate(
-                nodes.data_ptr(), R, self.memory.data_ptr(), self.last_update.data_ptr(), M, self.num_nodes,
-                self._st_lo[0].data_ptr(), self._st_cnt[0].data_ptr(), self._st_lo[1].data_ptr(), self._st_cnt[1].data_ptr(),
-                _native.ptr(self._log_other), _native.ptr(self._log_t), _native.ptr(self._log_raw), D, tw.data_ptr(), tb.data_ptr(),
-                T, self.aggr_module.mean, aggr.data_ptr(), new_lu.data_ptr(), _native.ptr(assoc), stamp, stream,
-            ),
-            'tgmx_tgn_aggregate',
-        )  # fmt: skip
-        h = _ops.gather_rows(self.memory.detach(), nodes)
-        gru = self.memory_updater
-        gi = torch.empty((R, 3 * M), dtype=torch.float32, device=dev)
-        gh = torch.empty((R, 3 * M), dtype=torch.float32, device=dev)
-        _ops.sgemm_nt(aggr, gru.weight_ih.detach(), gi, bias=gru.bias_ih.detach())
-        _ops.sgemm_nt(h, gru.weight_hh.detach(), gh, bias=gru.bias_hh.detach())
+        if _COMPOSE_IN_PYTHON:  # A/B knob: the same launches, one ctypes call each
+            stream = _native.stream_ptr()
+            aggr = torch.empty((R, W), dtype=torch.float32, device=dev)
+            new_lu = torch.empty(R, dtype=torch.int64, device=dev)
+            tw, tb = self.time_enc.w.weight.detach().reshape(-1), self.time_enc.w.bias.detach()
+            _native.check(
+                lib.tgmx_tgn_aggregate(
+                    nodes.data_ptr(), R, self.memory.data_ptr(), self.last_update.data_ptr(), M, self.num_nodes,
+                    self._st_lo[0].data_ptr(), self._st_cnt[0].data_ptr(), self._st_lo[1].data_ptr(), self._st_cnt[1].data_ptr(),
+                    _native.ptr(self._log_other), _native.ptr(self._log_t), _native.ptr(self._log_raw), D, tw.data_ptr(), tb.data_ptr(),
+                    T, self.aggr_module.mean, aggr.data_ptr(), new_lu.data_ptr(), _native.ptr(assoc), stamp, stream,
+                ),
+                'tgmx_tgn_aggregate',
+            )  # fmt: skip
+            h = _ops.gather_rows(self.memory.detach(), nodes)
+            gru = self.memory_updater
+            gi = torch.empty((R, 3 * M), dtype=torch.float32, device=dev)
+            gh = torch.empty((R, 3 * M), dtype=torch.float32, device=dev)
+            _ops.sgemm_nt(aggr, gru.weight_ih.detach(), gi, bias=gru.bias_ih.detach())
+            _ops.sgemm_nt(h, gru.weight_hh.detach(), gh, bias=gru.bias_hh.detach())
+            out = torch.empty((R, M), dtype=torch.float32, device=dev)
+            _native.check(lib.tgmx_tgn_gru_gate(gi.data_ptr(), gh.data_ptr(), h.data_ptr(), M, R, out.data_ptr(), stream), 'tgmx_tgn_gru_gate')
+            return out, new_lu
+        # one native call (tgmx_tgn_memory_forward): aggregate, gather, the two GRU GEMMs, gates
+        ws = torch.empty(R * (W + 7 * M), dtype=torch.float32, device=dev)  # aggr [R, W] | h [R, M] | gi [R, 3M] | gh [R, 3M]
         out = torch.empty((R, M), dtype=torch.float32, device=dev)
-        _native.check(lib.tgmx_tgn_gru_gate(gi.data_ptr(), gh.data_ptr(), h.data_ptr(), M, R, out.data_ptr(), stream), 'tgmx_tgn_gru_gate')
+        new_lu = torch.empty(R, dtype=torch.int64, device=dev)
+        gru = self.memory_updater
+        a = self._fwd_args
+        if a is None:
+            a = self._fwd_args = _native.TgnMemoryFwd()
+        tw, tb = self.time_enc.w.weight.detach().reshape(-1), self.time_enc.w.bias.detach()
+        base = ws.data_ptr()
+        a.nodes, a.R, a.memory, a.last_update, a.M, a.num_nodes = nodes.data_ptr(), R, self.memory.data_ptr(), self.last_update.data_ptr(), M, self.num_nodes
+        a.st_lo_s, a.st_cnt_s, a.st_lo_d, a.st_cnt_d = (self._st_lo[0].data_ptr(), self._st_cnt[0].data_ptr(), self._st_lo[1].data_ptr(),
+                                                        self._st_cnt[1].data_ptr())  # fmt: skip
+        a.log_other, a.log_t, a.log_raw, a.D = _native.ptr(self._log_other), _native.ptr(self._log_t), _native.ptr(self._log_raw), D
+        a.tw, a.tb, a.T, a.mean = tw.data_ptr(), tb.data_ptr(), T, self.aggr_module.mean
+        a.W_ih, a.b_ih, a.W_hh, a.b_hh = (gru.weight_ih.detach().data_ptr(), gru.bias_ih.detach().data_ptr(), gru.weight_hh.detach().data_ptr(),
+                                          gru.bias_hh.detach().data_ptr())  # fmt: skip
+        a.ws_aggr, a.ws_h, a.ws_gi, a.ws_gh = base, base + 4 * R * W, base + 4 * R * (W + M), base + 4 * R * (W + 4 * M)
+        a.out_mem, a.out_lu, a.assoc, a.stamp = out.data_ptr(), new_lu.data_ptr(), _native.ptr(assoc), stamp
+        _native.check(lib.tgmx_tgn_memory_forward(a, _native.stream_ptr()), 'tgmx_tgn_memory_forward')
         return out, new_lu
 
     def _updated_train(self, nodes: Tensor, assoc: Optional[Tensor] = None, stamp: int = 0) -> Tuple[Tensor, Tensor]:
@@ -480,7 +506,8 @@ class TransformerConv(nn.Module):
 
     def forward(self, x: Tensor, edge_index: Tensor, edge_attr: Tensor) -> Tensor:
         lib = _native.load()
-        if torch.is_grad_enabled() and (x.requires_grad or edge_attr.requires_grad or any(p.requires_grad for p in self.parameters())):
+        if torch.is_grad_enabled() and (x.requires_grad or (edge_attr is not None and edge_attr.requires_grad) or any(p.requires_grad for p in self.parameters())):
+            self._edge_ctx = None
             return self._forward_train(x, edge_index, edge_attr)
         x = _ops._f32c(x, 'x')
         dev, U, H, C = x.device, x.shape[0], self.heads, self.out_channels
@@ -489,9 +516,34 @@ class TransformerConv(nn.Module):
         # query / key / value / skip projections of the same x: ONE batched launch over the stacked weights
         W4, b4 = self._stacked_projections()
         qkvs = torch.empty((4, U, HC), **f32)
+        E = edge_index.shape[1]
+        drop = self._dropout_site()
+        if drop[0] == 0.0 and getattr(self, '_edge_ctx', None) is not None and E:
+            # GraphAttentionEmbedding handed the raw edge inputs over: the whole layer is one native call (tgmx_tconv_forward)
+            lu, t, msg, tw, tb, T = self._edge_ctx
+            self._edge_ctx = None
+            D = msg.shape[1]
+            src, tgt = edge_index[0].contiguous(), edge_index[1].contiguous()
+            need = int(lib.tgmx_segment_sort_workspace_bytes(E))
+            wsd = getattr(self, '_seg_ws', None)
+            if wsd is None or wsd[0].device != dev or wsd[0].numel() < need:
+                wsd = self._seg_ws = (torch.empty(need, dtype=torch.uint8, device=dev), torch.zeros(1, dtype=torch.int32, device=dev))
+            fl = torch.empty(E * (T + D + HC), **f32)  # edge_attr [E, T + D] | eproj [E, HC]
+            ints = torch.empty(E + 2 * U, dtype=torch.int64, device=dev)  # order [E] | seg_lo [U] | seg_hi [U]
+            a = getattr(self, '_fwd_args', None)
+            if a is None:
+                a = self._fwd_args = _native.TconvFwd()
+            a.x, a.U, a.in_ch, a.last_update_local = x.data_ptr(), U, x.shape[1], lu.data_ptr()
+            a.src, a.tgt, a.t, a.msg, a.E, a.D, a.T = src.data_ptr(), tgt.data_ptr(), t.data_ptr(), msg.data_ptr(), E, D, T
+            a.tw, a.tb, a.W4, a.b4, a.W_edge, a.H, a.C = tw.data_ptr(), tb.data_ptr(), W4.data_ptr(), b4.data_ptr(), self.lin_edge.weight.detach().data_ptr(), H, C
+            a.edge_attr, a.qkvs, a.eproj = fl.data_ptr(), qkvs.data_ptr(), fl.data_ptr() + 4 * E * (T + D)
+            a.order, a.seg_lo, a.seg_hi = ints.data_ptr(), ints.data_ptr() + 8 * E, ints.data_ptr() + 8 * (E + U)
+            a.sort_ws, a.sort_ws_bytes, a.status = wsd[0].data_ptr(), wsd[0].numel(), wsd[1].data_ptr()
+            _native.check(lib.tgmx_tconv_forward(a, _native.stream_ptr()), 'tgmx_tconv_forward')
+            return qkvs[3]
+        self._edge_ctx = None
         _ops.sgemm_nt(x, W4[0], qkvs[0], bias=b4, batch=4, sA=0, sB=W4.stride(0), sC=U * HC)
         q, k, v, out = qkvs[0], qkvs[1], qkvs[2], qkvs[3]
-        E = edge_index.shape[1]
         if E:
             eproj = torch.empty((E, HC), **f32)
             _ops.sgemm_nt(_ops._f32c(edge_attr, 'edge_attr'), self.lin_edge.weight.detach(), eproj)
@@ -500,7 +552,7 @@ class TransformerConv(nn.Module):
             _native.check(
                 lib.tgmx_tconv_attend(q.data_ptr(), k.data_ptr(), v.data_ptr(), eproj.data_ptr(), order.data_ptr(), src.data_ptr(),
                                       seg_lo.data_ptr(), seg_hi.data_ptr(), U, H, C, float(C) ** -0.5, out.data_ptr(),
-                                      _native.dropout_desc(*self._dropout_site()), _native.stream_ptr()),
+                                      _native.dropout_desc(*drop), _native.stream_ptr()),
                 'tgmx_tconv_attend',
             )  # fmt: skip
         return out
@@ -551,12 +603,16 @@ class GraphAttentionEmbedding(nn.Module):
             edge_attr = EdgeAttrFn.apply(self.time_enc.w.weight, self.time_enc.w.bias, last_update.to(torch.int64).contiguous(),
                                          edge_index[0].contiguous(), t.to(torch.int64).contiguous(), msg)  # fmt: skip
             return self.conv(x, edge_index, edge_attr)
-        edge_attr = torch.empty((E, T + D), dtype=torch.float32, device=x.device)
         tw, tb = self.time_enc.w.weight.detach().reshape(-1), self.time_enc.w.bias.detach()
+        lu64, t64 = last_update.to(torch.int64).contiguous(), t.to(torch.int64).contiguous()
+        if E and not _COMPOSE_IN_PYTHON and not (self.conv.training and self.conv.dropout > 0):
+            # inference: edge encoding + TransformerConv as one native call; the conv picks the raw inputs up
+            self.conv._edge_ctx = (lu64, t64, msg, tw, tb, T)
+            return self.conv(x, edge_index, None)
+        edge_attr = torch.empty((E, T + D), dtype=torch.float32, device=x.device)
         _native.check(
-            lib.tgmx_tconv_edge_attr(last_update.to(torch.int64).contiguous().data_ptr(), edge_index[0].contiguous().data_ptr(),
-                                     t.to(torch.int64).contiguous().data_ptr(), msg.data_ptr(), tw.data_ptr(), tb.data_ptr(), T, D, E,
-                                     edge_attr.data_ptr(), _native.stream_ptr()),
+            lib.tgmx_tconv_edge_attr(lu64.data_ptr(), edge_index[0].contiguous().data_ptr(), t64.data_ptr(), msg.data_ptr(), tw.data_ptr(),
+                                     tb.data_ptr(), T, D, E, edge_attr.data_ptr(), _native.stream_ptr()),
             'tgmx_tconv_edge_attr',
         )  # fmt: skip
         return self.conv(x, edge_index, edge_attr)
