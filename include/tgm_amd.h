@@ -66,6 +66,7 @@ const char* tgmx_last_error(void);
 int tgmx_event_create(tgmx_event_t* ev);
 int tgmx_event_destroy(tgmx_event_t ev);
 int tgmx_event_elapsed_ms(tgmx_event_t start, tgmx_event_t stop, float* ms);
+int tgmx_event_synchronize(tgmx_event_t ev); /* host wait until the work recorded before `ev` is done */
 
 /* ------------------------------------------------------------------------
  * k-most-recent neighbor lookup over a static per-node index (CSR).
@@ -248,8 +249,29 @@ typedef struct tgmx_pipeline_out {
   tgmx_event_t ev_start, ev_stop;
 } tgmx_pipeline_out_t;
 
+/* Optional tail of the chain, for the TGN loop: DeduplicationHook (tgm/hooks/dedup.py:35-67) over [batch src | batch dst |
+ * negatives | every hop's neighbor ids] and the sampled edge list of one hop (tgmx_tgn_edge_list), enqueued behind the sampler
+ * in the same call; the three sizes the host must learn (unique count, dedup status, edge count) are copied to pinned host
+ * memory asynchronously and `sizes_ready` is recorded behind the copy. */
+typedef struct tgmx_pipeline_post {
+  int32_t dedup;               /* 1: unique ids */
+  int32_t dedup_neg, dedup_nbr;/* include the negatives / the sampled neighbor ids */
+  int32_t num_nodes;
+  void* dedup_ws;              /* tgmx_unique_ids workspace (zero at first use) */
+  int32_t* uniq_out;           /* [min(total ids, num_nodes)] */
+  int32_t edge_hop;            /* -1: no edge list */
+  int64_t edge_cap;            /* >= rows * k of that hop */
+  int64_t* row_off;            /* [rows + 1] scratch */
+  int64_t* edge_index;         /* [2, edge_cap] */
+  int64_t* edge_t;             /* [edge_cap] */
+  float* edge_x;               /* [edge_cap, D] */
+  int64_t* dev_sizes;          /* device [3]: unique count | status (low word) | edge count; status word zero at first use */
+  int64_t* host_sizes;         /* pinned host [3] */
+  tgmx_event_t sizes_ready;
+} tgmx_pipeline_post_t;
+
 int tgmx_pipeline_step(const tgmx_pipeline_t* pipe, int64_t edge_lo, int64_t n_edges, uint64_t neg_call,
-                       const tgmx_pipeline_out_t* out, tgmx_stream_t stream);
+                       const tgmx_pipeline_out_t* out, const tgmx_pipeline_post_t* post /* NULL: none */, tgmx_stream_t stream);
 
 /* DGStorageArrayBackend._binary_search (tgm/core/_storage/backends/array_backend.py:301-321): event index range
  * [*lb, *ub) of the slice {start_time <= t <= end_time (inclusive; has_* = 0: unbounded), start_idx <= i < end_idx

@@ -119,15 +119,16 @@ def test_lowered_chain_vs_oracle_and_pool_recycling():
 
 
 def test_hooks_behind_the_lowered_prefix_still_run():
+    """A hook the native step does not cover (here: a DeduplicationHook with an id suffix) runs as usual behind the lowered prefix."""
     from tgm_amd.hooks import DeduplicationHook
 
     st = _stream(E=3000, D=8)
-    hm_a, _, plain = _build(st, 128, [5], 'ring', 0, extra=[DeduplicationHook(seed_nodes_keys=['neg', 'nbr_nids'])])
-    hm_b, _, pooled = _build(st, 128, [5], 'ring', 2, extra=[DeduplicationHook(seed_nodes_keys=['neg', 'nbr_nids'])])
+    hm_a, _, plain = _build(st, 128, [5], 'ring', 0, extra=[DeduplicationHook(seed_nodes_keys=['neg', 'nbr_nids'], id='t')])
+    hm_b, _, pooled = _build(st, 128, [5], 'ring', 2, extra=[DeduplicationHook(seed_nodes_keys=['neg', 'nbr_nids'], id='t')])
     with hm_a.activate('k'), hm_b.activate('k'):
         for ba, bb in zip(plain, pooled):
-            _same(ba.unique_nids, bb.unique_nids, 'unique_nids')
-            _same(ba.global_to_local(ba.edge_src), bb.global_to_local(bb.edge_src), 'global_to_local')
+            _same(ba.unique_nids_t, bb.unique_nids_t, 'unique_nids')
+            _same(ba.global_to_local_t(ba.edge_src), bb.global_to_local_t(bb.edge_src), 'global_to_local')
         assert pooled._compiled[1].n_lowered == 2
 
 
@@ -208,3 +209,55 @@ def test_masks_are_fresh_tensors_per_batch():
         b1 = next(it)
         assert torch.equal(b1.seed_node_nbr_mask['edge_dst'].cpu(), torch.arange(100, 200))
         assert torch.equal(b1.seed_node_nbr_mask['neg'].cpu(), torch.arange(200, 300))
+
+
+def test_negatives_not_used_as_seeds_are_not_lowered():
+    """A negative hook whose ids the sampler does not seed from cannot ride in the lowered step (the ids are drawn in the seed
+    fetch): the chain then runs hook by hook, and `neg` is still produced."""
+    from tgm_amd import DGData, DGDataLoader, DGraph
+    from tgm_amd.hooks import HookManager, RandomNegativeEdgeSamplerHook, RecencyNeighborHook
+
+    st = _stream(E=800, D=4)
+    dg = DGraph(DGData.from_raw(st.ts, torch.stack([st.src, st.dst], 1), st.edge_x), device=DEV)
+    hm = HookManager(keys=['k'])
+    hm.register('k', RandomNegativeEdgeSamplerHook(int(st.dst.min()), st.num_nodes, seed=1))
+    hm.register('k', RecencyNeighborHook(st.num_nodes, [3], ['edge_src', 'edge_dst'], ['edge_time', 'edge_time'], validate='deferred'))
+    loader = DGDataLoader(dg, batch_size=100, hook_manager=hm, output_pool=2)
+    with hm.activate('k'):
+        b = next(iter(loader))
+        assert loader._compiled[1] is None
+        assert b.neg.shape == (100,) and int(b.neg.min()) >= int(st.dst.min()) and b.seed_nids[0].shape == (200,)
+
+
+def test_lowered_tgn_tail_dedup_and_edge_list():
+    """The chain negatives -> sampler -> DeduplicationHook -> SampledEdgeListHook as ONE tgmx_pipeline_step (post block): every
+    tensor equals the hook-by-hook chain's, with and without the loader running a batch ahead, for hop 0 of a two-hop sampler
+    and with the neighbor ids of both hops deduplicated."""
+    from tgm_amd import DGData, DGDataLoader, DGraph
+    from tgm_amd.hooks import DeduplicationHook, HookManager, RandomNegativeEdgeSamplerHook, RecencyNeighborHook, SampledEdgeListHook
+
+    st = _stream(E=4000, D=8, shape='review', n_src=400, n_dst=80)
+    dg = DGraph(DGData.from_raw(st.ts, torch.stack([st.src, st.dst], 1), st.edge_x), device=DEV)
+
+    def chain():
+        hm = HookManager(keys=['k'])
+        hm.register('k', RandomNegativeEdgeSamplerHook(400, st.num_nodes, seed=9))
+        hm.register('k', RecencyNeighborHook(st.num_nodes, [6, 3], ['edge_src', 'edge_dst', 'neg'], ['edge_time', 'edge_time', 'neg_time'], validate='deferred'))
+        hm.register('k', DeduplicationHook(seed_nodes_keys=['neg', 'nbr_nids']))
+        hm.register('k', SampledEdgeListHook(hop=0))
+        return hm
+
+    hm_a, hm_b, hm_c = chain(), chain(), chain()
+    plain = DGDataLoader(dg, batch_size=256, hook_manager=hm_a)
+    pooled = DGDataLoader(dg, batch_size=256, hook_manager=hm_b, output_pool=1)
+    ahead = DGDataLoader(dg, batch_size=256, hook_manager=hm_c, output_pool=3, prefetch=2)
+    names = ('neg', 'unique_nids', 'sampled_edge_index', 'sampled_edge_time', 'sampled_edge_x')
+    with hm_a.activate('k'), hm_b.activate('k'), hm_c.activate('k'):
+        for n, (a, b, c) in enumerate(zip(plain, pooled, ahead)):
+            for other in (b, c):
+                for name in names:
+                    _same(getattr(a, name), getattr(other, name), f'batch {n} {name}')
+                _same(a.nbr_nids, other.nbr_nids, f'batch {n} nbr_nids')
+                _same(a.global_to_local(a.edge_dst), other.global_to_local(other.edge_dst), 'global_to_local')
+        assert n == 15
+        assert pooled._compiled[1].n_lowered == 4 and ahead._compiled[1].n_lowered == 4

@@ -152,6 +152,16 @@ class RecencyStep(ctypes.Structure):
     ]  # fmt: skip
 
 
+class PipelinePost(ctypes.Structure):
+    """tgmx_pipeline_post_t (include/tgm_amd.h)."""
+
+    _fields_ = [
+        ('dedup', c_int32), ('dedup_neg', c_int32), ('dedup_nbr', c_int32), ('num_nodes', c_int32), ('dedup_ws', c_void_p), ('uniq_out', c_void_p),
+        ('edge_hop', c_int32), ('edge_cap', c_int64), ('row_off', c_void_p), ('edge_index', c_void_p), ('edge_t', c_void_p), ('edge_x', c_void_p),
+        ('dev_sizes', c_void_p), ('host_sizes', c_void_p), ('sizes_ready', c_void_p),
+    ]  # fmt: skip
+
+
 class TgnMemoryFwd(ctypes.Structure):
     """tgmx_tgn_memory_fwd_t (include/tgm_amd.h)."""
 
@@ -217,7 +227,8 @@ SIGNATURES['tgmx_csr_build_workspace_bytes'] = (c_size_t, [c_int64, c_int32, c_i
 SIGNATURES['tgmx_csr_build'] = (c_int32, [_P, _P, _P, c_int64, c_int32, _P, c_int64, c_int32, _P, _P, _P, c_size_t, _P, _P])
 SIGNATURES['tgmx_recency_step'] = (c_int32, [ctypes.POINTER(RecencyStep), _P])
 SIGNATURES['tgmx_recency_step_plan'] = (c_int32, [ctypes.POINTER(RecencyStep)])
-SIGNATURES['tgmx_pipeline_step'] = (c_int32, [ctypes.POINTER(Pipeline), c_int64, c_int64, ctypes.c_uint64, ctypes.POINTER(PipelineOut), _P])
+SIGNATURES['tgmx_pipeline_step'] = (c_int32, [ctypes.POINTER(Pipeline), c_int64, c_int64, ctypes.c_uint64, ctypes.POINTER(PipelineOut), ctypes.POINTER(PipelinePost), _P])
+SIGNATURES['tgmx_event_synchronize'] = (c_int32, [_P])
 SIGNATURES['tgmx_slice'] = (c_int32, [_P, c_int64, c_int32, c_int64, c_int32, c_int64, c_int64, c_int64, ctypes.POINTER(c_int64), ctypes.POINTER(c_int64)])
 SIGNATURES['tgmx_discretize_workspace_bytes'] = (c_size_t, [c_int64])
 SIGNATURES['tgmx_discretize_keep'] = (c_int32, [_P, _P, _P, c_int64, ctypes.c_double, _P, _P, _P, _P, c_size_t, _P])

@@ -30,10 +30,20 @@ extern "C" size_t tgmx_abi_sizeof(int32_t which) {
     case 8: return sizeof(tgmx_dropout_t);
     case 9: return sizeof(tgmx_tgn_memory_fwd_t);
     case 10: return sizeof(tgmx_tconv_fwd_t);
+    case 11: return sizeof(tgmx_pipeline_post_t);
     default: return 0;
   }
 }
 extern "C" const char* tgmx_last_error(void) { return tgmx::g_err; }
+
+extern "C" int tgmx_event_synchronize(tgmx_event_t ev) {
+  TGMX_REQUIRE(ev, "event_synchronize: null event");
+  if (hipEventSynchronize((hipEvent_t)ev) != hipSuccess) {
+    tgmx::set_error("event_synchronize: hipEventSynchronize failed");
+    return TGMX_E_LAUNCH;
+  }
+  return TGMX_OK;
+}
 
 extern "C" int tgmx_event_create(tgmx_event_t* ev) {
   TGMX_REQUIRE(ev, "event_create: null pointer");

@@ -11,8 +11,44 @@
 
 using namespace tgmx;
 
+static int pipeline_post(const tgmx_pipeline_t* p, const tgmx_recency_step_t& s, int64_t edge_lo, int64_t n_edges, long long share,
+                         const tgmx_pipeline_out_t* out, const tgmx_pipeline_post_t* post, tgmx_stream_t stream) {
+  TGMX_REQUIRE(post->dev_sizes && post->host_sizes && post->sizes_ready, "pipeline_step: post block needs dev_sizes / host_sizes / sizes_ready");
+  long long rows[TGMX_MAX_HOPS + 1];  // rows[h] = seeds of hop h
+  rows[0] = share * p->n_roles;
+  for (int h = 0; h < s.n_hops; ++h) rows[h + 1] = rows[h] * s.k[h];
+  if (post->dedup) {
+    TGMX_REQUIRE(post->dedup_ws && post->uniq_out, "pipeline_step: null dedup buffer");
+    const int32_t* parts[16];
+    int64_t sizes[16];
+    int np = 0;
+    parts[np] = p->src + edge_lo; sizes[np++] = n_edges;
+    parts[np] = p->dst + edge_lo; sizes[np++] = n_edges;
+    if (post->dedup_neg && s.neg_out) { parts[np] = s.neg_out; sizes[np++] = share; }
+    if (post->dedup_nbr)
+      for (int h = 0; h < s.n_hops && np < 16; ++h) { parts[np] = s.out_nid[h]; sizes[np++] = rows[h + 1]; }
+    const int rc = tgmx_unique_ids(parts, sizes, np, post->num_nodes, post->dedup_ws, post->uniq_out, post->dev_sizes,
+                                   reinterpret_cast<int32_t*>(post->dev_sizes + 1), stream);
+    if (rc) return rc;
+  }
+  if (post->edge_hop >= 0) {
+    const int h = post->edge_hop;
+    TGMX_REQUIRE(post->dedup && h < s.n_hops, "pipeline_step: the edge list needs the unique ids and a sampled hop");
+    const int32_t* seeds = h == 0 ? out->seed_nid0 : s.out_nid[h - 1];
+    const int rc = tgmx_tgn_edge_list(seeds, s.out_nid[h], s.out_ts[h], s.out_x[h], rows[h], s.k[h], s.D, post->uniq_out, 0, post->dev_sizes,
+                                      post->edge_cap, post->row_off, post->edge_index, post->edge_t, post->edge_x, post->dev_sizes + 2, stream);
+    if (rc) return rc;
+  }
+  if (hipMemcpyAsync(post->host_sizes, post->dev_sizes, 3 * sizeof(int64_t), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
+      hipEventRecord((hipEvent_t)post->sizes_ready, (hipStream_t)stream) != hipSuccess) {
+    set_error("pipeline_step: size read-back failed");
+    return TGMX_E_LAUNCH;
+  }
+  return TGMX_OK;
+}
+
 extern "C" int tgmx_pipeline_step(const tgmx_pipeline_t* p, int64_t edge_lo, int64_t n_edges, uint64_t neg_call,
-                                  const tgmx_pipeline_out_t* out, tgmx_stream_t stream) {
+                                  const tgmx_pipeline_out_t* out, const tgmx_pipeline_post_t* post, tgmx_stream_t stream) {
   TGMX_REQUIRE(p && out, "pipeline_step: null argument block");
   TGMX_REQUIRE(p->src && p->dst && p->ts && p->num_edges >= 0, "pipeline_step: null stream pointer");
   TGMX_REQUIRE(edge_lo >= 0 && n_edges >= 0 && edge_lo + n_edges <= p->num_edges, "pipeline_step: edges [%lld, +%lld) outside the store (%lld)",
@@ -68,7 +104,9 @@ extern "C" int tgmx_pipeline_step(const tgmx_pipeline_t* p, int64_t edge_lo, int
     // no seeds: the reference emits empties and SKIPS the update (recency.py:127-139)
     return TGMX_OK;
   }
-  return tgmx_recency_step(&s, stream);
+  const int rc = tgmx_recency_step(&s, stream);
+  if (rc || !post) return rc;
+  return pipeline_post(p, s, edge_lo, n_edges, share, out, post, stream);
 }
 
 extern "C" int tgmx_slice(const int64_t* t, int64_t n, int32_t has_start_time, int64_t start_time, int32_t has_end_time,

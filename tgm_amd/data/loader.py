@@ -60,6 +60,8 @@ class DGDataLoader:
         # hooks that must learn an output size from the device (DeduplicationHook, SampledEdgeListHook) find it waiting instead
         # of stalling the stream.  Hook state (sampler rings) does not depend on what the consumer does with a batch.
         self._prefetch = int(prefetch)
+        if not 0 <= self._prefetch <= 2:
+            raise ValueError(f'prefetch must be 0, 1 or 2 (hooks keep 4 size mirrors in flight), got {prefetch}')
         if self._prefetch and 0 < self._output_pool <= self._prefetch:
             raise ValueError(f'prefetch={prefetch} keeps {prefetch + 1} batches alive: output_pool must be 0 (fresh tensors) or > prefetch')
         self._compiled = None  # (hook list identity, CompiledPipeline or None)
@@ -141,9 +143,10 @@ class DGDataLoader:
                     batch.edge_type = arr.edge_type.narrow(0, lo, n)
         else:
             batch = view.materialize()
-        if not pipe.step(lo, n, batch):
-            return None
         batch.__dict__['_deferred'] = deferred
+        if not pipe.step(lo, n, batch):
+            batch.__dict__['_deferred'] = False
+            return None
         rest = hooks[pipe.n_lowered :] if pipe.n_lowered < len(hooks) else None
         if rest:
             if view is None:

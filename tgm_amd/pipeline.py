@@ -5,7 +5,7 @@ At the headline shape a batch is ~40 us of kernels; walking the chain in Python
 allocation per output) costs more than that on the host, so the GPU idles.
 ``DGDataLoader(..., output_pool=R)`` asks for the chain's lowerable prefix
 
-    [EdgeShardHook] -> [RandomNegativeEdgeSamplerHook] -> RecencyNeighborHook
+    [EdgeShardHook] -> [RandomNegativeEdgeSamplerHook] -> RecencyNeighborHook -> [DeduplicationHook -> [SampledEdgeListHook]]
 
 to run as one ``tgmx_pipeline_step`` (``include/tgm_amd.h``; it restates
 tgm/data/loader.py:158-170 + tgm/hooks/hook_manager.py:139-168 for that chain)
@@ -30,6 +30,8 @@ import torch
 from . import _native
 from .core import DGBatch, DGraph
 from .dist import EdgeShardHook, shard_bounds
+from .hooks.dedup import DeduplicationHook
+from .hooks.edge_list import SampledEdgeListHook
 from .hooks.negatives import RandomNegativeEdgeSamplerHook
 from .hooks.recency import RecencyNeighborHook
 
@@ -42,13 +44,16 @@ _ROLE_KEYS = {
 class _Slot:
     """One preallocated output set + its filled ``tgmx_pipeline_out_t`` + the attributes it puts on a batch."""
 
-    __slots__ = ('out', 'attrs', 'tensors', 'nbr_nids')
+    __slots__ = ('out', 'attrs', 'tensors', 'nbr_nids', 'post', 'post_bufs')
 
 
 class CompiledPipeline:
     def __init__(self, dg: DGraph, shard: Optional[EdgeShardHook], neg: Optional[RandomNegativeEdgeSamplerHook],
-                 nbr: RecencyNeighborHook, n_lowered: int, pool: int) -> None:  # fmt: skip
+                 nbr: RecencyNeighborHook, n_lowered: int, pool: int, dedup: Optional[DeduplicationHook] = None,
+                 edges: Optional[SampledEdgeListHook] = None) -> None:  # fmt: skip
         self.n_lowered = n_lowered  # hooks of the chain this object replaces
+        self._dedup, self._edges = dedup, edges
+        self._dedup_ws = None
         self._dg, self._shard, self._neg, self._nbr = dg, shard, neg, nbr
         self._R = max(1, int(pool))
         self._pools: Dict[int, List[_Slot]] = {}
@@ -87,10 +92,23 @@ class CompiledPipeline:
             and len(nbr._num_nbrs) <= _native.MAX_HOPS
             and 1 <= len(nbr._seed_nodes_keys) <= _native.MAX_SEED_GROUPS
             and all(k in keys and keys[k][1] == t for k, t in zip(nbr._seed_nodes_keys, nbr._seed_times_keys))
-            and (neg is not None or 'neg' not in nbr._seed_nodes_keys)
+            and (neg is not None) == ('neg' in nbr._seed_nodes_keys)  # negatives only exist as a seed role of the lowered step
             and nbr._seed_nodes_keys.count('neg') <= 1
         )
-        return CompiledPipeline(dg, shard, neg, nbr, i + 1, pool) if ok else None
+        if not ok:
+            return None
+        i += 1
+        # the TGN tail: unique ids over [src | dst | neg | sampled neighbors], then the compact edge list of one hop
+        dedup = edges = None
+        if i < len(hooks) and type(hooks[i]) is DeduplicationHook and hooks[i]._id is None:
+            extra = set(hooks[i].seed_keys or [])
+            if extra <= {'neg', 'nbr_nids'} and ('neg' not in extra or neg is not None) and len(nbr._num_nbrs) + 3 <= 16:
+                dedup = hooks[i]
+                i += 1
+                if i < len(hooks) and type(hooks[i]) is SampledEdgeListHook and hooks[i]._id is None and hooks[i].hop < len(nbr._num_nbrs):
+                    edges = hooks[i]
+                    i += 1
+        return CompiledPipeline(dg, shard, neg, nbr, i, pool, dedup, edges)
 
     def _bind(self) -> None:
         """(Re)build the native argument block from the hooks' current state."""
@@ -154,9 +172,64 @@ class CompiledPipeline:
             attrs.update(seed_nids=seed_n, seed_times=seed_ts, nbr_nids=nbr_n, nbr_edge_time=nbr_t, nbr_edge_x=nbr_x,
                          seed_node_nbr_mask={k: whole.narrow(0, o, share) for k, o in offsets.items()})  # fmt: skip
             sl.out, sl.attrs, sl.nbr_nids = out, attrs, nbr_n
+            sl.post = sl.post_bufs = None
+            if self._dedup is not None:
+                sl.post, sl.post_bufs = self._make_post(n, share, nbr_n, dev)
             slots.append(sl)
         self._pools[n] = slots
         return slots
+
+    def _make_post(self, n: int, share: int, nbr_n, dev):
+        """tgmx_pipeline_post_t of one slot: unique-id and edge-list buffers, the size mirror in pinned memory, its event."""
+        nbr = self._nbr
+        N = int(self._dg._storage.num_nodes_global)
+        extra = set(self._dedup.seed_keys or [])
+        total = 2 * n + (share if 'neg' in extra else 0) + (sum(t.numel() for t in nbr_n) if 'nbr_nids' in extra else 0)
+        if self._dedup_ws is None:
+            need = int(self._lib.tgmx_unique_ids_workspace_bytes(N))
+            self._dedup_ws = torch.zeros(need, dtype=torch.uint8, device=dev)  # zeros: the bitmap cleans itself
+        uniq = torch.empty(max(min(total, N), 1), dtype=torch.int32, device=dev)
+        dev_sizes = torch.zeros(3, dtype=torch.int64, device=dev)
+        pin = torch.zeros(3, dtype=torch.int64).pin_memory()
+        ev = ctypes.c_void_p()
+        _native.check(self._lib.tgmx_event_create(ctypes.byref(ev)), 'tgmx_event_create')
+        post = _native.PipelinePost()
+        post.dedup, post.dedup_neg, post.dedup_nbr, post.num_nodes = 1, int('neg' in extra), int('nbr_nids' in extra), N
+        post.dedup_ws, post.uniq_out = self._dedup_ws.data_ptr(), uniq.data_ptr()
+        post.edge_hop = -1
+        ei = et = ex = ro = None
+        if self._edges is not None:
+            h = self._edges.hop
+            S, k = nbr_n[h].shape
+            D = nbr._edge_x_dim
+            cap = max(S * k, 1)
+            ei = torch.empty((2, cap), dtype=torch.int64, device=dev)
+            et = torch.empty(cap, dtype=torch.int64, device=dev)
+            ex = torch.empty((cap, D), dtype=torch.float32, device=dev)
+            ro = torch.empty(S + 1, dtype=torch.int64, device=dev)
+            post.edge_hop, post.edge_cap = h, cap
+            post.row_off, post.edge_index, post.edge_t, post.edge_x = ro.data_ptr(), ei.data_ptr(), et.data_ptr(), ex.data_ptr()
+        post.dev_sizes, post.host_sizes, post.sizes_ready = dev_sizes.data_ptr(), pin.data_ptr(), ev.value
+        return post, (uniq, dev_sizes, pin, ev.value, ei, et, ex, ro, N)
+
+    def _defer_post(self, batch: DGBatch, slot: _Slot) -> None:
+        uniq, dev_sizes, pin, ev, ei, et, ex, _, N = slot.post_bufs
+        dedup, edges, lib = self._dedup, self._edges, self._lib
+        batch.__dict__['_unique_dev'] = (uniq, dev_sizes[0:1])
+
+        def finish() -> None:
+            _native.check(lib.tgmx_event_synchronize(ev), 'tgmx_event_synchronize')  # the only wait: three sizes
+            cnt, st, E = pin.tolist()
+            if st & 0xFFFFFFFF:
+                dev_sizes[1].zero_()
+                raise ValueError(f'node ids must satisfy 0 <= x < {N} (or -1 for a padded neighbor slot)')
+            dedup._publish(batch, uniq[:cnt])
+            if edges is not None:
+                edges.add_batch_attribute(batch, 'sampled_edge_index', ei[:, :E])
+                edges.add_batch_attribute(batch, 'sampled_edge_time', et[:E])
+                edges.add_batch_attribute(batch, 'sampled_edge_x', ex[:E])
+
+        batch._defer(finish)
 
     # -- per batch ----------------------------------------------------------------
     def step(self, lo: int, n: int, batch: DGBatch) -> bool:
@@ -174,6 +247,8 @@ class CompiledPipeline:
             return False
         slots = self._pools.get(n)
         if slots is None:
+            if len(self._pools) >= 8:  # time-unit batching: every batch may have its own size -- keep the 8 most recent shapes
+                self._pools.pop(next(iter(self._pools)))
             slots = self._make_pool(n)
         turn = self._turn
         self._turn = turn + 1
@@ -203,7 +278,7 @@ class CompiledPipeline:
         if nbr.profile_hop is not None and nbr._calls % nbr.profile_every == 0 and nbr.profile_pool:
             timer = nbr.profile_pool.pop()
             out.timed_hop, out.ev_start, out.ev_stop = nbr.profile_hop, timer.start, timer.stop
-        rc = self._lib.tgmx_pipeline_step(pipe, lo, n, call, out, _native.stream_ptr(self._device.index))
+        rc = self._lib.tgmx_pipeline_step(pipe, lo, n, call, out, slot.post, _native.stream_ptr(self._device.index))
         if rc:
             _native.check(rc, 'tgmx_pipeline_step')
         if timer is not None:
@@ -217,6 +292,8 @@ class CompiledPipeline:
             d['shard_time'] = arr.ts.narrow(0, lo + s_lo, s_hi - s_lo)
             d['shard_lo'] = s_lo
         d.update(slot.attrs)
+        if slot.post is not None:
+            self._defer_post(batch, slot)
         return True
 
     def _log_timed(self, timer, slot: _Slot) -> None:
