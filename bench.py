@@ -91,7 +91,7 @@ def build_pipeline(stream, rank, world, global_bs, num_nbrs, mode, device, pool=
         stream.num_nodes, num_nbrs, keys, tkeys, mode=mode, validate=validate, batch_size=global_bs if mode == 'csr' else None
     )
     hm.register('bench', hook)
-    loader = DGDataLoader(dg, batch_size=global_bs, hook_manager=hm, output_pool=pool if validate != 'sync' else 0)
+    loader = DGDataLoader(dg, batch_size=global_bs, hook_manager=hm, output_pool=pool)
     return dg, hm, hook, loader
 
 
@@ -322,7 +322,7 @@ def main():
     kernel_name = ('recency_lookup_fused01_kernel (hop 0 + hop 1 in one launch: ' if fused else f'recency_lookup_kernel (hop {last_hop}: ') + \
         ' + '.join(f'{seeds} seeds x k={k}' for seeds, k in shape) + ')'
 
-    lowered = args.pool > 0 and args.validate != 'sync'
+    lowered = args.pool > 0
     out = {
         'metric': 'sampled-edges/sec (TGAT 2-hop k=20 recency sampler, tgbl-wiki synthetic)' if args.workload == 'wiki'
         else f'sampled-edges/sec (recency sampler, tgbl-{args.workload} synthetic)',

@@ -196,6 +196,10 @@ typedef struct tgmx_recency_step {
   uint64_t neg_seed, neg_call;
   int32_t* neg_out;
   int64_t* neg_time_out;
+  /* != 0: if the lookups of this call flag a bad hop-0 seed (TGMX_ST_SEED_RANGE / _TIME), the update of the same call leaves
+   * rings and write_pos untouched -- the reference validates the seeds before it changes anything (recency.py:173-237), so a
+   * caller that raises on the status word after the call (validate='sync') sees unchanged state, with ONE read-back. */
+  int32_t guard_seed_errors;
 } tgmx_recency_step_t;
 
 int tgmx_recency_step(const tgmx_recency_step_t* step, tgmx_stream_t stream);

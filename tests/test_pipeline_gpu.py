@@ -132,27 +132,60 @@ def test_hooks_behind_the_lowered_prefix_still_run():
         assert pooled._compiled[1].n_lowered == 2
 
 
-def test_sync_validation_is_not_lowered_and_bad_seeds_raise_in_deferred_mode():
+def test_sync_validation_is_lowered_too_and_raises_per_batch():
+    """validate='sync' (the hook's default, the reference's raise-per-call behaviour) through the lowered chain: same tensors
+    as hook by hook, one status read per batch."""
     from tgm_amd import DGData, DGDataLoader, DGraph
     from tgm_amd.hooks import HookManager, RecencyNeighborHook
 
     st = _stream(E=600, D=4)
     dg = DGraph(DGData.from_raw(st.ts, torch.stack([st.src, st.dst], 1), st.edge_x), device=DEV)
-    hm = HookManager(keys=['k'])
-    hm.register('k', RecencyNeighborHook(st.num_nodes, [3], ['edge_src', 'edge_dst'], ['edge_time', 'edge_time']))  # validate='sync'
-    loader = DGDataLoader(dg, batch_size=100, hook_manager=hm, output_pool=2)
-    with hm.activate('k'):
-        next(iter(loader))
-        assert loader._compiled[1] is None  # the default mode keeps the reference's raise-per-call behaviour
-    # deferred validation through the lowered path: num_nodes too small for the stream's ids
-    hm2 = HookManager(keys=['k'])
-    bad = RecencyNeighborHook(10, [3], ['edge_src', 'edge_dst'], ['edge_time', 'edge_time'], validate='deferred', mode='csr', batch_size=100)
-    hm2.register('k', bad)
-    # (the static index build itself validates endpoints)
-    with hm2.activate('k'), pytest.raises(ValueError):
-        for _ in DGDataLoader(dg, batch_size=100, hook_manager=hm2, output_pool=2):
-            pass
-        bad.check()
+    outs = []
+    for pool in (0, 2):
+        hm = HookManager(keys=['k'])
+        hm.register('k', RecencyNeighborHook(st.num_nodes, [3], ['edge_src', 'edge_dst'], ['edge_time', 'edge_time']))  # validate='sync'
+        loader = DGDataLoader(dg, batch_size=100, hook_manager=hm, output_pool=pool)
+        with hm.activate('k'):
+            outs.append([(b.nbr_nids[0].clone(), b.nbr_edge_x[0].clone()) for b in loader])
+            assert (loader._compiled is not None and loader._compiled[1] is not None) == (pool > 0)
+    _same(outs[0], outs[1], 'sync mode, lowered vs hook by hook')
+    # a hook built for too few nodes: the stream's ids are out of range -> ValueError at the first batch, in both paths
+    for pool in (0, 2):
+        hm2 = HookManager(keys=['k'])
+        hm2.register('k', RecencyNeighborHook(10, [3], ['edge_src', 'edge_dst'], ['edge_time', 'edge_time']))
+        with hm2.activate('k'), pytest.raises(ValueError):
+            next(iter(DGDataLoader(dg, batch_size=100, hook_manager=hm2, output_pool=pool)))
+
+
+@pytest.mark.parametrize('bs', [100, 800, 2600])  # update plans: rider + commit (m = 200), chunked placement (m = 1600), radix sort (m = 5200)
+@pytest.mark.parametrize('validate', ['sync', 'deferred'])
+def test_bad_seeds_leave_the_rings_untouched(bs, validate):
+    """The reference validates the seeds before it changes anything (recency.py:173-237 runs before _update).  Here lookups and
+    update are ONE call; when the lookups flag a seed, every kernel that writes ring state returns untouched (guard_seed_errors)."""
+    from tgm_amd import DGData, DGraph
+    from tgm_amd.hooks import RecencyNeighborHook
+
+    st = _stream(E=3 * bs + 50, D=8)
+    dg = DGraph(DGData.from_raw(st.ts, torch.stack([st.src, st.dst], 1), st.edge_x), device=DEV)
+    hook = RecencyNeighborHook(st.num_nodes, [4, 2], ['edge_src', 'extra'], ['edge_time', 'extra_t'], validate=validate)
+    good = lambda b: (setattr(b, 'extra', b.edge_dst.clone()), setattr(b, 'extra_t', b.edge_time.clone()))
+    for i in range(2):
+        b = dg.slice_events(i * bs, (i + 1) * bs).materialize()
+        good(b)
+        hook(dg, b)
+    hook.check()
+    before = (hook._ring.clone(), hook._write_pos.clone(), hook._ring_x.clone())
+    b = dg.slice_events(2 * bs, 3 * bs).materialize()
+    good(b)
+    b.extra[bs // 2] = st.num_nodes + 5  # one seed out of range
+    with pytest.raises(ValueError):
+        hook(dg, b)
+        hook.check()
+    assert torch.equal(hook._ring, before[0]) and torch.equal(hook._write_pos, before[1]) and torch.equal(hook._ring_x, before[2])
+    good(b)  # the same batch with valid seeds goes through and does change the state
+    hook(dg, b)
+    hook.check()
+    assert not torch.equal(hook._write_pos, before[1])
 
 
 def test_csr_mode_refuses_batches_off_the_indexed_schedule():

@@ -190,6 +190,8 @@ struct UpdateArgs {
   int sort_bits;        // large path: number of low key bits the radix sort looks at (64 = all)
   int32_t* barrier;  // 2 ints at the head of the caller's scratch: the riders' self-resetting barrier (count, generation)
   int32_t* status;
+  int guard_mask;    // != 0: kernels that write ring state return untouched when *status has one of these bits (bad seeds seen by
+                     // the lookups of the same call): the reference validates before it changes anything (recency.py:173-237)
   long long n, m, eid0;
   int B, N, D, key_wrap32;
 };
@@ -271,6 +273,10 @@ __device__ __forceinline__ void bitonic_select(long long& key, int& pay, long lo
   }
 }
 
+__device__ __forceinline__ bool update_blocked(const UpdateArgs& a) {
+  return a.guard_mask != 0 && (__hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & a.guard_mask) != 0;
+}
+
 __device__ __forceinline__ void commit_write_pos(int32_t* wp, int kept, int B) {
   const int old = atomicAdd(wp, kept);
   constexpr int kFold = 1 << 30;
@@ -313,6 +319,7 @@ __device__ __forceinline__ void update_block_body(const UpdateArgs& a, PlaceLds<
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nthr = blockDim.x, nwaves = nthr >> 6;
   const int P = nthr * E;  // power of two >= m; thread t owns sorted positions t*E .. t*E + E-1
+  const bool blocked = DEFER ? false : update_blocked(a);  // immediate writers only; deferred decisions are applied by a guarded commit
 
   for (int x = tid; x < H; x += nthr) {
     h_key[x] = -1;
@@ -468,12 +475,16 @@ __device__ __forceinline__ void update_block_body(const UpdateArgs& a, PlaceLds<
           rec.eid = a.eid0 >= 0 ? (int)(a.eid0 + i) : -1;
           rec.ts = t;
         }
-        if constexpr (!DEFER) a.ring[tgt[r]] = rec;
-        win = tgt[r];
+        if constexpr (!DEFER) {
+          if (!blocked) a.ring[tgt[r]] = rec;
+        }
+        win = blocked ? -1 : tgt[r];
       }
       if (p == st[r] + cnt[r] - 1) {  // the run's last entry commits the run (every write_pos read is behind a barrier)
         kept = cnt[r] > a.B ? a.B : cnt[r];
-        if constexpr (!DEFER) commit_write_pos(&a.write_pos[node[r]], kept, a.B);
+        if constexpr (!DEFER) {
+          if (!blocked) commit_write_pos(&a.write_pos[node[r]], kept, a.B);
+        }
       }
     }
     a.winner[p] = win;
@@ -871,7 +882,7 @@ __device__ __forceinline__ void tail_commit(const UpdateArgs& a, unsigned tb, un
   ok = ok_s != 0;
   if (!ok) {
     if (threadIdx.x == 0) atomicOr(a.status, TGMX_ST_SCRATCH);
-  } else if (p < a.m) {
+  } else if (p < a.m && !update_blocked(a)) {
     if (lane == 0) {
       if (row >= 0) {
         long long* dst = reinterpret_cast<long long*>(&a.ring[row]);
@@ -1614,6 +1625,10 @@ __global__ __launch_bounds__(256) void ring_update_place_kernel(const UpdateArgs
 __global__ __launch_bounds__(256) void ring_update_write_kernel(const UpdateArgs a) {
   const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= a.m) return;
+  if (update_blocked(a)) {
+    a.winner[p] = -1;  // nothing placed: the feature copy behind this launch has nothing to do
+    return;
+  }
   const int tgt = a.target[p];
   const int kept = a.winner[p];
   int win = -1;
@@ -1643,6 +1658,7 @@ template <bool COMMIT>
 __global__ __launch_bounds__(256) void ring_update_feat_kernel(const UpdateArgs a) {
   const long long p = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (p >= a.m) return;
+  if (COMMIT && update_blocked(a)) return;
   const int row = a.winner[p];
   if constexpr (COMMIT) {
     if (lane_id() == 0) {
@@ -2178,6 +2194,7 @@ extern "C" int tgmx_recency_step(const tgmx_recency_step_t* s, tgmx_stream_t str
                                     s->edge_x, s->n, s->eid0, s->directed, s->key_wrap32, s->scratch, s->status);
     if (rc) return rc;
     u.ts_bound = s->ts_bound;
+    u.guard_mask = s->guard_seed_errors ? (TGMX_ST_SEED_RANGE | TGMX_ST_SEED_TIME) : 0;
     static const bool no_ride = getenv("TGMX_NO_RIDE") != nullptr;  // A/B knob: the update as its own launches
     if (u.m <= kBlockMaxM && s->n_hops > 0 && S > 0 && !no_ride) side_chunks = set_chunk_scratch(u, s->scratch + kScratchHead);
     ride_place = side_chunks > 0 && u.m <= kRidePlaceMaxM && s->n_hops >= 2;

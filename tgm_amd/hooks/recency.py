@@ -454,24 +454,16 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
                 st.src, st.dst, st.ts, st.edge_x = src.data_ptr(), dst.data_ptr(), tt.data_ptr(), _native.ptr(ex)
                 st.eid0 = -1 if batch._edge_lo is None else int(batch._edge_lo)
 
+            # bad seeds must leave the state untouched (the reference validates before it changes anything): with
+            # guard_seed_errors the update of this very call skips its writes when the lookups flagged a seed, so one call and --
+            # in 'sync' mode -- ONE read-back per batch reproduce "raise, state unchanged"
+            st.n, st.n_hops = n_edges, L
+            st.guard_seed_errors = 1 if self._validate != 'off' else 0
+            rc = lib.tgmx_recency_step(st, stream)
+            if rc:
+                _native.check(rc, 'tgmx_recency_step')
             if self._validate == 'sync':
-                # bad seeds must leave the state untouched: lookups, host check, then the update
-                st.n, st.n_hops = 0, L
-                rc = lib.tgmx_recency_step(st, stream)
-                if rc:
-                    _native.check(rc, 'tgmx_recency_step')
                 self.check()
-                if n_edges:
-                    st.n, st.n_hops, st.n_groups, st.timed_hop = n_edges, 0, 0, -1
-                    rc = lib.tgmx_recency_step(st, stream)
-                    if rc:
-                        _native.check(rc, 'tgmx_recency_step')
-                    self.check()
-            else:
-                st.n, st.n_hops = n_edges, L
-                rc = lib.tgmx_recency_step(st, stream)
-                if rc:
-                    _native.check(rc, 'tgmx_recency_step')
             del keep
             if timer is not None:
                 # every hop the timed launch covers: (seed rows, k) and the number of valid neighbor slots per hop as a

@@ -88,7 +88,6 @@ class CompiledPipeline:
         keys = _ROLE_KEYS[shard is not None]
         ok = (
             nbr._id is None
-            and nbr._validate != 'sync'
             and len(nbr._num_nbrs) <= _native.MAX_HOPS
             and 1 <= len(nbr._seed_nodes_keys) <= _native.MAX_SEED_GROUPS
             and all(k in keys and keys[k][1] == t for k, t in zip(nbr._seed_nodes_keys, nbr._seed_times_keys))
@@ -129,6 +128,7 @@ class CompiledPipeline:
         p.update = 1 if nbr._mode == 'ring' else 0
         ctypes.memmove(ctypes.byref(p.step), ctypes.byref(nbr._step), ctypes.sizeof(_native.RecencyStep))
         p.step.n_hops = len(nbr._num_nbrs)
+        p.step.guard_seed_errors = 1 if nbr._validate != 'off' else 0
         self._pipe, self._step_ref = p, nbr._step
         self._scratch_ptr = nbr._step.scratch
 
@@ -284,6 +284,8 @@ class CompiledPipeline:
         if timer is not None:
             out.timed_hop = -1
             self._log_timed(timer, slot)
+        if nbr._validate == 'sync':
+            nbr.check()  # one device -> host read per batch: the reference's raise-per-call behaviour
         d = batch.__dict__
         if shard is not None:
             arr = self._arr

@@ -11,6 +11,7 @@ python bench.py                                              2>/dev/null | j > "
 python bench.py --steps 20 --warmup 5                        2>/dev/null | j > "$OUT/r02_bench_ring_driver_args.json"
 python bench.py --cpu-batches 0 --pool 0                     2>/dev/null | j > "$OUT/r02_bench_ring_hook_by_hook.json"
 python bench.py --cpu-batches 0 --pool 0 --validate sync     2>/dev/null | j > "$OUT/r02_bench_ring_default_sync_validation.json"
+python bench.py --cpu-batches 0 --validate sync              2>/dev/null | j > "$OUT/r02_bench_ring_sync_validation_lowered.json"
 python bench.py --cpu-batches 0 --pool 4                     2>/dev/null | j > "$OUT/r02_bench_ring_pool4.json"
 python bench.py --cpu-batches 0 --mode csr                   2>/dev/null | j > "$OUT/r02_bench_csr.json"
 python bench.py --cpu-batches 0 --workload review            2>/dev/null | j > "$OUT/r02_bench_review_ring.json"
