@@ -200,6 +200,10 @@ typedef struct tgmx_recency_step {
    * rings and write_pos untouched -- the reference validates the seeds before it changes anything (recency.py:173-237), so a
    * caller that raises on the status word after the call (validate='sync') sees unchanged state, with ONE read-back. */
   int32_t guard_seed_errors;
+  /* != 0: a promise that the batch's timestamps are non-decreasing (every batch of a chronological loader over the
+   * time-sorted store): the large-batch update then takes max(ts) from the last edge instead of a reduction launch.  Checked on
+   * the device: a violation is reported as TGMX_ST_TS_BOUND. */
+  int32_t sorted_ts;
 } tgmx_recency_step_t;
 
 int tgmx_recency_step(const tgmx_recency_step_t* step, tgmx_stream_t stream);

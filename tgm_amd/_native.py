@@ -149,7 +149,7 @@ class RecencyStep(ctypes.Structure):
         ('ts_bound', c_int64),
         ('neg_group', c_int32), ('neg_low', c_int32), ('neg_high', c_int32),
         ('neg_seed', ctypes.c_uint64), ('neg_call', ctypes.c_uint64), ('neg_out', c_void_p), ('neg_time_out', c_void_p),
-        ('guard_seed_errors', c_int32),
+        ('guard_seed_errors', c_int32), ('sorted_ts', c_int32),
     ]  # fmt: skip
 
 

@@ -27,6 +27,8 @@
 #include <hip/hip_ext.h>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 
 #include "common.h"
 
@@ -182,11 +184,11 @@ struct UpdateArgs {
   unsigned int* vals_in;       // scratch [m]: entry indices
   int32_t* hash_key;           // scratch [2^hash_bits]: ring rows placed on (-1 empty)
   int32_t* hash_maxp;          // scratch [2^hash_bits]: last sorted position placed there
-  int32_t* run_flag;           // scratch [m]
   int32_t* run_start;          // scratch [m]: first sorted position of p's run
   int32_t* run_len;            // scratch [m]: run length, at the run's first position
   int hash_bits;
   long long ts_bound;   // > 0: every timestamp is promised to lie in [0, ts_bound] (bounded-bit radix sort)
+  int sorted_ts;        // != 0: the batch's timestamps are promised non-decreasing (large path: span = ts[n - 1] + 1)
   int sort_bits;        // large path: number of low key bits the radix sort looks at (64 = all)
   int32_t* barrier;  // 2 ints at the head of the caller's scratch: the riders' self-resetting barrier (count, generation)
   int32_t* status;
@@ -1557,7 +1559,10 @@ __global__ __launch_bounds__(256) void ring_update_keys_kernel(const UpdateArgs 
   int node, nbr;
   long long t, i;
   update_entry(a, j, node, nbr, t, i);
-  const long long key = update_key(node, t, *a.span, a.key_wrap32);
+  // a time-sorted batch (every batch of a chronological loader): max(ts) is its last timestamp -- no reduction launch
+  const long long span = a.sorted_ts ? a.ts[a.n - 1] + 1 : *a.span;
+  const long long key = update_key(node, t, span, a.key_wrap32);
+  if (a.sorted_ts && i + 1 < a.n && a.ts[i + 1] < t) atomicOr(a.status, TGMX_ST_TS_BOUND);  // the promise is checked, not trusted
   if (a.sort_bits < 64) {
     // bounded sort: t in [0, ts_bound] makes key + 2^31 (int32-wrapped product) resp. key (int64 product, valid node)
     // non-negative and narrower than sort_bits
@@ -1592,11 +1597,10 @@ __device__ __forceinline__ int global_hash_slot(int* keys, int hash_bits, int tg
 
 // run analysis of the sorted order: run_start by an inclusive max-scan (rocPRIM) of "p if p opens a run else 0",
 // run length scattered to the run's first position by the run's last one -- O(m) however long the hub runs are
-__global__ __launch_bounds__(256) void ring_update_flags_kernel(const UpdateArgs a) {
-  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= a.m) return;
-  a.run_flag[p] = (p > 0 && a.sorted_node[p - 1] == a.sorted_node[p]) ? 0 : (int)p;
-}
+struct RunFlag {
+  const int32_t* sorted_node;
+  __device__ __forceinline__ int operator()(int p) const { return (p > 0 && sorted_node[p - 1] == sorted_node[p]) ? 0 : p; }
+};
 
 __global__ __launch_bounds__(256) void ring_update_ends_kernel(const UpdateArgs a) {
   const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1957,7 +1961,7 @@ static int fill_update_args(UpdateArgs& a, tgmx_adj_t* ring, int32_t* write_pos,
 
 // scratch layout of the large-batch path (byte offsets from a 256-byte aligned base)
 struct LargeScratch {
-  size_t span, keys_in, keys_out, vals_in, hash_key, hash_maxp, run_flag, run_start, run_len, temp, temp_bytes, total;
+  size_t span, keys_in, keys_out, vals_in, hash_key, hash_maxp, run_start, run_len, temp, temp_bytes, total;
   int hash_bits;
 };
 
@@ -1972,7 +1976,6 @@ static int large_scratch_layout(long long m, LargeScratch& w) {
   while ((1ll << w.hash_bits) < 2 * m) ++w.hash_bits;  // load factor <= 0.5
   w.hash_key = off; off = up(off + ((size_t)4 << w.hash_bits));
   w.hash_maxp = off; off = up(off + ((size_t)4 << w.hash_bits));
-  w.run_flag = off; off = up(off + (size_t)m * 4);
   w.run_start = off; off = up(off + (size_t)m * 4);
   w.run_len = off; off = up(off + (size_t)m * 4);
   size_t tb = 0;
@@ -1983,7 +1986,8 @@ static int large_scratch_layout(long long m, LargeScratch& w) {
     return TGMX_E_LAUNCH;
   }
   size_t sb = 0;
-  const hipError_t err2 = rocprim::inclusive_scan(nullptr, sb, (const int*)nullptr, (int*)nullptr, (size_t)m, rocprim::maximum<int>());
+  const hipError_t err2 = rocprim::inclusive_scan(nullptr, sb, rocprim::make_transform_iterator(rocprim::counting_iterator<int>(0), RunFlag{nullptr}),
+                                                  (int*)nullptr, (size_t)m, rocprim::maximum<int>());
   if (err2 != hipSuccess) {
     set_error("ring_update: scan workspace query failed: %s", hipGetErrorString(err2));
     return TGMX_E_LAUNCH;
@@ -2008,14 +2012,15 @@ static int launch_update_large_front(UpdateArgs& a, int32_t* scratch, hipStream_
   a.hash_key = reinterpret_cast<int32_t*>(base + w.hash_key);
   a.hash_maxp = reinterpret_cast<int32_t*>(base + w.hash_maxp);
   a.hash_bits = w.hash_bits;
-  a.run_flag = reinterpret_cast<int32_t*>(base + w.run_flag);
   a.run_start = reinterpret_cast<int32_t*>(base + w.run_start);
   a.run_len = reinterpret_cast<int32_t*>(base + w.run_len);
   const unsigned blocks = (unsigned)((a.m + 255) / 256);
   (void)hipMemsetAsync(a.hash_key, 0xFF, (size_t)8 << w.hash_bits, st);  // keys and max positions (adjacent): all -1
-  (void)hipMemsetAsync(a.span, 0x80, sizeof(long long), st);  // 0x8080...: far below any timestamp
-  const unsigned span_blocks = (unsigned)((a.n + 2047) / 2048 < 64 ? (a.n + 2047) / 2048 : 64);
-  hipLaunchKernelGGL(ring_update_span_kernel, dim3(span_blocks), dim3(256), 0, st, a);
+  if (!a.sorted_ts) {
+    (void)hipMemsetAsync(a.span, 0x80, sizeof(long long), st);  // 0x8080...: far below any timestamp
+    const unsigned span_blocks = (unsigned)((a.n + 2047) / 2048 < 64 ? (a.n + 2047) / 2048 : 64);
+    hipLaunchKernelGGL(ring_update_span_kernel, dim3(span_blocks), dim3(256), 0, st, a);
+  }
   // how many key bits can be set?  (only with the caller's promise 0 <= t <= ts_bound)
   a.sort_bits = 64;
   if (a.ts_bound > 0) {
@@ -2041,9 +2046,10 @@ static int launch_update_large_front(UpdateArgs& a, int32_t* scratch, hipStream_
     return TGMX_E_LAUNCH;
   }
   hipLaunchKernelGGL(ring_update_scatter_kernel, dim3(blocks), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(ring_update_flags_kernel, dim3(blocks), dim3(256), 0, st, a);
+  // run_start = inclusive max-scan of "p if p opens a run else 0", the flag evaluated inside the scan's load (no flags launch)
   tb = w.temp_bytes;
-  const hipError_t err2 = rocprim::inclusive_scan(base + w.temp, tb, (const int*)a.run_flag, a.run_start, (size_t)a.m, rocprim::maximum<int>(), st);
+  const auto flags = rocprim::make_transform_iterator(rocprim::counting_iterator<int>(0), RunFlag{a.sorted_node});
+  const hipError_t err2 = rocprim::inclusive_scan(base + w.temp, tb, flags, a.run_start, (size_t)a.m, rocprim::maximum<int>(), st);
   if (err2 != hipSuccess) {
     set_error("ring_update: scan failed: %s", hipGetErrorString(err2));
     return TGMX_E_LAUNCH;
@@ -2195,6 +2201,7 @@ extern "C" int tgmx_recency_step(const tgmx_recency_step_t* s, tgmx_stream_t str
     if (rc) return rc;
     u.ts_bound = s->ts_bound;
     u.guard_mask = s->guard_seed_errors ? (TGMX_ST_SEED_RANGE | TGMX_ST_SEED_TIME) : 0;
+    u.sorted_ts = s->sorted_ts;
     static const bool no_ride = getenv("TGMX_NO_RIDE") != nullptr;  // A/B knob: the update as its own launches
     if (u.m <= kBlockMaxM && s->n_hops > 0 && S > 0 && !no_ride) side_chunks = set_chunk_scratch(u, s->scratch + kScratchHead);
     ride_place = side_chunks > 0 && u.m <= kRidePlaceMaxM && s->n_hops >= 2;

@@ -198,6 +198,8 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
         if times is not None and len(times) and int(times[0]) >= 0:
             bound = int(times[-1])
         self._step.ts_bound = bound
+        # batches materialized from this store are contiguous slices of a time-sorted stream
+        self._step.sorted_ts = 1 if times is not None else 0
 
     def fuses_first_hops(self) -> bool:
         """Did the last call run hop 0 and hop 1 as one launch?  (``tgmx_recency_step_plan`` on the argument block of
@@ -224,7 +226,7 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
         if st & _ST_EDGE_RANGE:
             raise ValueError(f'Batch edge endpoints must satisfy 0 <= x < {self._num_nodes}')
         if st & _ST_TS_BOUND:
-            raise RuntimeError('tgmx_recency_step: a batch timestamp lies outside [0, ts_bound] (the bound comes from the graph store)')
+            raise RuntimeError('tgmx_recency_step: a batch timestamp lies outside [0, ts_bound], or the batch is not time-sorted (both promises come from the graph store)')
         if st & _ST_SCRATCH:
             raise RuntimeError('tgmx_recency_step: the update scratch was not zero-initialised (internal error)')
 
