@@ -400,6 +400,13 @@ typedef struct tgmx_tgat_layer {
    * cos(tb) (the residual's time part is Time2Vec(0), attention.py:93-95).  NULL: Q and qf are computed per call. */
   const float* qf_U;  /* [H * p4(C), p4(d)] */
   const float* qf_v;  /* [H * p4(C)]        */
+  /* optional (inference): the four weights behind the attention reduce in the 16 x 16-tiled layout of tgmx_tgat_tile16()
+   * (made once per parameter version).  With all four set, everything behind the attention reduce of a layer -- W_V, W_O,
+   * LayerNorm(y + residual), concat, fc1 + ReLU, fc2 -- runs as ONE kernel over 16-row tiles.  NULL: the row-major copies. */
+  const float* W_V_t16; /* H blocks, head h = tile16(W_KV[O + h*dh : O + (h+1)*dh], dh, C) at h * tile16_floats(dh, C) */
+  const float* W_O_t16; /* tile16(W_O, O, O)                */
+  const float* fc1_t16; /* tile16(fc1.weight, emb, O + d0)  */
+  const float* fc2_t16; /* tile16(fc2.weight, emb_out, emb) */
   int32_t d, D, T, O, H, emb, emb_out;
   float ln_eps;
 } tgmx_tgat_layer_t;
@@ -431,6 +438,11 @@ typedef struct tgmx_tgat_layout {
   int64_t level_rows[TGMX_TGAT_MAX_LAYERS + 1], level_off[TGMX_TGAT_MAX_LAYERS + 2];
   tgmx_tgat_layer_layout_t layers[TGMX_TGAT_MAX_LAYERS];
 } tgmx_tgat_layout_t;
+/* Weight [N, K] (row stride ldw floats) -> out[tgmx_tgat_tile16_floats(N, K)]: block (nb, kb) of 16 x 16 is 256 consecutive
+ * floats, element 4 * lane + j = W[16 nb + (lane & 15)][16 kb + 4 (lane >> 4) + j], zero outside the matrix -- the order the
+ * 16x16x4 fp32 MFMA's A operand is fetched in, so one wave load is 1 KB of consecutive memory. */
+size_t tgmx_tgat_tile16_floats(int32_t N, int32_t K);
+int tgmx_tgat_tile16(const float* W, int64_t ldw, int32_t N, int32_t K, float* out, tgmx_stream_t stream);
 int tgmx_tgat_layout(const tgmx_tgat_model_t* model, int64_t S0, const tgmx_tgat_hop_t* hops,
                      int32_t save, tgmx_tgat_layout_t* out);
 size_t tgmx_tgat_workspace_bytes(const tgmx_tgat_model_t* model, int64_t S0, const tgmx_tgat_hop_t* hops);

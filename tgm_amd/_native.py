@@ -102,7 +102,8 @@ def dropout_desc(p: float, seed: int, stream: int, row0: int = 0):
 
 
 class TgatLayer(ctypes.Structure):
-    _fields_ = [(n, c_void_p) for n in ('W_Q', 'W_K_t', 'W_V', 'W_O', 'b_O', 'ln_g', 'ln_b', 'fc1_w', 'fc1_b', 'fc2_w', 'fc2_b', 'qf_U', 'qf_v')] + [
+    _fields_ = [(n, c_void_p) for n in ('W_Q', 'W_K_t', 'W_V', 'W_O', 'b_O', 'ln_g', 'ln_b', 'fc1_w', 'fc1_b', 'fc2_w', 'fc2_b', 'qf_U', 'qf_v',
+                                        'W_V_t16', 'W_O_t16', 'fc1_t16', 'fc2_t16')] + [
         (n, c_int32) for n in ('d', 'D', 'T', 'O', 'H', 'emb', 'emb_out')
     ] + [('ln_eps', ctypes.c_float)]
 
@@ -237,6 +238,8 @@ SIGNATURES['tgmx_tgn_memory_forward'] = (c_int32, [ctypes.POINTER(TgnMemoryFwd),
 SIGNATURES['tgmx_tconv_forward'] = (c_int32, [ctypes.POINTER(TconvFwd), _P])
 SIGNATURES['tgmx_segment_sort_workspace_bytes'] = (c_size_t, [c_int64])
 SIGNATURES['tgmx_segment_sort'] = (c_int32, [_P, c_int64, c_int32, _P, _P, _P, _P, c_size_t, _P, _P])
+SIGNATURES['tgmx_tgat_tile16_floats'] = (c_size_t, [c_int32, c_int32])
+SIGNATURES['tgmx_tgat_tile16'] = (c_int32, [_P, c_int64, c_int32, c_int32, _P, _P])
 SIGNATURES['tgmx_tgat_layout'] = (c_int32, [ctypes.POINTER(TgatModel), c_int64, ctypes.POINTER(TgatHop), c_int32, ctypes.POINTER(TgatLayout)])
 SIGNATURES['tgmx_tgat_workspace_bytes'] = (c_size_t, [ctypes.POINTER(TgatModel), c_int64, ctypes.POINTER(TgatHop)])
 SIGNATURES['tgmx_tgat_forward'] = (

@@ -13,6 +13,8 @@
 // exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) in sgemm_nt below.
 #include "common.h"
 
+#include <type_traits>
+
 namespace tgmx {
 
 using floatx16 = __attribute__((__vector_size__(16 * sizeof(float)))) float;
@@ -284,6 +286,8 @@ struct ChainArgs {
   int Cp, Op, Kc, Ep;  // row strides of the padded weight copies
   int LD;              // LDS row stride in floats
   float eps;
+  long long* dbg_t;
+  int dbg_mode;
 };
 
 template <bool A_LDS>
@@ -483,6 +487,433 @@ __global__ __launch_bounds__(kChainThreads) void tgat_post_chain_kernel(const Ch
   // stage 5: out = h1 . fc2^T + b2  -> global
   for (int nb = wave; nb < (g.emb_out + 31) / 32; nb += kChainWaves)
     chain_block<true, false>(buf1, LD, rows, g.fc2_w, g.Ep, g.emb_out, nb * 32, g.emb, g.fc2_b, 0, g.out + m0 * g.ldo, g.ldo, 0, lane);
+}
+
+// ---------------------------------------------------------------------------
+// The same tail as tgat_post_chain_kernel, TRANSPOSED and with the weights shared through LDS: tgat_chain64_kernel.
+//
+// Tiles of 16 rows and Y^T = W . X^T on v_mfma_f32_16x16x4_f32: the WEIGHT rows are the MFMA's A operand (lane (n, kq) holds
+// W[n][16 kb + 4 kq + j]) and the activations its B operand (lane (r, kq) holds X[r][16 kb + 4 kq + j]).  The result lands as
+// lane (r, rq) <- Y[r][16 nb + 4 rq + j]: four consecutive columns of the lane's own row, so a stage's output goes back to
+// the wave's activation slab in LDS as 16-byte row pieces and the next stage reads it the same way.  One wave owns one
+// 16-row tile through all five stages -- its NB <= 12 output blocks are NB independent accumulators per k-step, which keeps
+// the matrix pipe issuing back to back (32 cycles each, 40 dependent) -- and needs no partner: 12 600 rows are 788 waves.
+//
+// What bounds this kernel is the CU's load path, not the matrix pipe: a CU takes ~12 bytes per clock from L2 however the
+// loads are shaped (measured: one wave per tile streaming its own copy of the weights from L2 = 1.8 MB per CU = 66 us, the
+// same with row-major or tiled weights, with deeper prefetch, and with the MFMAs removed).  So the FOUR waves of a
+// workgroup (64 rows, one CU) share each weight chunk: 24 tiles (24 KB) are copied global -> registers -> LDS by all
+// 256 threads, double-buffered one chunk ahead, one barrier per chunk, and every wave feeds its MFMAs from LDS
+// (ds_read_b128, 256 B/clk).  Per CU that is 0.4 MB of weights + 0.14 MB of zbar against 51k cycles of MFMA per wave.
+// The weights come pre-tiled (tgmx_tgat_tile16) in the order the chunks are consumed, so a chunk is one contiguous range.
+// ---------------------------------------------------------------------------
+using floatx4 = __attribute__((__vector_size__(4 * sizeof(float)))) float;
+
+constexpr int kC64Waves = 4;
+constexpr int kC64Threads = kC64Waves * kWave;
+constexpr int kC64ChunkTiles = 24;  // weight tiles (1 KB each) per LDS buffer
+constexpr int kC64MaxB = 12;        // output blocks per stage: N <= 192
+__host__ __device__ constexpr int c64_steps(int nb) { return kC64ChunkTiles / nb < 8 ? kC64ChunkTiles / nb : 8; }  // k-steps per chunk
+
+// The weights of the five GEMMs are ONE stream of chunks (<= 24 tiles each) through a ring of three LDS buffers: chunk p
+// lives in buffer p % 3 and is issued as LDS-DMA two chunks before it is consumed, across GEMM boundaries, so a DMA has two
+// chunks of MFMAs (~6000 cycles) to land and no GEMM starts with an exposed load.  Wave w moves tiles w, w + 4, ... of a
+// chunk, 1 KB per instruction (destination = wave-uniform tile base + 16 bytes per lane), and ALWAYS issues kC64Issue
+// instructions per chunk (a tile it has no use for goes to a dummy slot): the wait at the end of an iteration is the
+// counted `s_waitcnt vmcnt(kC64Issue)` -- everything but the newest chunk has landed -- followed by a raw s_barrier
+// (__syncthreads would drain the queue).
+constexpr int kC64Issue = kC64ChunkTiles / kC64Waves;
+
+struct C64Stream {
+  // four kinds of GEMM: V = W_V (H of them, `vstride` floats apart), O = W_O, F1 = fc1, F2 = fc2; per kind: tiled image, tiles
+  // per chunk, chunks, tiles.  (Plain scalars selected by compares, never indexed: the table stays in scalar registers.)
+  const float *W_V, *W_O, *W_F1, *W_F2;
+  int CT_V, CT_O, CT_F1, CT_F2, nch_V, nch_O, nch_F1, nch_F2, nt_V, nt_O, nt_F1, nt_F2;
+  long long vstride;
+  int H;
+};
+
+__device__ __forceinline__ void c64_geom(int NB, int K, int& CT, int& nch, int& nt) {
+  const int KB = (K + 15) / 16, CK = c64_steps(NB);
+  CT = CK * NB; nch = (KB + CK - 1) / CK; nt = KB * NB;
+}
+
+// The chunk under the cursor as kC64Issue (source, LDS destination) pairs for this wave -- a tile it has no use for (or
+// anything past the end of the stream) is a dummy move -- and advance the cursor.  The moves themselves are issued one at a
+// time between groups of MFMAs (c64_dma).
+struct C64Moves {
+  const float* src[kC64Issue];
+  float* dst[kC64Issue];
+};
+__device__ __forceinline__ C64Moves c64_next_moves(const C64Stream st, int& ck, int& cc, int& cp, float* __restrict__ wbuf, int tid) {
+  const int wave = tid >> 6, lane = tid & 63;
+  const bool live = ck < st.H + 3;
+  const int kind = ck < st.H ? 0 : ck - st.H + 1;
+  const float* Wt = kind == 0 ? st.W_V + ck * st.vstride : kind == 1 ? st.W_O : kind == 2 ? st.W_F1 : st.W_F2;
+  const int CT = kind == 0 ? st.CT_V : kind == 1 ? st.CT_O : kind == 2 ? st.CT_F1 : st.CT_F2;
+  const int nch = kind == 0 ? st.nch_V : kind == 1 ? st.nch_O : kind == 2 ? st.nch_F1 : st.nch_F2;
+  const int ntiles = kind == 0 ? st.nt_V : kind == 1 ? st.nt_O : kind == 2 ? st.nt_F1 : st.nt_F2;
+  const int first = cc * CT, count = live ? CT : 0;
+  float* buf = wbuf + (cp % 3) * (kC64ChunkTiles * 256);
+  float* dummy = wbuf + 3 * (kC64ChunkTiles * 256) + wave * 256;
+  C64Moves m;
+#pragma unroll
+  for (int i = 0; i < kC64Issue; ++i) {
+    const int t = i * kC64Waves + wave;
+    const bool ok = t < count && first + t < ntiles;
+    m.src[i] = Wt + (long long)(ok ? first + t : 0) * 256 + lane * 4;
+    m.dst[i] = ok ? buf + t * 256 : dummy;
+  }
+  ++cp;
+  const int c1 = cc + (live ? 1 : 0);
+  const bool wrap = c1 == nch;
+  cc = wrap ? 0 : c1;
+  ck += wrap ? 1 : 0;
+  return m;
+}
+// One LDS-DMA instruction, as inline assembly ON PURPOSE: hipcc tracks the builtin as an LDS store and puts a vmcnt(0) in front
+// of the next ds_read it cannot prove disjoint -- which drains the chunk that is supposed to stay in flight.  Written this
+// way the compiler knows nothing about it; the counted waits in c64_sync are what orders it (the compiler's own vmcnt waits
+// for ordinary loads can only be too strict with unknown operations in the queue, never too weak).
+__device__ __forceinline__ void c64_dma(const float* src, float* dst) {
+  const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)dst);
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(src), "s"(lds)
+               : "memory");
+}
+
+// all but the newest chunk have landed and every wave is done with the buffer the next issue overwrites
+template <int INFLIGHT>
+__device__ __forceinline__ void c64_sync() {
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(INFLIGHT) : "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// One GEMM of the chain for the four waves of the workgroup at once (every thread must call it):
+//   acc[i] (i < NB) <- W[16 i .. 16 i + 16, 0 .. K) . X[the wave's 16 rows, 0 .. K)^T,
+// the weights being the next chunks of the stream (q = position of this GEMM's first chunk, advanced).  XG: the activations
+// come from global memory (the lane's zbar row, padded length Kxp) and xc holds the first chunk's on entry; xnext = the
+// next GEMM's row, whose first chunk is fetched into xc during this one's last.  Otherwise xrow is the lane's row of the
+// wave's LDS slab.
+template <int NB, bool XG>
+struct C64Gemm {
+  static constexpr int CK = c64_steps(NB);  // k-steps per chunk
+  static constexpr int CT = CK * NB;        // tiles per chunk
+
+  // the lane's activations of k-steps [c CK, (c + 1) CK): forced to zero past K (a slab column past K holds an older stage,
+  // zbar padding is not initialised; the weight tiles carry zeros there)
+  static __device__ __forceinline__ void xfetch(float4 (&xd)[CK], const float* __restrict__ xrow, int c, int K, int Kxp, int lane) {
+    const int KB = (K + 15) / 16, k4l = (lane >> 4) * 4, kx_last = Kxp - 4;
+#pragma unroll
+    for (int s = 0; s < CK; ++s) {
+      int kb = c * CK + s;
+      kb = kb < KB ? kb : KB - 1;
+      const int k4 = kb * 16 + k4l;
+      float4 x;
+      if constexpr (XG) x = *reinterpret_cast<const float4*>(xrow + (k4 < kx_last ? k4 : kx_last));
+      else x = *reinterpret_cast<const float4*>(xrow + k4);
+      xd[s].x = k4 < K ? x.x : 0.f;
+      xd[s].y = k4 + 1 < K ? x.y : 0.f;
+      xd[s].z = k4 + 2 < K ? x.z : 0.f;
+      xd[s].w = k4 + 3 < K ? x.w : 0.f;
+    }
+  }
+
+  // one activation vector (k-step kb) of a row: zero past K
+  static __device__ __forceinline__ float4 xload(const float* __restrict__ xrow, int kb, int K, int Kxp, int lane) {
+    const int KB = (K + 15) / 16, k4l = (lane >> 4) * 4, kx_last = Kxp - 4;
+    kb = kb < KB ? kb : KB - 1;
+    const int k4 = kb * 16 + k4l;
+    float4 x;
+    if constexpr (XG) x = *reinterpret_cast<const float4*>(xrow + (k4 < kx_last ? k4 : kx_last));
+    else x = *reinterpret_cast<const float4*>(xrow + k4);
+    return float4{k4 < K ? x.x : 0.f, k4 + 1 < K ? x.y : 0.f, k4 + 2 < K ? x.z : 0.f, k4 + 3 < K ? x.w : 0.f};
+  }
+
+  // The chunk loop is software-pipelined BY HAND and pinned with scheduling fences, because what stalls this kernel is issue
+  // order: a VMEM instruction blocks the wave while the CU's address unit takes it (~50 cycles per KB, and all four waves
+  // come out of the barrier together: the 6 DMAs of a chunk issued in a burst = 1200 cycles of idle matrix pipe per chunk,
+  // 28k of the kernel's 130k cycles), and a tile read issued right before its MFMAs exposes the LDS latency 60 times.  So,
+  // between every two groups of NB MFMAs: ONE memory instruction group -- first the next chunk's activations (ordinary loads,
+  // older than the DMAs: the counted wait covers them), then the six DMAs of chunk q + 2, and a quarter of the next k-step's
+  // tile reads.  The wait + barrier that retires chunk q + 1 sits before the LAST group of MFMAs of chunk q, followed by the
+  // first tile reads of chunk q + 1, which that last group covers.
+  static __device__ __forceinline__ void run(const C64Stream st, int& ck, int& cc, int& cp, int& q, int K, const float* __restrict__ xrow, int Kxp,
+                                             float4 (&xc)[CK], const float* __restrict__ xnext, float* __restrict__ wbuf, floatx4 (&acc)[NB], int tid,
+                                             int dbg_mode = 0, long long* tacc = nullptr) {
+    static_assert(4 * CK >= CK + kC64Issue, "not enough MFMA groups per chunk to carry the loads");
+    constexpr int Q4 = (NB + 3) / 4;  // tile reads per MFMA group
+    const int lane = tid & 63;
+    const int KB = (K + 15) / 16, nchunks = (KB + CK - 1) / CK;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) acc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (!XG) {
+#pragma unroll
+      for (int s = 0; s < CK; ++s) xc[s] = xload(xrow, s, K, Kxp, lane);
+    }
+    float4 w[2][NB];
+    {
+      const float* wl = wbuf + (q % 3) * (kC64ChunkTiles * 256) + lane * 4;
+#pragma unroll
+      for (int i = 0; i < NB; ++i) w[0][i] = *reinterpret_cast<const float4*>(wl + i * 256);
+    }
+    for (int c = 0; c < nchunks; ++c) {
+      const bool more = c + 1 < nchunks;
+      const float* xsrc = more ? xrow : (XG && xnext ? xnext : xrow);
+      const int cnext = more ? c + 1 : 0;
+      const C64Moves mv = c64_next_moves(st, ck, cc, cp, wbuf, tid);  // position q + 2
+      const float* wl = wbuf + (q % 3) * (kC64ChunkTiles * 256) + lane * 4;
+      const float* wl_next = wbuf + ((q + 1) % 3) * (kC64ChunkTiles * 256) + lane * 4;
+      float4 xn[CK];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < CK; ++s) {
+        // k-step s reads w[(s & 1) ^ par]: par flips per chunk when CK is odd -- so keep it simple: the parity of s within
+        // the chunk selects the register set and an odd CK copies once at the end of the chunk
+        float4(&wc)[NB] = w[s & 1];
+        float4(&wn)[NB] = w[(s & 1) ^ 1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int grp = 4 * s + j;
+          if (s == CK - 1 && j == 3) {  // chunk q + 1 has landed, everybody is done reading chunk q: its first tiles can be fetched
+            c64_sync<(3 * CK - 1 < kC64Issue ? 3 * CK - 1 : kC64Issue)>();  // = the DMAs of chunk q + 2 issued so far: all that may stay in flight
+            if (more) {
+#pragma unroll
+              for (int i = 0; i < NB; ++i) wn[i] = *reinterpret_cast<const float4*>(wl_next + i * 256);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+#pragma unroll
+          for (int i = 0; i < NB; ++i) {
+            const float a = j == 0 ? wc[i].x : j == 1 ? wc[i].y : j == 2 ? wc[i].z : wc[i].w;
+            const float b = j == 0 ? xc[s].x : j == 1 ? xc[s].y : j == 2 ? xc[s].z : xc[s].w;
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (grp < CK) xn[grp] = xload(xsrc, cnext * CK + grp, K, Kxp, lane);
+          else if (grp < CK + kC64Issue) c64_dma(mv.src[grp - CK], mv.dst[grp - CK]);
+          if (s + 1 < CK) {
+#pragma unroll
+            for (int i = j * Q4; i < (j + 1) * Q4 && i < NB; ++i) wn[i] = *reinterpret_cast<const float4*>(wl + ((s + 1) * NB + i) * 256);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if constexpr ((CK & 1) == 1) {  // the next chunk's step 0 was read into w[1]: step 0 always reads w[0]
+#pragma unroll
+        for (int i = 0; i < NB; ++i) w[0][i] = w[1][i];
+      }
+      ++q;
+#pragma unroll
+      for (int s = 0; s < CK; ++s) xc[s] = xn[s];
+    }
+  }
+};
+
+// run f(integral_constant<NB>) for the (workgroup-uniform) block count nb in [1, MAXB]
+template <int NB, int MAXB, class F>
+__device__ __forceinline__ void chain64_dispatch(int nb, F&& f) {
+  if (nb == NB) {
+    f(std::integral_constant<int, NB>{});
+  } else if constexpr (NB < MAXB) {
+    chain64_dispatch<NB + 1, MAXB>(nb, f);
+  }
+}
+
+__global__ __launch_bounds__(kC64Threads) void tgat_chain64_kernel(const ChainArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float c64_lds[];
+  constexpr int NT = kC64Threads;
+  const int O = g.O, H = g.H, dh = O / H, LD = g.LD, T = g.T, d = g.d, d0 = g.d0;
+  const int nbO = (O + 15) / 16, nbE = (g.emb + 15) / 16, nbEo = (g.emb_out + 15) / 16;
+  float* wbuf = c64_lds;                            // [3][24 tiles x 256] weight chunks + one dummy tile per wave
+  float* slabs = wbuf + 3 * kC64ChunkTiles * 256 + kC64Waves * 256;  // [4 waves][16, LD] activations, one slab per wave
+  float* br = slabs + kC64Waves * 16 * LD;          // [16 nbO]  b_O + the residual's time part cos(tb), zero-padded
+  float* lg = br + 16 * nbO;                        // [16 nbO]  LayerNorm weight, zero-padded
+  float* lb = lg + 16 * nbO;                        // [16 nbO]  LayerNorm bias, zero-padded
+  float* b1 = lb + 16 * nbO;                        // [16 nbE]  zero-padded
+  float* b2 = b1 + 16 * nbE;                        // [16 nbEo] zero-padded
+  float* xs = b2 + 16 * nbEo;                       // [64, d]  residual feature part
+  float* zs = xs + 64 * d;                          // [64, d0] skip features
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, rq = lane >> 4;
+  const long long w0 = (long long)blockIdx.x * 64;  // first row of the workgroup
+  const long long m0 = w0 + wave * 16;              // first row of this wave's tile
+  const int wrows = (g.R - w0) < 64 ? (int)(g.R - w0) : 64;
+  const int rows = g.R - m0 < 0 ? 0 : (g.R - m0 < 16 ? (int)(g.R - m0) : 16);  // 0: the wave only helps with the copies
+  float* slab = slabs + wave * 16 * LD;
+  long long* dbg = g.dbg_t ? g.dbg_t + ((long long)blockIdx.x * kC64Waves + wave) * 8 : nullptr;
+  auto stamp = [&](int i) { if (dbg && lane == 0) dbg[i] = (long long)__builtin_readcyclecounter(); };
+  long long tacc[4] = {0, 0, 0, 0};
+  stamp(0);
+  const int HB = (dh + 15) / 16, KBc = (g.C + 15) / 16;
+  int q = 0;
+  C64Stream st;
+  int ck = 0, cc = 0, cp = 0;
+  st.H = H; st.vstride = (long long)HB * KBc * 256;
+  st.W_V = g.W_V; st.W_O = g.W_O; st.W_F1 = g.fc1_w; st.W_F2 = g.fc2_w;
+  c64_geom(HB, g.C, st.CT_V, st.nch_V, st.nt_V);
+  c64_geom(nbO, O, st.CT_O, st.nch_O, st.nt_O);
+  c64_geom(nbE, O + d0, st.CT_F1, st.nch_F1, st.nt_F1);
+  c64_geom(nbEo, g.emb, st.CT_F2, st.nch_F2, st.nt_F2);
+  // the slabs and the weight ring start as zeros: a partial chunk's trailing k-steps multiply whatever the ring holds with zeros
+  for (int e = tid * 4; e < 3 * kC64ChunkTiles * 256 + kC64Waves * 256 + kC64Waves * 16 * LD; e += NT * 4)
+    *reinterpret_cast<float4*>(wbuf + e) = float4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  for (int u = 0; u < 2; ++u) {  // the first two weight chunks fly during the rest of the prologue
+    const C64Moves mv = c64_next_moves(st, ck, cc, cp, wbuf, tid);
+#pragma unroll
+    for (int i = 0; i < kC64Issue; ++i) c64_dma(mv.src[i], mv.dst[i]);
+  }
+  {
+    // row constants and this workgroup's residual / skip inputs: every global load first, then the LDS stores
+    const int t0 = O - T;
+    const int c = tid;  // nbO, nbE, nbEo <= 12: one element per thread covers every padded vector
+    const float v_bo = c < O ? g.b_O[c] : 0.f, v_tb = (c >= t0 && c < O) ? g.tb[c - t0] : 0.f;
+    const float v_lg = c < O ? g.ln_g[c] : 0.f, v_lb = c < O ? g.ln_b[c] : 0.f;
+    const float v_b1 = c < g.emb ? g.fc1_b[c] : 0.f, v_b2 = c < g.emb_out ? g.fc2_b[c] : 0.f;
+    const float v_x = c < wrows * d ? g.x[(w0 + c / d) * g.ldx + (c % d)] : 0.f;
+    const float v_z = c < wrows * d0 ? g.z0[w0 * d0 + c] : 0.f;
+    if (c < 16 * nbO) {
+      br[c] = v_bo + ((c >= t0 && c < O) ? cos_t2v(v_tb) : 0.f);
+      lg[c] = v_lg;
+      lb[c] = v_lb;
+    }
+    if (c < 16 * nbE) b1[c] = v_b1;
+    if (c < 16 * nbEo) b2[c] = v_b2;
+    if (c < 64 * d) xs[c] = v_x;
+    if (c < 64 * d0) zs[c] = v_z;
+    for (int e = tid + NT; e < wrows * d; e += NT) xs[e] = g.x[(w0 + e / d) * g.ldx + (e % d)];
+    for (int e = tid + NT; e < wrows * d0; e += NT) zs[e] = g.z0[w0 * d0 + e];
+  }
+  __syncthreads();  // drains both DMAs too: the stream's first wait finds nothing in flight, which a counted wait allows
+  stamp(1);
+
+  // stage 1: oattn (slab) -- per head, the lane's zbar row straight from global.  Head h writes columns h dh .. h dh + 16 HB:
+  // its zero padding (the tiles are zero past dh) is overwritten by head h + 1, the last head's lands past O where no stage looks
+  {
+    long long grow = m0 + (r < rows ? r : rows - 1);
+    grow = grow < g.R ? (grow < 0 ? 0 : grow) : g.R - 1;
+    const float* zrow = g.zbar + grow * g.ld_zbar;
+    chain64_dispatch<1, kC64MaxB>(HB, [&](auto nbc) __attribute__((always_inline)) {
+      constexpr int NB = decltype(nbc)::value;
+      using G = C64Gemm<NB, true>;
+      float4 xc[G::CK];
+#pragma unroll
+      for (int s = 0; s < G::CK; ++s) xc[s] = G::xload(zrow, s, g.C, g.Cp, lane);
+      for (int h = 0; h < H; ++h) {
+        floatx4 acc[NB];
+        const bool last = h + 1 == H;
+        G::run(st, ck, cc, cp, q, g.C, zrow + (long long)h * g.Cp, g.Cp, xc, last ? nullptr : zrow + (long long)(h + 1) * g.Cp, wbuf, acc, tid, g.dbg_mode, tacc);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) slab[r * LD + h * dh + 16 * i + 4 * rq + j] = acc[i][j];
+        }
+      }
+    });
+  }
+  stamp(2);
+  // stage 2 + 3: cat = [LayerNorm(oattn . W_O^T + b_O + residual) | z0].  The wave holds whole rows (4 lanes x 4 NB registers
+  // each), so the statistics are two shuffles away and y never goes to LDS
+  chain64_dispatch<1, kC64MaxB>(nbO, [&](auto nbc) __attribute__((always_inline)) {
+    constexpr int NB = decltype(nbc)::value;
+    using G = C64Gemm<NB, false>;
+    float4 xc[G::CK];
+    floatx4 acc[NB];
+    G::run(st, ck, cc, cp, q, O, slab + r * LD, 0, xc, nullptr, wbuf, acc, tid, g.dbg_mode, tacc);
+    stamp(3);
+    float y[NB][4];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int c0 = 16 * i + 4 * rq;
+      const float4 b = *reinterpret_cast<const float4*>(br + c0);
+      y[i][0] = acc[i][0] + b.x; y[i][1] = acc[i][1] + b.y; y[i][2] = acc[i][2] + b.z; y[i][3] = acc[i][3] + b.w;
+      if (16 * i < d) {  // the residual's feature part: the first ceil(d / 16) blocks only
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (c0 + j < d) y[i][j] += xs[(wave * 16 + r) * d + c0 + j];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sum += c0 + j < O ? y[i][j] : 0.f;
+    }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float mean = sum / (float)O;
+    float var = 0.f;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float u = 16 * i + 4 * rq + j < O ? y[i][j] - mean : 0.f;
+        var += u * u;
+      }
+    }
+    var += __shfl_xor(var, 16);
+    var += __shfl_xor(var, 32);
+    const float rstd = 1.0f / sqrtf(var / (float)O + g.eps);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int c0 = 16 * i + 4 * rq;
+      const float4 gw = *reinterpret_cast<const float4*>(lg + c0), gb = *reinterpret_cast<const float4*>(lb + c0);
+      // columns past O: weight and bias are zero-padded, so they are written as zeros
+      *reinterpret_cast<float4*>(slab + r * LD + c0) = float4{(y[i][0] - mean) * rstd * gw.x + gb.x, (y[i][1] - mean) * rstd * gw.y + gb.y,
+                                                               (y[i][2] - mean) * rstd * gw.z + gb.z, (y[i][3] - mean) * rstd * gw.w + gb.w};
+    }
+    for (int e = lane; e < 16 * d0; e += 64) {
+      const int row = e / d0, c = e - row * d0;
+      slab[row * LD + O + c] = row < rows ? zs[(wave * 16 + row) * d0 + c] : 0.f;
+    }
+  });
+  stamp(4);
+  // stage 4: h1 = relu(cat . fc1^T + b1), in place
+  chain64_dispatch<1, kC64MaxB>(nbE, [&](auto nbc) __attribute__((always_inline)) {
+    constexpr int NB = decltype(nbc)::value;
+    using G = C64Gemm<NB, false>;
+    float4 xc[G::CK];
+    floatx4 acc[NB];
+    G::run(st, ck, cc, cp, q, O + d0, slab + r * LD, 0, xc, nullptr, wbuf, acc, tid, g.dbg_mode, tacc);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int c0 = 16 * i + 4 * rq;
+      const float4 b = *reinterpret_cast<const float4*>(b1 + c0);
+      float4 v{acc[i][0] + b.x, acc[i][1] + b.y, acc[i][2] + b.z, acc[i][3] + b.w};  // columns past emb: zero tiles + zero bias
+      v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+      *reinterpret_cast<float4*>(slab + r * LD + c0) = v;
+    }
+  });
+  stamp(5);
+  // stage 5: out = h1 . fc2^T + b2 -> global
+  chain64_dispatch<1, kC64MaxB>(nbEo, [&](auto nbc) __attribute__((always_inline)) {
+    constexpr int NB = decltype(nbc)::value;
+    using G = C64Gemm<NB, false>;
+    float4 xc[G::CK];
+    floatx4 acc[NB];
+    G::run(st, ck, cc, cp, q, g.emb, slab + r * LD, 0, xc, nullptr, wbuf, acc, tid, g.dbg_mode, tacc);
+    stamp(7);
+    if (r < rows) {
+      float* orow = g.out + (m0 + r) * g.ldo;
+      const bool vec = (g.ldo & 3) == 0;
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int c0 = 16 * i + 4 * rq;
+        const float4 b = *reinterpret_cast<const float4*>(b2 + c0);
+        const float4 v{acc[i][0] + b.x, acc[i][1] + b.y, acc[i][2] + b.z, acc[i][3] + b.w};
+        if (vec && c0 + 3 < g.emb_out) {
+          *reinterpret_cast<float4*>(orow + c0) = v;
+        } else {
+          if (c0 < g.emb_out) orow[c0] = v.x;
+          if (c0 + 1 < g.emb_out) orow[c0 + 1] = v.y;
+          if (c0 + 2 < g.emb_out) orow[c0 + 2] = v.z;
+          if (c0 + 3 < g.emb_out) orow[c0 + 3] = v.w;
+        }
+      }
+    }
+  });
+  stamp(6);
 }
 
 // ---------------------------------------------------------------------------
@@ -1272,6 +1703,80 @@ static int launch_post_chain(const tgmx_tgat_layer_t& ly, const tgmx_tgat_layer_
   return TGMX_OK;
 }
 
+// row-major weight [N, K] (row stride ldw) -> the 16 x 16 tiles chain64_gemm streams, k-block major: [KB][NB][256]
+__global__ __launch_bounds__(256) void tile16_kernel(const float* __restrict__ W, long long ldw, int N, int K, float* __restrict__ out) {
+  const int KB = (K + 15) / 16;
+  const long long total = (long long)((N + 15) / 16) * KB * 256;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long tile = e >> 8;
+    const int NBk = (N + 15) / 16;
+    const int within = (int)(e & 255), ln = within >> 2, j = within & 3;
+    const int n = (int)(tile % NBk) * 16 + (ln & 15), k = (int)(tile / NBk) * 16 + 4 * (ln >> 4) + j;
+    out[e] = (n < N && k < K) ? W[(long long)n * ldw + k] : 0.f;
+  }
+}
+
+extern "C" size_t tgmx_tgat_tile16_floats(int32_t N, int32_t K) {
+  return N > 0 && K > 0 ? (size_t)((N + 15) / 16) * (size_t)((K + 15) / 16) * 256 : 0;
+}
+
+extern "C" int tgmx_tgat_tile16(const float* W, int64_t ldw, int32_t N, int32_t K, float* out, tgmx_stream_t stream) {
+  TGMX_REQUIRE(N >= 0 && K >= 0 && ldw >= K, "tgat_tile16: bad shape");
+  if (N == 0 || K == 0) return TGMX_OK;
+  TGMX_REQUIRE(W && out, "tgat_tile16: null pointer");
+  const long long total = (long long)tgmx_tgat_tile16_floats(N, K);
+  long long blocks = (total + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(tile16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, W, (long long)ldw, N, K, out);
+  TGMX_CHECK_LAUNCH("tgat_tile16");
+  return TGMX_OK;
+}
+
+static long long* g_chain_dbg = nullptr;
+extern "C" void tgmx_debug_chain_times(long long* p) { g_chain_dbg = p; }
+
+// The transposed 16-row-tile chain (tgat_chain64_kernel).  Returns TGMX_E_UNSUPPORTED (no error text) when the layer does not
+// fit it (a stage wider than 192 columns, no tiled weights) -- the caller falls back to tgat_post_chain_kernel / the unfused kernels.
+static int launch_chain64(const tgmx_tgat_layer_t& ly, const tgmx_tgat_layer_layout_t& lo, const float* zbar, const float* x,
+                          long long ldx, const float* tb, const float* z0, int d0, long long R, float* out, long long ldo,
+                          hipStream_t st, bool dry) {
+  static const bool off = [] { const char* e = getenv("TGMX_CHAIN64"); return e && atoi(e) == 0; }();  // A/B knob
+  if (off || !ly.W_V_t16 || !ly.W_O_t16 || !ly.fc1_t16 || !ly.fc2_t16) return TGMX_E_UNSUPPORTED;
+  const int blocks[4] = {(ly.O / ly.H + 15) / 16, (ly.O + 15) / 16, (ly.emb + 15) / 16, (ly.emb_out + 15) / 16};
+  for (int b : blocks)
+    if (b > kC64MaxB) return TGMX_E_UNSUPPORTED;
+  ChainArgs g{};
+  g.zbar = zbar; g.x = x; g.tb = tb; g.z0 = z0;
+  g.W_V = ly.W_V_t16; g.W_O = ly.W_O_t16; g.b_O = ly.b_O; g.ln_g = ly.ln_g; g.ln_b = ly.ln_b;
+  g.fc1_w = ly.fc1_t16; g.fc1_b = ly.fc1_b; g.fc2_w = ly.fc2_t16; g.fc2_b = ly.fc2_b;
+  g.out = out; g.R = R; g.ld_zbar = (long long)ly.H * lo.Cp; g.ldx = ldx; g.ldo = ldo;
+  g.d = ly.d; g.T = ly.T; g.d0 = d0; g.O = ly.O; g.H = ly.H; g.C = ly.d + ly.D + ly.T; g.emb = ly.emb; g.emb_out = ly.emb_out;
+  g.Cp = lo.Cp; g.Op = lo.Op; g.Kc = lo.Kc; g.Ep = lo.Ep; g.eps = ly.ln_eps;
+  // slab row: every stage's padded width (stage 1 writes 16-column blocks from column (H - 1) dh on)
+  int kmax = ly.O + d0;
+  if (ly.emb > kmax) kmax = ly.emb;
+  if ((ly.H - 1) * (ly.O / ly.H) + 16 * blocks[0] > kmax) kmax = (ly.H - 1) * (ly.O / ly.H) + 16 * blocks[0];
+  g.LD = (kmax + 15) / 16 * 16 + 4;
+  const size_t lds = ((size_t)3 * kC64ChunkTiles * 256 + kC64Waves * 256 + (size_t)kC64Waves * 16 * g.LD + 16 * (size_t)(3 * blocks[1] + blocks[2] + blocks[3]) +
+                      64 * (size_t)ly.d + 64 * (size_t)d0) * sizeof(float);
+  if (lds > 160 * 1024) return TGMX_E_UNSUPPORTED;
+  if (dry) return TGMX_OK;
+  g.dbg_t = g_chain_dbg;
+  { const char* e = getenv("TGMX_C64_MODE"); g.dbg_mode = e ? atoi(e) : 0; }
+  static bool attr_set = false;
+  if (!attr_set) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tgat_chain64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+      set_error("tgat_forward: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+      return TGMX_E_LAUNCH;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(tgat_chain64_kernel, dim3((unsigned)((R + 63) / 64)), dim3(kC64Threads), lds, st, g);
+  TGMX_CHECK_LAUNCH("tgat_chain64");
+  return TGMX_OK;
+}
+
 extern "C" int tgmx_tgat_forward(const tgmx_tgat_model_t* m, const float* node_x, int64_t num_nodes, const int32_t* seed_ids,
                                  int64_t S0, const tgmx_tgat_hop_t* hops, float* workspace, size_t workspace_bytes, int32_t save,
                                  float* out, tgmx_stream_t stream) {
@@ -1320,7 +1825,10 @@ extern "C" int tgmx_tgat_forward(const tgmx_tgat_model_t* m, const float* node_x
     float* probs = lo.probs >= 0 ? base + lo.probs : nullptr;
     float* nxt = (j == L) ? out : base + lo.out;
     const long long ld_nxt = ly.emb_out;  // layer outputs stay densely packed: they are the next layer's neighbor features
-    const bool chain = !save && R >= 2048;     // the fused tail rebuilds the residual itself
+    // inference, enough row tiles to fill the chip: the whole tail of the layer is one kernel over row tiles (both variants
+    // rebuild the residual themselves) -- 64-row workgroups of 16-row MFMA tiles when the layer fits that kernel, else 32-row tiles
+    const bool chain = !save && R >= 2048;
+    const bool chain64 = chain && launch_chain64(ly, lo, nullptr, nullptr, 0, nullptr, nullptr, d0, R, nullptr, 0, nullptr, true) == TGMX_OK;
     const bool folded = !save && ly.qf_U != nullptr;  // inference: qf = x . U^T + v in one GEMM, no Q / rres round trip
     const int dp = (ly.d + 3) / 4 * 4;
     if (!folded || !chain)
@@ -1357,8 +1865,13 @@ extern "C" int tgmx_tgat_forward(const tgmx_tgat_model_t* m, const float* node_x
       TGMX_REQUIRE(ld_prev == ly.d, "tgat_forward: layer %d expects densely packed input rows", j);
       if (a.R > 0 && (rc = attn_reduce_impl(a, H, (hipStream_t)stream))) return rc;
     }
-    if (chain) {  // inference, enough row tiles to fill the chip: the whole tail of the layer is one row-tile kernel,
-                  // intermediates stay in LDS
+    if (chain64) {
+      if ((rc = launch_chain64(ly, lo, zbar, prev, ld_prev, m->tb, z0, d0, R, nxt, ld_nxt, (hipStream_t)stream, false))) return rc;
+      prev = nxt;
+      ld_prev = ld_nxt;
+      continue;
+    }
+    if (chain) {  // intermediates stay in LDS
       if ((rc = launch_post_chain(ly, lo, zbar, prev, ld_prev, m->tb, z0, d0, R, nxt, ld_nxt, (hipStream_t)stream))) return rc;
       prev = nxt;
       ld_prev = ld_nxt;

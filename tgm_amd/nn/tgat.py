@@ -142,6 +142,23 @@ class TGAT(nn.Module):
                 _ops.sgemm_nt(M[:, O - T_ :], ct, v[h * Cp : h * Cp + C])
             keep += [U, v]
             ly.qf_U, ly.qf_v = U.data_ptr(), v.data_ptr()
+            # the tail's weights in the tiled order its one-kernel form streams them in (tgmx_tgat_tile16)
+            merge = self.merge_layers[l]
+            lib = _native.load()
+
+            def tiled(w: Tensor, heads: int = 1) -> int:
+                w = w.detach().float().contiguous()
+                n, k = w.shape[0] // heads, w.shape[1]
+                per = lib.tgmx_tgat_tile16_floats(n, k)
+                out = torch.empty(heads * per, dtype=torch.float32, device=dev)
+                for h in range(heads):
+                    _native.check(lib.tgmx_tgat_tile16(w[h * n :].data_ptr(), k, n, k, out[h * per :].data_ptr(), _native.stream_ptr()),
+                                  'tgmx_tgat_tile16')
+                keep.extend([w, out])
+                return out.data_ptr()
+
+            ly.W_V_t16, ly.W_O_t16 = tiled(WKV[O:], H), tiled(attn.W_O.weight)
+            ly.fc1_t16, ly.fc2_t16 = tiled(merge.fc1.weight), tiled(merge.fc2.weight)
         self._desc_folded = True
 
     def forward(self, node_x: Tensor, seed_nids: List[Tensor], seed_times: List[Tensor], nbr_nids: List[Tensor],
