@@ -126,6 +126,18 @@ def test_tgat_forward_matches_reference(case):
     close(z, z_ref, case)
 
 
+def test_unsupported_head_count_fails_loudly():
+    """The attention kernels exist for 1, 2, 4 and 8 heads; anything else must raise, not compute something else."""
+    from tgm_amd.nn import TGAT
+
+    enc = TGAT(node_dim=6, edge_dim=4, time_dim=9, embed_dim=12, num_layers=1, n_heads=3).to(DEV).eval()
+    n = torch.randint(0, 50, (8, 5), dtype=torch.int32, device=DEV)
+    with pytest.raises(RuntimeError, match='n_heads'):
+        enc(torch.randn(50, 6, device=DEV), [torch.arange(8, dtype=torch.int32, device=DEV)], [torch.full((8,), 100, dtype=torch.int64, device=DEV)],
+            [n], [torch.randn(8, 5, 4, device=DEV)], [torch.randint(1, 90, (8, 5), dtype=torch.int64, device=DEV)])
+        torch.cuda.synchronize()
+
+
 def test_tgat_headline_shape_vs_oracle():
     """Example dims at the headline batch shape (600 seeds, k=[20,20] -> 12 600 attention rows in layer 1),
     sampler outputs produced by the HIP sampler, embeddings vs the torch-fp32 oracle."""
@@ -160,7 +172,8 @@ def test_tgat_headline_shape_vs_oracle():
 
 
 @pytest.mark.parametrize('nd,ed,td,emb,H,ks,S0,L', [(8, 12, 16, 32, 4, [16, 16], 144, 2), (3, 8, 10, 20, 1, [30], 2100, 1), (16, 4, 6, 24, 2, [8, 8, 8], 40, 3),
-                                                   (1, 16, 12, 16, 8, [20, 20], 110, 2)])
+                                                   (1, 16, 12, 16, 8, [20, 20], 110, 2), (40, 60, 88, 190, 4, [6], 2100, 1),
+                                                   (21, 9, 30, 76, 4, [5, 5], 400, 2)])
 def test_tgat_fused_inference_paths_vs_oracle(nd, ed, td, emb, H, ks, S0, L):
     """Shapes that take the fused row-tile chain (>= 2048 rows in a layer) and the folded-query GEMM with other head
     counts, widths, depths and k than the example dims; random hop trees with pads (-1 ids, zero times / features)."""

@@ -286,8 +286,6 @@ struct ChainArgs {
   int Cp, Op, Kc, Ep;  // row strides of the padded weight copies
   int LD;              // LDS row stride in floats
   float eps;
-  long long* dbg_t;
-  int dbg_mode;
 };
 
 template <bool A_LDS>
@@ -495,29 +493,38 @@ __global__ __launch_bounds__(kChainThreads) void tgat_post_chain_kernel(const Ch
 // Tiles of 16 rows and Y^T = W . X^T on v_mfma_f32_16x16x4_f32: the WEIGHT rows are the MFMA's A operand (lane (n, kq) holds
 // W[n][16 kb + 4 kq + j]) and the activations its B operand (lane (r, kq) holds X[r][16 kb + 4 kq + j]).  The result lands as
 // lane (r, rq) <- Y[r][16 nb + 4 rq + j]: four consecutive columns of the lane's own row, so a stage's output goes back to
-// the wave's activation slab in LDS as 16-byte row pieces and the next stage reads it the same way.  One wave owns one
-// 16-row tile through all five stages -- its NB <= 12 output blocks are NB independent accumulators per k-step, which keeps
-// the matrix pipe issuing back to back (32 cycles each, 40 dependent) -- and needs no partner: 12 600 rows are 788 waves.
+// the tile's activation slab in LDS as 16-byte row pieces and the next stage reads it the same way; no stage but the last
+// touches global memory.  A workgroup is 64 rows = 4 tiles x 2 waves (the two waves of a tile own the even and the odd
+// 16-column output blocks: <= 6 independent accumulators per k-step each); 12 600 rows are 197 workgroups, one per CU.
 //
-// What bounds this kernel is the CU's load path, not the matrix pipe: a CU takes ~12 bytes per clock from L2 however the
-// loads are shaped (measured: one wave per tile streaming its own copy of the weights from L2 = 1.8 MB per CU = 66 us, the
-// same with row-major or tiled weights, with deeper prefetch, and with the MFMAs removed).  So the FOUR waves of a
-// workgroup (64 rows, one CU) share each weight chunk: 24 tiles (24 KB) are copied global -> registers -> LDS by all
-// 256 threads, double-buffered one chunk ahead, one barrier per chunk, and every wave feeds its MFMAs from LDS
-// (ds_read_b128, 256 B/clk).  Per CU that is 0.4 MB of weights + 0.14 MB of zbar against 51k cycles of MFMA per wave.
-// The weights come pre-tiled (tgmx_tgat_tile16) in the order the chunks are consumed, so a chunk is one contiguous range.
+// What the first versions taught (per-phase cycle stamps, 12 600 rows; the MFMAs alone are 51k cycles per SIMD):
+// * one wave per tile streaming its own copy of the weights from L2: 66 us -- a CU takes ~12 bytes per clock from L2 however
+//   the loads are shaped (row-major or tiled weights, deeper prefetch, MFMAs removed: all the same), and that was 1.8 MB;
+// * so the waves of a CU share each weight chunk through LDS (24 tiles = 24 KB by LDS-DMA, 0.4 MB per CU in all), the weights
+//   come pre-tiled (tgmx_tgat_tile16) in the order the chunks are consumed, and the five GEMMs are one chunk stream;
+// * every dependent LDS access of a one-wave-per-SIMD kernel is exposed: biases / LayerNorm vectors are zero-padded float4
+//   reads, LayerNorm runs on the accumulators (the row statistics are two shuffles and one LDS exchange away), padding
+//   columns are written as zeros so that no activation read needs a guard;
+// * a burst of VMEM instructions blocks the wave (~50 cycles per KB at the CU's address unit): memory instructions are woven
+//   one at a time between groups of MFMAs, by hand, pinned with scheduling fences (C64Gemm::run).
+// 159k cycles (tgat_post_chain_kernel, 69 us) -> 119k (51 us).  Still 2.3 x the MFMA time: the per-chunk bookkeeping between
+// the MFMA groups does not overlap with them (measured: removing DMA, tile reads and barriers leaves ~1.9k cycles per chunk
+// iteration); the next step is fewer, longer chunks without the k-step waste that a 48-tile chunk costs at these widths.
 // ---------------------------------------------------------------------------
 using floatx4 = __attribute__((__vector_size__(4 * sizeof(float)))) float;
 
-constexpr int kC64Waves = 4;
+constexpr int kC64Tiles = 4;               // 16-row tiles per workgroup
+constexpr int kC64Waves = 2 * kC64Tiles;   // two waves per tile (each owns every other output block): 2 waves per SIMD, so one
+                                           // wave's memory-instruction issue and LDS latencies hide behind the other's MFMAs
 constexpr int kC64Threads = kC64Waves * kWave;
 constexpr int kC64ChunkTiles = 24;  // weight tiles (1 KB each) per LDS buffer
+constexpr int kC64Ring = 3;          // LDS buffers: chunk p lives in buffer p % kC64Ring and is issued kC64Ring - 1 chunks ahead
 constexpr int kC64MaxB = 12;        // output blocks per stage: N <= 192
 __host__ __device__ constexpr int c64_steps(int nb) { return kC64ChunkTiles / nb < 8 ? kC64ChunkTiles / nb : 8; }  // k-steps per chunk
 
 // The weights of the five GEMMs are ONE stream of chunks (<= 24 tiles each) through a ring of three LDS buffers: chunk p
 // lives in buffer p % 3 and is issued as LDS-DMA two chunks before it is consumed, across GEMM boundaries, so a DMA has two
-// chunks of MFMAs (~6000 cycles) to land and no GEMM starts with an exposed load.  Wave w moves tiles w, w + 4, ... of a
+// chunks of MFMAs (~6000 cycles) to land and no GEMM starts with an exposed load.  Wave w moves tiles w, w + 8, ... of a
 // chunk, 1 KB per instruction (destination = wave-uniform tile base + 16 bytes per lane), and ALWAYS issues kC64Issue
 // instructions per chunk (a tile it has no use for goes to a dummy slot): the wait at the end of an iteration is the
 // counted `s_waitcnt vmcnt(kC64Issue)` -- everything but the newest chunk has landed -- followed by a raw s_barrier
@@ -554,8 +561,8 @@ __device__ __forceinline__ C64Moves c64_next_moves(const C64Stream st, int& ck, 
   const int nch = kind == 0 ? st.nch_V : kind == 1 ? st.nch_O : kind == 2 ? st.nch_F1 : st.nch_F2;
   const int ntiles = kind == 0 ? st.nt_V : kind == 1 ? st.nt_O : kind == 2 ? st.nt_F1 : st.nt_F2;
   const int first = cc * CT, count = live ? CT : 0;
-  float* buf = wbuf + (cp % 3) * (kC64ChunkTiles * 256);
-  float* dummy = wbuf + 3 * (kC64ChunkTiles * 256) + wave * 256;
+  float* buf = wbuf + (cp % kC64Ring) * (kC64ChunkTiles * 256);
+  float* dummy = wbuf + kC64Ring * (kC64ChunkTiles * 256) + wave * 256;
   C64Moves m;
 #pragma unroll
   for (int i = 0; i < kC64Issue; ++i) {
@@ -592,123 +599,123 @@ __device__ __forceinline__ void c64_sync() {
   asm volatile("" ::: "memory");
 }
 
-// One GEMM of the chain for the four waves of the workgroup at once (every thread must call it):
-//   acc[i] (i < NB) <- W[16 i .. 16 i + 16, 0 .. K) . X[the wave's 16 rows, 0 .. K)^T,
+__device__ __forceinline__ void c64_lds_barrier() {  // LDS writes of the workgroup visible; never drains the DMA queue
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// One GEMM of the chain for the eight waves of the workgroup at once (every thread must call it): wave (tile, HALF) computes
+//   acc[i] (i < NBW) <- W[16 b .. 16 b + 16, 0 .. K) . X[the tile's 16 rows, 0 .. K)^T   for its blocks b = HALF + 2 i < NBT,
 // the weights being the next chunks of the stream (q = position of this GEMM's first chunk, advanced).  XG: the activations
 // come from global memory (the lane's zbar row, padded length Kxp) and xc holds the first chunk's on entry; xnext = the
 // next GEMM's row, whose first chunk is fetched into xc during this one's last.  Otherwise xrow is the lane's row of the
-// wave's LDS slab.
-template <int NB, bool XG>
+// tile's LDS slab (written by both waves of the tile: the GEMM starts with a barrier).
+template <int NBT, int HALF, bool XG>
 struct C64Gemm {
-  static constexpr int CK = c64_steps(NB);  // k-steps per chunk
-  static constexpr int CT = CK * NB;        // tiles per chunk
+  static constexpr int CK = c64_steps(NBT);          // k-steps per chunk
+  static constexpr int CT = CK * NBT;                // tiles per chunk
+  static constexpr int NBW = (NBT + 1 - HALF) / 2;   // this wave's blocks
+  static constexpr int NBS = NBW > 0 ? NBW : 1;      // (array extents)
 
-  // the lane's activations of k-steps [c CK, (c + 1) CK): forced to zero past K (a slab column past K holds an older stage,
-  // zbar padding is not initialised; the weight tiles carry zeros there)
-  static __device__ __forceinline__ void xfetch(float4 (&xd)[CK], const float* __restrict__ xrow, int c, int K, int Kxp, int lane) {
-    const int KB = (K + 15) / 16, k4l = (lane >> 4) * 4, kx_last = Kxp - 4;
-#pragma unroll
-    for (int s = 0; s < CK; ++s) {
-      int kb = c * CK + s;
-      kb = kb < KB ? kb : KB - 1;
-      const int k4 = kb * 16 + k4l;
-      float4 x;
-      if constexpr (XG) x = *reinterpret_cast<const float4*>(xrow + (k4 < kx_last ? k4 : kx_last));
-      else x = *reinterpret_cast<const float4*>(xrow + k4);
-      xd[s].x = k4 < K ? x.x : 0.f;
-      xd[s].y = k4 + 1 < K ? x.y : 0.f;
-      xd[s].z = k4 + 2 < K ? x.z : 0.f;
-      xd[s].w = k4 + 3 < K ? x.w : 0.f;
-    }
-  }
-
-  // one activation vector (k-step kb) of a row: zero past K
+  // One activation vector (k-step kb) of the lane's row.  Slab rows need no guard: every stage writes its padding columns as
+  // zeros (zero-padded tiles and biases), so a column past K is either zero or multiplies a zero weight.  zbar's padding
+  // [C, Cp) is not initialised: the last k-block (only) is masked.
   static __device__ __forceinline__ float4 xload(const float* __restrict__ xrow, int kb, int K, int Kxp, int lane) {
-    const int KB = (K + 15) / 16, k4l = (lane >> 4) * 4, kx_last = Kxp - 4;
+    const int KB = (K + 15) / 16, k4l = (lane >> 4) * 4;
     kb = kb < KB ? kb : KB - 1;
     const int k4 = kb * 16 + k4l;
-    float4 x;
-    if constexpr (XG) x = *reinterpret_cast<const float4*>(xrow + (k4 < kx_last ? k4 : kx_last));
-    else x = *reinterpret_cast<const float4*>(xrow + k4);
-    return float4{k4 < K ? x.x : 0.f, k4 + 1 < K ? x.y : 0.f, k4 + 2 < K ? x.z : 0.f, k4 + 3 < K ? x.w : 0.f};
+    if constexpr (!XG) {
+      return *reinterpret_cast<const float4*>(xrow + k4);
+    } else {
+      const int kx_last = Kxp - 4;
+      float4 x = *reinterpret_cast<const float4*>(xrow + (k4 < kx_last ? k4 : kx_last));
+      if (kb == KB - 1) x = float4{k4 < K ? x.x : 0.f, k4 + 1 < K ? x.y : 0.f, k4 + 2 < K ? x.z : 0.f, k4 + 3 < K ? x.w : 0.f};
+      return x;
+    }
   }
 
   // The chunk loop is software-pipelined BY HAND and pinned with scheduling fences, because what stalls this kernel is issue
-  // order: a VMEM instruction blocks the wave while the CU's address unit takes it (~50 cycles per KB, and all four waves
-  // come out of the barrier together: the 6 DMAs of a chunk issued in a burst = 1200 cycles of idle matrix pipe per chunk,
-  // 28k of the kernel's 130k cycles), and a tile read issued right before its MFMAs exposes the LDS latency 60 times.  So,
-  // between every two groups of NB MFMAs: ONE memory instruction group -- first the next chunk's activations (ordinary loads,
-  // older than the DMAs: the counted wait covers them), then the six DMAs of chunk q + 2, and a quarter of the next k-step's
-  // tile reads.  The wait + barrier that retires chunk q + 1 sits before the LAST group of MFMAs of chunk q, followed by the
-  // first tile reads of chunk q + 1, which that last group covers.
+  // order: a VMEM instruction blocks the wave while the CU's address unit takes it (~50 cycles per KB, and the waves come
+  // out of a barrier together: the DMAs of a chunk issued in a burst = 1200 cycles of idle matrix pipe per chunk, 28k of
+  // the first version's 130k cycles), and a tile read issued right before its MFMAs exposes the LDS latency 60 times.  So,
+  // between every two groups of NBW MFMAs: at most one VMEM instruction (this wave's three DMAs of chunk q + 2 in groups
+  // CK .. CK + 2; after the last group of every k-step the next chunk's activation vector for that step, straight into the
+  // register the step just released) and a quarter of the next k-step's tile reads.  The wait + barrier that retires chunk
+  // q + 1 sits before the LAST group of MFMAs of chunk q, followed by the first tile reads of chunk q + 1, which that last
+  // group covers.  The two waves that share a SIMD (w and w + 4) run half a group apart (one sleeps 128 cycles after every
+  // barrier), so that one's memory / address instructions fall into the other's MFMAs instead of both idling the pipe.
   static __device__ __forceinline__ void run(const C64Stream st, int& ck, int& cc, int& cp, int& q, int K, const float* __restrict__ xrow, int Kxp,
-                                             float4 (&xc)[CK], const float* __restrict__ xnext, float* __restrict__ wbuf, floatx4 (&acc)[NB], int tid,
-                                             int dbg_mode = 0, long long* tacc = nullptr) {
-    static_assert(4 * CK >= CK + kC64Issue, "not enough MFMA groups per chunk to carry the loads");
-    constexpr int Q4 = (NB + 3) / 4;  // tile reads per MFMA group
+                                             float4 (&xc)[CK], const float* __restrict__ xnext, float* __restrict__ wbuf, floatx4 (&acc)[NBS], int tid) {
+    static_assert(4 * CK > CK + kC64Issue, "not enough MFMA groups per chunk to carry the loads");
+    constexpr int Q4 = (NBW + 3) / 4;  // tile reads per MFMA group
     const int lane = tid & 63;
+    const bool late = (tid >> 8) != 0;  // waves 4 .. 7
     const int KB = (K + 15) / 16, nchunks = (KB + CK - 1) / CK;
 #pragma unroll
-    for (int i = 0; i < NB; ++i) acc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < NBS; ++i) acc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
     if constexpr (!XG) {
+      c64_lds_barrier();  // the previous stage's slab writes of both waves of the tile
 #pragma unroll
       for (int s = 0; s < CK; ++s) xc[s] = xload(xrow, s, K, Kxp, lane);
     }
-    float4 w[2][NB];
+    float4 w[2][NBS];
     {
-      const float* wl = wbuf + (q % 3) * (kC64ChunkTiles * 256) + lane * 4;
+      const float* wl = wbuf + (q % kC64Ring) * (kC64ChunkTiles * 256) + lane * 4;
 #pragma unroll
-      for (int i = 0; i < NB; ++i) w[0][i] = *reinterpret_cast<const float4*>(wl + i * 256);
+      for (int i = 0; i < NBW; ++i) w[0][i] = *reinterpret_cast<const float4*>(wl + (HALF + 2 * i) * 256);
     }
+    C64Moves mv = c64_next_moves(st, ck, cc, cp, wbuf, tid);  // position q + 2
     for (int c = 0; c < nchunks; ++c) {
       const bool more = c + 1 < nchunks;
       const float* xsrc = more ? xrow : (XG && xnext ? xnext : xrow);
       const int cnext = more ? c + 1 : 0;
-      const C64Moves mv = c64_next_moves(st, ck, cc, cp, wbuf, tid);  // position q + 2
-      const float* wl = wbuf + (q % 3) * (kC64ChunkTiles * 256) + lane * 4;
-      const float* wl_next = wbuf + ((q + 1) % 3) * (kC64ChunkTiles * 256) + lane * 4;
-      float4 xn[CK];
+      C64Moves mv_next = mv;
+      const float* wl = wbuf + (q % kC64Ring) * (kC64ChunkTiles * 256) + lane * 4;
+      const float* wl_next = wbuf + ((q + 1) % kC64Ring) * (kC64ChunkTiles * 256) + lane * 4;
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int s = 0; s < CK; ++s) {
-        // k-step s reads w[(s & 1) ^ par]: par flips per chunk when CK is odd -- so keep it simple: the parity of s within
-        // the chunk selects the register set and an odd CK copies once at the end of the chunk
-        float4(&wc)[NB] = w[s & 1];
-        float4(&wn)[NB] = w[(s & 1) ^ 1];
+        float4(&wc)[NBS] = w[s & 1];  // k-step s of a chunk reads register set s & 1 (an odd CK copies once per chunk)
+        float4(&wn)[NBS] = w[(s & 1) ^ 1];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int grp = 4 * s + j;
-          if (s == CK - 1 && j == 3) {  // chunk q + 1 has landed, everybody is done reading chunk q: its first tiles can be fetched
-            c64_sync<(3 * CK - 1 < kC64Issue ? 3 * CK - 1 : kC64Issue)>();  // = the DMAs of chunk q + 2 issued so far: all that may stay in flight
+          if (s == CK - 1 && j == 3) {
+            // chunk q + 1 has landed and everybody is done reading chunk q.  In flight may stay: the newest kC64Issue VMEM
+            // operations, all of which are younger than chunk q + 1's DMAs
+            c64_sync<(kC64Ring - 2) * kC64Issue>();
+            if (late) __builtin_amdgcn_s_sleep(2);
             if (more) {
 #pragma unroll
-              for (int i = 0; i < NB; ++i) wn[i] = *reinterpret_cast<const float4*>(wl_next + i * 256);
+              for (int i = 0; i < NBW; ++i) wn[i] = *reinterpret_cast<const float4*>(wl_next + (HALF + 2 * i) * 256);
             }
             __builtin_amdgcn_sched_barrier(0);
           }
 #pragma unroll
-          for (int i = 0; i < NB; ++i) {
+          for (int i = 0; i < NBW; ++i) {
             const float a = j == 0 ? wc[i].x : j == 1 ? wc[i].y : j == 2 ? wc[i].z : wc[i].w;
             const float b = j == 0 ? xc[s].x : j == 1 ? xc[s].y : j == 2 ? xc[s].z : xc[s].w;
             acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
           }
           __builtin_amdgcn_sched_barrier(0);
-          if (grp < CK) xn[grp] = xload(xsrc, cnext * CK + grp, K, Kxp, lane);
-          else if (grp < CK + kC64Issue) c64_dma(mv.src[grp - CK], mv.dst[grp - CK]);
+          // the next iteration's address arithmetic in the shadow of these MFMAs
+          if (grp == CK + kC64Issue && more) mv_next = c64_next_moves(st, ck, cc, cp, wbuf, tid);
+          if (grp >= CK && grp < CK + kC64Issue) c64_dma(mv.src[grp - CK], mv.dst[grp - CK]);
+          if (j == 3) xc[s] = xload(xsrc, cnext * CK + s, K, Kxp, lane);  // step s is done with xc[s]
           if (s + 1 < CK) {
 #pragma unroll
-            for (int i = j * Q4; i < (j + 1) * Q4 && i < NB; ++i) wn[i] = *reinterpret_cast<const float4*>(wl + ((s + 1) * NB + i) * 256);
+            for (int i = j * Q4; i < (j + 1) * Q4 && i < NBW; ++i) wn[i] = *reinterpret_cast<const float4*>(wl + ((s + 1) * NBT + HALF + 2 * i) * 256);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
       }
       if constexpr ((CK & 1) == 1) {  // the next chunk's step 0 was read into w[1]: step 0 always reads w[0]
 #pragma unroll
-        for (int i = 0; i < NB; ++i) w[0][i] = w[1][i];
+        for (int i = 0; i < NBW; ++i) w[0][i] = w[1][i];
       }
       ++q;
-#pragma unroll
-      for (int s = 0; s < CK; ++s) xc[s] = xn[s];
+      mv = mv_next;
     }
   }
 };
@@ -728,26 +735,23 @@ __global__ __launch_bounds__(kC64Threads) void tgat_chain64_kernel(const ChainAr
   constexpr int NT = kC64Threads;
   const int O = g.O, H = g.H, dh = O / H, LD = g.LD, T = g.T, d = g.d, d0 = g.d0;
   const int nbO = (O + 15) / 16, nbE = (g.emb + 15) / 16, nbEo = (g.emb_out + 15) / 16;
-  float* wbuf = c64_lds;                            // [3][24 tiles x 256] weight chunks + one dummy tile per wave
-  float* slabs = wbuf + 3 * kC64ChunkTiles * 256 + kC64Waves * 256;  // [4 waves][16, LD] activations, one slab per wave
-  float* br = slabs + kC64Waves * 16 * LD;          // [16 nbO]  b_O + the residual's time part cos(tb), zero-padded
+  float* wbuf = c64_lds;                                             // [3][24 tiles x 256] weight chunks + one dummy tile per wave
+  float* slabs = wbuf + kC64Ring * kC64ChunkTiles * 256 + kC64Waves * 256;  // [4 tiles][16, LD] activations
+  float* br = slabs + kC64Tiles * 16 * LD;          // [16 nbO]  b_O + the residual's time part cos(tb), zero-padded
   float* lg = br + 16 * nbO;                        // [16 nbO]  LayerNorm weight, zero-padded
   float* lb = lg + 16 * nbO;                        // [16 nbO]  LayerNorm bias, zero-padded
   float* b1 = lb + 16 * nbO;                        // [16 nbE]  zero-padded
   float* b2 = b1 + 16 * nbE;                        // [16 nbEo] zero-padded
-  float* xs = b2 + 16 * nbEo;                       // [64, d]  residual feature part
+  float* stat = b2 + 16 * nbEo;                     // [4 tiles][2 halves][16 rows] LayerNorm partial sums
+  float* xs = stat + kC64Waves * 16;                // [64, d]  residual feature part
   float* zs = xs + 64 * d;                          // [64, d0] skip features
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tile = wave >> 1, half = wave & 1;
   const int r = lane & 15, rq = lane >> 4;
   const long long w0 = (long long)blockIdx.x * 64;  // first row of the workgroup
-  const long long m0 = w0 + wave * 16;              // first row of this wave's tile
+  const long long m0 = w0 + tile * 16;              // first row of this wave's tile
   const int wrows = (g.R - w0) < 64 ? (int)(g.R - w0) : 64;
   const int rows = g.R - m0 < 0 ? 0 : (g.R - m0 < 16 ? (int)(g.R - m0) : 16);  // 0: the wave only helps with the copies
-  float* slab = slabs + wave * 16 * LD;
-  long long* dbg = g.dbg_t ? g.dbg_t + ((long long)blockIdx.x * kC64Waves + wave) * 8 : nullptr;
-  auto stamp = [&](int i) { if (dbg && lane == 0) dbg[i] = (long long)__builtin_readcyclecounter(); };
-  long long tacc[4] = {0, 0, 0, 0};
-  stamp(0);
+  float* slab = slabs + tile * 16 * LD;
   const int HB = (dh + 15) / 16, KBc = (g.C + 15) / 16;
   int q = 0;
   C64Stream st;
@@ -759,10 +763,10 @@ __global__ __launch_bounds__(kC64Threads) void tgat_chain64_kernel(const ChainAr
   c64_geom(nbE, O + d0, st.CT_F1, st.nch_F1, st.nt_F1);
   c64_geom(nbEo, g.emb, st.CT_F2, st.nch_F2, st.nt_F2);
   // the slabs and the weight ring start as zeros: a partial chunk's trailing k-steps multiply whatever the ring holds with zeros
-  for (int e = tid * 4; e < 3 * kC64ChunkTiles * 256 + kC64Waves * 256 + kC64Waves * 16 * LD; e += NT * 4)
+  for (int e = tid * 4; e < kC64Ring * kC64ChunkTiles * 256 + kC64Waves * 256 + kC64Tiles * 16 * LD; e += NT * 4)
     *reinterpret_cast<float4*>(wbuf + e) = float4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
-  for (int u = 0; u < 2; ++u) {  // the first two weight chunks fly during the rest of the prologue
+  for (int u = 0; u < kC64Ring - 1; ++u) {  // the first weight chunks fly during the rest of the prologue
     const C64Moves mv = c64_next_moves(st, ck, cc, cp, wbuf, tid);
 #pragma unroll
     for (int i = 0; i < kC64Issue; ++i) c64_dma(mv.src[i], mv.dst[i]);
@@ -789,131 +793,151 @@ __global__ __launch_bounds__(kC64Threads) void tgat_chain64_kernel(const ChainAr
     for (int e = tid + NT; e < wrows * d0; e += NT) zs[e] = g.z0[w0 * d0 + e];
   }
   __syncthreads();  // drains both DMAs too: the stream's first wait finds nothing in flight, which a counted wait allows
-  stamp(1);
+
+  // every stage below runs as <blocks of the stage, this wave's half>: both are workgroup- resp. wave-uniform
+  auto with_half = [&](auto nbc, auto&& f) __attribute__((always_inline)) {
+    if (half == 0) f(nbc, std::integral_constant<int, 0>{});
+    else f(nbc, std::integral_constant<int, 1>{});
+  };
 
   // stage 1: oattn (slab) -- per head, the lane's zbar row straight from global.  Head h writes columns h dh .. h dh + 16 HB:
-  // its zero padding (the tiles are zero past dh) is overwritten by head h + 1, the last head's lands past O where no stage looks
+  // its zero padding (the tiles are zero past dh) is overwritten by head h + 1 (a barrier later: the chunk barriers of head
+  // h + 1's GEMM order the two waves' writes), the last head's lands past O where no stage looks
   {
     long long grow = m0 + (r < rows ? r : rows - 1);
     grow = grow < g.R ? (grow < 0 ? 0 : grow) : g.R - 1;
     const float* zrow = g.zbar + grow * g.ld_zbar;
     chain64_dispatch<1, kC64MaxB>(HB, [&](auto nbc) __attribute__((always_inline)) {
-      constexpr int NB = decltype(nbc)::value;
-      using G = C64Gemm<NB, true>;
+      with_half(nbc, [&](auto nbc2, auto hc) __attribute__((always_inline)) {
+        constexpr int NBT = decltype(nbc2)::value, HALF = decltype(hc)::value;
+        using G = C64Gemm<NBT, HALF, true>;
+        float4 xc[G::CK];
+#pragma unroll
+        for (int s = 0; s < G::CK; ++s) xc[s] = G::xload(zrow, s, g.C, g.Cp, lane);
+        for (int h = 0; h < H; ++h) {
+          floatx4 acc[G::NBS];
+          const bool last = h + 1 == H;
+          G::run(st, ck, cc, cp, q, g.C, zrow + (long long)h * g.Cp, g.Cp, xc, last ? nullptr : zrow + (long long)(h + 1) * g.Cp, wbuf, acc, tid);
+#pragma unroll
+          for (int i = 0; i < G::NBW; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) slab[r * LD + h * dh + 16 * (HALF + 2 * i) + 4 * rq + j] = acc[i][j];
+          }
+        }
+      });
+    });
+  }
+  // stage 2 + 3: cat = [LayerNorm(oattn . W_O^T + b_O + residual) | z0].  The two waves of a tile hold whole rows between them
+  // (4 lanes x 4 NBW registers each): the statistics are two shuffles and one LDS exchange away, y never goes to LDS
+  chain64_dispatch<1, kC64MaxB>(nbO, [&](auto nbc) __attribute__((always_inline)) {
+    with_half(nbc, [&](auto nbc2, auto hc) __attribute__((always_inline)) {
+      constexpr int NBT = decltype(nbc2)::value, HALF = decltype(hc)::value;
+      using G = C64Gemm<NBT, HALF, false>;
       float4 xc[G::CK];
+      floatx4 acc[G::NBS];
+      G::run(st, ck, cc, cp, q, O, slab + r * LD, 0, xc, nullptr, wbuf, acc, tid);
+      float y[G::NBS][4];
+      float sum = 0.f;
 #pragma unroll
-      for (int s = 0; s < G::CK; ++s) xc[s] = G::xload(zrow, s, g.C, g.Cp, lane);
-      for (int h = 0; h < H; ++h) {
-        floatx4 acc[NB];
-        const bool last = h + 1 == H;
-        G::run(st, ck, cc, cp, q, g.C, zrow + (long long)h * g.Cp, g.Cp, xc, last ? nullptr : zrow + (long long)(h + 1) * g.Cp, wbuf, acc, tid, g.dbg_mode, tacc);
+      for (int i = 0; i < G::NBW; ++i) {
+        const int c0 = 16 * (HALF + 2 * i) + 4 * rq;
+        const float4 b = *reinterpret_cast<const float4*>(br + c0);
+        y[i][0] = acc[i][0] + b.x; y[i][1] = acc[i][1] + b.y; y[i][2] = acc[i][2] + b.z; y[i][3] = acc[i][3] + b.w;
+        if (16 * (HALF + 2 * i) < d) {  // the residual's feature part: the first ceil(d / 16) blocks only
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
+          for (int j = 0; j < 4; ++j)
+            if (c0 + j < d) y[i][j] += xs[(tile * 16 + r) * d + c0 + j];
+        }
 #pragma unroll
-          for (int j = 0; j < 4; ++j) slab[r * LD + h * dh + 16 * i + 4 * rq + j] = acc[i][j];
+        for (int j = 0; j < 4; ++j) sum += c0 + j < O ? y[i][j] : 0.f;
+      }
+      sum += __shfl_xor(sum, 16);
+      sum += __shfl_xor(sum, 32);
+      float* mystat = stat + (tile * 2 + HALF) * 16;
+      const float* other = stat + (tile * 2 + (HALF ^ 1)) * 16;
+      if (rq == 0) mystat[r] = sum;
+      c64_lds_barrier();
+      const float mean = (sum + other[r]) / (float)O;
+      float var = 0.f;
+#pragma unroll
+      for (int i = 0; i < G::NBW; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float u = 16 * (HALF + 2 * i) + 4 * rq + j < O ? y[i][j] - mean : 0.f;
+          var += u * u;
+        }
+      }
+      var += __shfl_xor(var, 16);
+      var += __shfl_xor(var, 32);
+      c64_lds_barrier();  // everybody has read the sums
+      if (rq == 0) mystat[r] = var;
+      c64_lds_barrier();
+      const float rstd = 1.0f / sqrtf((var + other[r]) / (float)O + g.eps);
+#pragma unroll
+      for (int i = 0; i < G::NBW; ++i) {
+        const int c0 = 16 * (HALF + 2 * i) + 4 * rq;
+        const float4 gw = *reinterpret_cast<const float4*>(lg + c0), gb = *reinterpret_cast<const float4*>(lb + c0);
+        // columns past O: weight and bias are zero-padded, so they are written as zeros
+        *reinterpret_cast<float4*>(slab + r * LD + c0) = float4{(y[i][0] - mean) * rstd * gw.x + gb.x, (y[i][1] - mean) * rstd * gw.y + gb.y,
+                                                                 (y[i][2] - mean) * rstd * gw.z + gb.z, (y[i][3] - mean) * rstd * gw.w + gb.w};
+      }
+      if (d0 > 0) {
+        c64_lds_barrier();  // the skip columns may share a block with LayerNorm's zero padding written by the other wave
+        if (HALF == 0) {
+          for (int e = lane; e < 16 * d0; e += 64) {
+            const int row = e / d0, c = e - row * d0;
+            slab[row * LD + O + c] = row < rows ? zs[(tile * 16 + row) * d0 + c] : 0.f;
+          }
         }
       }
     });
-  }
-  stamp(2);
-  // stage 2 + 3: cat = [LayerNorm(oattn . W_O^T + b_O + residual) | z0].  The wave holds whole rows (4 lanes x 4 NB registers
-  // each), so the statistics are two shuffles away and y never goes to LDS
-  chain64_dispatch<1, kC64MaxB>(nbO, [&](auto nbc) __attribute__((always_inline)) {
-    constexpr int NB = decltype(nbc)::value;
-    using G = C64Gemm<NB, false>;
-    float4 xc[G::CK];
-    floatx4 acc[NB];
-    G::run(st, ck, cc, cp, q, O, slab + r * LD, 0, xc, nullptr, wbuf, acc, tid, g.dbg_mode, tacc);
-    stamp(3);
-    float y[NB][4];
-    float sum = 0.f;
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const int c0 = 16 * i + 4 * rq;
-      const float4 b = *reinterpret_cast<const float4*>(br + c0);
-      y[i][0] = acc[i][0] + b.x; y[i][1] = acc[i][1] + b.y; y[i][2] = acc[i][2] + b.z; y[i][3] = acc[i][3] + b.w;
-      if (16 * i < d) {  // the residual's feature part: the first ceil(d / 16) blocks only
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (c0 + j < d) y[i][j] += xs[(wave * 16 + r) * d + c0 + j];
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) sum += c0 + j < O ? y[i][j] : 0.f;
-    }
-    sum += __shfl_xor(sum, 16);
-    sum += __shfl_xor(sum, 32);
-    const float mean = sum / (float)O;
-    float var = 0.f;
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float u = 16 * i + 4 * rq + j < O ? y[i][j] - mean : 0.f;
-        var += u * u;
-      }
-    }
-    var += __shfl_xor(var, 16);
-    var += __shfl_xor(var, 32);
-    const float rstd = 1.0f / sqrtf(var / (float)O + g.eps);
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const int c0 = 16 * i + 4 * rq;
-      const float4 gw = *reinterpret_cast<const float4*>(lg + c0), gb = *reinterpret_cast<const float4*>(lb + c0);
-      // columns past O: weight and bias are zero-padded, so they are written as zeros
-      *reinterpret_cast<float4*>(slab + r * LD + c0) = float4{(y[i][0] - mean) * rstd * gw.x + gb.x, (y[i][1] - mean) * rstd * gw.y + gb.y,
-                                                               (y[i][2] - mean) * rstd * gw.z + gb.z, (y[i][3] - mean) * rstd * gw.w + gb.w};
-    }
-    for (int e = lane; e < 16 * d0; e += 64) {
-      const int row = e / d0, c = e - row * d0;
-      slab[row * LD + O + c] = row < rows ? zs[(wave * 16 + row) * d0 + c] : 0.f;
-    }
   });
-  stamp(4);
   // stage 4: h1 = relu(cat . fc1^T + b1), in place
   chain64_dispatch<1, kC64MaxB>(nbE, [&](auto nbc) __attribute__((always_inline)) {
-    constexpr int NB = decltype(nbc)::value;
-    using G = C64Gemm<NB, false>;
-    float4 xc[G::CK];
-    floatx4 acc[NB];
-    G::run(st, ck, cc, cp, q, O + d0, slab + r * LD, 0, xc, nullptr, wbuf, acc, tid, g.dbg_mode, tacc);
+    with_half(nbc, [&](auto nbc2, auto hc) __attribute__((always_inline)) {
+      constexpr int NBT = decltype(nbc2)::value, HALF = decltype(hc)::value;
+      using G = C64Gemm<NBT, HALF, false>;
+      float4 xc[G::CK];
+      floatx4 acc[G::NBS];
+      G::run(st, ck, cc, cp, q, O + d0, slab + r * LD, 0, xc, nullptr, wbuf, acc, tid);
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const int c0 = 16 * i + 4 * rq;
-      const float4 b = *reinterpret_cast<const float4*>(b1 + c0);
-      float4 v{acc[i][0] + b.x, acc[i][1] + b.y, acc[i][2] + b.z, acc[i][3] + b.w};  // columns past emb: zero tiles + zero bias
-      v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
-      *reinterpret_cast<float4*>(slab + r * LD + c0) = v;
-    }
+      for (int i = 0; i < G::NBW; ++i) {
+        const int c0 = 16 * (HALF + 2 * i) + 4 * rq;
+        const float4 b = *reinterpret_cast<const float4*>(b1 + c0);
+        float4 v{acc[i][0] + b.x, acc[i][1] + b.y, acc[i][2] + b.z, acc[i][3] + b.w};  // columns past emb: zero tiles + zero bias
+        v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+        *reinterpret_cast<float4*>(slab + r * LD + c0) = v;
+      }
+    });
   });
-  stamp(5);
   // stage 5: out = h1 . fc2^T + b2 -> global
   chain64_dispatch<1, kC64MaxB>(nbEo, [&](auto nbc) __attribute__((always_inline)) {
-    constexpr int NB = decltype(nbc)::value;
-    using G = C64Gemm<NB, false>;
-    float4 xc[G::CK];
-    floatx4 acc[NB];
-    G::run(st, ck, cc, cp, q, g.emb, slab + r * LD, 0, xc, nullptr, wbuf, acc, tid, g.dbg_mode, tacc);
-    stamp(7);
-    if (r < rows) {
-      float* orow = g.out + (m0 + r) * g.ldo;
-      const bool vec = (g.ldo & 3) == 0;
+    with_half(nbc, [&](auto nbc2, auto hc) __attribute__((always_inline)) {
+      constexpr int NBT = decltype(nbc2)::value, HALF = decltype(hc)::value;
+      using G = C64Gemm<NBT, HALF, false>;
+      float4 xc[G::CK];
+      floatx4 acc[G::NBS];
+      G::run(st, ck, cc, cp, q, g.emb, slab + r * LD, 0, xc, nullptr, wbuf, acc, tid);
+      if (r < rows) {
+        float* orow = g.out + (m0 + r) * g.ldo;
+        const bool vec = (g.ldo & 3) == 0;
 #pragma unroll
-      for (int i = 0; i < NB; ++i) {
-        const int c0 = 16 * i + 4 * rq;
-        const float4 b = *reinterpret_cast<const float4*>(b2 + c0);
-        const float4 v{acc[i][0] + b.x, acc[i][1] + b.y, acc[i][2] + b.z, acc[i][3] + b.w};
-        if (vec && c0 + 3 < g.emb_out) {
-          *reinterpret_cast<float4*>(orow + c0) = v;
-        } else {
-          if (c0 < g.emb_out) orow[c0] = v.x;
-          if (c0 + 1 < g.emb_out) orow[c0 + 1] = v.y;
-          if (c0 + 2 < g.emb_out) orow[c0 + 2] = v.z;
-          if (c0 + 3 < g.emb_out) orow[c0 + 3] = v.w;
+        for (int i = 0; i < G::NBW; ++i) {
+          const int c0 = 16 * (HALF + 2 * i) + 4 * rq;
+          const float4 b = *reinterpret_cast<const float4*>(b2 + c0);
+          const float4 v{acc[i][0] + b.x, acc[i][1] + b.y, acc[i][2] + b.z, acc[i][3] + b.w};
+          if (vec && c0 + 3 < g.emb_out) {
+            *reinterpret_cast<float4*>(orow + c0) = v;
+          } else {
+            if (c0 < g.emb_out) orow[c0] = v.x;
+            if (c0 + 1 < g.emb_out) orow[c0 + 1] = v.y;
+            if (c0 + 2 < g.emb_out) orow[c0 + 2] = v.z;
+            if (c0 + 3 < g.emb_out) orow[c0 + 3] = v.w;
+          }
         }
       }
-    }
+    });
   });
-  stamp(6);
 }
 
 // ---------------------------------------------------------------------------
@@ -1503,6 +1527,7 @@ extern "C" int tgmx_ln_residual_concat(const float* y, int64_t ldy, const float*
 
 // shared by the C entry point and the forward driver (which may pass queries folded onto the row input)
 static int attn_reduce_impl(const AttnArgs& a, int H, hipStream_t st) {
+  TGMX_REQUIRE(H == 1 || H == 2 || H == 4 || H == 8, "tgat_attn_reduce: the attention kernels are built for n_heads in {1, 2, 4, 8} (got %d)", H);
   const int k = a.k, T = a.T;
   const long long R = a.R;
   const size_t per_wave = ((size_t)k * T + (size_t)k * (H + 2)) * sizeof(float);
@@ -1732,9 +1757,6 @@ extern "C" int tgmx_tgat_tile16(const float* W, int64_t ldw, int32_t N, int32_t 
   return TGMX_OK;
 }
 
-static long long* g_chain_dbg = nullptr;
-extern "C" void tgmx_debug_chain_times(long long* p) { g_chain_dbg = p; }
-
 // The transposed 16-row-tile chain (tgat_chain64_kernel).  Returns TGMX_E_UNSUPPORTED (no error text) when the layer does not
 // fit it (a stage wider than 192 columns, no tiled weights) -- the caller falls back to tgat_post_chain_kernel / the unfused kernels.
 static int launch_chain64(const tgmx_tgat_layer_t& ly, const tgmx_tgat_layer_layout_t& lo, const float* zbar, const float* x,
@@ -1757,12 +1779,10 @@ static int launch_chain64(const tgmx_tgat_layer_t& ly, const tgmx_tgat_layer_lay
   if (ly.emb > kmax) kmax = ly.emb;
   if ((ly.H - 1) * (ly.O / ly.H) + 16 * blocks[0] > kmax) kmax = (ly.H - 1) * (ly.O / ly.H) + 16 * blocks[0];
   g.LD = (kmax + 15) / 16 * 16 + 4;
-  const size_t lds = ((size_t)3 * kC64ChunkTiles * 256 + kC64Waves * 256 + (size_t)kC64Waves * 16 * g.LD + 16 * (size_t)(3 * blocks[1] + blocks[2] + blocks[3]) +
+  const size_t lds = ((size_t)kC64Ring * kC64ChunkTiles * 256 + kC64Waves * 256 + (size_t)kC64Tiles * 16 * g.LD + 16 * (size_t)(3 * blocks[1] + blocks[2] + blocks[3]) + kC64Waves * 16 +
                       64 * (size_t)ly.d + 64 * (size_t)d0) * sizeof(float);
   if (lds > 160 * 1024) return TGMX_E_UNSUPPORTED;
   if (dry) return TGMX_OK;
-  g.dbg_t = g_chain_dbg;
-  { const char* e = getenv("TGMX_C64_MODE"); g.dbg_mode = e ? atoi(e) : 0; }
   static bool attr_set = false;
   if (!attr_set) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tgat_chain64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
