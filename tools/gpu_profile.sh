@@ -15,9 +15,6 @@ grep '^{' "$OUT/trace.log" | tail -1 > "$OUT/bench_under_trace.json"
 {
   python tools/prof_summary.py trace "$OUT/trace" --title "rocprofv3 --kernel-trace --stats -- python bench.py $ARGS   (ring mode, wiki-shaped, bs=200, k=[20,20])"
   echo
-  echo '# the dominant kernel over bench.py\'s TIMED steps only (the last 393 launches; the table above averages over the untimed ring fill too)'
-  python tools/prof_summary.py tail "$OUT/trace" --kernel recency_lookup_fused01 --last 393
-  echo
   echo "# the dominant kernel over bench.py's TIMED steps only (the last 393 launches; the table above also averages over the untimed ring fill)"
   echo '| what | avg | min | max |'
   echo '|---|---|---|---|'

@@ -27,6 +27,12 @@ python tools/hbm_probe.py         2>/dev/null > "$OUT/r02_hbm_probe.txt"
 python tools/host_time.py --workload wiki   2>/dev/null | tail -1 >  "$OUT/r02_host_vs_device.txt"
 python tools/host_time.py --workload review 2>/dev/null | tail -1 >> "$OUT/r02_host_vs_device.txt"
 python tools/scaling_model.py > /dev/null 2>&1; cp profiles/r02_scaling_model.json "$OUT/" 2>/dev/null
+tools/gpu_trace_cmd.sh tgat 18 python "$ROOT/tools/bench_tgat.py" 50 2>/dev/null | grep -v '^{' > "$OUT/r02_tgat_rocprof_summary.md"
+{
+  echo '# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- python tools/bench_tgat.py 20   (separate counter pass; averages per dispatch;'
+  echo '# SQ_* rows are per shader engine (32 of them, 32 SIMDs each), GRBM_GUI_ACTIVE per XCD: MFMA utilisation = 32 x busy / (1024 x cycles) = busy / (32 x cycles))'
+  tools/gpu_pmc_cmd.sh mfma "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" tgat_ python "$ROOT/tools/bench_tgat.py" 20
+} > "$OUT/r02_tgat_mfma_pmc.md" 2>/dev/null
 tools/gpu_profile.sh > "$OUT/gpu_profile.log" 2>&1
 cp profiles/r02_sampler_rocprof_summary.md profiles/pmc_hop1.json "$OUT/" 2>/dev/null
 rm -rf "$ROOT/gpurun_out/prof_r02"
