@@ -792,7 +792,8 @@ __global__ __launch_bounds__(kC64Threads) void tgat_chain64_kernel(const ChainAr
     for (int e = tid + NT; e < wrows * d; e += NT) xs[e] = g.x[(w0 + e / d) * g.ldx + (e % d)];
     for (int e = tid + NT; e < wrows * d0; e += NT) zs[e] = g.z0[w0 * d0 + e];
   }
-  __syncthreads();  // drains both DMAs too: the stream's first wait finds nothing in flight, which a counted wait allows
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the compiler does not know about the DMAs above
+  __syncthreads();  // both chunks have landed: the stream's first wait finds nothing in flight, which a counted wait allows
 
   // every stage below runs as <blocks of the stage, this wave's half>: both are workgroup- resp. wave-uniform
   auto with_half = [&](auto nbc, auto&& f) __attribute__((always_inline)) {
