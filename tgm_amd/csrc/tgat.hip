@@ -236,30 +236,63 @@ __global__ __launch_bounds__(256) void time2vec_kernel(const TI* __restrict__ x,
 }
 
 // out[r, :O] = LayerNorm(y[r] + res[r]) * gamma + beta ; out[r, O:O+d0] = z0[r]   (one wave per row)
+// res == nullptr: the residual is rebuilt here, [x[r, :d] | 0 | cos(tb)] (what tgat_rres_kernel would have written: same values)
 __global__ __launch_bounds__(256) void ln_residual_concat_kernel(const float* __restrict__ y, const float* __restrict__ res,
                                                                  const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, int O, float eps,
                                                                  const float* __restrict__ z0, int d0, long long R,
                                                                  float* __restrict__ out, long long ldy, long long ldr,
-                                                                 long long ldo) {
+                                                                 long long ldo, const float* __restrict__ x, long long ldx, int d,
+                                                                 const float* __restrict__ tb, int T) {
   const int lane = lane_id();
   const long long r = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (r >= R) return;
   const float* yr = y + r * ldy;
-  const float* rr = res + r * ldr;
+  const float* rr = res ? res + r * ldr : nullptr;
+  const float* xr = x + r * ldx;
+  const int t0 = O - T;
+  auto resid = [&](int c) -> float { return rr ? rr[c] : (c < d ? xr[c] : (c >= t0 ? cos_t2v(tb[c - t0]) : 0.f)); };
+  float* orow = out + r * ldo;
+  if (O <= 8 * kWave) {  // the row's y + residual held in registers: one read, one Time2Vec per column
+    float t[8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = lane + i * kWave;
+      t[i] = c < O ? yr[c] + resid(c) : 0.f;
+      s += t[i];
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)O;
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float u = lane + i * kWave < O ? t[i] - mean : 0.f;
+      v += u * u;
+    }
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const float rstd = 1.0f / sqrtf(v / (float)O + eps);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = lane + i * kWave;
+      if (c < O) orow[c] = (t[i] - mean) * rstd * gamma[c] + beta[c];
+    }
+    for (int c = lane; c < d0; c += kWave) orow[O + c] = z0[r * d0 + c];
+    for (int c = O + d0 + lane; c < ldo; c += kWave) orow[c] = 0.f;  // padding of a padded row
+    return;
+  }
   float s = 0.f;
-  for (int c = lane; c < O; c += kWave) s += yr[c] + rr[c];
+  for (int c = lane; c < O; c += kWave) s += yr[c] + resid(c);
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
   const float mean = s / (float)O;
   float v = 0.f;
   for (int c = lane; c < O; c += kWave) {
-    const float t = yr[c] + rr[c] - mean;
+    const float t = yr[c] + resid(c) - mean;
     v += t * t;
   }
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   const float rstd = 1.0f / sqrtf(v / (float)O + eps);
-  float* orow = out + r * ldo;
-  for (int c = lane; c < O; c += kWave) orow[c] = (yr[c] + rr[c] - mean) * rstd * gamma[c] + beta[c];
+  for (int c = lane; c < O; c += kWave) orow[c] = (yr[c] + resid(c) - mean) * rstd * gamma[c] + beta[c];
   for (int c = lane; c < d0; c += kWave) orow[O + c] = z0[r * d0 + c];
   for (int c = O + d0 + lane; c < ldo; c += kWave) orow[c] = 0.f;  // padding of a padded row
 }
@@ -1510,20 +1543,63 @@ extern "C" int tgmx_tgat_rres(const float* x, int64_t ldx, int32_t d, const floa
   return TGMX_OK;
 }
 
-extern "C" int tgmx_ln_residual_concat(const float* y, int64_t ldy, const float* res, int64_t ldr, const float* gamma,
-                                       const float* beta, int32_t O, float eps, const float* z0, int32_t d0, int64_t R, float* out,
-                                       int64_t ldo, tgmx_stream_t stream) {
+// res == nullptr: the residual is [x[:, :d] | 0 | cos(tb)], rebuilt inside the kernel (no tgat_rres launch)
+static int ln_residual_concat_impl(const float* y, int64_t ldy, const float* res, int64_t ldr, const float* gamma, const float* beta,
+                                   int32_t O, float eps, const float* z0, int32_t d0, int64_t R, float* out, int64_t ldo, const float* x,
+                                   int64_t ldx, int32_t d, const float* tb, int32_t T, tgmx_stream_t stream) {
   TGMX_REQUIRE(O > 0 && d0 >= 0 && R >= 0, "ln_residual_concat: bad sizes");
   if (R == 0) return TGMX_OK;
-  TGMX_REQUIRE(y && res && gamma && beta && out && (d0 == 0 || z0), "ln_residual_concat: null pointer");
+  TGMX_REQUIRE(y && (res || (x && tb && d >= 0 && T >= 0 && d + T <= O)) && gamma && beta && out && (d0 == 0 || z0), "ln_residual_concat: null pointer");
   if (ldy == 0) ldy = O;
   if (ldr == 0) ldr = O;
   if (ldo == 0) ldo = O + d0;
   TGMX_REQUIRE(ldy >= O && ldr >= O && ldo >= O + d0, "ln_residual_concat: leading dimension too small");
   hipLaunchKernelGGL(ln_residual_concat_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, y, res, gamma,
-                     beta, O, eps, z0, d0, (long long)R, out, (long long)ldy, (long long)ldr, (long long)ldo);
+                     beta, O, eps, z0, d0, (long long)R, out, (long long)ldy, (long long)ldr, (long long)ldo, x, (long long)ldx, d, tb, T);
   TGMX_CHECK_LAUNCH("ln_residual_concat");
   return TGMX_OK;
+}
+
+extern "C" int tgmx_ln_residual_concat(const float* y, int64_t ldy, const float* res, int64_t ldr, const float* gamma,
+                                       const float* beta, int32_t O, float eps, const float* z0, int32_t d0, int64_t R, float* out,
+                                       int64_t ldo, tgmx_stream_t stream) {
+  TGMX_REQUIRE(res, "ln_residual_concat: null pointer");
+  return ln_residual_concat_impl(y, ldy, res, ldr, gamma, beta, O, eps, z0, d0, R, out, ldo, nullptr, 0, 0, nullptr, 0, stream);
+}
+
+// qf[r, i] = v[i] + sum_{j < d} x[r, j] * U[i, j]  for d <= 4 (U rows padded to 4): the folded queries of a layer with a narrow input
+// as a streaming outer product -- the same fma chain per element as the K = d GEMM it replaces (bit-identical), at the write
+// bandwidth instead of MFMA tiles that are 15/16 padding
+__global__ __launch_bounds__(256) void tgat_qfold_small_kernel(const float* __restrict__ x, long long ldx, int d, const float* __restrict__ U,
+                                                               const float* __restrict__ v, int n4, long long R, float* __restrict__ out,
+                                                               long long ldo) {
+  // one work item = 4 consecutive columns x 16 consecutive rows: the 4 U rows and v stay in registers, consecutive threads write
+  // consecutive 16-byte pieces of a row
+  constexpr int RB = 16;
+  const long long items = ((R + RB - 1) / RB) * n4;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < items; e += (long long)gridDim.x * blockDim.x) {
+    const long long rb = e / n4;
+    const int i = (int)(e - rb * n4) * 4;
+    const float4 vv = *reinterpret_cast<const float4*>(v + i);
+    float4 w[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) w[u] = *reinterpret_cast<const float4*>(U + (long long)(i + u) * 4);
+    const long long r1 = (rb + 1) * RB < R ? (rb + 1) * RB : R;
+    for (long long r = rb * RB; r < r1; ++r) {
+      const float* xr = x + r * ldx;
+      const float x0 = xr[0], x1 = d > 1 ? xr[1] : 0.f, x2 = d > 2 ? xr[2] : 0.f, x3 = d > 3 ? xr[3] : 0.f;
+      float o[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float acc = __fmul_rn(x0, w[u].x);
+        if (d > 1) acc = __fmaf_rn(x1, w[u].y, acc);
+        if (d > 2) acc = __fmaf_rn(x2, w[u].z, acc);
+        if (d > 3) acc = __fmaf_rn(x3, w[u].w, acc);
+        o[u] = acc;
+      }
+      *reinterpret_cast<float4*>(out + r * ldo + i) = make_float4(__fadd_rn(o[0], vv.x), __fadd_rn(o[1], vv.y), __fadd_rn(o[2], vv.z), __fadd_rn(o[3], vv.w));
+    }
+  }
 }
 
 // shared by the C entry point and the forward driver (which may pass queries folded onto the row input)
@@ -1852,7 +1928,7 @@ extern "C" int tgmx_tgat_forward(const tgmx_tgat_model_t* m, const float* node_x
     const bool chain64 = chain && launch_chain64(ly, lo, nullptr, nullptr, 0, nullptr, nullptr, d0, R, nullptr, 0, nullptr, true) == TGMX_OK;
     const bool folded = !save && ly.qf_U != nullptr;  // inference: qf = x . U^T + v in one GEMM, no Q / rres round trip
     const int dp = (ly.d + 3) / 4 * 4;
-    if (!folded || !chain)
+    if (!folded)  // the residual as a buffer is the Q projection's input; LayerNorm rebuilds it on the fly
       if ((rc = tgmx_tgat_rres(prev, ld_prev, ly.d, m->tb, nullptr, ly.T, O, R, rres, Op, stream))) return rc;
     if (!folded) {
       // Q[:, head h] = rres @ W_Q[head h rows]^T     (heads written dhp apart)
@@ -1860,6 +1936,12 @@ extern "C" int tgmx_tgat_forward(const tgmx_tgat_model_t* m, const float* node_x
       // qf[:, h, :] = Q[:, head h] @ W_K[head h]  via the transposed padded copy W_K_t [C, H*dhp]
       if ((rc = tgmx_sgemm_nt(Q, (long long)H * dhp, ly.W_K_t, (long long)H * dhp, qf, (long long)H * Cp, R, C, dh, nullptr, 0, H, dhp, dhp, Cp, stream)))
         return rc;
+    } else if (ly.d <= 4) {
+      long long blocks = ((R + 15) / 16 * (H * Cp / 4) + 255) / 256;
+      if (blocks > 16384) blocks = 16384;
+      hipLaunchKernelGGL(tgat_qfold_small_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, prev, ld_prev, ly.d, ly.qf_U, ly.qf_v,
+                         H * Cp / 4, R, qf, (long long)H * Cp);
+      TGMX_CHECK_LAUNCH("tgat_qfold_small");
     } else {
       if ((rc = tgmx_sgemm_nt(prev, ld_prev, ly.qf_U, dp, qf, (long long)H * Cp, R, H * Cp, ly.d, ly.qf_v, 0, 1, 0, 0, 0, stream))) return rc;
     }
@@ -1905,7 +1987,9 @@ extern "C" int tgmx_tgat_forward(const tgmx_tgat_model_t* m, const float* node_x
       const tgmx_dropout_t dy{m->drop.p, m->drop.seed, m->drop.stream * 64 + 2 * (uint64_t)j + 1, 0};
       if ((rc = tgmx_dropout(y, Op, R, O, &dy, y, Op, stream))) return rc;
     }
-    if ((rc = tgmx_ln_residual_concat(y, Op, rres, Op, ly.ln_g, ly.ln_b, O, ly.ln_eps, z0, d0, R, cat, Kc, stream))) return rc;
+    if ((rc = ln_residual_concat_impl(y, Op, folded ? nullptr : rres, Op, ly.ln_g, ly.ln_b, O, ly.ln_eps, z0, d0, R, cat, Kc, prev, ld_prev, ly.d, m->tb,
+                                      ly.T, stream)))
+      return rc;
     if ((rc = tgmx_sgemm_nt(cat, Kc, ly.fc1_w, Kc, h1, Ep, R, ly.emb, O + d0, ly.fc1_b, 1, 1, 0, 0, 0, stream))) return rc;
     if ((rc = tgmx_sgemm_nt(h1, Ep, ly.fc2_w, Ep, nxt, ld_nxt, R, ly.emb_out, ly.emb, ly.fc2_b, 0, 1, 0, 0, 0, stream))) return rc;
     prev = nxt;
