@@ -124,6 +124,8 @@ def test_tgat_forward_matches_reference(case):
     dev = lambda v: [t.to(DEV) for t in v] if isinstance(v, list) else v.to(DEV)
     z = enc(**{k: dev(v) for k, v in inputs.items()})
     close(z, z_ref, case)
+    with torch.no_grad():  # the inference path (folded queries, fused tails)
+        close(enc(**{k: dev(v) for k, v in inputs.items()}), z_ref, case + ' (no_grad)')
 
 
 def test_one_kernel_tail_is_race_free_under_load():
@@ -200,12 +202,15 @@ def test_tgat_headline_shape_vs_oracle():
         for b, batch in enumerate(DGDataLoader(dg, batch_size=200, hook_manager=hm)):
             if b == 120:
                 break
-    z = enc(dg.static_node_x, batch.seed_nids, batch.seed_times, batch.nbr_nids, batch.nbr_edge_x, batch.nbr_edge_time)
+    with torch.no_grad():  # inference: what the bench times (folded queries, one-kernel tail); below: the saving forward
+        z = enc(dg.static_node_x, batch.seed_nids, batch.seed_times, batch.nbr_nids, batch.nbr_edge_x, batch.nbr_edge_time)
+    z_train = enc(dg.static_node_x, batch.seed_nids, batch.seed_times, batch.nbr_nids, batch.nbr_edge_x, batch.nbr_edge_time)
     cpu = lambda v: [t.cpu() for t in v]
     z_ref = tgat_ref.tgat_forward(params, 2, st.node_x, cpu(batch.seed_nids), cpu(batch.seed_times), cpu(batch.nbr_nids),
                                   cpu(batch.nbr_edge_x), cpu(batch.nbr_edge_time))  # fmt: skip
     assert z.shape == (600, 172)
-    close(z, z_ref, 'headline shape')
+    close(z, z_ref, 'headline shape, inference')
+    close(z_train, z_ref, 'headline shape, grad-enabled (saving) forward')
 
 
 @pytest.mark.parametrize('nd,ed,td,emb,H,ks,S0,L', [(8, 12, 16, 32, 4, [16, 16], 144, 2), (3, 8, 10, 20, 1, [30], 2100, 1), (16, 4, 6, 24, 2, [8, 8, 8], 40, 3),
@@ -238,6 +243,8 @@ def test_tgat_fused_inference_paths_vs_oracle(nd, ed, td, emb, H, ks, S0, L):
         cur_n, cur_t = n.reshape(-1), t.reshape(-1)
     params = {k_: v.detach().cpu() for k_, v in enc.state_dict().items()}
     dev = lambda v: [t.to(DEV) for t in v]
-    z = enc(node_x.to(DEV), dev(seed_n), dev(seed_t), dev(nbr_n), dev(nbr_x), dev(nbr_t))
     z_ref = tgat_ref.tgat_forward(params, H, node_x, seed_n, seed_t, nbr_n, nbr_x, nbr_t)
-    close(z, z_ref, f'nd={nd} H={H} ks={ks}')
+    args = (node_x.to(DEV), dev(seed_n), dev(seed_t), dev(nbr_n), dev(nbr_x), dev(nbr_t))
+    with torch.no_grad():  # the inference path: folded queries, one-kernel tail
+        close(enc(*args), z_ref, f'inference nd={nd} H={H} ks={ks}')
+    close(enc(*args), z_ref, f'grad-enabled (saving) forward nd={nd} H={H} ks={ks}')

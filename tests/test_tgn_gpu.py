@@ -23,11 +23,23 @@ def _memory(meta, a):
     return mem.train()
 
 
+def _grad_mode(inference):
+    """The modules dispatch on the autograd state: grad-enabled calls take the saving forward (autograd Functions), no_grad calls
+    the one-call inference drivers.  Every oracle comparison below runs both."""
+    return torch.no_grad() if inference else torch.enable_grad()
+
+
+@pytest.mark.parametrize('inference', [False, True])
 @pytest.mark.parametrize('case', CASES)
-def test_tgn_memory_matches_reference(case):
+def test_tgn_memory_matches_reference(case, inference):
     meta, a = gu.load(case)
     T = torch.from_numpy
     mem = _memory(meta, a)
+    with _grad_mode(inference):
+        _check_memory_golden(case, meta, a, mem, T)
+
+
+def _check_memory_golden(case, meta, a, mem, T):
     for ev in drive(meta, a, mem, to=lambda t: t.to(DEV)):
         if ev[0] == 'fwd':
             _, b, z, lu = ev
@@ -42,9 +54,10 @@ def test_tgn_memory_matches_reference(case):
             assert torch.equal(mem.last_update.cpu(), T(a['flush_last_update']))
 
 
+@pytest.mark.parametrize('inference', [False, True])
 @pytest.mark.parametrize('aggr,bs,log_cap', [('last', 512, None), ('mean', 512, None), ('last', 700, None), ('mean', 100, None), ('last', 512, 64),
                                              ('mean', 100, 256)])
-def test_tgn_memory_matches_oracle_review_shaped(aggr, bs, log_cap):
+def test_tgn_memory_matches_oracle_review_shaped(aggr, bs, log_cap, inference):
     """Example dims (memory/time 100, msg 16) on a review-shaped stream with hubs; bs=512 is the BASELINE batch (one-launch
     id grouping: 2*bs <= 1024), bs=700 takes the torch.sort fallback of the message store / commit.  log_cap: a tiny
     message-log capacity, so the store is compacted every few batches (the log must not grow with the events
@@ -73,11 +86,13 @@ def test_tgn_memory_matches_oracle_review_shaped(aggr, bs, log_cap):
         src, dst, t, raw = st.src[lo:hi], st.dst[lo:hi], ts[lo:hi], st.edge_x[lo:hi]
         neg = torch.randint(900, N, (hi - lo,), generator=g, dtype=torch.int32)
         n_id = torch.unique(torch.cat([src, dst, neg]))
-        z, lu = mem(n_id.to(DEV))
+        with _grad_mode(inference):
+            z, lu = mem(n_id.to(DEV))
         z_ref, lu_ref = ref.forward(n_id.long())
         close(z.cpu(), z_ref, f'b{b} z')
         assert torch.equal(lu.cpu(), lu_ref)
-        mem.update_state(src.to(DEV), dst.to(DEV), t.to(DEV), raw.to(DEV))
+        with _grad_mode(inference):
+            mem.update_state(src.to(DEV), dst.to(DEV), t.to(DEV), raw.to(DEV))
         ref.update_state(src, dst, t, raw)
         if log_cap and mem.training:
             live = int(mem._st_cnt[0].sum()) + int(mem._st_cnt[1].sum())
@@ -86,7 +101,8 @@ def test_tgn_memory_matches_oracle_review_shaped(aggr, bs, log_cap):
     assert torch.equal(mem.last_update.cpu(), ref.last_update)
 
 
-def test_graph_attention_embedding_matches_restatement():
+@pytest.mark.parametrize('inference', [False, True])
+def test_graph_attention_embedding_matches_restatement(inference):
     from oracle.tgn_ref import graph_attention_embedding_ref
     from tgm_amd.nn import GraphAttentionEmbedding, Time2Vec
 
@@ -99,7 +115,8 @@ def test_graph_attention_embedding_matches_restatement():
     edge_index[1, :500] = torch.randint(0, U, (500,))
     t = torch.randint(0, 1_000_000, (E,))
     msg = torch.rand(E, D)
-    out = enc(x.to(DEV), last_update.to(DEV), edge_index.to(DEV), t.to(DEV), msg.to(DEV))
+    with _grad_mode(inference):
+        out = enc(x.to(DEV), last_update.to(DEV), edge_index.to(DEV), t.to(DEV), msg.to(DEV))
     ref = graph_attention_embedding_ref({k: v.cpu() for k, v in enc.state_dict().items()}, x, last_update, edge_index, t, msg)
     assert out.shape == (U, emb)
     close(out.cpu(), ref, 'graph attention embedding')

@@ -654,18 +654,21 @@ struct C64Gemm {
   // One activation vector (k-step kb) of the lane's row.  Slab rows need no guard: every stage writes its padding columns as
   // zeros (zero-padded tiles and biases), so a column past K is either zero or multiplies a zero weight.  zbar's padding
   // [C, Cp) is not initialised: the last k-block (only) is masked.
+  // A k-step past KB (the tail of a GEMM's last chunk) returns zeros: its MFMAs then add 0 x whatever (finite) tiles the ring holds.
   static __device__ __forceinline__ float4 xload(const float* __restrict__ xrow, int kb, int K, int Kxp, int lane) {
     const int KB = (K + 15) / 16, k4l = (lane >> 4) * 4;
-    kb = kb < KB ? kb : KB - 1;
+    const bool live = kb < KB;  // wave-uniform
+    kb = live ? kb : KB - 1;
     const int k4 = kb * 16 + k4l;
+    float4 x;
     if constexpr (!XG) {
-      return *reinterpret_cast<const float4*>(xrow + k4);
+      x = *reinterpret_cast<const float4*>(xrow + k4);
     } else {
       const int kx_last = Kxp - 4;
-      float4 x = *reinterpret_cast<const float4*>(xrow + (k4 < kx_last ? k4 : kx_last));
+      x = *reinterpret_cast<const float4*>(xrow + (k4 < kx_last ? k4 : kx_last));
       if (kb == KB - 1) x = float4{k4 < K ? x.x : 0.f, k4 + 1 < K ? x.y : 0.f, k4 + 2 < K ? x.z : 0.f, k4 + 3 < K ? x.w : 0.f};
-      return x;
     }
+    return live ? x : float4{0.f, 0.f, 0.f, 0.f};
   }
 
   // The chunk loop is software-pipelined BY HAND and pinned with scheduling fences, because what stalls this kernel is issue
