@@ -305,17 +305,22 @@ def main():
     hook.profile_hop = None
     if not log:
         raise SystemExit('bench.py: no launch of the dominant kernel was timed (steps too small for --profile-every?)')
-    ker_ms = [t.elapsed_ms() for t, *_ in log]
+    ker_ms = [e[0].elapsed_ms() for e in log]
     avg_ms = sum(ker_ms) / len(ker_ms)
     # the timed launch covers one hop, or hop 0 + hop 1 when tgmx_recency_step runs them as one launch; average the
     # per-launch figures over the timed launches (shapes only differ for the ragged last batch of an epoch)
-    seeds_l = sum(sum(seeds for seeds, _ in shape) for _, shape, _ in log) / len(log)
-    total_slots = sum(sum(seeds * k for seeds, k in shape) for _, shape, _ in log) / len(log)
-    valid = sum(int(counts.sum().item()) for *_, counts in log) / len(log)
-    # algorithmic bytes per launch, VALID-AWARE: every slot is written (id 4 + ts 8 + 4D); only
-    # valid slots read their 16-byte record and 4D-byte feature row (pads are written as zeros without reading anything --
-    # charging SURVEY 8(d)'s 28 + 8D per slot to pad slots too would report more than the HBM peak); 68 B of index traffic per seed
-    algo_bytes = total_slots * (12 + 4 * D) + valid * (16 + 4 * D) + seeds_l * 68
+    seeds_l = sum(sum(seeds for seeds, _ in e[1]) for e in log) / len(log)
+    total_slots = sum(sum(seeds * k for seeds, k in e[1]) for e in log) / len(log)
+    valid = sum(int(e[2].sum().item()) for e in log) / len(log)
+    delta = all(e[3] is not None for e in log)
+    # feature rows written per launch: every slot, or -- pooled outputs with delta writes (tgmx_recency_step_t.out_valid) -- the
+    # slots from the first one that changes on, max(valid before, valid now) per row, measured on the timed launches
+    feat_slots = (sum(int(e[3].sum().item()) for e in log) / len(log)) if delta else total_slots
+    # algorithmic bytes per launch, VALID-AWARE: every slot's id 4 + ts 8 is written, a feature row (4D) for
+    # every slot that has to change; only valid slots read their 16-byte record and 4D-byte feature row (pads are zeros written
+    # without reading anything -- charging SURVEY 8(d)'s 28 + 8D per slot to pad slots too would report more than the HBM peak);
+    # 68 B of index traffic per seed (+ 8 B of valid-count read / write per row with delta writes)
+    algo_bytes = total_slots * 12 + feat_slots * 4 * D + valid * (16 + 4 * D) + seeds_l * (68 + (8 if delta else 0))
     achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
     shape = log[0][1]
     fused = len(shape) > 1
@@ -363,7 +368,10 @@ def main():
             'launches_timed': len(ker_ms),
             'algorithmic_bytes_per_launch': algo_bytes,
             'valid_slot_fraction': valid / max(total_slots, 1),
-            'bytes_model': 'valid-aware: slots x (12 + 4D) written + valid slots x (16 + 4D) read + 68 B per seed',
+            'feature_rows_written_fraction': feat_slots / max(total_slots, 1),
+            'bytes_model': ('valid-aware, delta feature writes into the persistent output set: slots x 12 (ids, times) + rewritten slots x 4D '
+                            '(a row is written from its first changing slot on: max(valid before, valid now)) + valid slots x (16 + 4D) read + 76 B per seed')
+            if delta else 'valid-aware: slots x (12 + 4D) written + valid slots x (16 + 4D) read + 68 B per seed',
         },
     }
     if rank == 0 or args.emulate_world:

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TGMX_ABI_VERSION 2
+#define TGMX_ABI_VERSION 3
 
 #define TGMX_OK 0
 #define TGMX_E_INVALID (-1)  /* bad argument (null pointer, size, alignment) */
@@ -204,6 +204,14 @@ typedef struct tgmx_recency_step {
    * time-sorted store): the large-batch update then takes max(ts) from the last edge instead of a reduction launch.  Checked on
    * the device: a violation is reported as TGMX_ST_TS_BOUND. */
   int32_t sorted_ts;
+  /* Optional, per hop: DELTA writes of the feature rows into PERSISTENT output buffers (a loader's output pool).  A row's
+   * neighbors sit at the right end of its k slots and everything left of the leftmost non-pad slot is zero, so a caller
+   * that hands the same out_x[h] to consecutive calls -- unmodified in between -- and keeps out_valid[h][row] = the row's
+   * SPAN (slots from its leftmost non-pad one to the end; 0 = all pads) needs writes only from slot k - max(previous span,
+   * new span) on; the call updates out_valid.  Start with out_x[h] zeroed and out_valid[h] zeroed.  ~60 % of all slots
+   * are pads at steady state: this halves the bytes the lookup launch writes.
+   * NULL: every slot of every row is written (fresh buffers).  Ids and times are always written in full. */
+  int32_t* out_valid[TGMX_MAX_HOPS];
 } tgmx_recency_step_t;
 
 int tgmx_recency_step(const tgmx_recency_step_t* step, tgmx_stream_t stream);
@@ -255,6 +263,7 @@ typedef struct tgmx_pipeline_out {
   float* out_x[TGMX_MAX_HOPS];
   int32_t timed_hop;           /* -1: none; else ev_start / ev_stop bracket that hop's lookup launch */
   tgmx_event_t ev_start, ev_stop;
+  int32_t* out_valid[TGMX_MAX_HOPS]; /* optional: tgmx_recency_step_t.out_valid of this output set (delta feature writes) */
 } tgmx_pipeline_out_t;
 
 /* Optional tail of the chain, for the TGN loop: DeduplicationHook (tgm/hooks/dedup.py:35-67) over [batch src | batch dst |

@@ -83,6 +83,7 @@ extern "C" int tgmx_pipeline_step(const tgmx_pipeline_t* p, int64_t edge_lo, int
     s.out_nid[h] = out->out_nid[h];
     s.out_ts[h] = out->out_ts[h];
     s.out_x[h] = out->out_x[h];
+    s.out_valid[h] = out->out_valid[h];
   }
   s.timed_hop = out->timed_hop;
   s.ev_start = out->ev_start;

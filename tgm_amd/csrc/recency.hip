@@ -91,6 +91,11 @@ struct LookupArgs {
   int32_t* out_nid1;
   int64_t* out_ts1;
   float* out_x1;
+  // DELTA feature writes (persistent output buffers, tgmx_recency_step_t.out_valid): out_valid[s] = the SPAN row s of out_x still
+  // holds from the previous call -- the slots from its leftmost non-pad one to the end; everything left of that is zero.  The row
+  // then needs writes only from slot k - max(old span, new span) on: the pads left of that are zeros already.  NULL: every slot.
+  int32_t* out_valid;
+  int32_t* out_valid1;
 };
 
 template <int VEC>
@@ -1111,13 +1116,13 @@ __device__ __forceinline__ SmallPick small_pick(const LookupArgs& a, int n, long
 
 // phase B: stream the [k, D] block of row s; lds_eid[c] = feature row of output slot c (-1: zeros)
 template <int VEC>
-__device__ __forceinline__ void gather_rows(const LookupArgs& a, long long s, int k, int lane, const int* lds_eid, float* out_x) {
+__device__ __forceinline__ void gather_rows(const LookupArgs& a, long long s, int k, int lane, const int* lds_eid, float* out_x, int first_slot) {
   using V = typename VecOf<VEC>::type;
   const V* __restrict__ X = reinterpret_cast<const V*>(a.edge_x);
   V* __restrict__ O = reinterpret_cast<V*>(out_x + s * (long long)k * a.D);
   const int total = k * a.row_vecs;
   constexpr int U = 4;
-  for (int f0 = lane; f0 < total; f0 += kWave * U) {
+  for (int f0 = first_slot * a.row_vecs + lane; f0 < total; f0 += kWave * U) {
     V v[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -1141,8 +1146,12 @@ __device__ __forceinline__ void gather_rows(const LookupArgs& a, long long s, in
 // the k most recent neighbors of (n, q) into row s of (out_nid, out_ts, out_x)
 template <bool RING, int VEC, bool SMALL>
 __device__ __forceinline__ void lookup_seed(const LookupArgs& a, long long s, int n, long long q, int k, int lane, int* lds_eid,
-                                            int32_t* out_nid, int64_t* out_ts, float* out_x) {
+                                            int32_t* out_nid, int64_t* out_ts, float* out_x, int32_t* out_valid) {
   const bool live = n >= 0 && n < a.N;
+  // the row's SPAN: slots from its leftmost non-pad one to the end (0: all pads).  Valid slots sit at the right end of a row, but a
+  // ring can hold a pad record between real ones (the oracle's lookup keeps it: an interior -1), so it is the leftmost
+  // non-pad slot that bounds what has to be written, not the count.  Wave-uniform.
+  int v_new = 0;
   if (SMALL) {
     const SmallPick o = small_pick<RING>(a, n, q, k, live, lane);
     if (lane < k) {
@@ -1150,6 +1159,8 @@ __device__ __forceinline__ void lookup_seed(const LookupArgs& a, long long s, in
       out_ts[s * k + lane] = o.ts;
       lds_eid[lane] = o.src;
     }
+    const unsigned long long m = __ballot(lane < k && o.has);
+    v_new = m ? k - __builtin_ctzll(m) : 0;
   } else {
     const int B = a.B;
     const Window w = find_window<RING>(a, n, live, lane);
@@ -1174,11 +1185,22 @@ __device__ __forceinline__ void lookup_seed(const LookupArgs& a, long long s, in
       out_nid[s * k + c] = has ? r.nbr : -1;
       out_ts[s * k + c] = has ? r.ts : 0;
       lds_eid[c] = has ? (RING ? (int)slot_of<RING>(w, B, i) : r.eid) : -1;
+      if (has && k - c > v_new) v_new = k - c;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      const int other = __shfl_xor(v_new, o);
+      v_new = other > v_new ? other : v_new;
     }
   }
   if (a.D == 0) return;
+  int first_slot = 0;
+  if (out_valid) {  // the row's previous contents are known: leave the zeros left of both valid tails alone
+    const int v_old = out_valid[s];
+    first_slot = k - (v_old > v_new ? v_old : v_new);
+    if (lane == 0) out_valid[s] = v_new;
+  }
   __builtin_amdgcn_wave_barrier();  // lds_eid written above is read cross-lane below
-  gather_rows<VEC>(a, s, k, lane, lds_eid, out_x);
+  gather_rows<VEC>(a, s, k, lane, lds_eid, out_x, first_slot);
   __builtin_amdgcn_wave_barrier();  // the next seed reuses lds_eid
 }
 
@@ -1208,7 +1230,7 @@ __global__ __launch_bounds__(256) void recency_lookup_kernel(const LookupArgs a,
     long long q;
     fetch_seed(a, s, lane, true, n, q);
     check_seed(a, n, q, a.allow_pad, lane);
-    lookup_seed<RING, VEC, SMALL>(a, s, n, q, a.k, lane, lds_eid, a.out_nid, a.out_ts, a.out_x);
+    lookup_seed<RING, VEC, SMALL>(a, s, n, q, a.k, lane, lds_eid, a.out_nid, a.out_ts, a.out_x, a.out_valid);
   }
   if constexpr (RING && RIDE) {
     if (a.tail_blocks) tail_signal(u.barrier, false, bid, nblk);
@@ -1250,7 +1272,7 @@ __global__ __launch_bounds__(256) void recency_lookup_fused01_kernel(const Looku
     if (w < S0) {
       fetch_seed(a, w, lane, true, n, q);
       check_seed(a, n, q, 0, lane);
-      lookup_seed<RING, VEC, true>(a, w, n, q, k0, lane, lds_eid, a.out_nid, a.out_ts, a.out_x);
+      lookup_seed<RING, VEC, true>(a, w, n, q, k0, lane, lds_eid, a.out_nid, a.out_ts, a.out_x, a.out_valid);
     } else {
       const long long idx = w - S0;
       const long long s0 = idx / k0;
@@ -1261,7 +1283,7 @@ __global__ __launch_bounds__(256) void recency_lookup_fused01_kernel(const Looku
       const SmallPick o = small_pick<RING>(a, n0, q0, k0, n0 >= 0 && n0 < a.N, lane);
       n = __shfl(o.nbr, j);
       q = __shfl(o.ts, j);
-      lookup_seed<RING, VEC, true>(a, idx, n, q, k1, lane, lds_eid, a.out_nid1, a.out_ts1, a.out_x1);
+      lookup_seed<RING, VEC, true>(a, idx, n, q, k1, lane, lds_eid, a.out_nid1, a.out_ts1, a.out_x1, a.out_valid1);
     }
   }
   if constexpr (RING) {
@@ -1329,8 +1351,8 @@ __device__ __forceinline__ GroupPick group_pick(const LookupArgs& a, int n, long
 
 // row s of (out_nid, out_ts, out_x) from the group's pick; k is wave-uniform
 template <int VEC, int GL>
-__device__ __forceinline__ void group_emit(const LookupArgs& a, bool act, long long s, int k, const GroupPick& o, int* lds_eid, int gl,
-                                           int32_t* out_nid, int64_t* out_ts, float* out_x) {
+__device__ __forceinline__ void group_emit(const LookupArgs& a, bool act, long long s, int k, const GroupPick& o, int* lds_eid, int gl, int sub,
+                                           int32_t* out_nid, int64_t* out_ts, float* out_x, int32_t* out_valid) {
   using V = typename VecOf<VEC>::type;
   if (act && gl < k) {
     out_nid[s * k + gl] = o.nbr;
@@ -1338,13 +1360,24 @@ __device__ __forceinline__ void group_emit(const LookupArgs& a, bool act, long l
     lds_eid[gl] = o.src;
   }
   if (a.D == 0) return;
+  int first_slot = 0;
+  if (out_valid) {  // delta feature writes: see LookupArgs::out_valid
+    const unsigned long long m = (__ballot(act && gl < k && o.has) >> (sub * GL)) & ((GL == 64) ? ~0ull : ((1ull << GL) - 1));
+    const int v_new = m ? k - __builtin_ctzll(m) : 0;  // span from the leftmost non-pad slot (see lookup_seed)
+    if (act) {
+      const int v_old = out_valid[s];
+      first_slot = k - (v_old > v_new ? v_old : v_new);
+    }
+  __builtin_amdgcn_wave_barrier();  // every lane of the group has read the old count
+    if (act && gl == 0) out_valid[s] = v_new;
+  }
   __builtin_amdgcn_wave_barrier();
   if (act) {
     const V* __restrict__ X = reinterpret_cast<const V*>(a.edge_x);
     V* __restrict__ O = reinterpret_cast<V*>(out_x + s * (long long)k * a.D);
     const int total = k * a.row_vecs;
     constexpr int U = 4;
-    for (int f0 = gl; f0 < total; f0 += GL * U) {
+    for (int f0 = first_slot * a.row_vecs + gl; f0 < total; f0 += GL * U) {
       V v[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -1410,7 +1443,7 @@ __global__ __launch_bounds__(256) void lookup_packed_kernel(const LookupArgs a, 
       if (st) atomicOr(a.status, st);
     }
     const GroupPick o = group_pick<RING, GL>(a, n, q, k, n >= 0 && n < a.N, gl, sub);
-    group_emit<VEC, GL>(a, act, s, k, o, lds_eid, gl, a.out_nid, a.out_ts, a.out_x);
+    group_emit<VEC, GL>(a, act, s, k, o, lds_eid, gl, sub, a.out_nid, a.out_ts, a.out_x, a.out_valid);
   }
   if constexpr (RING && RIDE) {
     if (a.tail_blocks) tail_signal(u.barrier, false, bid, nblk);
@@ -2248,6 +2281,7 @@ extern "C" int tgmx_recency_step(const tgmx_recency_step_t* s, tgmx_stream_t str
     a.indptr = s->indptr; a.recs = reinterpret_cast<const Rec*>(s->ring); a.write_pos = s->write_pos; a.edge_x = s->ring_x;
     a.seeds = cur_n; a.qtimes = cur_t; a.out_nid = s->out_nid[0]; a.out_ts = s->out_ts[0]; a.out_x = s->out_x[0];
     a.k1 = k1; a.out_nid1 = s->out_nid[1]; a.out_ts1 = s->out_ts[1]; a.out_x1 = s->out_x[1];
+    a.out_valid = s->out_valid[0]; a.out_valid1 = s->out_valid[1];
     a.status = s->status; a.S = S; a.D = s->D; a.k = k0; a.B = s->B; a.N = s->num_nodes; a.allow_pad = 0;
     a.ev_lo = s->ev_lo; a.ev_hi = s->ev_hi;
     const bool timed = s->timed_hop == 0 || s->timed_hop == 1;
@@ -2271,6 +2305,7 @@ extern "C" int tgmx_recency_step(const tgmx_recency_step_t* s, tgmx_stream_t str
     if (h == 0) a.grp = grp;
     a.indptr = s->indptr; a.recs = reinterpret_cast<const Rec*>(s->ring); a.write_pos = s->write_pos; a.edge_x = s->ring_x;
     a.seeds = cur_n; a.qtimes = cur_t; a.out_nid = s->out_nid[h]; a.out_ts = s->out_ts[h]; a.out_x = s->out_x[h];
+    a.out_valid = s->out_valid[h];
     a.status = s->status; a.S = S; a.D = s->D; a.k = k; a.B = s->B; a.N = s->num_nodes; a.allow_pad = h > 0;
     a.ev_lo = s->ev_lo; a.ev_hi = s->ev_hi;
     const bool timed = h == s->timed_hop;

@@ -474,7 +474,7 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
                 counts = torch.empty(len(hops), dtype=torch.int64, device=device)
                 for i, h in enumerate(hops):
                     torch.sum((out_n[h] != -1).view(-1), dim=0, dtype=torch.int64, out=counts[i])  # asynchronous, unlike count_nonzero
-                self.profile_log.append((timer, [(out_seed_n[h].shape[0], self._num_nbrs[h]) for h in hops], counts))
+                self.profile_log.append((timer, [(out_seed_n[h].shape[0], self._num_nbrs[h]) for h in hops], counts, None))
         return self._publish(batch, out_seed_n, out_seed_t, out_n, out_t, out_x, seed_mask)
 
     # ------------------------------------------------------------------

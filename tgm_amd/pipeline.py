@@ -23,6 +23,7 @@ hands out fresh tensors per batch like the reference.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -44,7 +45,7 @@ _ROLE_KEYS = {
 class _Slot:
     """One preallocated output set + its filled ``tgmx_pipeline_out_t`` + the attributes it puts on a batch."""
 
-    __slots__ = ('out', 'attrs', 'tensors', 'nbr_nids', 'post', 'post_bufs')
+    __slots__ = ('out', 'attrs', 'tensors', 'nbr_nids', 'post', 'post_bufs', 'valid')
 
 
 class CompiledPipeline:
@@ -56,6 +57,8 @@ class CompiledPipeline:
         self._dedup_ws = None
         self._dg, self._shard, self._neg, self._nbr = dg, shard, neg, nbr
         self._R = max(1, int(pool))
+        # delta feature writes into the pooled outputs (include/tgm_amd.h: tgmx_recency_step_t.out_valid); TGMX_DELTA_WRITES=0: off
+        self._delta = os.environ.get('TGMX_DELTA_WRITES', '1') != '0'
         self._pools: Dict[int, List[_Slot]] = {}
         self._turn = 0
         self._pipe: Optional[_native.Pipeline] = None
@@ -156,10 +159,20 @@ class CompiledPipeline:
             out.seed_nid0, out.seed_ts0 = seeds.data_ptr(), seed_t.data_ptr()
             seed_n, seed_ts, nbr_n, nbr_t, nbr_x = [], [], [], [], []
             cur_n, cur_t, S = seeds, seed_t, S0
+            valid = []
             for hop, k in enumerate(nbr._num_nbrs):
                 nid = torch.empty((S, k), dtype=torch.int32, device=dev)
                 nts = torch.empty((S, k), dtype=torch.int64, device=dev)
-                nx = torch.empty((S, k, D), dtype=torch.float32, device=dev)
+                if self._delta:
+                    # persistent buffers: the lookups write a feature row only from the first slot that changes (its valid slots
+                    # are the right-aligned tail, the rest is zero and stays zero) -- tgmx_recency_step_t.out_valid.  The
+                    # buffers start as all-pad rows; consumers must treat them as read-only.
+                    nx = torch.zeros((S, k, D), dtype=torch.float32, device=dev)
+                    nv = torch.zeros(S, dtype=torch.int32, device=dev)
+                    out.out_valid[hop] = nv.data_ptr()
+                    valid.append(nv)
+                else:
+                    nx = torch.empty((S, k, D), dtype=torch.float32, device=dev)
                 out.out_nid[hop], out.out_ts[hop], out.out_x[hop] = nid.data_ptr(), nts.data_ptr(), nx.data_ptr()
                 seed_n.append(cur_n)
                 seed_ts.append(cur_t)
@@ -171,7 +184,7 @@ class CompiledPipeline:
             whole = torch.arange(S0, device=dev)
             attrs.update(seed_nids=seed_n, seed_times=seed_ts, nbr_nids=nbr_n, nbr_edge_time=nbr_t, nbr_edge_x=nbr_x,
                          seed_node_nbr_mask={k: whole.narrow(0, o, share) for k, o in offsets.items()})  # fmt: skip
-            sl.out, sl.attrs, sl.nbr_nids = out, attrs, nbr_n
+            sl.out, sl.attrs, sl.nbr_nids, sl.valid = out, attrs, nbr_n, valid
             sl.post = sl.post_bufs = None
             if self._dedup is not None:
                 sl.post, sl.post_bufs = self._make_post(n, share, nbr_n, dev)
@@ -278,12 +291,13 @@ class CompiledPipeline:
         if nbr.profile_hop is not None and nbr._calls % nbr.profile_every == 0 and nbr.profile_pool:
             timer = nbr.profile_pool.pop()
             out.timed_hop, out.ev_start, out.ev_stop = nbr.profile_hop, timer.start, timer.stop
+        prev_valid = [v.clone() for v in slot.valid] if (timer is not None and slot.valid) else None
         rc = self._lib.tgmx_pipeline_step(pipe, lo, n, call, out, slot.post, _native.stream_ptr(self._device.index))
         if rc:
             _native.check(rc, 'tgmx_pipeline_step')
         if timer is not None:
             out.timed_hop = -1
-            self._log_timed(timer, slot)
+            self._log_timed(timer, slot, prev_valid)
         if nbr._validate == 'sync':
             nbr.check()  # one device -> host read per batch: the reference's raise-per-call behaviour
         d = batch.__dict__
@@ -298,7 +312,7 @@ class CompiledPipeline:
             self._defer_post(batch, slot)
         return True
 
-    def _log_timed(self, timer, slot: _Slot) -> None:
+    def _log_timed(self, timer, slot: _Slot, prev_valid=None) -> None:
         nbr = self._nbr
         st = self._pipe.step
         # what tgmx_recency_step_plan needs of the per-call fields: the seed count and the hop-1 output alignment
@@ -310,4 +324,9 @@ class CompiledPipeline:
         counts = torch.empty(len(hops), dtype=torch.int64, device=self._device)
         for i, h in enumerate(hops):
             torch.sum((slot.nbr_nids[h] != -1).view(-1), dim=0, dtype=torch.int64, out=counts[i])
-        nbr.profile_log.append((timer, [(slot.attrs['seed_nids'][h].shape[0], nbr._num_nbrs[h]) for h in hops], counts))
+        written = None
+        if prev_valid is not None:  # delta feature writes: slots whose feature row was (re)written = max(valid before, valid now) per row
+            written = torch.empty(len(hops), dtype=torch.int64, device=self._device)
+            for i, h in enumerate(hops):
+                torch.sum(torch.maximum(prev_valid[h], slot.valid[h]), dim=0, dtype=torch.int64, out=written[i])
+        nbr.profile_log.append((timer, [(slot.attrs['seed_nids'][h].shape[0], nbr._num_nbrs[h]) for h in hops], counts, written))
