@@ -89,6 +89,30 @@ def test_lowered_chain_equals_hook_by_hook(mode, world, rank, neg):
     hook_b.check()
 
 
+@pytest.mark.parametrize('mode', ['ring', 'csr'])
+@pytest.mark.parametrize('k,D,shape', [([70], 8, 'wiki'), ([10, 10], 16, 'review'), ([20, 20], 20, 'wiki'), ([3, 2, 2], 5, 'comment')])
+def test_delta_feature_writes_equal_full_writes(mode, k, D, shape):
+    """Pooled outputs are persistent, so the lookups rewrite a feature row only from its leftmost slot that changes
+    (tgmx_recency_step_t.out_valid).  Every kernel that emits rows -- one wave per seed with k <= 64 and k > 64, the packed
+    narrow-row groups, the fused hop 0 + 1 launch, three hops -- against fresh tensors per batch (every slot written), over two
+    epochs with a reset in between (rows that held neighbors become all-pad again) and a ragged last batch."""
+    st = _stream(E=3000, D=D, shape=shape)
+    bs = 128
+    hm_a, hook_a, plain = _build(st, bs, k, mode, 0)
+    hm_b, hook_b, pooled = _build(st, bs, k, mode, 1)
+    with hm_a.activate('k'), hm_b.activate('k'):
+        for epoch in range(2):
+            for n, (ba, bb) in enumerate(zip(plain, pooled)):
+                for name in ('nbr_nids', 'nbr_edge_time', 'nbr_edge_x'):
+                    _same(getattr(ba, name), getattr(bb, name), f'epoch {epoch} batch {n} {name}')
+            hm_a.reset_state()
+            hm_b.reset_state()
+    cp = pooled._compiled[1]
+    assert cp is not None and cp._delta and all(sl.valid for slots in cp._pools.values() for sl in slots), 'the pooled loader did not take the delta path'
+    hook_a.check()
+    hook_b.check()
+
+
 def test_lowered_chain_vs_oracle_and_pool_recycling():
     """Pooled outputs against the CPU restatement of the reference (oracle/ring_port.py), with the comment-like
     non-bipartite shape (timestamp ties inside batches, self loops possible); the tensors of batch i are recycled by
