@@ -9,6 +9,7 @@ mkdir -p "$OUT"
 j() { grep '^{' | tail -1; }
 python bench.py                                              2>/dev/null | j > "$OUT/r02_bench_ring.json"
 python bench.py --steps 20 --warmup 5                        2>/dev/null | j > "$OUT/r02_bench_ring_driver_args.json"
+TGMX_DELTA_WRITES=0 python bench.py --cpu-batches 0          2>/dev/null | j > "$OUT/r02_bench_ring_full_writes.json"
 python bench.py --cpu-batches 0 --pool 0                     2>/dev/null | j > "$OUT/r02_bench_ring_hook_by_hook.json"
 python bench.py --cpu-batches 0 --pool 0 --validate sync     2>/dev/null | j > "$OUT/r02_bench_ring_default_sync_validation.json"
 python bench.py --cpu-batches 0 --validate sync              2>/dev/null | j > "$OUT/r02_bench_ring_sync_validation_lowered.json"
