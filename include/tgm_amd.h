@@ -212,6 +212,8 @@ typedef struct tgmx_recency_step {
    * are pads at steady state: this halves the bytes the lookup launch writes.
    * NULL: every slot of every row is written (fresh buffers).  Ids and times are always written in full. */
   int32_t* out_valid[TGMX_MAX_HOPS];
+  /* optional with out_valid: receives the span each row held BEFORE the call (the byte accounting of a timed launch needs both) */
+  int32_t* out_valid_prev[TGMX_MAX_HOPS];
 } tgmx_recency_step_t;
 
 int tgmx_recency_step(const tgmx_recency_step_t* step, tgmx_stream_t stream);
@@ -264,6 +266,7 @@ typedef struct tgmx_pipeline_out {
   int32_t timed_hop;           /* -1: none; else ev_start / ev_stop bracket that hop's lookup launch */
   tgmx_event_t ev_start, ev_stop;
   int32_t* out_valid[TGMX_MAX_HOPS]; /* optional: tgmx_recency_step_t.out_valid of this output set (delta feature writes) */
+  int32_t* out_valid_prev[TGMX_MAX_HOPS]; /* optional: tgmx_recency_step_t.out_valid_prev */
 } tgmx_pipeline_out_t;
 
 /* Optional tail of the chain, for the TGN loop: DeduplicationHook (tgm/hooks/dedup.py:35-67) over [batch src | batch dst |
@@ -287,6 +290,13 @@ typedef struct tgmx_pipeline_post {
   tgmx_event_t sizes_ready;
 } tgmx_pipeline_post_t;
 
+/* Byte accounting of one lookup launch (bench / profiling), as TGMX_ACCOUNTING_PARTIALS partial triples that the caller adds
+ * up whenever it likes (one launch, nothing to zero): column 0 = non-pad slots of ids[0 .. slots), column 1 = sum over rows of
+ * max(span_prev, span_cur) (slots whose feature row was rewritten), column 2 = sum of span_cur.  counts: device,
+ * int64[TGMX_ACCOUNTING_PARTIALS][3], overwritten.  span_* may be NULL (columns 1 and 2 are then zero). */
+#define TGMX_ACCOUNTING_PARTIALS 1024
+int tgmx_lookup_accounting(const int32_t* ids, int64_t slots, const int32_t* span_prev, const int32_t* span_cur, int64_t rows,
+                           int64_t* counts, tgmx_stream_t stream);
 int tgmx_pipeline_step(const tgmx_pipeline_t* pipe, int64_t edge_lo, int64_t n_edges, uint64_t neg_call,
                        const tgmx_pipeline_out_t* out, const tgmx_pipeline_post_t* post /* NULL: none */, tgmx_stream_t stream);
 

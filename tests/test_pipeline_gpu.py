@@ -113,6 +113,24 @@ def test_delta_feature_writes_equal_full_writes(mode, k, D, shape):
     hook_b.check()
 
 
+def test_lookup_accounting_matches_torch():
+    """tgmx_lookup_accounting (the byte model's counts of a timed launch as partial sums) against torch reductions."""
+    from tgm_amd import _native
+
+    lib = _native.load()
+    g = torch.Generator().manual_seed(4)
+    for rows, k in ((1, 1), (600, 20), (12_000, 20), (70_001, 3)):
+        ids = torch.randint(-1, 50, (rows, k), generator=g, dtype=torch.int32).to(DEV)
+        sp = torch.randint(0, k + 1, (2, rows), generator=g, dtype=torch.int32).to(DEV)
+        parts = torch.full((_native.ACCOUNTING_PARTIALS, 3), -7, dtype=torch.int64, device=DEV)
+        _native.check(lib.tgmx_lookup_accounting(ids.data_ptr(), ids.numel(), sp[1].data_ptr(), sp[0].data_ptr(), rows, parts.data_ptr(),
+                                                 _native.stream_ptr()), 'tgmx_lookup_accounting')
+        got = parts.sum(0).tolist()
+        assert got == [int((ids != -1).sum()), int(torch.maximum(sp[0], sp[1]).sum()), int(sp[0].sum())], (rows, k, got)
+        _native.check(lib.tgmx_lookup_accounting(ids.data_ptr(), ids.numel(), None, None, rows, parts.data_ptr(), _native.stream_ptr()), 'accounting')
+        assert parts.sum(0).tolist() == [int((ids != -1).sum()), 0, 0]
+
+
 def test_lowered_chain_vs_oracle_and_pool_recycling():
     """Pooled outputs against the CPU restatement of the reference (oracle/ring_port.py), with the comment-like
     non-bipartite shape (timestamp ties inside batches, self loops possible); the tensors of batch i are recycled by

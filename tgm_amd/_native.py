@@ -151,7 +151,7 @@ class RecencyStep(ctypes.Structure):
         ('neg_group', c_int32), ('neg_low', c_int32), ('neg_high', c_int32),
         ('neg_seed', ctypes.c_uint64), ('neg_call', ctypes.c_uint64), ('neg_out', c_void_p), ('neg_time_out', c_void_p),
         ('guard_seed_errors', c_int32), ('sorted_ts', c_int32),
-        ('out_valid', c_void_p * MAX_HOPS),
+        ('out_valid', c_void_p * MAX_HOPS), ('out_valid_prev', c_void_p * MAX_HOPS),
     ]  # fmt: skip
 
 
@@ -212,10 +212,12 @@ class PipelineOut(ctypes.Structure):
         ('neg', c_void_p), ('neg_time', c_void_p), ('seed_nid0', c_void_p), ('seed_ts0', c_void_p),
         ('out_nid', c_void_p * MAX_HOPS), ('out_ts', c_void_p * MAX_HOPS), ('out_x', c_void_p * MAX_HOPS),
         ('timed_hop', c_int32), ('ev_start', c_void_p), ('ev_stop', c_void_p),
-        ('out_valid', c_void_p * MAX_HOPS),
+        ('out_valid', c_void_p * MAX_HOPS), ('out_valid_prev', c_void_p * MAX_HOPS),
     ]  # fmt: skip
 
 
+ACCOUNTING_PARTIALS = 1024
+SIGNATURES['tgmx_lookup_accounting'] = (c_int32, [_P, c_int64, _P, _P, c_int64, _P, _P])
 SIGNATURES['tgmx_uniform_lookup_csr'] = (c_int32, [_P, _P, _P, c_int32, _P, c_int64, c_int32, c_int64, c_int32, c_int32, ctypes.c_uint64, ctypes.c_uint64,
                                                    _P, _P, _P, _P, _P])
 SIGNATURES['tgmx_ring_update_scratch_bytes'] = (c_size_t, [c_int64, c_int32])

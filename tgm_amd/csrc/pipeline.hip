@@ -84,6 +84,7 @@ extern "C" int tgmx_pipeline_step(const tgmx_pipeline_t* p, int64_t edge_lo, int
     s.out_ts[h] = out->out_ts[h];
     s.out_x[h] = out->out_x[h];
     s.out_valid[h] = out->out_valid[h];
+    s.out_valid_prev[h] = out->out_valid_prev[h];
   }
   s.timed_hop = out->timed_hop;
   s.ev_start = out->ev_start;
@@ -120,5 +121,40 @@ extern "C" int tgmx_slice(const int64_t* t, int64_t n, int32_t has_start_time, i
   u = std::max(lo_c, std::min(hi_c, u));
   *lb = l;
   *ub = u;
+  return TGMX_OK;
+}
+
+// ---- byte accounting of one lookup launch (bench.py's roofline; one launch instead of eight torch reductions inside the timed region)
+namespace {
+__global__ __launch_bounds__(256) void lookup_accounting_kernel(const int32_t* __restrict__ ids, long long slots, const int32_t* __restrict__ sp,
+                                                                const int32_t* __restrict__ sc, long long rows, unsigned long long* __restrict__ counts) {
+  unsigned long long v = 0, m = 0, c = 0;
+  const long long step = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += step) v += ids[i] != -1;
+  if (sp && sc)
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += step) {
+      const int a = sp[i], b = sc[i];
+      m += (unsigned long long)(a > b ? a : b);
+      c += (unsigned long long)b;
+    }
+  for (int o = 32; o > 0; o >>= 1) {
+    v += __shfl_xor(v, o);
+    m += __shfl_xor(m, o);
+    c += __shfl_xor(c, o);
+  }
+  if ((threadIdx.x & 63) == 0) {  // one partial triple per wave: nothing to zero beforehand, the host adds them up later
+    unsigned long long* o = counts + ((long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 3;
+    o[0] = v; o[1] = m; o[2] = c;
+  }
+}
+}  // namespace
+
+extern "C" int tgmx_lookup_accounting(const int32_t* ids, int64_t slots, const int32_t* span_prev, const int32_t* span_cur, int64_t rows,
+                                      int64_t* counts, tgmx_stream_t stream) {
+  TGMX_REQUIRE(ids && counts && slots >= 0 && rows >= 0, "lookup_accounting: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(lookup_accounting_kernel, dim3(TGMX_ACCOUNTING_PARTIALS / 4), dim3(256), 0, st, ids, (long long)slots, span_prev, span_cur, (long long)rows,
+                     reinterpret_cast<unsigned long long*>(counts));
+  TGMX_CHECK_LAUNCH("lookup_accounting");
   return TGMX_OK;
 }

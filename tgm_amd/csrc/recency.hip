@@ -96,6 +96,8 @@ struct LookupArgs {
   // then needs writes only from slot k - max(old span, new span) on: the pads left of that are zeros already.  NULL: every slot.
   int32_t* out_valid;
   int32_t* out_valid1;
+  int32_t* out_valid_prev;   // optional: receives the span a row held BEFORE this call (byte accounting of a timed launch)
+  int32_t* out_valid_prev1;
 };
 
 template <int VEC>
@@ -1146,7 +1148,7 @@ __device__ __forceinline__ void gather_rows(const LookupArgs& a, long long s, in
 // the k most recent neighbors of (n, q) into row s of (out_nid, out_ts, out_x)
 template <bool RING, int VEC, bool SMALL>
 __device__ __forceinline__ void lookup_seed(const LookupArgs& a, long long s, int n, long long q, int k, int lane, int* lds_eid,
-                                            int32_t* out_nid, int64_t* out_ts, float* out_x, int32_t* out_valid) {
+                                            int32_t* out_nid, int64_t* out_ts, float* out_x, int32_t* out_valid, int32_t* out_valid_prev) {
   const bool live = n >= 0 && n < a.N;
   // the row's SPAN: slots from its leftmost non-pad one to the end (0: all pads).  Valid slots sit at the right end of a row, but a
   // ring can hold a pad record between real ones (the oracle's lookup keeps it: an interior -1), so it is the leftmost
@@ -1197,7 +1199,10 @@ __device__ __forceinline__ void lookup_seed(const LookupArgs& a, long long s, in
   if (out_valid) {  // the row's previous contents are known: leave the zeros left of both valid tails alone
     const int v_old = out_valid[s];
     first_slot = k - (v_old > v_new ? v_old : v_new);
-    if (lane == 0) out_valid[s] = v_new;
+    if (lane == 0) {
+      out_valid[s] = v_new;
+      if (out_valid_prev) out_valid_prev[s] = v_old;
+    }
   }
   __builtin_amdgcn_wave_barrier();  // lds_eid written above is read cross-lane below
   gather_rows<VEC>(a, s, k, lane, lds_eid, out_x, first_slot);
@@ -1230,7 +1235,7 @@ __global__ __launch_bounds__(256) void recency_lookup_kernel(const LookupArgs a,
     long long q;
     fetch_seed(a, s, lane, true, n, q);
     check_seed(a, n, q, a.allow_pad, lane);
-    lookup_seed<RING, VEC, SMALL>(a, s, n, q, a.k, lane, lds_eid, a.out_nid, a.out_ts, a.out_x, a.out_valid);
+    lookup_seed<RING, VEC, SMALL>(a, s, n, q, a.k, lane, lds_eid, a.out_nid, a.out_ts, a.out_x, a.out_valid, a.out_valid_prev);
   }
   if constexpr (RING && RIDE) {
     if (a.tail_blocks) tail_signal(u.barrier, false, bid, nblk);
@@ -1272,7 +1277,7 @@ __global__ __launch_bounds__(256) void recency_lookup_fused01_kernel(const Looku
     if (w < S0) {
       fetch_seed(a, w, lane, true, n, q);
       check_seed(a, n, q, 0, lane);
-      lookup_seed<RING, VEC, true>(a, w, n, q, k0, lane, lds_eid, a.out_nid, a.out_ts, a.out_x, a.out_valid);
+      lookup_seed<RING, VEC, true>(a, w, n, q, k0, lane, lds_eid, a.out_nid, a.out_ts, a.out_x, a.out_valid, a.out_valid_prev);
     } else {
       const long long idx = w - S0;
       const long long s0 = idx / k0;
@@ -1283,7 +1288,7 @@ __global__ __launch_bounds__(256) void recency_lookup_fused01_kernel(const Looku
       const SmallPick o = small_pick<RING>(a, n0, q0, k0, n0 >= 0 && n0 < a.N, lane);
       n = __shfl(o.nbr, j);
       q = __shfl(o.ts, j);
-      lookup_seed<RING, VEC, true>(a, idx, n, q, k1, lane, lds_eid, a.out_nid1, a.out_ts1, a.out_x1, a.out_valid1);
+      lookup_seed<RING, VEC, true>(a, idx, n, q, k1, lane, lds_eid, a.out_nid1, a.out_ts1, a.out_x1, a.out_valid1, a.out_valid_prev1);
     }
   }
   if constexpr (RING) {
@@ -1352,7 +1357,7 @@ __device__ __forceinline__ GroupPick group_pick(const LookupArgs& a, int n, long
 // row s of (out_nid, out_ts, out_x) from the group's pick; k is wave-uniform
 template <int VEC, int GL>
 __device__ __forceinline__ void group_emit(const LookupArgs& a, bool act, long long s, int k, const GroupPick& o, int* lds_eid, int gl, int sub,
-                                           int32_t* out_nid, int64_t* out_ts, float* out_x, int32_t* out_valid) {
+                                           int32_t* out_nid, int64_t* out_ts, float* out_x, int32_t* out_valid, int32_t* out_valid_prev) {
   using V = typename VecOf<VEC>::type;
   if (act && gl < k) {
     out_nid[s * k + gl] = o.nbr;
@@ -1364,12 +1369,16 @@ __device__ __forceinline__ void group_emit(const LookupArgs& a, bool act, long l
   if (out_valid) {  // delta feature writes: see LookupArgs::out_valid
     const unsigned long long m = (__ballot(act && gl < k && o.has) >> (sub * GL)) & ((GL == 64) ? ~0ull : ((1ull << GL) - 1));
     const int v_new = m ? k - __builtin_ctzll(m) : 0;  // span from the leftmost non-pad slot (see lookup_seed)
+    int v_old = 0;
     if (act) {
-      const int v_old = out_valid[s];
+      v_old = out_valid[s];
       first_slot = k - (v_old > v_new ? v_old : v_new);
     }
-  __builtin_amdgcn_wave_barrier();  // every lane of the group has read the old count
-    if (act && gl == 0) out_valid[s] = v_new;
+    __builtin_amdgcn_wave_barrier();  // every lane of the group has read the old span
+    if (act && gl == 0) {
+      out_valid[s] = v_new;
+      if (out_valid_prev) out_valid_prev[s] = v_old;
+    }
   }
   __builtin_amdgcn_wave_barrier();
   if (act) {
@@ -1443,7 +1452,7 @@ __global__ __launch_bounds__(256) void lookup_packed_kernel(const LookupArgs a, 
       if (st) atomicOr(a.status, st);
     }
     const GroupPick o = group_pick<RING, GL>(a, n, q, k, n >= 0 && n < a.N, gl, sub);
-    group_emit<VEC, GL>(a, act, s, k, o, lds_eid, gl, sub, a.out_nid, a.out_ts, a.out_x, a.out_valid);
+    group_emit<VEC, GL>(a, act, s, k, o, lds_eid, gl, sub, a.out_nid, a.out_ts, a.out_x, a.out_valid, a.out_valid_prev);
   }
   if constexpr (RING && RIDE) {
     if (a.tail_blocks) tail_signal(u.barrier, false, bid, nblk);
@@ -2282,6 +2291,7 @@ extern "C" int tgmx_recency_step(const tgmx_recency_step_t* s, tgmx_stream_t str
     a.seeds = cur_n; a.qtimes = cur_t; a.out_nid = s->out_nid[0]; a.out_ts = s->out_ts[0]; a.out_x = s->out_x[0];
     a.k1 = k1; a.out_nid1 = s->out_nid[1]; a.out_ts1 = s->out_ts[1]; a.out_x1 = s->out_x[1];
     a.out_valid = s->out_valid[0]; a.out_valid1 = s->out_valid[1];
+    a.out_valid_prev = s->out_valid_prev[0]; a.out_valid_prev1 = s->out_valid_prev[1];
     a.status = s->status; a.S = S; a.D = s->D; a.k = k0; a.B = s->B; a.N = s->num_nodes; a.allow_pad = 0;
     a.ev_lo = s->ev_lo; a.ev_hi = s->ev_hi;
     const bool timed = s->timed_hop == 0 || s->timed_hop == 1;
@@ -2305,7 +2315,7 @@ extern "C" int tgmx_recency_step(const tgmx_recency_step_t* s, tgmx_stream_t str
     if (h == 0) a.grp = grp;
     a.indptr = s->indptr; a.recs = reinterpret_cast<const Rec*>(s->ring); a.write_pos = s->write_pos; a.edge_x = s->ring_x;
     a.seeds = cur_n; a.qtimes = cur_t; a.out_nid = s->out_nid[h]; a.out_ts = s->out_ts[h]; a.out_x = s->out_x[h];
-    a.out_valid = s->out_valid[h];
+    a.out_valid = s->out_valid[h]; a.out_valid_prev = s->out_valid_prev[h];
     a.status = s->status; a.S = S; a.D = s->D; a.k = k; a.B = s->B; a.N = s->num_nodes; a.allow_pad = h > 0;
     a.ev_lo = s->ev_lo; a.ev_hi = s->ev_hi;
     const bool timed = h == s->timed_hop;

@@ -168,8 +168,8 @@ class CompiledPipeline:
                     # are the right-aligned tail, the rest is zero and stays zero) -- tgmx_recency_step_t.out_valid.  The
                     # buffers start as all-pad rows; consumers must treat them as read-only.
                     nx = torch.zeros((S, k, D), dtype=torch.float32, device=dev)
-                    nv = torch.zeros(S, dtype=torch.int32, device=dev)
-                    out.out_valid[hop] = nv.data_ptr()
+                    nv = torch.zeros((2, S), dtype=torch.int32, device=dev)  # [0]: the rows' spans, [1]: the spans before the last call
+                    out.out_valid[hop], out.out_valid_prev[hop] = nv[0].data_ptr(), nv[1].data_ptr()
                     valid.append(nv)
                 else:
                     nx = torch.empty((S, k, D), dtype=torch.float32, device=dev)
@@ -291,13 +291,12 @@ class CompiledPipeline:
         if nbr.profile_hop is not None and nbr._calls % nbr.profile_every == 0 and nbr.profile_pool:
             timer = nbr.profile_pool.pop()
             out.timed_hop, out.ev_start, out.ev_stop = nbr.profile_hop, timer.start, timer.stop
-        prev_valid = [v.clone() for v in slot.valid] if (timer is not None and slot.valid) else None
         rc = self._lib.tgmx_pipeline_step(pipe, lo, n, call, out, slot.post, _native.stream_ptr(self._device.index))
         if rc:
             _native.check(rc, 'tgmx_pipeline_step')
         if timer is not None:
             out.timed_hop = -1
-            self._log_timed(timer, slot, prev_valid)
+            self._log_timed(timer, slot)
         if nbr._validate == 'sync':
             nbr.check()  # one device -> host read per batch: the reference's raise-per-call behaviour
         d = batch.__dict__
@@ -312,7 +311,9 @@ class CompiledPipeline:
             self._defer_post(batch, slot)
         return True
 
-    def _log_timed(self, timer, slot: _Slot, prev_valid=None) -> None:
+    def _log_timed(self, timer, slot: _Slot) -> None:
+        """What bench.py's byte model needs of a timed launch, as ONE small launch per hop behind it (tgmx_lookup_accounting: partial sums
+        the reader adds up after the run): valid slots, and -- delta feature writes -- the slots whose feature row was rewritten."""
         nbr = self._nbr
         st = self._pipe.step
         # what tgmx_recency_step_plan needs of the per-call fields: the seed count and the hop-1 output alignment
@@ -321,12 +322,23 @@ class CompiledPipeline:
             st.out_x[h] = slot.out.out_x[h]
         fused = bool(self._lib.tgmx_recency_step_plan(st) & 1)
         hops = [0, 1] if nbr.profile_hop in (0, 1) and fused else [nbr.profile_hop]
-        counts = torch.empty(len(hops), dtype=torch.int64, device=self._device)
+        parts = torch.empty((len(hops), _native.ACCOUNTING_PARTIALS, 3), dtype=torch.int64, device=self._device)
+        stream = _native.stream_ptr(self._device.index)
         for i, h in enumerate(hops):
-            torch.sum((slot.nbr_nids[h] != -1).view(-1), dim=0, dtype=torch.int64, out=counts[i])
-        written = None
-        if prev_valid is not None:  # delta feature writes: slots whose feature row was (re)written = max(valid before, valid now) per row
-            written = torch.empty(len(hops), dtype=torch.int64, device=self._device)
-            for i, h in enumerate(hops):
-                torch.sum(torch.maximum(prev_valid[h], slot.valid[h]), dim=0, dtype=torch.int64, out=written[i])
-        nbr.profile_log.append((timer, [(slot.attrs['seed_nids'][h].shape[0], nbr._num_nbrs[h]) for h in hops], counts, written))
+            ids = slot.nbr_nids[h]
+            sp = slot.valid[h] if slot.valid else None
+            _native.check(self._lib.tgmx_lookup_accounting(ids.data_ptr(), ids.numel(), sp[1].data_ptr() if sp is not None else None,
+                                                           sp[0].data_ptr() if sp is not None else None, ids.shape[0], parts[i].data_ptr(), stream),
+                          'tgmx_lookup_accounting')
+        nbr.profile_log.append((timer, [(slot.attrs['seed_nids'][h].shape[0], nbr._num_nbrs[h]) for h in hops], _Counts(parts, 0),
+                                _Counts(parts, 1) if slot.valid else None))
+
+
+class _Counts:
+    """column `col` of tgmx_lookup_accounting's partial sums, one entry per hop -- summed when somebody asks (after the timed region)"""
+
+    def __init__(self, parts: torch.Tensor, col: int) -> None:
+        self._parts, self._col = parts, col
+
+    def sum(self) -> torch.Tensor:
+        return self._parts[:, :, self._col].sum()
