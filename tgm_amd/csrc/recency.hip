@@ -313,7 +313,7 @@ template <int E, int MAXM, bool PRESORTED, bool DEFER>
 __device__ __forceinline__ void update_block_body(const UpdateArgs& a, PlaceLds<MAXM>& L, SortLds<PRESORTED ? 1 : MAXM>& S,
                                                   int part = 0, int parts = 1) {
   constexpr int H = 2 * MAXM;
-  constexpr int HBITS = MAXM == 1024 ? 11 : (MAXM == 2048 ? 12 : 13);
+  constexpr int HBITS = MAXM == 512 ? 10 : (MAXM == 1024 ? 11 : (MAXM == 2048 ? 12 : 13));
   static_assert((1 << HBITS) == H, "hash size");
   long long* s_key = S.key;
   int* s_pay = S.pay;
@@ -926,14 +926,24 @@ __device__ __forceinline__ void tail_commit(const UpdateArgs& a, unsigned tb, un
   }
 }
 
+// PCAP: capacity of the riding placement (entries); 0 = this launch's riders only sort / merge.  The union is static LDS of EVERY
+// workgroup of the launch, rider or not: 24.9 KB at 1024 entries caps a lookup launch at 6 workgroups per CU, 12.6 KB at 512
+// (the single-rank wiki batch: m = 400) at 12, 6.2 KB without the placement tables at 25.
+template <int PCAP>
 union RiderLds {
   ChunkSortLds sort;
   SampleLds smp;
-  PlaceLds<kRidePlaceMaxM> place;
+  PlaceLds<PCAP> place;
+};
+template <>
+union RiderLds<0> {
+  ChunkSortLds sort;
+  SampleLds smp;
 };
 
+template <int PCAP = kRidePlaceMaxM>
 __device__ __forceinline__ void update_side_work(const UpdateArgs& u, int stage, int block) {
-  __shared__ RiderLds W;
+  __shared__ RiderLds<PCAP> W;
   if (stage == kSideSort) {
     update_chunk_sort(u, block, W.sort);
   } else if (stage == kSideMerge) {
@@ -942,19 +952,20 @@ __device__ __forceinline__ void update_side_work(const UpdateArgs& u, int stage,
     update_chunk_sort<true>(u, block, W.sort);
     if (!rider_barrier(u.barrier, (int)((u.m + kChunk - 1) / kChunk)) && threadIdx.x == 0) atomicOr(u.status, TGMX_ST_SCRATCH);
     update_merge_riding<1, kBlockMaxM / kChunk>(u, block, W.smp);
-  } else {
+  } else if constexpr (PCAP > 0) {
+    constexpr int NCH = PCAP / kChunk;  // chunks of a batch this rider takes whole: one entry of every chunk per thread
     if (stage == kSideAll) {
       const int chunks = (int)((u.m + kChunk - 1) / kChunk);
 #pragma unroll 1
-      for (int c = 0; c < kRidePlaceMaxM / kChunk; ++c) {
+      for (int c = 0; c < NCH; ++c) {
         if (c < chunks) update_chunk_sort(u, c, W.sort);
         __syncthreads();  // W.sort is reused; the chunk-sorted pairs written above are read below by other threads
       }
     }
-    update_merge_riding<4, 4>(u, 0, W.smp);
+    update_merge_riding<NCH, NCH>(u, 0, W.smp);
     __syncthreads();  // the sorted arrays written above are read below by other threads of this workgroup
     SortLds<1> none;
-    update_block_body<4, kRidePlaceMaxM, true, true>(u, W.place, none);
+    update_block_body<NCH, PCAP, true, true>(u, W.place, none);
   }
 }
 
@@ -1248,13 +1259,13 @@ __global__ __launch_bounds__(256) void recency_lookup_kernel(const LookupArgs a,
 // the dependency between the launches: the few hundred hop-0 seeds -- a launch bound by its three dependent reads, not
 // by bandwidth -- run inside the big hop-1 launch instead of in front of it.  Waves [0, S0) are hop 0 (they also
 // publish the concatenated seeds), waves [S0, S0 + S0 k0) are hop 1; results are identical to the two launches.
-template <bool RING, int VEC>
+template <bool RING, int VEC, int PCAP = kRidePlaceMaxM>
 __global__ __launch_bounds__(256) void recency_lookup_fused01_kernel(const LookupArgs a, const UpdateArgs u) {
   extern __shared__ __attribute__((aligned(16))) int lds_eid_all[];
   unsigned bid = blockIdx.x, nblk = gridDim.x;
   if constexpr (RING) {
     if (bid < a.side_blocks) {
-      update_side_work(u, a.side_stage, (int)bid);
+      update_side_work<PCAP>(u, a.side_stage, (int)bid);
       if (a.tail_blocks) tail_signal(u.barrier, true, 0, 0);
       return;
     }
@@ -1563,7 +1574,11 @@ static int launch_fused01(LookupArgs a, hipStream_t stream, hipEvent_t ev_start,
   if (blocks > (1 << 20)) blocks = 1 << 20;
   const dim3 grid((unsigned)blocks + a.side_blocks + a.tail_blocks), block(waves_per_block * kWave);
   const size_t lds = (size_t)waves_per_block * kmax * sizeof(int);
-  if (vec == 4) TGMX_LAUNCH_TIMED((recency_lookup_fused01_kernel<RING, 4>), grid, block, lds, stream, ev_start, ev_stop, a, u);
+  // the riders' static LDS sized for what rides (RiderLds): placement of <= 512 entries, of <= 1024, or sort / merge only
+  const int pcap = !(RING && side) ? 1024 : (side_stage != kSideAll ? 0 : (u.m <= 512 ? 512 : 1024));
+  if (vec == 4 && pcap == 512) TGMX_LAUNCH_TIMED((recency_lookup_fused01_kernel<RING, 4, RING ? 512 : 1024>), grid, block, lds, stream, ev_start, ev_stop, a, u);
+  else if (vec == 4 && pcap == 0) TGMX_LAUNCH_TIMED((recency_lookup_fused01_kernel<RING, 4, RING ? 0 : 1024>), grid, block, lds, stream, ev_start, ev_stop, a, u);
+  else if (vec == 4) TGMX_LAUNCH_TIMED((recency_lookup_fused01_kernel<RING, 4>), grid, block, lds, stream, ev_start, ev_stop, a, u);
   else if (vec == 2) TGMX_LAUNCH_TIMED((recency_lookup_fused01_kernel<RING, 2>), grid, block, lds, stream, ev_start, ev_stop, a, u);
   else TGMX_LAUNCH_TIMED((recency_lookup_fused01_kernel<RING, 1>), grid, block, lds, stream, ev_start, ev_stop, a, u);
   TGMX_CHECK_LAUNCH("recency_lookup_fused01");
