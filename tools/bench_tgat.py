@@ -15,7 +15,7 @@ from tgm_amd.synth import make_stream  # noqa: E402
 
 stream = make_stream('wiki', seed=1337)
 dev = torch.device('cuda', 0)
-dg, hm, hook, loader = bench.build_pipeline(stream, 0, 1, 200, [20, 20], 'ring', dev)
+dg, hm, hook, loader = bench.build_pipeline(stream, 0, 1, 200, [20, 20], 'ring', dev, pool=1)  # the lowered chain into one persistent output set
 enc = TGAT(node_dim=1, edge_dim=172, time_dim=100, embed_dim=172, num_layers=2).to(dev).eval()
 starts = loader._starts
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
