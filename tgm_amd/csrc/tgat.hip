@@ -1349,6 +1349,11 @@ __global__ __launch_bounds__(256) void tgat_attn_reduce_reg_kernel(const AttnArg
   // as straight-line code: with the choice (a wave vote and a branch) inside every evaluation the 40 evaluations of a
   // row cost 23 of the kernel's 73 us.  Lanes past T carry w = b = 0: their cos(0) meets a zero query weight below and
   // is never stored.
+  // A masked slot of a row that has a valid one gets attention weight exactly 0: its Time2Vec columns never reach the output, so
+  // they are not evaluated (zeros stand in).  63 % of the slots are pads at the headline shape and the cosines are this kernel's
+  // largest single cost.  A row with NO valid slot attends uniformly over all of them (attention.py:114-118): everything is needed.
+  const unsigned long long okm = __ballot(my_ok);
+  const unsigned long long need = okm ? okm : ~0ull;
   bool small = true;
 #pragma unroll
   for (int s = 0; s < G; ++s) {
@@ -1368,16 +1373,22 @@ __global__ __launch_bounds__(256) void tgat_attn_reduce_reg_kernel(const AttnArg
   } else if (row_small) {
 #pragma unroll
     for (int s = 0; s < G; ++s) {
-      const float dt = lane_bcast(my_dt, s);
-      tz0[s] = cos_t2v_small(__fmaf_rn(dt, w0, b0));
-      tz1[s] = cos_t2v_small(__fmaf_rn(dt, w1, b1));
+      tz0[s] = tz1[s] = 0.f;
+      if ((need >> s) & 1) {  // wave-uniform
+        const float dt = lane_bcast(my_dt, s);
+        tz0[s] = cos_t2v_small(__fmaf_rn(dt, w0, b0));
+        tz1[s] = cos_t2v_small(__fmaf_rn(dt, w1, b1));
+      }
     }
   } else {
 #pragma unroll
     for (int s = 0; s < G; ++s) {
-      const float dt = lane_bcast(my_dt, s);
-      tz0[s] = cos_t2v_big(__fmaf_rn(dt, w0, b0));
-      tz1[s] = cos_t2v_big(__fmaf_rn(dt, w1, b1));
+      tz0[s] = tz1[s] = 0.f;
+      if ((need >> s) & 1) {
+        const float dt = lane_bcast(my_dt, s);
+        tz0[s] = cos_t2v_big(__fmaf_rn(dt, w0, b0));
+        tz1[s] = cos_t2v_big(__fmaf_rn(dt, w1, b1));
+      }
     }
   }
 #pragma unroll
