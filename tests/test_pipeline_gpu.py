@@ -113,6 +113,39 @@ def test_delta_feature_writes_equal_full_writes(mode, k, D, shape):
     hook_b.check()
 
 
+def test_delta_feature_writes_fuzz():
+    """Random shapes through the pooled loader (delta feature writes) vs fresh tensors per batch: hop counts, k (incl. > 64), feature
+    widths that are and are not multiples of 4, batch sizes that put the ring update on each of its plans, both modes, pool sizes
+    1-3.  TGMX_FUZZ=<n> runs n configurations (default 12)."""
+    import os
+    import random
+
+    rng = random.Random(2024)
+    for it in range(int(os.environ.get('TGMX_FUZZ', '12'))):
+        mode = rng.choice(['ring', 'ring', 'csr'])
+        hops = rng.choice([1, 2, 2, 3])
+        k = [rng.choice([1, 2, 3, 5, 8, 10, 16, 20, 33, 70]) for _ in range(hops)]
+        while sum(1 for _ in k) > 1 and __import__('math').prod(k) > 4000:
+            k[k.index(max(k))] = 4
+        D = rng.choice([0, 1, 3, 4, 8, 12, 16, 20, 43])
+        bs = rng.choice([7, 64, 200, 513, 700])
+        shape = rng.choice(['wiki', 'review', 'comment'])
+        pool = rng.choice([1, 1, 2, 3])
+        st = _stream(E=rng.choice([900, 2500]), D=D, shape=shape)
+        hm_a, hook_a, plain = _build(st, bs, k, mode, 0)
+        hm_b, hook_b, pooled = _build(st, bs, k, mode, pool)
+        tag = f'config {it}: mode={mode} k={k} D={D} bs={bs} {shape} pool={pool}'
+        with hm_a.activate('k'), hm_b.activate('k'):
+            for epoch in range(2):
+                for n, (ba, bb) in enumerate(zip(plain, pooled)):
+                    for name in ('nbr_nids', 'nbr_edge_time', 'nbr_edge_x'):
+                        _same(getattr(ba, name), getattr(bb, name), f'{tag} epoch {epoch} batch {n} {name}')
+                hm_a.reset_state()
+                hm_b.reset_state()
+        hook_a.check()
+        hook_b.check()
+
+
 def test_lookup_accounting_matches_torch():
     """tgmx_lookup_accounting (the byte model's counts of a timed launch as partial sums) against torch reductions."""
     from tgm_amd import _native
