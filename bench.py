@@ -346,7 +346,10 @@ def main():
             'workload': f'tgbl-{args.workload}-shaped synthetic stream: N={stream.num_nodes}, E={stream.num_edges}, D={D}; '
             f'seeds = src|dst|neg, num_nbrs={num_nbrs}, global batch {global_bs} edges, {bs_rank} seed edges per rank, mode={args.mode}; '
             f'timed batches {first_timed}..{first_timed + steps - 1} of {n_batches} (batches before them replayed untimed: rings in steady state); '
-            + (f'loader output_pool={args.pool}: one tgmx_pipeline_step per batch into a ring of preallocated outputs; ' if lowered
+            + (f'loader output_pool={args.pool}: one tgmx_pipeline_step per batch into a ring of preallocated, persistent outputs '
+               + ('(every neighbor is looked up and copied every batch; a feature row is rewritten from its leftmost slot that changes on -- the '
+                  'all-pad slots left of it hold zeros already --, ids and times in full; TGMX_DELTA_WRITES=0 rewrites every slot); '
+                  if os.environ.get('TGMX_DELTA_WRITES', '1') != '0' else '(every slot rewritten: TGMX_DELTA_WRITES=0); ') if lowered
                else 'hook-by-hook path, fresh output tensors per batch; ')
             + f"seed validation on the device, validate='{args.validate}'"
             + (' (status word read back once after the timed steps)' if args.validate == 'deferred' else ''),
