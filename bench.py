@@ -65,6 +65,7 @@ def parse_args():
     p.add_argument('--seed', type=int, default=1337)
     p.add_argument('--emulate-world', type=int, default=0, help='single process: run the step of rank --emulate-rank of a W-rank job (there is no data-path collective, so nothing is missing from it); modelling aid, n_gpus stays 1')
     p.add_argument('--emulate-rank', type=int, default=0)
+    p.add_argument('--no-default-path', action='store_true', help="skip the second timed region (the same steps through DGDataLoader / RecencyNeighborHook with their DEFAULT arguments)")
     return p.parse_args()
 
 
@@ -87,11 +88,13 @@ def build_pipeline(stream, rank, world, global_bs, num_nbrs, mode, device, pool=
     else:
         keys, tkeys = ['edge_src', 'edge_dst', 'neg'], ['edge_time', 'edge_time', 'neg_time']
         hm.register('bench', RandomNegativeEdgeSamplerHook(lo_dst, stream.num_nodes))
-    hook = RecencyNeighborHook(
-        stream.num_nodes, num_nbrs, keys, tkeys, mode=mode, validate=validate, batch_size=global_bs if mode == 'csr' else None
-    )
+    kw = {} if validate is None else {'validate': validate}  # None: the hook's own default ('sync', the reference's raise-per-call)
+    hook = RecencyNeighborHook(stream.num_nodes, num_nbrs, keys, tkeys, mode=mode, batch_size=global_bs if mode == 'csr' else None, **kw)
     hm.register('bench', hook)
-    loader = DGDataLoader(dg, batch_size=global_bs, hook_manager=hm, output_pool=pool)
+    if pool is None:  # the loader's own default: what an unmodified TGM script gets
+        loader = DGDataLoader(dg, batch_size=global_bs, hook_manager=hm)
+    else:
+        loader = DGDataLoader(dg, batch_size=global_bs, hook_manager=hm, output_pool=pool)
     return dg, hm, hook, loader
 
 
@@ -284,10 +287,40 @@ def main():
         elapsed = time.perf_counter() - t0
         hook.check()
 
+    # ---- the same steps through the library's DEFAULT arguments (what an unmodified TGM script gets): DGDataLoader(dg, bs,
+    # hook_manager=hm) + RecencyNeighborHook(...) with validate='sync'; the consumer holds batch i while batch i + 1 is produced,
+    # like `for batch in loader` does ----
+    default_elapsed = None
+    if not args.no_default_path and args.mode == 'ring':
+        dg2, hm2, hook2, loader2 = build_pipeline(stream, rank, world, global_bs, num_nbrs, args.mode, device, pool=None, validate=None)
+        with hm2.activate('bench'):
+            it, held = 0, None
+            for _ in range(first_timed):
+                held = loader2(starts[it])
+                it += 1
+            if real_world > 1:
+                torch.distributed.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                if it == n_batches:
+                    hm2.reset_state()
+                    it = 0
+                held = loader2(starts[it])
+                it += 1
+            torch.cuda.synchronize()
+            if real_world > 1:
+                torch.distributed.barrier()
+            default_elapsed = time.perf_counter() - t0
+            hook2.check()
+            default_sets = len(loader2._compiled[1]._sets) if loader2._compiled and loader2._compiled[1] is not None else 0
+            del held
+
     if real_world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed, default_elapsed or 0.0], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = float(t[0].item())
+        default_elapsed = float(t[1].item()) if default_elapsed is not None else None
 
     # units actually processed by the timed steps (the ragged last batch of an epoch is smaller), all ranks together
     total_units, total_events, it = 0, 0, first_timed
@@ -377,6 +410,15 @@ def main():
             if delta else 'valid-aware: slots x (12 + 4D) written + valid slots x (16 + 4D) read + 68 B per seed',
         },
     }
+    out['valid_edges_per_s'] = out['value'] * out['roofline']['valid_slot_fraction']  # sampled slots that hold a neighbor (pads excluded)
+    if default_elapsed is not None:
+        out['default_path'] = {
+            'ms_per_step': 1e3 * default_elapsed / steps,
+            'value': total_units / default_elapsed,
+            'what': "the same timed steps through DGDataLoader(dg, batch_size, hook_manager=hm) and RecencyNeighborHook(...) with their DEFAULT "
+            "arguments (validate='sync': raise-per-call; fresh-tensor semantics: an output set is reused only once nothing can reach its "
+            f'tensors), the consumer holding batch i while batch i + 1 is produced like `for batch in loader`; {default_sets} output sets in use',
+        }
     if rank == 0 or args.emulate_world:
         if world == 1 and real_world == 1 and args.cpu_batches > 0:
             out['cpu_baseline'] = cpu_baseline(stream, bs, num_nbrs, args.cpu_batches, args.seed, first_timed)

@@ -255,3 +255,25 @@ def test_reference_side_binding_script():
     r = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count('[binding] ok') == 5
+
+
+def test_loader_is_a_torch_dataloader_like_the_reference():
+    """tgm/data/loader.py:64,147-149: the reference subclasses torch.utils.data.DataLoader and forwards **kwargs to it.  Ours
+    does too (isinstance, len, dataset = the slice starts, torch validates the keyword arguments), and refuses the one setting
+    that cannot work for either implementation: worker processes (hook state would fork)."""
+    import torch.utils.data
+
+    from tgm_amd import DGData, DGDataLoader, DGraph
+
+    ts = torch.arange(50)
+    src, dst = torch.randint(0, 10, (50,), dtype=torch.int32), torch.randint(0, 10, (50,), dtype=torch.int32)
+    dg = DGraph(DGData.from_raw(ts, torch.stack([src, dst], 1), torch.rand(50, 3)))
+    loader = DGDataLoader(dg, batch_size=7, drop_last=True, pin_memory=False, timeout=0)
+    assert isinstance(loader, torch.utils.data.DataLoader)
+    assert len(loader) == 7 and list(loader.dataset) == list(range(0, 43, 7)) and loader.drop_last and loader.collate_fn is loader
+    assert sum(b.edge_src.numel() for b in loader) == 49
+    assert len(DGDataLoader(dg, batch_size=7)) == 8
+    with pytest.raises(TypeError, match='bogus'):
+        DGDataLoader(dg, batch_size=7, bogus=1)
+    with pytest.raises(ValueError, match='num_workers'):
+        DGDataLoader(dg, batch_size=7, num_workers=2)

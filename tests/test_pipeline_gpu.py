@@ -108,7 +108,7 @@ def test_delta_feature_writes_equal_full_writes(mode, k, D, shape):
             hm_a.reset_state()
             hm_b.reset_state()
     cp = pooled._compiled[1]
-    assert cp is not None and cp._delta and all(sl.valid for slots in cp._pools.values() for sl in slots), 'the pooled loader did not take the delta path'
+    assert cp is not None and cp._delta and cp._sets and all(sl.valid for os_ in cp._sets for sl in os_.views.values()), 'the pooled loader did not take the delta path'
     hook_a.check()
     hook_b.check()
 
@@ -369,3 +369,165 @@ def test_lowered_tgn_tail_dedup_and_edge_list():
                 _same(a.global_to_local(a.edge_dst), other.global_to_local(other.edge_dst), 'global_to_local')
         assert n == 15
         assert pooled._compiled[1].n_lowered == 4 and ahead._compiled[1].n_lowered == 4
+
+
+# ---- the loader's DEFAULT: lowered chain, fresh-tensor semantics from liveness-checked output sets (round 3) --------------------
+def _default_loader(st, bs, k, mode='ring', validate='sync', D=None, num_nodes=None):
+    from tgm_amd import DGData, DGDataLoader, DGraph
+    from tgm_amd.hooks import HookManager, RandomNegativeEdgeSamplerHook, RecencyNeighborHook
+
+    dg = DGraph(DGData.from_raw(st.ts, torch.stack([st.src, st.dst], 1), st.edge_x), device=DEV)
+    hm = HookManager(keys=['k'])
+    N = num_nodes or st.num_nodes
+    hm.register('k', RandomNegativeEdgeSamplerHook(int(st.dst.min()), N, seed=5))
+    hook = RecencyNeighborHook(N, k, ['edge_src', 'edge_dst', 'neg'], ['edge_time', 'edge_time', 'neg_time'], mode=mode, validate=validate,
+                               batch_size=bs if mode == 'csr' else None)  # fmt: skip
+    hm.register('k', hook)
+    return dg, hm, hook, DGDataLoader(dg, batch_size=bs, hook_manager=hm)  # no output_pool=: the default
+
+
+@pytest.mark.parametrize('mode', ['ring', 'csr'])
+def test_default_loader_lowers_and_keeps_fresh_tensor_semantics(mode):
+    """An unmodified script -- DGDataLoader(dg, batch_size, hook_manager=hm), RecencyNeighborHook's default validate='sync' -- runs
+    the lowered chain.  Its tensors behave like the reference's fresh ones (recency.py:119-171 returns new gathers per call): a
+    batch somebody still holds is never overwritten, whatever they hold of it."""
+    st = _stream(E=3000, D=8)
+    bs, k = 100, [5, 4]
+    hm_a, hook_a, plain = _build(st, bs, k, mode, 0)
+    plain_batches = []
+    with hm_a.activate('k'):
+        for b in plain:
+            plain_batches.append(b)
+    dg, hm, hook, loader = _default_loader(st, bs, k, mode)
+    names = ('seed_nids', 'seed_times', 'nbr_nids', 'nbr_edge_time', 'nbr_edge_x', 'seed_node_nbr_mask', 'neg', 'neg_time')
+    with hm.activate('k'):
+        kept = list(loader)  # every batch alive at once: nothing may be recycled
+        cp = loader._compiled[1]
+        assert cp is not None and cp._safe and cp.n_lowered == 2, 'the default loader did not lower the chain'
+        for n, (a, b) in enumerate(zip(plain_batches, kept)):
+            for name in names:
+                _same(getattr(a, name), getattr(b, name), f'all alive, batch {n} {name}')
+        del kept, b
+        hm.reset_state()
+        # a loop that drops each batch before the next is produced stays on ONE set
+        ptrs = set()
+        for n, s0 in enumerate(loader._starts):
+            b = loader(s0)
+            ptrs.add(b.nbr_edge_x[1].data_ptr())
+            for name in names:
+                _same(getattr(plain_batches[n], name), getattr(b, name), f'dropped, batch {n} {name}')
+            del b
+        assert len(ptrs) <= 2, f'{len(ptrs)} output sets used by a loop that holds no batch'  # (ragged last batch: other views, same set)
+        hm.reset_state()
+        # `for batch in loader` holds batch i while batch i + 1 is produced: two sets alternate, contents stay right
+        prev = None
+        for n, b in enumerate(loader):
+            if prev is not None:
+                for name in names:
+                    _same(getattr(plain_batches[n - 1], name), getattr(prev, name), f'for-loop, previous batch {n - 1} {name}')
+            prev = b
+        hm.reset_state()
+        # what a consumer may hold of a batch: a tensor, a view of one, a detached alias, a tensor autograd saved
+        holders = []
+        w = torch.ones(8, 1, device=DEV, requires_grad=True)
+        for n, s0 in enumerate(loader._starts[:8]):
+            b = loader(s0)
+            ref = plain_batches[n]
+            how = n % 4
+            if how == 0:
+                holders.append((b.nbr_nids[1], ref.nbr_nids[1]))
+            elif how == 1:
+                holders.append((b.nbr_edge_x[1][3:9], ref.nbr_edge_x[1][3:9]))
+            elif how == 2:
+                holders.append((b.nbr_edge_time[0].detach(), ref.nbr_edge_time[0]))
+            else:
+                y = (b.nbr_edge_x[0] @ w).sum()  # saves nbr_edge_x[0] for backward
+                holders.append((y, ref.nbr_edge_x[0]))
+            del b
+        for n, (got, want) in enumerate(holders):
+            if got.dim() == 0:
+                (g,) = torch.autograd.grad(got, w)
+                _same(g, want.sum((0, 1)).view(8, 1), f'holder {n}: the tensor autograd saved was overwritten')
+            else:
+                _same(got, want, f'holder {n}')
+    hook.check()
+
+
+def test_default_loader_survives_in_place_modification():
+    """Fresh tensors may be modified in place by their owner.  The persistent sets rely on pad slots staying zero (delta feature
+    writes): an in-place torch op moves the buffer's version counter and the set is re-initialised before its next use."""
+    st = _stream(E=2000, D=8)
+    bs, k = 100, [6, 3]
+    hm_a, _, plain = _build(st, bs, k, 'ring', 0)
+    dg, hm, hook, loader = _default_loader(st, bs, k)
+    with hm_a.activate('k'), hm.activate('k'):
+        for n, (a, s0) in enumerate(zip(plain, loader._starts)):
+            b = loader(s0)
+            for name in ('nbr_nids', 'nbr_edge_time', 'nbr_edge_x'):
+                _same(getattr(a, name), getattr(b, name), f'batch {n} {name}')
+            if n % 3 == 1:
+                b.nbr_edge_x[1].add_(1.0)  # pads are no longer zero
+                b.nbr_nids[0].fill_(7)
+                b.seed_node_nbr_mask['neg'].zero_()
+            del b
+    hook.check()
+
+
+def test_default_sync_validation_raises_per_call_without_touching_state():
+    """validate='sync' (the hook's default) through the lowered chain: the reference raises in the call that carries a bad seed,
+    before it touches its state (recency.py:214-229).  The seeds are rows of the resident store, so the loader knows the
+    offending edges up front: the batch that contains one raises ValueError, the others run, no device read per batch."""
+    st = _stream(E=1500, D=4)
+    N = st.num_nodes
+    bad_edge = 777
+    src = st.src.clone()
+    src[bad_edge] = N + 3  # out of the hook's node range (the store itself allows it: DGData infers num_nodes from the ids)
+    import dataclasses
+
+    st2 = dataclasses.replace(st, src=src)
+    dg, hm, hook, loader = _default_loader(st2, 100, [4, 2], num_nodes=N)
+    with hm.activate('k'):
+        for n, s0 in enumerate(loader._starts):
+            if s0 <= bad_edge < s0 + 100:
+                ring_before = hook._ring.clone()
+                with pytest.raises(ValueError, match='Seed nodes must satisfy'):
+                    loader(s0)
+                assert torch.equal(ring_before, hook._ring), 'a refused batch changed the rings'
+            else:
+                loader(s0)
+        cp = loader._compiled[1]
+        assert cp._static_ok[0] and list(cp._static_ok[1]) == [bad_edge]
+    hook.check()  # the device never saw the bad seed
+
+
+def test_prefetch_settles_finalizers_for_hooks_that_need_them():
+    """A hook ordered behind DeduplicationHook that READS unique_nids must find it even when the loader runs a batch ahead and
+    the dedup result's size is still in flight (the finalizer is then run before that hook instead of one batch later)."""
+    from tgm_amd import DGData, DGDataLoader, DGraph
+    from tgm_amd.hooks import DeduplicationHook, HookManager, RandomNegativeEdgeSamplerHook, RecencyNeighborHook
+    from tgm_amd.hooks.base import StatelessHook
+
+    class NeedsUnique(StatelessHook):
+        _cls_requires = {'unique_nids'}
+        _cls_produces = {'n_unique'}
+
+        def __init__(self):
+            super().__init__()
+            self.__post_init__()
+
+        def __call__(self, dg, batch):
+            batch.n_unique = int(batch.unique_nids.numel())  # AttributeError before the fix
+            return batch
+
+    st = _stream(E=1200, D=4, shape='review', n_src=300, n_dst=60)
+    dg = DGraph(DGData.from_raw(st.ts, torch.stack([st.src, st.dst], 1), st.edge_x), device=DEV)
+    for pool in (None, 0, 3):
+        hm = HookManager(keys=['k'])
+        hm.register('k', RandomNegativeEdgeSamplerHook(300, st.num_nodes, seed=9))
+        hm.register('k', RecencyNeighborHook(st.num_nodes, [5], ['edge_src', 'edge_dst', 'neg'], ['edge_time', 'edge_time', 'neg_time'], validate='deferred'))
+        hm.register('k', DeduplicationHook(seed_nodes_keys=['neg', 'nbr_nids']))
+        hm.register('k', NeedsUnique())
+        loader = DGDataLoader(dg, batch_size=128, hook_manager=hm, output_pool=pool, prefetch=1)
+        with hm.activate('k'):
+            for b in loader:
+                assert b.n_unique == b.unique_nids.numel() > 0

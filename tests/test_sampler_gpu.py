@@ -586,13 +586,16 @@ def _against_oracle(st, bs, ks, n_batches, pool=3):
     assert loader._compiled[1] is not None
 
 
-def test_cfg2_benched_mode_full_size_vs_oracle():
+@pytest.mark.parametrize('pool', [1, 3, None])
+def test_cfg2_benched_mode_full_size_vs_oracle(pool):
     """BASELINE cfg 2 exactly as bench.py runs it -- full N = 9227, D = 172, bs = 200, k = [20, 20], the reference's
     wrapping int32 key arithmetic (recency.py:347), pooled outputs, negatives generated in the seed fetch -- against the
-    CPU restatement of the reference for the first 160 batches (32 000 edges: rings of the hubs wrap several times)."""
+    CPU restatement of the reference for the first 160 batches (32 000 edges: rings of the hubs wrap several times).
+    pool = 1: the benched pool (ONE persistent output set, delta feature writes at D = 172); pool = None: the loader's default
+    (liveness-checked sets: the loop below holds batch i while batch i + 1 is produced, so two sets alternate)."""
     from tgm_amd.synth import make_stream
 
-    _against_oracle(make_stream('wiki', seed=1337), 200, [20, 20], 160)
+    _against_oracle(make_stream('wiki', seed=1337), 200, [20, 20], 160, pool=pool)
 
 
 def test_cfg3_review_shape_two_hops_vs_oracle():

@@ -38,17 +38,27 @@ class DGBatch:
     # Hooks whose output SIZE is only known on the device (unique ids, compacted edge lists) enqueue their kernels, start an
     # asynchronous copy of the size and register a finalizer here instead of waiting for it; the loader runs the
     # finalizers right away (default) or one batch later (DGDataLoader(prefetch=1)), when the size arrived long ago.
-    def _defer(self, fn) -> None:
+    def _defer(self, fn, produces=frozenset()) -> None:
+        """``produces``: the batch attributes ``fn`` publishes -- a hook further down the chain that requires one of them makes the
+        loader run the finalizers first (:meth:`_settle`)."""
         if self.__dict__.get('_deferred', False):
-            self.__dict__.setdefault('_pending', []).append(fn)
+            self.__dict__.setdefault('_pending', []).append((fn, frozenset(produces)))
         else:
             fn()
+
+    def _settle(self, requires) -> None:
+        """Run the pending finalizers now if any of them publishes an attribute in ``requires`` (None: whatever they publish)."""
+        pending = self.__dict__.get('_pending')
+        if pending and (requires is None or any(not p or (p & requires) for _, p in pending)):
+            del self.__dict__['_pending']
+            for fn, _ in pending:
+                fn()
 
     def _finalize(self) -> 'DGBatch':
         pending = self.__dict__.pop('_pending', None)
         self.__dict__['_deferred'] = False
         if pending:
-            for fn in pending:
+            for fn, _ in pending:
                 fn()
         return self
 

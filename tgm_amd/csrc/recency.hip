@@ -98,6 +98,7 @@ struct LookupArgs {
   int32_t* out_valid1;
   int32_t* out_valid_prev;   // optional: receives the span a row held BEFORE this call (byte accounting of a timed launch)
   int32_t* out_valid_prev1;
+  int ablate;  // TGMX_ABLATE (diagnosis only, results are WRONG): 1 no feature loads, 2 no feature stores, 4 no window reads, 8 no id / time stores
 };
 
 template <int VEC>
@@ -1326,6 +1327,7 @@ __device__ __forceinline__ GroupPick group_pick(const LookupArgs& a, int n, long
   // window of <= B records in time order: the ring row rotated by write_pos, or the last B visible index entries
   long long w0 = 0;
   int wrot = 0, wlen = 0;
+  if (a.ablate & 4) live = false;
   if constexpr (RING) {
     w0 = (long long)(live ? n : 0) * B;
     wrot = live ? a.write_pos[n] % B : 0;
@@ -1371,8 +1373,10 @@ __device__ __forceinline__ void group_emit(const LookupArgs& a, bool act, long l
                                            int32_t* out_nid, int64_t* out_ts, float* out_x, int32_t* out_valid, int32_t* out_valid_prev) {
   using V = typename VecOf<VEC>::type;
   if (act && gl < k) {
-    out_nid[s * k + gl] = o.nbr;
-    out_ts[s * k + gl] = o.ts;
+    if (!(a.ablate & 8)) {
+      out_nid[s * k + gl] = o.nbr;
+      out_ts[s * k + gl] = o.ts;
+    }
     lds_eid[gl] = o.src;
   }
   if (a.D == 0) return;
@@ -1407,8 +1411,15 @@ __device__ __forceinline__ void group_emit(const LookupArgs& a, bool act, long l
           const int slot = (int)a.dv.div((uint32_t)f);
           const int col = f - slot * a.row_vecs;
           const int e = lds_eid[slot];
-          if (e >= 0) v[u] = X[(long long)e * a.row_vecs + col];
+          if (e >= 0 && !(a.ablate & 1)) v[u] = X[(long long)e * a.row_vecs + col];
         }
+      }
+      if (a.ablate & 2) {  // keep the loads alive without the stores
+        float acc = 0.f;
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc += reinterpret_cast<const float*>(&v[u])[0];
+        if (acc == 123.456f) O[0] = v[0];
+        continue;
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -1510,6 +1521,10 @@ static int launch_lookup(LookupArgs a, hipStream_t stream, hipEvent_t ev_start, 
   a.side_stage = side_stage;
   a.tail_blocks = a.side_blocks ? tail_blocks : 0;
   const bool small = a.B <= kWave && a.k <= kWave;
+  {
+    static const int ablate = getenv("TGMX_ABLATE") ? atoi(getenv("TGMX_ABLATE")) : 0;
+    a.ablate = ablate;
+  }
   const int vec = prepare_lookup(a, a.out_x, a.k);
   if (vec < 0) return vec;
   const int waves_per_block = 4;
@@ -1529,6 +1544,10 @@ static int launch_lookup(LookupArgs a, hipStream_t stream, hipEvent_t ev_start, 
     const int per_wave = 64 / gl;
     long long pblocks = ((a.S + per_wave - 1) / per_wave + waves_per_block - 1) / waves_per_block;
     if (pblocks > (1 << 20)) pblocks = 1 << 20;
+    {
+      static const long long cap = getenv("TGMX_PACKED_BLOCKS") ? atoll(getenv("TGMX_PACKED_BLOCKS")) : 0;  // diagnosis: grid-stride over fewer workgroups
+      if (cap > 0 && pblocks > cap) pblocks = cap;
+    }
     const dim3 pgrid((unsigned)pblocks + a.side_blocks + a.tail_blocks);
     const size_t plds = (size_t)waves_per_block * per_wave * a.k * sizeof(int);
 #define TGMX_PACKED(VEC_)                                                                              \

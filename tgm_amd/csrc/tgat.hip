@@ -13,6 +13,7 @@
 // exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) in sgemm_nt below.
 #include "common.h"
 
+#include <atomic>
 #include <type_traits>
 
 namespace tgmx {
@@ -1872,14 +1873,19 @@ static int launch_chain64(const tgmx_tgat_layer_t& ly, const tgmx_tgat_layer_lay
                       64 * (size_t)ly.d + 64 * (size_t)d0) * sizeof(float);
   if (lds > 160 * 1024) return TGMX_E_UNSUPPORTED;
   if (dry) return TGMX_OK;
-  static bool attr_set = false;
-  if (!attr_set) {
+  // the opt-in to > 64 KB of dynamic LDS is a per-DEVICE function attribute: one flag per device id, set with a release store so that
+  // two threads racing on it at worst set the attribute twice (idempotent)
+  constexpr int kMaxDevices = 64;
+  static std::atomic<bool> attr_set[kMaxDevices];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = -1;
+  if (dev < 0 || !attr_set[dev].load(std::memory_order_acquire)) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tgat_chain64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
       set_error("tgat_forward: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
       return TGMX_E_LAUNCH;
     }
-    attr_set = true;
+    if (dev >= 0) attr_set[dev].store(true, std::memory_order_release);
   }
   hipLaunchKernelGGL(tgat_chain64_kernel, dim3((unsigned)((R + 63) / 64)), dim3(kC64Threads), lds, st, g);
   TGMX_CHECK_LAUNCH("tgat_chain64");

@@ -1,27 +1,34 @@
 """``DGDataLoader`` -- iterate a ``DGraph`` in event- or time-unit batches.
 
 Same constructor and behaviour as tgm/data/loader.py:64-170 (batch_size,
-batch_unit, on_empty, hook_manager, drop_last), but it is a plain Python
-iterator instead of a ``torch.utils.data.DataLoader`` subclass: a batch here is
-two integers plus zero-copy views, so the DataLoader machinery (sampler,
-fetcher, collate indirection) would be the dominant per-batch cost.  Like the
-reference it always runs in the caller's process (hook state must not fork).
+batch_unit, on_empty, hook_manager, ``**kwargs`` forwarded to
+``torch.utils.data.DataLoader``, of which it is a subclass like the reference:
+``isinstance``, ``len``, ``.dataset`` = the range of slice starts, ``collate_fn``
+= the loader itself).  Iteration does not go through the DataLoader machinery
+(sampler, fetcher, collate indirection): a batch here is two integers plus
+zero-copy views, and that machinery would be the dominant per-batch cost.
+Like the reference it always runs in the caller's process -- ``num_workers > 0``
+would fork the hooks' state and the device context, and is refused.
 
-``output_pool=R`` (ours, default 0 = off): run the lowerable prefix of the hook
-chain -- [shard] -> [negatives] -> recency sampler -- as one native call per
-batch writing into a ring of ``R`` preallocated output sets
-(``tgm_amd/pipeline.py``).  Same tensors as the hook-by-hook path; they are
-recycled after ``R`` further batches instead of being freshly allocated.
+``output_pool`` (ours): the lowerable prefix of the hook chain -- [shard] ->
+[negatives] -> recency sampler [-> dedup -> edge list] -- runs as ONE native
+call per batch writing into persistent output sets (``tgm_amd/pipeline.py``).
+``None`` (default): lowered whenever the chain allows it, with FRESH-TENSOR
+semantics -- a set is reused only once nothing can reach its tensors any more.
+``R > 0``: a ring of R sets recycled after R further batches (read-only
+tensors).  ``0``: never lower; hooks run one by one and allocate per batch.
 """
 from __future__ import annotations
 
 from typing import Any, Iterator, Literal, Optional
 
+import torch.utils.data
+
 from ..core import DGBatch, DGraph, TimeDeltaDG
 from ..exceptions import EmptyBatchError, EventOrderedConversionError, InvalidDiscretizationError
 
 
-class DGDataLoader:
+class DGDataLoader(torch.utils.data.DataLoader):
     def __init__(
         self,
         dg: DGraph,
@@ -29,7 +36,7 @@ class DGDataLoader:
         batch_unit: str = 'r',
         on_empty: Literal['skip', 'raise', None] = 'skip',
         hook_manager: Optional[Any] = None,
-        output_pool: int = 0,
+        output_pool: Optional[int] = None,
         prefetch: int = 0,
         **kwargs: Any,
     ) -> None:
@@ -55,14 +62,16 @@ class DGDataLoader:
         self._batch_size = batch_size
         self._hook_manager = hook_manager
         self._on_empty = on_empty
-        self._output_pool = int(output_pool)
+        self._output_pool = None if output_pool is None else int(output_pool)
+        if kwargs.get('num_workers', 0):
+            raise ValueError('DGDataLoader runs in the caller\'s process (hook state and device memory cannot be forked): num_workers must be 0')
         # prefetch=p (ours): iteration runs p batches ahead -- batch i is handed out after batch i + p has been ENQUEUED, so
         # hooks that must learn an output size from the device (DeduplicationHook, SampledEdgeListHook) find it waiting instead
         # of stalling the stream.  Hook state (sampler rings) does not depend on what the consumer does with a batch.
         self._prefetch = int(prefetch)
         if not 0 <= self._prefetch <= 2:
             raise ValueError(f'prefetch must be 0, 1 or 2 (hooks keep 4 size mirrors in flight), got {prefetch}')
-        if self._prefetch and 0 < self._output_pool <= self._prefetch:
+        if self._prefetch and self._output_pool is not None and 0 < self._output_pool <= self._prefetch:
             raise ValueError(f'prefetch={prefetch} keeps {prefetch + 1} batches alive: output_pool must be 0 (fresh tensors) or > prefetch')
         self._compiled = None  # (hook list identity, CompiledPipeline or None)
         self._event_fast = False
@@ -83,6 +92,8 @@ class DGDataLoader:
         if kwargs.get('drop_last', False):
             stop = stop - batch_size
         self._starts = range(start, stop, batch_size)
+        # the reference's base-class call (loader.py:147-149): torch validates the keyword arguments; unknown ones raise TypeError
+        super().__init__(self._starts, 1, shuffle=False, collate_fn=self, **kwargs)
 
     @property
     def dgraph(self) -> DGraph:
@@ -94,7 +105,7 @@ class DGDataLoader:
     def __call__(self, slice_start, _deferred: bool = False) -> DGBatch:
         """Materialize the batch beginning at ``slice_start`` and run the active hooks."""
         s = slice_start[0] if isinstance(slice_start, (list, tuple)) else slice_start
-        if self._output_pool > 0 and hasattr(self._hook_manager, 'active_hooks'):
+        if self._output_pool != 0 and hasattr(self._hook_manager, 'active_hooks'):
             batch = self._call_compiled(s, _deferred)
             if batch is not None:
                 return batch if _deferred else batch._finalize()
@@ -105,6 +116,8 @@ class DGDataLoader:
             batch.__dict__['_deferred'] = _deferred
             if hasattr(hm, 'active_hooks'):
                 for h in hm.active_hooks():
+                    if '_pending' in batch.__dict__:
+                        self._settle_for(batch, h)
                     batch = h(view, batch)
             else:  # a foreign manager (the reference's): its own entry point
                 batch = hm.execute_active_hooks(view, batch)
@@ -152,8 +165,19 @@ class DGDataLoader:
             if view is None:
                 view = self._slice_op(s, s + self._batch_size)
             for h in rest:
+                if '_pending' in batch.__dict__:
+                    self._settle_for(batch, h)
                 batch = h(view, batch)
         return batch
+
+    @staticmethod
+    def _settle_for(batch: DGBatch, h: Any) -> None:
+        """Batch attributes whose SIZE is learnt from the device are published by finalizers that a prefetching loader runs one
+        batch later; a hook that requires such an attribute gets them run before it is called."""
+        req = getattr(h, 'requires', None)
+        if req is not None:
+            req = set(req) - set(getattr(h, '_device_side_requires', ()))
+        batch._settle(req)
 
     @staticmethod
     def _is_batch_empty(batch: DGBatch) -> bool:

@@ -109,4 +109,4 @@ class DeduplicationHook(StatelessHook, SeedableHook):
             res = out[:cnt]
             self._publish(batch, res if dtype == torch.int32 else res.to(dtype))
 
-        batch._defer(finish)
+        batch._defer(finish, self.produces)

@@ -32,6 +32,8 @@ class SampledEdgeListHook(StatelessHook):
 
     _cls_requires = {'seed_nids', 'nbr_nids', 'nbr_edge_time', 'nbr_edge_x', 'unique_nids'}
     _cls_produces = {'sampled_edge_index', 'sampled_edge_time', 'sampled_edge_x'}
+    # consumed through the dedup hook's device-side handoff (batch._unique_dev): a pending finalizer for it need not run first
+    _device_side_requires = frozenset({'unique_nids'})
 
     def __init__(self, hop: int = 0, id: Optional[str] = None) -> None:
         super().__init__()
@@ -61,5 +63,5 @@ class SampledEdgeListHook(StatelessHook):
             self.add_batch_attribute(batch, 'sampled_edge_time', et[:E])
             self.add_batch_attribute(batch, 'sampled_edge_x', ex[:E])
 
-        batch._defer(finish)
+        batch._defer(finish, self.produces)
         return batch

@@ -197,9 +197,9 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
         times = getattr(store, '_time_np', None)
         if times is not None and len(times) and int(times[0]) >= 0:
             bound = int(times[-1])
-        self._step.ts_bound = bound
-        # batches materialized from this store are contiguous slices of a time-sorted stream
-        self._step.sorted_ts = 1 if times is not None else 0
+        # both promises hold for batches that ARE contiguous slices of this time-sorted store; _call_step makes them per call
+        self._store_promise = (bound, 1 if times is not None else 0)
+        self._step.ts_bound, self._step.sorted_ts = self._store_promise
 
     def fuses_first_hops(self) -> bool:
         """Did the last call run hop 0 and hop 1 as one launch?  (``tgmx_recency_step_plan`` on the argument block of
@@ -323,6 +323,13 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
             self._scratch = torch.zeros(need, dtype=torch.uint8, device=device)
             self._scratch_edges = n_edges
             self._step.scratch = self._scratch.data_ptr()
+
+    def _is_store_slice(self, batch: DGBatch, tt: Tensor, device: torch.device) -> bool:
+        lo, store = batch._edge_lo, self._bound_store
+        if lo is None or store is None or not hasattr(store, 'on'):
+            return False
+        base = store.on(device).ts
+        return tt.data_ptr() == base.data_ptr() + 8 * int(lo) and lo + tt.shape[0] <= base.shape[0]
 
     def _note_batch_time(self, dg: DGraph, batch: DGBatch) -> None:
         """The reference warns when a query is older than everything the buffers hold (recency.py:242-251:
@@ -455,12 +462,16 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
                 keep = (src, dst, tt, ex)
                 st.src, st.dst, st.ts, st.edge_x = src.data_ptr(), dst.data_ptr(), tt.data_ptr(), _native.ptr(ex)
                 st.eid0 = -1 if batch._edge_lo is None else int(batch._edge_lo)
+                # "time-sorted, 0 <= t <= ts_bound" is the STORE's promise: it covers this batch only if the batch is a zero-copy
+                # slice of the store (a user-built, filtered or permuted batch gets the span reduction and no sortedness claim)
+                st.ts_bound, st.sorted_ts = self._store_promise if self._is_store_slice(batch, tt, device) else (0, 0)
 
             # bad seeds must leave the state untouched (the reference validates before it changes anything): with
-            # guard_seed_errors the update of this very call skips its writes when the lookups flagged a seed, so one call and --
-            # in 'sync' mode -- ONE read-back per batch reproduce "raise, state unchanged"
+            # guard_seed_errors the update of this very call skips its writes when the lookups flagged a seed, so one call and
+            # ONE read-back per batch reproduce "raise, state unchanged".  'sync' only: the status word is sticky until check()
+            # zeroes it, so under 'deferred' a guard would silently drop every later batch's update after one bad seed
             st.n, st.n_hops = n_edges, L
-            st.guard_seed_errors = 1 if self._validate != 'off' else 0
+            st.guard_seed_errors = 1 if self._validate == 'sync' else 0
             rc = lib.tgmx_recency_step(st, stream)
             if rc:
                 _native.check(rc, 'tgmx_recency_step')

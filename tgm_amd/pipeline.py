@@ -15,15 +15,31 @@ RNG call counter, status word), so ``reset_state`` / ``check`` and switching
 between the lowered and the hook-by-hook path keep working, and both paths
 produce identical tensors (``tests/test_pipeline_gpu.py``).
 
-Contract of ``output_pool=R`` (the only difference to the reference's
-semantics): the tensors a batch carries are recycled -- they stay valid until
-``R`` more batches have been produced on the same stream; ``R=0`` (default)
-hands out fresh tensors per batch like the reference.
+Output sets.  Every tensor a batch carries is carved out of ONE persistent byte
+buffer per output set (one storage), sized for the largest batch seen.
+
+``output_pool=None`` (the loader's default): FRESH-TENSOR SEMANTICS from a pool.
+A set is handed out again only when nothing outside the pipeline can reach any
+of its tensors any more -- Python reference counts of the handed-out tensors,
+their ``TensorImpl`` use counts (views, tensors saved for backward) and the
+storage's use count (``detach()``, any other alias) are all back at their
+baseline -- otherwise another set is taken (at most ``_MAX_AUTO_SETS`` are kept;
+beyond that a batch gets a set nobody keeps: plain fresh tensors).  A loop that
+drops a batch before asking for the next one runs on one set, ``for batch in
+loader`` alternates between two.  In-place modification through torch ops is
+seen in the buffer's version counter and the set is re-initialised before its
+next use, so the delta feature writes (below) stay exact.
+
+``output_pool=R`` (explicit): a ring of ``R`` sets recycled unconditionally --
+the tensors stay valid until ``R`` more batches have been produced on the same
+stream and must be treated as read-only.  ``output_pool=0``: no lowering, the
+hooks run one by one and allocate fresh tensors per batch.
 """
 from __future__ import annotations
 
 import ctypes
 import os
+import sys
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -42,24 +58,52 @@ _ROLE_KEYS = {
 }
 
 
-class _Slot:
-    """One preallocated output set + its filled ``tgmx_pipeline_out_t`` + the attributes it puts on a batch."""
+_MAX_AUTO_SETS = 4  # output sets kept by the liveness-checked pool (output_pool=None); a batch beyond that gets an unpooled set
+_storage_uses = torch._C._storage_Use_Count
 
-    __slots__ = ('out', 'attrs', 'tensors', 'nbr_nids', 'post', 'post_bufs', 'valid')
+
+def _snapshot(tensors: list) -> list:
+    """(Python references, TensorImpl references) of every handed-out tensor of a set -- ONE code path for the baseline and for
+    the check at reuse, so the references the measurement itself holds cancel."""
+    return [(sys.getrefcount(t), t._use_count()) for t in tensors]
+
+
+class _Slot:
+    """The tensors one batch of `n` edges carries, as views into an output set's buffer, + the filled ``tgmx_pipeline_out_t``."""
+
+    __slots__ = ('out', 'attrs', 'nbr_nids', 'post', 'post_bufs', 'valid', 'watch', 'base')
+
+
+class _OutputSet:
+    """One persistent output set: a single byte buffer (one storage) that every tensor of a batch is a view of."""
+
+    __slots__ = ('buf', 'cap', 'off', 'views', 'storage', 'uses', 'version', 'pin', 'event', 'arange_n', 'lib')
+
+    def __del__(self) -> None:
+        ev, lib = getattr(self, 'event', None), getattr(self, 'lib', None)
+        if ev and lib is not None:
+            try:
+                lib.tgmx_event_destroy(ev)
+            except Exception:
+                pass
 
 
 class CompiledPipeline:
     def __init__(self, dg: DGraph, shard: Optional[EdgeShardHook], neg: Optional[RandomNegativeEdgeSamplerHook],
-                 nbr: RecencyNeighborHook, n_lowered: int, pool: int, dedup: Optional[DeduplicationHook] = None,
+                 nbr: RecencyNeighborHook, n_lowered: int, pool: Optional[int], dedup: Optional[DeduplicationHook] = None,
                  edges: Optional[SampledEdgeListHook] = None) -> None:  # fmt: skip
         self.n_lowered = n_lowered  # hooks of the chain this object replaces
         self._dedup, self._edges = dedup, edges
         self._dedup_ws = None
         self._dg, self._shard, self._neg, self._nbr = dg, shard, neg, nbr
-        self._R = max(1, int(pool))
-        # delta feature writes into the pooled outputs (include/tgm_amd.h: tgmx_recency_step_t.out_valid); TGMX_DELTA_WRITES=0: off
+        # pool=None: liveness-checked sets (fresh-tensor semantics); pool=R: a ring of R sets recycled unconditionally
+        self._safe = pool is None
+        self._R = 1 if pool is None else max(1, int(pool))
+        # delta feature writes into the persistent outputs (include/tgm_amd.h: tgmx_recency_step_t.out_valid); TGMX_DELTA_WRITES=0: off
         self._delta = os.environ.get('TGMX_DELTA_WRITES', '1') != '0'
-        self._pools: Dict[int, List[_Slot]] = {}
+        self._sets: List[_OutputSet] = []
+        self._cap = 0
+        self._last = 0
         self._turn = 0
         self._pipe: Optional[_native.Pipeline] = None
         self._step_ref = None  # the hook's argument block this pipeline was bound to
@@ -67,12 +111,14 @@ class CompiledPipeline:
         self._arr = dg._storage.on(dg.device)
         self._device = self._arr.src.device  # with its index ('cuda' -> 'cuda:0'): what the hooks see on batch tensors
         self._roles = [_ROLE_KEYS[shard is not None][k][0] for k in nbr._seed_nodes_keys]
+        self._static_ok: Optional[tuple] = None  # host-side seed validation of the resident store (validate='sync')
 
     # -- lowering ---------------------------------------------------------------
     @staticmethod
-    def lower(dg: DGraph, hooks: Sequence, pool: int) -> Optional['CompiledPipeline']:
-        """The pipeline for the longest lowerable prefix of ``hooks`` (None: nothing to lower)."""
-        if pool <= 0 or dg.device.type != 'cuda' or not hasattr(dg, '_storage'):
+    def lower(dg: DGraph, hooks: Sequence, pool: Optional[int]) -> Optional['CompiledPipeline']:
+        """The pipeline for the longest lowerable prefix of ``hooks`` (None: nothing to lower).  ``pool``: None = sets recycled
+        only when dead (fresh-tensor semantics), R > 0 = a ring of R sets, 0 = do not lower."""
+        if (pool is not None and pool <= 0) or dg.device.type != 'cuda' or not hasattr(dg, '_storage'):
             return None
         i = 0
         shard = neg = None
@@ -131,81 +177,181 @@ class CompiledPipeline:
         p.update = 1 if nbr._mode == 'ring' else 0
         ctypes.memmove(ctypes.byref(p.step), ctypes.byref(nbr._step), ctypes.sizeof(_native.RecencyStep))
         p.step.n_hops = len(nbr._num_nbrs)
-        p.step.guard_seed_errors = 1 if nbr._validate != 'off' else 0
+        p.step.guard_seed_errors = 1 if nbr._validate == 'sync' else 0
+        p.step.ts_bound, p.step.sorted_ts = nbr._store_promise  # the lowered chain's batches are slices of the resident store
         self._pipe, self._step_ref = p, nbr._step
         self._scratch_ptr = nbr._step.scratch
 
-    def _make_pool(self, n: int) -> List[_Slot]:
-        nbr, dev = self._nbr, self._device
+    # -- output sets -----------------------------------------------------------------
+    def _share(self, n: int) -> int:
         lo, hi = shard_bounds(n, *((self._shard.rank, self._shard.world_size) if self._shard is not None else (0, 1)))
-        share = hi - lo
+        return hi - lo
+
+    def _layout(self, cap: int) -> tuple:
+        """Byte offsets of every sub-buffer of an output set for batches of up to ``cap`` edges (256-byte aligned, like torch's own
+        allocations).  Row r of a [S, k, ...] output lives at the same offset whatever the batch size, so the delta-write state
+        (tgmx_recency_step_t.out_valid: one span per row) stays valid when the batch size changes."""
+        nbr = self._nbr
+        D = nbr._edge_x_dim
+        world = self._shard.world_size if self._shard is not None else 1
+        share = -(-cap // world)
+        S0 = share * len(self._roles)
+        off: Dict[str, int] = {}
+        pos = 0
+
+        def take(name: str, nbytes: int) -> None:
+            nonlocal pos
+            off[name] = pos
+            pos = (pos + nbytes + 255) & ~255
+
+        take('neg', 4 * share)
+        take('neg_time', 8 * share)
+        take('seeds', 4 * S0)
+        take('seed_t', 8 * S0)
+        take('arange', 8 * S0)
+        S = S0
+        total_ids = 0
+        for hop, k in enumerate(nbr._num_nbrs):
+            take(f'nid{hop}', 4 * S * k)
+            take(f'nts{hop}', 8 * S * k)
+            take(f'nx{hop}', 4 * S * k * D)
+            take(f'nv{hop}', 8 * S)  # [2, S] int32: the rows' spans, and the spans before the last call
+            total_ids += S * k
+            S *= k
+        if self._dedup is not None:
+            N = int(self._dg._storage.num_nodes_global)
+            extra = set(self._dedup.seed_keys or [])
+            total = 2 * cap + (share if 'neg' in extra else 0) + (total_ids if 'nbr_nids' in extra else 0)
+            take('uniq', 4 * max(min(total, N), 1))
+            take('dev_sizes', 24)
+            if self._edges is not None:
+                h = self._edges.hop
+                Sh = S0
+                for k in nbr._num_nbrs[:h]:
+                    Sh *= k
+                ecap = max(Sh * nbr._num_nbrs[h], 1)
+                take('ei', 16 * ecap)
+                take('et', 8 * ecap)
+                take('ex', 4 * ecap * D)
+                take('ro', 8 * (Sh + 1))
+        return off, pos, S0
+
+    def _new_set(self, cap: int) -> _OutputSet:
+        os_ = _OutputSet()
+        os_.lib = self._lib
+        os_.cap = cap
+        os_.off, total, S0 = self._layout(cap)
+        # zeros: the feature rows start as all-pad rows with span 0 (delta writes), dev_sizes as "no error"
+        os_.buf = torch.zeros(max(total, 256), dtype=torch.uint8, device=self._device)
+        os_.views = {}
+        os_.pin, os_.event = None, None
+        if self._dedup is not None:
+            os_.pin = torch.zeros(3, dtype=torch.int64).pin_memory()
+            ev = ctypes.c_void_p()
+            _native.check(self._lib.tgmx_event_create(ctypes.byref(ev)), 'tgmx_event_create')
+            os_.event = ev.value
+            if self._dedup_ws is None:
+                need = int(self._lib.tgmx_unique_ids_workspace_bytes(int(self._dg._storage.num_nodes_global)))
+                self._dedup_ws = torch.zeros(need, dtype=torch.uint8, device=self._device)  # zeros: the bitmap cleans itself
+        os_.arange_n = S0
+        os_.storage = os_.buf.untyped_storage()
+        self._init_set(os_)
+        os_.uses = _storage_uses(os_.storage._cdata)
+        return os_
+
+    def _init_set(self, os_: _OutputSet) -> None:
+        """Contents a set must hold before a batch is written into it: the seed-mask arange (never rewritten by a kernel)."""
+        a = os_.off['arange']
+        if os_.arange_n:
+            torch.arange(os_.arange_n, out=os_.buf[a:a + 8 * os_.arange_n].view(torch.int64))
+        os_.version = os_.buf._version
+
+    def _reinit_set(self, os_: _OutputSet) -> None:
+        """Somebody modified a handed-out tensor in place (the buffer's version counter moved): back to all-pad rows."""
+        os_.buf.zero_()
+        self._init_set(os_)
+
+    def _views(self, os_: _OutputSet, n: int) -> _Slot:
+        """The tensor set of an `n`-edge batch over output set `os_` (cached per n: views cost ~1 us each to build)."""
+        sl = os_.views.get(n)
+        if sl is not None:
+            return sl
+        if len(os_.views) >= 4:  # time-unit batching: nearly every batch has its own size -- keep the most recent few
+            os_.views.pop(next(iter(os_.views)))
+        nbr, buf, off = self._nbr, os_.buf, os_.off
+        share = self._share(n)
         D = nbr._edge_x_dim
         S0 = share * len(self._roles)
-        offsets = {k: g * share for g, k in enumerate(nbr._seed_nodes_keys)}
-        slots = []
-        for _ in range(self._R):
-            sl = _Slot()
-            out = _native.PipelineOut()
-            out.timed_hop = -1
-            attrs: dict = {}
-            tensors = []
-            if self._neg is not None:
-                neg_t = torch.empty(share, dtype=torch.int32, device=dev)
-                negt_t = torch.empty(share, dtype=torch.int64, device=dev)
-                out.neg, out.neg_time = neg_t.data_ptr(), negt_t.data_ptr()
-                attrs['neg'], attrs['neg_time'] = neg_t, negt_t
-            seeds = torch.empty(S0, dtype=torch.int32, device=dev)
-            seed_t = torch.empty(S0, dtype=torch.int64, device=dev)
-            out.seed_nid0, out.seed_ts0 = seeds.data_ptr(), seed_t.data_ptr()
-            seed_n, seed_ts, nbr_n, nbr_t, nbr_x = [], [], [], [], []
-            cur_n, cur_t, S = seeds, seed_t, S0
-            valid = []
-            for hop, k in enumerate(nbr._num_nbrs):
-                nid = torch.empty((S, k), dtype=torch.int32, device=dev)
-                nts = torch.empty((S, k), dtype=torch.int64, device=dev)
-                if self._delta:
-                    # persistent buffers: the lookups write a feature row only from the first slot that changes (its valid slots
-                    # are the right-aligned tail, the rest is zero and stays zero) -- tgmx_recency_step_t.out_valid.  The
-                    # buffers start as all-pad rows; consumers must treat them as read-only.
-                    nx = torch.zeros((S, k, D), dtype=torch.float32, device=dev)
-                    nv = torch.zeros((2, S), dtype=torch.int32, device=dev)  # [0]: the rows' spans, [1]: the spans before the last call
-                    out.out_valid[hop], out.out_valid_prev[hop] = nv[0].data_ptr(), nv[1].data_ptr()
-                    valid.append(nv)
-                else:
-                    nx = torch.empty((S, k, D), dtype=torch.float32, device=dev)
-                out.out_nid[hop], out.out_ts[hop], out.out_x[hop] = nid.data_ptr(), nts.data_ptr(), nx.data_ptr()
-                seed_n.append(cur_n)
-                seed_ts.append(cur_t)
-                nbr_n.append(nid)
-                nbr_t.append(nts)
-                nbr_x.append(nx)
-                cur_n, cur_t = nid.view(-1), nts.view(-1)
-                S *= k
-            whole = torch.arange(S0, device=dev)
-            attrs.update(seed_nids=seed_n, seed_times=seed_ts, nbr_nids=nbr_n, nbr_edge_time=nbr_t, nbr_edge_x=nbr_x,
-                         seed_node_nbr_mask={k: whole.narrow(0, o, share) for k, o in offsets.items()})  # fmt: skip
-            sl.out, sl.attrs, sl.nbr_nids, sl.valid = out, attrs, nbr_n, valid
-            sl.post = sl.post_bufs = None
-            if self._dedup is not None:
-                sl.post, sl.post_bufs = self._make_post(n, share, nbr_n, dev)
-            slots.append(sl)
-        self._pools[n] = slots
-        return slots
+        watch: list = []
 
-    def _make_post(self, n: int, share: int, nbr_n, dev):
-        """tgmx_pipeline_post_t of one slot: unique-id and edge-list buffers, the size mirror in pinned memory, its event."""
-        nbr = self._nbr
+        def view(name: str, dtype, *shape):
+            numel = 1
+            for d in shape:
+                numel *= d
+            nbytes = numel * torch.empty(0, dtype=dtype).element_size()
+            t = buf[off[name]:off[name] + nbytes].view(dtype).view(*shape)
+            watch.append(t)
+            return t
+
+        sl = _Slot()
+        out = _native.PipelineOut()
+        out.timed_hop = -1
+        attrs: dict = {}
+        if self._neg is not None:
+            neg_t, negt_t = view('neg', torch.int32, share), view('neg_time', torch.int64, share)
+            out.neg, out.neg_time = neg_t.data_ptr(), negt_t.data_ptr()
+            attrs['neg'], attrs['neg_time'] = neg_t, negt_t
+        seeds, seed_t = view('seeds', torch.int32, S0), view('seed_t', torch.int64, S0)
+        out.seed_nid0, out.seed_ts0 = seeds.data_ptr(), seed_t.data_ptr()
+        seed_n, seed_ts, nbr_n, nbr_t, nbr_x, valid = [], [], [], [], [], []
+        cur_n, cur_t, S = seeds, seed_t, S0
+        for hop, k in enumerate(nbr._num_nbrs):
+            nid, nts, nx = view(f'nid{hop}', torch.int32, S, k), view(f'nts{hop}', torch.int64, S, k), view(f'nx{hop}', torch.float32, S, k, D)
+            if self._delta:
+                # persistent buffers: the lookups write a feature row only from the first slot that changes (its valid slots are the
+                # right-aligned tail, the rest is zero and stays zero) -- tgmx_recency_step_t.out_valid
+                o = off[f'nv{hop}']
+                nv = (buf[o:o + 4 * S].view(torch.int32), buf[o + 4 * S:o + 8 * S].view(torch.int32))
+                out.out_valid[hop], out.out_valid_prev[hop] = nv[0].data_ptr(), nv[1].data_ptr()
+                valid.append(nv)
+            out.out_nid[hop], out.out_ts[hop], out.out_x[hop] = nid.data_ptr(), nts.data_ptr(), nx.data_ptr()
+            seed_n.append(cur_n)
+            seed_ts.append(cur_t)
+            nbr_n.append(nid)
+            nbr_t.append(nts)
+            nbr_x.append(nx)
+            if hop + 1 < len(nbr._num_nbrs):
+                cur_n, cur_t = nid.view(-1), nts.view(-1)
+                watch += [cur_n, cur_t]
+            S *= k
+        whole = view('arange', torch.int64, S0)
+        mask = {}
+        for g, key in enumerate(nbr._seed_nodes_keys):
+            mask[key] = whole.narrow(0, g * share, share)
+            watch.append(mask[key])
+        attrs.update(seed_nids=seed_n, seed_times=seed_ts, nbr_nids=nbr_n, nbr_edge_time=nbr_t, nbr_edge_x=nbr_x, seed_node_nbr_mask=mask)
+        sl.out, sl.attrs, sl.nbr_nids, sl.valid = out, attrs, nbr_n, valid
+        sl.post = sl.post_bufs = None
+        if self._dedup is not None:
+            sl.post, sl.post_bufs = self._make_post(os_, n, share, nbr_n)
+        sl.watch, sl.base = watch, None  # the baseline is taken by the caller, once this frame's locals are gone
+        os_.views[n] = sl
+        return sl
+
+    def _baseline(self, os_: _OutputSet, sl: _Slot) -> None:
+        """Reference counts of a tensor set that nothing outside the pipeline refers to (it was just built)."""
+        sl.base = _snapshot(sl.watch)
+        os_.uses = _storage_uses(os_.storage._cdata)  # the new views alias the buffer
+
+    def _make_post(self, os_: _OutputSet, n: int, share: int, nbr_n):
+        """tgmx_pipeline_post_t of one tensor set: unique-id and edge-list buffers, the size mirror in pinned memory, its event."""
+        nbr, buf, off = self._nbr, os_.buf, os_.off
         N = int(self._dg._storage.num_nodes_global)
         extra = set(self._dedup.seed_keys or [])
         total = 2 * n + (share if 'neg' in extra else 0) + (sum(t.numel() for t in nbr_n) if 'nbr_nids' in extra else 0)
-        if self._dedup_ws is None:
-            need = int(self._lib.tgmx_unique_ids_workspace_bytes(N))
-            self._dedup_ws = torch.zeros(need, dtype=torch.uint8, device=dev)  # zeros: the bitmap cleans itself
-        uniq = torch.empty(max(min(total, N), 1), dtype=torch.int32, device=dev)
-        dev_sizes = torch.zeros(3, dtype=torch.int64, device=dev)
-        pin = torch.zeros(3, dtype=torch.int64).pin_memory()
-        ev = ctypes.c_void_p()
-        _native.check(self._lib.tgmx_event_create(ctypes.byref(ev)), 'tgmx_event_create')
+        ucap = max(min(total, N), 1)
+        uniq = buf[off['uniq']:off['uniq'] + 4 * ucap].view(torch.int32)
+        dev_sizes = buf[off['dev_sizes']:off['dev_sizes'] + 24].view(torch.int64)
         post = _native.PipelinePost()
         post.dedup, post.dedup_neg, post.dedup_nbr, post.num_nodes = 1, int('neg' in extra), int('nbr_nids' in extra), N
         post.dedup_ws, post.uniq_out = self._dedup_ws.data_ptr(), uniq.data_ptr()
@@ -216,14 +362,55 @@ class CompiledPipeline:
             S, k = nbr_n[h].shape
             D = nbr._edge_x_dim
             cap = max(S * k, 1)
-            ei = torch.empty((2, cap), dtype=torch.int64, device=dev)
-            et = torch.empty(cap, dtype=torch.int64, device=dev)
-            ex = torch.empty((cap, D), dtype=torch.float32, device=dev)
-            ro = torch.empty(S + 1, dtype=torch.int64, device=dev)
+            ei = buf[off['ei']:off['ei'] + 16 * cap].view(torch.int64).view(2, cap)
+            et = buf[off['et']:off['et'] + 8 * cap].view(torch.int64)
+            ex = buf[off['ex']:off['ex'] + 4 * cap * D].view(torch.float32).view(cap, D)
+            ro = buf[off['ro']:off['ro'] + 8 * (S + 1)].view(torch.int64)
             post.edge_hop, post.edge_cap = h, cap
             post.row_off, post.edge_index, post.edge_t, post.edge_x = ro.data_ptr(), ei.data_ptr(), et.data_ptr(), ex.data_ptr()
-        post.dev_sizes, post.host_sizes, post.sizes_ready = dev_sizes.data_ptr(), pin.data_ptr(), ev.value
-        return post, (uniq, dev_sizes, pin, ev.value, ei, et, ex, ro, N)
+        post.dev_sizes, post.host_sizes, post.sizes_ready = dev_sizes.data_ptr(), os_.pin.data_ptr(), os_.event
+        return post, (uniq, dev_sizes, os_.pin, os_.event, ei, et, ex, ro, N)
+
+    def _is_free(self, os_: _OutputSet) -> bool:
+        """Can nothing outside the pipeline reach a tensor of this set any more?"""
+        if _storage_uses(os_.storage._cdata) != os_.uses:
+            return False  # a view, a detach() or any other alias of the buffer is alive
+        for sl in os_.views.values():
+            if sl.base is not None and _snapshot(sl.watch) != sl.base:
+                return False  # a Python reference to a handed-out tensor, or autograd saved it
+        return True
+
+    def _acquire(self, n: int) -> _OutputSet:
+        """The output set the next batch of `n` edges is written into."""
+        if n > self._cap:
+            # larger batches than any before: new sets (the old ones die with their last batch)
+            self._cap = n if not self._cap else max(n, self._cap + self._cap // 2)
+            self._sets = []
+        sets = self._sets
+        if not self._safe:
+            while len(sets) < self._R:
+                sets.append(self._new_set(self._cap))
+            turn = self._turn
+            self._turn = turn + 1
+            os_ = sets[turn % self._R]
+        else:
+            os_ = None
+            # the set used last comes first: a consumer that drops batch i before asking for batch i + 1 stays on ONE set, whose
+            # bytes are then still in the Infinity Cache
+            for i in range(len(sets)):
+                cand = sets[(self._last + i) % len(sets)]
+                if self._is_free(cand):
+                    os_, self._last = cand, (self._last + i) % len(sets)
+                    break
+            if os_ is None:
+                os_ = self._new_set(self._cap)
+                if len(sets) < _MAX_AUTO_SETS:
+                    sets.append(os_)
+                    self._last = len(sets) - 1
+                # else: nobody keeps it -- the batch owns plain fresh tensors
+        if os_.buf._version != os_.version:
+            self._reinit_set(os_)
+        return os_
 
     def _defer_post(self, batch: DGBatch, slot: _Slot) -> None:
         uniq, dev_sizes, pin, ev, ei, et, ex, _, N = slot.post_bufs
@@ -242,7 +429,7 @@ class CompiledPipeline:
                 edges.add_batch_attribute(batch, 'sampled_edge_time', et[:E])
                 edges.add_batch_attribute(batch, 'sampled_edge_x', ex[:E])
 
-        batch._defer(finish)
+        batch._defer(finish, dedup.produces | (edges.produces if edges is not None else set()))
 
     # -- per batch ----------------------------------------------------------------
     def step(self, lo: int, n: int, batch: DGBatch) -> bool:
@@ -258,14 +445,12 @@ class CompiledPipeline:
                 return False
         elif n == 0:
             return False
-        slots = self._pools.get(n)
-        if slots is None:
-            if len(self._pools) >= 8:  # time-unit batching: every batch may have its own size -- keep the 8 most recent shapes
-                self._pools.pop(next(iter(self._pools)))
-            slots = self._make_pool(n)
-        turn = self._turn
-        self._turn = turn + 1
-        slot = slots[turn % self._R]
+        if nbr._validate == 'sync':
+            self._validate_static(lo, n, (lo + s_lo, lo + s_hi) if shard is not None else (lo, lo + n))
+        os_ = self._acquire(n)
+        slot = self._views(os_, n)
+        if slot.base is None:
+            self._baseline(os_, slot)
         pipe = self._pipe
         ring_mode = nbr._mode == 'ring'
         if ring_mode:
@@ -297,8 +482,8 @@ class CompiledPipeline:
         if timer is not None:
             out.timed_hop = -1
             self._log_timed(timer, slot)
-        if nbr._validate == 'sync':
-            nbr.check()  # one device -> host read per batch: the reference's raise-per-call behaviour
+        if nbr._validate == 'sync' and not self._static_ok[0]:
+            nbr.check()  # seeds that the store does not vouch for: one device -> host read per batch
         d = batch.__dict__
         if shard is not None:
             arr = self._arr
@@ -306,10 +491,55 @@ class CompiledPipeline:
             d['shard_dst'] = arr.dst.narrow(0, lo + s_lo, s_hi - s_lo)
             d['shard_time'] = arr.ts.narrow(0, lo + s_lo, s_hi - s_lo)
             d['shard_lo'] = s_lo
-        d.update(slot.attrs)
+        if self._safe:
+            # the batch owns its containers (a consumer may append to / reorder them); the tensors inside are the set's views
+            for key, v in slot.attrs.items():
+                d[key] = list(v) if type(v) is list else (dict(v) if type(v) is dict else v)
+        else:
+            d.update(slot.attrs)
         if slot.post is not None:
             self._defer_post(batch, slot)
         return True
+
+    # -- validate='sync' without a device read per batch ------------------------------------------------
+    def _validate_static(self, lo: int, n: int, seed_range: tuple) -> None:
+        """The reference validates every call's seeds before it touches its state (recency.py:214-229).  The lowered chain's seeds are
+        rows of the RESIDENT store (+ negatives drawn in [low, high)), so their validity is a property of the store: it is established
+        once, on the device, and a batch is then checked on the host against the (normally empty) sorted lists of offending edges --
+        raise-per-call without a device -> host read per batch.  Seeds the store cannot vouch for (a negative range outside [0, N))
+        keep the per-call read of the device status word."""
+        ok = self._static_ok
+        if ok is None:
+            ok = self._static_ok = self._build_static()
+        if not ok[0]:
+            return
+        import numpy as np
+
+        _, bad_seed, bad_time, bad_edge = ok
+        N = self._nbr._num_nodes
+        for arr_, rng, msg in ((bad_seed, seed_range, f'Seed nodes must satisfy 0 <= x < {N}'), (bad_time, seed_range, 'Seed times must be >= 0'),
+                               (bad_edge, (lo, lo + n), f'Batch edge endpoints must satisfy 0 <= x < {N}')):
+            if len(arr_):
+                i = int(np.searchsorted(arr_, rng[0]))
+                if i < len(arr_) and arr_[i] < rng[1]:
+                    raise ValueError(msg)
+
+    def _build_static(self) -> tuple:
+        nbr, arr = self._nbr, self._arr
+        N = nbr._num_nodes
+        if self._neg is not None and not (0 <= self._neg.low and self._neg.high <= N):
+            return (False,)
+        with torch.cuda.device(self._device):
+            oob = lambda t: (t < 0) | (t >= N)
+            bad_src, bad_dst = oob(arr.src), oob(arr.dst)
+            seed = torch.zeros_like(bad_src)
+            if _native.SEED_SRC in self._roles:
+                seed |= bad_src
+            if _native.SEED_DST in self._roles:
+                seed |= bad_dst
+            idx = lambda m: m.nonzero().view(-1).cpu().numpy()
+            edge = (bad_src | bad_dst) if nbr._mode == 'ring' else torch.zeros_like(bad_src)
+            return (True, idx(seed), idx(arr.ts < 0), idx(edge))
 
     def _log_timed(self, timer, slot: _Slot) -> None:
         """What bench.py's byte model needs of a timed launch, as ONE small launch per hop behind it (tgmx_lookup_accounting: partial sums

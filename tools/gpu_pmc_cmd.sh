@@ -8,7 +8,7 @@ TAG=$1; CTRS=$2; KERN=$3; shift 3
 OUT=$ROOT/gpurun_out/pmc_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
-(cd /tmp && rocprofv3 --pmc $CTRS -d "$OUT" -- "$@") > "$OUT.log" 2>&1
+(cd /tmp && timeout -k 10 140 rocprofv3 --pmc $CTRS -d "$OUT" -- "$@") > "$OUT.log" 2>&1
 python - "$OUT" "$KERN" <<'PY'
 import glob, os, sqlite3, sys
 out, kern = sys.argv[1], sys.argv[2]
