@@ -156,48 +156,57 @@ def cpu_baseline(stream, bs, num_nbrs, n_batches, seed, first_batch):
     )
 
 
-def pmc_traffic(args, grid_slots):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-    of this very command, separate runs; tools/gpu_round.sh writes profiles/pmc_hop1.json).  FETCH_SIZE is doubled: the
-    gfx950 correction of MI355X_MICROARCH.md for wide coalesced reads.  None when no profile of this configuration exists."""
-    path = os.path.join(ROOT, 'profiles', 'pmc_hop1.json')
-    if not os.path.exists(path):
-        return None
-    with open(path) as f:
-        p = json.load(f)
-    same = (p.get('workload'), p.get('mode'), p.get('batch_size'), p.get('num_nbrs')) == (
-        args.workload, args.mode, args.batch_size or DEFAULTS[args.workload][0], args.num_nbrs or DEFAULTS[args.workload][1])
-    if not same or p.get('slots_per_launch') != grid_slots:
+def profile_key(args, bs, num_nbrs, steps):
+    """What a committed profile must have been taken with to describe THIS run's timed launches."""
+    return f'{args.workload}|{args.mode}|bs{bs}|k{"x".join(map(str, num_nbrs))}|steps{steps}|warmup{args.warmup}|pool{args.pool}|{args.validate}|start{args.start_frac}'
+
+
+def committed_profile(key):
+    """(pmc json, its path) of the committed round-3 profile taken with exactly these arguments (tools/gpu_profile_r3.sh), or (None, None)."""
+    import glob
+
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r03_*_pmc.json'))):
+        try:
+            with open(path) as f:
+                p = json.load(f)
+        except Exception:
+            continue
+        if p.get('profile_key') == key and p.get('fetch_kb') is not None and p.get('write_kb') is not None:
+            return p, path
+    return None, None
+
+
+def pmc_traffic(key):
+    """HBM-side bytes per TIMED launch of the dominant kernel from the committed PMC passes of this very command (rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE, separate runs, averaged over the timed launches only: tools/gpu_profile_r3.sh).  FETCH_SIZE is doubled:
+    the gfx950 correction of MI355X_MICROARCH.md for wide coalesced reads.  None when no profile of these arguments exists."""
+    p, path = committed_profile(key)
+    if p is None:
         return None
     return {'bytes': 2 * 1024 * p['fetch_kb'] + 1024 * p['write_kb'], 'fetch_kb_x2': 2 * p['fetch_kb'], 'write_kb': p['write_kb'],
-            'source': 'profiles/pmc_hop1.json (rocprofv3 --pmc, separate passes)'}
+            'dispatches_counted': p.get('dispatches_counted'),
+            'source': f'{os.path.relpath(path, ROOT)}: rocprofv3 --pmc in separate passes of `python bench.py {p.get("bench_args")}`, {p.get("which")} '
+                      '(a separate run of the same command, not this process)'}
 
 
-def rocprof_kernel_us(fused: bool):
-    """Average duration of the dominant kernel in the committed rocprofv3 --kernel-trace --stats summary of this very
-    command (profiles/rNN_sampler_rocprof_summary.md, latest round; tools/gpu_profile.sh writes it): the "timed region" line -- the
-    last 393 launches, i.e. the steady-state steps bench.py times -- when present, else the whole-run average.  Cross-check of the
-    figure measured live (the dispatch's own begin / end timestamps through hipExtLaunchKernelGGL)."""
-    path = next((p for p in (os.path.join(ROOT, 'profiles', f'r{r:02d}_sampler_rocprof_summary.md') for r in (2, 1)) if os.path.exists(p)), None)
-    if path is None:
+def rocprof_kernel_us(key):
+    """Average duration of the dominant kernel over the TIMED launches in the committed rocprofv3 --kernel-trace --stats summary taken
+    with exactly these arguments (profiles/r03_<tag>_rocprof_summary.md next to the matching r03_<tag>_pmc.json).  Cross-check of
+    the figure measured live (the dispatch's own begin / end timestamps through hipExtLaunchKernelGGL); a separate run."""
+    p, path = committed_profile(key)
+    if p is None:
         return None
-    want = 'recency_lookup_fused01_kernel' if fused else 'recency_lookup_kernel'
-    best = None
-    for line in open(path):
+    md = path.replace('_pmc.json', '_rocprof_summary.md')
+    if not os.path.exists(md):
+        return None
+    for line in open(md):
         cells = [c.strip() for c in line.split('|')]
-        if len(cells) > 3 and cells[1].startswith('timed region') and want in cells[1]:
+        if len(cells) > 3 and cells[1].startswith('timed region'):
             try:
-                return float(cells[2].split()[1])  # "avg 38.12 us": the same steady-state launches bench.py times
+                return {'avg_us': float(cells[2].split()[1]), 'source': f'{os.path.relpath(md, ROOT)} (rocprofv3 --kernel-trace of the same command, a separate run: {cells[1]})'}
             except (ValueError, IndexError):
-                pass
-        if len(cells) > 6 and want in cells[1]:
-            try:
-                calls, avg = int(cells[3]), float(cells[5])
-            except ValueError:
-                continue
-            if best is None or calls > best[0]:
-                best = (calls, avg)
-    return None if best is None else best[1]
+                return None
+    return None
 
 
 def main():
@@ -316,6 +325,25 @@ def main():
             default_sets = len(loader2._compiled[1]._sets) if loader2._compiled and loader2._compiled[1] is not None else 0
             del held
 
+    # ---- N > 1: proof that N ranks met over RCCL (the data path itself has no collective): ranks counted by an all-reduce,
+    # and what a small all-reduce costs on this node's xGMI links ----
+    rccl = None
+    if real_world > 1:
+        import torch.distributed as dist
+
+        ones = torch.ones(1, dtype=torch.float32, device=device)
+        dist.all_reduce(ones)
+        buf = torch.zeros(1024, dtype=torch.float32, device=device)
+        for _ in range(5):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        rccl = {'backend': dist.get_backend(), 'ranks_seen': int(ones.item()), 'allreduce_us': 1e6 * (time.perf_counter() - t0) / 20,
+                'what': '4 KiB float32 all-reduce, 20 back to back (latency of one collective on this node); not on the sampler\'s data path'}
+
     if real_world > 1:
         t = torch.tensor([elapsed, default_elapsed or 0.0], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -361,6 +389,7 @@ def main():
         ' + '.join(f'{seeds} seeds x k={k}' for seeds, k in shape) + ')'
 
     lowered = args.pool > 0
+    pkey = profile_key(args, bs, num_nbrs, steps)
     out = {
         'metric': 'sampled-edges/sec (TGAT 2-hop k=20 recency sampler, tgbl-wiki synthetic)' if args.workload == 'wiki'
         else f'sampled-edges/sec (recency sampler, tgbl-{args.workload} synthetic)',
@@ -387,6 +416,7 @@ def main():
             + f"seed validation on the device, validate='{args.validate}'"
             + (' (status word read back once after the timed steps)' if args.validate == 'deferred' else ''),
             'slots_per_step_per_rank': slots_of(bs_rank),
+            'profile_key': pkey,
             'events_per_s': total_events / elapsed,
             'parallelism': f'edge-batch sharding x{world} ({args.scaling} scaling), replicated stream, no data-path collective'
             + (f' -- EMULATED: this is rank {rank} of {world} alone on one GPU (value = that rank\'s units only)' if args.emulate_world else ''),
@@ -398,9 +428,9 @@ def main():
             'peak': HBM_PEAK_GBS,
             'unit': 'GB/s',
             'frac': achieved / HBM_PEAK_GBS,
-            'traffic': pmc_traffic(args, int(total_slots)),
+            'traffic': pmc_traffic(pkey),
             'avg_kernel_ms': avg_ms,
-            'rocprof_avg_kernel_us': rocprof_kernel_us(fused) if (args.workload == 'wiki' and args.mode == 'ring' and world == 1) else None,
+            'rocprof_avg_kernel_us': rocprof_kernel_us(pkey) if world == 1 else None,
             'launches_timed': len(ker_ms),
             'algorithmic_bytes_per_launch': algo_bytes,
             'valid_slot_fraction': valid / max(total_slots, 1),
@@ -410,6 +440,8 @@ def main():
             if delta else 'valid-aware: slots x (12 + 4D) written + valid slots x (16 + 4D) read + 68 B per seed',
         },
     }
+    if rccl is not None:
+        out['rccl'] = rccl
     out['valid_edges_per_s'] = out['value'] * out['roofline']['valid_slot_fraction']  # sampled slots that hold a neighbor (pads excluded)
     if default_elapsed is not None:
         out['default_path'] = {

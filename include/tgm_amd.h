@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TGMX_ABI_VERSION 3
+#define TGMX_ABI_VERSION 4
 
 #define TGMX_OK 0
 #define TGMX_E_INVALID (-1)  /* bad argument (null pointer, size, alignment) */
@@ -214,6 +214,10 @@ typedef struct tgmx_recency_step {
   int32_t* out_valid[TGMX_MAX_HOPS];
   /* optional with out_valid: receives the span each row held BEFORE the call (the byte accounting of a timed launch needs both) */
   int32_t* out_valid_prev[TGMX_MAX_HOPS];
+  /* ABI v4.  Generated negatives of a SHARD: draw i of this call is draw neg_index0 + i of the batch, so that the shares of a
+   * batch drawn by different ranks are slices of the ids a single rank would draw for the whole batch (rank order concatenation
+   * of the ranks' outputs then equals the single-rank tensors).  0 for an unsharded batch. */
+  int64_t neg_index0;
 } tgmx_recency_step_t;
 
 int tgmx_recency_step(const tgmx_recency_step_t* step, tgmx_stream_t stream);
@@ -660,6 +664,10 @@ int tgmx_tgcn_output(const float* u_pre, const float* c_pre, const float* H, int
  * copy of time_in (the reference: torch.randint + edge_time.clone()), one launch.  Counter-based generator keyed by
  * (seed, call, i): same distribution as the reference, a different stream than torch's. */
 int tgmx_random_negatives(int32_t low, int32_t high, int64_t n, uint64_t seed, uint64_t call, int32_t* out_neg,
+                          const int64_t* time_in, int64_t n_time, int64_t* out_time, tgmx_stream_t stream);
+/* ABI v4: the same draws starting at index `index0` of the call's sequence (a rank's share of a sharded batch: index0 = the
+ * share's offset in the batch); tgmx_random_negatives is index0 = 0. */
+int tgmx_random_negatives_at(int32_t low, int32_t high, int64_t n, uint64_t seed, uint64_t call, int64_t index0, int32_t* out_neg,
                           const int64_t* time_in, int64_t n_time, int64_t* out_time, tgmx_stream_t stream);
 
 /* DeduplicationHook (tgm/hooks/dedup.py:35-67): the sorted unique ids of up to 16 int32 id arrays (edge endpoints, extra

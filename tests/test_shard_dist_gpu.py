@@ -1,0 +1,94 @@
+"""Strong-scaling edge-batch sharding, two ranks (sharing the one test GPU; gloo for the rendezvous -- there is NO collective on
+the sampler's data path): rank r samples the edges [n r / 2, n (r + 1) / 2) of every global batch.
+Put back in the single-rank row order, the ranks' tensors must equal the single-rank tensors bit for bit -- ids, times,
+feature rows AND the generated negatives (a rank's draws are a slice of the whole batch's: tgmx_recency_step_t.neg_index0) --
+in the stateless mode (static index: DESIGN.md's multi-GPU mode) and with streaming rings (every rank replays the whole
+batch's update), through the lowered chain and hook by hook.  On a multi-GPU node the same code runs one rank per GPU."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+BS, KS, E, D = 200, [6, 4], 2300, 8  # 2300 % 200 = 100: a ragged last batch; odd shares exist (bs 200 / 2 ranks is even, the last is 50)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(rank, world, port, out, mode, pool):
+    import torch.distributed as dist
+
+    from tgm_amd import DGData, DGDataLoader, DGraph
+    from tgm_amd.dist import EdgeShardHook
+    from tgm_amd.hooks import HookManager, RandomNegativeEdgeSamplerHook, RecencyNeighborHook
+    from tgm_amd.synth import make_stream
+
+    if world > 1:
+        os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    st = make_stream('comment', seed=9, num_edges=E, edge_dim=D, n_src=300)
+    dg = DGraph(DGData.from_raw(st.ts, torch.stack([st.src, st.dst], 1), st.edge_x), device='cuda')
+    hm = HookManager(keys=['k'])
+    if world > 1:
+        hm.register('k', EdgeShardHook(rank, world))
+        hm.register('k', RandomNegativeEdgeSamplerHook(0, st.num_nodes, seed=17, like='shard_dst', time_key='shard_time'))
+        keys, tkeys = ['shard_src', 'shard_dst', 'neg'], ['shard_time', 'shard_time', 'neg_time']
+    else:
+        hm.register('k', RandomNegativeEdgeSamplerHook(0, st.num_nodes, seed=17))
+        keys, tkeys = ['edge_src', 'edge_dst', 'neg'], ['edge_time', 'edge_time', 'neg_time']
+    hm.register('k', RecencyNeighborHook(st.num_nodes, KS, keys, tkeys, mode=mode, validate='deferred', key_arith='int64',
+                                         batch_size=BS if mode == 'csr' else None))  # fmt: skip
+    loader = DGDataLoader(dg, batch_size=BS, hook_manager=hm, output_pool=pool)
+    got = []
+    with hm.activate('k'):
+        for b in loader:
+            got.append({'neg': b.neg.cpu(), 'seed_nids': [t.cpu() for t in b.seed_nids], 'nbr_nids': [t.cpu() for t in b.nbr_nids],
+                        'nbr_edge_time': [t.cpu() for t in b.nbr_edge_time], 'nbr_edge_x': [t.cpu() for t in b.nbr_edge_x]})
+    torch.save(got, f'{out}.{mode}.{pool}.{world}.{rank}')
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _rows(share_sizes, roles, k_prod):
+    """Single-rank row order of hop h (k_prod = rows per hop-0 seed) from the ranks' [role-major per rank] rows: for every role,
+    rank 0's share then rank 1's."""
+    order = []
+    for role in range(roles):
+        for r, n in enumerate(share_sizes):
+            order.append((r, role * n * k_prod, n * k_prod))
+    return order
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize('mode,pool', [('csr', None), ('ring', None), ('ring', 0)])
+def test_two_rank_strong_scaling_concat_equals_single_rank(tmp_path, mode, pool):
+    out = str(tmp_path / 'o')
+    _run(0, 1, 0, out, mode, pool)
+    mp.spawn(_run, args=(2, _free_port(), out, mode, pool), nprocs=2, join=True)
+    one = torch.load(f'{out}.{mode}.{pool}.1.0')
+    two = [torch.load(f'{out}.{mode}.{pool}.2.{r}') for r in (0, 1)]
+    assert len(one) == len(two[0]) == len(two[1]) == -(-E // BS)
+    n_valid = 0
+    for b, ref in enumerate(one):
+        parts = [two[0][b], two[1][b]]
+        shares = [p['neg'].shape[0] for p in parts]
+        assert sum(shares) == ref['neg'].shape[0]
+        assert torch.equal(torch.cat([p['neg'] for p in parts]), ref['neg']), f'batch {b}: the shares\' negatives are not slices of the batch\'s'
+        k_prod = 1
+        for h in range(len(KS)):
+            for name in ('seed_nids', 'nbr_nids', 'nbr_edge_time', 'nbr_edge_x'):
+                rebuilt = torch.cat([parts[r][name][h][lo:lo + n] for r, lo, n in _rows(shares, 3, k_prod)])
+                assert torch.equal(rebuilt, ref[name][h]), f'{mode} pool={pool} batch {b} hop {h} {name}'
+            n_valid += int((ref['nbr_nids'][h] >= 0).sum())
+            k_prod *= KS[h]
+    assert n_valid > 1000

@@ -152,6 +152,7 @@ class RecencyStep(ctypes.Structure):
         ('neg_seed', ctypes.c_uint64), ('neg_call', ctypes.c_uint64), ('neg_out', c_void_p), ('neg_time_out', c_void_p),
         ('guard_seed_errors', c_int32), ('sorted_ts', c_int32),
         ('out_valid', c_void_p * MAX_HOPS), ('out_valid_prev', c_void_p * MAX_HOPS),
+        ('neg_index0', c_int64),
     ]  # fmt: skip
 
 
@@ -227,6 +228,7 @@ SIGNATURES['tgmx_tconv_edge_attr_backward'] = (c_int32, [_P, _P, _P, _P, _P, _P,
 SIGNATURES['tgmx_tconv_attend_backward'] = (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, ctypes.c_float, _P, _P, _P, _P, _P, _P, _P])
 SIGNATURES['tgmx_group_ids'] = (c_int32, [_P, c_int32, _P, _P, _P, _P, _P, _P])
 SIGNATURES['tgmx_random_negatives'] = (c_int32, [c_int32, c_int32, c_int64, ctypes.c_uint64, ctypes.c_uint64, _P, _P, c_int64, _P, _P])
+SIGNATURES['tgmx_random_negatives_at'] = (c_int32, [c_int32, c_int32, c_int64, ctypes.c_uint64, ctypes.c_uint64, c_int64, _P, _P, c_int64, _P, _P])
 SIGNATURES['tgmx_unique_ids_workspace_bytes'] = (c_size_t, [c_int32])
 SIGNATURES['tgmx_unique_ids'] = (c_int32, [_P, _P, c_int32, c_int32, _P, _P, _P, _P, _P])
 SIGNATURES['tgmx_csr_build_workspace_bytes'] = (c_size_t, [c_int64, c_int32, c_int32])

@@ -32,13 +32,16 @@ void set_error(const char* fmt, ...);
 
 // q = n / d for n < 2^32 / d via one v_mul_hi_u32 (m = floor(2^32 / d) + 1).
 struct FastDiv {
-  uint32_t d, m;
+  uint32_t d, m, pass;  // pass: all ones when d <= 1 (m is 0 then)
   __device__ __forceinline__ uint32_t div(uint32_t n) const { return d <= 1 ? n : __umulhi(n, m); }
+  // the same without a branch (a uniform branch still ends the basic block: loads on either side of it are not batched)
+  __device__ __forceinline__ uint32_t div_nb(uint32_t n) const { return __umulhi(n, m) + (n & pass); }
 };
 inline FastDiv make_fastdiv(uint32_t div) {
   FastDiv f;
   f.d = div;
   f.m = div <= 1 ? 0u : (uint32_t)((1ull << 32) / div) + 1u;
+  f.pass = div <= 1 ? 0xFFFFFFFFu : 0u;
   return f;
 }
 

@@ -83,11 +83,11 @@ __global__ __launch_bounds__(1024) void dedup_scan_compact_kernel(unsigned int* 
 // RandomNegativeEdgeSamplerHook (tgm/hooks/negatives/sampler.py:45-65): neg[i] uniform in [low, high), neg_time = copy of
 // the batch's edge times -- the reference's randint + clone as one launch, counter-based generator (seed, call, i)
 __global__ __launch_bounds__(256) void random_negatives_kernel(int32_t* __restrict__ neg, long long n, int low, unsigned range,
-                                                               unsigned long long seed, unsigned long long call,
+                                                               unsigned long long seed, unsigned long long call, unsigned long long i0,
                                                                const int64_t* __restrict__ t_in, int64_t* __restrict__ t_out,
                                                                long long nt) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) neg[i] = negative_draw(seed, call, (unsigned long long)i, low, range);
+  if (i < n) neg[i] = negative_draw(seed, call, i0 + (unsigned long long)i, low, range);
   if (i < nt) t_out[i] = t_in[i];
 }
 
@@ -128,15 +128,20 @@ extern "C" int tgmx_unique_ids(const int32_t* const* parts, const int64_t* part_
   return TGMX_OK;
 }
 
-extern "C" int tgmx_random_negatives(int32_t low, int32_t high, int64_t n, uint64_t seed, uint64_t call, int32_t* out_neg,
-                                     const int64_t* time_in, int64_t n_time, int64_t* out_time, tgmx_stream_t stream) {
-  TGMX_REQUIRE(low < high && n >= 0 && n_time >= 0, "random_negatives: bad arguments low=%d high=%d n=%lld", low, high, (long long)n);
+extern "C" int tgmx_random_negatives_at(int32_t low, int32_t high, int64_t n, uint64_t seed, uint64_t call, int64_t index0, int32_t* out_neg,
+                                        const int64_t* time_in, int64_t n_time, int64_t* out_time, tgmx_stream_t stream) {
+  TGMX_REQUIRE(low < high && n >= 0 && n_time >= 0 && index0 >= 0, "random_negatives: bad arguments low=%d high=%d n=%lld", low, high, (long long)n);
   const long long work = n > n_time ? n : n_time;
   if (work == 0) return TGMX_OK;
   TGMX_REQUIRE((n == 0 || out_neg) && (n_time == 0 || (time_in && out_time)), "random_negatives: null pointer");
   hipLaunchKernelGGL(random_negatives_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out_neg, (long long)n,
-                     low, (unsigned)((long long)high - low), (unsigned long long)seed, (unsigned long long)call, time_in, out_time,
-                     (long long)n_time);
+                     low, (unsigned)((long long)high - low), (unsigned long long)seed, (unsigned long long)call, (unsigned long long)index0, time_in,
+                     out_time, (long long)n_time);
   TGMX_CHECK_LAUNCH("random_negatives");
   return TGMX_OK;
+}
+
+extern "C" int tgmx_random_negatives(int32_t low, int32_t high, int64_t n, uint64_t seed, uint64_t call, int32_t* out_neg,
+                                     const int64_t* time_in, int64_t n_time, int64_t* out_time, tgmx_stream_t stream) {
+  return tgmx_random_negatives_at(low, high, n, seed, call, 0, out_neg, time_in, n_time, out_time, stream);
 }

@@ -72,6 +72,7 @@ extern "C" int tgmx_pipeline_step(const tgmx_pipeline_t* p, int64_t edge_lo, int
         TGMX_REQUIRE(share == 0 || (out->neg && out->neg_time), "pipeline_step: null negatives output");
         s.grp_nid[g] = nullptr;
         s.neg_group = g; s.neg_low = p->neg_low; s.neg_high = p->neg_high; s.neg_seed = p->neg_seed; s.neg_call = neg_call;
+        s.neg_index0 = lo;  // the share's draws are a slice of the whole batch's (tgmx_recency_step_t.neg_index0)
         s.neg_out = out->neg; s.neg_time_out = out->neg_time;
         break;
       default: TGMX_REQUIRE(false, "pipeline_step: seed role %d", p->seed_role[g]);

@@ -21,6 +21,7 @@
 //   lookup pieces (fetch_seed ... lookup_seed) and the kernels built from them: recency_lookup_kernel (one hop),
 //     recency_lookup_fused01_kernel (hop 0 + hop 1 in one launch), lookup_packed_kernel (narrow rows)
 //   the stand-alone update paths (one workgroup / chunk sort + merge / rocPRIM radix sort), uniform sampler, C entry points
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 
@@ -56,7 +57,7 @@ struct SeedGroups {
   int gen;
   int gen_low;
   unsigned gen_range;
-  unsigned long long gen_seed, gen_call;
+  unsigned long long gen_seed, gen_call, gen_index0;
   int32_t* gen_out;
   int64_t* gen_out_ts;
 };
@@ -78,6 +79,8 @@ struct LookupArgs {
   int D, k, B, N, allow_pad;
   int row_vecs;  // D / VEC
   FastDiv dv;    // division by row_vecs
+  FastDiv dv_seed;  // division by k * row_vecs (tile kernel: flat piece index -> seed of the tile)
+  int leave_room;   // tile kernel: other launches must fit beside this one (the large ring update's chain on the side stream)
   // ring update work riding along (tgmx_recency_step): the first side_blocks workgroups run side_stage on the
   // launch's second argument instead of looking anything up
   unsigned side_blocks;
@@ -98,7 +101,6 @@ struct LookupArgs {
   int32_t* out_valid1;
   int32_t* out_valid_prev;   // optional: receives the span a row held BEFORE this call (byte accounting of a timed launch)
   int32_t* out_valid_prev1;
-  int ablate;  // TGMX_ABLATE (diagnosis only, results are WRONG): 1 no feature loads, 2 no feature stores, 4 no window reads, 8 no id / time stores
 };
 
 template <int VEC>
@@ -1024,7 +1026,7 @@ __device__ __forceinline__ void fetch_seed(const LookupArgs& a, long long s, int
       }
     }
     const bool gen = sel == a.grp.gen;  // wave-uniform
-    n = gen ? negative_draw(a.grp.gen_seed, a.grp.gen_call, (unsigned long long)(s - base), a.grp.gen_low, a.grp.gen_range) : pn[s - base];
+    n = gen ? negative_draw(a.grp.gen_seed, a.grp.gen_call, a.grp.gen_index0 + (unsigned long long)(s - base), a.grp.gen_low, a.grp.gen_range) : pn[s - base];
     q = pt[s - base];
     if (publish && lane == 0) {
       a.grp.out_nid[s] = n;
@@ -1327,7 +1329,6 @@ __device__ __forceinline__ GroupPick group_pick(const LookupArgs& a, int n, long
   // window of <= B records in time order: the ring row rotated by write_pos, or the last B visible index entries
   long long w0 = 0;
   int wrot = 0, wlen = 0;
-  if (a.ablate & 4) live = false;
   if constexpr (RING) {
     w0 = (long long)(live ? n : 0) * B;
     wrot = live ? a.write_pos[n] % B : 0;
@@ -1373,10 +1374,8 @@ __device__ __forceinline__ void group_emit(const LookupArgs& a, bool act, long l
                                            int32_t* out_nid, int64_t* out_ts, float* out_x, int32_t* out_valid, int32_t* out_valid_prev) {
   using V = typename VecOf<VEC>::type;
   if (act && gl < k) {
-    if (!(a.ablate & 8)) {
-      out_nid[s * k + gl] = o.nbr;
-      out_ts[s * k + gl] = o.ts;
-    }
+    out_nid[s * k + gl] = o.nbr;
+    out_ts[s * k + gl] = o.ts;
     lds_eid[gl] = o.src;
   }
   if (a.D == 0) return;
@@ -1411,15 +1410,8 @@ __device__ __forceinline__ void group_emit(const LookupArgs& a, bool act, long l
           const int slot = (int)a.dv.div((uint32_t)f);
           const int col = f - slot * a.row_vecs;
           const int e = lds_eid[slot];
-          if (e >= 0 && !(a.ablate & 1)) v[u] = X[(long long)e * a.row_vecs + col];
+          if (e >= 0) v[u] = X[(long long)e * a.row_vecs + col];
         }
-      }
-      if (a.ablate & 2) {  // keep the loads alive without the stores
-        float acc = 0.f;
-#pragma unroll
-        for (int u = 0; u < U; ++u) acc += reinterpret_cast<const float*>(&v[u])[0];
-        if (acc == 123.456f) O[0] = v[0];
-        continue;
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -1481,6 +1473,296 @@ __global__ __launch_bounds__(256) void lookup_packed_kernel(const LookupArgs a, 
   }
 }
 
+
+// ---- narrow rows, a TILE of 64 seeds per wave: one LANE per seed for the index work, the whole wave for the copies -------------
+// The packed kernel above keeps 2-4 seeds in flight per wave behind a chain of dependent reads (seed -> write_pos / window ->
+// feature rows -> stores); counters say its waves spend 82 % of their life waiting at memory latencies that are close to
+// unloaded (TCP -> TCC 780 cycles, TCC -> fabric 1150), i.e. the launch is bound by how few requests a CU has in flight, not by
+// bandwidth (ablation: with every memory access but the seed reads removed it still takes 40 of its 139 us).  Here a wave
+// takes 64 consecutive seeds:
+//   index phase  lane = seed: its window of <= BCAP 16-byte records arrives as BCAP independent loads per lane (64 x BCAP
+//                in flight per wave); the pick is straight-line code over registers; ids / times / feature-row sources of the
+//                tile are staged in LDS in the outputs' own row-major layout
+//   flush        the tile's [64, k] ids and times leave as flat, fully coalesced 16-byte stores
+//   copy phase   the tile's [64, k, D] block is ONE contiguous stretch of the output: the wave streams it as flat 16-byte pieces,
+//                8 independent loads in flight per lane, sources looked up in LDS; pieces left of a row's first changing slot
+//                (delta writes) are skipped
+// CSR: the batch-boundary prefix searches are per-lane 4-ary searches (64 independent searches per wave).
+// Stores with a per-lane predicate and NO branch: a buffer store whose offset lies outside the descriptor's range is dropped by
+// the hardware.  (A branch around every store makes hipcc's wait-count insertion give up counting -- it then drains the whole
+// queue, `s_waitcnt vmcnt(0)`, before EVERY store, i.e. each store waits for the one before it to reach L2: the first version of
+// this copy loop ran 8 stores per batch as 8 serial round trips.)
+typedef unsigned int tgmx_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned int tgmx_u2 __attribute__((ext_vector_type(2)));
+// (off: per-lane byte offset, range-checked; soff: wave-uniform byte offset added after the check)
+__device__ __forceinline__ void buffer_store_vec(float4 v, __amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<tgmx_u4*>(&v), r, off, soff, 0);
+}
+__device__ __forceinline__ void buffer_store_vec(float2 v, __amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<tgmx_u2*>(&v), r, off, soff, 0);
+}
+__device__ __forceinline__ void buffer_store_vec(float v, __amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, off, soff, 0);
+}
+template <typename T>
+__device__ __forceinline__ T* wave_uniform_ptr(T* p) {  // tell the compiler what we know: the value is the same in every lane
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
+}
+
+template <int VEC>
+__device__ __forceinline__ void tile_copy(const LookupArgs& a, long long t, int rows, int k, int lane, const int* Lsrc, const int* Lfirst) {
+  using V = typename VecOf<VEC>::type;
+  const V* __restrict__ X = reinterpret_cast<const V*>(a.edge_x);
+  const int rv = a.row_vecs, per_seed = k * rv, total = rows * per_seed;
+  // the tile's [rows, k, D] block of the output behind one wave-uniform descriptor
+  float* base = wave_uniform_ptr(a.out_x + t * 64 * (long long)k * a.D);
+  const __amdgpu_buffer_rsrc_t O = __builtin_amdgcn_make_buffer_rsrc(base, 0, total * (int)sizeof(V), 0x00020000);
+  constexpr int U = 16;  // pieces per lane and trip: 16 independent 16-byte loads in flight per lane
+  constexpr unsigned kDrop = 0xFFFFFFF0u;  // outside every tile: the store is dropped
+  // One trip: every LDS lookup, then U unconditional loads (a piece without a source reads row 0 and is replaced by zeros), then U
+  // stores -- straight-line code.  (hipcc drains the queue at the top of the next trip before it overwrites a register that a store
+  // in flight was issued from; two register sets per trip were tried: same wait, more registers.)
+  // vmcnt(0), once, in front of the loop: with memory operations of the phases before still in hipcc's books at loop entry, its
+  // wait-count insertion puts a full drain at the TOP of every trip instead (every trip then pays a store round trip)
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  for (int fb = 0; fb < total; fb += kWave * U) {  // wave-uniform trip count
+    long long idx[U];
+    bool has[U], wr[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int f = fb + u * kWave + lane;
+      const bool in = f < total;
+      const int fc = in ? f : 0;
+      const int sl = (int)a.dv_seed.div_nb((uint32_t)fc);
+      const int r = fc - sl * per_seed;
+      const int slot = (int)a.dv.div_nb((uint32_t)r);
+      const int col = r - slot * rv;
+      const int e = Lsrc[sl * k + slot], fs = Lfirst[sl];
+      const bool w = in & (slot >= fs);
+      wr[u] = w;
+      has[u] = w & (e >= 0);
+      idx[u] = has[u] ? (long long)e * rv + col : 0;
+    }
+    V v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = X[idx[u]];
+    // piece u of the trip sits u KiB-rows behind the lane's first one: one offset register per lane, the rest is a scalar
+    const unsigned base_off = (unsigned)(fb + lane) * (unsigned)sizeof(V);
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      buffer_store_vec(has[u] ? v[u] : zero_vec<V>(), O, wr[u] ? base_off : kDrop, (unsigned)(u * kWave) * (unsigned)sizeof(V));
+  }
+}
+
+// records of [a, z) with eid < bound form a prefix: their number, by a 4-ary search private to the lane (3 probes in flight per round)
+__device__ __forceinline__ long long lane_prefix_count(const Rec* __restrict__ recs, long long a, long long z, long long bound) {
+  long long lo = a, hi = z;  // answer in [lo, hi]
+  while (hi - lo > 3) {
+    const long long q = (hi - lo) >> 2;
+    const long long m1 = lo + q, m2 = lo + 2 * q, m3 = lo + 3 * q;
+    const bool l1 = (long long)recs[m1].eid < bound, l2 = (long long)recs[m2].eid < bound, l3 = (long long)recs[m3].eid < bound;
+    if (l3) lo = m3 + 1;
+    else if (l2) { lo = m2 + 1; hi = m3; }
+    else if (l1) { lo = m1 + 1; hi = m2; }
+    else hi = m1;
+  }
+  while (lo < hi && (long long)recs[lo].eid < bound) ++lo;
+  return lo - a;
+}
+
+template <bool RING, int VEC, int BCAP, bool RIDE>
+__global__ __launch_bounds__(256) void lookup_tile_kernel(const LookupArgs a, const UpdateArgs u) {
+  extern __shared__ __attribute__((aligned(16))) int lds_eid_all[];
+  unsigned bid = blockIdx.x, nblk = gridDim.x;
+  if constexpr (RING && RIDE) {
+    if (bid < a.side_blocks) {
+      update_side_work(u, a.side_stage, (int)bid);
+      if (a.tail_blocks) tail_signal(u.barrier, true, 0, 0);
+      return;
+    }
+    bid -= a.side_blocks;
+    nblk -= a.side_blocks + a.tail_blocks;
+    if (bid >= nblk) {
+      tail_commit(u, bid - nblk, a.tail_blocks, nblk + a.side_blocks);
+      return;
+    }
+  }
+  const int lane = lane_id();
+  const int wave_in_block = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+  const int k = a.k, B = a.B;
+  // per wave: ONE staging area of [64, k] ints -- the tile's ids, then the times of rows 0..31, then of rows 32..63 (each flushed to
+  // the outputs as flat 16-byte pieces), then the feature-row sources the copy phase looks up -- | first slot to write [64].
+  // 5.3 KB at k = 20: every tile of a 250 k-seed launch is resident at once (15 waves per CU), no second round, no tail
+  int* L = lds_eid_all + wave_in_block * (kWave * k + kWave);
+  int* Lstage = L;
+  int* Lfirst = L + kWave * k;
+  const long long tiles = (a.S + kWave - 1) / kWave;
+  // normally ONE tile per wave (the launch sizes the grid for it); a launch that must leave room on every CU for the ring
+  // update's kernels on the side stream caps the grid, and its waves take a second tile
+  for (long long tv = (long long)bid * wpb + wave_in_block; tv < tiles; tv += (long long)nblk * wpb) {
+    // the tile index is the same in every lane of the wave: say so (scalar registers; the copy phase's buffer descriptor needs it)
+    const long long t = (long long)(((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)tv >> 32)) << 32) |
+                                    __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)tv));
+    const long long s = t * kWave + lane;
+    const bool act = s < a.S;
+    int n = -1, v_old = 0;
+    long long q = 0;
+    if (act) {
+      n = a.seeds[s];
+      q = a.qtimes[s];
+      if (a.out_valid) v_old = a.out_valid[s];  // (delta feature writes) read here: one round trip with the seeds, not one of its own
+      int st = 0;
+      if (n >= a.N || n < -1 || (n == -1 && !a.allow_pad)) st |= TGMX_ST_SEED_RANGE;
+      if (q < 0 && !a.allow_pad) st |= TGMX_ST_SEED_TIME;
+      if (st) atomicOr(a.status, st);
+    }
+    const bool live = n >= 0 && n < a.N;
+    // the lane's window: records [w0, w0 + wlen), oldest -> newest after rotating by wrot (rings)
+    long long w0 = 0;
+    int wrot = 0, wlen = 0;
+    if (live) {
+      if constexpr (RING) {
+        w0 = (long long)n * B;
+        wlen = B;
+      } else {
+        const long long ra = a.indptr[n], rz = a.indptr[n + 1];
+        const long long p_hi = ra + lane_prefix_count(a.recs, ra, rz, a.ev_hi);
+        const long long p_lo = a.ev_lo <= 0 ? ra : ra + lane_prefix_count(a.recs, ra, rz, a.ev_lo);
+        w0 = p_hi - B > p_lo ? p_hi - B : p_lo;
+        wlen = (int)(p_hi - w0);
+      }
+    }
+    Rec r[BCAP];
+#pragma unroll
+    for (int j = 0; j < BCAP; ++j) {
+      r[j].nbr = -1;
+      r[j].eid = 0;
+      r[j].ts = 0;
+      if (j < wlen) r[j] = a.recs[w0 + j];
+    }
+    if constexpr (RING) {
+      if (live) wrot = a.write_pos[n] % B;  // independent of the record loads above: one round trip for both
+    }
+    int cnt = 0;  // 1 + unrolled position of the newest entry with ts < q
+#pragma unroll
+    for (int j = 0; j < BCAP; ++j) {
+      int i = j - wrot;
+      if (i < 0) i += B;
+      if (j < wlen && r[j].nbr >= 0 && r[j].ts < q && i >= cnt) cnt = i + 1;
+      // keep the record ONE 16-byte load: rings never use `eid`, and hipcc would split the load into a dword and a dwordx2 --
+      // twice the instructions, each walking 64 scattered lines through the CU's address unit.  (An empty use, placed where the
+      // record is consumed anyway: next to the load it would put a wait behind every load.)
+      if constexpr (RING) asm volatile("" ::"v"(r[j].eid));
+    }
+    for (int c = 0; c < k; ++c) {  // pads; the entries below overwrite what the window fills
+      Lstage[lane * k + c] = -1;
+    }
+    // the output slot of window record j (-1: not part of the row -- newer than q, older than the k kept, or a pad record);
+    // everything below works from these and the records' payload
+    int cj[BCAP];
+    int minc = k;  // leftmost non-pad output slot (see lookup_seed: the row's SPAN, an interior pad record stays a pad)
+#pragma unroll
+    for (int j = 0; j < BCAP; ++j) {
+      int i = j - wrot;
+      if (i < 0) i += B;
+      const int c = i - (cnt - k);  // output slot of unrolled position i
+      cj[j] = (j < wlen && i < cnt && c >= 0 && r[j].nbr >= 0) ? c : -1;
+      if (cj[j] >= 0) {
+        Lstage[lane * k + c] = r[j].nbr;
+        minc = c < minc ? c : minc;
+      }
+    }
+    int first_slot = act ? 0 : k;
+    if (a.out_valid && act) {  // delta feature writes: see LookupArgs::out_valid
+      const int v_new = k - minc;
+      first_slot = k - (v_old > v_new ? v_old : v_new);
+      a.out_valid[s] = v_new;
+      if (a.out_valid_prev) a.out_valid_prev[s] = v_old;
+    }
+    Lfirst[lane] = first_slot;
+    __builtin_amdgcn_wave_barrier();
+    // flush the tile's ids: flat 16-byte pieces of [rows, k]
+    const int rows = (int)((a.S - t * kWave) < kWave ? (a.S - t * kWave) : kWave);
+    const int ne = rows * k;
+    {
+      const int4* __restrict__ L4 = reinterpret_cast<const int4*>(Lstage);
+      int32_t* __restrict__ G = a.out_nid + t * kWave * k;
+      int4* __restrict__ G4 = reinterpret_cast<int4*>(G);
+      for (int f = lane; f < (ne >> 2); f += kWave) G4[f] = L4[f];
+      for (int f = (ne & ~3) + lane; f < ne; f += kWave) G[f] = Lstage[f];
+    }
+    // the times, 32 rows at a time through the same staging area ([32, k] int64 = [64, k] ints)
+    long long* Lts = reinterpret_cast<long long*>(Lstage);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      __builtin_amdgcn_wave_barrier();  // the staging area's previous contents have been read
+      const bool mine = (lane >> 5) == half;
+      const int lr = lane & 31;
+      if (mine) {
+        for (int c = 0; c < k; ++c) Lts[lr * k + c] = 0;
+#pragma unroll
+        for (int j = 0; j < BCAP; ++j)
+          if (cj[j] >= 0) Lts[lr * k + cj[j]] = r[j].ts;
+      }
+      __builtin_amdgcn_wave_barrier();
+      const int hrows = rows - 32 * half < 32 ? rows - 32 * half : 32;  // rows of this half that exist
+      if (hrows > 0) {
+        const int he = hrows * k;
+        const int4* __restrict__ T4 = reinterpret_cast<const int4*>(Lts);
+        int64_t* __restrict__ H = a.out_ts + (t * kWave + 32 * half) * k;
+        int4* __restrict__ H4 = reinterpret_cast<int4*>(H);
+        for (int f = lane; f < (he >> 1); f += kWave) H4[f] = T4[f];
+        if ((he & 1) && lane == 0) H[he - 1] = Lts[he - 1];
+      }
+    }
+    if (a.D > 0) {
+      // the staging area's last tenant: the feature row every output slot is copied from (-1: zeros)
+      __builtin_amdgcn_wave_barrier();
+      for (int c = 0; c < k; ++c) Lstage[lane * k + c] = -1;
+#pragma unroll
+      for (int j = 0; j < BCAP; ++j)
+        if (cj[j] >= 0) Lstage[lane * k + cj[j]] = RING ? (int)(w0 + j) : r[j].eid;
+      __builtin_amdgcn_wave_barrier();
+      tile_copy<VEC>(a, t, rows, k, lane, Lstage, Lfirst);
+    }
+    __builtin_amdgcn_wave_barrier();  // the next tile reuses the staging area
+  }
+  if constexpr (RING && RIDE) {
+    if (a.tail_blocks) tail_signal(u.barrier, false, bid, nblk);
+  }
+}
+
+// > 64 KB of LDS per workgroup (static + dynamic) is a per-DEVICE opt-in of the kernel function
+template <auto Kernel>
+static bool lds_optin() {
+  constexpr int kMaxDevices = 64;
+  static std::atomic<bool> done[kMaxDevices];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = -1;
+  if (dev >= 0 && done[dev].load(std::memory_order_acquire)) return true;
+  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+  if (e != hipSuccess) {
+    set_error("recency_lookup: cannot reserve LDS: %s", hipGetErrorString(e));
+    return false;
+  }
+  if (dev >= 0) done[dev].store(true, std::memory_order_release);
+  return true;
+}
+
+static int device_cu_count() {
+  static std::atomic<int> cus[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  int n = cus[dev].load(std::memory_order_relaxed);
+  if (n == 0) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus[dev].store(n, std::memory_order_relaxed);
+  }
+  return n;
+}
+
 // A launch that may be timed: with an event pair the kernel goes through hipExtLaunchKernelGGL, whose events carry the
 // dispatch's OWN begin / end timestamps (what rocprofv3 --kernel-trace reports); hipEventRecord before / after the launch
 // brackets it from outside and adds the command processor's event handling (~4-6 us under a full queue)
@@ -1499,6 +1781,7 @@ static int prepare_lookup(LookupArgs& a, const float* out_x, int kmax) {
   }
   a.row_vecs = a.D > 0 ? a.D / vec : 1;
   a.dv = make_fastdiv((uint32_t)a.row_vecs);
+  a.dv_seed = make_fastdiv((uint32_t)(kmax * a.row_vecs));
   if ((unsigned long long)kmax * a.row_vecs * (unsigned long long)a.row_vecs >= (1ull << 32)) {
     set_error("recency_lookup: k*D^2 too large for the slot divider (k=%d, D=%d)", kmax, a.D);
     return TGMX_E_UNSUPPORTED;
@@ -1521,10 +1804,6 @@ static int launch_lookup(LookupArgs a, hipStream_t stream, hipEvent_t ev_start, 
   a.side_stage = side_stage;
   a.tail_blocks = a.side_blocks ? tail_blocks : 0;
   const bool small = a.B <= kWave && a.k <= kWave;
-  {
-    static const int ablate = getenv("TGMX_ABLATE") ? atoi(getenv("TGMX_ABLATE")) : 0;
-    a.ablate = ablate;
-  }
   const int vec = prepare_lookup(a, a.out_x, a.k);
   if (vec < 0) return vec;
   const int waves_per_block = 4;
@@ -1540,14 +1819,52 @@ static int launch_lookup(LookupArgs a, hipStream_t stream, hipEvent_t ev_start, 
   } while (0)
   // narrow rows: several seeds per wave (streaming rings, plain seed arrays)
   const int gl = a.grp.groups == 0 ? packed_group_lanes(a, a.k, true) : 64;
-  if (gl < 64) {
+  static const bool tile_on = !(getenv("TGMX_TILE") && atoi(getenv("TGMX_TILE")) == 0);  // A/B knob: 0 = the packed kernel
+  const bool tile_ok = gl < 64 && tile_on && a.B <= 32 && a.k <= 32 && (((uintptr_t)a.out_nid | (uintptr_t)a.out_ts) & 15) == 0 && a.S <= (1ll << 25);
+  if (tile_ok) {
+    // a tile of 64 seeds per wave; without riders one wave per workgroup (finest balance, every tile resident at once)
+    const int wpb = ride ? 4 : 1;
+    const long long tiles = (a.S + kWave - 1) / kWave;
+    long long tblocks = (tiles + wpb - 1) / wpb;  // one tile per wave (tile_ok: fits a grid)
+    if (a.leave_room && !ride) {
+      // Every tile resident at once means 15-16 waves of 128 registers per CU: nothing else can be dispatched until tiles
+      // retire, and the side stream's dozen small kernels (the large ring update's front half) then run AFTER the lookups instead
+      // of beside them (measured, comment shape: lookup 128 -> 112 us but the step 179 -> 202 us).  12 waves per CU leave a
+      // quarter of every SIMD's registers and half the LDS free; the surplus tiles are second tiles of the first waves.
+      const long long room = (long long)device_cu_count() * 12;
+      if (tblocks > room) tblocks = room;
+    }
+    const dim3 tgrid((unsigned)tblocks + a.side_blocks + a.tail_blocks), tblock(wpb * kWave);
+    const size_t tlds = (size_t)wpb * (kWave * a.k + kWave) * sizeof(int);
+    const int bcap = a.B <= 10 ? 10 : (a.B <= 20 ? 20 : 32);
+#define TGMX_TILE_LAUNCH(VEC_, BCAP_)                                                                                                       \
+  do {                                                                                                                                      \
+    if (ride) {                                                                                                                             \
+      if (tlds > 32 * 1024 && !lds_optin<lookup_tile_kernel<RING, VEC_, BCAP_, RING>>()) return TGMX_E_LAUNCH;                               \
+      TGMX_LAUNCH_TIMED((lookup_tile_kernel<RING, VEC_, BCAP_, RING>), tgrid, tblock, tlds, stream, ev_start, ev_stop, a, u);                \
+    } else TGMX_LAUNCH_TIMED((lookup_tile_kernel<RING, VEC_, BCAP_, false>), tgrid, tblock, tlds, stream, ev_start, ev_stop, a, u);         \
+  } while (0)
+#define TGMX_TILE_VEC(VEC_)                         \
+  do {                                              \
+    if (bcap == 10) TGMX_TILE_LAUNCH(VEC_, 10);     \
+    else if (bcap == 20) TGMX_TILE_LAUNCH(VEC_, 20); \
+    else TGMX_TILE_LAUNCH(VEC_, 32);                \
+  } while (0)
+    if (vec == 4) TGMX_TILE_VEC(4);
+    else {
+      if (vec == 2) {  // no 8-byte instantiation: float pieces
+        a.row_vecs = a.D;
+        a.dv = make_fastdiv((uint32_t)a.row_vecs);
+        a.dv_seed = make_fastdiv((uint32_t)(a.k * a.row_vecs));
+      }
+      TGMX_TILE_VEC(1);
+    }
+#undef TGMX_TILE_VEC
+#undef TGMX_TILE_LAUNCH
+  } else if (gl < 64) {
     const int per_wave = 64 / gl;
     long long pblocks = ((a.S + per_wave - 1) / per_wave + waves_per_block - 1) / waves_per_block;
     if (pblocks > (1 << 20)) pblocks = 1 << 20;
-    {
-      static const long long cap = getenv("TGMX_PACKED_BLOCKS") ? atoll(getenv("TGMX_PACKED_BLOCKS")) : 0;  // diagnosis: grid-stride over fewer workgroups
-      if (cap > 0 && pblocks > cap) pblocks = cap;
-    }
     const dim3 pgrid((unsigned)pblocks + a.side_blocks + a.tail_blocks);
     const size_t plds = (size_t)waves_per_block * per_wave * a.k * sizeof(int);
 #define TGMX_PACKED(VEC_)                                                                              \
@@ -2190,7 +2507,12 @@ static SideStream* side_stream_for_current_device() {
   if (off || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
   SideStream& s = side[dev];
   if (!s.stream) {
-    if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    // highest priority the device offers: the chain of small launches on this stream runs beside a lookup launch that keeps the
+    // whole chip busy, and every one of its launches would otherwise queue behind that launch's workgroups
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    static const bool no_prio = getenv("TGMX_SIDE_NO_PRIO") != nullptr;  // A/B knob
+    if (hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, no_prio ? prio_lo : prio_hi) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess) {
       s.stream = nullptr;
@@ -2254,7 +2576,7 @@ extern "C" int tgmx_recency_step(const tgmx_recency_step_t* s, tgmx_stream_t str
     if (gen >= 0) {
       TGMX_REQUIRE(s->neg_low < s->neg_high && s->neg_time_out, "recency_step: generated negatives need low < high and neg_time_out");
       grp.gen = gen; grp.gen_low = s->neg_low; grp.gen_range = (unsigned)((long long)s->neg_high - s->neg_low);
-      grp.gen_seed = s->neg_seed; grp.gen_call = s->neg_call; grp.gen_out = s->neg_out; grp.gen_out_ts = s->neg_time_out;
+      grp.gen_seed = s->neg_seed; grp.gen_call = s->neg_call; grp.gen_index0 = (unsigned long long)s->neg_index0; grp.gen_out = s->neg_out; grp.gen_out_ts = s->neg_time_out;
     }
     for (int g = 0; g < s->n_groups; ++g) {
       TGMX_REQUIRE(s->grp_n[g] >= 0 && (s->grp_n[g] == 0 || ((g == gen || s->grp_nid[g]) && s->grp_ts[g])), "recency_step: seed group %d", g);
@@ -2303,12 +2625,21 @@ extern "C" int tgmx_recency_step(const tgmx_recency_step_t* s, tgmx_stream_t str
   static const bool use_tail = getenv("TGMX_TAIL") != nullptr;
   const unsigned tail_blocks = (ride_place && use_tail && s->n_hops == 2) ? (unsigned)((u.m + 3) / 4) : 0u;
   SideStream* side = nullptr;  // set: the large update's front half runs on the side stream next to the lookups
+  bool side_pending = false;   // its launches are enqueued BEHIND the first lookup launch (below)
   if (s->n > 0 && u.m > kBlockMaxM && s->n_hops > 0 && S > 0 && (side = side_stream_for_current_device()) != nullptr) {
     (void)hipEventRecord(side->fork, st);  // the batch's inputs and the previous batch's ring writes are complete
     (void)hipStreamWaitEvent(side->stream, side->fork, 0);
+    side_pending = true;
+  }
+  // The front half is a dozen small launches (~40 us of host time).  Enqueued in front of the lookups, the caller's stream has
+  // nothing to run until the host gets to the first lookup launch; behind it, that launch covers the host's work.
+  auto enqueue_side = [&]() -> int {
+    if (!side_pending) return TGMX_OK;
+    side_pending = false;
     if (const int rl = launch_update_large_front(u, s->scratch + kScratchHead, side->stream)) return rl;
     (void)hipEventRecord(side->join, side->stream);
-  }
+    return TGMX_OK;
+  };
 
   // ---- lookups, hop by hop (hop h + 1 consumes hop h's outputs in place); hops 0 and 1 as one launch when possible
   const int32_t* cur_n = s->seed_nid0;
@@ -2335,6 +2666,7 @@ extern "C" int tgmx_recency_step(const tgmx_recency_step_t* s, tgmx_stream_t str
                        : launch_fused01<true>(a, st, e0, e1, side_chunks > 0 ? &u : nullptr,
                                               ride_place ? kSideAll : kSideSortMerge, ride_place ? 1u : side_chunks, tail_blocks);
     if (rc) return rc;
+    if (const int rs = enqueue_side()) return rs;
     cur_n = s->out_nid[1];
     cur_t = s->out_ts[1];
     S *= (long long)k0 * k1;
@@ -2352,6 +2684,7 @@ extern "C" int tgmx_recency_step(const tgmx_recency_step_t* s, tgmx_stream_t str
     a.out_valid = s->out_valid[h]; a.out_valid_prev = s->out_valid_prev[h];
     a.status = s->status; a.S = S; a.D = s->D; a.k = k; a.B = s->B; a.N = s->num_nodes; a.allow_pad = h > 0;
     a.ev_lo = s->ev_lo; a.ev_hi = s->ev_hi;
+    a.leave_room = side != nullptr;
     const bool timed = h == s->timed_hop;
     hipEvent_t e0 = timed ? (hipEvent_t)s->ev_start : nullptr, e1 = timed ? (hipEvent_t)s->ev_stop : nullptr;
     const bool ride = side_chunks > 0 && h < 2;
@@ -2360,10 +2693,12 @@ extern "C" int tgmx_recency_step(const tgmx_recency_step_t* s, tgmx_stream_t str
                                              h == 0 ? kSideSort : (ride_place ? kSidePlace : kSideMerge),
                                              (h == 1 && ride_place) ? 1u : side_chunks, (h == 1 && ride_place) ? tail_blocks : 0u);
     if (rc) return rc;
+    if (const int rs = enqueue_side()) return rs;
     cur_n = s->out_nid[h];
     cur_t = s->out_ts[h];
     S *= k;
   }
+  if (const int rs = enqueue_side()) return rs;
 
   // ---- ring update (after every lookup, recency.py:161-163)
   if (s->n > 0) {

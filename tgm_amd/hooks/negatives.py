@@ -75,10 +75,13 @@ class RandomNegativeEdgeSamplerHook(StatelessHook):
             if self._rng_seed is None:
                 self._rng_seed = (self._seed if self._seed is not None else torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
             self._calls += 1
-            rc = _native.load().tgmx_random_negatives(self.low, self.high, n, self._rng_seed, self._calls, neg.data_ptr(), t_in.data_ptr(),
-                                                      t_in.shape[0], neg_time.data_ptr(), _native.stream_ptr(device.index))  # fmt: skip
+            # a rank's share of a sharded batch (like='shard_dst', tgm_amd.dist.EdgeShardHook): its draws are the slice
+            # [shard_lo, shard_lo + n) of the ids one rank would draw for the whole batch
+            index0 = int(getattr(batch, 'shard_lo', 0) or 0) if self._like != 'edge_dst' else 0
+            rc = _native.load().tgmx_random_negatives_at(self.low, self.high, n, self._rng_seed, self._calls, index0, neg.data_ptr(), t_in.data_ptr(),
+                                                         t_in.shape[0], neg_time.data_ptr(), _native.stream_ptr(device.index))  # fmt: skip
             if rc:
-                _native.check(rc, 'tgmx_random_negatives')
+                _native.check(rc, 'tgmx_random_negatives_at')
         else:
             gen = None
             if self._seed is not None:

@@ -215,7 +215,8 @@ class CompiledPipeline:
             take(f'nid{hop}', 4 * S * k)
             take(f'nts{hop}', 8 * S * k)
             take(f'nx{hop}', 4 * S * k * D)
-            take(f'nv{hop}', 8 * S)  # [2, S] int32: the rows' spans, and the spans before the last call
+            take(f'nv{hop}', 4 * S)  # [S] int32: the rows' spans (delta feature writes)
+            take(f'nvp{hop}', 4 * S)  # the spans before the last call (byte accounting of a timed launch)
             total_ids += S * k
             S *= k
         if self._dedup is not None:
@@ -310,8 +311,8 @@ class CompiledPipeline:
             if self._delta:
                 # persistent buffers: the lookups write a feature row only from the first slot that changes (its valid slots are the
                 # right-aligned tail, the rest is zero and stays zero) -- tgmx_recency_step_t.out_valid
-                o = off[f'nv{hop}']
-                nv = (buf[o:o + 4 * S].view(torch.int32), buf[o + 4 * S:o + 8 * S].view(torch.int32))
+                o, op = off[f'nv{hop}'], off[f'nvp{hop}']
+                nv = (buf[o:o + 4 * S].view(torch.int32), buf[op:op + 4 * S].view(torch.int32))
                 out.out_valid[hop], out.out_valid_prev[hop] = nv[0].data_ptr(), nv[1].data_ptr()
                 valid.append(nv)
             out.out_nid[hop], out.out_ts[hop], out.out_x[hop] = nid.data_ptr(), nts.data_ptr(), nx.data_ptr()

@@ -83,13 +83,35 @@ def pmc(db, kernel):
         print(f'| `{short(name, 60)}` | {cn} | {grid} | {n} | {avg:.1f} | {mn:.1f} | {mx:.1f} |')
 
 
+def pmctail(db, kernel, last):
+    """per-counter average over the LAST `last` dispatches of one kernel (bench.py's timed steps are the end of the run: the
+    whole-run average also covers the untimed ring fill, whose launches move far fewer bytes); one JSON object"""
+    rows = db.execute('select k.dispatch_id, k.start, k.grid_x, p.counter_name, sum(p.counter_value) from pmc_events p join kernels k '
+                      'on k.dispatch_id = p.dispatch_id where k.name like ? group by k.dispatch_id, p.counter_name order by k.dispatch_id', ('%' + kernel + '%',)).fetchall()
+    if not rows:
+        sys.exit(f'no dispatch of a kernel matching {kernel}')
+    grids = {}
+    for d, _, g, _, _ in rows:
+        grids.setdefault(g, set()).add(d)
+    main_grid = max(grids, key=lambda g: len(grids[g]))
+    ids = sorted(grids[main_grid])[-last:]
+    keep = set(ids)
+    out = {}
+    for d, _, g, c, v in rows:
+        if d in keep:
+            out.setdefault(c, []).append(v)
+    print(json.dumps({'kernel': kernel, 'grid_x': main_grid, 'dispatches': len(ids),
+                      'counters': {c: {'avg': sum(v) / len(v), 'min': min(v), 'max': max(v)} for c, v in out.items()}}))
+
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
-    ap.add_argument('what', choices=['trace', 'gaps', 'pmc', 'tail'])
+    ap.add_argument('what', choices=['trace', 'gaps', 'pmc', 'tail', 'pmctail'])
     ap.add_argument('--last', type=int, default=393)
     ap.add_argument('path')
     ap.add_argument('--title', default='rocprofv3 --kernel-trace --stats')
     ap.add_argument('--kernel', default='')
     a = ap.parse_args()
     db = open_db(a.path)
-    {'trace': lambda: trace(db, a.title), 'gaps': lambda: gaps(db, a.kernel), 'pmc': lambda: pmc(db, a.kernel), 'tail': lambda: tail(db, a.kernel, a.last)}[a.what]()
+    {'trace': lambda: trace(db, a.title), 'gaps': lambda: gaps(db, a.kernel), 'pmc': lambda: pmc(db, a.kernel), 'tail': lambda: tail(db, a.kernel, a.last),
+     'pmctail': lambda: pmctail(db, a.kernel, a.last)}[a.what]()
