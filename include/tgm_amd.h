@@ -218,6 +218,15 @@ typedef struct tgmx_recency_step {
    * batch drawn by different ranks are slices of the ids a single rank would draw for the whole batch (rank order concatenation
    * of the ranks' outputs then equals the single-rank tensors).  0 for an unsharded batch. */
   int64_t neg_index0;
+  /* ABI v4, static index only, optional (NULL: off): int64[num_nodes], zero-initialised by the caller and owned by it.  The lookups
+   * keep, per node, where its visible prefix ended the last time it was looked up, and start the next batch-boundary search there
+   * (a node gains a handful of entries per batch: two probes instead of a search over its whole history).  A cache: results never
+   * depend on its contents; any values are safe. */
+  int64_t* csr_cursor;
+  /* ABI v4, static index only.  != 0: `ring_x` holds the feature rows in ADJACENCY order -- row p belongs to adjacency record p
+   * (a copy of edge_x[adj[p].eid] made once at index build) -- so a node's window of B records gathers B consecutive rows instead
+   * of B rows scattered by edge id.  0: `ring_x` is edge_x[E, D], addressed by eid. */
+  int32_t csr_x_by_pos;
 } tgmx_recency_step_t;
 
 int tgmx_recency_step(const tgmx_recency_step_t* step, tgmx_stream_t stream);

@@ -454,7 +454,7 @@ def test_dirty_scratch_head_is_reported_not_hung():
     hm = HookManager(keys=['k'])
     hm.register('k', hook)
     dg = _graph(a, 0, E, edge_x)
-    loader = DGDataLoader(dg, batch_size=bs, hook_manager=hm)
+    loader = DGDataLoader(dg, batch_size=bs, hook_manager=hm, output_pool=0)  # hook by hook: the hook's own argument block is the one inspected
     with hm.activate('k'):
         it = iter(loader)
         next(it)  # allocates (and zeroes) the scratch
@@ -474,13 +474,13 @@ def test_violated_timestamp_bound_is_reported():
     hook = RecencyNeighborHook(N, [4], ['edge_src', 'edge_dst'], ['edge_time', 'edge_time'], validate='deferred')
     hm = HookManager(keys=['k'])
     hm.register('k', hook)
-    loader = DGDataLoader(_graph(a, 0, E, edge_x), batch_size=bs, hook_manager=hm)
+    loader = DGDataLoader(_graph(a, 0, E, edge_x), batch_size=bs, hook_manager=hm, output_pool=0)  # hook by hook: the hook's own argument block
     with hm.activate('k'):
         it = iter(loader)
         next(it)
         hook.check()  # the bound taken from the store holds
-        assert hook._step.ts_bound == int(a['ts'][-1])
-        hook._step.ts_bound = 10  # a promise the second batch breaks
+        assert hook._step.ts_bound == int(a['ts'][-1]) == hook._store_promise[0]
+        hook._store_promise = (10, hook._store_promise[1])  # a promise the second batch breaks
         next(it)
         with pytest.raises(RuntimeError, match='ts_bound'):
             hook.check()

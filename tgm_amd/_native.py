@@ -152,7 +152,7 @@ class RecencyStep(ctypes.Structure):
         ('neg_seed', ctypes.c_uint64), ('neg_call', ctypes.c_uint64), ('neg_out', c_void_p), ('neg_time_out', c_void_p),
         ('guard_seed_errors', c_int32), ('sorted_ts', c_int32),
         ('out_valid', c_void_p * MAX_HOPS), ('out_valid_prev', c_void_p * MAX_HOPS),
-        ('neg_index0', c_int64),
+        ('neg_index0', c_int64), ('csr_cursor', c_void_p), ('csr_x_by_pos', c_int32),
     ]  # fmt: skip
 
 

@@ -26,6 +26,8 @@
 #include <cstring>
 
 #include <hip/hip_ext.h>
+#include <rocprim/block/block_radix_sort.hpp>
+#include <rocprim/block/block_scan.hpp>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 #include <rocprim/iterator/counting_iterator.hpp>
@@ -80,6 +82,8 @@ struct LookupArgs {
   int row_vecs;  // D / VEC
   FastDiv dv;    // division by row_vecs
   FastDiv dv_seed;  // division by k * row_vecs (tile kernel: flat piece index -> seed of the tile)
+  int x_by_pos;       // static index: feature rows are stored in ADJACENCY order (row = record position), not addressed by eid
+  long long* cursor;  // static index, optional: per node, where its visible prefix ended the last time it was looked up (a hint)
   int leave_room;   // tile kernel: other launches must fit beside this one (the large ring update's chain on the side stream)
   // ring update work riding along (tgmx_recency_step): the first side_blocks workgroups run side_stage on the
   // launch's second argument instead of looking anything up
@@ -1126,7 +1130,7 @@ __device__ __forceinline__ SmallPick small_pick(const LookupArgs& a, int n, long
   o.has = i >= 0 && g_nbr >= 0;
   o.nbr = o.has ? g_nbr : -1;
   o.ts = o.has ? g_ts : 0;
-  o.src = o.has ? (RING ? (int)slot_of<RING>(w, B, from) : g_eid) : -1;
+  o.src = o.has ? ((RING || a.x_by_pos) ? (int)slot_of<RING>(w, B, from) : g_eid) : -1;
   return o;
 }
 
@@ -1200,7 +1204,7 @@ __device__ __forceinline__ void lookup_seed(const LookupArgs& a, long long s, in
       const bool has = r.nbr >= 0;
       out_nid[s * k + c] = has ? r.nbr : -1;
       out_ts[s * k + c] = has ? r.ts : 0;
-      lds_eid[c] = has ? (RING ? (int)slot_of<RING>(w, B, i) : r.eid) : -1;
+      lds_eid[c] = has ? ((RING || a.x_by_pos) ? (int)slot_of<RING>(w, B, i) : r.eid) : -1;
       if (has && k - c > v_new) v_new = k - c;
     }
     for (int o = 32; o > 0; o >>= 1) {
@@ -1364,7 +1368,7 @@ __device__ __forceinline__ GroupPick group_pick(const LookupArgs& a, int n, long
   o.ts = o.has ? g_ts : 0;
   int sl = wrot + from;
   if (sl >= B) sl -= B;
-  o.src = o.has ? (RING ? (int)(w0 + sl) : g_eid) : -1;
+  o.src = o.has ? ((RING || a.x_by_pos) ? (int)(w0 + sl) : g_eid) : -1;
   return o;
 }
 
@@ -1504,6 +1508,18 @@ __device__ __forceinline__ void buffer_store_vec(float2 v, __amdgpu_buffer_rsrc_
 __device__ __forceinline__ void buffer_store_vec(float v, __amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff) {
   __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, off, soff, 0);
 }
+// ... and loads whose out-of-range lanes read zeros
+__device__ __forceinline__ void buffer_load_vec(float4& v, __amdgpu_buffer_rsrc_t r, unsigned off) {
+  const tgmx_u4 x = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+  v = *reinterpret_cast<const float4*>(&x);
+}
+__device__ __forceinline__ void buffer_load_vec(float2& v, __amdgpu_buffer_rsrc_t r, unsigned off) {
+  const tgmx_u2 x = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
+  v = *reinterpret_cast<const float2*>(&x);
+}
+__device__ __forceinline__ void buffer_load_vec(float& v, __amdgpu_buffer_rsrc_t r, unsigned off) {
+  v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
 template <typename T>
 __device__ __forceinline__ T* wave_uniform_ptr(T* p) {  // tell the compiler what we know: the value is the same in every lane
   const unsigned long long v = (unsigned long long)p;
@@ -1511,48 +1527,73 @@ __device__ __forceinline__ T* wave_uniform_ptr(T* p) {  // tell the compiler wha
   return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
 }
 
-template <int VEC>
-__device__ __forceinline__ void tile_copy(const LookupArgs& a, long long t, int rows, int k, int lane, const int* Lsrc, const int* Lfirst) {
+// The tile's feature rows: Lsrc[seed * k + slot] = the row each output slot is copied from (-1: zeros), Llist[0 .. n_rows) = the
+// output slots that have to be written at all, as (seed << 8 | slot) -- the rows of pad seeds and, with delta writes, everything left
+// of a row's first changing slot are not in it (47 % of a comment-shaped tile: two trips of the loop below instead of five walking
+// every slot with most lanes predicated off).
+// SMALL_TABLE: the feature table is smaller than 4 GB (the launch checks: rings of up to ~16 M rows of 64 B): it sits behind a buffer
+// descriptor too, a piece's address is ONE register, and a piece without a source simply reads out of range (zeros) -- no select.
+template <int VEC, bool SMALL_TABLE>
+__device__ __forceinline__ void tile_copy(const LookupArgs& a, long long t, int rows, int k, int lane, const int* Lsrc,
+                                          const unsigned short* Llist, int n_rows, long long table_rows) {
   using V = typename VecOf<VEC>::type;
   const V* __restrict__ X = reinterpret_cast<const V*>(a.edge_x);
-  const int rv = a.row_vecs, per_seed = k * rv, total = rows * per_seed;
+  const int rv = a.row_vecs, total = n_rows * rv;
   // the tile's [rows, k, D] block of the output behind one wave-uniform descriptor
   float* base = wave_uniform_ptr(a.out_x + t * 64 * (long long)k * a.D);
-  const __amdgpu_buffer_rsrc_t O = __builtin_amdgcn_make_buffer_rsrc(base, 0, total * (int)sizeof(V), 0x00020000);
-  constexpr int U = 16;  // pieces per lane and trip: 16 independent 16-byte loads in flight per lane
-  constexpr unsigned kDrop = 0xFFFFFFF0u;  // outside every tile: the store is dropped
-  // One trip: every LDS lookup, then U unconditional loads (a piece without a source reads row 0 and is replaced by zeros), then U
-  // stores -- straight-line code.  (hipcc drains the queue at the top of the next trip before it overwrites a register that a store
-  // in flight was issued from; two register sets per trip were tried: same wait, more registers.)
+  const __amdgpu_buffer_rsrc_t O = __builtin_amdgcn_make_buffer_rsrc(base, 0, rows * k * rv * (int)sizeof(V), 0x00020000);
+  const __amdgpu_buffer_rsrc_t T = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.edge_x), 0,
+                                                                     SMALL_TABLE ? (int)(unsigned)(table_rows * rv * (long long)sizeof(V)) : 0, 0x00020000);
+  constexpr int U = SMALL_TABLE ? 16 : 12;  // pieces per lane and trip: U independent 16-byte loads in flight per lane
+  constexpr unsigned kDrop = 0xFFFFFFF0u;  // outside every tile and every table: the store is dropped, the load reads zeros
   // vmcnt(0), once, in front of the loop: with memory operations of the phases before still in hipcc's books at loop entry, its
   // wait-count insertion puts a full drain at the TOP of every trip instead (every trip then pays a store round trip)
   __builtin_amdgcn_s_waitcnt(0x0F70);
+  // One trip: every LDS lookup, then U unconditional loads, then U range-checked stores -- straight-line code.
   for (int fb = 0; fb < total; fb += kWave * U) {  // wave-uniform trip count
-    long long idx[U];
-    bool has[U], wr[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int f = fb + u * kWave + lane;
-      const bool in = f < total;
-      const int fc = in ? f : 0;
-      const int sl = (int)a.dv_seed.div_nb((uint32_t)fc);
-      const int r = fc - sl * per_seed;
-      const int slot = (int)a.dv.div_nb((uint32_t)r);
-      const int col = r - slot * rv;
-      const int e = Lsrc[sl * k + slot], fs = Lfirst[sl];
-      const bool w = in & (slot >= fs);
-      wr[u] = w;
-      has[u] = w & (e >= 0);
-      idx[u] = has[u] ? (long long)e * rv + col : 0;
-    }
+    unsigned off[U];
     V v[U];
+    if constexpr (SMALL_TABLE) {
+      unsigned src[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) v[u] = X[idx[u]];
-    // piece u of the trip sits u KiB-rows behind the lane's first one: one offset register per lane, the rest is a scalar
-    const unsigned base_off = (unsigned)(fb + lane) * (unsigned)sizeof(V);
+      for (int u = 0; u < U; ++u) {
+        const int f = fb + u * kWave + lane;
+        const bool in = f < total;
+        const int fc = in ? f : 0;
+        const int row = (int)a.dv.div_nb((uint32_t)fc);
+        const int col = fc - row * rv;
+        const int entry = Llist[row];
+        const int at = (entry >> 8) * k + (entry & 255);  // seed * k + slot
+        const int e = Lsrc[at];
+        src[u] = (in & (e >= 0)) ? ((unsigned)e * (unsigned)rv + (unsigned)col) * (unsigned)sizeof(V) : kDrop;
+        off[u] = in ? (unsigned)(at * rv + col) * (unsigned)sizeof(V) : kDrop;
+      }
 #pragma unroll
-    for (int u = 0; u < U; ++u)
-      buffer_store_vec(has[u] ? v[u] : zero_vec<V>(), O, wr[u] ? base_off : kDrop, (unsigned)(u * kWave) * (unsigned)sizeof(V));
+      for (int u = 0; u < U; ++u) buffer_load_vec(v[u], T, src[u]);
+    } else {
+      long long idx[U];
+      bool has[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int f = fb + u * kWave + lane;
+        const bool in = f < total;
+        const int fc = in ? f : 0;
+        const int row = (int)a.dv.div_nb((uint32_t)fc);
+        const int col = fc - row * rv;
+        const int entry = Llist[row];
+        const int at = (entry >> 8) * k + (entry & 255);
+        const int e = Lsrc[at];
+        has[u] = in & (e >= 0);
+        idx[u] = has[u] ? (long long)e * rv + col : 0;  // a piece without a source reads row 0 and is replaced by zeros
+        off[u] = in ? (unsigned)(at * rv + col) * (unsigned)sizeof(V) : kDrop;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = X[idx[u]];
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = has[u] ? v[u] : zero_vec<V>();
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) buffer_store_vec(v[u], O, off[u], 0u);
   }
 }
 
@@ -1570,6 +1611,32 @@ __device__ __forceinline__ long long lane_prefix_count(const Rec* __restrict__ r
   }
   while (lo < hi && (long long)recs[lo].eid < bound) ++lo;
   return lo - a;
+}
+
+// The same with a HINT: where node n's visible prefix ended the last time somebody looked (LookupArgs::cursor).  Batch boundaries
+// only move forward within an epoch and a node gains a handful of entries per batch, so the answer is the hint itself or a few
+// entries to its right: two probes (one round trip) confirm it, a gallop finds it otherwise -- instead of the ~log4(degree)
+// dependent rounds of a search from scratch.  A hint that does not fit (another epoch, never set) costs nothing but the
+// two probes.  Returns the ABSOLUTE index of the first record with eid >= bound.
+__device__ __forceinline__ long long lane_prefix_end_hinted(const Rec* __restrict__ recs, long long ra, long long rz, long long bound, long long hint) {
+  long long lo = ra, hi = rz;  // answer in [lo, hi]
+  if (hint >= ra && hint <= rz) {
+    const bool below = hint == ra || (long long)recs[hint - 1].eid < bound;  // everything left of the hint is visible
+    const bool at = hint < rz && (long long)recs[hint].eid < bound;         // ... and so is the entry at the hint
+    if (below && !at) return hint;
+    if (below) {  // gallop to the right
+      lo = hint + 1;
+      long long step = 1;
+      while (lo + step <= rz && (long long)recs[lo + step - 1].eid < bound) {
+        lo += step;
+        step <<= 1;
+      }
+      hi = lo + step - 1 < rz ? lo + step - 1 : rz;
+    } else {
+      hi = hint - 1;  // recs[hint - 1] is not visible: the answer is at or left of it
+    }
+  }
+  return lo + lane_prefix_count(recs, lo, hi, bound);
 }
 
 template <bool RING, int VEC, int BCAP, bool RIDE>
@@ -1593,11 +1660,11 @@ __global__ __launch_bounds__(256) void lookup_tile_kernel(const LookupArgs a, co
   const int wave_in_block = threadIdx.x >> 6, wpb = blockDim.x >> 6;
   const int k = a.k, B = a.B;
   // per wave: ONE staging area of [64, k] ints -- the tile's ids, then the times of rows 0..31, then of rows 32..63 (each flushed to
-  // the outputs as flat 16-byte pieces), then the feature-row sources the copy phase looks up -- | first slot to write [64].
-  // 5.3 KB at k = 20: every tile of a 250 k-seed launch is resident at once (15 waves per CU), no second round, no tail
-  int* L = lds_eid_all + wave_in_block * (kWave * k + kWave);
+  // the outputs as flat 16-byte pieces), then the feature-row sources the copy phase looks up -- | the copy phase's list of output
+  // slots to write, [64, k] 16-bit entries.  7.9 KB at k = 20 (12 waves per CU fit by registers: 3 per SIMD)
+  int* L = lds_eid_all + wave_in_block * (kWave * k + kWave * k / 2 + kWave);
   int* Lstage = L;
-  int* Lfirst = L + kWave * k;
+  int* Lfirst = L + kWave * k;  // the copy phase's list of output slots to write: [64 * k] 16-bit entries
   const long long tiles = (a.S + kWave - 1) / kWave;
   // normally ONE tile per wave (the launch sizes the grid for it); a launch that must leave room on every CU for the ring
   // update's kernels on the side stream caps the grid, and its waves take a second tile
@@ -1610,8 +1677,12 @@ __global__ __launch_bounds__(256) void lookup_tile_kernel(const LookupArgs a, co
     int n = -1, v_old = 0;
     long long q = 0;
     if (act) {
-      n = a.seeds[s];
-      q = a.qtimes[s];
+      if (a.grp.groups > 0) {  // hop 0: the seed comes from its group (or is drawn: generated negatives) and is published
+        fetch_seed(a, s, 0, true, n, q);
+      } else {
+        n = a.seeds[s];
+        q = a.qtimes[s];
+      }
       if (a.out_valid) v_old = a.out_valid[s];  // (delta feature writes) read here: one round trip with the seeds, not one of its own
       int st = 0;
       if (n >= a.N || n < -1 || (n == -1 && !a.allow_pad)) st |= TGMX_ST_SEED_RANGE;
@@ -1628,7 +1699,9 @@ __global__ __launch_bounds__(256) void lookup_tile_kernel(const LookupArgs a, co
         wlen = B;
       } else {
         const long long ra = a.indptr[n], rz = a.indptr[n + 1];
-        const long long p_hi = ra + lane_prefix_count(a.recs, ra, rz, a.ev_hi);
+        const long long hint = a.cursor ? a.cursor[n] : -1;  // (one round trip with the two loads above)
+        const long long p_hi = lane_prefix_end_hinted(a.recs, ra, rz, a.ev_hi, hint);
+        if (a.cursor && p_hi != hint) a.cursor[n] = p_hi;  // lanes that share the node store the same value
         const long long p_lo = a.ev_lo <= 0 ? ra : ra + lane_prefix_count(a.recs, ra, rz, a.ev_lo);
         w0 = p_hi - B > p_lo ? p_hi - B : p_lo;
         wlen = (int)(p_hi - w0);
@@ -1681,7 +1754,6 @@ __global__ __launch_bounds__(256) void lookup_tile_kernel(const LookupArgs a, co
       a.out_valid[s] = v_new;
       if (a.out_valid_prev) a.out_valid_prev[s] = v_old;
     }
-    Lfirst[lane] = first_slot;
     __builtin_amdgcn_wave_barrier();
     // flush the tile's ids: flat 16-byte pieces of [rows, k]
     const int rows = (int)((a.S - t * kWave) < kWave ? (a.S - t * kWave) : kWave);
@@ -1723,9 +1795,22 @@ __global__ __launch_bounds__(256) void lookup_tile_kernel(const LookupArgs a, co
       for (int c = 0; c < k; ++c) Lstage[lane * k + c] = -1;
 #pragma unroll
       for (int j = 0; j < BCAP; ++j)
-        if (cj[j] >= 0) Lstage[lane * k + cj[j]] = RING ? (int)(w0 + j) : r[j].eid;
+        if (cj[j] >= 0) Lstage[lane * k + cj[j]] = (RING || a.x_by_pos) ? (int)(w0 + j) : r[j].eid;
+      // ... and the list of output slots that need a write at all: an exclusive scan of the rows' counts over the lanes
+      const int nact = k - first_slot;  // first_slot = k for rows beyond S
+      int incl = nact;
+#pragma unroll
+      for (int d = 1; d < kWave; d <<= 1) {
+        const int up = __shfl_up(incl, d);
+        if (lane >= d) incl += up;
+      }
+      const int n_rows = __shfl(incl, kWave - 1);
+      unsigned short* Llist = reinterpret_cast<unsigned short*>(Lfirst);
+      for (int i = 0; i < nact; ++i) Llist[incl - nact + i] = (unsigned short)((lane << 8) | (first_slot + i));
       __builtin_amdgcn_wave_barrier();
-      tile_copy<VEC>(a, t, rows, k, lane, Lstage, Lfirst);
+      // (rings: the feature table is < 4 GB -- checked at launch; a static index may cover any number of edges)
+      if constexpr (RING) tile_copy<VEC, true>(a, t, rows, k, lane, Lstage, Llist, n_rows, (long long)a.N * B);
+      else tile_copy<VEC, false>(a, t, rows, k, lane, Lstage, Llist, n_rows, 0);
     }
     __builtin_amdgcn_wave_barrier();  // the next tile reuses the staging area
   }
@@ -1818,9 +1903,16 @@ static int launch_lookup(LookupArgs a, hipStream_t stream, hipEvent_t ev_start, 
     else TGMX_LAUNCH_TIMED((recency_lookup_kernel<RING, VEC_, SMALL_, false>), grid, block, lds, stream, ev_start, ev_stop, a, u);     \
   } while (0)
   // narrow rows: several seeds per wave (streaming rings, plain seed arrays)
-  const int gl = a.grp.groups == 0 ? packed_group_lanes(a, a.k, true) : 64;
+  const int gl_any = packed_group_lanes(a, a.k, true);            // narrow rows?
+  const int gl = a.grp.groups == 0 ? gl_any : 64;                 // the packed kernel reads plain seed arrays only
   static const bool tile_on = !(getenv("TGMX_TILE") && atoi(getenv("TGMX_TILE")) == 0);  // A/B knob: 0 = the packed kernel
-  const bool tile_ok = gl < 64 && tile_on && a.B <= 32 && a.k <= 32 && (((uintptr_t)a.out_nid | (uintptr_t)a.out_ts) & 15) == 0 && a.S <= (1ll << 25);
+  // A tile's phases are a chain of ~8 dependent round trips (15-20 us on an idle chip): it pays when the launch has several tiles
+  // per CU to overlap them (comment shape, hop 1: 3840 tiles), not for a few hundred seeds -- measured: review shape, hop 0 (24
+  // tiles) 6 -> 19 us, hop 1 (240 tiles) 17.7 -> 19.5 us; comment shape, hop 0 (192 tiles) slower too.  Small launches keep the
+  // kernels that give every seed (group) a wave of its own.
+  const bool tile_ok = gl_any < 64 && tile_on && a.B <= 32 && a.k <= 32 && (((uintptr_t)a.out_nid | (uintptr_t)a.out_ts) & 15) == 0 &&
+                       a.S <= (1ll << 25) && a.S >= 4ll * kWave * device_cu_count() &&
+                       (!RING || (long long)a.N * a.B * (a.D > 0 ? a.D : 1) * 4 < (1ll << 32) - 64);
   if (tile_ok) {
     // a tile of 64 seeds per wave; without riders one wave per workgroup (finest balance, every tile resident at once)
     const int wpb = ride ? 4 : 1;
@@ -1835,7 +1927,7 @@ static int launch_lookup(LookupArgs a, hipStream_t stream, hipEvent_t ev_start, 
       if (tblocks > room) tblocks = room;
     }
     const dim3 tgrid((unsigned)tblocks + a.side_blocks + a.tail_blocks), tblock(wpb * kWave);
-    const size_t tlds = (size_t)wpb * (kWave * a.k + kWave) * sizeof(int);
+    const size_t tlds = (size_t)wpb * (kWave * a.k + kWave * a.k / 2 + kWave) * sizeof(int);
     const int bcap = a.B <= 10 ? 10 : (a.B <= 20 ? 20 : 32);
 #define TGMX_TILE_LAUNCH(VEC_, BCAP_)                                                                                                       \
   do {                                                                                                                                      \
@@ -1999,6 +2091,102 @@ __global__ __launch_bounds__(256) void ring_update_ends_kernel(const UpdateArgs 
   const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= a.m) return;
   if (p == a.m - 1 || a.sorted_node[p + 1] != a.sorted_node[p]) a.run_len[a.run_start[p]] = (int)p - a.run_start[p] + 1;
+}
+
+// ---- 4096 < m <= 8192 (a comment-shaped batch: 2 x 4096 entries): the state-independent half of the update as ONE workgroup ----
+// The generic path above is a chain of 13 small launches (keys, six radix-sort kernels, scatter, scan x 2, ends, ...).  On the side
+// stream, beside a lookup launch that saturates the memory system, every one of them crawls (each dependent access costs
+// microseconds: 143 us for the chain beside the packed lookup kernel, not finished when the faster tile kernel ends).  Here ONE
+// workgroup of 1024 threads sorts the batch in registers / LDS (rocprim::block_radix_sort over the key bits that can be set,
+// stable like argsort(stable=True)), and derives the runs with a block scan: compute on one CU, a few coalesced global accesses,
+// nothing for the lookups to slow down.  Writes what keys + sort + scatter + scan + ends wrote; the placement launch follows.
+constexpr int kFrontIPT = 8, kFrontMaxM = kBlockThreads * kFrontIPT;
+__global__ __launch_bounds__(kBlockThreads) void ring_update_front_block_kernel(const UpdateArgs a) {
+  using Sort = rocprim::block_radix_sort<unsigned long long, kBlockThreads, kFrontIPT, unsigned>;
+  using Scan = rocprim::block_scan<int, kBlockThreads>;
+  __shared__ union {
+    typename Sort::storage_type sort;
+    int node[kFrontMaxM + 1];
+  } L;
+  __shared__ typename Scan::storage_type scan_storage;
+  __shared__ long long red[kBlockThreads / kWave];
+  const int tid = threadIdx.x, m = (int)a.m;
+  // the placement's hash: keys and max positions (adjacent), all -1 (was a memset launch)
+  for (int i = tid; i < (2 << a.hash_bits); i += kBlockThreads) a.hash_key[i] = -1;
+  long long span;
+  if (a.sorted_ts) {
+    span = a.ts[a.n - 1] + 1;  // a time-sorted batch: max(ts) is its last timestamp
+  } else {
+    long long mx = strided_max_ts(a.ts, a.n, tid, kBlockThreads);
+    for (int off = 32; off > 0; off >>= 1) {
+      const long long o = __shfl_xor(mx, off);
+      mx = o > mx ? o : mx;
+    }
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = red[0];
+    for (int w = 1; w < kBlockThreads / kWave; ++w) mx = red[w] > mx ? red[w] : mx;
+    span = mx + 1;
+  }
+  unsigned long long key[kFrontIPT];
+  unsigned val[kFrontIPT];
+#pragma unroll
+  for (int e = 0; e < kFrontIPT; ++e) {
+    const int j = tid * kFrontIPT + e;
+    val[e] = (unsigned)j;
+    key[e] = ~0ull;  // padding: sorts behind every entry (stable: equal keys keep entry order, pads have the largest indices)
+    if (j < m) {
+      int node, nbr;
+      long long t, i;
+      update_entry(a, j, node, nbr, t, i);
+      const long long k = update_key(node, t, span, a.key_wrap32);
+      if (a.sorted_ts && i + 1 < a.n && a.ts[i + 1] < t) atomicOr(a.status, TGMX_ST_TS_BOUND);  // the promise is checked, not trusted
+      if (a.sort_bits < 64) {
+        if (t < 0 || t > a.ts_bound) atomicOr(a.status, TGMX_ST_TS_BOUND);
+        key[e] = (unsigned long long)(a.key_wrap32 ? k + 2147483648LL : k);
+      } else {
+        key[e] = (unsigned long long)k ^ 0x8000000000000000ull;  // signed -> radix order
+      }
+    }
+  }
+  Sort().sort(key, val, L.sort, 0u, (unsigned)a.sort_bits);
+  __syncthreads();
+  // thread tid now holds sorted positions tid * IPT + e
+  int node_at[kFrontIPT];
+#pragma unroll
+  for (int e = 0; e < kFrontIPT; ++e) {
+    const int p = tid * kFrontIPT + e;
+    node_at[e] = -1;
+    if (p < m) {
+      int node, nbr;
+      long long t, i;
+      update_entry(a, val[e], node, nbr, t, i);
+      const bool valid = node >= 0 && node < a.N && nbr >= 0 && nbr < a.N;
+      if (!valid) atomicOr(a.status, TGMX_ST_EDGE_RANGE);
+      node_at[e] = valid ? node : -1;
+      a.sorted_j[p] = (int)val[e];
+      a.sorted_node[p] = node_at[e];
+      L.node[p] = node_at[e];
+    }
+  }
+  if (tid == 0) L.node[m] = -2;  // sentinel behind the last entry: never equal to a node
+  __syncthreads();
+  // run_start = inclusive max-scan of "p if p opens a run else 0"; the run's last position scatters the run length to its first
+  int flag[kFrontIPT], rs[kFrontIPT];
+#pragma unroll
+  for (int e = 0; e < kFrontIPT; ++e) {
+    const int p = tid * kFrontIPT + e;
+    flag[e] = (p < m && p > 0 && L.node[p - 1] == node_at[e]) ? 0 : (p < m ? p : 0);
+  }
+  Scan().inclusive_scan(flag, rs, scan_storage, rocprim::maximum<int>());
+#pragma unroll
+  for (int e = 0; e < kFrontIPT; ++e) {
+    const int p = tid * kFrontIPT + e;
+    if (p < m) {
+      a.run_start[p] = rs[e];
+      if (L.node[p + 1] != node_at[e]) a.run_len[rs[e]] = p - rs[e] + 1;
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void ring_update_place_kernel(const UpdateArgs a) {
@@ -2393,7 +2581,7 @@ static int large_scratch_layout(long long m, LargeScratch& w) {
 
 // front: everything up to the placement decisions -- nothing there writes ring state, so it may run next to the lookups
 // of the same batch on another stream; back: the writes (ring records, write_pos, feature rows)
-static int launch_update_large_front(UpdateArgs& a, int32_t* scratch, hipStream_t st) {
+static int launch_update_large_front(UpdateArgs& a, int32_t* scratch, hipStream_t st, bool beside_lookups = false) {
   LargeScratch w;
   const int rc = large_scratch_layout(a.m, w);
   if (rc) return rc;
@@ -2408,11 +2596,16 @@ static int launch_update_large_front(UpdateArgs& a, int32_t* scratch, hipStream_
   a.run_start = reinterpret_cast<int32_t*>(base + w.run_start);
   a.run_len = reinterpret_cast<int32_t*>(base + w.run_len);
   const unsigned blocks = (unsigned)((a.m + 255) / 256);
-  (void)hipMemsetAsync(a.hash_key, 0xFF, (size_t)8 << w.hash_bits, st);  // keys and max positions (adjacent): all -1
-  if (!a.sorted_ts) {
-    (void)hipMemsetAsync(a.span, 0x80, sizeof(long long), st);  // 0x8080...: far below any timestamp
-    const unsigned span_blocks = (unsigned)((a.n + 2047) / 2048 < 64 ? (a.n + 2047) / 2048 : 64);
-    hipLaunchKernelGGL(ring_update_span_kernel, dim3(span_blocks), dim3(256), 0, st, a);
+  static const bool no_front_block = getenv("TGMX_NO_FRONT_BLOCK") != nullptr;  // A/B knob: the chain of small launches
+  // (on an idle chip the chain is the faster of the two: 74 vs 105 us for the whole update at m = 8192 -- one workgroup is one CU)
+  const bool front_block = beside_lookups && a.m <= kFrontMaxM && !no_front_block;
+  if (!front_block) {
+    (void)hipMemsetAsync(a.hash_key, 0xFF, (size_t)8 << w.hash_bits, st);  // keys and max positions (adjacent): all -1
+    if (!a.sorted_ts) {
+      (void)hipMemsetAsync(a.span, 0x80, sizeof(long long), st);  // 0x8080...: far below any timestamp
+      const unsigned span_blocks = (unsigned)((a.n + 2047) / 2048 < 64 ? (a.n + 2047) / 2048 : 64);
+      hipLaunchKernelGGL(ring_update_span_kernel, dim3(span_blocks), dim3(256), 0, st, a);
+    }
   }
   // how many key bits can be set?  (only with the caller's promise 0 <= t <= ts_bound)
   a.sort_bits = 64;
@@ -2428,6 +2621,11 @@ static int launch_update_large_front(UpdateArgs& a, int32_t* scratch, hipStream_
       if (top < ((__int128)1 << 62)) bits = 64 - __builtin_clzll((unsigned long long)top);
     }
     a.sort_bits = bits;
+  }
+  if (front_block) {  // one workgroup: keys, sort, scatter, runs -- then the placement
+    hipLaunchKernelGGL(ring_update_front_block_kernel, dim3(1), dim3(kBlockThreads), 0, st, a);
+    hipLaunchKernelGGL(ring_update_place_kernel, dim3(blocks), dim3(256), 0, st, a);
+    return TGMX_OK;
   }
   hipLaunchKernelGGL(ring_update_keys_kernel, dim3(blocks), dim3(256), 0, st, a);
   size_t tb = w.temp_bytes;
@@ -2636,7 +2834,7 @@ extern "C" int tgmx_recency_step(const tgmx_recency_step_t* s, tgmx_stream_t str
   auto enqueue_side = [&]() -> int {
     if (!side_pending) return TGMX_OK;
     side_pending = false;
-    if (const int rl = launch_update_large_front(u, s->scratch + kScratchHead, side->stream)) return rl;
+    if (const int rl = launch_update_large_front(u, s->scratch + kScratchHead, side->stream, true)) return rl;
     (void)hipEventRecord(side->join, side->stream);
     return TGMX_OK;
   };
@@ -2659,6 +2857,7 @@ extern "C" int tgmx_recency_step(const tgmx_recency_step_t* s, tgmx_stream_t str
     a.out_valid_prev = s->out_valid_prev[0]; a.out_valid_prev1 = s->out_valid_prev[1];
     a.status = s->status; a.S = S; a.D = s->D; a.k = k0; a.B = s->B; a.N = s->num_nodes; a.allow_pad = 0;
     a.ev_lo = s->ev_lo; a.ev_hi = s->ev_hi;
+    a.x_by_pos = csr && s->csr_x_by_pos;
     const bool timed = s->timed_hop == 0 || s->timed_hop == 1;
     hipEvent_t e0 = timed ? (hipEvent_t)s->ev_start : nullptr, e1 = timed ? (hipEvent_t)s->ev_stop : nullptr;
     // riders: m <= 1024 -> one workgroup does it all and only the commit follows; else sort | barrier | merge
@@ -2684,6 +2883,8 @@ extern "C" int tgmx_recency_step(const tgmx_recency_step_t* s, tgmx_stream_t str
     a.out_valid = s->out_valid[h]; a.out_valid_prev = s->out_valid_prev[h];
     a.status = s->status; a.S = S; a.D = s->D; a.k = k; a.B = s->B; a.N = s->num_nodes; a.allow_pad = h > 0;
     a.ev_lo = s->ev_lo; a.ev_hi = s->ev_hi;
+    a.cursor = csr ? reinterpret_cast<long long*>(s->csr_cursor) : nullptr;
+    a.x_by_pos = csr && s->csr_x_by_pos;
     a.leave_room = side != nullptr;
     const bool timed = h == s->timed_hop;
     hipEvent_t e0 = timed ? (hipEvent_t)s->ev_start : nullptr, e1 = timed ? (hipEvent_t)s->ev_stop : nullptr;

@@ -74,6 +74,7 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
         mode: 'ring' (streaming state, default) or 'csr' (static index, stateless).
         validate: 'sync' | 'deferred' | 'off'.
         batch_size / batch_starts: loader schedule, required by ``mode='csr'``.
+        adj_features: mode='csr' only (default on): a second copy of the edge features in the index's adjacency order.
         key_arith: ring mode only.  'int32' (default) reproduces the reference bit for bit,
             including the int32 wrap of its update sort key (recency.py:347) that leaves
             stale / empty ring slots at dataset scale; 'int64' is the intended per-node
@@ -98,11 +99,15 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
         batch_size: Optional[int] = None,
         batch_starts: Optional[Sequence[int]] = None,
         key_arith: str = 'int32',
+        adj_features: bool = True,
     ) -> None:
         super().__init__()
         if key_arith not in ('int32', 'int64'):
             raise ValueError(f"key_arith must be 'int32' or 'int64', got {key_arith!r}")
         self._key_wrap32 = 1 if key_arith == 'int32' else 0
+        # mode='csr': keep a copy of the feature rows in adjacency order (False: gather by edge id from the store's edge_x)
+        self._adj_features = bool(adj_features)
+        self._adj_features_max_bytes = 32 << 30
         if not len(num_nbrs):
             raise ValueError('num_nbrs must be non-empty')
         if not all(isinstance(x, int) and x > 0 for x in num_nbrs):
@@ -295,6 +300,18 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
             self._csr_store = store
             st = self._step
             st.indptr, st.ring, st.ring_x = self._csr.indptr.data_ptr(), self._csr.adj.data_ptr(), _native.ptr(arr.edge_x)
+            # feature rows in adjacency order (one copy of edge_x[adj.eid] at build time: 2E x D floats, 5.6 GB of 288 for the
+            # comment-shaped stream): a node's window then gathers consecutive rows instead of rows scattered by edge id
+            self._csr_adj_x = None
+            st.csr_x_by_pos = 0
+            if arr.edge_x is not None and self._adj_features and self._csr.adj.shape[0] * arr.edge_x.shape[1] * 4 <= self._adj_features_max_bytes:
+                eid = self._csr.records()[1].to(torch.int64)
+                self._csr_adj_x = arr.edge_x.index_select(0, eid)
+                del eid
+                st.ring_x, st.csr_x_by_pos = self._csr_adj_x.data_ptr(), 1
+            # per node: where its visible prefix ended at its last lookup -- a search hint the kernels keep (tgmx_recency_step_t.csr_cursor)
+            self._csr_cursor = torch.zeros(self._num_nodes, dtype=torch.int64, device=self._device)
+            st.csr_cursor = self._csr_cursor.data_ptr()
         return self._csr
 
     def _check_csr_boundary(self, ev_hi: int) -> None:

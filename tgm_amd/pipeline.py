@@ -466,6 +466,7 @@ class CompiledPipeline:
                 nbr._epoch_lo = lo
             st = pipe.step
             st.indptr, st.ring, st.ring_x, st.ev_lo = nbr._step.indptr, nbr._step.ring, nbr._step.ring_x, nbr._epoch_lo
+            st.csr_cursor, st.csr_x_by_pos = nbr._step.csr_cursor, nbr._step.csr_x_by_pos
         nbr._note_batch_time(self._dg, batch)
         call = 0
         neg = self._neg

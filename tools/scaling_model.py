@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Modelled multi-GPU scaling from ONE GPU: run the slowest rank's exact step of a W-rank job (bench.py --emulate-world W)
 for W = 1, 2, 4, 8.  There is no collective on the sampling data path, so the emulated rank misses nothing; what it cannot
-show is interference between processes on a shared host.  Writes profiles/r02_scaling_model.json.
+show is interference between processes on a shared host.  Writes profiles/r03_scaling_model.json (the model's inputs -- every emulated run's own numbers -- are the rows of that file).
 
     python tools/scaling_model.py            (on the GPU box, from the repo root)
 """
@@ -12,10 +12,12 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = {}
-for workload, scaling, extra in (('wiki', 'weak', []), ('comment', 'weak', ['--steps', '300']), ('comment', 'strong', ['--steps', '300'])):
+CASES = (('wiki', 'weak', 'ring', []), ('comment', 'weak', 'ring', ['--steps', '200']), ('comment', 'strong', 'ring', ['--steps', '200']),
+         ('comment', 'weak', 'csr', ['--steps', '200']), ('comment', 'strong', 'csr', ['--steps', '200']))
+for workload, scaling, mode, extra in CASES:
     rows = []
     for W in (1, 2, 4, 8):
-        cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--workload', workload, '--scaling', scaling, '--cpu-batches', '0'] + extra
+        cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--workload', workload, '--scaling', scaling, '--mode', mode, '--cpu-batches', '0', '--no-default-path'] + extra
         if W > 1:
             cmd += ['--emulate-world', str(W), '--emulate-rank', str(W - 1)]
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -32,7 +34,7 @@ for workload, scaling, extra in (('wiki', 'weak', []), ('comment', 'weak', ['--s
             # weak: per-rank work fixed -> efficiency = t1 / tW, speed-up = W * efficiency; strong: total work fixed -> speed-up = t1 / tW
             r['modelled_speedup'] = (r['world'] * base / r['ms_per_step']) if scaling == 'weak' else base / r['ms_per_step']
             r['modelled_efficiency'] = r['modelled_speedup'] / r['world']
-    out[f'{workload}_{scaling}'] = rows
-    print(workload, scaling, json.dumps(rows), flush=True)
+    out[f'{workload}_{scaling}_{mode}'] = rows
+    print(workload, scaling, mode, json.dumps(rows), flush=True)
 json.dump({'method': 'bench.py --emulate-world W --emulate-rank W-1 on one MI355X (the last rank; all ranks do the same amount of work); '
-           'no hardware multi-GPU curve exists yet (SCALE was skipped)', 'results': out}, open(os.path.join(ROOT, 'profiles', 'r02_scaling_model.json'), 'w'), indent=1)
+           'no hardware multi-GPU curve exists yet (SCALE was skipped in rounds 1-2)', 'results': out}, open(os.path.join(ROOT, 'profiles', 'r03_scaling_model.json'), 'w'), indent=1)
