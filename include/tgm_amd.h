@@ -694,6 +694,11 @@ int tgmx_unique_ids(const int32_t* const* parts, const int64_t* part_sizes, int3
  * searchsorted glue around the TGN message store and commit (tgm/nn/encoder/tgn.py:165-177, 218-229). */
 int tgmx_group_ids(const int32_t* ids, int32_t n, int32_t* sorted, int64_t* perm, int64_t* run_lo, int64_t* run_hi,
                    uint8_t* first, tgmx_stream_t stream);
+/* The same for any n (a 4096-edge batch groups 8192 endpoint ids): one stable rocPRIM radix sort (signed int32 order, like
+ * torch.sort(stable=True)) + one finishing launch.  workspace: 256-byte aligned, tgmx_group_ids_workspace_bytes(n) bytes. */
+size_t tgmx_group_ids_workspace_bytes(int64_t n);
+int tgmx_group_ids_large(const int32_t* ids, int64_t n, int32_t* sorted, int64_t* perm, int64_t* run_lo, int64_t* run_hi,
+                         uint8_t* first, void* workspace, size_t workspace_bytes, tgmx_stream_t stream);
 
 /* ---- TGN backward building blocks (training; composed by tgm_amd/nn/_tgn_train.py).  The reference trains through
  * torch autograd (examples/linkproppred/tgn.py:97-118); memory / last_update are buffers, so the parameters reached are

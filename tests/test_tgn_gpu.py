@@ -55,11 +55,11 @@ def _check_memory_golden(case, meta, a, mem, T):
 
 
 @pytest.mark.parametrize('inference', [False, True])
-@pytest.mark.parametrize('aggr,bs,log_cap', [('last', 512, None), ('mean', 512, None), ('last', 700, None), ('mean', 100, None), ('last', 512, 64),
+@pytest.mark.parametrize('aggr,bs,log_cap', [('last', 512, None), ('mean', 512, None), ('last', 700, None), ('mean', 100, None), ('last', 4096, None), ('last', 512, 64),
                                              ('mean', 100, 256)])
 def test_tgn_memory_matches_oracle_review_shaped(aggr, bs, log_cap, inference):
     """Example dims (memory/time 100, msg 16) on a review-shaped stream with hubs; bs=512 is the BASELINE batch (one-launch
-    id grouping: 2*bs <= 1024), bs=700 takes the torch.sort fallback of the message store / commit.  log_cap: a tiny
+    id grouping: 2*bs <= 1024), bs=700 and bs=4096 (BASELINE cfg 4's batch) take tgmx_group_ids_large for the message store / commit.  log_cap: a tiny
     message-log capacity, so the store is compacted every few batches (the log must not grow with the events
     seen) -- results must not change and the log must stay within a small multiple of the live windows."""
     from oracle.tgn_ref import TGNMemoryRef
@@ -235,3 +235,30 @@ def test_prefetching_loader_and_edge_list_hook_yield_the_same_batches():
             assert torch.equal(bb.global_to_local(bb.edge_src), ba.global_to_local(ba.edge_src))
             n += 1
     assert n == 12
+
+
+@pytest.mark.parametrize('n', [1025, 5000, 8192, 70_000])
+def test_group_ids_large_matches_torch(n):
+    """tgmx_group_ids_large (one stable radix sort + a finishing launch: what a 4096-edge batch's message store and commit use) against
+    the torch formulation it replaces (tgm/nn/encoder/tgn.py:218-229: sort per role; :165-177: unique endpoints)."""
+    from tgm_amd import _native
+
+    lib = _native.load()
+    g = torch.Generator().manual_seed(n)
+    ids = torch.randint(0, max(n // 7, 3), (n,), generator=g, dtype=torch.int32).to(DEV)  # ~7 entries per id: every run length occurs
+    ws = torch.empty(int(lib.tgmx_group_ids_workspace_bytes(n)), dtype=torch.uint8, device=DEV)
+    srt = torch.empty(n, dtype=torch.int32, device=DEV)
+    perm, lo, hi = (torch.empty(n, dtype=torch.int64, device=DEV) for _ in range(3))
+    first = torch.empty(n, dtype=torch.uint8, device=DEV)
+    _native.check(lib.tgmx_group_ids_large(ids.data_ptr(), n, srt.data_ptr(), perm.data_ptr(), lo.data_ptr(), hi.data_ptr(), first.data_ptr(),
+                                           ws.data_ptr(), ws.numel(), _native.stream_ptr()), 'tgmx_group_ids_large')
+    ref_s, ref_p = torch.sort(ids, stable=True)
+    assert torch.equal(srt, ref_s) and torch.equal(perm, ref_p)
+    assert torch.equal(lo, torch.searchsorted(ref_s, ref_s, right=False)) and torch.equal(hi, torch.searchsorted(ref_s, ref_s, right=True))
+    ref_first = torch.ones(n, dtype=torch.uint8, device=DEV)
+    ref_first[1:] = (ref_s[1:] != ref_s[:-1]).to(torch.uint8)
+    assert torch.equal(first, ref_first)
+    # every output is optional
+    _native.check(lib.tgmx_group_ids_large(ids.data_ptr(), n, None, None, None, None, first.data_ptr(), ws.data_ptr(), ws.numel(), _native.stream_ptr()),
+                  'tgmx_group_ids_large')
+    assert torch.equal(first, ref_first)

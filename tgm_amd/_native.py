@@ -227,6 +227,8 @@ SIGNATURES['tgmx_tgn_aggregate_backward'] = (c_int32, [c_int64, _P, _P, _P, _P, 
 SIGNATURES['tgmx_tconv_edge_attr_backward'] = (c_int32, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int64, _P, _P])
 SIGNATURES['tgmx_tconv_attend_backward'] = (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, ctypes.c_float, _P, _P, _P, _P, _P, _P, _P])
 SIGNATURES['tgmx_group_ids'] = (c_int32, [_P, c_int32, _P, _P, _P, _P, _P, _P])
+SIGNATURES['tgmx_group_ids_workspace_bytes'] = (c_size_t, [c_int64])
+SIGNATURES['tgmx_group_ids_large'] = (c_int32, [_P, c_int64, _P, _P, _P, _P, _P, _P, c_size_t, _P])
 SIGNATURES['tgmx_random_negatives'] = (c_int32, [c_int32, c_int32, c_int64, ctypes.c_uint64, ctypes.c_uint64, _P, _P, c_int64, _P, _P])
 SIGNATURES['tgmx_random_negatives_at'] = (c_int32, [c_int32, c_int32, c_int64, ctypes.c_uint64, ctypes.c_uint64, c_int64, _P, _P, c_int64, _P, _P])
 SIGNATURES['tgmx_unique_ids_workspace_bytes'] = (c_size_t, [c_int32])

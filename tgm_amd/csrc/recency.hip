@@ -1906,12 +1906,12 @@ static int launch_lookup(LookupArgs a, hipStream_t stream, hipEvent_t ev_start, 
   const int gl_any = packed_group_lanes(a, a.k, true);            // narrow rows?
   const int gl = a.grp.groups == 0 ? gl_any : 64;                 // the packed kernel reads plain seed arrays only
   static const bool tile_on = !(getenv("TGMX_TILE") && atoi(getenv("TGMX_TILE")) == 0);  // A/B knob: 0 = the packed kernel
-  // A tile's phases are a chain of ~8 dependent round trips (15-20 us on an idle chip): it pays when the launch has several tiles
+  // A tile's phases are a chain of ~8 dependent round trips (15-20 us on an idle chip): it pays when the launch has at least two tiles
   // per CU to overlap them (comment shape, hop 1: 3840 tiles), not for a few hundred seeds -- measured: review shape, hop 0 (24
   // tiles) 6 -> 19 us, hop 1 (240 tiles) 17.7 -> 19.5 us; comment shape, hop 0 (192 tiles) slower too.  Small launches keep the
   // kernels that give every seed (group) a wave of its own.
   const bool tile_ok = gl_any < 64 && tile_on && a.B <= 32 && a.k <= 32 && (((uintptr_t)a.out_nid | (uintptr_t)a.out_ts) & 15) == 0 &&
-                       a.S <= (1ll << 25) && a.S >= 4ll * kWave * device_cu_count() &&
+                       a.S <= (1ll << 25) && a.S >= 2ll * kWave * device_cu_count() &&
                        (!RING || (long long)a.N * a.B * (a.D > 0 ? a.D : 1) * 4 < (1ll << 32) - 64);
   if (tile_ok) {
     // a tile of 64 seeds per wave; without riders one wave per workgroup (finest balance, every tile resident at once)

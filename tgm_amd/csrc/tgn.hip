@@ -9,6 +9,8 @@
 // row(s) it needs.  Everything is a segmented, HBM/latency-bound reduction: one wave
 // per node row, lanes across the message columns.  The dense GRU contractions reuse
 // sgemm_nt (exact-fp32 MFMA) from tgat.hip.
+#include <rocprim/device/device_radix_sort.hpp>
+
 #include "common.h"
 
 namespace tgmx {
@@ -615,6 +617,78 @@ extern "C" int tgmx_group_ids(const int32_t* ids, int32_t n, int32_t* sorted, in
   while (P < n) P <<= 1;
   hipLaunchKernelGGL(group_ids_kernel, dim3(1), dim3(P), 0, (hipStream_t)stream, ids, n, sorted, perm, run_lo, run_hi, first);
   TGMX_CHECK_LAUNCH("group_ids");
+  return TGMX_OK;
+}
+
+// ---- the same grouping for any n (a 4096-edge batch groups 8192 endpoint ids): one stable rocPRIM radix sort + a finishing launch ----
+__global__ __launch_bounds__(256) void group_ids_finish_kernel(const int32_t* __restrict__ sorted, const unsigned* __restrict__ perm32, long long n,
+                                                               int64_t* __restrict__ perm, int64_t* __restrict__ run_lo, int64_t* __restrict__ run_hi,
+                                                               uint8_t* __restrict__ first) {
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const int v = sorted[p];
+  if (perm) perm[p] = (int64_t)perm32[p];
+  if (first) first[p] = (p == 0 || sorted[p - 1] != v) ? 1 : 0;
+  if (run_lo) {  // first position holding v
+    long long lo = 0, hi = p;
+    while (lo < hi) {
+      const long long mid = (lo + hi) >> 1;
+      if (sorted[mid] < v) lo = mid + 1;
+      else hi = mid;
+    }
+    run_lo[p] = lo;
+  }
+  if (run_hi) {  // one past the last position holding v
+    long long lo = p + 1, hi = n;
+    while (lo < hi) {
+      const long long mid = (lo + hi) >> 1;
+      if (sorted[mid] <= v) lo = mid + 1;
+      else hi = mid;
+    }
+    run_hi[p] = lo;
+  }
+}
+__global__ __launch_bounds__(256) void iota_u32_kernel(unsigned* out, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (unsigned)i;
+}
+
+static size_t group_ids_sort_temp_bytes(int64_t n) {
+  size_t tb = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, tb, (const int*)nullptr, (int*)nullptr, (const unsigned*)nullptr, (unsigned*)nullptr, (size_t)n, 0u, 32u);
+  return tb;
+}
+
+extern "C" size_t tgmx_group_ids_workspace_bytes(int64_t n) {
+  if (n <= 0) return 256;
+  auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  return up((size_t)n * 4) * 3 + up(group_ids_sort_temp_bytes(n)) + 256;  // iota | perm32 | sorted (when the caller wants none) | sort temp
+}
+
+extern "C" int tgmx_group_ids_large(const int32_t* ids, int64_t n, int32_t* sorted, int64_t* perm, int64_t* run_lo, int64_t* run_hi,
+                                    uint8_t* first, void* workspace, size_t workspace_bytes, tgmx_stream_t stream) {
+  TGMX_REQUIRE(n >= 0 && n < (1ll << 31), "group_ids_large: n=%lld", (long long)n);
+  if (n == 0) return TGMX_OK;
+  TGMX_REQUIRE(ids && workspace && ((uintptr_t)workspace & 255) == 0 && workspace_bytes >= tgmx_group_ids_workspace_bytes(n),
+               "group_ids_large: null / misaligned / short workspace");
+  auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  char* base = reinterpret_cast<char*>(workspace);
+  unsigned* iota = reinterpret_cast<unsigned*>(base);
+  unsigned* perm32 = reinterpret_cast<unsigned*>(base + up((size_t)n * 4));
+  int32_t* sorted_ws = reinterpret_cast<int32_t*>(base + 2 * up((size_t)n * 4));
+  void* temp = base + 3 * up((size_t)n * 4);
+  int32_t* out_sorted = sorted ? sorted : sorted_ws;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(iota_u32_kernel, dim3(blocks), dim3(256), 0, st, iota, (long long)n);
+  size_t tb = group_ids_sort_temp_bytes(n);
+  const hipError_t err = rocprim::radix_sort_pairs(temp, tb, (const int*)ids, (int*)out_sorted, (const unsigned*)iota, perm32, (size_t)n, 0u, 32u, st);
+  if (err != hipSuccess) {
+    set_error("group_ids_large: radix sort failed: %s", hipGetErrorString(err));
+    return TGMX_E_LAUNCH;
+  }
+  hipLaunchKernelGGL(group_ids_finish_kernel, dim3(blocks), dim3(256), 0, st, out_sorted, perm32, (long long)n, perm, run_lo, run_hi, first);
+  TGMX_CHECK_LAUNCH("group_ids_large");
   return TGMX_OK;
 }
 

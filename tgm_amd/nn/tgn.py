@@ -326,10 +326,8 @@ class TGNMemory(nn.Module):
             perm, left, right = (torch.empty(n, dtype=torch.int64, device=dev) for _ in range(3))
             _native.check(lib.tgmx_group_ids(node.data_ptr(), n, node_sorted.data_ptr(), perm.data_ptr(), left.data_ptr(), right.data_ptr(),
                                              None, _native.stream_ptr()), 'tgmx_group_ids')  # fmt: skip
-        else:
-            node_sorted, perm = torch.sort(node, stable=True)
-            left = torch.searchsorted(node_sorted, node_sorted, right=False)
-            right = torch.searchsorted(node_sorted, node_sorted, right=True)
+        else:  # any n: one stable radix sort + a finishing launch (tgmx_group_ids_large), no torch ops
+            node_sorted, perm, left, right, _ = self._group_large(node, want_first=False)
         _native.check(
             lib.tgmx_tgn_store(perm.data_ptr(), node_sorted.data_ptr(), left.data_ptr(), right.data_ptr(), other.data_ptr(), t.data_ptr(),
                                _native.ptr(raw), self.raw_msg_dim, n, self._log_len, self._log_other.data_ptr(), self._log_t.data_ptr(),
@@ -337,6 +335,27 @@ class TGNMemory(nn.Module):
             'tgmx_tgn_store',
         )  # fmt: skip
         self._log_len += n
+
+    def _group_large(self, ids: Tensor, want_first: bool):
+        """(sorted ids, perm, run_lo, run_hi, first-of-run) of more than 1024 int32 ids on our kernels (tgn.py:218-229 sorts per role;
+        :165-177 takes the unique endpoints): what torch.sort(stable=True) + 2 x searchsorted / a neighbour compare produced."""
+        lib = _native.load()
+        n = ids.numel()
+        dev = ids.device
+        need = int(lib.tgmx_group_ids_workspace_bytes(n))
+        ws = getattr(self, '_group_ws', None)
+        if ws is None or ws.numel() < need or ws.device != dev:
+            ws = self._group_ws = torch.empty(max(need, 1 << 16), dtype=torch.uint8, device=dev)
+        srt = torch.empty(n, dtype=torch.int32, device=dev)
+        if want_first:
+            first = torch.empty(n, dtype=torch.uint8, device=dev)
+            perm = left = right = None
+        else:
+            first = None
+            perm, left, right = (torch.empty(n, dtype=torch.int64, device=dev) for _ in range(3))
+        _native.check(lib.tgmx_group_ids_large(ids.data_ptr(), n, srt.data_ptr(), _native.ptr(perm), _native.ptr(left), _native.ptr(right),
+                                               _native.ptr(first), ws.data_ptr(), ws.numel(), _native.stream_ptr()), 'tgmx_group_ids_large')  # fmt: skip
+        return srt, perm, left, right, first
 
     # -- reference protocol -------------------------------------------------------
     def forward(self, n_id: Tensor) -> Tuple[Tensor, Tensor]:
@@ -380,9 +399,7 @@ class TGNMemory(nn.Module):
             _native.check(_native.load().tgmx_group_ids(both.data_ptr(), both.numel(), srt.data_ptr(), None, None, None, first.data_ptr(),
                                                         _native.stream_ptr()), 'tgmx_group_ids')  # fmt: skip
         else:
-            srt, _ = torch.sort(both)
-            first = torch.ones(srt.numel(), dtype=torch.uint8, device=srt.device)
-            first[1:] = (srt[1:] != srt[:-1]).to(torch.uint8)
+            srt, _, _, _, first = self._group_large(both, want_first=True)
         if self.training:
             self._commit(srt, first)
             self._store_batch(src32, dst32, t, raw)

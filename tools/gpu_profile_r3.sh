@@ -2,13 +2,15 @@
 # Round-3 profiles of a bench.py command on the GPU box: kernel trace + FETCH_SIZE / WRITE_SIZE counters, both restricted to the
 # launches bench.py TIMES (the last <steps> dispatches of the dominant kernel: --no-default-path keeps them last).
 #   tools/gpu_profile_r3.sh <tag> <kernel substring> <steps> [bench.py args ...]
-# writes profiles/r03_<tag>_rocprof_summary.md and profiles/r03_<tag>_pmc.json (counters in separate passes, never with a trace)
+# writes gpurun_out/profiles_r03/r03_<tag>_rocprof_summary.md and r03_<tag>_pmc.json (counters in separate passes, never with a trace);
+# copy them into profiles/ afterwards (only gpurun_out/ travels back from the GPU box)
 set -u
 cd "$(dirname "$0")/.."
 ROOT=$PWD
 TAG=$1; KERN=$2; STEPS=$3; shift 3
 OUT=$ROOT/gpurun_out/prof_r03_$TAG
-rm -rf "$OUT"; mkdir -p "$OUT" profiles
+PROF=$ROOT/gpurun_out/profiles_r03
+rm -rf "$OUT"; mkdir -p "$OUT" "$PROF"
 export TMPDIR=/tmp
 ARGS="--cpu-batches 0 --no-default-path --steps $STEPS $*"
 (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -- python "$ROOT/bench.py" $ARGS) > "$OUT/trace.log" 2>&1
@@ -20,14 +22,14 @@ grep '^{' "$OUT/trace.log" | tail -1 > "$OUT/bench_under_trace.json"
   echo '| what | avg | min | max |'
   echo '|---|---|---|---|'
   python tools/prof_summary.py tail "$OUT/trace" --kernel "$KERN" --last "$STEPS"
-} > "profiles/r03_${TAG}_rocprof_summary.md"
+} > "$PROF/r03_${TAG}_rocprof_summary.md"
 for C in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && timeout -k 10 300 rocprofv3 --pmc $C -d "$OUT/pmc_$C" -- python "$ROOT/bench.py" $ARGS) > "$OUT/pmc_$C.log" 2>&1
   python tools/prof_summary.py pmctail "$OUT/pmc_$C" --kernel "$KERN" --last "$STEPS" > "$OUT/pmc_$C.json" 2>>"$OUT/pmc_$C.log" || echo '{}' > "$OUT/pmc_$C.json"
 done
-python - "$OUT" "$TAG" "$KERN" "$STEPS" "$ARGS" <<'PY'
+python - "$OUT" "$TAG" "$KERN" "$STEPS" "$ARGS" "$PROF" <<'PY'
 import json, sys
-out, tag, kern, steps, args = sys.argv[1:6]
+out, tag, kern, steps, args, prof = sys.argv[1:7]
 f = json.load(open(f'{out}/pmc_FETCH_SIZE.json')); w = json.load(open(f'{out}/pmc_WRITE_SIZE.json'))
 bench = {}
 try:
@@ -42,8 +44,8 @@ res = {'bench_args': args, 'kernel': kern, 'dispatches_counted': f.get('dispatch
 r = bench.get('roofline') or {}
 res['algorithmic_bytes_per_launch_under_trace'] = r.get('algorithmic_bytes_per_launch')
 res['profile_key'] = (bench.get('config') or {}).get('profile_key')
-json.dump(res, open(f'profiles/r03_{tag}_pmc.json', 'w'), indent=1)
+json.dump(res, open(f'{prof}/r03_{tag}_pmc.json', 'w'), indent=1)
 print(json.dumps(res))
 PY
-cat "profiles/r03_${TAG}_rocprof_summary.md" | tail -6
+cat "$PROF/r03_${TAG}_rocprof_summary.md" | tail -6
 rm -rf "$OUT/trace" "$OUT"/pmc_FETCH_SIZE "$OUT"/pmc_WRITE_SIZE
