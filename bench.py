@@ -72,7 +72,7 @@ def parse_args():
 DEFAULTS = {'wiki': (200, [20, 20]), 'review': (512, [10, 10]), 'comment': (4096, [20, 20])}
 
 
-def build_pipeline(stream, rank, world, global_bs, num_nbrs, mode, device, pool=0, validate='deferred'):
+def build_pipeline(stream, rank, world, global_bs, num_nbrs, mode, device, pool=0, validate='deferred', edge_features='dense'):
     from tgm_amd import DGData, DGDataLoader, DGraph
     from tgm_amd.dist import EdgeShardHook
     from tgm_amd.hooks import HookManager, RandomNegativeEdgeSamplerHook, RecencyNeighborHook
@@ -89,6 +89,8 @@ def build_pipeline(stream, rank, world, global_bs, num_nbrs, mode, device, pool=
         keys, tkeys = ['edge_src', 'edge_dst', 'neg'], ['edge_time', 'edge_time', 'neg_time']
         hm.register('bench', RandomNegativeEdgeSamplerHook(lo_dst, stream.num_nodes))
     kw = {} if validate is None else {'validate': validate}  # None: the hook's own default ('sync', the reference's raise-per-call)
+    if edge_features != 'dense':
+        kw['edge_features'] = edge_features
     hook = RecencyNeighborHook(stream.num_nodes, num_nbrs, keys, tkeys, mode=mode, batch_size=global_bs if mode == 'csr' else None, **kw)
     hm.register('bench', hook)
     if pool is None:  # the loader's own default: what an unmodified TGM script gets

@@ -227,6 +227,11 @@ typedef struct tgmx_recency_step {
    * (a copy of edge_x[adj[p].eid] made once at index build) -- so a node's window of B records gathers B consecutive rows instead
    * of B rows scattered by edge id.  0: `ring_x` is edge_x[E, D], addressed by eid. */
   int32_t csr_x_by_pos;
+  /* ABI v4, optional per hop: [S_h, k_h] int32, the EDGE ID behind every output slot (-1 for a pad slot; -1 everywhere for batches
+   * whose edges carry no store ids, eid0 < 0).  With out_eid[h] set, out_x[h] may be NULL: the feature rows are then not copied at all
+   * -- a consumer that holds the resident store (tgmx_tgat_forward: tgmx_tgat_hop_t.nbr_eid) gathers them by id where it uses them,
+   * which removes the copy's writes and the consumer's re-read of them (177 of the 244 MB of a wiki-shaped batch). */
+  int32_t* out_eid[TGMX_MAX_HOPS];
 } tgmx_recency_step_t;
 
 int tgmx_recency_step(const tgmx_recency_step_t* step, tgmx_stream_t stream);
@@ -280,6 +285,7 @@ typedef struct tgmx_pipeline_out {
   tgmx_event_t ev_start, ev_stop;
   int32_t* out_valid[TGMX_MAX_HOPS]; /* optional: tgmx_recency_step_t.out_valid of this output set (delta feature writes) */
   int32_t* out_valid_prev[TGMX_MAX_HOPS]; /* optional: tgmx_recency_step_t.out_valid_prev */
+  int32_t* out_eid[TGMX_MAX_HOPS];   /* optional: tgmx_recency_step_t.out_eid (out_x[h] may then be NULL) */
 } tgmx_pipeline_out_t;
 
 /* Optional tail of the chain, for the TGN loop: DeduplicationHook (tgm/hooks/dedup.py:35-67) over [batch src | batch dst |
@@ -455,8 +461,14 @@ typedef struct tgmx_tgat_hop {
   const int64_t* seed_t; /* [rows_i]        seed_times[i]    */
   const int32_t* nbr_id; /* [rows_i, k]     nbr_nids[i]      */
   const int64_t* nbr_t;  /* [rows_i, k]     nbr_edge_time[i] */
-  const float* edge_x;   /* [rows_i, k, D]  nbr_edge_x[i]    */
+  const float* edge_x;   /* [rows_i, k, D]  nbr_edge_x[i]; NULL with nbr_eid set */
   int32_t k;
+  /* ABI v4: edge features by id.  With edge_x == NULL and nbr_eid / edge_table set, slot (r, s) reads edge_table[nbr_eid[r, s]]
+   * ([E, D] rows of the resident store; -1: a pad slot, zeros) where the attention consumes it -- the sampler then never writes
+   * the dense [rows, k, D] copy (tgmx_recency_step_t.out_eid) and the attention never re-reads it.  Inference (save = 0) with the
+   * register-resident attention kernel (n_heads <= 2, k <= 20, D a multiple of 4); otherwise TGMX_E_UNSUPPORTED: gather the rows first. */
+  const int32_t* nbr_eid;  /* [rows_i, k] */
+  const float* edge_table; /* [E, D] */
 } tgmx_tgat_hop_t;
 /* Where tgmx_tgat_forward keeps its intermediates (offsets in floats from the 256-byte aligned
  * workspace base; -1 = not kept).  Row strides: rres/oattn/y Op, Q H*dhp, qf/zbar H*Cp, cat Kc, h1 Ep,

@@ -249,3 +249,51 @@ def test_tgat_fused_inference_paths_vs_oracle(nd, ed, td, emb, H, ks, S0, L):
     with torch.no_grad():  # the inference path: folded queries, one-kernel tail
         close(enc(*args), z_ref, f'inference nd={nd} H={H} ks={ks}')
     close(enc(*args), z_ref, f'grad-enabled (saving) forward nd={nd} H={H} ks={ks}')
+
+
+@pytest.mark.parametrize('mode', ['ring', 'csr'])
+@pytest.mark.parametrize('pool', [None, 0])
+def test_edge_features_by_id_match_the_dense_copies(mode, pool):
+    """RecencyNeighborHook(edge_features='by_id'): the sampler publishes the edge id behind every slot instead of copying its
+    feature row, and TGAT's attention reads the rows of the resident store where it consumes them.  Same ids / times as the dense
+    sampler, the lazily gathered rows equal the dense copies bit for bit, and the embeddings are bit-identical (the kernel does
+    the same arithmetic on the same values) -- through the lowered chain and hook by hook, streaming rings and static index,
+    at the headline model dims; a 4-head model (which the by-id attention kernel does not cover) falls back to gathering."""
+    from tgm_amd import DGData, DGDataLoader, DGraph
+    from tgm_amd.core import EdgeFeaturesById
+    from tgm_amd.hooks import HookManager, RandomNegativeEdgeSamplerHook, RecencyNeighborHook
+    from tgm_amd.nn import TGAT
+    from tgm_amd.synth import make_stream
+
+    st = make_stream('wiki', seed=3, num_edges=6000, edge_dim=172)
+    dg = DGraph(DGData.from_raw(st.ts, torch.stack([st.src, st.dst], 1), st.edge_x, static_node_x=st.node_x), device=DEV)
+
+    def chain(features):
+        hm = HookManager(keys=['k'])
+        hm.register('k', RandomNegativeEdgeSamplerHook(int(st.dst.min()), st.num_nodes, seed=4))
+        hm.register('k', RecencyNeighborHook(st.num_nodes, [20, 20], ['edge_src', 'edge_dst', 'neg'], ['edge_time', 'edge_time', 'neg_time'], mode=mode,
+                                             validate='deferred', batch_size=200 if mode == 'csr' else None, edge_features=features))
+        return hm, DGDataLoader(dg, batch_size=200, hook_manager=hm, output_pool=pool)
+
+    hm_a, dense = chain('dense')
+    hm_b, lazy = chain('by_id')
+    torch.manual_seed(0)
+    enc = TGAT(node_dim=1, edge_dim=172, time_dim=100, embed_dim=172, num_layers=2).to(DEV).eval()
+    enc4 = TGAT(node_dim=1, edge_dim=172, time_dim=100, embed_dim=172, num_layers=2, n_heads=4).to(DEV).eval()
+    node_x = dg.static_node_x
+    with hm_a.activate('k'), hm_b.activate('k'), torch.no_grad():
+        for n, (a, b) in enumerate(zip(dense, lazy)):
+            assert isinstance(b.nbr_edge_x, EdgeFeaturesById) and len(b.nbr_edge_x) == 2
+            for h in range(2):
+                assert torch.equal(a.nbr_nids[h], b.nbr_nids[h]) and torch.equal(a.nbr_edge_time[h], b.nbr_edge_time[h])
+            if n % 5 == 4:
+                za = enc(node_x, a.seed_nids, a.seed_times, a.nbr_nids, a.nbr_edge_x, a.nbr_edge_time)
+                zb = enc(node_x, b.seed_nids, b.seed_times, b.nbr_nids, b.nbr_edge_x, b.nbr_edge_time)
+                assert all(x is None for x in list.__iter__(b.nbr_edge_x)), 'TGAT materialized the feature rows'
+                assert torch.equal(za, zb), f'batch {n}: embeddings differ'
+                z4a = enc4(node_x, a.seed_nids, a.seed_times, a.nbr_nids, a.nbr_edge_x, a.nbr_edge_time)
+                z4b = enc4(node_x, b.seed_nids, b.seed_times, b.nbr_nids, b.nbr_edge_x, b.nbr_edge_time)  # falls back: gathers
+                assert torch.equal(z4a, z4b)
+                for h in range(2):
+                    assert torch.equal(a.nbr_edge_x[h], b.nbr_edge_x[h]), f'batch {n} hop {h}: gathered rows differ from the copies'
+        assert n == 29

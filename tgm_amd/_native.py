@@ -85,6 +85,7 @@ SIGNATURES = {
 }
 
 TGAT_MAX_LAYERS = 4
+E_UNSUPPORTED = -3  # TGMX_E_UNSUPPORTED
 
 
 class Dropout(ctypes.Structure):
@@ -113,7 +114,7 @@ class TgatModel(ctypes.Structure):
 
 
 class TgatHop(ctypes.Structure):
-    _fields_ = [('seed_t', c_void_p), ('nbr_id', c_void_p), ('nbr_t', c_void_p), ('edge_x', c_void_p), ('k', c_int32)]
+    _fields_ = [('seed_t', c_void_p), ('nbr_id', c_void_p), ('nbr_t', c_void_p), ('edge_x', c_void_p), ('k', c_int32), ('nbr_eid', c_void_p), ('edge_table', c_void_p)]
 
 
 class TgatLayerLayout(ctypes.Structure):
@@ -152,7 +153,7 @@ class RecencyStep(ctypes.Structure):
         ('neg_seed', ctypes.c_uint64), ('neg_call', ctypes.c_uint64), ('neg_out', c_void_p), ('neg_time_out', c_void_p),
         ('guard_seed_errors', c_int32), ('sorted_ts', c_int32),
         ('out_valid', c_void_p * MAX_HOPS), ('out_valid_prev', c_void_p * MAX_HOPS),
-        ('neg_index0', c_int64), ('csr_cursor', c_void_p), ('csr_x_by_pos', c_int32),
+        ('neg_index0', c_int64), ('csr_cursor', c_void_p), ('csr_x_by_pos', c_int32), ('out_eid', c_void_p * MAX_HOPS),
     ]  # fmt: skip
 
 
@@ -213,7 +214,7 @@ class PipelineOut(ctypes.Structure):
         ('neg', c_void_p), ('neg_time', c_void_p), ('seed_nid0', c_void_p), ('seed_ts0', c_void_p),
         ('out_nid', c_void_p * MAX_HOPS), ('out_ts', c_void_p * MAX_HOPS), ('out_x', c_void_p * MAX_HOPS),
         ('timed_hop', c_int32), ('ev_start', c_void_p), ('ev_stop', c_void_p),
-        ('out_valid', c_void_p * MAX_HOPS), ('out_valid_prev', c_void_p * MAX_HOPS),
+        ('out_valid', c_void_p * MAX_HOPS), ('out_valid_prev', c_void_p * MAX_HOPS), ('out_eid', c_void_p * MAX_HOPS),
     ]  # fmt: skip
 
 

@@ -86,6 +86,7 @@ extern "C" int tgmx_pipeline_step(const tgmx_pipeline_t* p, int64_t edge_lo, int
     s.out_x[h] = out->out_x[h];
     s.out_valid[h] = out->out_valid[h];
     s.out_valid_prev[h] = out->out_valid_prev[h];
+    s.out_eid[h] = out->out_eid[h];
   }
   s.timed_hop = out->timed_hop;
   s.ev_start = out->ev_start;

@@ -82,6 +82,8 @@ struct LookupArgs {
   int row_vecs;  // D / VEC
   FastDiv dv;    // division by row_vecs
   FastDiv dv_seed;  // division by k * row_vecs (tile kernel: flat piece index -> seed of the tile)
+  int32_t* out_eid;   // optional [S, k]: the edge id behind every output slot (-1: pad) -- with out_x == NULL the features are not
+  int32_t* out_eid1;  //   copied at all and the consumer gathers them from the resident store by id (fused launch: hop 1's)
   int x_by_pos;       // static index: feature rows are stored in ADJACENCY order (row = record position), not addressed by eid
   long long* cursor;  // static index, optional: per node, where its visible prefix ended the last time it was looked up (a hint)
   int leave_room;   // tile kernel: other launches must fit beside this one (the large ring update's chain on the side stream)
@@ -1097,7 +1099,7 @@ __device__ __forceinline__ long long slot_of(const Window& w, int B, int i) {
 // feature row it gathers from (ring slot / edge id; -1 for a pad)
 struct SmallPick {
   bool has;
-  int nbr, src;
+  int nbr, src, eid;
   long long ts;
 };
 
@@ -1115,6 +1117,7 @@ __device__ __forceinline__ SmallPick small_pick(const LookupArgs& a, int n, long
     if (lane >= B) from_slot = lane;
     r.nbr = __shfl(r.nbr, from_slot);
     r.ts = __shfl(r.ts, from_slot);
+    if (a.out_eid || a.out_eid1) r.eid = __shfl(r.eid, from_slot);  // (only a caller that asked for edge ids reads it: wave-uniform)
   } else if (lane < w.wlen) {
     r = a.recs[slot_of<RING>(w, B, lane)];
   }
@@ -1131,6 +1134,7 @@ __device__ __forceinline__ SmallPick small_pick(const LookupArgs& a, int n, long
   o.nbr = o.has ? g_nbr : -1;
   o.ts = o.has ? g_ts : 0;
   o.src = o.has ? ((RING || a.x_by_pos) ? (int)slot_of<RING>(w, B, from) : g_eid) : -1;
+  o.eid = o.has ? g_eid : -1;
   return o;
 }
 
@@ -1166,7 +1170,8 @@ __device__ __forceinline__ void gather_rows(const LookupArgs& a, long long s, in
 // the k most recent neighbors of (n, q) into row s of (out_nid, out_ts, out_x)
 template <bool RING, int VEC, bool SMALL>
 __device__ __forceinline__ void lookup_seed(const LookupArgs& a, long long s, int n, long long q, int k, int lane, int* lds_eid,
-                                            int32_t* out_nid, int64_t* out_ts, float* out_x, int32_t* out_valid, int32_t* out_valid_prev) {
+                                            int32_t* out_nid, int64_t* out_ts, float* out_x, int32_t* out_valid, int32_t* out_valid_prev,
+                                            int32_t* out_eid = nullptr) {
   const bool live = n >= 0 && n < a.N;
   // the row's SPAN: slots from its leftmost non-pad one to the end (0: all pads).  Valid slots sit at the right end of a row, but a
   // ring can hold a pad record between real ones (the oracle's lookup keeps it: an interior -1), so it is the leftmost
@@ -1177,6 +1182,7 @@ __device__ __forceinline__ void lookup_seed(const LookupArgs& a, long long s, in
     if (lane < k) {
       out_nid[s * k + lane] = o.nbr;
       out_ts[s * k + lane] = o.ts;
+      if (out_eid) out_eid[s * k + lane] = o.eid;
       lds_eid[lane] = o.src;
     }
     const unsigned long long m = __ballot(lane < k && o.has);
@@ -1204,6 +1210,7 @@ __device__ __forceinline__ void lookup_seed(const LookupArgs& a, long long s, in
       const bool has = r.nbr >= 0;
       out_nid[s * k + c] = has ? r.nbr : -1;
       out_ts[s * k + c] = has ? r.ts : 0;
+      if (out_eid) out_eid[s * k + c] = has ? r.eid : -1;
       lds_eid[c] = has ? ((RING || a.x_by_pos) ? (int)slot_of<RING>(w, B, i) : r.eid) : -1;
       if (has && k - c > v_new) v_new = k - c;
     }
@@ -1212,7 +1219,7 @@ __device__ __forceinline__ void lookup_seed(const LookupArgs& a, long long s, in
       v_new = other > v_new ? other : v_new;
     }
   }
-  if (a.D == 0) return;
+  if (a.D == 0 || out_x == nullptr) return;  // no features, or the consumer gathers them by edge id (out_eid)
   int first_slot = 0;
   if (out_valid) {  // the row's previous contents are known: leave the zeros left of both valid tails alone
     const int v_old = out_valid[s];
@@ -1253,7 +1260,7 @@ __global__ __launch_bounds__(256) void recency_lookup_kernel(const LookupArgs a,
     long long q;
     fetch_seed(a, s, lane, true, n, q);
     check_seed(a, n, q, a.allow_pad, lane);
-    lookup_seed<RING, VEC, SMALL>(a, s, n, q, a.k, lane, lds_eid, a.out_nid, a.out_ts, a.out_x, a.out_valid, a.out_valid_prev);
+    lookup_seed<RING, VEC, SMALL>(a, s, n, q, a.k, lane, lds_eid, a.out_nid, a.out_ts, a.out_x, a.out_valid, a.out_valid_prev, a.out_eid);
   }
   if constexpr (RING && RIDE) {
     if (a.tail_blocks) tail_signal(u.barrier, false, bid, nblk);
@@ -1295,7 +1302,7 @@ __global__ __launch_bounds__(256) void recency_lookup_fused01_kernel(const Looku
     if (w < S0) {
       fetch_seed(a, w, lane, true, n, q);
       check_seed(a, n, q, 0, lane);
-      lookup_seed<RING, VEC, true>(a, w, n, q, k0, lane, lds_eid, a.out_nid, a.out_ts, a.out_x, a.out_valid, a.out_valid_prev);
+      lookup_seed<RING, VEC, true>(a, w, n, q, k0, lane, lds_eid, a.out_nid, a.out_ts, a.out_x, a.out_valid, a.out_valid_prev, a.out_eid);
     } else {
       const long long idx = w - S0;
       const long long s0 = idx / k0;
@@ -1306,7 +1313,7 @@ __global__ __launch_bounds__(256) void recency_lookup_fused01_kernel(const Looku
       const SmallPick o = small_pick<RING>(a, n0, q0, k0, n0 >= 0 && n0 < a.N, lane);
       n = __shfl(o.nbr, j);
       q = __shfl(o.ts, j);
-      lookup_seed<RING, VEC, true>(a, idx, n, q, k1, lane, lds_eid, a.out_nid1, a.out_ts1, a.out_x1, a.out_valid1, a.out_valid_prev1);
+      lookup_seed<RING, VEC, true>(a, idx, n, q, k1, lane, lds_eid, a.out_nid1, a.out_ts1, a.out_x1, a.out_valid1, a.out_valid_prev1, a.out_eid1);
     }
   }
   if constexpr (RING) {
@@ -1903,7 +1910,7 @@ static int launch_lookup(LookupArgs a, hipStream_t stream, hipEvent_t ev_start, 
     else TGMX_LAUNCH_TIMED((recency_lookup_kernel<RING, VEC_, SMALL_, false>), grid, block, lds, stream, ev_start, ev_stop, a, u);     \
   } while (0)
   // narrow rows: several seeds per wave (streaming rings, plain seed arrays)
-  const int gl_any = packed_group_lanes(a, a.k, true);            // narrow rows?
+  const int gl_any = a.out_eid ? 64 : packed_group_lanes(a, a.k, true);  // narrow rows?  (edge ids are written by the wave-per-seed kernels only)
   const int gl = a.grp.groups == 0 ? gl_any : 64;                 // the packed kernel reads plain seed arrays only
   static const bool tile_on = !(getenv("TGMX_TILE") && atoi(getenv("TGMX_TILE")) == 0);  // A/B knob: 0 = the packed kernel
   // A tile's phases are a chain of ~8 dependent round trips (15-20 us on an idle chip): it pays when the launch has at least two tiles
@@ -2847,7 +2854,7 @@ extern "C" int tgmx_recency_step(const tgmx_recency_step_t* s, tgmx_stream_t str
     const int k0 = s->k[0], k1 = s->k[1];
     TGMX_REQUIRE(s->B >= k0 && s->B >= k1, "recency_step: k=[%d, %d] but B=%d", k0, k1, s->B);
     TGMX_REQUIRE(cur_n && cur_t && s->out_nid[0] && s->out_ts[0] && s->out_nid[1] && s->out_ts[1] &&
-                     (s->D == 0 || (s->ring_x && s->out_x[0] && s->out_x[1])), "recency_step: null pointer at hop 0 / 1");
+                     (s->D == 0 || (s->ring_x && (s->out_x[0] || s->out_eid[0]) && (s->out_x[1] || s->out_eid[1]))), "recency_step: null pointer at hop 0 / 1");
     LookupArgs a{};
     a.grp = grp;
     a.indptr = s->indptr; a.recs = reinterpret_cast<const Rec*>(s->ring); a.write_pos = s->write_pos; a.edge_x = s->ring_x;
@@ -2855,6 +2862,7 @@ extern "C" int tgmx_recency_step(const tgmx_recency_step_t* s, tgmx_stream_t str
     a.k1 = k1; a.out_nid1 = s->out_nid[1]; a.out_ts1 = s->out_ts[1]; a.out_x1 = s->out_x[1];
     a.out_valid = s->out_valid[0]; a.out_valid1 = s->out_valid[1];
     a.out_valid_prev = s->out_valid_prev[0]; a.out_valid_prev1 = s->out_valid_prev[1];
+    a.out_eid = s->out_eid[0]; a.out_eid1 = s->out_eid[1];
     a.status = s->status; a.S = S; a.D = s->D; a.k = k0; a.B = s->B; a.N = s->num_nodes; a.allow_pad = 0;
     a.ev_lo = s->ev_lo; a.ev_hi = s->ev_hi;
     a.x_by_pos = csr && s->csr_x_by_pos;
@@ -2874,13 +2882,14 @@ extern "C" int tgmx_recency_step(const tgmx_recency_step_t* s, tgmx_stream_t str
   for (; h < s->n_hops && S > 0; ++h) {
     const int k = s->k[h];
     TGMX_REQUIRE(k > 0 && s->B >= k, "recency_step: hop %d has k=%d, B=%d", h, k, s->B);
-    TGMX_REQUIRE(cur_n && cur_t && s->out_nid[h] && s->out_ts[h] && (s->D == 0 || (s->ring_x && s->out_x[h])),
+    TGMX_REQUIRE(cur_n && cur_t && s->out_nid[h] && s->out_ts[h] && (s->D == 0 || (s->ring_x && (s->out_x[h] || s->out_eid[h]))),
                  "recency_step: null pointer at hop %d", h);
     LookupArgs a{};
     if (h == 0) a.grp = grp;
     a.indptr = s->indptr; a.recs = reinterpret_cast<const Rec*>(s->ring); a.write_pos = s->write_pos; a.edge_x = s->ring_x;
     a.seeds = cur_n; a.qtimes = cur_t; a.out_nid = s->out_nid[h]; a.out_ts = s->out_ts[h]; a.out_x = s->out_x[h];
     a.out_valid = s->out_valid[h]; a.out_valid_prev = s->out_valid_prev[h];
+    a.out_eid = s->out_eid[h];
     a.status = s->status; a.S = S; a.D = s->D; a.k = k; a.B = s->B; a.N = s->num_nodes; a.allow_pad = h > 0;
     a.ev_lo = s->ev_lo; a.ev_hi = s->ev_hi;
     a.cursor = csr ? reinterpret_cast<long long*>(s->csr_cursor) : nullptr;

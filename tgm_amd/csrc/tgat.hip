@@ -1006,6 +1006,9 @@ struct AttnArgs {
   long long seg_begin[TGMX_TGAT_MAX_LAYERS];
   const float* seg_nbrf[TGMX_TGAT_MAX_LAYERS];
   const float* seg_ex[TGMX_TGAT_MAX_LAYERS];
+  // edge features by id (tgmx_tgat_hop_t.nbr_eid): slot (r, s) reads seg_table[i][eid] instead of seg_ex[i][r, s] (register kernel only)
+  const int32_t* seg_eid[TGMX_TGAT_MAX_LAYERS];
+  const float* seg_table[TGMX_TGAT_MAX_LAYERS];
   const int64_t* seg_seed_t[TGMX_TGAT_MAX_LAYERS];
   const int64_t* seg_nbr_t[TGMX_TGAT_MAX_LAYERS];
   const int32_t* seg_nbr_id[TGMX_TGAT_MAX_LAYERS];
@@ -1013,6 +1016,8 @@ struct AttnArgs {
 
 // the level (segment) of row r: wave-uniform, so this is scalar code
 struct AttnLevel {
+  const int32_t* eid = nullptr;
+  const float* table = nullptr;
   const float* nbrf;
   const float* ex;
   const int64_t* seed_t;
@@ -1020,13 +1025,16 @@ struct AttnLevel {
   const int32_t* nbr_id;
 };
 __device__ __forceinline__ AttnLevel attn_level(const AttnArgs& a, long long r) {
-  AttnLevel v{a.nbrf, a.ex, a.seed_t, a.nbr_t, a.nbr_id};
+  AttnLevel v;
+  v.nbrf = a.nbrf; v.ex = a.ex; v.seed_t = a.seed_t; v.nbr_t = a.nbr_t; v.nbr_id = a.nbr_id;
+  v.eid = a.seg_eid[0]; v.table = a.seg_table[0];
   if (a.n_seg > 1) {
     int si = 0;
 #pragma unroll
     for (int i = 1; i < TGMX_TGAT_MAX_LAYERS; ++i)
       if (i < a.n_seg && r >= a.seg_begin[i]) si = i;
     v.nbrf = a.seg_nbrf[si]; v.ex = a.seg_ex[si]; v.seed_t = a.seg_seed_t[si]; v.nbr_t = a.seg_nbr_t[si]; v.nbr_id = a.seg_nbr_id[si];
+    v.eid = a.seg_eid[si]; v.table = a.seg_table[si];
   }
   return v;
 }
@@ -1244,10 +1252,13 @@ __global__ __launch_bounds__(256) void tgat_attn_reduce_reg_kernel(const AttnArg
   // slot metadata: lane s holds slot s
   float my_dt = 0.f;
   bool my_ok = false;
+  int my_eid = -1;  // edge features by id: lane s holds slot s's edge id
   if (lane < k) {
     my_dt = (float)(lv.seed_t[r] - lv.nbr_t[r * k + lane]);  // int64 subtract, then round-to-nearest f32
     my_ok = a.mask ? a.mask[r * k + lane] != 0 : lv.nbr_id[r * k + lane] != -1;
+    if (lv.eid) my_eid = lv.eid[r * k + lane];
   }
+  const float4* __restrict__ table4 = reinterpret_cast<const float4*>(lv.table);
 
   // The sampler's all-pad row (every seed that is itself a pad slot of the hop above: ~1/3 of the layer-1 rows at the
   // headline shape): no valid slot, so the reference attends uniformly (attention.py:114-118) over k slots that are all
@@ -1276,7 +1287,7 @@ __global__ __launch_bounds__(256) void tgat_attn_reduce_reg_kernel(const AttnArg
       const bool t0 = lane < T, t1 = lane + kWave < T;
       const float c0 = cos_t2v(__fmaf_rn(dt0, t0 ? a.tw[lane] : 0.f, t0 ? a.tb[lane] : 0.f));
       const float c1 = cos_t2v(__fmaf_rn(dt0, t1 ? a.tw[lane + kWave] : 0.f, t1 ? a.tb[lane + kWave] : 0.f));
-      const float4 e = e_on ? ex4[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 e = (e_on && !lv.eid) ? ex4[lane] : make_float4(0.f, 0.f, 0.f, 0.f);  // (by id: an all-pad row's slots have no edge)
       float* __restrict__ zb0 = a.zbar + r * (long long)H * a.Cs;
 #pragma unroll
       for (int h = 0; h < H; ++h) {
@@ -1303,7 +1314,12 @@ __global__ __launch_bounds__(256) void tgat_attn_reduce_reg_kernel(const AttnArg
 #pragma unroll
   for (int s = 0; s < G; ++s) {
     const int sl = s < k ? s : k - 1;
-    ze[s] = e_on ? ex4[sl * D4 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lv.eid) {  // wave-uniform: the slot's row of the resident store (scalar base + lane offset), zeros for a pad slot
+      const int e = __builtin_amdgcn_readlane(my_eid, sl);
+      ze[s] = (e_on && e >= 0) ? table4[(long long)e * D4 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+      ze[s] = e_on ? ex4[sl * D4 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   }
   float4 zn[NBV ? G : 1];
   float zs[NBV ? 1 : G];
@@ -1630,6 +1646,11 @@ static int attn_reduce_impl(const AttnArgs& a, int H, hipStream_t st) {
     TGMX_CHECK_LAUNCH("tgat_attn_reduce(reg)");
     return TGMX_OK;
   }
+  for (int i = 0; i < TGMX_TGAT_MAX_LAYERS; ++i)
+    if (a.seg_eid[i]) {  // only the register kernel gathers edge features by id
+      set_error("tgat_attn_reduce: edge features by id need the register-resident kernel (n_heads <= 2, k <= 20, D %% 4 == 0)");
+      return TGMX_E_UNSUPPORTED;
+    }
   // slots per score group: the smallest instantiated G >= min(k, 64 / H)
   const int want = k < 64 / H ? k : 64 / H;
 #define TGMX_ATTN(H_, G_) launch_attn<H_, G_>(grid, block, lds, st, a)
@@ -1966,6 +1987,7 @@ extern "C" int tgmx_tgat_forward(const tgmx_tgat_model_t* m, const float* node_x
     {
       // every level this layer aggregates, in ONE launch (same weights, same k; qf / zbar / probs are contiguous)
       AttnArgs a{};
+      bool any_by_id = false;
       a.qf = qf; a.zbar = zbar; a.probs = probs; a.R = off[n_lvl];
       a.tw = m->tw; a.tb = m->tb;
       a.d = ly.d; a.D = ly.D; a.T = ly.T; a.k = k; a.C = C; a.scale = 1.0f / sqrtf((float)dh); a.Cs = Cp;
@@ -1973,11 +1995,22 @@ extern "C" int tgmx_tgat_forward(const tgmx_tgat_model_t* m, const float* node_x
       if (save && m->drop.p > 0.f) a.drop = make_dropout(m->drop.p, m->drop.seed, m->drop.stream * 64 + 2 * (unsigned long long)j);
       for (int i = 0; i < n_lvl; ++i) {
         TGMX_REQUIRE(hops[i].k == k, "tgat_forward: layer %d needs the same k at every hop it aggregates", j);
-        TGMX_REQUIRE(rows[i] == 0 || ly.D == 0 || hops[i].edge_x, "tgat_forward: hop %d has no edge features", i);
+        TGMX_REQUIRE(rows[i] == 0 || ly.D == 0 || hops[i].edge_x || (hops[i].nbr_eid && hops[i].edge_table), "tgat_forward: hop %d has no edge features", i);
+        const bool by_id = !hops[i].edge_x && hops[i].nbr_eid && ly.D > 0;
+        const bool reg_kernel = H <= 2 && k <= 20 && ly.D % 4 == 0 && ly.D / 4 <= 64 && ly.T <= 128 && ((ly.d % 4 == 0 && ly.d / 4 <= 64) || ly.d <= 64) &&
+                                ((uintptr_t)hops[i].edge_table & 15) == 0;  // launch_attn_reg's own conditions
+        if (by_id && (save || !reg_kernel)) {
+          set_error("tgat_forward: edge features by id need the inference path and the register-resident attention kernel");
+          return TGMX_E_UNSUPPORTED;
+        }
+        any_by_id |= by_id;
+        (void)any_by_id;
         const long long b = off[i];  // the kernel indexes with the global row: bias every level's arrays by its first row
         a.seg_begin[i] = b;
         a.seg_nbrf[i] = prev + off[i + 1] * ld_prev - b * (long long)k * ly.d;
         a.seg_ex[i] = hops[i].edge_x ? hops[i].edge_x - b * (long long)k * ly.D : nullptr;
+        a.seg_eid[i] = by_id ? hops[i].nbr_eid - b * (long long)k : nullptr;
+        a.seg_table[i] = by_id ? hops[i].edge_table : nullptr;
         a.seg_seed_t[i] = hops[i].seed_t - b;
         a.seg_nbr_t[i] = hops[i].nbr_t - b * (long long)k;
         a.seg_nbr_id[i] = hops[i].nbr_id - b * (long long)k;

@@ -74,6 +74,8 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
         mode: 'ring' (streaming state, default) or 'csr' (static index, stateless).
         validate: 'sync' | 'deferred' | 'off'.
         batch_size / batch_starts: loader schedule, required by ``mode='csr'``.
+        edge_features: 'dense' (default, the reference's [S, k, D] copies) or 'by_id' (edge ids + lazy gather, see
+            ``tgm_amd.core.lazy.EdgeFeaturesById``; batches must come from the graph store).
         adj_features: mode='csr' only (default on): a second copy of the edge features in the index's adjacency order.
         key_arith: ring mode only.  'int32' (default) reproduces the reference bit for bit,
             including the int32 wrap of its update sort key (recency.py:347) that leaves
@@ -100,12 +102,18 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
         batch_starts: Optional[Sequence[int]] = None,
         key_arith: str = 'int32',
         adj_features: bool = True,
+        edge_features: str = 'dense',
     ) -> None:
         super().__init__()
         if key_arith not in ('int32', 'int64'):
             raise ValueError(f"key_arith must be 'int32' or 'int64', got {key_arith!r}")
         self._key_wrap32 = 1 if key_arith == 'int32' else 0
         # mode='csr': keep a copy of the feature rows in adjacency order (False: gather by edge id from the store's edge_x)
+        if edge_features not in ('dense', 'by_id'):
+            raise ValueError(f"edge_features must be 'dense' or 'by_id', got {edge_features!r}")
+        # 'by_id' (ours): publish the edge id behind every sampled slot instead of copying its feature row; batch.nbr_edge_x is an
+        # EdgeFeaturesById (rows gathered from the resident store when -- and only if -- somebody indexes it)
+        self._by_id = edge_features == 'by_id'
         self._adj_features = bool(adj_features)
         self._adj_features_max_bytes = 32 << 30
         if not len(num_nbrs):
@@ -443,11 +451,21 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
 
             out_seed_n, out_seed_t, out_n, out_t, out_x = [], [], [], [], []
             cur_n, cur_t, S = seeds, seed_times, S0
+            by_id = self._by_id and D > 0
+            if by_id and ring_mode and batch._edge_lo is None:
+                raise ValueError("edge_features='by_id' needs batches materialized from the graph store (their edges carry store ids)")
+            out_eid = []
             for hop, k in enumerate(self._num_nbrs):
                 nid = ne32((S, k))
                 nts = ne64((S, k))
-                nx = nef((S, k, D))
-                st.out_nid[hop], st.out_ts[hop], st.out_x[hop] = nid.data_ptr(), nts.data_ptr(), nx.data_ptr()
+                if by_id:
+                    nx = None
+                    out_eid.append(ne32((S, k)))
+                    st.out_eid[hop] = out_eid[-1].data_ptr()
+                else:
+                    nx = nef((S, k, D))
+                    st.out_eid[hop] = 0
+                st.out_nid[hop], st.out_ts[hop], st.out_x[hop] = nid.data_ptr(), nts.data_ptr(), _native.ptr(nx)
                 out_seed_n.append(cur_n)
                 out_seed_t.append(cur_t)
                 out_n.append(nid)
@@ -503,7 +521,15 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
                 for i, h in enumerate(hops):
                     torch.sum((out_n[h] != -1).view(-1), dim=0, dtype=torch.int64, out=counts[i])  # asynchronous, unlike count_nonzero
                 self.profile_log.append((timer, [(out_seed_n[h].shape[0], self._num_nbrs[h]) for h in hops], counts, None))
+        if by_id:
+            from ..core.lazy import EdgeFeaturesById
+
+            out_x = EdgeFeaturesById(out_eid, self._feature_table(dg, device))
         return self._publish(batch, out_seed_n, out_seed_t, out_n, out_t, out_x, seed_mask)
+
+    def _feature_table(self, dg: DGraph, device: torch.device) -> Tensor:
+        """[E, D] edge features of the resident store: what the edge ids of edge_features='by_id' index."""
+        return dg._storage.on(device).edge_x
 
     # ------------------------------------------------------------------
     def _get_seed_tensors(self, batch: DGBatch, device: torch.device, concat: bool = True):

@@ -179,16 +179,24 @@ class TGAT(nn.Module):
         seeds = c(seed_nids[0])
         S0 = seeds.numel()
         rows = S0
+        from ..core.lazy import EdgeFeaturesById
+
+        drop_p = float(self.attn[0].dropout.p) if self.training else 0.0
+        saving = bool(S0) and (drop_p > 0 or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())))
+        # edge features by id (RecencyNeighborHook(edge_features='by_id')): the inference path's attention kernel reads the rows of the
+        # resident store where it consumes them; the saving path (and shapes that kernel does not cover) gathers them first
+        by_id = isinstance(nbr_edge_x, EdgeFeaturesById) and not saving and not getattr(self, '_by_id_unsupported', False)
         for i in range(L):
-            nid, nt, ex, st = c(nbr_nids[i]), c(nbr_edge_time[i]), c(nbr_edge_x[i]), c(seed_times[i])
+            nid, nt, st = c(nbr_nids[i]), c(nbr_edge_time[i]), c(seed_times[i])
+            ex = None if by_id else c(nbr_edge_x[i])
             if nid.shape[0] != rows or st.numel() != rows:
                 raise ValueError(f'hop {i}: expected {rows} rows, got nbr_nids {tuple(nid.shape)} / seed_times {tuple(st.shape)}')
             hold += [nid, nt, ex, st]
             h = hops[i]
             h.seed_t, h.nbr_id, h.nbr_t, h.edge_x, h.k = st.data_ptr(), nid.data_ptr(), nt.data_ptr(), _native.ptr(ex), nid.shape[-1]
+            h.nbr_eid, h.edge_table = (c(nbr_edge_x.eids[i]).data_ptr(), nbr_edge_x.table.data_ptr()) if by_id else (0, 0)
             rows *= nid.shape[-1]
-        drop_p = float(self.attn[0].dropout.p) if self.training else 0.0
-        if S0 and (drop_p > 0 or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()))):
+        if saving:
             # training: same native forward with every intermediate kept, hand-written backward (nn/_tgat_train.py);
             # also the path that applies dropout (train mode under no_grad included, like the reference)
             from ._tgat_train import TGATFunction
@@ -211,9 +219,11 @@ class TGAT(nn.Module):
         ws = getattr(self, '_workspace', None)
         if ws is None or ws.device != dev or ws.numel() < need:
             ws = self._workspace = torch.empty(need, dtype=torch.uint8, device=dev)
-        _native.check(
-            lib.tgmx_tgat_forward(model, node_x.data_ptr(), node_x.shape[0], seeds.data_ptr(), S0, hops, ws.data_ptr(), ws.numel(), 0,
-                                  out.data_ptr(), _native.stream_ptr()),
-            'tgmx_tgat_forward',
-        )  # fmt: skip
+        rc = lib.tgmx_tgat_forward(model, node_x.data_ptr(), node_x.shape[0], seeds.data_ptr(), S0, hops, ws.data_ptr(), ws.numel(), 0,
+                                   out.data_ptr(), _native.stream_ptr())  # fmt: skip
+        if rc == _native.E_UNSUPPORTED and by_id:
+            # a shape the by-id attention kernel does not cover (n_heads > 2, k > 20, ...): gather the rows, like everybody else
+            self._by_id_unsupported = True
+            return self.forward(node_x, seed_nids, seed_times, nbr_nids, nbr_edge_x, nbr_edge_time)
+        _native.check(rc, 'tgmx_tgat_forward')
         return out

@@ -214,7 +214,8 @@ class CompiledPipeline:
         for hop, k in enumerate(nbr._num_nbrs):
             take(f'nid{hop}', 4 * S * k)
             take(f'nts{hop}', 8 * S * k)
-            take(f'nx{hop}', 4 * S * k * D)
+            take(f'nx{hop}', 0 if nbr._by_id else 4 * S * k * D)
+            take(f'eid{hop}', 4 * S * k if nbr._by_id else 0)
             take(f'nv{hop}', 4 * S)  # [S] int32: the rows' spans (delta feature writes)
             take(f'nvp{hop}', 4 * S)  # the spans before the last call (byte accounting of a timed launch)
             total_ids += S * k
@@ -307,15 +308,21 @@ class CompiledPipeline:
         seed_n, seed_ts, nbr_n, nbr_t, nbr_x, valid = [], [], [], [], [], []
         cur_n, cur_t, S = seeds, seed_t, S0
         for hop, k in enumerate(nbr._num_nbrs):
-            nid, nts, nx = view(f'nid{hop}', torch.int32, S, k), view(f'nts{hop}', torch.int64, S, k), view(f'nx{hop}', torch.float32, S, k, D)
-            if self._delta:
+            nid, nts = view(f'nid{hop}', torch.int32, S, k), view(f'nts{hop}', torch.int64, S, k)
+            by_id = nbr._by_id and D > 0
+            if by_id:  # edge ids instead of feature rows (tgmx_recency_step_t.out_eid)
+                nx = view(f'eid{hop}', torch.int32, S, k)
+                out.out_eid[hop] = nx.data_ptr()
+            else:
+                nx = view(f'nx{hop}', torch.float32, S, k, D)
+            if self._delta and not by_id:
                 # persistent buffers: the lookups write a feature row only from the first slot that changes (its valid slots are the
                 # right-aligned tail, the rest is zero and stays zero) -- tgmx_recency_step_t.out_valid
                 o, op = off[f'nv{hop}'], off[f'nvp{hop}']
                 nv = (buf[o:o + 4 * S].view(torch.int32), buf[op:op + 4 * S].view(torch.int32))
                 out.out_valid[hop], out.out_valid_prev[hop] = nv[0].data_ptr(), nv[1].data_ptr()
                 valid.append(nv)
-            out.out_nid[hop], out.out_ts[hop], out.out_x[hop] = nid.data_ptr(), nts.data_ptr(), nx.data_ptr()
+            out.out_nid[hop], out.out_ts[hop], out.out_x[hop] = nid.data_ptr(), nts.data_ptr(), (0 if by_id else nx.data_ptr())
             seed_n.append(cur_n)
             seed_ts.append(cur_t)
             nbr_n.append(nid)
@@ -493,12 +500,18 @@ class CompiledPipeline:
             d['shard_dst'] = arr.dst.narrow(0, lo + s_lo, s_hi - s_lo)
             d['shard_time'] = arr.ts.narrow(0, lo + s_lo, s_hi - s_lo)
             d['shard_lo'] = s_lo
+        if nbr._by_id and nbr._edge_x_dim:
+            from .core.lazy import EdgeFeaturesById
+
+            d_eids = slot.attrs['nbr_edge_x']
         if self._safe:
             # the batch owns its containers (a consumer may append to / reorder them); the tensors inside are the set's views
             for key, v in slot.attrs.items():
                 d[key] = list(v) if type(v) is list else (dict(v) if type(v) is dict else v)
         else:
             d.update(slot.attrs)
+        if nbr._by_id and nbr._edge_x_dim:
+            d['nbr_edge_x'] = EdgeFeaturesById(d_eids, self._arr.edge_x)  # per batch: it caches what it materializes
         if slot.post is not None:
             self._defer_post(batch, slot)
         return True

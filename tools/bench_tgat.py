@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Time the TGAT eval forward (and sampler + forward) at the headline batch shape on the GPU box;
-prints one JSON line.  `python tools/bench_tgat.py [n_batches]`"""
+prints one JSON line.  `python tools/bench_tgat.py [n_batches] [dense|by_id]` (by_id: the sampler publishes edge ids, the
+attention reads the rows of the resident store -- RecencyNeighborHook(edge_features='by_id'))"""
 import json
 import os
 import sys
@@ -15,7 +16,8 @@ from tgm_amd.synth import make_stream  # noqa: E402
 
 stream = make_stream('wiki', seed=1337)
 dev = torch.device('cuda', 0)
-dg, hm, hook, loader = bench.build_pipeline(stream, 0, 1, 200, [20, 20], 'ring', dev, pool=1)  # the lowered chain into one persistent output set
+features = sys.argv[2] if len(sys.argv) > 2 else 'dense'
+dg, hm, hook, loader = bench.build_pipeline(stream, 0, 1, 200, [20, 20], 'ring', dev, pool=1, edge_features=features)  # the lowered chain into one persistent output set
 enc = TGAT(node_dim=1, edge_dim=172, time_dim=100, embed_dim=172, num_layers=2).to(dev).eval()
 starts = loader._starts
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
@@ -44,6 +46,7 @@ with hm.activate('bench'), torch.no_grad():
     torch.cuda.synchronize()
     t2 = time.perf_counter()
 print(json.dumps({
+    'edge_features': features,
     'what': 'TGAT eval forward, example dims (node 1 / edge 172 / time 100 / embed 172, 2 heads, 2 layers), 600 seeds, k=[20,20]',
     'tgat_forward_us': fwd_us, 'sampler_plus_forward_us_per_batch': 1e6 * (t2 - t0) / n, 'host_us_per_batch': 1e6 * (t1 - t0) / n,
     'algorithmic_gflop_folded': 3.5, 'reference_cpu_forward_ms': 166.0,
