@@ -158,9 +158,10 @@ def cpu_baseline(stream, bs, num_nbrs, n_batches, seed, first_batch):
     )
 
 
-def profile_key(args, bs, num_nbrs, steps):
+def profile_key(args, bs, num_nbrs, steps, world=1):
     """What a committed profile must have been taken with to describe THIS run's timed launches."""
-    return f'{args.workload}|{args.mode}|bs{bs}|k{"x".join(map(str, num_nbrs))}|steps{steps}|warmup{args.warmup}|pool{args.pool}|{args.validate}|start{args.start_frac}'
+    return (f'{args.workload}|{args.mode}|bs{bs}|k{"x".join(map(str, num_nbrs))}|steps{steps}|warmup{args.warmup}|pool{args.pool}|{args.validate}|start{args.start_frac}'
+            + (f'|world{world}|{args.scaling}' if world > 1 else ''))
 
 
 def committed_profile(key):
@@ -391,7 +392,7 @@ def main():
         ' + '.join(f'{seeds} seeds x k={k}' for seeds, k in shape) + ')'
 
     lowered = args.pool > 0
-    pkey = profile_key(args, bs, num_nbrs, steps)
+    pkey = profile_key(args, bs, num_nbrs, steps, world)
     out = {
         'metric': 'sampled-edges/sec (TGAT 2-hop k=20 recency sampler, tgbl-wiki synthetic)' if args.workload == 'wiki'
         else f'sampled-edges/sec (recency sampler, tgbl-{args.workload} synthetic)',

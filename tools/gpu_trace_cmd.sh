@@ -7,7 +7,7 @@ TAG=$1; ROWS=$2; shift 2
 OUT=$ROOT/gpurun_out/trace_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
-(cd /tmp && rocprofv3 --kernel-trace --stats -d "$OUT" -- "$@") > "$OUT.log" 2>&1
+(cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT" -- "$@") > "$OUT.log" 2>&1
 grep '^{' "$OUT.log" | tail -1
 python tools/prof_summary.py trace "$OUT" --title "rocprofv3 --kernel-trace --stats -- $*" | head -$ROWS
 rm -rf "$OUT"
