@@ -1139,30 +1139,36 @@ __device__ __forceinline__ SmallPick small_pick(const LookupArgs& a, int n, long
 }
 
 // phase B: stream the [k, D] block of row s; lds_eid[c] = feature row of output slot c (-1: zeros)
+// Round 3: straight-line trips -- every LDS lookup of the trip first, then U UNCONDITIONAL loads (a piece of a pad slot reads row 0 and
+// is replaced by zeros), then the stores: a branch around each load put an LDS round trip in front of every one of them, and four in
+// flight per lane were two trips more per seed than eight.
 template <int VEC>
 __device__ __forceinline__ void gather_rows(const LookupArgs& a, long long s, int k, int lane, const int* lds_eid, float* out_x, int first_slot) {
   using V = typename VecOf<VEC>::type;
   const V* __restrict__ X = reinterpret_cast<const V*>(a.edge_x);
   V* __restrict__ O = reinterpret_cast<V*>(out_x + s * (long long)k * a.D);
   const int total = k * a.row_vecs;
-  constexpr int U = 4;
+  constexpr int U = 8;
   for (int f0 = first_slot * a.row_vecs + lane; f0 < total; f0 += kWave * U) {
+    long long idx[U];
+    bool has[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int f = f0 + u * kWave;
+      const int fc = f < total ? f : f0;  // (f0 < total: a piece of this very row)
+      const int slot = (int)a.dv.div_nb((uint32_t)fc);
+      const int col = fc - slot * a.row_vecs;
+      const int e = lds_eid[slot];
+      has[u] = e >= 0;
+      idx[u] = has[u] ? (long long)e * a.row_vecs + col : 0;
+    }
     V v[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int f = f0 + u * kWave;
-      v[u] = zero_vec<V>();
-      if (f < total) {
-        const int slot = (int)a.dv.div((uint32_t)f);
-        const int col = f - slot * a.row_vecs;
-        const int e = lds_eid[slot];
-        if (e >= 0) v[u] = X[(long long)e * a.row_vecs + col];
-      }
-    }
+    for (int u = 0; u < U; ++u) v[u] = X[idx[u]];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int f = f0 + u * kWave;
-      if (f < total) O[f] = v[u];
+      if (f < total) O[f] = has[u] ? v[u] : zero_vec<V>();
     }
   }
 }
@@ -1468,8 +1474,16 @@ __global__ __launch_bounds__(256) void lookup_packed_kernel(const LookupArgs a, 
   for (long long w = (long long)bid * (blockDim.x >> 6) + wave_in_block; w < n_rounds; w += waves_total) {
     const long long s = w * kGroups + sub;
     const bool act = s < a.S;
-    const int n = act ? a.seeds[s] : -1;
-    const long long q = act ? a.qtimes[s] : 0;
+    int n = -1;
+    long long q = 0;
+    if (act) {
+      if (a.grp.groups > 0) {  // hop 0: the seed comes from its group (or is drawn) and the group's first lane publishes it
+        fetch_seed(a, s, gl, true, n, q);
+      } else {
+        n = a.seeds[s];
+        q = a.qtimes[s];
+      }
+    }
     if (act && gl == 0) {
       int st = 0;
       if (n >= a.N || n < -1 || (n == -1 && !a.allow_pad)) st |= TGMX_ST_SEED_RANGE;
@@ -1911,7 +1925,8 @@ static int launch_lookup(LookupArgs a, hipStream_t stream, hipEvent_t ev_start, 
   } while (0)
   // narrow rows: several seeds per wave (streaming rings, plain seed arrays)
   const int gl_any = a.out_eid ? 64 : packed_group_lanes(a, a.k, true);  // narrow rows?  (edge ids are written by the wave-per-seed kernels only)
-  const int gl = a.grp.groups == 0 ? gl_any : 64;                 // the packed kernel reads plain seed arrays only
+  static const bool packed_hop0 = !(getenv("TGMX_PACKED_HOP0") && atoi(getenv("TGMX_PACKED_HOP0")) == 0);  // A/B knob
+  const int gl = (a.grp.groups == 0 || packed_hop0) ? gl_any : 64;  // (round 3: the packed kernel takes seed groups -- hop 0 -- too)
   static const bool tile_on = !(getenv("TGMX_TILE") && atoi(getenv("TGMX_TILE")) == 0);  // A/B knob: 0 = the packed kernel
   // A tile's phases are a chain of ~8 dependent round trips (15-20 us on an idle chip): it pays when the launch has at least two tiles
   // per CU to overlap them (comment shape, hop 1: 3840 tiles), not for a few hundred seeds -- measured: review shape, hop 0 (24
