@@ -2128,7 +2128,9 @@ __global__ __launch_bounds__(kBlockThreads) void ring_update_front_block_kernel(
   using Scan = rocprim::block_scan<int, kBlockThreads>;
   __shared__ union {
     typename Sort::storage_type sort;
-    int node[kFrontMaxM + 1];
+    struct {
+      int node[kFrontMaxM + 1];
+    } r;
   } L;
   __shared__ typename Scan::storage_type scan_storage;
   __shared__ long long red[kBlockThreads / kWave];
@@ -2188,17 +2190,17 @@ __global__ __launch_bounds__(kBlockThreads) void ring_update_front_block_kernel(
       node_at[e] = valid ? node : -1;
       a.sorted_j[p] = (int)val[e];
       a.sorted_node[p] = node_at[e];
-      L.node[p] = node_at[e];
+      L.r.node[p] = node_at[e];
     }
   }
-  if (tid == 0) L.node[m] = -2;  // sentinel behind the last entry: never equal to a node
+  if (tid == 0) L.r.node[m] = -2;  // sentinel behind the last entry: never equal to a node
   __syncthreads();
   // run_start = inclusive max-scan of "p if p opens a run else 0"; the run's last position scatters the run length to its first
   int flag[kFrontIPT], rs[kFrontIPT];
 #pragma unroll
   for (int e = 0; e < kFrontIPT; ++e) {
     const int p = tid * kFrontIPT + e;
-    flag[e] = (p < m && p > 0 && L.node[p - 1] == node_at[e]) ? 0 : (p < m ? p : 0);
+    flag[e] = (p < m && p > 0 && L.r.node[p - 1] == node_at[e]) ? 0 : (p < m ? p : 0);
   }
   Scan().inclusive_scan(flag, rs, scan_storage, rocprim::maximum<int>());
 #pragma unroll
@@ -2206,7 +2208,7 @@ __global__ __launch_bounds__(kBlockThreads) void ring_update_front_block_kernel(
     const int p = tid * kFrontIPT + e;
     if (p < m) {
       a.run_start[p] = rs[e];
-      if (L.node[p + 1] != node_at[e]) a.run_len[rs[e]] = p - rs[e] + 1;
+      if (L.r.node[p + 1] != node_at[e]) a.run_len[rs[e]] = p - rs[e] + 1;
     }
   }
 }
@@ -2257,6 +2259,47 @@ __global__ __launch_bounds__(256) void ring_update_write_kernel(const UpdateArgs
     if (old < kFold && old + kept >= kFold) atomicSub(wp, kFold / a.B * a.B);
   }
   a.winner[p] = win;
+}
+
+// The write pass and the feature rows as ONE launch (D > 0), one wave per sorted position: the position's scalars are wave-uniform
+// (scalar loads), lane 0 writes the record and advances write_pos, the wave copies the row.
+__global__ __launch_bounds__(256) void ring_update_write_feat_kernel(const UpdateArgs a) {
+  const long long p = (long long)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (p >= a.m) return;
+  const bool first = lane_id() == 0;
+  if (update_blocked(a)) {
+    if (first) a.winner[p] = -1;
+    return;
+  }
+  const int tgt = a.target[p];
+  const int kept = a.winner[p];
+  int win = -1;
+  long long i = 0;
+  if (tgt >= 0 && a.hash_maxp[global_hash_slot(a.hash_key, a.hash_bits, tgt, false)] == (int)p) {
+    int nd, nbr;
+    long long t;
+    update_entry(a, a.sorted_j[p], nd, nbr, t, i);
+    if (first) {
+      Rec r;
+      r.nbr = nbr;
+      r.eid = a.eid0 >= 0 ? (int)(a.eid0 + i) : -1;
+      r.ts = t;
+      a.ring[tgt] = r;
+    }
+    win = tgt;
+  }
+  if (first) {
+    if (kept > 0) commit_write_pos(&a.write_pos[a.sorted_node[p]], kept, a.B);
+    a.winner[p] = win;
+  }
+  if (win < 0) return;
+  float* __restrict__ o = a.ring_x + (long long)win * a.D;
+  if (a.edge_x) {
+    const float* __restrict__ x = a.edge_x + i * a.D;
+    for (int c = lane_id(); c < a.D; c += kWave) o[c] = x[c];
+  } else {
+    for (int c = lane_id(); c < a.D; c += kWave) o[c] = 0.f;
+  }
 }
 
 // one wave per sorted position: copy the winning entry's D-float feature row.  COMMIT (after a riding placement, which
@@ -2644,7 +2687,8 @@ static int launch_update_large_front(UpdateArgs& a, int32_t* scratch, hipStream_
     }
     a.sort_bits = bits;
   }
-  if (front_block) {  // one workgroup: keys, sort, scatter, runs -- then the placement
+  if (front_block) {  // one workgroup: keys, sort, scatter, runs -- then the placement (folded into the one workgroup, its
+    // dependent atomics under the lookups' load took longer than the lookup launch: measured, step 154 -> 189 us)
     hipLaunchKernelGGL(ring_update_front_block_kernel, dim3(1), dim3(kBlockThreads), 0, st, a);
     hipLaunchKernelGGL(ring_update_place_kernel, dim3(blocks), dim3(256), 0, st, a);
     return TGMX_OK;
@@ -2673,9 +2717,12 @@ static int launch_update_large_front(UpdateArgs& a, int32_t* scratch, hipStream_
 }
 
 static void launch_update_large_back(const UpdateArgs& a, hipStream_t st) {
+  if (a.D > 0) {
+    hipLaunchKernelGGL(ring_update_write_feat_kernel, dim3((unsigned)((a.m + 3) / 4)), dim3(256), 0, st, a);
+    return;
+  }
   const unsigned blocks = (unsigned)((a.m + 255) / 256);
   hipLaunchKernelGGL(ring_update_write_kernel, dim3(blocks), dim3(256), 0, st, a);
-  if (a.D > 0) hipLaunchKernelGGL(ring_update_feat_kernel<false>, dim3((unsigned)((a.m + 3) / 4)), dim3(256), 0, st, a);
 }
 
 static int launch_update_large(UpdateArgs& a, int32_t* scratch, hipStream_t st) {
