@@ -122,14 +122,37 @@ def test_graph_attention_embedding_matches_restatement(inference):
     close(out.cpu(), ref, 'graph attention embedding')
 
 
-@pytest.mark.parametrize('U,E', [(1, 1), (5, 0), (300, 40), (7000, 15000), (40_000, 3)])
-def test_segment_sort_matches_stable_argsort(U, E):
+@pytest.mark.parametrize('one_launch', ['1', '0'])
+@pytest.mark.parametrize('U,E', [(1, 1), (5, 0), (300, 40), (7000, 15000), (40_000, 3), (32768, 16384), (3, 16385)])
+def test_segment_sort_matches_stable_argsort(U, E, one_launch, monkeypatch):
     """``tgmx_segment_sort`` (TransformerConv's incoming-edge grouping) == torch's stable argsort + searchsorted bounds."""
     from tgm_amd.nn.tgn import TransformerConv
 
+    monkeypatch.setenv('TGMX_SEGSORT_SMALL', one_launch)
     conv = TransformerConv(8, 4, heads=1, dropout=0.0, edge_dim=2).to(DEV).eval()
     g = torch.Generator().manual_seed(U + E)
     tgt = torch.randint(0, U, (E,), generator=g).to(DEV)
+    order, lo, hi = conv._incoming_segments(tgt, U)
+    srt, ref_order = torch.sort(tgt, stable=True)
+    ids = torch.arange(U, device=DEV)
+    assert torch.equal(order, ref_order)
+    assert torch.equal(lo, torch.searchsorted(srt, ids, right=False)) and torch.equal(hi, torch.searchsorted(srt, ids, right=True))
+
+
+@pytest.mark.parametrize('U,seeds,k', [(9000, 1536, 10), (9000, 1536, 1), (300, 4096, 4), (300, 4097, 3), (32768, 1638, 10), (40, 1, 16384), (5, 2, 3), (9000, 1700, 10)])
+@pytest.mark.parametrize('one_launch', ['1', '0'])
+def test_segment_sort_of_seed_major_edge_lists(U, seeds, k, one_launch, monkeypatch):
+    """Keys that come in runs (the k slots of a seed share its target; ragged: pad slots are compacted away) take the one-launch
+    kernel's run path (<= 4096 runs), anything else its radix sort; the default is the rocPRIM chain: same result."""
+    from tgm_amd.nn.tgn import TransformerConv
+
+    monkeypatch.setenv('TGMX_SEGSORT_SMALL', one_launch)
+    conv = TransformerConv(8, 4, heads=1, dropout=0.0, edge_dim=2).to(DEV).eval()
+    g = torch.Generator().manual_seed(U + seeds + k)
+    per_seed = torch.randint(0, U, (seeds,), generator=g)
+    keep = torch.rand(seeds, k, generator=g) < 0.8
+    keep[0, 0] = True
+    tgt = per_seed[:, None].expand(seeds, k)[keep].to(DEV)
     order, lo, hi = conv._incoming_segments(tgt, U)
     srt, ref_order = torch.sort(tgt, stable=True)
     ids = torch.arange(U, device=DEV)

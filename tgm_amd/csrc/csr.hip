@@ -10,6 +10,8 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <rocprim/block/block_radix_sort.hpp>
+#include <rocprim/block/block_scan.hpp>
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include "common.h"
@@ -253,33 +255,18 @@ static int segsort_layout(long long n, SegSortLayout& w) {
 }  // namespace tgmx
 
 namespace tgmx {
-// Small inputs (n <= 16384 keys below 2^15: the edge list of one TGN batch) in ONE launch and without any library call:
-// one workgroup sorts the packed values (key << 14 | index) -- unique, so ascending order IS the stable order -- with a
-// bitonic network in LDS (16 values per thread), then writes the permutation and every key's [lo, hi) range.  The rocPRIM
-// path costs the host ~60 us of launches for the same result.
-constexpr int kSegSmallMax = 16384;
-__global__ __launch_bounds__(1024) void segsort_small_kernel(const int64_t* __restrict__ key, int n, int num_keys, int64_t* __restrict__ order,
-                                                             int64_t* __restrict__ seg_lo, int64_t* __restrict__ seg_hi,
-                                                             int32_t* __restrict__ status) {
-  __shared__ unsigned v[kSegSmallMax];
-  const int tid = threadIdx.x;
-  int P = 1024;
-  while (P < n) P <<= 1;
-  bool bad = false;
-  for (int i = tid; i < P; i += 1024) {
-    unsigned x = 0xffffffffu;
-    if (i < n) {
-      long long kk = key[i];
-      if (kk < 0 || kk >= num_keys) {
-        bad = true;
-        kk = kk < 0 ? 0 : num_keys - 1;
-      }
-      x = ((unsigned)kk << 14) | (unsigned)i;
-    }
-    v[i] = x;
-  }
-  if (bad) atomicOr(status, TGMX_ST_EDGE_RANGE);
-  __syncthreads();
+// Small inputs (n <= 16384 keys below 2^15: the edge list of one TGN batch) in ONE launch, one workgroup, no library call.
+// The edge list of a sampled batch is seed-major: the k slots of a seed share a target, so the keys come in RUNS (at most one
+// per seed: 1536 for a 512-edge batch with negatives, against ~15 000 edges).  Sorting the run HEADS -- packed (key << 12 | run
+// number), unique, so ascending order IS the stable order -- with a bitonic network in LDS is a 2048-element problem; the runs'
+// lengths in sorted order are scanned into output offsets and every output position finds its run by binary search.  Keys that do
+// not come in runs (more than 4096 of them) take the same network over all elements (16 values per thread, ~58 us), still one
+// launch and the same result.  (Round 2 measured only that element-wise network and kept the rocPRIM chain -- keys, six sort
+// launches, bounds: 43 us of kernels -- for being faster.  It still is for a TGN batch, whose targets are the neighbours:
+// see the knob in tgmx_segment_sort.)
+constexpr int kSegSmallMax = 16384, kSegRunsMax = 4096;
+
+__device__ __forceinline__ void lds_bitonic(unsigned* v, int P, int tid) {
   for (int k = 2; k <= P; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
       for (int t = tid; t < (P >> 1); t += 1024) {
@@ -295,17 +282,143 @@ __global__ __launch_bounds__(1024) void segsort_small_kernel(const int64_t* __re
       __syncthreads();
     }
   }
-  // bounds as searchsorted gives them: a key without entries gets lo = hi = the position where it would be inserted
+}
+
+__global__ __launch_bounds__(1024) void segsort_small_kernel(const int64_t* __restrict__ key, int n, int num_keys, int64_t* __restrict__ order,
+                                                             int64_t* __restrict__ seg_lo, int64_t* __restrict__ seg_hi,
+                                                             int32_t* __restrict__ status) {
+  using Scan = rocprim::block_scan<int, 1024>;
+  using Sort = rocprim::block_radix_sort<unsigned, 1024, 16>;
+  __shared__ union {
+    unsigned all[kSegSmallMax];  // the element-wise result
+    typename Sort::storage_type sort;
+    struct {
+      unsigned v[kSegRunsMax];            // sorted run heads: key << 12 | run number
+      unsigned off[kSegRunsMax + 1];      // output offset of the sorted run
+      unsigned short start[kSegRunsMax + 1];  // input position of run number r
+      typename Scan::storage_type scan;
+    } r;
+  } L;
+  __shared__ int total_runs;
+  const int tid = threadIdx.x;
+  auto clamp_key = [&](long long kk, bool& bad) {
+    if (kk < 0 || kk >= num_keys) {
+      bad = true;
+      kk = kk < 0 ? 0 : num_keys - 1;
+    }
+    return (int)kk;
+  };
+  bool bad = false;
+  // ---- runs: thread t owns the positions [c t, c (t + 1)) ----
+  const int c = (n + 1023) >> 10;  // <= 16
+  const int lo = tid * c < n ? tid * c : n, hi = lo + c < n ? lo + c : n;
+  int kk[16];
+  int prev = lo > 0 && lo < n ? clamp_key(key[lo - 1], bad) : -1;
+  unsigned heads = 0;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    kk[e] = -1;
+    if (lo + e < hi) {
+      kk[e] = clamp_key(key[lo + e], bad);
+      if (lo + e == 0 || kk[e] != prev) heads |= 1u << e;
+      prev = kk[e];
+    }
+  }
+  if (bad) atomicOr(status, TGMX_ST_EDGE_RANGE);
+  int first_run;
+  Scan().exclusive_scan(__popc(heads), first_run, 0, L.r.scan);
+  if (tid == 1023) total_runs = first_run + __popc(heads);
+  __syncthreads();
+  const int R = total_runs;
+  if (R <= kSegRunsMax) {
+    int P = 64;
+    while (P < R) P <<= 1;
+    int rid = first_run;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      if (heads >> e & 1) {
+        L.r.v[rid] = ((unsigned)kk[e] << 12) | (unsigned)rid;
+        L.r.start[rid] = (unsigned short)(lo + e);
+        ++rid;
+      }
+    }
+    for (int i = R + tid; i < P; i += 1024) L.r.v[i] = 0xffffffffu;
+    if (tid == 0) L.r.start[R] = (unsigned short)n;  // n <= 16384 fits
+    __syncthreads();
+    lds_bitonic(L.r.v, P, tid);
+    // output offsets: exclusive scan of the run lengths in sorted order (4 runs per thread)
+    int len[4], sum = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int q = tid * 4 + e;
+      len[e] = 0;
+      if (q < R) {
+        const int id = (int)(L.r.v[q] & 0xfffu);
+        len[e] = (int)L.r.start[id + 1] - (int)L.r.start[id];
+      }
+      sum += len[e];
+    }
+    int base;
+    __syncthreads();  // (the scan's storage is next to, not inside, what was just read -- but the previous scan's use of it is over)
+    Scan().exclusive_scan(sum, base, 0, L.r.scan);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int q = tid * 4 + e;
+      if (q < R) L.r.off[q] = (unsigned)base;
+      base += len[e];
+    }
+    if (tid == 0) L.r.off[R] = (unsigned)n;
+    __syncthreads();
+    // every output position finds its run: the last sorted run whose offset is <= q
+    for (int q = tid; q < n; q += 1024) {
+      int a = 0, b = R;  // off[a] <= q < off[b]
+      while (b - a > 1) {
+        const int mid = (a + b) >> 1;
+        if (L.r.off[mid] <= (unsigned)q) a = mid;
+        else b = mid;
+      }
+      const int id = (int)(L.r.v[a] & 0xfffu);
+      order[q] = (long long)L.r.start[id] + (q - (int)L.r.off[a]);
+    }
+    // bounds as searchsorted gives them: a key without entries gets lo = hi = the position where it would be inserted
+    for (int q = tid; q < R; q += 1024) {
+      const int kq = (int)(L.r.v[q] >> 12);
+      const int kp = q == 0 ? -1 : (int)(L.r.v[q - 1] >> 12);
+      const long long at = L.r.off[q];
+      if (kp != kq) {
+        seg_lo[kq] = at;
+        for (int g = kp + 1; g < kq; ++g) seg_lo[g] = seg_hi[g] = at;  // the absent keys just below this one
+      }
+      if (q == R - 1 || (int)(L.r.v[q + 1] >> 12) != kq) seg_hi[kq] = L.r.off[q + 1];
+    }
+    const int last = (int)(L.r.v[R - 1] >> 12);
+    for (int g = last + 1 + tid; g < num_keys; g += 1024) seg_lo[g] = seg_hi[g] = n;
+    return;
+  }
+  // ---- keys without run structure: a stable radix sort of the packed values (key << 14 | index) over the KEY bits only, the
+  // elements in registers in input order (thread t holds [c t, c (t + 1)); pads sort behind everything)
+  __syncthreads();  // the scan's storage lies inside the union
+  unsigned x[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) x[e] = lo + e < hi ? ((unsigned)kk[e] << 14) | (unsigned)(lo + e) : 0xffffffffu;
+  unsigned bits = 1;
+  while ((1 << bits) < num_keys) ++bits;
+  Sort().sort(x, L.sort, 14u, 14u + bits > 31u ? 32u : 14u + bits + 1u);  // (+1: the pads' all-ones key sorts last)
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 16; ++e) L.all[tid * 16 + e] = x[e];
+  __syncthreads();
+  const unsigned* v = L.all;
   for (int i = tid; i < n; i += 1024) {
     const unsigned x = v[i];
-    const int kk = (int)(x >> 14);
+    const int kq = (int)(x >> 14);
     order[i] = (long long)(x & 0x3fffu);
-    const int prev = i == 0 ? -1 : (int)(v[i - 1] >> 14);
-    if (prev != kk) {
-      seg_lo[kk] = i;
-      for (int g = prev + 1; g < kk; ++g) seg_lo[g] = seg_hi[g] = i;  // the absent keys just below this one
+    const int kp = i == 0 ? -1 : (int)(v[i - 1] >> 14);
+    if (kp != kq) {
+      seg_lo[kq] = i;
+      for (int g = kp + 1; g < kq; ++g) seg_lo[g] = seg_hi[g] = i;  // the absent keys just below this one
     }
-    if (i == n - 1 || (int)(v[i + 1] >> 14) != kk) seg_hi[kk] = i + 1;
+    if (i == n - 1 || (int)(v[i + 1] >> 14) != kq) seg_hi[kq] = i + 1;
   }
   const int last = (int)(v[n - 1] >> 14);
   for (int g = last + 1 + tid; g < num_keys; g += 1024) seg_lo[g] = seg_hi[g] = n;
@@ -330,9 +443,11 @@ extern "C" int tgmx_segment_sort(const int64_t* key, int64_t n, int32_t num_keys
     return TGMX_OK;
   }
   TGMX_REQUIRE(key && order && workspace, "segment_sort: null pointer");
-  // measured (TGN batch, ~5 k edges): the bitonic network takes 58 us on the device against ~25 us of rocPRIM kernels, and once
-  // the pipeline is GPU-bound that outweighs the ~50 us of host launches it saves: off unless TGMX_SEGSORT_SMALL=1
-  static const bool small_on = getenv("TGMX_SEGSORT_SMALL") != nullptr;
+  // measured (TGN batch, ~13 k edges whose targets are the NEIGHBOURS, so no run structure): the one-workgroup kernel takes ~49 us
+  // (block radix sort; 58 with the bitonic network) against 43 us for the rocPRIM chain -- one CU against the chip -- so it is off
+  // unless TGMX_SEGSORT_SMALL=1 (read per call: the tests switch it); seed-major targets (run path, ~12 us) would want it on
+  const char* knob = getenv("TGMX_SEGSORT_SMALL");
+  const bool small_on = knob && atoi(knob) != 0;
   if (small_on && n <= kSegSmallMax && num_keys <= (1 << 15)) {
     hipLaunchKernelGGL(segsort_small_kernel, dim3(1), dim3(1024), 0, st, key, (int)n, num_keys, order, seg_lo, seg_hi, status);
     TGMX_CHECK_LAUNCH("segment_sort");
