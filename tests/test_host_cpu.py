@@ -277,3 +277,31 @@ def test_loader_is_a_torch_dataloader_like_the_reference():
         DGDataLoader(dg, batch_size=7, bogus=1)
     with pytest.raises(ValueError, match='num_workers'):
         DGDataLoader(dg, batch_size=7, num_workers=2)
+
+
+def test_parameter_cache_key_sees_fused_optimizer_steps_and_explicit_invalidation():
+    """Derived weight copies are cached against tgm_amd.nn._paramver.param_key.  A fused optimizer step leaves Tensor._version alone
+    (which is why the key carries an optimizer-step count); writes through .data need invalidate_parameter_caches()."""
+    import torch
+
+    from tgm_amd.nn import invalidate_parameter_caches
+    from tgm_amd.nn._paramver import param_key
+
+    lin = torch.nn.Linear(4, 4)
+    for make in (lambda: torch.optim.Adam(lin.parameters(), lr=1e-3, fused=True), lambda: torch.optim.Adam(lin.parameters(), lr=1e-3),
+                 lambda: torch.optim.SGD(lin.parameters(), lr=1e-3, fused=True)):  # fmt: skip
+        opt = make()
+        for p in lin.parameters():
+            p.grad = torch.ones_like(p)
+        k0 = param_key(lin.parameters())
+        assert param_key(lin.parameters()) == k0  # stable between steps
+        opt.step()
+        assert param_key(lin.parameters()) != k0
+    k0 = param_key(lin.parameters())
+    lin.weight.data.mul_(0.5)
+    assert param_key(lin.parameters()) == k0  # the blind spot ...
+    invalidate_parameter_caches()
+    assert param_key(lin.parameters()) != k0  # ... and its remedy
+    k0 = param_key(lin.parameters())
+    lin.load_state_dict({k: v + 1 for k, v in lin.state_dict().items()})
+    assert param_key(lin.parameters()) != k0

@@ -68,9 +68,8 @@ def test_tgat_parameter_gradients(case):
     assert min(w64[1], w32[1]) <= 1e-4, f'{case}: worst rel err vs fp64 {w64}, vs fp32 {w32}'
 
 
-def test_tgat_training_step_reduces_loss():
-    """A few Adam steps on a fixed batch with the HIP forward/backward must drive a regression loss down."""
-    from tgm_amd.nn import TGAT
+def _train_losses(make_opt, steps=40):
+    from tgm_amd.nn import TGAT, invalidate_parameter_caches
 
     meta, params, inputs, _ = gu.tgat_case('g5_tgat_small_nd8')
     enc = TGAT(edge_dim=meta['edge_dim'], num_layers=2, dropout=0.0, **meta['dims']).to(DEV).train()
@@ -79,15 +78,45 @@ def test_tgat_training_step_reduces_loss():
     args = {k: dev(v) for k, v in inputs.items()}
     torch.manual_seed(1)
     target = torch.randn(30, meta['dims']['embed_dim'], device=DEV)
-    opt = torch.optim.Adam(enc.parameters(), lr=1e-2)
+    opt = make_opt(enc.parameters())
     losses = []
-    for _ in range(40):
-        opt.zero_grad()
+    for _ in range(steps):
+        enc.zero_grad()
         loss = ((enc(**args) - target) ** 2).mean()
         loss.backward()
-        opt.step()
+        if opt is not None:
+            opt.step()
+        else:  # hand-rolled SGD through .data: invisible to autograd's version counter
+            for p in enc.parameters():
+                if p.grad is not None:
+                    p.data.add_(p.grad, alpha=-1e-2)
+            invalidate_parameter_caches()
         losses.append(float(loss.detach()))
+    return losses
+
+
+def test_tgat_training_step_reduces_loss():
+    """A few Adam steps on a fixed batch with the HIP forward/backward must drive a regression loss down."""
+    losses = _train_losses(lambda ps: torch.optim.Adam(ps, lr=1e-2))
     assert losses[-1] < 0.8 * losses[0] and all(b < a * 1.05 for a, b in zip(losses, losses[1:])), losses
+
+
+@pytest.mark.parametrize('variant', ['adam_fused', 'sgd_fused', 'data_writes'])
+def test_training_sees_updates_that_do_not_bump_tensor_versions(variant):
+    """The fused optimizers update the parameters without bumping ``Tensor._version``; so do writes through ``p.data``.  The kernels'
+    padded weight copies are cached against tgm_amd.nn._paramver.param_key (counts optimizer steps; ``invalidate_parameter_caches()``
+    for hand-rolled updates): the loss trajectory must be the plain optimizer's, not that of a model that never sees its updates."""
+    plain, other = {
+        'adam_fused': (lambda ps: torch.optim.Adam(ps, lr=1e-2), lambda ps: torch.optim.Adam(ps, lr=1e-2, fused=True)),
+        'sgd_fused': (lambda ps: torch.optim.SGD(ps, lr=1e-2), lambda ps: torch.optim.SGD(ps, lr=1e-2, fused=True)),
+        'data_writes': (lambda ps: torch.optim.SGD(ps, lr=1e-2), lambda ps: None),
+    }[variant]
+    a, b = _train_losses(plain, 25), _train_losses(other, 25)
+    assert a[-1] < 0.97 * a[0], a  # the plain run does learn ...
+    # ... and the other one follows it (the fused kernels round differently and training amplifies it; a model
+    # that never saw its updates would sit at a[0])
+    tol = 2e-3 if variant == 'data_writes' else 5e-2
+    assert all(abs(x - y) <= tol * abs(x) for x, y in zip(a, b)) and b[-1] < 0.97 * b[0], (variant, a, b)
 
 
 @pytest.mark.parametrize('case', ['g5_tgat_small_nd8', 'g5_tgat_example_dims'])

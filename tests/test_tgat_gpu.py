@@ -27,9 +27,10 @@ def close(got, ref, tag):
     # The bar is |got - ref| <= 1e-5 * max(1, |ref|): relative for |ref| >= 1, absolute 1e-5 below that (every output here
     # comes out of a LayerNorm / MLP with O(1) scale, where a pure relative bound on an element that happens to be ~0 is not
     # meaningful).  TGMX_PARITY_STATS=<file>: also record the worst PURE relative error over the elements with |ref| >= 1e-2.
+    big = ref.abs() >= 1e-2
+    rel = (err[big] / ref.abs()[big]).max().item() if bool(big.any()) else 0.0
+    print(f'[parity] {tag}: max abs err {err.max().item():.3e}, worst relative err (|ref| >= 1e-2) {rel:.3e}, {worst:.2f}x the bound')  # pytest -rP
     if os.environ.get('TGMX_PARITY_STATS'):
-        big = ref.abs() >= 1e-2
-        rel = (err[big] / ref.abs()[big]).max().item() if bool(big.any()) else 0.0
         with open(os.environ['TGMX_PARITY_STATS'], 'a') as f:
             f.write(json.dumps({'case': tag, 'elements': got.numel(), 'max_abs_err': err.max().item(), 'worst_multiple_of_bound': worst,
                                 'worst_relative_err_where_ref_ge_1e-2': rel, 'max_abs_ref': ref.abs().max().item()}) + '\n')

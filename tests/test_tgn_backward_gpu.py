@@ -90,8 +90,8 @@ def test_tgn_parameter_gradients(aggr, dropout):
     assert worst[1] <= 2e-4, f'{aggr}: worst relative gradient error {worst}; all: {report}'
 
 
-@pytest.mark.parametrize('dropout', [False, True])
-def test_tgn_training_step_reduces_loss(dropout):
+@pytest.mark.parametrize('dropout,fused', [(False, None), (True, None), (False, True)])
+def test_tgn_training_step_reduces_loss(dropout, fused):
     """A few Adam steps through memory -> embedding on a fixed batch drive a regression loss down -- also with the
     reference-default constructor arguments (TransformerConv dropout 0.1), which used to raise."""
     mem, enc, ref, mp, ep, batches, rng, (N, D, M, T_) = _setup('last', seed=3, dropout=dropout)
@@ -105,7 +105,7 @@ def test_tgn_training_step_reduces_loss(dropout):
     e_x = torch.from_numpy(rng.random((E, D), dtype=np.float32)).to(DEV)
     target = torch.randn(N, 16, device=DEV)
     params = list({id(p): p for p in list(mem.parameters()) + list(enc.parameters())}.values())
-    opt = torch.optim.Adam(params, lr=1e-2)
+    opt = torch.optim.Adam(params, lr=1e-2, fused=fused)  # fused: the step does not bump Tensor._version (tgm_amd.nn._paramver)
     losses = []
     for _ in range(40):
         opt.zero_grad()

@@ -1,3 +1,4 @@
+from ._paramver import invalidate_parameter_caches
 from .attention import TemporalAttention
 from .base import EncoderModule
 from .tgat import TGAT, MergeLayer
@@ -7,5 +8,5 @@ from .time_encoding import Time2Vec
 
 __all__ = [
     'EncoderModule', 'GCNConv', 'GraphAttentionEmbedding', 'IdentityMessage', 'LastAggregator', 'MeanAggregator', 'MergeLayer', 'TGAT', 'TGCN',
-    'TGNMemory', 'TemporalAttention', 'Time2Vec', 'TransformerConv', 'sampled_edge_list',
+    'TGNMemory', 'TemporalAttention', 'Time2Vec', 'TransformerConv', 'invalidate_parameter_caches', 'sampled_edge_list',
 ]  # fmt: skip

@@ -1,0 +1,34 @@
+"""When did a module's parameters last change?  Derived copies of the weights (padded / transposed layouts for the kernels, the
+folded query side of the TGAT inference path, stacked projections) are cached against this key.
+
+``Tensor._version`` alone is NOT enough: the fused optimizers (``torch.optim.Adam(..., fused=True)``, ``AdamW``, ``SGD``) update
+the parameters with one multi-tensor kernel that does not bump it (checked on torch 2.10: ``p._version`` is unchanged after
+``opt.step()``), so a cache keyed on (data_ptr, _version) would keep serving the weights of step 0 -- training that silently
+never sees its own updates.  The key therefore also carries a process-wide count of optimizer steps (a global post-step hook:
+any optimizer, any parameter group).  What is still invisible: writes through ``p.data`` (its own version counter) -- code that
+does that calls :func:`invalidate_parameter_caches`.
+"""
+from typing import Iterable, Tuple
+
+import torch
+from torch.optim.optimizer import register_optimizer_step_post_hook
+
+_epoch = 0
+
+
+def _after_step(optimizer, args, kwargs) -> None:
+    global _epoch
+    _epoch += 1
+
+
+register_optimizer_step_post_hook(_after_step)
+
+
+def invalidate_parameter_caches() -> None:
+    """Drop every cached derived copy of any module's weights (after in-place writes autograd cannot see, e.g. ``p.data.mul_()``)."""
+    global _epoch
+    _epoch += 1
+
+
+def param_key(params: Iterable[torch.Tensor]) -> Tuple:
+    return (_epoch,) + tuple((p.data_ptr(), p._version) for p in params)

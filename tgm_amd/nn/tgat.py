@@ -26,6 +26,7 @@ from torch import Tensor
 
 from .. import _native
 from . import _ops
+from ._paramver import param_key
 from .attention import TemporalAttention
 from .time_encoding import Time2Vec
 
@@ -66,7 +67,7 @@ class TGAT(nn.Module):
     def _model_desc(self):
         """ctypes description of the parameters for ``tgmx_tgat_forward`` -- rebuilt only when a
         parameter was reallocated or modified in place (optimizer step, load_state_dict)."""
-        key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        key = param_key(self.parameters())
         cached = getattr(self, '_desc_cache', None)
         if cached is not None and cached[0] == key:
             return cached[1]

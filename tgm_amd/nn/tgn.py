@@ -27,6 +27,7 @@ from torch import Tensor
 
 from .. import _native
 from . import _ops
+from ._paramver import param_key
 from .time_encoding import Time2Vec
 
 _COMPOSE_IN_PYTHON = bool(os.environ.get('TGMX_TGN_PY'))  # A/B knob: module forwards as sequences of ctypes calls instead of one C driver call
@@ -366,7 +367,7 @@ class TGNMemory(nn.Module):
             if not self.reuse_forward:
                 return self._updated(n_id.to(torch.int32).contiguous())
             mem, lu = self._updated(n_id.to(torch.int32).contiguous(), record=True)
-            self._fwd = (self._version, self._stamp, mem.detach(), lu)
+            self._fwd = (self._version, self._stamp, mem.detach(), lu, param_key(self.parameters()))
             return mem, lu
         idx = n_id.long()
         return self.memory[idx], self.last_update[idx]
@@ -378,9 +379,10 @@ class TGNMemory(nn.Module):
         t = t.to(torch.int64).contiguous()
         raw = _ops._f32c(raw_msg, 'raw_msg') if self.raw_msg_dim else None
         fwd = self._fwd
-        if self.training and self.reuse_forward and fwd is not None and fwd[0] == self._version and not self._sharded(2 * src32.numel()):
+        if (self.training and self.reuse_forward and fwd is not None and fwd[0] == self._version and not self._sharded(2 * src32.numel())
+                and fwd[4] == param_key(self.parameters())):  # (an optimizer step in between: the reference recomputes with the new weights)
             # the rows this batch's nodes need are the ones the forward just computed: commit by row copy, then store
-            _, stamp, mem_rows, lu_rows = fwd
+            _, stamp, mem_rows, lu_rows, _ = fwd
             self._version += 1
             _native.check(
                 _native.load().tgmx_tgn_commit_assoc(src32.data_ptr(), dst32.data_ptr(), src32.numel(), self._assoc64.data_ptr(), stamp,
@@ -504,7 +506,7 @@ class TransformerConv(nn.Module):
         """[4, HC, in] weights and [4, HC] biases of lin_query / lin_key / lin_value / lin_skip, rebuilt only when a
         parameter was reallocated or modified in place (optimizer step, load_state_dict)."""
         lins = (self.lin_query, self.lin_key, self.lin_value, self.lin_skip)
-        key = tuple((p.data_ptr(), p._version) for lin in lins for p in (lin.weight, lin.bias))
+        key = param_key(p for lin in lins for p in (lin.weight, lin.bias))
         cached = getattr(self, '_stacked', None)
         if cached is None or cached[0] != key:
             W4 = torch.stack([lin.weight.detach().float() for lin in lins]).contiguous()

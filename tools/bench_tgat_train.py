@@ -17,7 +17,7 @@ stream = make_stream('wiki', seed=1337)
 dev = torch.device('cuda', 0)
 dg, hm, hook, loader = bench.build_pipeline(stream, 0, 1, 200, [20, 20], 'ring', dev)
 enc = TGAT(node_dim=1, edge_dim=172, time_dim=100, embed_dim=172, num_layers=2).to(dev).train()  # the reference default dropout 0.1
-opt = torch.optim.Adam(enc.parameters(), lr=1e-4)
+opt = torch.optim.Adam(enc.parameters(), lr=1e-4, fused=bool(int(os.environ.get('FUSED_ADAM', '0'))) or None)
 starts = loader._starts
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 node_x = dg.static_node_x

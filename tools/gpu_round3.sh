@@ -21,5 +21,9 @@ TGMX_TILE=0 timeout 300 python bench.py --cpu-batches 0 --workload comment --ste
 tools/gpu_profile_r3.sh wiki_ring recency_lookup_fused01 20 --warmup 5
 tools/gpu_profile_r3.sh comment_csr lookup_tile 100 --workload comment --mode csr
 tools/gpu_profile_r3.sh comment_ring lookup_tile 100 --workload comment
+for f in dense by_id; do timeout 300 python tools/bench_tgat.py 200 $f 2>/dev/null | j > "$OUT/r03_bench_tgat_$f.json"; done
+timeout 300 python tools/bench_tgn.py 400 2>/dev/null | j > "$OUT/r03_bench_tgn.json"
+rm -f "$OUT/r03_tgat_parity_stats.jsonl"
+TGMX_PARITY_STATS="$OUT/r03_tgat_parity_stats.jsonl" timeout 900 python -m pytest tests/test_tgat_gpu.py -q -m gpu -k "reference or headline" > "$OUT/r03_tgat_parity_pytest.log" 2>&1
 timeout 1200 python tools/scaling_model.py > "$OUT/scaling_model.log" 2>&1; cp profiles/r03_scaling_model.json "$OUT/" 2>/dev/null
 ls -la "$OUT"
