@@ -485,6 +485,19 @@ typedef struct tgmx_tgat_layout {
 /* Weight [N, K] (row stride ldw floats) -> out[tgmx_tgat_tile16_floats(N, K)]: block (nb, kb) of 16 x 16 is 256 consecutive
  * floats, element 4 * lane + j = W[16 nb + (lane & 15)][16 kb + 4 (lane >> 4) + j], zero outside the matrix -- the order the
  * 16x16x4 fp32 MFMA's A operand is fetched in, so one wave load is 1 KB of consecutive memory. */
+/* Batched 2-D repacking of small matrices -- a module's weights into the zero-padded / transposed layouts the kernels read -- as ONE
+ * launch (round 3: the training step rebuilt them after every optimizer step with ~25 torch launches).  Job i writes, for r < dst_rows and
+ * c < dst_cols, dst[r * dst_ld + c] = src[r * src_ld + c] (transpose == 0) or src[c * src_ld + r] (transpose != 0) where r < rows and
+ * c < cols (the extent of the data in dst coordinates), 0 elsewhere.  Replaces torch.zeros + slice assignment (tgm_amd/nn/tgat.py). */
+#define TGMX_PACK_MAX_JOBS 32
+typedef struct tgmx_pack_job {
+  const float* src;
+  float* dst;
+  int64_t src_ld, dst_ld;
+  int32_t rows, cols, dst_rows, dst_cols;
+  int32_t transpose, reserved_;
+} tgmx_pack_job_t;
+int tgmx_pack2d(const tgmx_pack_job_t* jobs, int32_t n_jobs, tgmx_stream_t stream);
 size_t tgmx_tgat_tile16_floats(int32_t N, int32_t K);
 int tgmx_tgat_tile16(const float* W, int64_t ldw, int32_t N, int32_t K, float* out, tgmx_stream_t stream);
 int tgmx_tgat_layout(const tgmx_tgat_model_t* model, int64_t S0, const tgmx_tgat_hop_t* hops,

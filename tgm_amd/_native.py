@@ -117,6 +117,15 @@ class TgatHop(ctypes.Structure):
     _fields_ = [('seed_t', c_void_p), ('nbr_id', c_void_p), ('nbr_t', c_void_p), ('edge_x', c_void_p), ('k', c_int32), ('nbr_eid', c_void_p), ('edge_table', c_void_p)]
 
 
+PACK_MAX_JOBS = 32
+
+
+class PackJob(ctypes.Structure):
+    """tgmx_pack_job_t"""
+    _fields_ = [('src', c_void_p), ('dst', c_void_p), ('src_ld', c_int64), ('dst_ld', c_int64), ('rows', c_int32), ('cols', c_int32),
+                ('dst_rows', c_int32), ('dst_cols', c_int32), ('transpose', c_int32), ('reserved_', c_int32)]  # fmt: skip
+
+
 class TgatLayerLayout(ctypes.Structure):
     _fields_ = [(n, c_int64) for n in ('R', 'rres', 'oattn', 'y', 'Q', 'qf', 'zbar', 'cat', 'h1', 'probs', 'out')] + [
         (n, c_int32) for n in ('Op', 'dhp', 'Cp', 'Kc', 'Ep')
@@ -249,6 +258,7 @@ SIGNATURES['tgmx_segment_sort_workspace_bytes'] = (c_size_t, [c_int64])
 SIGNATURES['tgmx_segment_sort'] = (c_int32, [_P, c_int64, c_int32, _P, _P, _P, _P, c_size_t, _P, _P])
 SIGNATURES['tgmx_tgat_tile16_floats'] = (c_size_t, [c_int32, c_int32])
 SIGNATURES['tgmx_tgat_tile16'] = (c_int32, [_P, c_int64, c_int32, c_int32, _P, _P])
+SIGNATURES['tgmx_pack2d'] = (c_int32, [_P, c_int32, _P])
 SIGNATURES['tgmx_tgat_layout'] = (c_int32, [ctypes.POINTER(TgatModel), c_int64, ctypes.POINTER(TgatHop), c_int32, ctypes.POINTER(TgatLayout)])
 SIGNATURES['tgmx_tgat_workspace_bytes'] = (c_size_t, [ctypes.POINTER(TgatModel), c_int64, ctypes.POINTER(TgatHop)])
 SIGNATURES['tgmx_tgat_forward'] = (

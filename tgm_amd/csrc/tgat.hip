@@ -1852,6 +1852,44 @@ __global__ __launch_bounds__(256) void tile16_kernel(const float* __restrict__ W
   }
 }
 
+struct PackJobs {
+  tgmx_pack_job_t job[TGMX_PACK_MAX_JOBS];
+};
+// blockIdx.y = job; the job's dst elements strided over blockIdx.x
+__global__ __launch_bounds__(256) void pack2d_kernel(const PackJobs J) {
+  const tgmx_pack_job_t j = J.job[blockIdx.y];
+  const long long total = (long long)j.dst_rows * j.dst_cols;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(e / j.dst_cols), c = (int)(e - (long long)r * j.dst_cols);
+    float v = 0.f;
+    if (r < j.rows && c < j.cols) v = j.transpose ? j.src[(long long)c * j.src_ld + r] : j.src[(long long)r * j.src_ld + c];
+    j.dst[(long long)r * j.dst_ld + c] = v;
+  }
+}
+
+extern "C" int tgmx_pack2d(const tgmx_pack_job_t* jobs, int32_t n_jobs, tgmx_stream_t stream) {
+  TGMX_REQUIRE(n_jobs >= 0 && n_jobs <= TGMX_PACK_MAX_JOBS, "pack2d: %d jobs (at most %d per call)", n_jobs, TGMX_PACK_MAX_JOBS);
+  if (n_jobs == 0) return TGMX_OK;
+  TGMX_REQUIRE(jobs, "pack2d: null pointer");
+  PackJobs J{};
+  long long most = 0;
+  for (int i = 0; i < n_jobs; ++i) {
+    const tgmx_pack_job_t& j = jobs[i];
+    TGMX_REQUIRE(j.src && j.dst && j.rows >= 0 && j.cols >= 0 && j.dst_rows >= j.rows && j.dst_cols >= j.cols && j.dst_ld >= j.dst_cols &&
+                     j.src_ld >= (j.transpose ? j.rows : j.cols),
+                 "pack2d: job %d is malformed", i);
+    J.job[i] = j;
+    const long long total = (long long)j.dst_rows * j.dst_cols;
+    most = total > most ? total : most;
+  }
+  if (most == 0) return TGMX_OK;
+  long long bx = (most + 1023) / 1024;  // ~4 elements per thread
+  if (bx > 256) bx = 256;
+  hipLaunchKernelGGL(pack2d_kernel, dim3((unsigned)bx, (unsigned)n_jobs), dim3(256), 0, (hipStream_t)stream, J);
+  TGMX_CHECK_LAUNCH("pack2d");
+  return TGMX_OK;
+}
+
 extern "C" size_t tgmx_tgat_tile16_floats(int32_t N, int32_t K) {
   return N > 0 && K > 0 ? (size_t)((N + 15) / 16) * (size_t)((K + 15) / 16) * 256 : 0;
 }

@@ -65,30 +65,60 @@ class TGAT(nn.Module):
 
     # ------------------------------------------------------------------
     def _model_desc(self):
-        """ctypes description of the parameters for ``tgmx_tgat_forward`` -- rebuilt only when a
-        parameter was reallocated or modified in place (optimizer step, load_state_dict)."""
+        """ctypes description of the parameters for ``tgmx_tgat_forward``.  The weights the kernels read in padded / transposed layouts
+        live in persistent buffers that are refreshed by ONE native launch (``tgmx_pack2d``) whenever a parameter changed -- after
+        every optimizer step when training (``_paramver.param_key``; the ~25 torch launches this took were 0.2 ms of every step) --
+        and rebuilt only when a parameter was reallocated."""
         key = param_key(self.parameters())
         cached = getattr(self, '_desc_cache', None)
         if cached is not None and cached[0] == key:
             return cached[1]
         if self.num_layers > _native.TGAT_MAX_LAYERS:
             raise NotImplementedError(f'tgm_amd TGAT supports up to {_native.TGAT_MAX_LAYERS} layers')
-        m = _native.TgatModel()
-        keep = []  # tensors the struct points into
+        skey = tuple((p.data_ptr(), p.dtype, p.is_contiguous(), tuple(p.shape)) for p in self.parameters())
+        st = getattr(self, '_desc_struct', None)
+        if st is None or st[0] != skey or getattr(self, '_desc_volatile', False):
+            self._desc_volatile = False
+            st = self._desc_struct = (skey,) + self._build_desc()
+        _, m, keep, jobs = st
+        for lo in range(0, len(jobs), _native.PACK_MAX_JOBS):
+            part = jobs[lo : lo + _native.PACK_MAX_JOBS]
+            arr = (_native.PackJob * len(part))(*part)
+            _native.check(_native.load().tgmx_pack2d(arr, len(part), _native.stream_ptr()), 'tgmx_pack2d')
+        self._desc_cache = (key, (m, keep))
+        self._desc_folded = False
+        return m, keep
 
-        def ptr(t: Tensor) -> int:
+    def _build_desc(self):
+        """The model struct, the tensors it points into, and the repacking jobs that fill the derived ones."""
+        m = _native.TgatModel()
+        keep, jobs = [], []  # tensors the struct points into; tgmx_pack_job_t entries
+
+        def f32(t: Tensor) -> Tensor:
+            """the parameter itself (fp32, contiguous: the normal case) -- anything else is converted once per optimizer step by
+            forcing a structural rebuild"""
             t = t.detach()
             if t.dtype != torch.float32 or not t.is_contiguous():
                 t = t.float().contiguous()
+                self._desc_volatile = True  # a converted copy goes stale with the parameter: rebuild at the next change
             keep.append(t)
-            return t.data_ptr()
+            return t
 
-        def padded(t: Tensor, cols: int) -> int:
-            """zero-padded copy [rows, cols] so that every row starts 16-byte aligned"""
-            t = t.detach().float()
-            out = torch.zeros((t.shape[0], cols), dtype=torch.float32, device=t.device)
-            out[:, : t.shape[1]] = t
+        def ptr(t: Tensor) -> int:
+            return f32(t).data_ptr()
+
+        def packed(src: Tensor, rows: int, cols: int, src_ld: int, dst: Tensor, dst_off: int, dst_rows: int, dst_cols: int, dst_ld: int,
+                   transpose: bool = False, src_off: int = 0) -> None:  # fmt: skip
+            jobs.append(_native.PackJob(src.data_ptr() + 4 * src_off, dst.data_ptr() + 4 * dst_off, src_ld, dst_ld, rows, cols, dst_rows, dst_cols,
+                                        int(transpose), 0))  # fmt: skip
+
+        def padded(t: Tensor, cols: int, row0: int = 0, rows: int = -1) -> int:
+            """zero-padded copy [rows, cols] of rows [row0, row0 + rows) so that every row starts 16-byte aligned"""
+            t = f32(t)
+            rows = t.shape[0] - row0 if rows < 0 else rows
+            out = torch.empty((rows, cols), dtype=torch.float32, device=t.device)
             keep.append(out)
+            packed(t, rows, t.shape[1], t.shape[1], out, 0, rows, cols, cols, src_off=row0 * t.shape[1])
             return out.data_ptr()
 
         p4 = lambda x: (x + 3) // 4 * 4
@@ -98,21 +128,19 @@ class TGAT(nn.Module):
             ly = m.layers[l]
             O, H, dh = attn.out_dim, attn.n_heads, attn.head_dim
             C = attn.node_dim + attn.edge_dim + attn.time_dim
-            WKV = attn.W_KV.weight.detach().float()
-            wkt = torch.zeros((C, H * p4(dh)), dtype=torch.float32, device=WKV.device)  # W_K^T, heads p4(dh) apart
-            for h in range(H):
-                wkt[:, h * p4(dh) : h * p4(dh) + dh] = WKV[h * dh : (h + 1) * dh].t()
+            WKV = f32(attn.W_KV.weight)  # [2 O, C]: keys, then values
+            wkt = torch.empty((C, H * p4(dh)), dtype=torch.float32, device=WKV.device)  # W_K^T, heads p4(dh) apart
             keep.append(wkt)
-            ly.W_Q, ly.W_K_t, ly.W_V = padded(attn.W_Q.weight, p4(O)), wkt.data_ptr(), padded(WKV[O:], p4(C))
+            for h in range(H):  # dst[c, j] = W_K[h dh + j, c]
+                packed(WKV, C, dh, C, wkt, h * p4(dh), C, p4(dh), H * p4(dh), transpose=True, src_off=h * dh * C)
+            ly.W_Q, ly.W_K_t, ly.W_V = padded(attn.W_Q.weight, p4(O)), wkt.data_ptr(), padded(WKV, p4(C), row0=O, rows=O)
             ly.W_O, ly.b_O = padded(attn.W_O.weight, p4(O)), ptr(attn.W_O.bias)
             ly.ln_g, ly.ln_b, ly.ln_eps = ptr(attn.layer_norm.weight), ptr(attn.layer_norm.bias), float(attn.layer_norm.eps)
             ly.fc1_w, ly.fc1_b = padded(merge.fc1.weight, p4(O + self.node_dim)), ptr(merge.fc1.bias)
             ly.fc2_w, ly.fc2_b = padded(merge.fc2.weight, p4(merge.fc1.out_features)), ptr(merge.fc2.bias)
             ly.d, ly.D, ly.T, ly.O, ly.H = attn.node_dim, attn.edge_dim, attn.time_dim, O, H
             ly.emb, ly.emb_out = merge.fc1.out_features, merge.fc2.out_features
-        self._desc_cache = (key, (m, keep))
-        self._desc_folded = False
-        return m, keep
+        return m, keep, jobs
 
     def _ensure_fold(self, m, keep) -> None:
         """Inference only: fold the query side of every layer onto the layer input (weights only; lives and dies
@@ -120,6 +148,7 @@ class TGAT(nn.Module):
         v_h = M_h[:, O-T:] cos(tb) -- computed with the native GEMM."""
         if self._desc_folded:
             return
+        keep = self._fold_keep = []  # (the struct's own tensors persist across refreshes; these are replaced with every fold)
         p4 = lambda x: (x + 3) // 4 * 4
         for l, attn in enumerate(self.attn):
             ly = m.layers[l]
