@@ -547,6 +547,26 @@ int tgmx_tgat_attn_backward(const float* qf, const float* probs, const float* dz
                             float* dnbr, float* dtime_rows, const tgmx_dropout_t* drop /* the forward's, NULL = off */,
                             tgmx_stream_t stream);
 
+/* ---- The whole TGAT backward as ONE call (round 3) ------------------------------------------------------------------------
+ * What tgm_amd/nn/_tgat_train.py composed from the building blocks above, launch by launch from Python (~100 ctypes calls and
+ * ~60 torch launches per step: the training step was host-bound), driven from C++ in the same order with the same kernels -- the
+ * gradients are bit-identical to the composed path (TGMX_TGAT_BWD=py keeps it for the tests), d tb to one rounding (its
+ * -sin(tb) * colsum term is evaluated by our kernel instead of torch's).  `saved` is the workspace of the
+ * tgmx_tgat_forward(..., save = 1) call with the same model / layout / hops; `dz` [S0, emb_out of the last layer] (row stride ldz);
+ * `drop` the forward's dropout block (model->drop at that call; NULL or p = 0: off).  Every gradient has its parameter's own
+ * shape, contiguous (W_KV: [2 O, C], keys then values; tw: [T]).  workspace: tgmx_tgat_backward_workspace_bytes(). */
+typedef struct tgmx_tgat_layer_grads {
+  float *W_Q, *W_KV, *W_O, *b_O, *ln_g, *ln_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+} tgmx_tgat_layer_grads_t;
+typedef struct tgmx_tgat_grads {
+  float *tw, *tb;
+  tgmx_tgat_layer_grads_t layers[TGMX_TGAT_MAX_LAYERS];
+} tgmx_tgat_grads_t;
+size_t tgmx_tgat_backward_workspace_bytes(const tgmx_tgat_model_t* model, const tgmx_tgat_layout_t* layout, const tgmx_tgat_hop_t* hops);
+int tgmx_tgat_backward(const tgmx_tgat_model_t* model, const tgmx_tgat_layout_t* layout, const tgmx_tgat_hop_t* hops,
+                       const float* saved, const float* dz, int64_t ldz, const tgmx_dropout_t* drop,
+                       const tgmx_tgat_grads_t* grads, float* workspace, size_t workspace_bytes, tgmx_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * TGN memory module (tgm/nn/encoder/tgn.py:80-251), forward arithmetic.
  * A node's stored events ("the events of the last batch in which it appeared",

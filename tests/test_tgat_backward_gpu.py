@@ -68,6 +68,35 @@ def test_tgat_parameter_gradients(case):
     assert min(w64[1], w32[1]) <= 1e-4, f'{case}: worst rel err vs fp64 {w64}, vs fp32 {w32}'
 
 
+@pytest.mark.parametrize('case,dropout', [('g5_tgat_small_nd8', 0.0), ('g5_tgat_small_nd8', 0.1), ('g5_tgat_example_dims', 0.1)])
+def test_one_call_backward_equals_the_composed_one(case, dropout, monkeypatch):
+    """``tgmx_tgat_backward`` (the whole backward as one native call) runs the kernels the Python composition launches one by one, in
+    its order: every parameter gradient is bit-identical, the Time2Vec bias to one rounding of a sine (``TGMX_TGAT_BWD=py`` selects the
+    composition)."""
+    from tgm_amd.nn import TGAT
+
+    meta, params, inputs, _ = gu.tgat_case(case)
+    dev = lambda v: [t.to(DEV) for t in v] if isinstance(v, list) else v.to(DEV)
+    args = {k: dev(v) for k, v in inputs.items()}
+
+    def grads(mode):
+        monkeypatch.setenv('TGMX_TGAT_BWD', mode)
+        torch.manual_seed(7)
+        enc = TGAT(edge_dim=meta['edge_dim'], num_layers=2, dropout=dropout, **meta['dims']).to(DEV).train()
+        enc.load_state_dict(params)
+        z = enc(**args)
+        z.backward(torch.cos(torch.arange(z.numel(), device=DEV, dtype=torch.float32)).view_as(z))
+        return z.detach().clone(), {n: p.grad.clone() for n, p in enc.named_parameters()}
+
+    (za, a), (zb, b) = grads('py'), grads('native')
+    assert torch.equal(za, zb) and a.keys() == b.keys() and len(a) == 22
+    diff = {n: float((a[n] - b[n]).abs().max()) for n in a if a[n].shape != b[n].shape or not torch.equal(a[n], b[n])}
+    # the one arithmetic difference: d tb -= sin(tb) * g evaluates sin in our kernel instead of torch's (<= 1 ulp of the term)
+    tb = diff.pop('time_encoder.w.bias', 0.0)
+    assert not diff and tb <= 4e-7 * float(a['time_encoder.w.bias'].abs().max()), (diff, tb)
+    assert all(float(v.abs().max()) > 0 for v in a.values())
+
+
 def _train_losses(make_opt, steps=40):
     from tgm_amd.nn import TGAT, invalidate_parameter_caches
 

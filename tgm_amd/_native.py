@@ -117,6 +117,14 @@ class TgatHop(ctypes.Structure):
     _fields_ = [('seed_t', c_void_p), ('nbr_id', c_void_p), ('nbr_t', c_void_p), ('edge_x', c_void_p), ('k', c_int32), ('nbr_eid', c_void_p), ('edge_table', c_void_p)]
 
 
+class TgatLayerGrads(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in ('W_Q', 'W_KV', 'W_O', 'b_O', 'ln_g', 'ln_b', 'fc1_w', 'fc1_b', 'fc2_w', 'fc2_b')]
+
+
+class TgatGrads(ctypes.Structure):
+    _fields_ = [('tw', c_void_p), ('tb', c_void_p), ('layers', TgatLayerGrads * TGAT_MAX_LAYERS)]
+
+
 PACK_MAX_JOBS = 32
 
 
@@ -258,9 +266,13 @@ SIGNATURES['tgmx_segment_sort_workspace_bytes'] = (c_size_t, [c_int64])
 SIGNATURES['tgmx_segment_sort'] = (c_int32, [_P, c_int64, c_int32, _P, _P, _P, _P, c_size_t, _P, _P])
 SIGNATURES['tgmx_tgat_tile16_floats'] = (c_size_t, [c_int32, c_int32])
 SIGNATURES['tgmx_tgat_tile16'] = (c_int32, [_P, c_int64, c_int32, c_int32, _P, _P])
-SIGNATURES['tgmx_pack2d'] = (c_int32, [_P, c_int32, _P])
+SIGNATURES['tgmx_pack2d'] = (c_int32, [ctypes.POINTER(PackJob), c_int32, _P])
+
 SIGNATURES['tgmx_tgat_layout'] = (c_int32, [ctypes.POINTER(TgatModel), c_int64, ctypes.POINTER(TgatHop), c_int32, ctypes.POINTER(TgatLayout)])
 SIGNATURES['tgmx_tgat_workspace_bytes'] = (c_size_t, [ctypes.POINTER(TgatModel), c_int64, ctypes.POINTER(TgatHop)])
+SIGNATURES['tgmx_tgat_backward_workspace_bytes'] = (c_size_t, [ctypes.POINTER(TgatModel), ctypes.POINTER(TgatLayout), ctypes.POINTER(TgatHop)])
+SIGNATURES['tgmx_tgat_backward'] = (c_int32, [ctypes.POINTER(TgatModel), ctypes.POINTER(TgatLayout), ctypes.POINTER(TgatHop), _P, _P, c_int64,
+                                              ctypes.POINTER(Dropout), ctypes.POINTER(TgatGrads), _P, c_size_t, _P])  # fmt: skip
 SIGNATURES['tgmx_tgat_forward'] = (
     c_int32,
     [ctypes.POINTER(TgatModel), _P, c_int64, _P, c_int64, ctypes.POINTER(TgatHop), _P, c_size_t, c_int32, _P, _P],

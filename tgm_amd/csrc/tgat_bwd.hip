@@ -456,3 +456,262 @@ extern "C" int tgmx_tgat_attn_backward(const float* qf, const float* probs, cons
   TGMX_CHECK_LAUNCH("tgat_attn_backward");
   return TGMX_OK;
 }
+
+// ---------------------------------------------------------------------------
+// The whole backward as one call: tgm_amd/nn/_tgat_train.py's composition, in its order, from C++.
+// ---------------------------------------------------------------------------
+namespace tgmx {
+// d_tb[c] -= sin(tb[c]) * g[c]  (the residual's time columns are cos(tb): rres = [x | 0 | cos(tb)]); two roundings, like the
+// torch expression it replaces (no contraction into an fma)
+__global__ __launch_bounds__(256) void time_bias_residual_kernel(float* __restrict__ d_tb, const float* __restrict__ tb,
+                                                                 const float* __restrict__ g, int T) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < T) d_tb[c] = __fsub_rn(d_tb[c], __fmul_rn(sinf(tb[c]), g[c]));
+}
+}  // namespace tgmx
+
+namespace {
+struct Bump {
+  float* base;
+  size_t off;
+  float* take(size_t n) {
+    const size_t p = off;
+    off += (n + 63) & ~(size_t)63;  // 256-byte granules
+    return base + p;
+  }
+};
+
+// One pass over the backward; dry: only the workspace layout is computed (floats needed -> *need_floats, sgemm_tn scratch bytes -> *tn_bytes)
+int tgat_backward_pass(const tgmx_tgat_model_t* m, const tgmx_tgat_layout_t* lay, const tgmx_tgat_hop_t* hops, const float* saved,
+                       const float* dz, long long ldz, const tgmx_dropout_t* drop, const tgmx_tgat_grads_t* g, float* ws, float* tn_ws,
+                       hipStream_t st, bool dry, size_t* need_floats, size_t* tn_bytes) {
+  const int L = m->num_layers, d0 = m->d0, T = m->layers[0].T;
+  const float p_drop = drop ? drop->p : 0.f;
+  static const tgmx_tgat_grads_t no_grads{};
+  if (!g) g = &no_grads;  // (dry pass: nothing below is dereferenced)
+  tgmx_stream_t stream = (tgmx_stream_t)st;
+  Bump b{ws, 0};
+  size_t tn_need = 0;
+  static const bool sync_each = getenv("TGMX_BWD_SYNC") != nullptr;  // diagnosis: name every step and wait for it
+  // (tn sizes its scratch in the dry pass: evaluated in both)
+#define RUN_ALWAYS(call)                                      \
+  do {                                                        \
+    if (!dry && sync_each) fprintf(stderr, "[bwd] %s\n", #call); \
+    const int rc_ = (call);                                   \
+    if (rc_) return rc_;                                      \
+    if (!dry && sync_each) (void)hipStreamSynchronize(st);    \
+  } while (0)
+#define RUN(call)                                             \
+  do {                                                        \
+    if (!dry) {                                               \
+      if (sync_each) fprintf(stderr, "[bwd] %s\n", #call);    \
+      const int rc_ = (call);                                 \
+      if (rc_) return rc_;                                    \
+      if (sync_each) (void)hipStreamSynchronize(st);          \
+    }                                                         \
+  } while (0)
+  auto tn = [&](const float* A, long long lda, const float* B, long long ldb, float* C, long long ldc, long long R, int M, int N, int batch,
+                long long sA, long long sB, long long sC) -> int {
+    const size_t need = tgmx_sgemm_tn_workspace_bytes(R, M, N, batch);
+    tn_need = need > tn_need ? need : tn_need;
+    if (dry) return TGMX_OK;
+    if (sync_each) fprintf(stderr, "[bwd]   tn R=%lld M=%d N=%d batch=%d need=%zu A=%p B=%p C=%p\n", R, M, N, batch, need, (const void*)A, (const void*)B, (void*)C);
+    return tgmx_sgemm_tn(A, lda, B, ldb, C, ldc, R, M, N, batch, sA, sB, sC, 0, tn_ws, stream);
+  };
+  auto nt = [&](const float* A, long long lda, const float* B, long long ldb, float* C, long long ldc, long long M, int N, int K, int batch,
+                long long sA, long long sB, long long sC) -> int {
+    if (dry) return TGMX_OK;
+    return tgmx_sgemm_nt(A, lda, B, ldb, C, ldc, M, N, K, nullptr, 0, batch, sA, sB, sC, stream);
+  };
+  float* cs_ws = b.take((size_t)256 * 2048);
+  auto colsum = [&](const float* X, long long ld, long long R, int C, float* out, int accumulate) -> int {
+    if (dry) return TGMX_OK;
+    if (C > 2048) {
+      tgmx::set_error("tgat_backward: %d columns (at most 2048)", C);
+      return TGMX_E_INVALID;
+    }
+    return tgmx_colsum(X, ld, R, C, out, accumulate, cs_ws, stream);
+  };
+  // ---- the weights in the layouts the NT GEMMs below read them in: one launch for all layers ----
+  struct LayerW {
+    float *F2_t, *F1_t, *WO_t, *WV_t, *WK_p, *WQ_t;
+  } W[TGMX_TGAT_MAX_LAYERS];
+  tgmx_pack_job_t jobs[TGMX_PACK_MAX_JOBS];
+  int n_jobs = 0;
+  auto job = [&](const float* src, long long src_ld, float* dst, long long dst_ld, int rows, int cols, int dst_rows, int dst_cols) -> int {
+    if (n_jobs == TGMX_PACK_MAX_JOBS) {
+      RUN(tgmx_pack2d(jobs, n_jobs, stream));
+      n_jobs = 0;
+    }
+    jobs[n_jobs++] = tgmx_pack_job_t{src, dst, src_ld, dst_ld, rows, cols, dst_rows, dst_cols, 1, 0};  // every one is a transpose
+    return TGMX_OK;
+  };
+  for (int l = 0; l < L; ++l) {
+    const tgmx_tgat_layer_t& ly = m->layers[l];
+    const tgmx_tgat_layer_layout_t& lo = lay->layers[l];
+    const int O = ly.O, H = ly.H, dh = O / H, C = ly.d + ly.D + ly.T, emb = ly.emb, emb_out = ly.emb_out;
+    const int Op = lo.Op, dhp = lo.dhp, Cp = lo.Cp, Kc = lo.Kc, Ep = lo.Ep;
+    LayerW& w = W[l];
+    w.F2_t = b.take((size_t)emb * emb_out);        // [emb, emb_out]      = fc2.weight^T
+    w.F1_t = b.take((size_t)(O + d0) * emb);       // [O + d0, emb]       = fc1.weight^T
+    w.WO_t = b.take((size_t)O * O);                // [O, O]              = W_O^T
+    w.WV_t = b.take((size_t)C * H * dhp);          // [C, H * dhp]        = W_V^T, heads dhp apart
+    w.WK_p = b.take((size_t)O * Cp);               // [O, Cp]             = W_K, rows padded
+    w.WQ_t = b.take((size_t)O * H * dhp);          // [O, H * dhp]        = W_Q^T, heads dhp apart
+    int rc = job(ly.fc2_w, Ep, w.F2_t, emb_out, emb, emb_out, emb, emb_out);
+    if (!rc) rc = job(ly.fc1_w, Kc, w.F1_t, emb, O + d0, emb, O + d0, emb);
+    if (!rc) rc = job(ly.W_O, Op, w.WO_t, O, O, O, O, O);
+    for (int h = 0; h < H && !rc; ++h) {
+      rc = job(ly.W_V + (long long)h * dh * Cp, Cp, w.WV_t + h * dhp, (long long)H * dhp, C, dh, C, dhp);
+      if (!rc) rc = job(ly.W_K_t + h * dhp, (long long)H * dhp, w.WK_p + (long long)h * dh * Cp, Cp, dh, C, dh, Cp);
+      if (!rc) rc = job(ly.W_Q + (long long)h * dh * Op, Op, w.WQ_t + h * dhp, (long long)H * dhp, O, dh, O, dhp);
+    }
+    if (rc) return rc;
+  }
+  if (n_jobs) RUN(tgmx_pack2d(jobs, n_jobs, stream));
+  if (!dry) {
+    (void)hipMemsetAsync(g->tw, 0, (size_t)T * sizeof(float), st);
+    (void)hipMemsetAsync(g->tb, 0, (size_t)T * sizeof(float), st);
+    if (sync_each) {
+      const hipError_t e = hipStreamSynchronize(st);
+      fprintf(stderr, "[bwd] memsets done (%s); ws=%p tn_ws=%p (+%zu floats) T=%d L=%d\n", hipGetErrorString(e), (void*)ws, (void*)tn_ws, (size_t)(tn_ws - ws), T, L);
+    }
+  }
+  const float* S = saved;
+  const float* z0 = S + lay->z0;
+  const float* dout = dz;
+  long long ld_dout = ldz;
+  for (int j = L; j >= 1; --j) {
+    const tgmx_tgat_layer_t& ly = m->layers[j - 1];
+    const tgmx_tgat_layer_layout_t& lo = lay->layers[j - 1];
+    const tgmx_tgat_layer_grads_t& gl = g->layers[j - 1];
+    const LayerW& w = W[j - 1];
+    const long long R = lo.R;
+    const int Op = lo.Op, dhp = lo.dhp, Cp = lo.Cp, Kc = lo.Kc, Ep = lo.Ep;
+    const int O = ly.O, H = ly.H, dh = O / H, d = ly.d, D = ly.D, C = d + D + T, emb = ly.emb, emb_out = ly.emb_out;
+    const int k = hops[j - 1].k, n_lvl = L - j + 1;
+    const float *rres = S + lo.rres, *oattn = S + lo.oattn, *y = S + lo.y, *Q = S + lo.Q, *qf = S + lo.qf, *zbar = S + lo.zbar;
+    const float *cat = S + lo.cat, *h1 = S + lo.h1, *probs = S + lo.probs;
+    const float* prev = j == 1 ? z0 : S + lay->layers[j - 2].out;  // [level_off[n_lvl + 1], d]
+    // ---- merge MLP ----
+    RUN_ALWAYS(tn(dout, ld_dout, h1, Ep, gl.fc2_w, emb, R, emb_out, emb, 1, 0, 0, 0));
+    RUN(colsum(dout, ld_dout, R, emb_out, gl.fc2_b, 0));
+    float* dh1 = b.take((size_t)R * Ep);
+    RUN(nt(dout, ld_dout, w.F2_t, emb_out, dh1, Ep, R, emb, emb_out, 1, 0, 0, 0));
+    RUN(tgmx_relu_mask(dh1, Ep, h1, Ep, R, emb, stream));
+    RUN_ALWAYS(tn(dh1, Ep, cat, Kc, gl.fc1_w, O + d0, R, emb, O + d0, 1, 0, 0, 0));
+    RUN(colsum(dh1, Ep, R, emb, gl.fc1_b, 0));
+    float* dcat = b.take((size_t)R * Kc);
+    RUN(nt(dh1, Ep, w.F1_t, emb, dcat, Kc, R, O + d0, emb, 1, 0, 0, 0));
+    // ---- LayerNorm(y + rres) ----
+    float* du = b.take((size_t)R * Op);
+    float* dgx = b.take((size_t)R * Op);
+    RUN(tgmx_ln_backward(dcat, Kc, y, Op, rres, Op, ly.ln_g, O, ly.ln_eps, R, du, Op, dgx, Op, stream));
+    RUN(colsum(dgx, Op, R, O, gl.ln_g, 0));
+    RUN(colsum(dcat, Kc, R, O, gl.ln_b, 0));
+    // ---- W_O (its output went through dropout: the gradient takes the same mask; the residual branch keeps the unmasked du) ----
+    float* du_y = du;
+    float* du_masked = b.take((size_t)R * Op);  // (taken with or without dropout: the layout does not depend on the call's arguments)
+    if (p_drop > 0.f) {
+      du_y = du_masked;
+      const tgmx_dropout_t site{p_drop, drop->seed, drop->stream * 64 + 2 * (uint64_t)j + 1, 0};
+      RUN(tgmx_dropout(du, Op, R, O, &site, du_y, Op, stream));
+    }
+    RUN_ALWAYS(tn(du_y, Op, oattn, Op, gl.W_O, O, R, O, O, 1, 0, 0, 0));
+    RUN(colsum(du_y, Op, R, O, gl.b_O, 0));
+    float* doattn = b.take((size_t)R * Op);
+    RUN(nt(du_y, Op, w.WO_t, O, doattn, Op, R, O, O, 1, 0, 0, 0));
+    // ---- W_V fold: oattn[:, head h] = zbar[:, h, :] @ W_V[head h]^T ----
+    float* g_WK = gl.W_KV;
+    float* g_WV = gl.W_KV + (long long)O * C;
+    RUN_ALWAYS(tn(doattn, Op, zbar, (long long)H * Cp, g_WV, C, R, dh, C, H, dh, Cp, (long long)dh * C));
+    float* dzbar = b.take((size_t)R * H * Cp);
+    RUN(nt(doattn, Op, w.WV_t, (long long)H * dhp, dzbar, (long long)H * Cp, R, C, dh, H, dh, dhp, Cp));
+    // ---- per-row attention backward, level by level ----
+    float* dqf = b.take((size_t)R * H * Cp);
+    float* dtime = b.take((size_t)R * 2 * T);
+    const bool need_dprev = j > 1;
+    const size_t prev_rows = (size_t)lay->level_off[n_lvl + 1];
+    float* dprev = need_dprev ? b.take(prev_rows * d) : nullptr;
+    if (need_dprev && !dry) (void)hipMemsetAsync(dprev, 0, prev_rows * d * sizeof(float), st);
+    const float scale = (float)pow((double)dh, -0.5);
+    for (int i = 0; i < n_lvl; ++i) {
+      const long long Ri = lay->level_rows[i];
+      if (!Ri) continue;
+      const long long o = lay->level_off[i], o1 = lay->level_off[i + 1];
+      const tgmx_dropout_t site{p_drop, drop ? drop->seed : 0, (drop ? drop->stream : 0) * 64 + 2 * (uint64_t)j, o};
+      RUN(tgmx_tgat_attn_backward(qf + o * H * Cp, probs + o * H * k, dzbar + o * H * Cp, prev + o1 * d, d, hops[i].edge_x, D, hops[i].seed_t,
+                                  hops[i].nbr_t, m->tw, m->tb, T, H, k, Ri, scale, Cp, dqf + o * H * Cp, need_dprev ? dprev + o1 * d : nullptr,
+                                  dtime + o * 2 * T, p_drop > 0.f ? &site : nullptr, stream));
+    }
+    RUN(colsum(dtime, 2 * T, R, T, g->tw, 1));
+    RUN(colsum(dtime + T, 2 * T, R, T, g->tb, 1));
+    // ---- W_K fold: qf[:, h, :] = Q[:, head h] @ W_K[head h] ----
+    RUN_ALWAYS(tn(Q, (long long)H * dhp, dqf, (long long)H * Cp, g_WK, C, R, dh, C, H, dhp, Cp, (long long)dh * C));
+    float* dQ = b.take((size_t)R * H * dhp);
+    if (!dry) (void)hipMemsetAsync(dQ, 0, (size_t)R * H * dhp * sizeof(float), st);
+    RUN(nt(dqf, (long long)H * Cp, w.WK_p, Cp, dQ, (long long)H * dhp, R, dh, C, H, Cp, (long long)dh * Cp, dhp));
+    // ---- W_Q: Q[:, head h] = rres @ W_Q[head h rows]^T ----
+    RUN_ALWAYS(tn(dQ, (long long)H * dhp, rres, Op, gl.W_Q, O, R, dh, O, H, dhp, 0, (long long)dh * O));
+    float* drres = b.take((size_t)R * Op);
+    RUN(nt(dQ, (long long)H * dhp, w.WQ_t, (long long)H * dhp, drres, Op, R, O, H * dhp, 1, 0, 0, 0));
+    RUN(tgmx_add_cols(drres, Op, du, Op, R, O, 1, stream));  // + the residual branch
+    // rres = [x | 0 | cos(tb)]:  d tb -= sin(tb) * colsum(drres[:, time columns]);  d x = drres[:, :d]
+    float* g_time_cols = b.take((size_t)T);
+    RUN(colsum(drres + (O - T), Op, R, T, g_time_cols, 0));
+    if (!dry) {
+      hipLaunchKernelGGL(tgmx::time_bias_residual_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, st, g->tb, m->tb, g_time_cols, T);
+      TGMX_CHECK_LAUNCH("tgat_backward");
+    }
+    if (need_dprev) RUN(tgmx_add_cols(dprev, d, drres, Op, R, d, 1, stream));
+    dout = dprev;
+    ld_dout = d;
+  }
+#undef RUN
+#undef RUN_ALWAYS
+  if (need_floats) *need_floats = b.off;
+  if (tn_bytes) *tn_bytes = tn_need;
+  return TGMX_OK;
+}
+
+int check_backward_args(const tgmx_tgat_model_t* m, const tgmx_tgat_layout_t* lay, const tgmx_tgat_hop_t* hops) {
+  TGMX_REQUIRE(m && lay && hops, "tgat_backward: null pointer");
+  const int L = m->num_layers;
+  TGMX_REQUIRE(L >= 1 && L <= TGMX_TGAT_MAX_LAYERS, "tgat_backward: num_layers=%d outside [1, %d]", L, TGMX_TGAT_MAX_LAYERS);
+  for (int l = 0; l < L; ++l) {
+    const tgmx_tgat_layer_t& ly = m->layers[l];
+    TGMX_REQUIRE(ly.T == m->layers[0].T && ly.H > 0 && ly.O % ly.H == 0 && ly.T <= ly.O, "tgat_backward: layer %d has an unsupported shape", l);
+    TGMX_REQUIRE(lay->layers[l].probs >= 0, "tgat_backward: the forward was not run with save = 1");
+  }
+  return TGMX_OK;
+}
+}  // namespace
+
+extern "C" size_t tgmx_tgat_backward_workspace_bytes(const tgmx_tgat_model_t* m, const tgmx_tgat_layout_t* lay, const tgmx_tgat_hop_t* hops) {
+  if (check_backward_args(m, lay, hops)) return 0;
+  size_t floats = 0, tn_bytes = 0;
+  if (tgat_backward_pass(m, lay, hops, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, true, &floats, &tn_bytes)) return 0;
+  return floats * sizeof(float) + ((tn_bytes + 255) & ~(size_t)255) + 512;
+}
+
+extern "C" int tgmx_tgat_backward(const tgmx_tgat_model_t* m, const tgmx_tgat_layout_t* lay, const tgmx_tgat_hop_t* hops, const float* saved,
+                                  const float* dz, int64_t ldz, const tgmx_dropout_t* drop, const tgmx_tgat_grads_t* grads, float* workspace,
+                                  size_t workspace_bytes, tgmx_stream_t stream) {
+  if (const int rc = check_backward_args(m, lay, hops)) return rc;
+  TGMX_REQUIRE(saved && dz && grads && workspace, "tgat_backward: null pointer");
+  TGMX_REQUIRE(grads->tw && grads->tb, "tgat_backward: null gradient pointer");
+  for (int l = 0; l < m->num_layers; ++l) {
+    const tgmx_tgat_layer_grads_t& gl = grads->layers[l];
+    TGMX_REQUIRE(gl.W_Q && gl.W_KV && gl.W_O && gl.b_O && gl.ln_g && gl.ln_b && gl.fc1_w && gl.fc1_b && gl.fc2_w && gl.fc2_b,
+                 "tgat_backward: null gradient pointer (layer %d)", l);
+  }
+  TGMX_REQUIRE(ldz >= m->layers[m->num_layers - 1].emb_out, "tgat_backward: ldz=%lld", (long long)ldz);
+  const size_t need = tgmx_tgat_backward_workspace_bytes(m, lay, hops);
+  TGMX_REQUIRE(need > 0 && workspace_bytes >= need, "tgat_backward: workspace too small (%zu of %zu bytes)", workspace_bytes, need);
+  size_t floats = 0, tn_bytes = 0;
+  (void)tgat_backward_pass(m, lay, hops, nullptr, nullptr, 0, drop, nullptr, nullptr, nullptr, nullptr, true, &floats, &tn_bytes);
+  float* base = reinterpret_cast<float*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  const float* S = reinterpret_cast<const float*>(((uintptr_t)saved + 255) & ~(uintptr_t)255);  // the forward aligns its workspace the same way
+  if (getenv("TGMX_BWD_SYNC")) fprintf(stderr, "[bwd] workspace %p, %zu bytes (need %zu): %zu floats + %zu tn bytes\n", (void*)workspace, workspace_bytes, need, floats, tn_bytes);
+  return tgat_backward_pass(m, lay, hops, S, dz, (long long)ldz, drop, grads, base, base + floats, (hipStream_t)stream, false, nullptr, nullptr);
+}

@@ -8,13 +8,18 @@ attention (``oracle/tgat_fold.py``), composed from the kernels of ``csrc/tgat_bw
     biases / LayerNorm / Time2Vec parameters -> ``tgmx_colsum``
     LayerNorm, ReLU, per-row attention backward -> dedicated kernels
 
+Round 3: the composition runs inside ONE native call (``tgmx_tgat_backward``: same kernels, same order, bit-identical
+gradients); the Python composition below stays as its readable specification and as the tests' cross-check
+(``TGMX_TGAT_BWD=py``).
+
 Gradients are produced for every parameter of the module (not for ``node_x`` or the sampled edge
 features, which are data).  Dropout (train mode): the forward call's ``tgmx_dropout_t`` (p, seed,
 stream) is kept on the context and the backward regenerates both masks of every layer from it.
 """
 from __future__ import annotations
 
-from typing import List
+import os
+from typing import List, Optional
 
 import torch
 from torch import Tensor
@@ -49,14 +54,55 @@ class TGATFunction(torch.autograd.Function):
             'tgmx_tgat_forward',
         )  # fmt: skip
         ctx.module, ctx.lay, ctx.ws, ctx.hop_tensors, ctx.ks, ctx.keep, ctx.S0 = module, lay, ws, hop_tensors, ks, keep, S0
+        ctx.hops = hops  # (points into hop_tensors, kept above)
         ctx.n_params = len(params)
         ctx.drop = (float(model.drop.p), int(model.drop.seed), int(model.drop.stream))  # the model block is shared: copy
         return out
 
     @staticmethod
     def backward(ctx, dz: Tensor):
-        grads = _backward(ctx, dz.contiguous().float())
+        composed = os.environ.get('TGMX_TGAT_BWD', '') == 'py'  # the launch-by-launch composition below (tests: same gradients)
+        grads = (_backward if composed else _backward_native)(ctx, dz.contiguous().float())
         return (None, None, None, None, None) + tuple(grads)
+
+
+_GRAD_FIELDS = {'W_Q.weight': 'W_Q', 'W_KV.weight': 'W_KV', 'W_O.weight': 'W_O', 'W_O.bias': 'b_O', 'layer_norm.weight': 'ln_g', 'layer_norm.bias': 'ln_b',
+                'fc1.weight': 'fc1_w', 'fc1.bias': 'fc1_b', 'fc2.weight': 'fc2_w', 'fc2.bias': 'fc2_b'}  # fmt: skip
+
+
+def _backward_native(ctx, dz: Tensor) -> List[Optional[Tensor]]:
+    """One native call: ``tgmx_tgat_backward`` runs what :func:`_backward` composes, in the same order with the same kernels."""
+    lib = _native.load()
+    module = ctx.module
+    dev = dz.device
+    model, _keep = module._model_desc()  # the forward's (parameters unchanged since: the cached block)
+    names = [n for n, _ in module.named_parameters()]
+    params = [p for _, p in module.named_parameters()]
+    sizes = [(p.numel() + 63) // 64 * 64 for p in params]
+    flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+    views, off = {}, 0
+    for n, p, sz in zip(names, params, sizes):
+        views[n] = flat[off : off + p.numel()].view(p.shape)
+        off += sz
+    g = _native.TgatGrads()
+    g.tw, g.tb = views['time_encoder.w.weight'].data_ptr(), views['time_encoder.w.bias'].data_ptr()
+    for n, v in views.items():
+        head, _, rest = n.partition('.')
+        if head in ('attn', 'merge_layers'):
+            idx, _, leaf = rest.partition('.')
+            setattr(g.layers[int(idx)], _GRAD_FIELDS[leaf], v.data_ptr())
+    drop_p, drop_seed, drop_stream = ctx.drop
+    drop = _native.Dropout(float(drop_p), drop_seed & 0xFFFFFFFFFFFFFFFF, drop_stream & 0xFFFFFFFFFFFFFFFF, 0)
+    need = int(lib.tgmx_tgat_backward_workspace_bytes(model, ctx.lay, ctx.hops))
+    if need == 0:
+        _native.check(-1, 'tgmx_tgat_backward_workspace_bytes')
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    _native.check(
+        lib.tgmx_tgat_backward(model, ctx.lay, ctx.hops, ctx.ws.data_ptr(), dz.data_ptr(), dz.stride(0), drop, g, ws.data_ptr(), need,
+                               _native.stream_ptr()),
+        'tgmx_tgat_backward',
+    )  # fmt: skip
+    return [views[n].to(p.dtype) if p.requires_grad else None for n, p in zip(names, params)]
 
 
 def _backward(ctx, dz: Tensor) -> List[Tensor]:
