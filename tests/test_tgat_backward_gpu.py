@@ -97,6 +97,40 @@ def test_one_call_backward_equals_the_composed_one(case, dropout, monkeypatch):
     assert all(float(v.abs().max()) > 0 for v in a.values())
 
 
+def test_one_call_backward_at_the_headline_shape(monkeypatch):
+    """600 seeds, k = [20, 20] (12 600 attention rows in layer 1: the weight-gradient GEMMs' split partials are megabytes -- a
+    scratch area sized for the golden cases only would be overrun here): native == composed, sampler outputs from the HIP sampler."""
+    from tgm_amd import DGData, DGDataLoader, DGraph
+    from tgm_amd.hooks import HookManager, RandomNegativeEdgeSamplerHook, RecencyNeighborHook
+    from tgm_amd.nn import TGAT
+    from tgm_amd.synth import make_stream
+
+    st = make_stream('wiki', seed=11, num_edges=30_000)
+    dg = DGraph(DGData.from_raw(st.ts, torch.stack([st.src, st.dst], 1), st.edge_x, static_node_x=st.node_x), device=DEV)
+    hm = HookManager(keys=['k'])
+    hm.register('k', RandomNegativeEdgeSamplerHook(8227, st.num_nodes, seed=3))
+    hm.register('k', RecencyNeighborHook(st.num_nodes, [20, 20], ['edge_src', 'edge_dst', 'neg'], ['edge_time', 'edge_time', 'neg_time']))
+    with hm.activate('k'):
+        for b, batch in enumerate(DGDataLoader(dg, batch_size=200, hook_manager=hm, output_pool=0)):
+            if b == 120:
+                break
+    args = (dg.static_node_x, batch.seed_nids, batch.seed_times, batch.nbr_nids, batch.nbr_edge_x, batch.nbr_edge_time)
+
+    def grads(mode):
+        monkeypatch.setenv('TGMX_TGAT_BWD', mode)
+        torch.manual_seed(7)
+        enc = TGAT(node_dim=1, edge_dim=172, time_dim=100, embed_dim=172, num_layers=2).to(DEV).train()  # the reference-default dropout 0.1
+        z = enc(*args)
+        ((z[:200] * z[200:400]).sum(-1).sigmoid().mean() - (z[:200] * z[400:]).sum(-1).sigmoid().mean()).backward()
+        return {n: p.grad.clone() for n, p in enc.named_parameters()}
+
+    a, b = grads('py'), grads('native')
+    diff = {n: float((a[n] - b[n]).abs().max()) for n in a if not torch.equal(a[n], b[n])}
+    tb = diff.pop('time_encoder.w.bias', 0.0)
+    assert not diff and tb <= 4e-7 * float(a['time_encoder.w.bias'].abs().max()), (diff, tb)
+    assert all(torch.isfinite(v).all() and float(v.abs().max()) > 0 for v in b.values())
+
+
 def _train_losses(make_opt, steps=40):
     from tgm_amd.nn import TGAT, invalidate_parameter_caches
 

@@ -468,7 +468,69 @@ __global__ __launch_bounds__(256) void time_bias_residual_kernel(float* __restri
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c < T) d_tb[c] = __fsub_rn(d_tb[c], __fmul_rn(sinf(tb[c]), g[c]));
 }
+
+// ---- every split reduction of a layer's backward in two launches ----
+// The composed path follows each weight-gradient GEMM with its own reduce_partials launch and runs two launches per bias /
+// LayerNorm / Time2Vec column sum: 25 launches per layer, 5-9 us each on a handful of CUs.  Here the GEMMs only leave their split
+// partials behind; at the end of the layer ONE launch forms all the column sums' partials and ONE reduces everything, each job
+// with the arithmetic (split counts, summation order) of the kernels above: bit-identical results.
+constexpr int kBatchJobs = 48;
+struct ReduceJob {
+  const float* partial;
+  float* out;
+  long long ldo;
+  int splits, M, N, accumulate;
+};
+struct ReduceJobs {
+  ReduceJob job[kBatchJobs];
+};
+__global__ __launch_bounds__(256) void reduce_batch_kernel(const ReduceJobs J) {
+  const ReduceJob j = J.job[blockIdx.y];
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long MN = (long long)j.M * j.N;
+  if (e >= MN) return;
+  const float* p = j.partial + e;
+  float acc = 0.f;
+  for (int s = 0; s < j.splits; s += 8) {  // as reduce_partials_kernel
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = s + u < j.splits ? p[(long long)(s + u) * MN] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += v[u];
+  }
+  const int m = (int)(e / j.N), n = (int)(e - (long long)m * j.N);
+  float* o = j.out + (long long)m * j.ldo + n;
+  *o = j.accumulate ? *o + acc : acc;
+}
+struct ColsumJob {
+  const float* in;
+  float* partial;
+  long long ld, R, rows_per_split;
+  int C, splits;
+};
+struct ColsumJobs {
+  ColsumJob job[kBatchJobs];
+};
+__global__ __launch_bounds__(256) void colsum_batch_kernel(const ColsumJobs J) {
+  const ColsumJob j = J.job[blockIdx.z];
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= j.C || (int)blockIdx.y >= j.splits) return;
+  const long long r0 = (long long)blockIdx.y * j.rows_per_split;
+  long long r1 = r0 + j.rows_per_split;
+  if (r1 > j.R) r1 = j.R;
+  float acc = 0.f;
+  for (long long r = r0; r < r1; r += 8) {  // as colsum_partial_kernel
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = r + u < r1 ? j.in[(r + u) * j.ld + c] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += v[u];
+  }
+  j.partial[(long long)blockIdx.y * j.C + c] = acc;
+}
 }  // namespace tgmx
+
+static int pick_splits(long long R, long long tiles);
 
 namespace {
 struct Bump {
@@ -491,7 +553,6 @@ int tgat_backward_pass(const tgmx_tgat_model_t* m, const tgmx_tgat_layout_t* lay
   if (!g) g = &no_grads;  // (dry pass: nothing below is dereferenced)
   tgmx_stream_t stream = (tgmx_stream_t)st;
   Bump b{ws, 0};
-  size_t tn_need = 0;
   static const bool sync_each = getenv("TGMX_BWD_SYNC") != nullptr;  // diagnosis: name every step and wait for it
   // (tn sizes its scratch in the dry pass: evaluated in both)
 #define RUN_ALWAYS(call)                                      \
@@ -510,27 +571,76 @@ int tgat_backward_pass(const tgmx_tgat_model_t* m, const tgmx_tgat_layout_t* lay
       if (sync_each) (void)hipStreamSynchronize(st);          \
     }                                                         \
   } while (0)
+  static const bool batched = !(getenv("TGMX_BWD_BATCH") && atoi(getenv("TGMX_BWD_BATCH")) == 0);  // A/B knob (0: a reduction launch per job)
+  tgmx::ReduceJobs rj;
+  tgmx::ColsumJobs cj;
+  int n_rj = 0, n_cj = 0;
+  long long rj_most = 0;
+  int cj_wide = 0, cj_splits = 0;
+  // the column sums' partials, then every reduction queued so far
+  auto flush = [&]() -> int {
+    if (!dry) {
+      if (n_cj) {
+        hipLaunchKernelGGL(tgmx::colsum_batch_kernel, dim3((unsigned)((cj_wide + 255) / 256), (unsigned)cj_splits, (unsigned)n_cj), dim3(256), 0, st, cj);
+        TGMX_CHECK_LAUNCH("tgat_backward (column sums)");
+      }
+      if (n_rj) {
+        hipLaunchKernelGGL(tgmx::reduce_batch_kernel, dim3((unsigned)((rj_most + 255) / 256), (unsigned)n_rj), dim3(256), 0, st, rj);
+        TGMX_CHECK_LAUNCH("tgat_backward (reductions)");
+      }
+      if (sync_each) (void)hipStreamSynchronize(st);
+    }
+    n_rj = n_cj = 0;
+    rj_most = 0;
+    cj_wide = cj_splits = 0;
+    return TGMX_OK;
+  };
+  auto queue_reduce = [&](const float* partial, int splits, int M, int N, float* out, long long ldo, int accumulate) -> int {
+    if (n_rj == tgmx::kBatchJobs) {
+      const int rc = flush();
+      if (rc) return rc;
+    }
+    rj.job[n_rj++] = tgmx::ReduceJob{partial, out, ldo, splits, M, N, accumulate};
+    rj_most = (long long)M * N > rj_most ? (long long)M * N : rj_most;
+    return batched ? TGMX_OK : flush();
+  };
+  // C[b] = A[b]^T B[b]: the split partials now (tgmx_sgemm_tn's kernel and split count), the reduction with the layer's others
   auto tn = [&](const float* A, long long lda, const float* B, long long ldb, float* C, long long ldc, long long R, int M, int N, int batch,
                 long long sA, long long sB, long long sC) -> int {
-    const size_t need = tgmx_sgemm_tn_workspace_bytes(R, M, N, batch);
-    tn_need = need > tn_need ? need : tn_need;
-    if (dry) return TGMX_OK;
-    if (sync_each) fprintf(stderr, "[bwd]   tn R=%lld M=%d N=%d batch=%d need=%zu A=%p B=%p C=%p\n", R, M, N, batch, need, (const void*)A, (const void*)B, (void*)C);
-    return tgmx_sgemm_tn(A, lda, B, ldb, C, ldc, R, M, N, batch, sA, sB, sC, 0, tn_ws, stream);
+    const long long tiles = (long long)((M + 31) / 32) * ((N + 63) / 64) * batch;
+    const int splits = R > 0 ? pick_splits(R, tiles) : 1;
+    float* partial = b.take((size_t)splits * M * N * batch);
+    if (!dry) {
+      tgmx::GemmTnArgs g{A, B, partial, lda, ldb, sA, sB, R, R > 0 ? (R + splits - 1) / splits : 0, M, N, splits};
+      g.rows_per_split = (g.rows_per_split + 7) / 8 * 8;
+      hipLaunchKernelGGL(tgmx::sgemm_tn_kernel, dim3((unsigned)((M + 127) / 128), (unsigned)((N + 63) / 64), (unsigned)(batch * splits)), dim3(256), 0, st, g);
+      TGMX_CHECK_LAUNCH("tgat_backward (weight gradient)");
+    }
+    for (int bi = 0; bi < batch; ++bi) {
+      const int rc = queue_reduce(partial + (long long)bi * splits * M * N, splits, M, N, C + (long long)bi * sC, ldc, 0);
+      if (rc) return rc;
+    }
+    return TGMX_OK;
   };
   auto nt = [&](const float* A, long long lda, const float* B, long long ldb, float* C, long long ldc, long long M, int N, int K, int batch,
                 long long sA, long long sB, long long sC) -> int {
     if (dry) return TGMX_OK;
     return tgmx_sgemm_nt(A, lda, B, ldb, C, ldc, M, N, K, nullptr, 0, batch, sA, sB, sC, stream);
   };
-  float* cs_ws = b.take((size_t)256 * 2048);
+  // out[c] (+)= sum_r X[r, c]: queued (tgmx_colsum's split count); X must stay as it is until the layer's flush
   auto colsum = [&](const float* X, long long ld, long long R, int C, float* out, int accumulate) -> int {
-    if (dry) return TGMX_OK;
-    if (C > 2048) {
-      tgmx::set_error("tgat_backward: %d columns (at most 2048)", C);
-      return TGMX_E_INVALID;
+    int splits = (int)((R + 63) / 64);
+    if (splits > 256) splits = 256;
+    if (splits < 1) splits = 1;
+    float* partial = b.take((size_t)splits * C);
+    if (n_cj == tgmx::kBatchJobs) {
+      const int rc = flush();
+      if (rc) return rc;
     }
-    return tgmx_colsum(X, ld, R, C, out, accumulate, cs_ws, stream);
+    cj.job[n_cj++] = tgmx::ColsumJob{X, partial, ld, R, (R + splits - 1) / splits, C, splits};
+    cj_wide = C > cj_wide ? C : cj_wide;
+    cj_splits = splits > cj_splits ? splits : cj_splits;
+    return queue_reduce(partial, splits, 1, C, out, (long long)C, accumulate);
   };
   // ---- the weights in the layouts the NT GEMMs below read them in: one launch for all layers ----
   struct LayerW {
@@ -595,20 +705,20 @@ int tgat_backward_pass(const tgmx_tgat_model_t* m, const tgmx_tgat_layout_t* lay
     const float* prev = j == 1 ? z0 : S + lay->layers[j - 2].out;  // [level_off[n_lvl + 1], d]
     // ---- merge MLP ----
     RUN_ALWAYS(tn(dout, ld_dout, h1, Ep, gl.fc2_w, emb, R, emb_out, emb, 1, 0, 0, 0));
-    RUN(colsum(dout, ld_dout, R, emb_out, gl.fc2_b, 0));
+    RUN_ALWAYS(colsum(dout, ld_dout, R, emb_out, gl.fc2_b, 0));
     float* dh1 = b.take((size_t)R * Ep);
     RUN(nt(dout, ld_dout, w.F2_t, emb_out, dh1, Ep, R, emb, emb_out, 1, 0, 0, 0));
     RUN(tgmx_relu_mask(dh1, Ep, h1, Ep, R, emb, stream));
     RUN_ALWAYS(tn(dh1, Ep, cat, Kc, gl.fc1_w, O + d0, R, emb, O + d0, 1, 0, 0, 0));
-    RUN(colsum(dh1, Ep, R, emb, gl.fc1_b, 0));
+    RUN_ALWAYS(colsum(dh1, Ep, R, emb, gl.fc1_b, 0));
     float* dcat = b.take((size_t)R * Kc);
     RUN(nt(dh1, Ep, w.F1_t, emb, dcat, Kc, R, O + d0, emb, 1, 0, 0, 0));
     // ---- LayerNorm(y + rres) ----
     float* du = b.take((size_t)R * Op);
     float* dgx = b.take((size_t)R * Op);
     RUN(tgmx_ln_backward(dcat, Kc, y, Op, rres, Op, ly.ln_g, O, ly.ln_eps, R, du, Op, dgx, Op, stream));
-    RUN(colsum(dgx, Op, R, O, gl.ln_g, 0));
-    RUN(colsum(dcat, Kc, R, O, gl.ln_b, 0));
+    RUN_ALWAYS(colsum(dgx, Op, R, O, gl.ln_g, 0));
+    RUN_ALWAYS(colsum(dcat, Kc, R, O, gl.ln_b, 0));
     // ---- W_O (its output went through dropout: the gradient takes the same mask; the residual branch keeps the unmasked du) ----
     float* du_y = du;
     float* du_masked = b.take((size_t)R * Op);  // (taken with or without dropout: the layout does not depend on the call's arguments)
@@ -618,7 +728,7 @@ int tgat_backward_pass(const tgmx_tgat_model_t* m, const tgmx_tgat_layout_t* lay
       RUN(tgmx_dropout(du, Op, R, O, &site, du_y, Op, stream));
     }
     RUN_ALWAYS(tn(du_y, Op, oattn, Op, gl.W_O, O, R, O, O, 1, 0, 0, 0));
-    RUN(colsum(du_y, Op, R, O, gl.b_O, 0));
+    RUN_ALWAYS(colsum(du_y, Op, R, O, gl.b_O, 0));
     float* doattn = b.take((size_t)R * Op);
     RUN(nt(du_y, Op, w.WO_t, O, doattn, Op, R, O, O, 1, 0, 0, 0));
     // ---- W_V fold: oattn[:, head h] = zbar[:, h, :] @ W_V[head h]^T ----
@@ -644,8 +754,8 @@ int tgat_backward_pass(const tgmx_tgat_model_t* m, const tgmx_tgat_layout_t* lay
                                   hops[i].nbr_t, m->tw, m->tb, T, H, k, Ri, scale, Cp, dqf + o * H * Cp, need_dprev ? dprev + o1 * d : nullptr,
                                   dtime + o * 2 * T, p_drop > 0.f ? &site : nullptr, stream));
     }
-    RUN(colsum(dtime, 2 * T, R, T, g->tw, 1));
-    RUN(colsum(dtime + T, 2 * T, R, T, g->tb, 1));
+    RUN_ALWAYS(colsum(dtime, 2 * T, R, T, g->tw, 1));
+    RUN_ALWAYS(colsum(dtime + T, 2 * T, R, T, g->tb, 1));
     // ---- W_K fold: qf[:, h, :] = Q[:, head h] @ W_K[head h] ----
     RUN_ALWAYS(tn(Q, (long long)H * dhp, dqf, (long long)H * Cp, g_WK, C, R, dh, C, H, dhp, Cp, (long long)dh * C));
     float* dQ = b.take((size_t)R * H * dhp);
@@ -658,7 +768,8 @@ int tgat_backward_pass(const tgmx_tgat_model_t* m, const tgmx_tgat_layout_t* lay
     RUN(tgmx_add_cols(drres, Op, du, Op, R, O, 1, stream));  // + the residual branch
     // rres = [x | 0 | cos(tb)]:  d tb -= sin(tb) * colsum(drres[:, time columns]);  d x = drres[:, :d]
     float* g_time_cols = b.take((size_t)T);
-    RUN(colsum(drres + (O - T), Op, R, T, g_time_cols, 0));
+    RUN_ALWAYS(colsum(drres + (O - T), Op, R, T, g_time_cols, 0));
+    RUN_ALWAYS(flush());  // every split reduction of this layer: two launches
     if (!dry) {
       hipLaunchKernelGGL(tgmx::time_bias_residual_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, st, g->tb, m->tb, g_time_cols, T);
       TGMX_CHECK_LAUNCH("tgat_backward");
@@ -670,7 +781,7 @@ int tgat_backward_pass(const tgmx_tgat_model_t* m, const tgmx_tgat_layout_t* lay
 #undef RUN
 #undef RUN_ALWAYS
   if (need_floats) *need_floats = b.off;
-  if (tn_bytes) *tn_bytes = tn_need;
+  if (tn_bytes) *tn_bytes = 0;  // (the GEMMs' partials live in the bump area: they outlive the GEMM until the layer's flush)
   return TGMX_OK;
 }
 
