@@ -27,13 +27,14 @@ struct GemmTnArgs {
   int M, N, splits;
 };
 
-__global__ __launch_bounds__(256) void sgemm_tn_kernel(const GemmTnArgs g) {
+// workgroup (bx, by, bz) of the grid [ceil(M / 128), ceil(N / 64), batch * splits]
+__device__ __forceinline__ void sgemm_tn_block(const GemmTnArgs& g, int bx, int by, int bz) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 31, half = lane >> 5;
-  const int batch = blockIdx.z / g.splits, split = blockIdx.z - batch * g.splits;
-  const int m0 = (blockIdx.x * 4 + wave) * 32;
+  const int batch = bz / g.splits, split = bz - batch * g.splits;
+  const int m0 = (bx * 4 + wave) * 32;
   if (m0 >= g.M) return;
-  const int n0 = blockIdx.y * 64;
+  const int n0 = by * 64;
   const float* __restrict__ A = g.A + (long long)batch * g.sA;
   const float* __restrict__ B = g.B + (long long)batch * g.sB;
   const long long r0 = (long long)split * g.rows_per_split;
@@ -73,6 +74,25 @@ __global__ __launch_bounds__(256) void sgemm_tn_kernel(const GemmTnArgs g) {
       if (col < g.N) P[(long long)row * g.N + col] = t ? acc1[rg] : acc0[rg];
     }
   }
+}
+
+__global__ __launch_bounds__(256) void sgemm_tn_kernel(const GemmTnArgs g) { sgemm_tn_block(g, blockIdx.x, blockIdx.y, blockIdx.z); }
+
+// several independent A^T B products as ONE launch (a layer's weight gradients: each alone is 500-700 workgroups of one
+// dependent MFMA chain per wave -- 20-30 us of latency on a third of the chip; together they fill it)
+constexpr int kTnJobs = 16;
+struct GemmTnJobs {
+  GemmTnArgs job[kTnJobs];
+  int first_block[kTnJobs + 1];  // prefix sums of the jobs' workgroup counts
+  int gx[kTnJobs], gy[kTnJobs];
+  int n;
+};
+__global__ __launch_bounds__(256) void sgemm_tn_batch_kernel(const GemmTnJobs J) {
+  int j = 0;
+  while (j + 1 < J.n && (int)blockIdx.x >= J.first_block[j + 1]) ++j;
+  const int local = (int)blockIdx.x - J.first_block[j];
+  const int bx = local % J.gx[j], rest = local / J.gx[j];
+  sgemm_tn_block(J.job[j], bx, rest % J.gy[j], rest / J.gy[j]);
 }
 
 // out[b][m * ldo + n] (+)= sum_s partial[b][s][m][n]   (fixed summation order: deterministic)
@@ -574,12 +594,19 @@ int tgat_backward_pass(const tgmx_tgat_model_t* m, const tgmx_tgat_layout_t* lay
   static const bool batched = !(getenv("TGMX_BWD_BATCH") && atoi(getenv("TGMX_BWD_BATCH")) == 0);  // A/B knob (0: a reduction launch per job)
   tgmx::ReduceJobs rj;
   tgmx::ColsumJobs cj;
+  tgmx::GemmTnJobs tj;
+  tj.n = 0;
+  tj.first_block[0] = 0;
   int n_rj = 0, n_cj = 0;
   long long rj_most = 0;
   int cj_wide = 0, cj_splits = 0;
   // the column sums' partials, then every reduction queued so far
   auto flush = [&]() -> int {
     if (!dry) {
+      if (tj.n) {
+        hipLaunchKernelGGL(tgmx::sgemm_tn_batch_kernel, dim3((unsigned)tj.first_block[tj.n]), dim3(256), 0, st, tj);
+        TGMX_CHECK_LAUNCH("tgat_backward (weight gradients)");
+      }
       if (n_cj) {
         hipLaunchKernelGGL(tgmx::colsum_batch_kernel, dim3((unsigned)((cj_wide + 255) / 256), (unsigned)cj_splits, (unsigned)n_cj), dim3(256), 0, st, cj);
         TGMX_CHECK_LAUNCH("tgat_backward (column sums)");
@@ -591,6 +618,7 @@ int tgat_backward_pass(const tgmx_tgat_model_t* m, const tgmx_tgat_layout_t* lay
       if (sync_each) (void)hipStreamSynchronize(st);
     }
     n_rj = n_cj = 0;
+    tj.n = 0;
     rj_most = 0;
     cj_wide = cj_splits = 0;
     return TGMX_OK;
@@ -610,11 +638,19 @@ int tgat_backward_pass(const tgmx_tgat_model_t* m, const tgmx_tgat_layout_t* lay
     const long long tiles = (long long)((M + 31) / 32) * ((N + 63) / 64) * batch;
     const int splits = R > 0 ? pick_splits(R, tiles) : 1;
     float* partial = b.take((size_t)splits * M * N * batch);
-    if (!dry) {
+    if (tj.n == tgmx::kTnJobs || n_rj + batch > tgmx::kBatchJobs) {
+      const int rc = flush();
+      if (rc) return rc;
+    }
+    {  // queued: A and B must stay as they are until the layer's flush (they do: see the call sites)
       tgmx::GemmTnArgs g{A, B, partial, lda, ldb, sA, sB, R, R > 0 ? (R + splits - 1) / splits : 0, M, N, splits};
       g.rows_per_split = (g.rows_per_split + 7) / 8 * 8;
-      hipLaunchKernelGGL(tgmx::sgemm_tn_kernel, dim3((unsigned)((M + 127) / 128), (unsigned)((N + 63) / 64), (unsigned)(batch * splits)), dim3(256), 0, st, g);
-      TGMX_CHECK_LAUNCH("tgat_backward (weight gradient)");
+      const int gx = (M + 127) / 128, gy = (N + 63) / 64;
+      tj.job[tj.n] = g;
+      tj.gx[tj.n] = gx;
+      tj.gy[tj.n] = gy;
+      tj.first_block[tj.n + 1] = tj.first_block[tj.n] + gx * gy * batch * splits;
+      ++tj.n;
     }
     for (int bi = 0; bi < batch; ++bi) {
       const int rc = queue_reduce(partial + (long long)bi * splits * M * N, splits, M, N, C + (long long)bi * sC, ldc, 0);
