@@ -23,6 +23,9 @@ tools/gpu_profile_r3.sh comment_csr lookup_tile 100 --workload comment --mode cs
 tools/gpu_profile_r3.sh comment_ring lookup_tile 100 --workload comment
 for f in dense by_id; do timeout 300 python tools/bench_tgat.py 200 $f 2>/dev/null | j > "$OUT/r03_bench_tgat_$f.json"; done
 timeout 300 python tools/bench_tgn.py 400 2>/dev/null | j > "$OUT/r03_bench_tgn.json"
+timeout 300 python tools/bench_tgat_train.py 200 2>/dev/null | j > "$OUT/r03_bench_tgat_train.json"
+TGMX_TGAT_BWD=py timeout 300 python tools/bench_tgat_train.py 200 2>/dev/null | j > "$OUT/r03_bench_tgat_train_composed_backward.json"
+tools/gpu_trace_cmd.sh train 40 python $ROOT/tools/bench_tgat_train.py 60 > "$OUT/r03_tgat_train_rocprof_summary.md" 2>/dev/null
 rm -f "$OUT/r03_tgat_parity_stats.jsonl"
 TGMX_PARITY_STATS="$OUT/r03_tgat_parity_stats.jsonl" timeout 900 python -m pytest tests/test_tgat_gpu.py -q -m gpu -k "reference or headline" > "$OUT/r03_tgat_parity_pytest.log" 2>&1
 timeout 1200 python tools/scaling_model.py > "$OUT/scaling_model.log" 2>&1; cp profiles/r03_scaling_model.json "$OUT/" 2>/dev/null
