@@ -8,12 +8,14 @@ never sees its own updates.  The key therefore also carries a process-wide count
 any optimizer, any parameter group).  What is still invisible: writes through ``p.data`` (its own version counter) -- code that
 does that calls :func:`invalidate_parameter_caches`.
 """
-from typing import Iterable, Tuple
+from typing import Iterable, Tuple, Union
 
 import torch
+from torch.nn.modules.module import register_module_parameter_registration_hook
 from torch.optim.optimizer import register_optimizer_step_post_hook
 
 _epoch = 0
+_registrations = 0  # bumped whenever ANY module registers a parameter (construction, setattr, load_state_dict(assign=True))
 
 
 def _after_step(optimizer, args, kwargs) -> None:
@@ -24,11 +26,30 @@ def _after_step(optimizer, args, kwargs) -> None:
 register_optimizer_step_post_hook(_after_step)
 
 
+def _on_registration(module, name, param) -> None:
+    global _registrations
+    _registrations += 1
+
+
+register_module_parameter_registration_hook(_on_registration)
+
+
+def param_list(module: torch.nn.Module) -> Tuple[torch.Tensor, ...]:
+    """``tuple(module.parameters())``, cached on the module: walking the module tree costs ~20 us, several times per batch on the TGN
+    path.  The cache is dropped when any module registers a parameter (``.to()`` / ``load_state_dict`` keep the Parameter objects)."""
+    cached = module.__dict__.get('_tgmx_plist')
+    if cached is None or cached[0] != _registrations:
+        cached = module.__dict__['_tgmx_plist'] = (_registrations, tuple(module.parameters()))
+    return cached[1]
+
+
 def invalidate_parameter_caches() -> None:
     """Drop every cached derived copy of any module's weights (after in-place writes autograd cannot see, e.g. ``p.data.mul_()``)."""
     global _epoch
     _epoch += 1
 
 
-def param_key(params: Iterable[torch.Tensor]) -> Tuple:
+def param_key(params: Union[torch.nn.Module, Iterable[torch.Tensor]]) -> Tuple:
+    if isinstance(params, torch.nn.Module):
+        params = param_list(params)
     return (_epoch,) + tuple((p.data_ptr(), p._version) for p in params)

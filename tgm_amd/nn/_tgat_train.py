@@ -25,6 +25,7 @@ import torch
 from torch import Tensor
 
 from .. import _native
+from ._paramver import param_list
 
 
 def _p4(x: int) -> int:
@@ -76,21 +77,26 @@ def _backward_native(ctx, dz: Tensor) -> List[Optional[Tensor]]:
     module = ctx.module
     dev = dz.device
     model, _keep = module._model_desc()  # the forward's (parameters unchanged since: the cached block)
-    names = [n for n, _ in module.named_parameters()]
-    params = [p for _, p in module.named_parameters()]
-    sizes = [(p.numel() + 63) // 64 * 64 for p in params]
+    params = param_list(module)
+    plan = module.__dict__.get('_tgmx_grad_plan')
+    if plan is None or plan[0] is not params:  # names, padded sizes and struct fields: once per parameter set
+        names = [n for n, _ in module.named_parameters()]
+        sizes = [(p.numel() + 63) // 64 * 64 for p in params]
+        fields = []
+        for n in names:
+            head, _, rest = n.partition('.')
+            if head in ('attn', 'merge_layers'):
+                idx, _, leaf = rest.partition('.')
+                fields.append((int(idx), _GRAD_FIELDS[leaf]))
+            else:
+                fields.append((-1, 'tw' if n == 'time_encoder.w.weight' else 'tb'))
+        plan = module.__dict__['_tgmx_grad_plan'] = (params, sizes, fields)
+    _, sizes, fields = plan
     flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
-    views, off = {}, 0
-    for n, p, sz in zip(names, params, sizes):
-        views[n] = flat[off : off + p.numel()].view(p.shape)
-        off += sz
+    views = [c[: p.numel()].view(p.shape) for c, p in zip(flat.split(sizes), params)]
     g = _native.TgatGrads()
-    g.tw, g.tb = views['time_encoder.w.weight'].data_ptr(), views['time_encoder.w.bias'].data_ptr()
-    for n, v in views.items():
-        head, _, rest = n.partition('.')
-        if head in ('attn', 'merge_layers'):
-            idx, _, leaf = rest.partition('.')
-            setattr(g.layers[int(idx)], _GRAD_FIELDS[leaf], v.data_ptr())
+    for v, (layer, field) in zip(views, fields):
+        setattr(g if layer < 0 else g.layers[layer], field, v.data_ptr())
     drop_p, drop_seed, drop_stream = ctx.drop
     drop = _native.Dropout(float(drop_p), drop_seed & 0xFFFFFFFFFFFFFFFF, drop_stream & 0xFFFFFFFFFFFFFFFF, 0)
     need = int(lib.tgmx_tgat_backward_workspace_bytes(model, ctx.lay, ctx.hops))
@@ -102,7 +108,7 @@ def _backward_native(ctx, dz: Tensor) -> List[Optional[Tensor]]:
                                _native.stream_ptr()),
         'tgmx_tgat_backward',
     )  # fmt: skip
-    return [views[n].to(p.dtype) if p.requires_grad else None for n, p in zip(names, params)]
+    return [v.to(p.dtype) if p.requires_grad else None for v, p in zip(views, params)]
 
 
 def _backward(ctx, dz: Tensor) -> List[Tensor]:

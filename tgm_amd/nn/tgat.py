@@ -26,7 +26,7 @@ from torch import Tensor
 
 from .. import _native
 from . import _ops
-from ._paramver import param_key
+from ._paramver import param_key, param_list
 from .attention import TemporalAttention
 from .time_encoding import Time2Vec
 
@@ -69,13 +69,13 @@ class TGAT(nn.Module):
         live in persistent buffers that are refreshed by ONE native launch (``tgmx_pack2d``) whenever a parameter changed -- after
         every optimizer step when training (``_paramver.param_key``; the ~25 torch launches this took were 0.2 ms of every step) --
         and rebuilt only when a parameter was reallocated."""
-        key = param_key(self.parameters())
+        key = param_key(self)
         cached = getattr(self, '_desc_cache', None)
         if cached is not None and cached[0] == key:
             return cached[1]
         if self.num_layers > _native.TGAT_MAX_LAYERS:
             raise NotImplementedError(f'tgm_amd TGAT supports up to {_native.TGAT_MAX_LAYERS} layers')
-        skey = tuple((p.data_ptr(), p.dtype, p.is_contiguous(), tuple(p.shape)) for p in self.parameters())
+        skey = tuple((p.data_ptr(), p.dtype, p.is_contiguous(), tuple(p.shape)) for p in param_list(self))
         st = getattr(self, '_desc_struct', None)
         if st is None or st[0] != skey or getattr(self, '_desc_volatile', False):
             self._desc_volatile = False
@@ -212,7 +212,7 @@ class TGAT(nn.Module):
         from ..core.lazy import EdgeFeaturesById
 
         drop_p = float(self.attn[0].dropout.p) if self.training else 0.0
-        saving = bool(S0) and (drop_p > 0 or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())))
+        saving = bool(S0) and (drop_p > 0 or (torch.is_grad_enabled() and any(p.requires_grad for p in param_list(self))))
         # edge features by id (RecencyNeighborHook(edge_features='by_id')): the inference path's attention kernel reads the rows of the
         # resident store where it consumes them; the saving path (and shapes that kernel does not cover) gathers them first
         by_id = isinstance(nbr_edge_x, EdgeFeaturesById) and not saving and not getattr(self, '_by_id_unsupported', False)
@@ -240,7 +240,7 @@ class TGAT(nn.Module):
 
             flat = [t for i in range(L) for t in hold[4 * i : 4 * i + 4]]
             flat = [flat[4 * i + j] for i in range(L) for j in (3, 0, 1, 2)]  # (seed_t, nbr_id, nbr_t, edge_x) per hop
-            return TGATFunction.apply(self, node_x, seeds, flat, [int(hops[i].k) for i in range(L)], *self.parameters())
+            return TGATFunction.apply(self, node_x, seeds, flat, [int(hops[i].k) for i in range(L)], *param_list(self))
         out = torch.empty((S0, self.embed_dim), dtype=torch.float32, device=dev)
         if S0 == 0:
             return out

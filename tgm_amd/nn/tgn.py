@@ -27,7 +27,7 @@ from torch import Tensor
 
 from .. import _native
 from . import _ops
-from ._paramver import param_key
+from ._paramver import param_key, param_list
 from .time_encoding import Time2Vec
 
 _COMPOSE_IN_PYTHON = bool(os.environ.get('TGMX_TGN_PY'))  # A/B knob: module forwards as sequences of ctypes calls instead of one C driver call
@@ -175,7 +175,7 @@ class TGNMemory(nn.Module):
                 self._reuse_status = torch.zeros(1, dtype=torch.int32, device=nodes.device)
             self._stamp += 1
             assoc, stamp = self._assoc64, self._stamp
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in param_list(self)):
             return self._updated_train(nodes, assoc, stamp)
         dev, R, M, D, T = nodes.device, nodes.numel(), self.memory_dim, self.raw_msg_dim, self.time_dim
         W = 2 * M + D + T
@@ -367,7 +367,7 @@ class TGNMemory(nn.Module):
             if not self.reuse_forward:
                 return self._updated(n_id.to(torch.int32).contiguous())
             mem, lu = self._updated(n_id.to(torch.int32).contiguous(), record=True)
-            self._fwd = (self._version, self._stamp, mem.detach(), lu, param_key(self.parameters()))
+            self._fwd = (self._version, self._stamp, mem.detach(), lu, param_key(self))
             return mem, lu
         idx = n_id.long()
         return self.memory[idx], self.last_update[idx]
@@ -380,7 +380,7 @@ class TGNMemory(nn.Module):
         raw = _ops._f32c(raw_msg, 'raw_msg') if self.raw_msg_dim else None
         fwd = self._fwd
         if (self.training and self.reuse_forward and fwd is not None and fwd[0] == self._version and not self._sharded(2 * src32.numel())
-                and fwd[4] == param_key(self.parameters())):  # (an optimizer step in between: the reference recomputes with the new weights)
+                and fwd[4] == param_key(self)):  # (an optimizer step in between: the reference recomputes with the new weights)
             # the rows this batch's nodes need are the ones the forward just computed: commit by row copy, then store
             _, stamp, mem_rows, lu_rows, _ = fwd
             self._version += 1
@@ -525,7 +525,7 @@ class TransformerConv(nn.Module):
 
     def forward(self, x: Tensor, edge_index: Tensor, edge_attr: Tensor) -> Tensor:
         lib = _native.load()
-        if torch.is_grad_enabled() and (x.requires_grad or (edge_attr is not None and edge_attr.requires_grad) or any(p.requires_grad for p in self.parameters())):
+        if torch.is_grad_enabled() and (x.requires_grad or (edge_attr is not None and edge_attr.requires_grad) or any(p.requires_grad for p in param_list(self))):
             self._edge_ctx = None
             return self._forward_train(x, edge_index, edge_attr)
         x = _ops._f32c(x, 'x')
@@ -616,7 +616,7 @@ class GraphAttentionEmbedding(nn.Module):
         msg = _ops._f32c(msg, 'msg')
         D = msg.shape[1]
         edge_index = edge_index.to(torch.int64)
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in param_list(self))):
             from ._tgn_train import EdgeAttrFn
 
             edge_attr = EdgeAttrFn.apply(self.time_enc.w.weight, self.time_enc.w.bias, last_update.to(torch.int64).contiguous(),
