@@ -280,22 +280,22 @@ class TGNMemory(nn.Module):
         R, M, dev = nodes.numel(), self.memory_dim, nodes.device
         per = (R + world - 1) // world
         lo, hi = min(rank * per, R), min((rank + 1) * per, R)
-        mem_l = torch.zeros((per, M), dtype=torch.float32, device=dev)
-        lu_l = torch.zeros(per, dtype=torch.int64, device=dev)
+        # one record per row: M floats of memory (padded to an even count) + the int64 last_update as two float-sized words
+        Mp = M + (M & 1)
+        rec_l = torch.zeros((per, Mp + 2), dtype=torch.float32, device=dev)
         if hi > lo:
             m, l = self._updated(nodes[lo:hi])
-            mem_l[: hi - lo], lu_l[: hi - lo] = m, l
-        mem_g = torch.empty((world * per, M), dtype=torch.float32, device=dev)
-        lu_g = torch.empty(world * per, dtype=torch.int64, device=dev)
+            rec_l[: hi - lo, :M] = m
+            rec_l[: hi - lo, Mp:].view(torch.int64)[:, 0] = l
+        rec_g = torch.empty((world * per, Mp + 2), dtype=torch.float32, device=dev)
         if dist.get_backend() == 'gloo':  # CPU collective (tests): stage through the host
-            mc, lc = torch.empty(mem_g.shape), torch.empty(lu_g.shape, dtype=torch.int64)
-            dist.all_gather_into_tensor(mc, mem_l.cpu())
-            dist.all_gather_into_tensor(lc, lu_l.cpu())
-            mem_g.copy_(mc)
-            lu_g.copy_(lc)
+            rc = torch.empty(rec_g.shape)
+            dist.all_gather_into_tensor(rc, rec_l.cpu())
+            rec_g.copy_(rc)
         else:
-            dist.all_gather_into_tensor(mem_g, mem_l)
-            dist.all_gather_into_tensor(lu_g, lu_l)
+            dist.all_gather_into_tensor(rec_g, rec_l)  # the step's only collective
+        mem_g = rec_g[:, :M].contiguous()
+        lu_g = rec_g[:, Mp:].view(torch.int64)[:, 0].contiguous()
         return mem_g[:R], lu_g[:R]
 
     def _store_batch(self, src32: Tensor, dst32: Tensor, t: Tensor, raw: Optional[Tensor]) -> None:
