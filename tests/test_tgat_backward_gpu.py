@@ -131,6 +131,42 @@ def test_one_call_backward_at_the_headline_shape(monkeypatch):
     assert all(torch.isfinite(v).all() and float(v.abs().max()) > 0 for v in b.values())
 
 
+def test_training_with_edge_features_by_id_equals_the_dense_copies():
+    """``RecencyNeighborHook(edge_features='by_id')`` in TRAINING: the saving forward's attention and the attention backward inside
+    ``tgmx_tgat_backward`` read the rows of the resident store by edge id instead of the sampler's dense [rows, k, D] copies -- same
+    values in the same order: embeddings and every parameter gradient bit-identical (dropout 0.1, the headline shape)."""
+    from tgm_amd import DGData, DGDataLoader, DGraph
+    from tgm_amd.core import EdgeFeaturesById
+    from tgm_amd.hooks import HookManager, RandomNegativeEdgeSamplerHook, RecencyNeighborHook
+    from tgm_amd.nn import TGAT
+    from tgm_amd.synth import make_stream
+
+    st = make_stream('wiki', seed=11, num_edges=30_000)
+    dg = DGraph(DGData.from_raw(st.ts, torch.stack([st.src, st.dst], 1), st.edge_x, static_node_x=st.node_x), device=DEV)
+
+    def run(features):
+        hm = HookManager(keys=['k'])
+        hm.register('k', RandomNegativeEdgeSamplerHook(8227, st.num_nodes, seed=3))
+        hm.register('k', RecencyNeighborHook(st.num_nodes, [20, 20], ['edge_src', 'edge_dst', 'neg'], ['edge_time', 'edge_time', 'neg_time'],
+                                             edge_features=features))  # fmt: skip
+        with hm.activate('k'):
+            for b, batch in enumerate(DGDataLoader(dg, batch_size=200, hook_manager=hm, output_pool=0)):
+                if b == 120:
+                    break
+        assert isinstance(batch.nbr_edge_x, EdgeFeaturesById) == (features == 'by_id')
+        torch.manual_seed(7)
+        enc = TGAT(node_dim=1, edge_dim=172, time_dim=100, embed_dim=172, num_layers=2).to(DEV).train()
+        z = enc(dg.static_node_x, batch.seed_nids, batch.seed_times, batch.nbr_nids, batch.nbr_edge_x, batch.nbr_edge_time)
+        ((z[:200] * z[200:400]).sum(-1).sigmoid().mean() - (z[:200] * z[400:]).sum(-1).sigmoid().mean()).backward()
+        assert not getattr(enc, '_by_id_unsupported', False)
+        return z.detach().clone(), {n: p.grad.clone() for n, p in enc.named_parameters()}
+
+    (za, a), (zb, b) = run('dense'), run('by_id')
+    assert torch.equal(za, zb)
+    diff = {n: float((a[n] - b[n]).abs().max()) for n in a if not torch.equal(a[n], b[n])}
+    assert not diff, diff
+
+
 def _train_losses(make_opt, steps=40):
     from tgm_amd.nn import TGAT, invalidate_parameter_caches
 

@@ -2037,8 +2037,8 @@ extern "C" int tgmx_tgat_forward(const tgmx_tgat_model_t* m, const float* node_x
         const bool by_id = !hops[i].edge_x && hops[i].nbr_eid && ly.D > 0;
         const bool reg_kernel = H <= 2 && k <= 20 && ly.D % 4 == 0 && ly.D / 4 <= 64 && ly.T <= 128 && ((ly.d % 4 == 0 && ly.d / 4 <= 64) || ly.d <= 64) &&
                                 ((uintptr_t)hops[i].edge_table & 15) == 0;  // launch_attn_reg's own conditions
-        if (by_id && (save || !reg_kernel)) {
-          set_error("tgat_forward: edge features by id need the inference path and the register-resident attention kernel");
+        if (by_id && !reg_kernel) {  // (round 3, later: the saving forward takes ids too -- tgmx_tgat_backward reads the same rows)
+          set_error("tgat_forward: edge features by id need the register-resident attention kernel");
           return TGMX_E_UNSUPPORTED;
         }
         any_by_id |= by_id;

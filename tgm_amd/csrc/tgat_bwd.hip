@@ -210,7 +210,9 @@ struct AttnBwdArgs {
   const float* probs;   // [R, H, k]
   const float* dzbar;   // [R, H, Cs]
   const float* nbrf;    // [R, k, d]
-  const float* ex;      // [R, k, D]
+  const float* ex;      // [R, k, D]; or NULL with the two below: edge features by id (tgmx_tgat_hop_t.nbr_eid / edge_table)
+  const int32_t* eid;   // [R, k] edge id behind every slot (-1: a pad slot, zeros)
+  const float* table;   // [E, D] the resident store's feature rows
   const int64_t* seed_t;
   const int64_t* nbr_t;
   const float* tw;
@@ -243,20 +245,24 @@ __global__ __launch_bounds__(256) void tgat_attn_backward_kernel(const AttnBwdAr
   extern __shared__ __attribute__((aligned(16))) float lds_all[];
   const int lane = lane_id(), wave = threadIdx.x >> 6;
   const int k = a.k, T = a.T, d = a.d, D = a.D, Cs = a.Cs;
-  float* s_cos = lds_all + (size_t)wave * (2 * k * T + k + 2 * H * k);
+  float* s_cos = lds_all + (size_t)wave * (2 * k * T + 2 * k + 2 * H * k);
   float* s_sin = s_cos + k * T;
   float* s_dt = s_sin + k * T;
   float* s_A = s_dt + k;
   float* s_ds = s_A + H * k;
+  int* s_eid = reinterpret_cast<int*>(s_ds + H * k);  // [k] (edge features by id)
   const long long r = (long long)blockIdx.x * (blockDim.x >> 6) + wave;
   if (r >= a.R) return;
   const float* __restrict__ q = a.qf + r * (long long)H * Cs;
   const float* __restrict__ dz = a.dzbar + r * (long long)H * Cs;
   const float* __restrict__ nb = a.nbrf + r * (long long)k * d;
-  const float* __restrict__ ex = a.ex + r * (long long)k * D;
+  const float* __restrict__ ex = a.ex ? a.ex + r * (long long)k * D : nullptr;
 
   const long long st = a.seed_t[r];
-  for (int s = lane; s < k; s += kWave) s_dt[s] = (float)(st - a.nbr_t[r * k + s]);
+  for (int s = lane; s < k; s += kWave) {
+    s_dt[s] = (float)(st - a.nbr_t[r * k + s]);
+    if (a.eid) s_eid[s] = a.eid[r * k + s];
+  }
   __builtin_amdgcn_wave_barrier();
   for (int e = lane; e < k * T; e += kWave) {
     const int s = e / T, t = e - s * T;
@@ -270,7 +276,16 @@ __global__ __launch_bounds__(256) void tgat_attn_backward_kernel(const AttnBwdAr
   float P[64];
 #pragma unroll
   for (int j = 0; j < 64; ++j) P[j] = 0.f;
-  auto accumulate = [&](const float* __restrict__ base, long long slot_stride, int dim, int col0) {
+  // feature c of slot sl: a strided block of the row's own slots, or (edge features by id) row eid[sl] of the resident store --
+  // the id is the same in every lane (a scalar base for the load); a pad slot (-1) reads zeros like the dense copy holds them
+  auto dense = [](const float* __restrict__ base, long long slot_stride) {
+    return [=](int sl, int c) -> float { return base[(long long)sl * slot_stride + c]; };
+  };
+  auto by_id = [&](int sl, int c) -> float {
+    const int e = __builtin_amdgcn_readfirstlane(s_eid[sl]);
+    return e >= 0 ? a.table[(long long)e * D + c] : 0.f;
+  };
+  auto accumulate = [&](auto&& load, int dim, int col0) {
     for (int c = lane; c < dim; c += kWave) {
       float gv[H];
 #pragma unroll
@@ -278,15 +293,18 @@ __global__ __launch_bounds__(256) void tgat_attn_backward_kernel(const AttnBwdAr
 #pragma clang loop unroll(full)
       for (int s = 0; s < G; ++s) {
         const int sl = s < k ? s : k - 1;
-        const float z = base[(long long)sl * slot_stride + c];
+        const float z = load(sl, c);
 #pragma unroll
         for (int h = 0; h < H; ++h) P[s * H + h] = __fmaf_rn(gv[h], z, P[s * H + h]);
       }
     }
   };
-  accumulate(nb, d, d, 0);
-  if (D > 0) accumulate(ex, D, D, d);
-  accumulate(s_cos, T, T, d + D);
+  accumulate(dense(nb, d), d, 0);
+  if (D > 0) {
+    if (ex) accumulate(dense(ex, D), D, d);
+    else accumulate(by_id, D, d);
+  }
+  accumulate(dense(s_cos, T), T, d + D);
   bwd_reduce_scatter_step<32>(P, lane);
   bwd_reduce_scatter_step<16>(P, lane);
   bwd_reduce_scatter_step<8>(P, lane);
@@ -311,7 +329,7 @@ __global__ __launch_bounds__(256) void tgat_attn_backward_kernel(const AttnBwdAr
 
   // ---- dqf[h][c] = scale * sum_s ds[h][s] z[s][c];  dz[s][c] = sum_h A dzbar + scale * ds * qf ----
   float* __restrict__ dq = a.dqf + r * (long long)H * Cs;
-  auto columns = [&](const float* __restrict__ base, long long slot_stride, int dim, int col0, int part) {
+  auto columns = [&](auto&& load, int dim, int col0, int part) {
     for (int c = lane; c < dim; c += kWave) {
       float acc[H], gv[H], qv[H];
 #pragma unroll
@@ -325,7 +343,7 @@ __global__ __launch_bounds__(256) void tgat_attn_backward_kernel(const AttnBwdAr
 #pragma clang loop unroll(full)
       for (int s = 0; s < G; ++s) {
         const int sl = s < k ? s : k - 1;
-        zs[s] = base[(long long)sl * slot_stride + c];
+        zs[s] = load(sl, c);
       }
 #pragma clang loop unroll(full)
       for (int s = 0; s < G; ++s) {
@@ -353,9 +371,12 @@ __global__ __launch_bounds__(256) void tgat_attn_backward_kernel(const AttnBwdAr
       }
     }
   };
-  columns(nb, d, d, 0, 0);
-  if (D > 0) columns(ex, D, D, d, 1);
-  columns(s_cos, T, T, d + D, 2);
+  columns(dense(nb, d), d, 0, 0);
+  if (D > 0) {
+    if (ex) columns(dense(ex, D), D, d, 1);
+    else columns(by_id, D, d, 1);
+  }
+  columns(dense(s_cos, T), T, d + D, 2);
 }
 
 }  // namespace tgmx
@@ -449,19 +470,34 @@ extern "C" int tgmx_ln_backward(const float* dout, int64_t ldd, const float* y, 
   return TGMX_OK;
 }
 
+static int attn_backward_impl(const float* qf, const float* probs, const float* dzbar, const float* nbrf, int32_t d, const float* ex,
+                              const int32_t* eid, const float* table, int32_t D, const int64_t* seed_t, const int64_t* nbr_t, const float* tw,
+                              const float* tb, int32_t T, int32_t H, int32_t k, int64_t R, float scale, int32_t head_stride, float* dqf,
+                              float* dnbr, float* dtime_rows, const tgmx_dropout_t* drop, tgmx_stream_t stream);
+
 extern "C" int tgmx_tgat_attn_backward(const float* qf, const float* probs, const float* dzbar, const float* nbrf, int32_t d,
                                        const float* ex, int32_t D, const int64_t* seed_t, const int64_t* nbr_t, const float* tw,
                                        const float* tb, int32_t T, int32_t H, int32_t k, int64_t R, float scale, int32_t head_stride,
                                        float* dqf, float* dnbr, float* dtime_rows, const tgmx_dropout_t* drop, tgmx_stream_t stream) {
+  return attn_backward_impl(qf, probs, dzbar, nbrf, d, ex, nullptr, nullptr, D, seed_t, nbr_t, tw, tb, T, H, k, R, scale, head_stride, dqf, dnbr,
+                            dtime_rows, drop, stream);
+}
+
+static int attn_backward_impl(const float* qf, const float* probs, const float* dzbar, const float* nbrf, int32_t d, const float* ex,
+                              const int32_t* eid, const float* table, int32_t D, const int64_t* seed_t, const int64_t* nbr_t, const float* tw,
+                              const float* tb, int32_t T, int32_t H, int32_t k, int64_t R, float scale, int32_t head_stride, float* dqf,
+                              float* dnbr, float* dtime_rows, const tgmx_dropout_t* drop, tgmx_stream_t stream) {
   TGMX_REQUIRE(d > 0 && D >= 0 && T > 0 && k > 0 && R >= 0, "tgat_attn_backward: bad sizes");
   TGMX_REQUIRE((H == 1 || H == 2 || H == 4 || H == 8) && k * H <= 64, "tgat_attn_backward: needs n_heads in {1,2,4,8} and k * n_heads <= 64 (k=%d, H=%d)", k, H);
   if (R == 0) return TGMX_OK;
-  TGMX_REQUIRE(qf && probs && dzbar && nbrf && (D == 0 || ex) && seed_t && nbr_t && tw && tb && dqf && dtime_rows, "tgat_attn_backward: null pointer");
+  TGMX_REQUIRE(qf && probs && dzbar && nbrf && (D == 0 || ex || (eid && table)) && seed_t && nbr_t && tw && tb && dqf && dtime_rows,
+               "tgat_attn_backward: null pointer");
   const int C = d + D + T;
-  AttnBwdArgs a{qf, probs, dzbar, nbrf, ex, seed_t, nbr_t, tw, tb, dqf, dnbr, dtime_rows, R, d, D, T, k, C, head_stride ? head_stride : C, scale};
+  AttnBwdArgs a{qf, probs, dzbar, nbrf, ex, ex ? nullptr : eid, ex ? nullptr : table, seed_t, nbr_t, tw, tb, dqf, dnbr, dtime_rows, R, d, D, T, k, C,
+                head_stride ? head_stride : C, scale};
   a.drop = make_dropout(drop);
   a.drop_row0 = drop ? drop->row0 : 0;
-  const size_t per_wave = ((size_t)2 * k * T + k + 2 * (size_t)H * k) * sizeof(float);
+  const size_t per_wave = ((size_t)2 * k * T + 2 * (size_t)k + 2 * (size_t)H * k) * sizeof(float);
   int waves = 4;
   while (waves > 1 && per_wave * waves > 64 * 1024) waves >>= 1;
   TGMX_REQUIRE(per_wave * waves <= 64 * 1024, "tgat_attn_backward: k*T=%d too large for LDS", k * T);
@@ -786,9 +822,9 @@ int tgat_backward_pass(const tgmx_tgat_model_t* m, const tgmx_tgat_layout_t* lay
       if (!Ri) continue;
       const long long o = lay->level_off[i], o1 = lay->level_off[i + 1];
       const tgmx_dropout_t site{p_drop, drop ? drop->seed : 0, (drop ? drop->stream : 0) * 64 + 2 * (uint64_t)j, o};
-      RUN(tgmx_tgat_attn_backward(qf + o * H * Cp, probs + o * H * k, dzbar + o * H * Cp, prev + o1 * d, d, hops[i].edge_x, D, hops[i].seed_t,
-                                  hops[i].nbr_t, m->tw, m->tb, T, H, k, Ri, scale, Cp, dqf + o * H * Cp, need_dprev ? dprev + o1 * d : nullptr,
-                                  dtime + o * 2 * T, p_drop > 0.f ? &site : nullptr, stream));
+      RUN(attn_backward_impl(qf + o * H * Cp, probs + o * H * k, dzbar + o * H * Cp, prev + o1 * d, d, hops[i].edge_x, hops[i].nbr_eid,
+                             hops[i].edge_table, D, hops[i].seed_t, hops[i].nbr_t, m->tw, m->tb, T, H, k, Ri, scale, Cp, dqf + o * H * Cp,
+                             need_dprev ? dprev + o1 * d : nullptr, dtime + o * 2 * T, p_drop > 0.f ? &site : nullptr, stream));
     }
     RUN_ALWAYS(colsum(dtime, 2 * T, R, T, g->tw, 1));
     RUN_ALWAYS(colsum(dtime + T, 2 * T, R, T, g->tb, 1));

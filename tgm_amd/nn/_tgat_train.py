@@ -32,6 +32,10 @@ def _p4(x: int) -> int:
     return (x + 3) // 4 * 4
 
 
+class ByIdUnsupported(Exception):
+    """the saving forward was handed edge features by id at a shape the by-id attention kernels do not cover"""
+
+
 class TGATFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, node_x: Tensor, seeds: Tensor, hop_tensors: List[Tensor], ks: List[int], *params: Tensor) -> Tensor:
@@ -41,19 +45,20 @@ class TGATFunction(torch.autograd.Function):
         model, keep = module._model_desc()
         hops = (_native.TgatHop * L)()
         for i in range(L):
-            st, nid, nt, ex = hop_tensors[4 * i : 4 * i + 4]
+            st, nid, nt, ex, eid, table = hop_tensors[6 * i : 6 * i + 6]
             h = hops[i]
             h.seed_t, h.nbr_id, h.nbr_t, h.edge_x, h.k = st.data_ptr(), nid.data_ptr(), nt.data_ptr(), _native.ptr(ex), ks[i]
+            h.nbr_eid, h.edge_table = _native.ptr(eid), _native.ptr(table)  # edge features by id (ex is None then)
         S0 = seeds.numel()
         lay = _native.TgatLayout()
         _native.check(lib.tgmx_tgat_layout(model, S0, hops, 1, lay), 'tgmx_tgat_layout')
         ws = torch.empty(int(lay.total_bytes), dtype=torch.uint8, device=dev)
         out = torch.empty((S0, module.embed_dim), dtype=torch.float32, device=dev)
-        _native.check(
-            lib.tgmx_tgat_forward(model, node_x.data_ptr(), node_x.shape[0], seeds.data_ptr(), S0, hops, ws.data_ptr(), ws.numel(), 1,
-                                  out.data_ptr(), _native.stream_ptr()),
-            'tgmx_tgat_forward',
-        )  # fmt: skip
+        rc = lib.tgmx_tgat_forward(model, node_x.data_ptr(), node_x.shape[0], seeds.data_ptr(), S0, hops, ws.data_ptr(), ws.numel(), 1,
+                                   out.data_ptr(), _native.stream_ptr())  # fmt: skip
+        if rc == _native.E_UNSUPPORTED and any(hop_tensors[6 * i + 4] is not None for i in range(L)):
+            raise ByIdUnsupported()
+        _native.check(rc, 'tgmx_tgat_forward')
         ctx.module, ctx.lay, ctx.ws, ctx.hop_tensors, ctx.ks, ctx.keep, ctx.S0 = module, lay, ws, hop_tensors, ks, keep, S0
         ctx.hops = hops  # (points into hop_tensors, kept above)
         ctx.n_params = len(params)
@@ -230,7 +235,7 @@ def _backward(ctx, dz: Tensor) -> List[Tensor]:
             Ri = level_rows[i]
             if not Ri:
                 continue
-            st_i, nid_i, nt_i, ex_i = hop_t[4 * i : 4 * i + 4]
+            st_i, nid_i, nt_i, ex_i = hop_t[6 * i : 6 * i + 4]
             o = level_off[i]
             nbrf = prev[level_off[i + 1] : level_off[i + 1] + Ri * k]
             _native.check(

@@ -18,6 +18,7 @@ tgat.py:67) are active: counter-based masks (``tgmx_dropout_t``) seeded from
 """
 from __future__ import annotations
 
+import os
 from typing import List
 
 import torch
@@ -213,23 +214,26 @@ class TGAT(nn.Module):
 
         drop_p = float(self.attn[0].dropout.p) if self.training else 0.0
         saving = bool(S0) and (drop_p > 0 or (torch.is_grad_enabled() and any(p.requires_grad for p in param_list(self))))
-        # edge features by id (RecencyNeighborHook(edge_features='by_id')): the inference path's attention kernel reads the rows of the
-        # resident store where it consumes them; the saving path (and shapes that kernel does not cover) gathers them first
-        by_id = isinstance(nbr_edge_x, EdgeFeaturesById) and not saving and not getattr(self, '_by_id_unsupported', False)
+        # edge features by id (RecencyNeighborHook(edge_features='by_id')): the attention kernels -- forward, and the backward inside
+        # tgmx_tgat_backward -- read the rows of the resident store where they consume them; shapes they do not cover (and the backward
+        # composed from Python, TGMX_TGAT_BWD=py) gather the rows first
+        by_id = (isinstance(nbr_edge_x, EdgeFeaturesById) and not getattr(self, '_by_id_unsupported', False)
+                 and not (saving and os.environ.get('TGMX_TGAT_BWD', '') == 'py'))
         for i in range(L):
             nid, nt, st = c(nbr_nids[i]), c(nbr_edge_time[i]), c(seed_times[i])
             ex = None if by_id else c(nbr_edge_x[i])
             if nid.shape[0] != rows or st.numel() != rows:
                 raise ValueError(f'hop {i}: expected {rows} rows, got nbr_nids {tuple(nid.shape)} / seed_times {tuple(st.shape)}')
-            hold += [nid, nt, ex, st]
+            eid, table = (c(nbr_edge_x.eids[i]), nbr_edge_x.table) if by_id else (None, None)
+            hold += [nid, nt, ex, st, eid, table]
             h = hops[i]
             h.seed_t, h.nbr_id, h.nbr_t, h.edge_x, h.k = st.data_ptr(), nid.data_ptr(), nt.data_ptr(), _native.ptr(ex), nid.shape[-1]
-            h.nbr_eid, h.edge_table = (c(nbr_edge_x.eids[i]).data_ptr(), nbr_edge_x.table.data_ptr()) if by_id else (0, 0)
+            h.nbr_eid, h.edge_table = _native.ptr(eid), _native.ptr(table)
             rows *= nid.shape[-1]
         if saving:
             # training: same native forward with every intermediate kept, hand-written backward (nn/_tgat_train.py);
             # also the path that applies dropout (train mode under no_grad included, like the reference)
-            from ._tgat_train import TGATFunction
+            from ._tgat_train import ByIdUnsupported, TGATFunction
 
             if any(float(a.dropout.p) != float(self.attn[0].dropout.p) for a in self.attn):
                 raise NotImplementedError('tgm_amd TGAT: every attention layer must use the same dropout probability')
@@ -238,9 +242,12 @@ class TGAT(nn.Module):
                 self._drop_seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
             model.drop.p, model.drop.seed, model.drop.stream, model.drop.row0 = drop_p, self._drop_seed, self._drop_calls, 0
 
-            flat = [t for i in range(L) for t in hold[4 * i : 4 * i + 4]]
-            flat = [flat[4 * i + j] for i in range(L) for j in (3, 0, 1, 2)]  # (seed_t, nbr_id, nbr_t, edge_x) per hop
-            return TGATFunction.apply(self, node_x, seeds, flat, [int(hops[i].k) for i in range(L)], *param_list(self))
+            flat = [hold[6 * i + j] for i in range(L) for j in (3, 0, 1, 2, 4, 5)]  # (seed_t, nbr_id, nbr_t, edge_x, eid, table) per hop
+            try:
+                return TGATFunction.apply(self, node_x, seeds, flat, [int(hops[i].k) for i in range(L)], *param_list(self))
+            except ByIdUnsupported:  # a shape the by-id attention kernels do not cover: gather the rows, like everybody else
+                self._by_id_unsupported = True
+                return self.forward(node_x, seed_nids, seed_times, nbr_nids, nbr_edge_x, nbr_edge_time)
         out = torch.empty((S0, self.embed_dim), dtype=torch.float32, device=dev)
         if S0 == 0:
             return out

@@ -15,7 +15,8 @@ from tgm_amd.synth import make_stream  # noqa: E402
 
 stream = make_stream('wiki', seed=1337)
 dev = torch.device('cuda', 0)
-dg, hm, hook, loader = bench.build_pipeline(stream, 0, 1, 200, [20, 20], 'ring', dev)
+features = sys.argv[2] if len(sys.argv) > 2 else 'dense'  # 'by_id': the sampler publishes edge ids, the attention kernels read the resident store
+dg, hm, hook, loader = bench.build_pipeline(stream, 0, 1, 200, [20, 20], 'ring', dev, edge_features=features)
 starts = loader._starts
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 node_x = dg.static_node_x
@@ -68,6 +69,6 @@ with hm.activate('bench'):
     fused = run(True)
 print(json.dumps({
     'what': 'TGAT training step (sampler + forward(save) + backward + Adam), example dims, 600 seeds, k=[20,20], dot-product link loss',
-    'backward': os.environ.get('TGMX_TGAT_BWD', 'native (tgmx_tgat_backward)'),
+    'backward': os.environ.get('TGMX_TGAT_BWD', 'native (tgmx_tgat_backward)'), 'edge_features': features,
     **plain, 'adam_fused': fused,
 }))

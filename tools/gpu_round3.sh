@@ -24,6 +24,7 @@ tools/gpu_profile_r3.sh comment_ring lookup_tile 100 --workload comment
 for f in dense by_id; do timeout 300 python tools/bench_tgat.py 200 $f 2>/dev/null | j > "$OUT/r03_bench_tgat_$f.json"; done
 timeout 300 python tools/bench_tgn.py 400 2>/dev/null | j > "$OUT/r03_bench_tgn.json"
 timeout 300 python tools/bench_tgat_train.py 200 2>/dev/null | j > "$OUT/r03_bench_tgat_train.json"
+timeout 300 python tools/bench_tgat_train.py 200 by_id 2>/dev/null | j > "$OUT/r03_bench_tgat_train_by_id.json"
 TGMX_TGAT_BWD=py timeout 300 python tools/bench_tgat_train.py 200 2>/dev/null | j > "$OUT/r03_bench_tgat_train_composed_backward.json"
 tools/gpu_trace_cmd.sh train 40 python $ROOT/tools/bench_tgat_train.py 60 > "$OUT/r03_tgat_train_rocprof_summary.md" 2>/dev/null
 rm -f "$OUT/r03_tgat_parity_stats.jsonl"
