@@ -465,8 +465,9 @@ typedef struct tgmx_tgat_hop {
   int32_t k;
   /* ABI v4: edge features by id.  With edge_x == NULL and nbr_eid / edge_table set, slot (r, s) reads edge_table[nbr_eid[r, s]]
    * ([E, D] rows of the resident store; -1: a pad slot, zeros) where the attention consumes it -- the sampler then never writes
-   * the dense [rows, k, D] copy (tgmx_recency_step_t.out_eid) and the attention never re-reads it.  Inference (save = 0) with the
-   * register-resident attention kernel (n_heads <= 2, k <= 20, D a multiple of 4); otherwise TGMX_E_UNSUPPORTED: gather the rows first. */
+   * the dense [rows, k, D] copy (tgmx_recency_step_t.out_eid) and the attention never re-reads it.  Needs the register-resident
+   * attention kernel (n_heads <= 2, k <= 20, D a multiple of 4); otherwise TGMX_E_UNSUPPORTED: gather the rows first.  With save != 0
+   * too (round 3, later): tgmx_tgat_backward then reads the same rows by id in its attention backward. */
   const int32_t* nbr_eid;  /* [rows_i, k] */
   const float* edge_table; /* [E, D] */
 } tgmx_tgat_hop_t;
