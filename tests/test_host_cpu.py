@@ -305,3 +305,36 @@ def test_parameter_cache_key_sees_fused_optimizer_steps_and_explicit_invalidatio
     k0 = param_key(lin.parameters())
     lin.load_state_dict({k: v + 1 for k, v in lin.state_dict().items()})
     assert param_key(lin.parameters()) != k0
+
+
+def test_modules_deep_copy_and_pickle_without_their_derived_caches():
+    """The modules cache ctypes blocks (pointers into device buffers) and workspaces on themselves; ctypes structures with pointers cannot
+    be pickled, so ``copy.deepcopy(model)`` / ``torch.save(model)`` after a forward used to raise.  Derived state stays behind."""
+    import copy
+    import io
+
+    import torch
+
+    from tgm_amd import _native
+    from tgm_amd.nn import TGAT, GraphAttentionEmbedding, IdentityMessage, LastAggregator, TGNMemory, Time2Vec
+
+    enc = TGAT(node_dim=3, edge_dim=4, time_dim=6, embed_dim=8, num_layers=2)
+    enc._desc_cache = ('key', (_native.TgatModel(), [torch.zeros(3)]))  # what a forward leaves behind
+    enc._desc_struct = ('skey', _native.TgatModel(), [torch.zeros(3)], [_native.PackJob()])
+    enc._workspace = torch.zeros(16)
+    enc.__dict__['_tgmx_plist'] = (0, tuple(enc.parameters()))
+    mem = TGNMemory(10, 4, 8, 6, IdentityMessage(4, 8, 6), LastAggregator())
+    mem._fwd_args = _native.TgnMemoryFwd()
+    gae = GraphAttentionEmbedding(8, 8, 4, Time2Vec(6))
+    gae.conv._fwd_args = _native.TconvFwd()
+    for mod in (enc, mem, gae):
+        twin = copy.deepcopy(mod)
+        buf = io.BytesIO()
+        torch.save(mod, buf)
+        buf.seek(0)
+        again = torch.load(buf, weights_only=False)
+        for other in (twin, again):
+            assert all(torch.equal(a, b) and a is not b for a, b in zip(mod.state_dict().values(), other.state_dict().values()))
+    twin = copy.deepcopy(enc)
+    assert twin._desc_cache is None and twin._desc_struct is None and twin._workspace is None and '_tgmx_plist' not in twin.__dict__
+    assert enc._desc_cache is not None  # the original keeps its own

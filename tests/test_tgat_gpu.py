@@ -129,6 +129,27 @@ def test_tgat_forward_matches_reference(case):
         close(enc(**{k: dev(v) for k, v in inputs.items()}), z_ref, case + ' (no_grad)')
 
 
+def test_deep_copy_after_a_forward_is_an_independent_twin():
+    """``copy.deepcopy(model)`` after the model has run (best-checkpoint copies, EMA twins): the copy leaves the original's ctypes blocks
+    and weight-layout buffers behind, rebuilds its own, and follows ITS parameters."""
+    import copy
+
+    from tgm_amd.nn import TGAT
+
+    meta, params, inputs, ref = gu.tgat_case('g5_tgat_small_nd8')
+    enc = TGAT(edge_dim=meta['edge_dim'], num_layers=2, **meta['dims']).to(DEV).eval()
+    enc.load_state_dict(params)
+    dev = lambda v: [t.to(DEV) for t in v] if isinstance(v, list) else v.to(DEV)
+    args = {k: dev(v) for k, v in inputs.items()}
+    with torch.no_grad():
+        z = enc(**args)
+        twin = copy.deepcopy(enc)
+        assert torch.equal(twin(**args), z)
+        for p in twin.parameters():
+            p.mul_(1.01)
+        assert not torch.equal(twin(**args), z) and torch.equal(enc(**args), z)
+
+
 def test_one_kernel_tail_is_race_free_under_load():
     """The inference tail streams its weights through LDS by DMA behind counted waits: a misplaced wait shows up as a rare wrong
     tile that comes and goes with timing.  60 forwards of the example dims (12 600 rows in layer 1) while another stream

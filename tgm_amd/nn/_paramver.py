@@ -53,3 +53,21 @@ def param_key(params: Union[torch.nn.Module, Iterable[torch.Tensor]]) -> Tuple:
     if isinstance(params, torch.nn.Module):
         params = param_list(params)
     return (_epoch,) + tuple((p.data_ptr(), p._version) for p in params)
+
+
+class TransientCaches:
+    """Mixin (in front of ``nn.Module``): the attributes named in ``_TRANSIENT`` and everything called ``_tgmx_*`` are DERIVED state --
+    ctypes blocks pointing into device buffers, workspaces, cached weight layouts -- and stay behind when the module is pickled or
+    deep-copied (``copy.deepcopy(model)`` for a best-checkpoint copy or an EMA twin; ``torch.save(model)``): ctypes structures with
+    pointers cannot be pickled at all, and a copy must not share the original's buffers.  The copy rebuilds them on its first call."""
+
+    _TRANSIENT: Tuple[str, ...] = ()
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        for k in list(state):
+            if k.startswith('_tgmx_'):
+                del state[k]
+            elif k in self._TRANSIENT:
+                state[k] = None
+        return state

@@ -27,7 +27,7 @@ from torch import Tensor
 
 from .. import _native
 from . import _ops
-from ._paramver import param_key, param_list
+from ._paramver import TransientCaches, param_key, param_list
 from .attention import TemporalAttention
 from .time_encoding import Time2Vec
 
@@ -52,7 +52,9 @@ class MergeLayer(nn.Module):
         return self.forward_cat(cat, out)
 
 
-class TGAT(nn.Module):
+class TGAT(TransientCaches, nn.Module):
+    _TRANSIENT = ('_desc_cache', '_desc_struct', '_fold_keep', '_workspace')
+
     def __init__(self, node_dim: int, edge_dim: int, time_dim: int, embed_dim: int, num_layers: int, n_heads: int = 2,
                  dropout: float = 0.1) -> None:  # fmt: skip
         super().__init__()

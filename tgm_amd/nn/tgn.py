@@ -27,7 +27,7 @@ from torch import Tensor
 
 from .. import _native
 from . import _ops
-from ._paramver import param_key, param_list
+from ._paramver import TransientCaches, param_key, param_list
 from .time_encoding import Time2Vec
 
 _COMPOSE_IN_PYTHON = bool(os.environ.get('TGMX_TGN_PY'))  # A/B knob: module forwards as sequences of ctypes calls instead of one C driver call
@@ -53,7 +53,9 @@ class IdentityMessage(nn.Module):
         self.out_channels = raw_msg_dim + 2 * memory_dim + time_dim
 
 
-class TGNMemory(nn.Module):
+class TGNMemory(TransientCaches, nn.Module):
+    _TRANSIENT = ('_fwd_args', '_group_ws', '_fwd')
+
     def __init__(self, num_nodes: int, raw_msg_dim: int, memory_dim: int, time_dim: int, message_module: Callable,
                  aggregator_module: Callable) -> None:  # fmt: skip
         super().__init__()
@@ -467,12 +469,14 @@ def sampled_edge_list(batch, hop: int = 0) -> Tuple[Tensor, Tensor, Tensor]:
     return ei[:, :E], et[:E], ex[:E]
 
 
-class TransformerConv(nn.Module):
+class TransformerConv(TransientCaches, nn.Module):
     """Graph transformer operator with edge features -- parameters named like
     ``torch_geometric.nn.TransformerConv`` (2.6.1; third-party to the reference, parity unpinned):
     concat=True, root_weight=True, beta=False, bias=True.  In ``.train()`` mode the attention coefficients go through
     dropout after the softmax like PyG's (``F.dropout(alpha, p=self.dropout)``): a counter-based mask per (edge, head),
     seeded from ``torch.initial_seed()``, a fresh stream per forward call, regenerated by the backward."""
+
+    _TRANSIENT = ('_fwd_args', '_seg_ws', '_stacked')
 
     def __init__(self, in_channels: int, out_channels: int, heads: int = 1, dropout: float = 0.0, edge_dim: Optional[int] = None) -> None:
         super().__init__()
