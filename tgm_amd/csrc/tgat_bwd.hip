@@ -245,9 +245,10 @@ __global__ __launch_bounds__(256) void tgat_attn_backward_kernel(const AttnBwdAr
   extern __shared__ __attribute__((aligned(16))) float lds_all[];
   const int lane = lane_id(), wave = threadIdx.x >> 6;
   const int k = a.k, T = a.T, d = a.d, D = a.D, Cs = a.Cs;
-  float* s_cos = lds_all + (size_t)wave * (2 * k * T + 2 * k + 2 * H * k);
-  float* s_sin = s_cos + k * T;
-  float* s_dt = s_sin + k * T;
+  // (only the cosines are staged: the sines are evaluated where the time gradient consumes them -- two [k, T] tables per wave were
+  // 16.5 KB at k = 20, T = 100: two workgroups per CU, two waves per SIMD, and the kernel is latency-bound)
+  float* s_cos = lds_all + (size_t)wave * (k * T + 2 * k + 2 * H * k);
+  float* s_dt = s_cos + k * T;
   float* s_A = s_dt + k;
   float* s_ds = s_A + H * k;
   int* s_eid = reinterpret_cast<int*>(s_ds + H * k);  // [k] (edge features by id)
@@ -268,7 +269,6 @@ __global__ __launch_bounds__(256) void tgat_attn_backward_kernel(const AttnBwdAr
     const int s = e / T, t = e - s * T;
     const float arg = __fmaf_rn(s_dt[s], a.tw[t], a.tb[t]);
     s_cos[e] = cos_t2v(arg);
-    s_sin[e] = sin_t2v(arg);
   }
   __builtin_amdgcn_wave_barrier();
 
@@ -339,6 +339,7 @@ __global__ __launch_bounds__(256) void tgat_attn_backward_kernel(const AttnBwdAr
         qv[h] = q[h * Cs + col0 + c];
       }
       float dw = 0.f, db = 0.f;
+      const float tw_c = part == 2 ? a.tw[c] : 0.f, tb_c = part == 2 ? a.tb[c] : 0.f;
       float zs[G];  // the column of every slot first: G independent loads in flight instead of one per iteration
 #pragma clang loop unroll(full)
       for (int s = 0; s < G; ++s) {
@@ -357,7 +358,7 @@ __global__ __launch_bounds__(256) void tgat_attn_backward_kernel(const AttnBwdAr
           }
           if (part == 0 && a.dnbr) a.dnbr[(r * k + s) * (long long)d + c] += dzs;
           if (part == 2) {
-            const float g = -s_sin[s * T + c] * dzs;  // d cos(arg) / d arg
+            const float g = -sin_t2v(__fmaf_rn(s_dt[s], tw_c, tb_c)) * dzs;  // d cos(arg) / d arg (the argument the cosine above took)
             dw = __fmaf_rn(g, s_dt[s], dw);
             db += g;
           }
@@ -497,7 +498,7 @@ static int attn_backward_impl(const float* qf, const float* probs, const float* 
                 head_stride ? head_stride : C, scale};
   a.drop = make_dropout(drop);
   a.drop_row0 = drop ? drop->row0 : 0;
-  const size_t per_wave = ((size_t)2 * k * T + 2 * (size_t)k + 2 * (size_t)H * k) * sizeof(float);
+  const size_t per_wave = ((size_t)k * T + 2 * (size_t)k + 2 * (size_t)H * k) * sizeof(float);
   int waves = 4;
   while (waves > 1 && per_wave * waves > 64 * 1024) waves >>= 1;
   TGMX_REQUIRE(per_wave * waves <= 64 * 1024, "tgat_attn_backward: k*T=%d too large for LDS", k * T);
