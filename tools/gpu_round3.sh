@@ -13,8 +13,8 @@ b r03_bench_ring_driver_args.json --steps 20 --warmup 5
 b r03_bench_csr.json --cpu-batches 0 --mode csr
 b r03_bench_review_ring.json --cpu-batches 0 --workload review
 b r03_bench_review_csr.json --cpu-batches 0 --workload review --mode csr
-b r03_bench_comment_ring.json --cpu-batches 0 --workload comment --steps 400
-b r03_bench_comment_csr.json --cpu-batches 0 --workload comment --steps 400 --mode csr
+b r03_bench_comment_ring.json --cpu-batches 0 --workload comment --steps 100
+b r03_bench_comment_csr.json --cpu-batches 0 --workload comment --steps 100 --mode csr
 TGMX_DELTA_WRITES=0 timeout 300 python bench.py --cpu-batches 0 --workload comment --steps 400 2>/dev/null | j > "$OUT/r03_bench_comment_ring_full_writes.json"
 TGMX_TILE=0 timeout 300 python bench.py --cpu-batches 0 --workload comment --steps 400 --no-default-path 2>/dev/null | j > "$OUT/r03_bench_comment_ring_packed_kernel.json"
 TGMX_TILE=0 timeout 300 python bench.py --cpu-batches 0 --workload comment --steps 400 --mode csr --no-default-path 2>/dev/null | j > "$OUT/r03_bench_comment_csr_packed_kernel.json"
