@@ -600,10 +600,10 @@ struct Bump {
   }
 };
 
-// One pass over the backward; dry: only the workspace layout is computed (floats needed -> *need_floats, sgemm_tn scratch bytes -> *tn_bytes)
+// One pass over the backward; dry: only the workspace layout is computed (floats needed -> *need_floats)
 int tgat_backward_pass(const tgmx_tgat_model_t* m, const tgmx_tgat_layout_t* lay, const tgmx_tgat_hop_t* hops, const float* saved,
-                       const float* dz, long long ldz, const tgmx_dropout_t* drop, const tgmx_tgat_grads_t* g, float* ws, float* tn_ws,
-                       hipStream_t st, bool dry, size_t* need_floats, size_t* tn_bytes) {
+                       const float* dz, long long ldz, const tgmx_dropout_t* drop, const tgmx_tgat_grads_t* g, float* ws,
+                       hipStream_t st, bool dry, size_t* need_floats) {
   const int L = m->num_layers, d0 = m->d0, T = m->layers[0].T;
   const float p_drop = drop ? drop->p : 0.f;
   static const tgmx_tgat_grads_t no_grads{};
@@ -755,10 +755,6 @@ int tgat_backward_pass(const tgmx_tgat_model_t* m, const tgmx_tgat_layout_t* lay
   if (!dry) {
     (void)hipMemsetAsync(g->tw, 0, (size_t)T * sizeof(float), st);
     (void)hipMemsetAsync(g->tb, 0, (size_t)T * sizeof(float), st);
-    if (sync_each) {
-      const hipError_t e = hipStreamSynchronize(st);
-      fprintf(stderr, "[bwd] memsets done (%s); ws=%p tn_ws=%p (+%zu floats) T=%d L=%d\n", hipGetErrorString(e), (void*)ws, (void*)tn_ws, (size_t)(tn_ws - ws), T, L);
-    }
   }
   const float* S = saved;
   const float* z0 = S + lay->z0;
@@ -854,7 +850,6 @@ int tgat_backward_pass(const tgmx_tgat_model_t* m, const tgmx_tgat_layout_t* lay
 #undef RUN
 #undef RUN_ALWAYS
   if (need_floats) *need_floats = b.off;
-  if (tn_bytes) *tn_bytes = 0;  // (the GEMMs' partials live in the bump area: they outlive the GEMM until the layer's flush)
   return TGMX_OK;
 }
 
@@ -873,9 +868,9 @@ int check_backward_args(const tgmx_tgat_model_t* m, const tgmx_tgat_layout_t* la
 
 extern "C" size_t tgmx_tgat_backward_workspace_bytes(const tgmx_tgat_model_t* m, const tgmx_tgat_layout_t* lay, const tgmx_tgat_hop_t* hops) {
   if (check_backward_args(m, lay, hops)) return 0;
-  size_t floats = 0, tn_bytes = 0;
-  if (tgat_backward_pass(m, lay, hops, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, true, &floats, &tn_bytes)) return 0;
-  return floats * sizeof(float) + ((tn_bytes + 255) & ~(size_t)255) + 512;
+  size_t floats = 0;  // (the weight-gradient GEMMs' split partials live in the same bump area: they outlive the GEMM until the layer's flush)
+  if (tgat_backward_pass(m, lay, hops, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, true, &floats)) return 0;
+  return floats * sizeof(float) + 512;
 }
 
 extern "C" int tgmx_tgat_backward(const tgmx_tgat_model_t* m, const tgmx_tgat_layout_t* lay, const tgmx_tgat_hop_t* hops, const float* saved,
@@ -892,10 +887,7 @@ extern "C" int tgmx_tgat_backward(const tgmx_tgat_model_t* m, const tgmx_tgat_la
   TGMX_REQUIRE(ldz >= m->layers[m->num_layers - 1].emb_out, "tgat_backward: ldz=%lld", (long long)ldz);
   const size_t need = tgmx_tgat_backward_workspace_bytes(m, lay, hops);
   TGMX_REQUIRE(need > 0 && workspace_bytes >= need, "tgat_backward: workspace too small (%zu of %zu bytes)", workspace_bytes, need);
-  size_t floats = 0, tn_bytes = 0;
-  (void)tgat_backward_pass(m, lay, hops, nullptr, nullptr, 0, drop, nullptr, nullptr, nullptr, nullptr, true, &floats, &tn_bytes);
   float* base = reinterpret_cast<float*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
   const float* S = reinterpret_cast<const float*>(((uintptr_t)saved + 255) & ~(uintptr_t)255);  // the forward aligns its workspace the same way
-  if (getenv("TGMX_BWD_SYNC")) fprintf(stderr, "[bwd] workspace %p, %zu bytes (need %zu): %zu floats + %zu tn bytes\n", (void*)workspace, workspace_bytes, need, floats, tn_bytes);
-  return tgat_backward_pass(m, lay, hops, S, dz, (long long)ldz, drop, grads, base, base + floats, (hipStream_t)stream, false, nullptr, nullptr);
+  return tgat_backward_pass(m, lay, hops, S, dz, (long long)ldz, drop, grads, base, (hipStream_t)stream, false, nullptr);
 }
