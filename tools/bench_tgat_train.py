@@ -16,7 +16,7 @@ from tgm_amd.synth import make_stream  # noqa: E402
 stream = make_stream('wiki', seed=1337)
 dev = torch.device('cuda', 0)
 features = sys.argv[2] if len(sys.argv) > 2 else 'dense'  # 'by_id': the sampler publishes edge ids, the attention kernels read the resident store
-dg, hm, hook, loader = bench.build_pipeline(stream, 0, 1, 200, [20, 20], 'ring', dev, edge_features=features)
+dg, hm, hook, loader = bench.build_pipeline(stream, 0, 1, 200, [20, 20], 'ring', dev, pool=None, validate=None, edge_features=features)  # the library's default loader / hook arguments
 starts = loader._starts
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 node_x = dg.static_node_x
@@ -40,7 +40,7 @@ def run(fused):
         return loss
 
     b = loader(starts[run.at])
-    for _ in range(5):
+    for _ in range(20):  # (allocator and weight-layout warm-up)
         step(b)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
