@@ -225,6 +225,18 @@ struct AttnBwdArgs {
   float scale;
   DropoutArgs drop;  // the forward's attention dropout: regenerated, element ((row0 + r) * H + h) * k + s
   long long drop_row0;
+  // Several levels of the hop tree in ONE launch (tgmx_tgat_backward: they share the layer's weights; qf / probs / dzbar / dqf /
+  // dtime are contiguous over the layer's rows, indexed by the layer-wide row r): level i covers rows [seg_begin[i], seg_begin[i+1])
+  // and brings its own sampler tensors, biased by the caller so that the layer-wide r addresses them.  n_seg = 0: the fields above.
+  int n_seg;
+  long long seg_begin[TGMX_TGAT_MAX_LAYERS];
+  const float* seg_nbrf[TGMX_TGAT_MAX_LAYERS];
+  const float* seg_ex[TGMX_TGAT_MAX_LAYERS];
+  const int32_t* seg_eid[TGMX_TGAT_MAX_LAYERS];
+  const float* seg_table[TGMX_TGAT_MAX_LAYERS];
+  const int64_t* seg_seed_t[TGMX_TGAT_MAX_LAYERS];
+  const int64_t* seg_nbr_t[TGMX_TGAT_MAX_LAYERS];
+  float* seg_dnbr[TGMX_TGAT_MAX_LAYERS];
 };
 
 template <int HALF>
@@ -256,13 +268,27 @@ __global__ __launch_bounds__(256) void tgat_attn_backward_kernel(const AttnBwdAr
   if (r >= a.R) return;
   const float* __restrict__ q = a.qf + r * (long long)H * Cs;
   const float* __restrict__ dz = a.dzbar + r * (long long)H * Cs;
-  const float* __restrict__ nb = a.nbrf + r * (long long)k * d;
-  const float* __restrict__ ex = a.ex ? a.ex + r * (long long)k * D : nullptr;
+  // this row's level (wave-uniform) and its tensors
+  const float* lv_nbrf = a.nbrf;
+  const float* lv_ex = a.ex;
+  const int32_t* lv_eid = a.eid;
+  const float* lv_table = a.table;
+  const int64_t *lv_seed_t = a.seed_t, *lv_nbr_t = a.nbr_t;
+  float* lv_dnbr = a.dnbr;
+  if (a.n_seg > 0) {
+    int sg = 0;
+    for (int i2 = 1; i2 < a.n_seg; ++i2)
+      if (r >= a.seg_begin[i2]) sg = i2;
+    lv_nbrf = a.seg_nbrf[sg]; lv_ex = a.seg_ex[sg]; lv_eid = a.seg_eid[sg]; lv_table = a.seg_table[sg];
+    lv_seed_t = a.seg_seed_t[sg]; lv_nbr_t = a.seg_nbr_t[sg]; lv_dnbr = a.seg_dnbr[sg];
+  }
+  const float* __restrict__ nb = lv_nbrf + r * (long long)k * d;
+  const float* __restrict__ ex = lv_ex ? lv_ex + r * (long long)k * D : nullptr;
 
-  const long long st = a.seed_t[r];
+  const long long st = lv_seed_t[r];
   for (int s = lane; s < k; s += kWave) {
-    s_dt[s] = (float)(st - a.nbr_t[r * k + s]);
-    if (a.eid) s_eid[s] = a.eid[r * k + s];
+    s_dt[s] = (float)(st - lv_nbr_t[r * k + s]);
+    if (lv_eid) s_eid[s] = lv_eid[r * k + s];
   }
   __builtin_amdgcn_wave_barrier();
   for (int e = lane; e < k * T; e += kWave) {
@@ -283,7 +309,7 @@ __global__ __launch_bounds__(256) void tgat_attn_backward_kernel(const AttnBwdAr
   };
   auto by_id = [&](int sl, int c) -> float {
     const int e = __builtin_amdgcn_readfirstlane(s_eid[sl]);
-    return e >= 0 ? a.table[(long long)e * D + c] : 0.f;
+    return e >= 0 ? lv_table[(long long)e * D + c] : 0.f;
   };
   auto accumulate = [&](auto&& load, int dim, int col0) {
     for (int c = lane; c < dim; c += kWave) {
@@ -356,7 +382,7 @@ __global__ __launch_bounds__(256) void tgat_attn_backward_kernel(const AttnBwdAr
             acc[h] = __fmaf_rn(s_ds[h * k + s], z, acc[h]);
             dzs += s_A[h * k + s] * gv[h] + a.scale * s_ds[h * k + s] * qv[h];
           }
-          if (part == 0 && a.dnbr) a.dnbr[(r * k + s) * (long long)d + c] += dzs;
+          if (part == 0 && lv_dnbr) lv_dnbr[(r * k + s) * (long long)d + c] += dzs;
           if (part == 2) {
             const float g = -sin_t2v(__fmaf_rn(s_dt[s], tw_c, tb_c)) * dzs;  // d cos(arg) / d arg (the argument the cosine above took)
             dw = __fmaf_rn(g, s_dt[s], dw);
@@ -475,6 +501,7 @@ static int attn_backward_impl(const float* qf, const float* probs, const float* 
                               const int32_t* eid, const float* table, int32_t D, const int64_t* seed_t, const int64_t* nbr_t, const float* tw,
                               const float* tb, int32_t T, int32_t H, int32_t k, int64_t R, float scale, int32_t head_stride, float* dqf,
                               float* dnbr, float* dtime_rows, const tgmx_dropout_t* drop, tgmx_stream_t stream);
+static int launch_attn_backward(const AttnBwdArgs& a, int H, tgmx_stream_t stream);
 
 extern "C" int tgmx_tgat_attn_backward(const float* qf, const float* probs, const float* dzbar, const float* nbrf, int32_t d,
                                        const float* ex, int32_t D, const int64_t* seed_t, const int64_t* nbr_t, const float* tw,
@@ -498,6 +525,12 @@ static int attn_backward_impl(const float* qf, const float* probs, const float* 
                 head_stride ? head_stride : C, scale};
   a.drop = make_dropout(drop);
   a.drop_row0 = drop ? drop->row0 : 0;
+  return launch_attn_backward(a, H, stream);
+}
+
+static int launch_attn_backward(const AttnBwdArgs& a, int H, tgmx_stream_t stream) {
+  const int k = a.k, T = a.T;
+  const long long R = a.R;
   const size_t per_wave = ((size_t)k * T + 2 * (size_t)k + 2 * (size_t)H * k) * sizeof(float);
   int waves = 4;
   while (waves > 1 && per_wave * waves > 64 * 1024) waves >>= 1;
@@ -814,14 +847,32 @@ int tgat_backward_pass(const tgmx_tgat_model_t* m, const tgmx_tgat_layout_t* lay
     float* dprev = need_dprev ? b.take(prev_rows * d) : nullptr;
     if (need_dprev && !dry) (void)hipMemsetAsync(dprev, 0, prev_rows * d * sizeof(float), st);
     const float scale = (float)pow((double)dh, -0.5);
-    for (int i = 0; i < n_lvl; ++i) {
-      const long long Ri = lay->level_rows[i];
-      if (!Ri) continue;
-      const long long o = lay->level_off[i], o1 = lay->level_off[i + 1];
-      const tgmx_dropout_t site{p_drop, drop ? drop->seed : 0, (drop ? drop->stream : 0) * 64 + 2 * (uint64_t)j, o};
-      RUN(attn_backward_impl(qf + o * H * Cp, probs + o * H * k, dzbar + o * H * Cp, prev + o1 * d, d, hops[i].edge_x, hops[i].nbr_eid,
-                             hops[i].edge_table, D, hops[i].seed_t, hops[i].nbr_t, m->tw, m->tb, T, H, k, Ri, scale, Cp, dqf + o * H * Cp,
-                             need_dprev ? dprev + o1 * d : nullptr, dtime + o * 2 * T, p_drop > 0.f ? &site : nullptr, stream));
+    {  // every level this layer aggregates in ONE launch (the 600-row levels alone take as long as one row's chain of round trips: 45 us)
+      AttnBwdArgs ab{};
+      ab.qf = qf; ab.probs = probs; ab.dzbar = dzbar; ab.tw = m->tw; ab.tb = m->tb; ab.dqf = dqf; ab.dtime = dtime;
+      ab.R = lay->level_off[n_lvl]; ab.d = d; ab.D = D; ab.T = T; ab.k = k; ab.C = C; ab.Cs = Cp; ab.scale = scale;
+      ab.n_seg = n_lvl;
+      bool ok = (H == 1 || H == 2 || H == 4 || H == 8) && k * H <= 64;
+      for (int i = 0; i < n_lvl; ++i) {
+        const long long o = lay->level_off[i], o1 = lay->level_off[i + 1];
+        const bool by_id = !hops[i].edge_x && hops[i].nbr_eid && hops[i].edge_table;
+        ok = ok && (lay->level_rows[i] == 0 || (hops[i].seed_t && hops[i].nbr_t && (D == 0 || hops[i].edge_x || by_id)));
+        ab.seg_begin[i] = o;  // the kernel indexes with the layer-wide row: bias every level's arrays by its first row
+        ab.seg_nbrf[i] = prev + o1 * d - o * (long long)k * d;
+        ab.seg_ex[i] = hops[i].edge_x ? hops[i].edge_x - o * (long long)k * D : nullptr;
+        ab.seg_eid[i] = by_id ? hops[i].nbr_eid - o * (long long)k : nullptr;
+        ab.seg_table[i] = by_id ? hops[i].edge_table : nullptr;
+        ab.seg_seed_t[i] = hops[i].seed_t - o;
+        ab.seg_nbr_t[i] = hops[i].nbr_t - o * (long long)k;
+        ab.seg_dnbr[i] = need_dprev ? dprev + o1 * d - o * (long long)k * d : nullptr;
+      }
+      if (!dry) {
+        TGMX_REQUIRE(ok, "tgat_backward: layer %d: unsupported head count / k, or a hop without its sampler tensors", j);
+        const tgmx_dropout_t site{p_drop, drop ? drop->seed : 0, (drop ? drop->stream : 0) * 64 + 2 * (uint64_t)j, 0};
+        ab.drop = make_dropout(p_drop > 0.f ? &site : nullptr);
+        ab.drop_row0 = 0;
+      }
+      if (ab.R > 0) RUN(launch_attn_backward(ab, H, stream));
     }
     RUN_ALWAYS(colsum(dtime, 2 * T, R, T, g->tw, 1));
     RUN_ALWAYS(colsum(dtime + T, 2 * T, R, T, g->tb, 1));
