@@ -785,10 +785,6 @@ int tgat_backward_pass(const tgmx_tgat_model_t* m, const tgmx_tgat_layout_t* lay
     if (rc) return rc;
   }
   if (n_jobs) RUN(tgmx_pack2d(jobs, n_jobs, stream));
-  if (!dry) {
-    (void)hipMemsetAsync(g->tw, 0, (size_t)T * sizeof(float), st);
-    (void)hipMemsetAsync(g->tb, 0, (size_t)T * sizeof(float), st);
-  }
   const float* S = saved;
   const float* z0 = S + lay->z0;
   const float* dout = dz;
@@ -874,8 +870,9 @@ int tgat_backward_pass(const tgmx_tgat_model_t* m, const tgmx_tgat_layout_t* lay
       }
       if (ab.R > 0) RUN(launch_attn_backward(ab, H, stream));
     }
-    RUN_ALWAYS(colsum(dtime, 2 * T, R, T, g->tw, 1));
-    RUN_ALWAYS(colsum(dtime + T, 2 * T, R, T, g->tb, 1));
+    // (the top layer's sums open the Time2Vec gradients -- 0 + x is x, what accumulating into zeroed buffers gave -- the others add to them)
+    RUN_ALWAYS(colsum(dtime, 2 * T, R, T, g->tw, j == L ? 0 : 1));
+    RUN_ALWAYS(colsum(dtime + T, 2 * T, R, T, g->tb, j == L ? 0 : 1));
     // ---- W_K fold: qf[:, h, :] = Q[:, head h] @ W_K[head h] ----
     RUN_ALWAYS(tn(Q, (long long)H * dhp, dqf, (long long)H * Cp, g_WK, C, R, dh, C, H, dhp, Cp, (long long)dh * C));
     float* dQ = b.take((size_t)R * H * dhp);
