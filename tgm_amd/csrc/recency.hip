@@ -2903,7 +2903,12 @@ extern "C" int tgmx_recency_step(const tgmx_recency_step_t* s, tgmx_stream_t str
   auto enqueue_side = [&]() -> int {
     if (!side_pending) return TGMX_OK;
     side_pending = false;
-    if (const int rl = launch_update_large_front(u, s->scratch + kScratchHead, side->stream, true)) return rl;
+    // "beside a saturating lookup launch": only then do the chain's small kernels crawl (and the one-workgroup front half pay); beside
+    // a few thousand seeds -- an 8-rank share of a 4096-edge batch -- the chain is the faster of the two and the step waits for it
+    long long widest = S;
+    for (int h = 0; h + 1 < s->n_hops; ++h) widest *= s->k[h];
+    const bool saturating = widest >= 2ll * kWave * device_cu_count();
+    if (const int rl = launch_update_large_front(u, s->scratch + kScratchHead, side->stream, saturating)) return rl;
     (void)hipEventRecord(side->join, side->stream);
     return TGMX_OK;
   };
