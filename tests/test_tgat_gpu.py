@@ -129,6 +129,40 @@ def test_tgat_forward_matches_reference(case):
         close(enc(**{k: dev(v) for k, v in inputs.items()}), z_ref, case + ' (no_grad)')
 
 
+def test_pack2d_matches_torch_and_refuses_malformed_jobs():
+    """``tgmx_pack2d`` (weights into the kernels' padded / transposed layouts, one launch for a list of jobs) against torch's zeros +
+    slice assignment, through the C ABI; more than TGMX_PACK_MAX_JOBS jobs or a destination smaller than its data are refused."""
+    import ctypes
+
+    from tgm_amd import _native
+
+    lib = _native.load()
+    g = torch.Generator().manual_seed(3)
+    W = torch.randn(86, 173, generator=g).to(DEV)
+    V = torch.randn(40, 7, generator=g).to(DEV)
+    pad = torch.full((86, 176), 7.0, device=DEV)           # rows padded to 176 columns
+    tr = torch.full((173, 2 * 88), 7.0, device=DEV)        # the transpose, written at column 88 of a wider destination
+    sub = torch.full((12, 8), 7.0, device=DEV)             # rows [20, 32) of V, padded
+    jobs = (_native.PackJob * 3)(
+        _native.PackJob(W.data_ptr(), pad.data_ptr(), 173, 176, 86, 173, 86, 176, 0, 0),
+        _native.PackJob(W.data_ptr(), tr.data_ptr() + 4 * 88, 173, 176, 173, 86, 173, 88, 1, 0),
+        _native.PackJob(V.data_ptr() + 4 * 20 * 7, sub.data_ptr(), 7, 8, 12, 7, 12, 8, 0, 0),
+    )
+    _native.check(lib.tgmx_pack2d(jobs, 3, _native.stream_ptr()), 'tgmx_pack2d')
+    ref_pad = torch.zeros(86, 176, device=DEV)
+    ref_pad[:, :173] = W
+    assert torch.equal(pad, ref_pad)
+    assert torch.equal(tr[:, 88:174], W.t()) and bool((tr[:, 174:] == 0).all()) and bool((tr[:, :88] == 7).all())
+    ref_sub = torch.zeros(12, 8, device=DEV)
+    ref_sub[:, :7] = V[20:32]
+    assert torch.equal(sub, ref_sub)
+    many = (_native.PackJob * (_native.PACK_MAX_JOBS + 1))()
+    assert lib.tgmx_pack2d(many, _native.PACK_MAX_JOBS + 1, _native.stream_ptr()) != 0
+    bad = (_native.PackJob * 1)(_native.PackJob(W.data_ptr(), pad.data_ptr(), 173, 100, 86, 173, 86, 100, 0, 0))  # 173 columns into 100
+    assert lib.tgmx_pack2d(bad, 1, _native.stream_ptr()) != 0
+    assert b'pack2d' in lib.tgmx_last_error()
+
+
 def test_deep_copy_after_a_forward_is_an_independent_twin():
     """``copy.deepcopy(model)`` after the model has run (best-checkpoint copies, EMA twins): the copy leaves the original's ctypes blocks
     and weight-layout buffers behind, rebuilds its own, and follows ITS parameters."""
