@@ -770,13 +770,13 @@ int tgat_backward_pass(const tgmx_tgat_model_t* m, const tgmx_tgat_layout_t* lay
     LayerW& w = W[l];
     w.F2_t = b.take((size_t)emb * emb_out);        // [emb, emb_out]      = fc2.weight^T
     w.F1_t = b.take((size_t)(O + d0) * emb);       // [O + d0, emb]       = fc1.weight^T
-    w.WO_t = b.take((size_t)O * O);                // [O, O]              = W_O^T
+    w.WO_t = b.take((size_t)H * dhp * O);          // [H * dhp, O]        = W_O^T, head h's dh rows at row h * dhp (zero rows between)
     w.WV_t = b.take((size_t)C * H * dhp);          // [C, H * dhp]        = W_V^T, heads dhp apart
     w.WK_p = b.take((size_t)O * Cp);               // [O, Cp]             = W_K, rows padded
     w.WQ_t = b.take((size_t)O * H * dhp);          // [O, H * dhp]        = W_Q^T, heads dhp apart
     int rc = job(ly.fc2_w, Ep, w.F2_t, emb_out, emb, emb_out, emb, emb_out);
     if (!rc) rc = job(ly.fc1_w, Kc, w.F1_t, emb, O + d0, emb, O + d0, emb);
-    if (!rc) rc = job(ly.W_O, Op, w.WO_t, O, O, O, O, O);
+    for (int h = 0; h < H && !rc; ++h) rc = job(ly.W_O + h * dh, Op, w.WO_t + (long long)h * dhp * O, O, dh, O, dhp, O);
     for (int h = 0; h < H && !rc; ++h) {
       rc = job(ly.W_V + (long long)h * dh * Cp, Cp, w.WV_t + h * dhp, (long long)H * dhp, C, dh, C, dhp);
       if (!rc) rc = job(ly.W_K_t + h * dhp, (long long)H * dhp, w.WK_p + (long long)h * dh * Cp, Cp, dh, C, dh, Cp);
@@ -827,14 +827,17 @@ int tgat_backward_pass(const tgmx_tgat_model_t* m, const tgmx_tgat_layout_t* lay
     }
     RUN_ALWAYS(tn(du_y, Op, oattn, Op, gl.W_O, O, R, O, O, 1, 0, 0, 0));
     RUN_ALWAYS(colsum(du_y, Op, R, O, gl.b_O, 0));
-    float* doattn = b.take((size_t)R * Op);
-    RUN(nt(du_y, Op, w.WO_t, O, doattn, Op, R, O, O, 1, 0, 0, 0));
+    // (d oattn with its heads dhp apart, like Q: head 1 of the dense [R, O] layout starts at column dh = 86 -- 8-byte aligned -- and the
+    // batched GEMM below then takes the scalar-load path, 32 us instead of 18; same dot products, same order: identical values)
+    const long long ld_do = (long long)H * dhp;
+    float* doattn = b.take((size_t)R * ld_do);
+    RUN(nt(du_y, Op, w.WO_t, O, doattn, ld_do, R, H * dhp, O, 1, 0, 0, 0));
     // ---- W_V fold: oattn[:, head h] = zbar[:, h, :] @ W_V[head h]^T ----
     float* g_WK = gl.W_KV;
     float* g_WV = gl.W_KV + (long long)O * C;
-    RUN_ALWAYS(tn(doattn, Op, zbar, (long long)H * Cp, g_WV, C, R, dh, C, H, dh, Cp, (long long)dh * C));
+    RUN_ALWAYS(tn(doattn, ld_do, zbar, (long long)H * Cp, g_WV, C, R, dh, C, H, dhp, Cp, (long long)dh * C));
     float* dzbar = b.take((size_t)R * H * Cp);
-    RUN(nt(doattn, Op, w.WV_t, (long long)H * dhp, dzbar, (long long)H * Cp, R, C, dh, H, dh, dhp, Cp));
+    RUN(nt(doattn, ld_do, w.WV_t, (long long)H * dhp, dzbar, (long long)H * Cp, R, C, dh, H, dhp, dhp, Cp));
     // ---- per-row attention backward, level by level ----
     float* dqf = b.take((size_t)R * H * Cp);
     float* dtime = b.take((size_t)R * 2 * T);
