@@ -777,13 +777,15 @@ __device__ __forceinline__ void update_merge_riding(const UpdateArgs& a, int c0,
 // What rides along with which launch (tgmx_recency_step):
 //   kSideSort  (hop 0): workgroup c chunk-sorts entries [256 c, 256 c + 256)
 //   kSideMerge (hop 1, 1024 < m <= 4096): workgroup c ranks chunk c's entries; the placement is its own launch
+//   kSideSortMerge / kSidePlaceOnly (hop 0 / hop 1 as two launches, m <= 1024, round 3): the chunk riders of hop 0 merge too (barrier between
+//     them), hop 1's ONE rider only decides the placement -- review shape: hop 1 17.9 -> 7.9 us, step 29.0 -> 25.0 us
 //   kSidePlace (hop 1, m <= 1024): ONE workgroup merges the whole batch and decides the placement (DEFER): after the
 //              lookups a single launch commits records, write_pos and feature rows
 //   kSideAll   (fused hop 0 + 1 launch, m <= 1024): ONE workgroup does all of it -- chunk sorts one after the other,
 //              merge, placement decisions -- inside the single lookup launch
 //   kSideSortMerge (fused hop 0 + 1 launch, 1024 < m <= 4096): workgroup c chunk-sorts, all riders meet at a barrier of
 //              their own (they are the launch's first <= 16 workgroups: resident together), then workgroup c merges
-constexpr int kSideSort = 1, kSideMerge = 2, kSidePlace = 3, kSideAll = 4, kSideSortMerge = 5;
+constexpr int kSideSort = 1, kSideMerge = 2, kSidePlace = 3, kSideAll = 4, kSideSortMerge = 5, kSidePlaceOnly = 6;
 
 // Barrier between the `parts` rider workgroups of one launch: bar[0] counts arrivals, bar[1] is the generation.  It
 // resets itself, so the words only have to be zero when the scratch buffer is first used.  What crosses it (the
@@ -971,8 +973,10 @@ __device__ __forceinline__ void update_side_work(const UpdateArgs& u, int stage,
         __syncthreads();  // W.sort is reused; the chunk-sorted pairs written above are read below by other threads
       }
     }
-    update_merge_riding<NCH, NCH>(u, 0, W.smp);
-    __syncthreads();  // the sorted arrays written above are read below by other threads of this workgroup
+    if (stage != kSidePlaceOnly) {  // (kSidePlaceOnly: the hop-0 launch's riders merged already -- kSideSortMerge)
+      update_merge_riding<NCH, NCH>(u, 0, W.smp);
+      __syncthreads();  // the sorted arrays written above are read below by other threads of this workgroup
+    }
     SortLds<1> none;
     update_block_body<NCH, PCAP, true, true>(u, W.place, none);
   }
@@ -2965,9 +2969,14 @@ extern "C" int tgmx_recency_step(const tgmx_recency_step_t* s, tgmx_stream_t str
     const bool timed = h == s->timed_hop;
     hipEvent_t e0 = timed ? (hipEvent_t)s->ev_start : nullptr, e1 = timed ? (hipEvent_t)s->ev_stop : nullptr;
     const bool ride = side_chunks > 0 && h < 2;
+    // m <= 1024, two lookup launches: the merge rides hop 0 with the chunk sorts (its riders meet at a barrier), hop 1's single rider
+    // only decides the placement -- the one workgroup that merged AND placed made hop 1 last 17.7 us at the review shape (TGMX_SPLIT_MERGE=0: A/B)
+    static const bool split_merge_on = !(getenv("TGMX_SPLIT_MERGE") && atoi(getenv("TGMX_SPLIT_MERGE")) == 0);
+    const bool split_merge = split_merge_on && ride_place && s->n_hops >= 2;
     const int rc = csr ? launch_lookup<false>(a, st, e0, e1)
                        : launch_lookup<true>(a, st, e0, e1, ride ? &u : nullptr,
-                                             h == 0 ? kSideSort : (ride_place ? kSidePlace : kSideMerge),
+                                             h == 0 ? (split_merge ? kSideSortMerge : kSideSort)
+                                                    : (ride_place ? (split_merge ? kSidePlaceOnly : kSidePlace) : kSideMerge),
                                              (h == 1 && ride_place) ? 1u : side_chunks, (h == 1 && ride_place) ? tail_blocks : 0u);
     if (rc) return rc;
     if (const int rs = enqueue_side()) return rs;
