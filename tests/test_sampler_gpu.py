@@ -190,6 +190,9 @@ def test_ring_mode_matches_oracle_random(N, E, D, tmax, num_nbrs, bs, directed, 
         (6000, 8196, 2, 2_600_000, [4, 2], 2049),  # m=4098: radix-sort path
         (700, 3000, 6, 900, [12], 300),  # single hop: chunk sort rides hop 0, the merge is its own launch
         (700, 3000, 0, 900, [12, 4], 300),  # no edge features: the commit launch still writes records and write_pos
+        (3000, 6000, 64, 2_600_000, [20, 20], 400),  # wide rows, m=800: fused hop 0 + 1 launch, a rider per chunk, the last one out places
+        (500, 4626, 172, 3000, [20, 20], 257),  # m=514: three chunks (the last with two entries), heavy ties, ragged last batch
+        (800, 4096, 32, 2_600_000, [16, 8], 512),  # m=1024 in the fused launch: four full chunks
     ],
 )
 def test_ring_step_variants(N, E, D, tmax, num_nbrs, bs, validate):

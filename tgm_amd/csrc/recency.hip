@@ -316,9 +316,22 @@ struct SortLds {
   int pay[MAXM];
 };
 
+// device-coherent accesses for what rider workgroups of ONE launch hand to each other (other CUs, other XCDs' L2s):
+// sc1 stores / loads reach the device's coherence point, so no cache write-back or invalidate is needed around the
+// riders' barrier -- the lookups around them keep their L2 contents
+template <typename T>
+__device__ __forceinline__ void st_agent(T* p, T v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename T>
+__device__ __forceinline__ T ld_agent(const T* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // DEFER: decide everything, write nothing to the rings -- winner[p] = the ring row position p finally owns (-1 none),
 // target[p] = the write_pos increment position p commits (0 none); `ring_update_commit_kernel` applies them.
-template <int E, int MAXM, bool PRESORTED, bool DEFER>
+// COH: the presorted arrays were written by OTHER workgroups of this launch (riders): read them device-coherently
+template <int E, int MAXM, bool PRESORTED, bool DEFER, bool COH = false>
 __device__ __forceinline__ void update_block_body(const UpdateArgs& a, PlaceLds<MAXM>& L, SortLds<PRESORTED ? 1 : MAXM>& S,
                                                   int part = 0, int parts = 1) {
   constexpr int H = 2 * MAXM;
@@ -353,9 +366,9 @@ __device__ __forceinline__ void update_block_body(const UpdateArgs& a, PlaceLds<
       node[r] = -1;
       w[r] = 0;
       if (p < m) {
-        pay[r] = a.sorted_j[p];
-        node[r] = a.sorted_node[p];
-        w[r] = a.target[p];
+        pay[r] = COH ? ld_agent(&a.sorted_j[p]) : a.sorted_j[p];
+        node[r] = COH ? ld_agent(&a.sorted_node[p]) : a.sorted_node[p];
+        w[r] = COH ? ld_agent(&a.target[p]) : a.target[p];
       }
     }
   } else {
@@ -537,18 +550,6 @@ __global__ __launch_bounds__(kBlockThreads) void ring_update_decide_kernel(const
 // (PRESORTED) and the feature copy.  The same pieces are the chunked path of the stand-alone `tgmx_ring_update`.
 
 // one 256-thread workgroup sorts entries [chunk * 256, chunk * 256 + 256) by (key, entry index)
-// device-coherent accesses for what rider workgroups of ONE launch hand to each other (other CUs, other XCDs' L2s):
-// sc1 stores / loads reach the device's coherence point, so no cache write-back or invalidate is needed around the
-// riders' barrier -- the lookups around them keep their L2 contents
-template <typename T>
-__device__ __forceinline__ void st_agent(T* p, T v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-template <typename T>
-__device__ __forceinline__ T ld_agent(const T* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 struct ChunkSortLds {
   long long key[kChunk];
   int pay[kChunk];
@@ -676,7 +677,7 @@ struct SampleLds {
 // NE entries per thread (entry `tid` of chunks c0 .. c0 + NE - 1), each searched in up to NC chunks; NE * NC
 // searches advance together.  <1, 16>: one workgroup per chunk, any m <= 4096.  <4, 4>: ONE workgroup merges a whole
 // batch of m <= 1024 entries (and goes on to place it, see below).
-template <int NE, int NC>
+template <int NE, int NC, bool COH = false>  // COH: the placement follows in ANOTHER workgroup of this launch
 __device__ __forceinline__ void update_merge_riding(const UpdateArgs& a, int c0, SampleLds& W) {
   const int m = (int)a.m;
   const int tid = threadIdx.x;
@@ -767,10 +768,16 @@ __device__ __forceinline__ void update_merge_riding(const UpdateArgs& a, int c0,
     rec.nbr = nbr[q];
     rec.eid = a.eid0 >= 0 ? (int)(a.eid0 + i[q]) : -1;
     rec.ts = t[q];
-    a.sorted_j[rank] = pay[q];
-    a.sorted_node[rank] = valid[q] ? node[q] : -1;
-    a.target[rank] = w[q] % a.B;
-    a.sorted_rec[rank] = rec;
+    if constexpr (COH) {
+      st_agent(&a.sorted_j[rank], pay[q]);
+      st_agent(&a.sorted_node[rank], valid[q] ? node[q] : -1);
+      st_agent(&a.target[rank], w[q] % a.B);
+    } else {
+      a.sorted_j[rank] = pay[q];
+      a.sorted_node[rank] = valid[q] ? node[q] : -1;
+      a.target[rank] = w[q] % a.B;
+    }
+    a.sorted_rec[rank] = rec;  // (read by the commit launch only)
   }
 }
 
@@ -785,7 +792,7 @@ __device__ __forceinline__ void update_merge_riding(const UpdateArgs& a, int c0,
 //              merge, placement decisions -- inside the single lookup launch
 //   kSideSortMerge (fused hop 0 + 1 launch, 1024 < m <= 4096): workgroup c chunk-sorts, all riders meet at a barrier of
 //              their own (they are the launch's first <= 16 workgroups: resident together), then workgroup c merges
-constexpr int kSideSort = 1, kSideMerge = 2, kSidePlace = 3, kSideAll = 4, kSideSortMerge = 5, kSidePlaceOnly = 6;
+constexpr int kSideSort = 1, kSideMerge = 2, kSidePlace = 3, kSideAll = 4, kSideSortMerge = 5, kSidePlaceOnly = 6, kSideSortMergePlace = 7;
 
 // Barrier between the `parts` rider workgroups of one launch: bar[0] counts arrivals, bar[1] is the generation.  It
 // resets itself, so the words only have to be zero when the scratch buffer is first used.  What crosses it (the
@@ -965,6 +972,27 @@ __device__ __forceinline__ void update_side_work(const UpdateArgs& u, int stage,
     update_merge_riding<1, kBlockMaxM / kChunk>(u, block, W.smp);
   } else if constexpr (PCAP > 0) {
     constexpr int NCH = PCAP / kChunk;  // chunks of a batch this rider takes whole: one entry of every chunk per thread
+    if (stage == kSideSortMergePlace) {
+      // fused hop 0 + 1 launch, 512 < m <= 1024 (a 2-rank share of the wiki batch: m = 800): one rider PER CHUNK sorts and, behind the
+      // riders' barrier, ranks its chunk; the last one out decides the placement.  (One rider doing the four chunk sorts one after
+      // the other, the merge and the placement took longer than the lookups around it: 42.7 us per step instead of 34.)
+      const int chunks = (int)((u.m + kChunk - 1) / kChunk);
+      __shared__ int last_out;
+      update_chunk_sort<true>(u, block, W.sort);
+      if (!rider_barrier(u.barrier, chunks) && threadIdx.x == 0) atomicOr(u.status, TGMX_ST_SCRATCH);
+      update_merge_riding<1, NCH, true>(u, block, W.smp);
+      __syncthreads();  // every thread's device-coherent stores have completed
+      if (threadIdx.x == 0) {
+        const int prev = __hip_atomic_fetch_add(&u.barrier[5], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_out = prev == chunks - 1;
+        if (last_out) __hip_atomic_store(&u.barrier[5], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // zero for the next launch
+      }
+      __syncthreads();
+      if (!last_out) return;
+      SortLds<1> none;
+      update_block_body<NCH, PCAP, true, true, true>(u, W.place, none);
+      return;
+    }
     if (stage == kSideAll) {
       const int chunks = (int)((u.m + kChunk - 1) / kChunk);
 #pragma unroll 1
@@ -2029,7 +2057,7 @@ static int launch_fused01(LookupArgs a, hipStream_t stream, hipEvent_t ev_start,
   const dim3 grid((unsigned)blocks + a.side_blocks + a.tail_blocks), block(waves_per_block * kWave);
   const size_t lds = (size_t)waves_per_block * kmax * sizeof(int);
   // the riders' static LDS sized for what rides (RiderLds): placement of <= 512 entries, of <= 1024, or sort / merge only
-  const int pcap = !(RING && side) ? 1024 : (side_stage != kSideAll ? 0 : (u.m <= 512 ? 512 : 1024));
+  const int pcap = !(RING && side) ? 1024 : ((side_stage != kSideAll && side_stage != kSideSortMergePlace) ? 0 : (u.m <= 512 ? 512 : 1024));
   if (vec == 4 && pcap == 512) TGMX_LAUNCH_TIMED((recency_lookup_fused01_kernel<RING, 4, RING ? 512 : 1024>), grid, block, lds, stream, ev_start, ev_stop, a, u);
   else if (vec == 4 && pcap == 0) TGMX_LAUNCH_TIMED((recency_lookup_fused01_kernel<RING, 4, RING ? 0 : 1024>), grid, block, lds, stream, ev_start, ev_stop, a, u);
   else if (vec == 4) TGMX_LAUNCH_TIMED((recency_lookup_fused01_kernel<RING, 4>), grid, block, lds, stream, ev_start, ev_stop, a, u);
@@ -2939,10 +2967,14 @@ extern "C" int tgmx_recency_step(const tgmx_recency_step_t* s, tgmx_stream_t str
     a.x_by_pos = csr && s->csr_x_by_pos;
     const bool timed = s->timed_hop == 0 || s->timed_hop == 1;
     hipEvent_t e0 = timed ? (hipEvent_t)s->ev_start : nullptr, e1 = timed ? (hipEvent_t)s->ev_stop : nullptr;
-    // riders: m <= 1024 -> one workgroup does it all and only the commit follows; else sort | barrier | merge
+    // riders: m <= 512 -> one workgroup does it all and only the commit follows; 512 < m <= 1024 -> a rider per chunk, the last one
+    // out places (TGMX_THREE_PHASE=0: one workgroup, A/B); else sort | barrier | merge and the placement is its own launch
+    static const bool three_phase_on = !(getenv("TGMX_THREE_PHASE") && atoi(getenv("TGMX_THREE_PHASE")) == 0);
+    const bool three_phase = three_phase_on && ride_place && u.m > 512 && !tail_blocks;
     const int rc = csr ? launch_fused01<false>(a, st, e0, e1, nullptr, 0, 0)
                        : launch_fused01<true>(a, st, e0, e1, side_chunks > 0 ? &u : nullptr,
-                                              ride_place ? kSideAll : kSideSortMerge, ride_place ? 1u : side_chunks, tail_blocks);
+                                              ride_place ? (three_phase ? kSideSortMergePlace : kSideAll) : kSideSortMerge,
+                                              (ride_place && !three_phase) ? 1u : side_chunks, tail_blocks);
     if (rc) return rc;
     if (const int rs = enqueue_side()) return rs;
     cur_n = s->out_nid[1];
