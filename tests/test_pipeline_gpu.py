@@ -391,6 +391,42 @@ def test_lowered_tgn_tail_dedup_and_edge_list():
         assert pooled._compiled[1].n_lowered == 4 and ahead._compiled[1].n_lowered == 4
 
 
+def test_edge_features_by_id_with_the_tgn_tail():
+    """ RecencyNeighborHook(edge_features='by_id') in front of DeduplicationHook -> SampledEdgeListHook under the DEFAULT
+    loader: the lowered post block reads the dense [S, k, D] copies, which that mode does not make, so the edge-list hook must
+    stay behind the lowered prefix (3 hooks lowered, not 4) -- and every tensor equals the dense chain's."""
+    from tgm_amd import DGData, DGDataLoader, DGraph
+    from tgm_amd.hooks import DeduplicationHook, HookManager, RandomNegativeEdgeSamplerHook, RecencyNeighborHook, SampledEdgeListHook
+
+    st = _stream(E=3000, D=8, shape='review', n_src=300, n_dst=60)
+    dg = DGraph(DGData.from_raw(st.ts, torch.stack([st.src, st.dst], 1), st.edge_x), device=DEV)
+
+    def chain(features):
+        hm = HookManager(keys=['k'])
+        hm.register('k', RandomNegativeEdgeSamplerHook(300, st.num_nodes, seed=9))
+        hm.register('k', RecencyNeighborHook(st.num_nodes, [5, 3], ['edge_src', 'edge_dst', 'neg'], ['edge_time', 'edge_time', 'neg_time'],
+                                             edge_features=features))
+        hm.register('k', DeduplicationHook(seed_nodes_keys=['neg', 'nbr_nids']))
+        hm.register('k', SampledEdgeListHook(hop=0))
+        return hm
+
+    hm_a, hm_b, hm_c = chain('dense'), chain('by_id'), chain('by_id')
+    dense = DGDataLoader(dg, batch_size=200, hook_manager=hm_a)
+    by_id = DGDataLoader(dg, batch_size=200, hook_manager=hm_b)  # the default pool: lowers
+    by_id_hooks = DGDataLoader(dg, batch_size=200, hook_manager=hm_c, output_pool=0)
+    names = ('neg', 'unique_nids', 'sampled_edge_index', 'sampled_edge_time', 'sampled_edge_x')
+    with hm_a.activate('k'), hm_b.activate('k'), hm_c.activate('k'):
+        for n, (a, b, c) in enumerate(zip(dense, by_id, by_id_hooks)):
+            for other in (b, c):
+                for name in names:
+                    _same(getattr(a, name), getattr(other, name), f'batch {n} {name}')
+                _same(a.nbr_nids, other.nbr_nids, f'batch {n} nbr_nids')
+                for h in range(2):
+                    _same(a.nbr_edge_x[h], other.nbr_edge_x[h], f'batch {n} nbr_edge_x[{h}]')
+        assert n == 14
+        assert dense._compiled[1].n_lowered == 4 and by_id._compiled[1].n_lowered == 3
+
+
 # ---- the loader's DEFAULT: lowered chain, fresh-tensor semantics from liveness-checked output sets (round 3) --------------------
 def _default_loader(st, bs, k, mode='ring', validate='sync', D=None, num_nodes=None):
     from tgm_amd import DGData, DGDataLoader, DGraph

@@ -312,11 +312,23 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
             # comment-shaped stream): a node's window then gathers consecutive rows instead of rows scattered by edge id
             self._csr_adj_x = None
             st.csr_x_by_pos = 0
-            if arr.edge_x is not None and self._adj_features and self._csr.adj.shape[0] * arr.edge_x.shape[1] * 4 <= self._adj_features_max_bytes:
-                eid = self._csr.records()[1].to(torch.int64)
-                self._csr_adj_x = arr.edge_x.index_select(0, eid)
-                del eid
-                st.ring_x, st.csr_x_by_pos = self._csr_adj_x.data_ptr(), 1
+            # Not with edge_features='by_id' (the lookups copy no feature row, so the second copy would never be read), not above the
+            # explicit cap, and not when it would take more than half of what the device has free right now (the copy itself + the
+            # int64 index of the gather); if the allocation fails anyway, the lookups gather by edge id (csr_x_by_pos = 0).
+            want = arr.edge_x is not None and self._adj_features and not self._by_id
+            if want:
+                nbytes = self._csr.adj.shape[0] * (arr.edge_x.shape[1] * 4 + 8)
+                free = torch.cuda.mem_get_info(self._device)[0]
+                want = nbytes <= self._adj_features_max_bytes and nbytes <= free // 2
+            if want:
+                try:
+                    eid = self._csr.records()[1].to(torch.int64)
+                    self._csr_adj_x = arr.edge_x.index_select(0, eid)
+                    del eid
+                    st.ring_x, st.csr_x_by_pos = self._csr_adj_x.data_ptr(), 1
+                except torch.OutOfMemoryError:
+                    self._csr_adj_x = None
+                    st.ring_x, st.csr_x_by_pos = _native.ptr(arr.edge_x), 0
             # per node: where its visible prefix ended at its last lookup -- a search hint the kernels keep (tgmx_recency_step_t.csr_cursor)
             self._csr_cursor = torch.zeros(self._num_nodes, dtype=torch.int64, device=self._device)
             st.csr_cursor = self._csr_cursor.data_ptr()

@@ -11,7 +11,7 @@ does that calls :func:`invalidate_parameter_caches`.
 from typing import Iterable, Tuple, Union
 
 import torch
-from torch.nn.modules.module import register_module_parameter_registration_hook
+from torch.nn.modules.module import register_module_module_registration_hook, register_module_parameter_registration_hook
 from torch.optim.optimizer import register_optimizer_step_post_hook
 
 _epoch = 0
@@ -32,6 +32,8 @@ def _on_registration(module, name, param) -> None:
 
 
 register_module_parameter_registration_hook(_on_registration)
+# replacing a submodule (``model.attn[0] = other``) changes the parameter set without registering a parameter
+register_module_module_registration_hook(_on_registration)
 
 
 def param_list(module: torch.nn.Module) -> Tuple[torch.Tensor, ...]:
@@ -41,6 +43,14 @@ def param_list(module: torch.nn.Module) -> Tuple[torch.Tensor, ...]:
     if cached is None or cached[0] != _registrations:
         cached = module.__dict__['_tgmx_plist'] = (_registrations, tuple(module.parameters()))
     return cached[1]
+
+
+def refresh_param_list(module: torch.nn.Module) -> Tuple[torch.Tensor, ...]:
+    """Re-walk the module tree now.  For the paths that assign ``module._parameters[key]`` directly and therefore run no registration
+    hook (``Module._apply`` under ``torch.__future__.set_overwrite_module_params_on_conversion(True)`` / ``set_swap_module_params_on_conversion``):
+    ``TransientCaches._apply`` calls this after every ``.to()`` / ``.float()`` / ``.cuda()``."""
+    module.__dict__.pop('_tgmx_plist', None)
+    return param_list(module)
 
 
 def invalidate_parameter_caches() -> None:
@@ -62,6 +72,12 @@ class TransientCaches:
     pointers cannot be pickled at all, and a copy must not share the original's buffers.  The copy rebuilds them on its first call."""
 
     _TRANSIENT: Tuple[str, ...] = ()
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)  # may REPLACE Parameter objects without any registration hook running
+        global _registrations
+        _registrations += 1
+        return out
 
     def __getstate__(self):
         state = self.__dict__.copy()

@@ -28,7 +28,14 @@ beyond that a batch gets a set nobody keeps: plain fresh tensors).  A loop that
 drops a batch before asking for the next one runs on one set, ``for batch in
 loader`` alternates between two.  In-place modification through torch ops is
 seen in the buffer's version counter and the set is re-initialised before its
-next use, so the delta feature writes (below) stay exact.
+next use, so the delta feature writes (below) stay exact.  THE STREAM CONTRACT of this
+mode: "no references left" proves that no host code can reach the tensors, not that
+device work reading them has finished -- that is guaranteed only for work enqueued on
+the stream the loader runs on (the next batch is produced behind it, in stream order).
+A consumer that reads a batch on a SIDE stream (or hands it to a collective that relies
+on ``record_stream``) must keep a reference to the batch until that work has been
+ordered before the loader's stream (``loader_stream.wait_stream(side)``), or ask for
+``output_pool=0``.  A set filled on one stream is never recycled from another one.
 
 ``output_pool=R`` (explicit): a ring of ``R`` sets recycled unconditionally --
 the tensors stay valid until ``R`` more batches have been produced on the same
@@ -58,6 +65,7 @@ _ROLE_KEYS = {
 }
 
 
+_STATUS_READ_EVERY = 512  # batches between reads of the device status word when the store vouches for the seeds (validate='sync')
 _MAX_AUTO_SETS = 4  # output sets kept by the liveness-checked pool (output_pool=None); a batch beyond that gets an unpooled set
 _storage_uses = torch._C._storage_Use_Count
 
@@ -77,7 +85,7 @@ class _Slot:
 class _OutputSet:
     """One persistent output set: a single byte buffer (one storage) that every tensor of a batch is a view of."""
 
-    __slots__ = ('buf', 'cap', 'off', 'views', 'storage', 'uses', 'version', 'pin', 'event', 'arange_n', 'lib')
+    __slots__ = ('buf', 'cap', 'off', 'views', 'storage', 'uses', 'version', 'pin', 'event', 'arange_n', 'lib', 'stream')
 
     def __del__(self) -> None:
         ev, lib = getattr(self, 'event', None), getattr(self, 'lib', None)
@@ -112,6 +120,7 @@ class CompiledPipeline:
         self._device = self._arr.src.device  # with its index ('cuda' -> 'cuda:0'): what the hooks see on batch tensors
         self._roles = [_ROLE_KEYS[shard is not None][k][0] for k in nbr._seed_nodes_keys]
         self._static_ok: Optional[tuple] = None  # host-side seed validation of the resident store (validate='sync')
+        self._since_check = 0
 
     # -- lowering ---------------------------------------------------------------
     @staticmethod
@@ -153,7 +162,11 @@ class CompiledPipeline:
             if extra <= {'neg', 'nbr_nids'} and ('neg' not in extra or neg is not None) and len(nbr._num_nbrs) + 3 <= 16:
                 dedup = hooks[i]
                 i += 1
-                if i < len(hooks) and type(hooks[i]) is SampledEdgeListHook and hooks[i]._id is None and hooks[i].hop < len(nbr._num_nbrs):
+                # (edge features by id: the lowered post block reads the dense [S, k, D] copies, which that mode does not make --
+                # the edge-list hook then runs behind the lowered prefix, where indexing EdgeFeaturesById gathers the rows)
+                by_id_rows = nbr._by_id and (dg.edge_x_dim or 0) > 0
+                if (i < len(hooks) and type(hooks[i]) is SampledEdgeListHook and hooks[i]._id is None and hooks[i].hop < len(nbr._num_nbrs)
+                        and not by_id_rows):  # fmt: skip
                     edges = hooks[i]
                     i += 1
         return CompiledPipeline(dg, shard, neg, nbr, i, pool, dedup, edges)
@@ -162,6 +175,8 @@ class CompiledPipeline:
         """(Re)build the native argument block from the hooks' current state."""
         nbr, arr = self._nbr, self._arr
         nbr._ensure_state(self._dg, self._device)
+        if getattr(nbr, '_bound_store', None) is not getattr(self._dg, '_storage', None):
+            nbr._refresh_ts_bound(self._dg)  # a hook shared with a loader over another store: the promise below must be THIS store's
         p = _native.Pipeline()
         p.src, p.dst, p.ts, p.edge_x = arr.src.data_ptr(), arr.dst.data_ptr(), arr.ts.data_ptr(), _native.ptr(arr.edge_x)
         p.num_edges = arr.src.shape[0]
@@ -246,7 +261,7 @@ class CompiledPipeline:
         # zeros: the feature rows start as all-pad rows with span 0 (delta writes), dev_sizes as "no error"
         os_.buf = torch.zeros(max(total, 256), dtype=torch.uint8, device=self._device)
         os_.views = {}
-        os_.pin, os_.event = None, None
+        os_.pin, os_.event, os_.stream = None, None, None
         if self._dedup is not None:
             os_.pin = torch.zeros(3, dtype=torch.int64).pin_memory()
             ev = ctypes.c_void_p()
@@ -379,8 +394,10 @@ class CompiledPipeline:
         post.dev_sizes, post.host_sizes, post.sizes_ready = dev_sizes.data_ptr(), os_.pin.data_ptr(), os_.event
         return post, (uniq, dev_sizes, os_.pin, os_.event, ei, et, ex, ro, N)
 
-    def _is_free(self, os_: _OutputSet) -> bool:
+    def _is_free(self, os_: _OutputSet, any_stream: bool = False) -> bool:
         """Can nothing outside the pipeline reach a tensor of this set any more?"""
+        if not any_stream and getattr(os_, 'stream', None) not in (None, _native.stream_ptr(self._device.index)):
+            return False  # filled on another stream: "no references left" says nothing about the order of the two streams' work
         if _storage_uses(os_.storage._cdata) != os_.uses:
             return False  # a view, a detach() or any other alias of the buffer is alive
         for sl in os_.views.values():
@@ -403,6 +420,11 @@ class CompiledPipeline:
             os_ = sets[turn % self._R]
         else:
             os_ = None
+            cur = _native.stream_ptr(self._device.index)
+            if any(c.stream not in (None, cur) for c in sets):
+                # sets filled on another stream are not recycled here (see _is_free); the dead ones leave the pool so that it can refill
+                sets[:] = [c for c in sets if c.stream in (None, cur) or not self._is_free(c, any_stream=True)]
+                self._last = 0
             # the set used last comes first: a consumer that drops batch i before asking for batch i + 1 stays on ONE set, whose
             # bytes are then still in the Infinity Cache
             for i in range(len(sets)):
@@ -456,6 +478,7 @@ class CompiledPipeline:
         if nbr._validate == 'sync':
             self._validate_static(lo, n, (lo + s_lo, lo + s_hi) if shard is not None else (lo, lo + n))
         os_ = self._acquire(n)
+        os_.stream = _native.stream_ptr(self._device.index)
         slot = self._views(os_, n)
         if slot.base is None:
             self._baseline(os_, slot)
@@ -491,8 +514,13 @@ class CompiledPipeline:
         if timer is not None:
             out.timed_hop = -1
             self._log_timed(timer, slot)
-        if nbr._validate == 'sync' and not self._static_ok[0]:
-            nbr.check()  # seeds that the store does not vouch for: one device -> host read per batch
+        if nbr._validate == 'sync':
+            self._since_check += 1
+            if not self._static_ok[0] or self._since_check >= _STATUS_READ_EVERY:
+                # seeds that the store does not vouch for: one device -> host read per batch.  Seeds it does vouch for: the status word
+                # still carries the non-seed bits (TGMX_ST_TS_BOUND, TGMX_ST_SCRATCH) -- read it once in a while so that they surface
+                self._since_check = 0
+                nbr.check()
         d = batch.__dict__
         if shard is not None:
             arr = self._arr
