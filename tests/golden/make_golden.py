@@ -21,6 +21,7 @@ Fixture families:
   g10_*  TGCN cell (gate wiring; GCNConv = placeholder restatement, third-party)
   g8_*   TGNMemory (in-tree arithmetic: messages, Last/Mean aggregation, GRU, store semantics)
   g11_*  NeighborSamplerHook (uniform sampling; Python's `random` seeded so the sampled rows are reproducible)
+  g12_*  time-unit iteration: slice_time windows, DGDataLoader(batch_unit, drop_last, on_empty) incl. empty windows
 """
 from __future__ import annotations
 
@@ -485,11 +486,82 @@ def g11_cases():
         print(f'g11_uniform_{tag}: {nb} batches')
 
 
+def g12_case():
+    """Time-unit iteration (tgm/data/loader.py:101-170, tgm/core/graph.py:130-152, array_backend.py:301-321): ``slice_time`` windows and
+    ``DGDataLoader(batch_unit=..., batch_size=..., drop_last=..., on_empty=...)`` over a seconds-granularity stream with long silent
+    gaps (empty windows).  Per loader configuration: the number of batches, every batch's edges, or the exception the iteration ends in."""
+    from tgm.exceptions import EmptyBatchError
+
+    rng = np.random.default_rng(1212)
+    N, D = 40, 3
+    # three bursts of activity with silent gaps between them (so minute / hour windows come up empty), ties inside the bursts
+    parts = [np.sort(rng.integers(lo, hi, n)) for lo, hi, n in ((5, 400, 90), (2_000, 2_300, 60), (9_000, 12_700, 150))]
+    ts = np.concatenate(parts).astype(np.int64)
+    E = len(ts)
+    ei = rng.integers(0, N, (E, 2)).astype(np.int32)
+    ex = rng.random((E, D), dtype=np.float32)
+    arrays = dict(ts=ts, ei=ei, ex=ex)
+    T_ = torch.from_numpy
+    dg = DGraph(DGData.from_raw(T_(ts), T_(ei), T_(ex), time_delta='s'))
+    meta = dict(N=N, start_time=int(dg.start_time), end_time=int(dg.end_time), slices=[], loaders=[], x_none=[])
+
+    def put(tag, b):
+        arrays[f'{tag}_src'] = b.edge_src.numpy().copy()
+        arrays[f'{tag}_dst'] = b.edge_dst.numpy().copy()
+        arrays[f'{tag}_time'] = b.edge_time.numpy().copy()
+        if b.edge_x is None:  # (the reference materializes no feature tensor for some empty slices: recorded, compared as such)
+            meta['x_none'].append(tag)
+        else:
+            arrays[f'{tag}_x'] = b.edge_x.numpy().copy()
+
+    # slice_time: half-open [start, end) in the graph's unit, None = open, nested slices intersect
+    windows = [(None, None), (0, 5), (5, 6), (0, 401), (400, 2_000), (2_000, None), (None, 9_000), (12_699, 12_700), (12_700, 20_000), (100, 100)]
+    for i, (a, b) in enumerate(windows):
+        put(f'sl{i}', dg.slice_time(a, b).materialize())
+        meta['slices'].append([a, b])
+    nested = dg.slice_time(50, 11_000).slice_time(None, 2_100).slice_events(3, None)
+    put('nested', nested.materialize())
+    meta['nested'] = dict(num_events=int(nested.num_events), start_time=int(nested.start_time), end_time=int(nested.end_time))
+
+    configs = []
+    for unit, size in (('s', 250), ('s', 3_600), ('m', 1), ('m', 7), ('h', 1), ('h', 2)):
+        for drop_last in (False, True):
+            for on_empty in ('skip', 'raise', None):
+                configs.append((unit, size, drop_last, on_empty))
+    for ci, (unit, size, drop_last, on_empty) in enumerate(configs):
+        rec = dict(unit=unit, size=size, drop_last=drop_last, on_empty=on_empty, error=None)
+        loader = DGDataLoader(dg, batch_size=size, batch_unit=unit, on_empty=on_empty, drop_last=drop_last)
+        rec['len'] = len(loader)
+        n = 0
+        got = dict(sizes=[], src=[], dst=[], time=[], x=[])
+        try:
+            for b in loader:
+                got['sizes'].append(b.edge_src.numel())
+                got['src'].append(b.edge_src.numpy().copy()); got['dst'].append(b.edge_dst.numpy().copy()); got['time'].append(b.edge_time.numpy().copy())
+                got['x'].append(np.zeros((0, D), np.float32) if b.edge_x is None else b.edge_x.numpy().copy())
+                if b.edge_x is None:
+                    meta['x_none'].append(f'c{ci}_b{n}')
+                n += 1
+        except EmptyBatchError:
+            rec['error'] = 'EmptyBatchError'
+        # one record per configuration: the batch sizes + the batches' edges concatenated in iteration order
+        arrays[f'c{ci}_sizes'] = np.asarray(got['sizes'], np.int64)
+        for f, dt in (('src', np.int32), ('dst', np.int32), ('time', np.int64)):
+            arrays[f'c{ci}_{f}'] = np.concatenate(got[f]).astype(dt) if got[f] else np.zeros(0, dt)
+        if on_empty == 'skip':  # (the feature rows once per (unit, size, drop_last): the other on_empty modes iterate the same slices)
+            arrays[f'c{ci}_x'] = np.concatenate(got['x']) if got['x'] else np.zeros((0, D), np.float32)
+        rec['batches'] = n
+        meta['loaders'].append(rec)
+    arrays['meta'] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, 'g12_time_batches.npz'), **arrays)
+    print(f'g12_time_batches: {len(windows)} slices, {len(configs)} loader configurations, E={E}')
+
+
 if __name__ == '__main__':
     import warnings
 
     warnings.filterwarnings('ignore')
     only = sys.argv[1:]
-    for fam, fn in [('g1', g1_cases), ('g2', g2_cases), ('g3', g3_case), ('g4', g4_case), ('g5', g5_cases), ('g6', g6_case), ('g7', g7_case), ('g8', g8_cases), ('g9', g9_case), ('g10', g10_case), ('g11', g11_cases)]:
+    for fam, fn in [('g1', g1_cases), ('g2', g2_cases), ('g3', g3_case), ('g4', g4_case), ('g5', g5_cases), ('g6', g6_case), ('g7', g7_case), ('g8', g8_cases), ('g9', g9_case), ('g10', g10_case), ('g11', g11_cases), ('g12', g12_case)]:
         if not only or fam in only:
             fn()
