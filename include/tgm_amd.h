@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TGMX_ABI_VERSION 4
+#define TGMX_ABI_VERSION 5
 
 #define TGMX_OK 0
 #define TGMX_E_INVALID (-1)  /* bad argument (null pointer, size, alignment) */
@@ -463,6 +463,14 @@ typedef struct tgmx_tgat_hop {
   const int64_t* nbr_t;  /* [rows_i, k]     nbr_edge_time[i] */
   const float* edge_x;   /* [rows_i, k, D]  nbr_edge_x[i]; NULL with nbr_eid set */
   int32_t k;
+  /* ABI v5 (the 4 bytes of padding behind k in v4).  != 0 on hop i >= 1: a PROMISE that row r of this hop is a function of its seed
+   * (hops[i-1].nbr_id[r], hops[i-1].nbr_t[r]) alone -- true when all hops come from one sampler call (hop i is seeded with hop i-1's
+   * flattened outputs and no lookup of a call changes the sampler's state: tgm/hooks/neighbors/recency.py:141-143, 161-163).  Slots
+   * with equal (id, time) are then the same row of every deeper level, and inference (save == 0) with every hop >= 1 so marked
+   * computes each distinct row ONCE (tgmx_pair_dedup) and lets the level above read it by index -- the embeddings are the ones the
+   * row-per-slot computation gives, bit for bit (a row's arithmetic does not depend on where it sits).  Pads alone -- one pair, (-1, 0)
+   * -- are 35-60 % of a level at the headline shape.  0: nothing is assumed (hand-made inputs, the reference's unit tests). */
+  int32_t seed_keyed;
   /* ABI v4: edge features by id.  With edge_x == NULL and nbr_eid / edge_table set, slot (r, s) reads edge_table[nbr_eid[r, s]]
    * ([E, D] rows of the resident store; -1: a pad slot, zeros) where the attention consumes it -- the sampler then never writes
    * the dense [rows, k, D] copy (tgmx_recency_step_t.out_eid) and the attention never re-reads it.  Needs the register-resident
@@ -482,6 +490,10 @@ typedef struct tgmx_tgat_layout {
   int64_t total_bytes, z0;
   int64_t level_rows[TGMX_TGAT_MAX_LAYERS + 1], level_off[TGMX_TGAT_MAX_LAYERS + 2];
   tgmx_tgat_layer_layout_t layers[TGMX_TGAT_MAX_LAYERS];
+  /* ABI v5, compact rows (tgmx_tgat_hop_t.seed_keyed; -1 = level not deduplicated).  Level i's block, n = level_rows[i] int32 each:
+   * [count + 15 pad | uniq n | owner n | cidx n | rep n | tgmx_pair_dedup workspace]: rep[r] = the compact row of original row r,
+   * uniq[c] = the original row compact row c stands for, count = the number of compact rows (all three device-side). */
+  int64_t compact[TGMX_TGAT_MAX_LAYERS + 1];
 } tgmx_tgat_layout_t;
 /* Weight [N, K] (row stride ldw floats) -> out[tgmx_tgat_tile16_floats(N, K)]: block (nb, kb) of 16 x 16 is 256 consecutive
  * floats, element 4 * lane + j = W[16 nb + (lane & 15)][16 kb + 4 (lane >> 4) + j], zero outside the matrix -- the order the
@@ -501,6 +513,13 @@ typedef struct tgmx_pack_job {
 int tgmx_pack2d(const tgmx_pack_job_t* jobs, int32_t n_jobs, tgmx_stream_t stream);
 size_t tgmx_tgat_tile16_floats(int32_t N, int32_t K);
 int tgmx_tgat_tile16(const float* W, int64_t ldw, int32_t N, int32_t K, float* out, tgmx_stream_t stream);
+/* ABI v5.  The distinct (id, time) pairs among n of them (one level of the hop tree; see tgmx_tgat_hop_t.seed_keyed): owner[r] = the
+ * smallest index carrying r's pair, *count = number of distinct pairs, numbered densely: cidx[owner] = the pair's number (written for
+ * owners only), uniq[number] = owner.  The numbering order is unspecified.  An open-addressing table in `workspace` (4-byte aligned,
+ * tgmx_pair_dedup_workspace_bytes(n), contents irrelevant on entry); a memset and two launches.  n <= 2^28. */
+size_t tgmx_pair_dedup_workspace_bytes(int64_t n);
+int tgmx_pair_dedup(const int32_t* ids, const int64_t* times, int64_t n, int32_t* uniq, int32_t* owner, int32_t* cidx,
+                    int32_t* count, void* workspace, size_t workspace_bytes, tgmx_stream_t stream);
 int tgmx_tgat_layout(const tgmx_tgat_model_t* model, int64_t S0, const tgmx_tgat_hop_t* hops,
                      int32_t save, tgmx_tgat_layout_t* out);
 size_t tgmx_tgat_workspace_bytes(const tgmx_tgat_model_t* model, int64_t S0, const tgmx_tgat_hop_t* hops);

@@ -92,3 +92,63 @@ def test_two_rank_strong_scaling_concat_equals_single_rank(tmp_path, mode, pool)
             n_valid += int((ref['nbr_nids'][h] >= 0).sum())
             k_prod *= KS[h]
     assert n_valid > 1000
+
+
+# ---- batch-level sharding (round 4): rank r takes batches r, r + world, ... of the SAME schedule -------------------------------------
+def _run_batches(rank, world, port, out, pool, epochs):
+    import torch.distributed as dist
+
+    from tgm_amd import DGData, DGDataLoader, DGraph
+    from tgm_amd.hooks import HookManager, RandomNegativeEdgeSamplerHook, RecencyNeighborHook
+    from tgm_amd.synth import make_stream
+
+    if world > 1:
+        os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    st = make_stream('comment', seed=9, num_edges=E, edge_dim=D, n_src=300)
+    dg = DGraph(DGData.from_raw(st.ts, torch.stack([st.src, st.dst], 1), st.edge_x), device='cuda')
+    hm = HookManager(keys=['k'])
+    hm.register('k', RandomNegativeEdgeSamplerHook(0, st.num_nodes, seed=17))
+    hm.register('k', RecencyNeighborHook(st.num_nodes, KS, ['edge_src', 'edge_dst', 'neg'], ['edge_time', 'edge_time', 'neg_time'], mode='csr',
+                                         batch_size=BS))  # fmt: skip
+    loader = DGDataLoader(dg, batch_size=BS, hook_manager=hm, output_pool=pool, batch_shard=(rank, world) if world > 1 else None)
+    got = []
+    with hm.activate('k'):
+        for ep in range(epochs):
+            hm.reset_state()
+            for b in loader:
+                got.append({'lo': int(b._edge_lo), 'neg': b.neg.cpu(), 'seed_nids': [t.cpu() for t in b.seed_nids], 'nbr_nids': [t.cpu() for t in b.nbr_nids],
+                            'nbr_edge_time': [t.cpu() for t in b.nbr_edge_time], 'nbr_edge_x': [t.cpu() for t in b.nbr_edge_x]})
+    torch.save(got, f'{out}.b.{pool}.{world}.{rank}')
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize('pool', [None, 0])
+def test_two_rank_batch_sharding_interleaves_to_the_single_rank_sequence(tmp_path, pool):
+    """DGDataLoader(batch_shard=(rank, 2)) over the static index: every batch a rank produces IS the batch the single-rank loader
+    produces at that position of the bs = 200 schedule -- same edges, same generated negatives, same sampled neighbors, bit for
+    bit, over two epochs (the epoch anchor and the negative sampler's call counter carry over) -- so the cfg-4 workload at its OWN
+    batch size spreads over G ranks with no exchange at all."""
+    out = str(tmp_path / 'o')
+    _run_batches(0, 1, 0, out, pool, 2)
+    mp.spawn(_run_batches, args=(2, _free_port(), out, pool, 2), nprocs=2, join=True)
+    one = torch.load(f'{out}.b.{pool}.1.0')
+    two = [torch.load(f'{out}.b.{pool}.2.{r}') for r in (0, 1)]
+    nb = -(-E // BS)
+    assert len(one) == 2 * nb and len(two[0]) + len(two[1]) == 2 * nb
+    n_valid = 0
+    for ep in range(2):
+        for j in range(nb):
+            ref = one[ep * nb + j]
+            per_rank = [len(range(r, nb, 2)) for r in (0, 1)]
+            got = two[j % 2][ep * per_rank[j % 2] + j // 2]
+            assert got['lo'] == ref['lo'] == j * BS
+            assert torch.equal(got['neg'], ref['neg']), f'epoch {ep} batch {j}: negatives'
+            for h in range(len(KS)):
+                for name in ('seed_nids', 'nbr_nids', 'nbr_edge_time', 'nbr_edge_x'):
+                    assert torch.equal(got[name][h], ref[name][h]), f'epoch {ep} batch {j} hop {h} {name}'
+                n_valid += int((ref['nbr_nids'][h] >= 0).sum())
+    assert n_valid > 2000

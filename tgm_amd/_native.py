@@ -114,7 +114,8 @@ class TgatModel(ctypes.Structure):
 
 
 class TgatHop(ctypes.Structure):
-    _fields_ = [('seed_t', c_void_p), ('nbr_id', c_void_p), ('nbr_t', c_void_p), ('edge_x', c_void_p), ('k', c_int32), ('nbr_eid', c_void_p), ('edge_table', c_void_p)]
+    _fields_ = [('seed_t', c_void_p), ('nbr_id', c_void_p), ('nbr_t', c_void_p), ('edge_x', c_void_p), ('k', c_int32), ('seed_keyed', c_int32),
+                ('nbr_eid', c_void_p), ('edge_table', c_void_p)]  # fmt: skip
 
 
 class TgatLayerGrads(ctypes.Structure):
@@ -142,7 +143,8 @@ class TgatLayerLayout(ctypes.Structure):
 
 class TgatLayout(ctypes.Structure):
     _fields_ = [('total_bytes', c_int64), ('z0', c_int64), ('level_rows', c_int64 * (TGAT_MAX_LAYERS + 1)),
-                ('level_off', c_int64 * (TGAT_MAX_LAYERS + 2)), ('layers', TgatLayerLayout * TGAT_MAX_LAYERS)]  # fmt: skip
+                ('level_off', c_int64 * (TGAT_MAX_LAYERS + 2)), ('layers', TgatLayerLayout * TGAT_MAX_LAYERS),
+                ('compact', c_int64 * (TGAT_MAX_LAYERS + 1))]  # fmt: skip
 
 
 MAX_SEED_GROUPS = 8
@@ -268,6 +270,8 @@ SIGNATURES['tgmx_tgat_tile16_floats'] = (c_size_t, [c_int32, c_int32])
 SIGNATURES['tgmx_tgat_tile16'] = (c_int32, [_P, c_int64, c_int32, c_int32, _P, _P])
 SIGNATURES['tgmx_pack2d'] = (c_int32, [ctypes.POINTER(PackJob), c_int32, _P])
 
+SIGNATURES['tgmx_pair_dedup_workspace_bytes'] = (c_size_t, [c_int64])
+SIGNATURES['tgmx_pair_dedup'] = (c_int32, [_P, _P, c_int64, _P, _P, _P, _P, _P, c_size_t, _P])
 SIGNATURES['tgmx_tgat_layout'] = (c_int32, [ctypes.POINTER(TgatModel), c_int64, ctypes.POINTER(TgatHop), c_int32, ctypes.POINTER(TgatLayout)])
 SIGNATURES['tgmx_tgat_workspace_bytes'] = (c_size_t, [ctypes.POINTER(TgatModel), c_int64, ctypes.POINTER(TgatHop)])
 SIGNATURES['tgmx_tgat_backward_workspace_bytes'] = (c_size_t, [ctypes.POINTER(TgatModel), ctypes.POINTER(TgatLayout), ctypes.POINTER(TgatHop)])

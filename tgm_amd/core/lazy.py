@@ -15,12 +15,48 @@ import torch
 from torch import Tensor
 
 
+class SamplerCallTag:
+    """Identity of ONE sampler call, shared by the per-hop lists it published (``SampledHops``, ``EdgeFeaturesById``).
+
+    ``tgm_amd.nn.TGAT`` uses it to recognise inputs whose deeper hops were sampled FOR the shallower hops' outputs by one call --
+    then slots with the same (neighbor id, time) are the same row of every deeper level and inference computes each distinct row
+    once (``tgmx_tgat_hop_t.seed_keyed``).  The stamp records every output tensor's (address, version, rows): a list whose items
+    were replaced, or a tensor modified in place through torch, no longer matches and gets the row-per-slot computation."""
+
+    __slots__ = ('stamp',)
+
+    def __init__(self, nbr_nids: List[Tensor], nbr_edge_time: List[Tensor]) -> None:
+        self.stamp = self._of(nbr_nids, nbr_edge_time)
+
+    @staticmethod
+    def _of(nbr_nids, nbr_edge_time) -> tuple:
+        return tuple((t.data_ptr(), t._version, t.shape[0]) for t in (*nbr_nids, *nbr_edge_time))
+
+    def matches(self, nbr_nids, nbr_edge_time) -> bool:
+        try:
+            return self._of(nbr_nids, nbr_edge_time) == self.stamp
+        except (AttributeError, IndexError, TypeError):
+            return False
+
+
+class SampledHops(list):
+    """A per-hop list (``seed_times``, ``nbr_nids``, ``nbr_edge_time``) as one sampler call published it: a plain ``list`` + the call's tag."""
+
+    def __init__(self, items=(), tag: Optional[SamplerCallTag] = None) -> None:
+        super().__init__(items)
+        self.tag = tag
+
+    def copy(self) -> 'SampledHops':
+        return SampledHops(self, self.tag)
+
+
 class EdgeFeaturesById(list):
     """``len(num hops)`` list of ``[S_h, k_h, D]`` tensors, backed by ``eids[h]`` (int32, -1 = pad) and ``table`` ([E, D])."""
 
-    def __init__(self, eids: List[Tensor], table: Tensor) -> None:
+    def __init__(self, eids: List[Tensor], table: Tensor, tag: Optional[SamplerCallTag] = None) -> None:
         super().__init__([None] * len(eids))
         self.eids, self.table = list(eids), table
+        self.tag = tag
 
     def _dense(self, h: int) -> Tensor:
         got: Optional[Tensor] = super().__getitem__(h)

@@ -203,6 +203,55 @@ __global__ __launch_bounds__(256) void gather_leaves_kernel(const LeafGatherArgs
   }
 }
 
+// Compact rows: behind tgmx_pair_dedup of every level >= 1.  Part A, one item per ORIGINAL row of a deduplicated level: rep[r] =
+// cidx[owner[r]], the compact row that stands for it (what the level above indexes its neighbor features with).  Part B, one item
+// per compact row and column: the leaf features z0[level i][c] = node_x[id of the row compact row c stands for] (pad id -1 reads the
+// LAST row, tgat.py:128-130); level 0 is not deduplicated.  Items past a level's device-side count do nothing.
+struct CompactGatherArgs {
+  int levels;                                         // levels 0 .. levels - 1 are row batches (the deepest level is read by node id)
+  long long rows[TGMX_TGAT_MAX_LAYERS + 1];           // original rows per level
+  long long off[TGMX_TGAT_MAX_LAYERS + 1];            // first row of the level in z0
+  const int32_t* ids[TGMX_TGAT_MAX_LAYERS + 1];       // level 0: the seeds; level i: hop i-1's neighbor ids
+  const int32_t* uniq[TGMX_TGAT_MAX_LAYERS + 1];
+  const int32_t* owner[TGMX_TGAT_MAX_LAYERS + 1];
+  const int32_t* cidx[TGMX_TGAT_MAX_LAYERS + 1];
+  int32_t* rep[TGMX_TGAT_MAX_LAYERS + 1];
+  const int32_t* count[TGMX_TGAT_MAX_LAYERS + 1];
+  const float* table;
+  float* out;
+  long long num_nodes, itemsA, itemsB;
+  int dim;
+};
+__global__ __launch_bounds__(256) void gather_compact_kernel(const CompactGatherArgs g) {
+  const long long step = (long long)gridDim.x * blockDim.x;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < g.itemsA + g.itemsB; e += step) {
+    if (e < g.itemsA) {
+      long long r = e;
+      int lv = 1;
+#pragma unroll
+      for (int l = 1; l < TGMX_TGAT_MAX_LAYERS; ++l)
+        if (l < g.levels - 1 && r >= g.rows[lv] && lv == l) { r -= g.rows[lv]; lv = l + 1; }
+      g.rep[lv][r] = g.cidx[lv][g.owner[lv][r]];
+    } else {
+      const long long f = e - g.itemsA;
+      long long i = f / g.dim;
+      const int c = (int)(f - i * g.dim);
+      int lv = 0;
+#pragma unroll
+      for (int l = 0; l < TGMX_TGAT_MAX_LAYERS; ++l)
+        if (l < g.levels - 1 && i >= g.rows[lv] && lv == l) { i -= g.rows[lv]; lv = l + 1; }
+      long long orig = i;
+      if (lv > 0) {
+        if (i >= (long long)*g.count[lv]) continue;
+        orig = g.uniq[lv][i];
+      }
+      long long node = g.ids[lv][orig];
+      if (node < 0) node += g.num_nodes;
+      g.out[(g.off[lv] + i) * g.dim + c] = g.table[node * g.dim + c];
+    }
+  }
+}
+
 // Rres[r] = [x[r, :d] | 0 (pad) | cos(tb)]  -- the residual == query input (attention.py:93-95);
 // Time2Vec of the zero vector is cos(fma(0, w, b)) = cos(b).
 __global__ __launch_bounds__(256) void tgat_rres_kernel(const float* __restrict__ x, long long ldx, int d,
@@ -308,7 +357,31 @@ __global__ __launch_bounds__(256) void ln_residual_concat_kernel(const float* __
 // straight from global memory; the weights (B, K-contiguous rows) are read from L2 in the MFMA register layout;
 // the 4 waves split the 32-column blocks of N.
 // ---------------------------------------------------------------------------
+// Which rows of a launch are LIVE.  Compact rows (tgmx_tgat_hop_t.seed_keyed): every level of the hop tree keeps its slice
+// [begin[i], begin[i + 1]) of a layer's row space, but only the first *live[i] rows of a deduplicated level exist -- a device-side
+// count, so launches are sized for the worst case and the workgroups / waves past the count leave at once.  n == 0: all rows live.
+struct RowSegs {
+  int n;
+  long long begin[TGMX_TGAT_MAX_LAYERS + 1];
+  const int32_t* live[TGMX_TGAT_MAX_LAYERS];
+};
+// any live row in [r0, r1)?  (workgroup- / wave-uniform arguments: scalar code)
+__device__ __forceinline__ bool rows_live(const RowSegs& s, long long r0, long long r1) {
+  if (s.n == 0) return true;
+  bool any = false;
+#pragma unroll
+  for (int i = 0; i < TGMX_TGAT_MAX_LAYERS; ++i) {
+    if (i < s.n) {
+      const long long lo = r0 > s.begin[i] ? r0 : s.begin[i];
+      const long long hi = r1 < s.begin[i + 1] ? r1 : s.begin[i + 1];
+      if (lo < hi && (!s.live[i] || lo - s.begin[i] < (long long)*s.live[i])) any = true;
+    }
+  }
+  return any;
+}
+
 struct ChainArgs {
+  RowSegs segs;
   const float* zbar;  // [R, H, Cp]
   const float* x;     // [R, >= d] layer input rows (the residual's feature part)
   const float* tb;    // [T] Time2Vec bias: the residual's time part is cos(tb) (attention.py:93-95)
@@ -455,6 +528,7 @@ __global__ __launch_bounds__(kChainThreads) void tgat_post_chain_kernel(const Ch
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long long m0 = (long long)blockIdx.x * 32;
   const int rows = (g.R - m0) < 32 ? (int)(g.R - m0) : 32;
+  if (!rows_live(g.segs, m0, m0 + rows)) return;  // compact rows: nothing of this tile exists
   for (int t = tid; t < g.T; t += kChainThreads) ct[t] = cos_t2v(g.tb[t]);
   for (int c = tid; c < O; c += kChainThreads) {
     lg[c] = g.ln_g[c];
@@ -785,6 +859,7 @@ __global__ __launch_bounds__(kC64Threads) void tgat_chain64_kernel(const ChainAr
   const long long w0 = (long long)blockIdx.x * 64;  // first row of the workgroup
   const long long m0 = w0 + tile * 16;              // first row of this wave's tile
   const int wrows = (g.R - w0) < 64 ? (int)(g.R - w0) : 64;
+  if (!rows_live(g.segs, w0, w0 + wrows)) return;  // compact rows: nothing of this workgroup's 64 rows exists
   const int rows = g.R - m0 < 0 ? 0 : (g.R - m0 < 16 ? (int)(g.R - m0) : 16);  // 0: the wave only helps with the copies
   float* slab = slabs + tile * 16 * LD;
   const int HB = (dh + 15) / 16, KBc = (g.C + 15) / 16;
@@ -1012,12 +1087,27 @@ struct AttnArgs {
   const int64_t* seg_seed_t[TGMX_TGAT_MAX_LAYERS];
   const int64_t* seg_nbr_t[TGMX_TGAT_MAX_LAYERS];
   const int32_t* seg_nbr_id[TGMX_TGAT_MAX_LAYERS];
+  // Compact rows (register kernel only; all NULL otherwise).  Row r of segment i stands for the ORIGINAL row seg_uniq[i][r] of its
+  // level (biased by -seg_begin[i] like everything else; NULL: r itself): the sampler's outputs are read there, qf / zbar / probs at r.
+  // Only the first *seg_live[i] rows of the segment exist (NULL: all of them).
+  const int32_t* seg_uniq[TGMX_TGAT_MAX_LAYERS];
+  const int32_t* seg_live[TGMX_TGAT_MAX_LAYERS];
+  // Neighbor features by index: slot (ro, s) reads row seg_nidx[i][ro * k + s] of seg_ntab[i] (d floats per row; a negative index reads
+  // row seg_npad[i]) instead of row ro * k + s of the dense block -- the compact rows of the level below, or node_x by node id.
+  const int32_t* seg_nidx[TGMX_TGAT_MAX_LAYERS];
+  const float* seg_ntab[TGMX_TGAT_MAX_LAYERS];
+  long long seg_npad[TGMX_TGAT_MAX_LAYERS];
 };
 
 // the level (segment) of row r: wave-uniform, so this is scalar code
 struct AttnLevel {
   const int32_t* eid = nullptr;
   const float* table = nullptr;
+  const int32_t* uniq = nullptr;
+  const int32_t* live = nullptr;
+  const int32_t* nidx = nullptr;
+  const float* ntab = nullptr;
+  long long npad = 0, begin = 0;
   const float* nbrf;
   const float* ex;
   const int64_t* seed_t;
@@ -1028,6 +1118,8 @@ __device__ __forceinline__ AttnLevel attn_level(const AttnArgs& a, long long r) 
   AttnLevel v;
   v.nbrf = a.nbrf; v.ex = a.ex; v.seed_t = a.seed_t; v.nbr_t = a.nbr_t; v.nbr_id = a.nbr_id;
   v.eid = a.seg_eid[0]; v.table = a.seg_table[0];
+  v.uniq = a.seg_uniq[0]; v.live = a.seg_live[0]; v.nidx = a.seg_nidx[0]; v.ntab = a.seg_ntab[0]; v.npad = a.seg_npad[0];
+  v.begin = a.n_seg > 0 ? a.seg_begin[0] : 0;
   if (a.n_seg > 1) {
     int si = 0;
 #pragma unroll
@@ -1035,6 +1127,8 @@ __device__ __forceinline__ AttnLevel attn_level(const AttnArgs& a, long long r) 
       if (i < a.n_seg && r >= a.seg_begin[i]) si = i;
     v.nbrf = a.seg_nbrf[si]; v.ex = a.seg_ex[si]; v.seed_t = a.seg_seed_t[si]; v.nbr_t = a.seg_nbr_t[si]; v.nbr_id = a.seg_nbr_id[si];
     v.eid = a.seg_eid[si]; v.table = a.seg_table[si];
+    v.uniq = a.seg_uniq[si]; v.live = a.seg_live[si]; v.nidx = a.seg_nidx[si]; v.ntab = a.seg_ntab[si]; v.npad = a.seg_npad[si];
+    v.begin = a.seg_begin[si];
   }
   return v;
 }
@@ -1236,7 +1330,9 @@ __device__ __forceinline__ float lane_bcast(float v, int src) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
 }
 
-template <int H, int G, bool NBV>
+// IDX: compact rows / neighbor features by index (AttnArgs.seg_uniq, seg_live, seg_nidx) -- a variant of its own so that the plain
+// kernels keep their register budget (7 VGPRs would cost the k <= 10 variants a wave per SIMD)
+template <int H, int G, bool NBV, bool IDX>
 __global__ __launch_bounds__(256) void tgat_attn_reduce_reg_kernel(const AttnArgs a) {
   static_assert(G * H <= 64, "a score group must fit the 64 lanes");
   const int lane = lane_id();
@@ -1246,18 +1342,29 @@ __global__ __launch_bounds__(256) void tgat_attn_reduce_reg_kernel(const AttnArg
   const int D4 = D >> 2, d4 = d >> 2;
   const float* __restrict__ q = a.qf + r * (long long)H * a.Cs;
   const AttnLevel lv = attn_level(a, r);
-  const float* __restrict__ nb = lv.nbrf + r * (long long)k * d;
-  const float4* __restrict__ ex4 = reinterpret_cast<const float4*>(lv.ex + r * (long long)k * D);
+  if (IDX && lv.live && r - lv.begin >= (long long)*lv.live) return;  // compact rows: past the level's distinct rows
+  // ro: the row of the sampler's outputs this row reads (compact rows: the original row it stands for); qf / zbar / probs live at r
+  const long long ro = (IDX && lv.uniq) ? (long long)lv.uniq[r] + lv.begin : r;
+  const float* __restrict__ nb = lv.nbrf + ro * (long long)k * d;
+  const float4* __restrict__ ex4 = reinterpret_cast<const float4*>(lv.ex + ro * (long long)k * D);
 
   // slot metadata: lane s holds slot s
   float my_dt = 0.f;
   bool my_ok = false;
   int my_eid = -1;  // edge features by id: lane s holds slot s's edge id
+  int my_nix = 0;   // neighbor features by index: lane s holds slot s's row of lv.ntab
   if (lane < k) {
-    my_dt = (float)(lv.seed_t[r] - lv.nbr_t[r * k + lane]);  // int64 subtract, then round-to-nearest f32
-    my_ok = a.mask ? a.mask[r * k + lane] != 0 : lv.nbr_id[r * k + lane] != -1;
-    if (lv.eid) my_eid = lv.eid[r * k + lane];
+    my_dt = (float)(lv.seed_t[ro] - lv.nbr_t[ro * k + lane]);  // int64 subtract, then round-to-nearest f32
+    my_ok = a.mask ? a.mask[ro * k + lane] != 0 : lv.nbr_id[ro * k + lane] != -1;
+    if (lv.eid) my_eid = lv.eid[ro * k + lane];
+    if (IDX && lv.nidx) my_nix = lv.nidx[ro * k + lane];
   }
+  // slot sl's neighbor feature row (sl wave-uniform: scalar address arithmetic)
+  auto nrow = [&](int sl) __attribute__((always_inline)) -> const float* {
+    if (!IDX || !lv.nidx) return nb + (long long)sl * d;
+    const int ix = __builtin_amdgcn_readlane(my_nix, sl);
+    return lv.ntab + (ix < 0 ? lv.npad : (long long)ix) * d;
+  };
   const float4* __restrict__ table4 = reinterpret_cast<const float4*>(lv.table);
 
   // The sampler's all-pad row (every seed that is itself a pad slot of the hop above: ~1/3 of the layer-1 rows at the
@@ -1295,11 +1402,11 @@ __global__ __launch_bounds__(256) void tgat_attn_reduce_reg_kernel(const AttnArg
         const float w = wh[h];
         if (NBV) {
           if (lane < d4) {
-            const float4 v = reinterpret_cast<const float4*>(nb)[lane];
+            const float4 v = reinterpret_cast<const float4*>(nrow(0))[lane];
             zh[4 * lane] = w * v.x; zh[4 * lane + 1] = w * v.y; zh[4 * lane + 2] = w * v.z; zh[4 * lane + 3] = w * v.w;
           }
         } else if (lane < d) {
-          zh[lane] = w * nb[lane];
+          zh[lane] = w * nrow(0)[lane];
         }
         if (e_on) { zh[d + 4 * lane] = w * e.x; zh[d + 4 * lane + 1] = w * e.y; zh[d + 4 * lane + 2] = w * e.z; zh[d + 4 * lane + 3] = w * e.w; }
         if (t0) zh[d + D + lane] = w * c0;
@@ -1324,17 +1431,16 @@ __global__ __launch_bounds__(256) void tgat_attn_reduce_reg_kernel(const AttnArg
   float4 zn[NBV ? G : 1];
   float zs[NBV ? 1 : G];
   if (NBV) {
-    const float4* __restrict__ nb4 = reinterpret_cast<const float4*>(nb);
 #pragma unroll
     for (int s = 0; s < G; ++s) {
       const int sl = s < k ? s : k - 1;
-      zn[NBV ? s : 0] = lane < d4 ? nb4[sl * d4 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+      zn[NBV ? s : 0] = lane < d4 ? reinterpret_cast<const float4*>(nrow(sl))[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   } else {
 #pragma unroll
     for (int s = 0; s < G; ++s) {
       const int sl = s < k ? s : k - 1;
-      zs[NBV ? 0 : s] = lane < d ? nb[sl * d + lane] : 0.f;
+      zs[NBV ? 0 : s] = lane < d ? nrow(sl)[lane] : 0.f;
     }
   }
   // folded query columns of this lane
@@ -1488,17 +1594,25 @@ static bool launch_attn_reg(hipStream_t st, const AttnArgs& a) {
   uintptr_t ex_bits = (uintptr_t)a.ex, nb_bits = (uintptr_t)a.nbrf;  // D, d multiples of 4: biased pointers keep their alignment
   for (int i = 0; i < a.n_seg; ++i) {
     ex_bits |= (uintptr_t)a.seg_ex[i];
-    nb_bits |= (uintptr_t)a.seg_nbrf[i];
+    nb_bits |= a.seg_nidx[i] ? (uintptr_t)a.seg_ntab[i] : (uintptr_t)a.seg_nbrf[i];
   }
   const bool edge_ok = a.D > 0 && a.D % 4 == 0 && a.D / 4 <= 64 && (ex_bits & 15) == 0;
   const bool nbv = a.d % 4 == 0 && a.d / 4 <= 64 && (nb_bits & 15) == 0;
   if (!edge_ok || a.tfeat || a.T > 128 || !(nbv || a.d <= 64)) return false;
   const dim3 grid((unsigned)((a.R + 3) / 4)), block(256);
+  bool idx = false;
+  for (int i = 0; i < TGMX_TGAT_MAX_LAYERS; ++i) idx |= a.seg_uniq[i] || a.seg_live[i] || a.seg_nidx[i];
 #define TGMX_REG(G_)                                                                                        \
   if constexpr (G_ * H <= 64) {                                                                             \
     if (a.k <= G_) {                                                                                        \
-      if (nbv) hipLaunchKernelGGL((tgat_attn_reduce_reg_kernel<H, G_, true>), grid, block, 0, st, a);       \
-      else hipLaunchKernelGGL((tgat_attn_reduce_reg_kernel<H, G_, false>), grid, block, 0, st, a);          \
+      if (idx) {                                                                                            \
+        if (nbv) hipLaunchKernelGGL((tgat_attn_reduce_reg_kernel<H, G_, true, true>), grid, block, 0, st, a);  \
+        else hipLaunchKernelGGL((tgat_attn_reduce_reg_kernel<H, G_, false, true>), grid, block, 0, st, a);     \
+      } else if (nbv) {                                                                                     \
+        hipLaunchKernelGGL((tgat_attn_reduce_reg_kernel<H, G_, true, false>), grid, block, 0, st, a);       \
+      } else {                                                                                              \
+        hipLaunchKernelGGL((tgat_attn_reduce_reg_kernel<H, G_, false, false>), grid, block, 0, st, a);      \
+      }                                                                                                     \
       return true;                                                                                          \
     }                                                                                                       \
   }
@@ -1601,7 +1715,7 @@ extern "C" int tgmx_ln_residual_concat(const float* y, int64_t ldy, const float*
 // bandwidth instead of MFMA tiles that are 15/16 padding
 __global__ __launch_bounds__(256) void tgat_qfold_small_kernel(const float* __restrict__ x, long long ldx, int d, const float* __restrict__ U,
                                                                const float* __restrict__ v, int n4, long long R, float* __restrict__ out,
-                                                               long long ldo) {
+                                                               long long ldo, const RowSegs segs) {
   // one work item = 4 consecutive columns x 16 consecutive rows: the 4 U rows and v stay in registers, consecutive threads write
   // consecutive 16-byte pieces of a row
   constexpr int RB = 16;
@@ -1614,6 +1728,7 @@ __global__ __launch_bounds__(256) void tgat_qfold_small_kernel(const float* __re
 #pragma unroll
     for (int u = 0; u < 4; ++u) w[u] = *reinterpret_cast<const float4*>(U + (long long)(i + u) * 4);
     const long long r1 = (rb + 1) * RB < R ? (rb + 1) * RB : R;
+    if (!rows_live(segs, rb * RB, r1)) continue;  // compact rows: none of these 16 exists
     for (long long r = rb * RB; r < r1; ++r) {
       const float* xr = x + r * ldx;
       const float x0 = xr[0], x1 = d > 1 ? xr[1] : 0.f, x2 = d > 2 ? xr[2] : 0.f, x3 = d > 3 ? xr[3] : 0.f;
@@ -1646,6 +1761,11 @@ static int attn_reduce_impl(const AttnArgs& a, int H, hipStream_t st) {
     TGMX_CHECK_LAUNCH("tgat_attn_reduce(reg)");
     return TGMX_OK;
   }
+  for (int i = 0; i < TGMX_TGAT_MAX_LAYERS; ++i)
+    if (a.seg_uniq[i] || a.seg_live[i] || a.seg_nidx[i]) {  // only the register kernel reads rows / neighbor features by index
+      set_error("tgat_attn_reduce: compact rows need the register-resident kernel");
+      return TGMX_E_UNSUPPORTED;
+    }
   for (int i = 0; i < TGMX_TGAT_MAX_LAYERS; ++i)
     if (a.seg_eid[i]) {  // only the register kernel gathers edge features by id
       set_error("tgat_attn_reduce: edge features by id need the register-resident kernel (n_heads <= 2, k <= 20, D %% 4 == 0)");
@@ -1746,6 +1866,32 @@ extern "C" int tgmx_time2vec(const void* x, int32_t x_is_int64, const float* w, 
 static inline size_t align_up(size_t x) { return (x + 63) & ~(size_t)63; }
 static inline int pad4(int x) { return (x + 3) & ~3; }
 
+extern "C" size_t tgmx_pair_dedup_workspace_bytes(int64_t n);
+extern "C" int tgmx_pair_dedup(const int32_t* ids, const int64_t* times, int64_t n, int32_t* uniq, int32_t* owner, int32_t* cidx, int32_t* count,
+                               void* workspace, size_t workspace_bytes, tgmx_stream_t stream);
+
+// Inference over the DISTINCT rows of every level (tgmx_tgat_hop_t.seed_keyed): at least two layers (a one-layer model has no level that
+// is both a row batch and somebody's neighbors), every hop >= 1 marked, and every layer's attention on the register-resident kernel
+// (the only one that reads rows and neighbor features by index).  TGMX_TGAT_COMPACT=0 is the A/B knob.
+static bool compact_wanted(const tgmx_tgat_model_t* m, const tgmx_tgat_hop_t* hops, int save) {
+  static const bool off = [] { const char* e = getenv("TGMX_TGAT_COMPACT"); return e && atoi(e) == 0; }();
+  const int L = m->num_layers;
+  if (off || save || L < 2) return false;
+  for (int i = 1; i < L; ++i)
+    if (!hops[i].seed_keyed) return false;
+  for (int j = 0; j < L; ++j) {
+    const tgmx_tgat_layer_t& ly = m->layers[j];
+    if (!(ly.H <= 2 && hops[0].k <= 20 && ly.D > 0 && ly.D % 4 == 0 && ly.D / 4 <= 64 && ly.T <= 128 && ((ly.d % 4 == 0 && ly.d / 4 <= 64) || ly.d <= 64))) return false;
+    if (!ly.qf_U) return false;  // (the folded query side: the inference path proper)
+  }
+  for (int i = 0; i < L; ++i) {
+    if (hops[i].k != hops[0].k) return false;
+    if (!hops[i].edge_x && !(hops[i].nbr_eid && hops[i].edge_table)) return false;
+    if (((uintptr_t)hops[i].edge_x & 15) || ((uintptr_t)hops[i].edge_table & 15)) return false;
+  }
+  return true;
+}
+
 // Workspace layout of tgmx_tgat_forward (offsets in floats from the 256-byte aligned base).  Internal
 // activation rows are padded so that every GEMM operand row starts 16-byte aligned: O -> Op, per-head
 // dh -> dhp, C -> Cp, O + d0 -> Kc, emb -> Ep.  With save == 0 the per-layer scratch is reused by every
@@ -1797,6 +1943,14 @@ extern "C" int tgmx_tgat_layout(const tgmx_tgat_model_t* m, int64_t S0, const tg
     const int64_t pp[2] = {take(emb_rows), take(emb_rows)};
     for (int j = 1; j <= L; ++j) out->layers[j - 1].out = (j == L) ? -1 : pp[j & 1];
   }
+  // compact rows (tgmx_tgat_hop_t.seed_keyed): one block of int32 per deduplicated level
+  for (int i = 0; i <= TGMX_TGAT_MAX_LAYERS; ++i) out->compact[i] = -1;
+  if (compact_wanted(m, hops, save)) {
+    for (int i = 1; i < L; ++i) {
+      const size_t n = (size_t)rows[i];
+      out->compact[i] = take(16 + 4 * n + (tgmx_pair_dedup_workspace_bytes((int64_t)n) + 3) / 4);
+    }
+  }
   out->total_bytes = (int64_t)(w * sizeof(float) + 256);
   return TGMX_OK;
 }
@@ -1808,8 +1962,9 @@ extern "C" size_t tgmx_tgat_workspace_bytes(const tgmx_tgat_model_t* m, int64_t 
 
 static int launch_post_chain(const tgmx_tgat_layer_t& ly, const tgmx_tgat_layer_layout_t& lo, const float* zbar, const float* x,
                              long long ldx, const float* tb, const float* z0, int d0, long long R, float* out, long long ldo,
-                             hipStream_t st) {
+                             hipStream_t st, const RowSegs& segs) {
   ChainArgs g{};
+  g.segs = segs;
   g.zbar = zbar; g.x = x; g.tb = tb; g.z0 = z0;
   g.W_V = ly.W_V; g.W_O = ly.W_O; g.b_O = ly.b_O; g.ln_g = ly.ln_g; g.ln_b = ly.ln_b;
   g.fc1_w = ly.fc1_w; g.fc1_b = ly.fc1_b; g.fc2_w = ly.fc2_w; g.fc2_b = ly.fc2_b;
@@ -1910,13 +2065,14 @@ extern "C" int tgmx_tgat_tile16(const float* W, int64_t ldw, int32_t N, int32_t 
 // fit it (a stage wider than 192 columns, no tiled weights) -- the caller falls back to tgat_post_chain_kernel / the unfused kernels.
 static int launch_chain64(const tgmx_tgat_layer_t& ly, const tgmx_tgat_layer_layout_t& lo, const float* zbar, const float* x,
                           long long ldx, const float* tb, const float* z0, int d0, long long R, float* out, long long ldo,
-                          hipStream_t st, bool dry) {
+                          hipStream_t st, bool dry, const RowSegs& segs) {
   static const bool off = [] { const char* e = getenv("TGMX_CHAIN64"); return e && atoi(e) == 0; }();  // A/B knob
   if (off || !ly.W_V_t16 || !ly.W_O_t16 || !ly.fc1_t16 || !ly.fc2_t16) return TGMX_E_UNSUPPORTED;
   const int blocks[4] = {(ly.O / ly.H + 15) / 16, (ly.O + 15) / 16, (ly.emb + 15) / 16, (ly.emb_out + 15) / 16};
   for (int b : blocks)
     if (b > kC64MaxB) return TGMX_E_UNSUPPORTED;
   ChainArgs g{};
+  g.segs = segs;
   g.zbar = zbar; g.x = x; g.tb = tb; g.z0 = z0;
   g.W_V = ly.W_V_t16; g.W_O = ly.W_O_t16; g.b_O = ly.b_O; g.ln_g = ly.ln_g; g.ln_b = ly.ln_b;
   g.fc1_w = ly.fc1_t16; g.fc1_b = ly.fc1_b; g.fc2_w = ly.fc2_t16; g.fc2_b = ly.fc2_b;
@@ -1967,8 +2123,36 @@ extern "C" int tgmx_tgat_forward(const tgmx_tgat_model_t* m, const float* node_x
   float* base = reinterpret_cast<float*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
   float* z0 = base + lay.z0;
 
-  // leaves: z0[level i] = node_x[V_i], V_0 = seeds, V_i = hop (i-1) neighbor ids (pad -1 -> last row)
-  {
+  // Compact rows (tgmx_tgat_hop_t.seed_keyed): the distinct (id, time) pairs of every level that is a row batch, then the leaf
+  // features of the distinct rows only; the deepest level is read from node_x by node id where the attention consumes it.
+  const bool compact = lay.compact[1] >= 0;
+  struct CompactLevel {
+    int32_t *count, *uniq, *owner, *cidx, *rep;
+  } cl[TGMX_TGAT_MAX_LAYERS + 1] = {};
+  if (compact) {
+    CompactGatherArgs cg{};
+    cg.levels = L;
+    cg.table = node_x; cg.out = z0; cg.num_nodes = num_nodes; cg.dim = d0;
+    cg.ids[0] = seed_ids; cg.rows[0] = rows[0]; cg.off[0] = 0;
+    cg.itemsB = rows[0] * d0;
+    for (int i = 1; i < L; ++i) {
+      TGMX_REQUIRE(hops[i - 1].nbr_id && hops[i - 1].nbr_t, "tgat_forward: hop %d has no neighbor ids / times", i - 1);
+      const long long n = rows[i];
+      int32_t* blk = reinterpret_cast<int32_t*>(base + lay.compact[i]);
+      cl[i] = CompactLevel{blk, blk + 16, blk + 16 + n, blk + 16 + 2 * n, blk + 16 + 3 * n};
+      if ((rc = tgmx_pair_dedup(hops[i - 1].nbr_id, hops[i - 1].nbr_t, n, cl[i].uniq, cl[i].owner, cl[i].cidx, cl[i].count, blk + 16 + 4 * n,
+                                tgmx_pair_dedup_workspace_bytes(n), stream)))
+        return rc;
+      cg.ids[i] = hops[i - 1].nbr_id; cg.rows[i] = n; cg.off[i] = off[i];
+      cg.uniq[i] = cl[i].uniq; cg.owner[i] = cl[i].owner; cg.cidx[i] = cl[i].cidx; cg.rep[i] = cl[i].rep; cg.count[i] = cl[i].count;
+      cg.itemsA += n;
+      cg.itemsB += n * d0;
+    }
+    long long blocks = (cg.itemsA + cg.itemsB + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks > 0) hipLaunchKernelGGL(gather_compact_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, cg);
+    TGMX_CHECK_LAUNCH("tgat_gather_compact");
+  } else {
     LeafGatherArgs lg{};
     lg.idx[0] = seed_ids;
     lg.end[0] = off[1];
@@ -2002,8 +2186,17 @@ extern "C" int tgmx_tgat_forward(const tgmx_tgat_model_t* m, const float* node_x
     // inference, enough row tiles to fill the chip: the whole tail of the layer is one kernel over row tiles (both variants
     // rebuild the residual themselves) -- 64-row workgroups of 16-row MFMA tiles when the layer fits that kernel, else 32-row tiles
     const bool chain = !save && R >= 2048;
-    const bool chain64 = chain && launch_chain64(ly, lo, nullptr, nullptr, 0, nullptr, nullptr, d0, R, nullptr, 0, nullptr, true) == TGMX_OK;
+    const bool chain64 = chain && launch_chain64(ly, lo, nullptr, nullptr, 0, nullptr, nullptr, d0, R, nullptr, 0, nullptr, true, RowSegs{}) == TGMX_OK;
     const bool folded = !save && ly.qf_U != nullptr;  // inference: qf = x . U^T + v in one GEMM, no Q / rres round trip
+    RowSegs segs{};  // which rows of this layer's row space exist (compact rows; all of them otherwise)
+    if (compact) {
+      segs.n = n_lvl;
+      for (int i = 0; i < n_lvl; ++i) {
+        segs.begin[i] = off[i];
+        segs.live[i] = i >= 1 ? cl[i].count : nullptr;
+      }
+      segs.begin[n_lvl] = off[n_lvl];
+    }
     const int dp = (ly.d + 3) / 4 * 4;
     if (!folded)  // the residual as a buffer is the Q projection's input; LayerNorm rebuilds it on the fly
       if ((rc = tgmx_tgat_rres(prev, ld_prev, ly.d, m->tb, nullptr, ly.T, O, R, rres, Op, stream))) return rc;
@@ -2017,7 +2210,7 @@ extern "C" int tgmx_tgat_forward(const tgmx_tgat_model_t* m, const float* node_x
       long long blocks = ((R + 15) / 16 * (H * Cp / 4) + 255) / 256;
       if (blocks > 16384) blocks = 16384;
       hipLaunchKernelGGL(tgat_qfold_small_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, prev, ld_prev, ly.d, ly.qf_U, ly.qf_v,
-                         H * Cp / 4, R, qf, (long long)H * Cp);
+                         H * Cp / 4, R, qf, (long long)H * Cp, segs);
       TGMX_CHECK_LAUNCH("tgat_qfold_small");
     } else {
       if ((rc = tgmx_sgemm_nt(prev, ld_prev, ly.qf_U, dp, qf, (long long)H * Cp, R, H * Cp, ly.d, ly.qf_v, 0, 1, 0, 0, 0, stream))) return rc;
@@ -2052,19 +2245,35 @@ extern "C" int tgmx_tgat_forward(const tgmx_tgat_model_t* m, const float* node_x
         a.seg_seed_t[i] = hops[i].seed_t - b;
         a.seg_nbr_t[i] = hops[i].nbr_t - b * (long long)k;
         a.seg_nbr_id[i] = hops[i].nbr_id - b * (long long)k;
+        if (compact) {
+          // rows: level i >= 1 holds its distinct rows only.  Neighbor features: the compact rows of level i + 1 through its rep map
+          // (the previous layer's outputs, or in layer 1 the compact leaf features), or -- layer 1, deepest level -- node_x by node id
+          a.seg_uniq[i] = i >= 1 ? cl[i].uniq - b : nullptr;
+          a.seg_live[i] = i >= 1 ? cl[i].count : nullptr;
+          a.seg_nbrf[i] = nullptr;
+          if (i + 1 < L) {
+            a.seg_nidx[i] = cl[i + 1].rep - b * (long long)k;
+            a.seg_ntab[i] = prev + off[i + 1] * ld_prev;
+            a.seg_npad[i] = 0;  // (a rep map has no negative entries)
+          } else {
+            a.seg_nidx[i] = hops[i].nbr_id - b * (long long)k;
+            a.seg_ntab[i] = node_x;
+            a.seg_npad[i] = num_nodes - 1;  // pad id -1 reads the LAST row of node_x (tgat.py:128-130)
+          }
+        }
       }
       a.nbrf = a.seg_nbrf[0]; a.ex = a.seg_ex[0]; a.seed_t = a.seg_seed_t[0]; a.nbr_t = a.seg_nbr_t[0]; a.nbr_id = a.seg_nbr_id[0];
       TGMX_REQUIRE(ld_prev == ly.d, "tgat_forward: layer %d expects densely packed input rows", j);
       if (a.R > 0 && (rc = attn_reduce_impl(a, H, (hipStream_t)stream))) return rc;
     }
     if (chain64) {
-      if ((rc = launch_chain64(ly, lo, zbar, prev, ld_prev, m->tb, z0, d0, R, nxt, ld_nxt, (hipStream_t)stream, false))) return rc;
+      if ((rc = launch_chain64(ly, lo, zbar, prev, ld_prev, m->tb, z0, d0, R, nxt, ld_nxt, (hipStream_t)stream, false, segs))) return rc;
       prev = nxt;
       ld_prev = ld_nxt;
       continue;
     }
     if (chain) {  // intermediates stay in LDS
-      if ((rc = launch_post_chain(ly, lo, zbar, prev, ld_prev, m->tb, z0, d0, R, nxt, ld_nxt, (hipStream_t)stream))) return rc;
+      if ((rc = launch_post_chain(ly, lo, zbar, prev, ld_prev, m->tb, z0, d0, R, nxt, ld_nxt, (hipStream_t)stream, segs))) return rc;
       prev = nxt;
       ld_prev = ld_nxt;
       continue;

@@ -38,6 +38,7 @@ class DGDataLoader(torch.utils.data.DataLoader):
         hook_manager: Optional[Any] = None,
         output_pool: Optional[int] = None,
         prefetch: int = 0,
+        batch_shard: Optional[tuple] = None,
         **kwargs: Any,
     ) -> None:
         if batch_size <= 0:
@@ -91,7 +92,23 @@ class DGDataLoader(torch.utils.data.DataLoader):
             start, stop = dg.start_time, dg.end_time + 1
         if kwargs.get('drop_last', False):
             stop = stop - batch_size
-        self._starts = range(start, stop, batch_size)
+        # batch_shard=(rank, world) (ours; SURVEY.md 8(e), tgm/data/loader.py:147-156: the loader is a range of slice starts): this
+        # loader yields batches rank, rank + world, ... of the schedule -- every batch exactly the one the unsharded loader yields at that
+        # position, so the ranks' outputs INTERLEAVED are the single-process batch sequence.  Only for hooks without per-batch state:
+        # the recency sampler over the static index (mode='csr'), whose batches are independent units; streaming rings are refused.
+        self._batch_shard = None
+        self._first_start = start
+        self._neg_base: dict = {}
+        if batch_shard is not None:
+            if not unit.is_event_ordered:
+                raise ValueError('batch_shard needs event-ordered batches (batch_unit="r"): the position of a batch in the schedule is what the ranks split')
+            rank, world = (int(v) for v in batch_shard)
+            if not 0 <= rank < world:
+                raise ValueError(f'batch_shard: rank {rank} outside [0, {world})')
+            self._batch_shard = (rank, world)
+            self._starts = range(start + rank * batch_size, stop, batch_size * world)
+        else:
+            self._starts = range(start, stop, batch_size)
         # the reference's base-class call (loader.py:147-149): torch validates the keyword arguments; unknown ones raise TypeError
         super().__init__(self._starts, 1, shuffle=False, collate_fn=self, **kwargs)
 
@@ -102,9 +119,32 @@ class DGDataLoader(torch.utils.data.DataLoader):
     def __len__(self) -> int:
         return len(self._starts)
 
+    def _check_shardable(self, hooks) -> None:
+        for h in hooks:
+            if getattr(h, 'has_state', False) and not getattr(h, 'batches_are_independent', False):
+                raise ValueError(
+                    f'batch_shard: {type(h).__name__} carries state from batch to batch, so a rank cannot skip the batches of the other '
+                    "ranks.  The recency sampler is stateless over the static index: RecencyNeighborHook(mode='csr', batch_size=...)."
+                )
+
     def __call__(self, slice_start, _deferred: bool = False) -> DGBatch:
         """Materialize the batch beginning at ``slice_start`` and run the active hooks."""
         s = slice_start[0] if isinstance(slice_start, (list, tuple)) else slice_start
+        if self._batch_shard is not None and self._hook_manager is not None and hasattr(self._hook_manager, 'active_hooks'):
+            hooks = self._hook_manager.active_hooks()
+            if getattr(self, '_shard_checked', None) is not hooks:
+                self._check_shardable(hooks)
+                self._shard_checked = hooks
+            self._anchor_epoch(hooks)
+            # generated negatives are a function of (seed, call number, position): the call number of schedule position j is the one
+            # the unsharded loader would be at, so every rank draws exactly the negatives of the batches it takes
+            j = (s - self._first_start) // self._batch_size
+            for h in hooks:
+                if hasattr(h, '_rng_seed') and hasattr(h, '_calls'):
+                    base = self._neg_base.get(id(h))
+                    if base is None:
+                        base = self._neg_base[id(h)] = h._calls
+                    h._calls = base + j
         if self._output_pool != 0 and hasattr(self._hook_manager, 'active_hooks'):
             batch = self._call_compiled(s, _deferred)
             if batch is not None:
@@ -170,6 +210,18 @@ class DGDataLoader(torch.utils.data.DataLoader):
                 batch = h(view, batch)
         return batch
 
+    def _anchor_epoch(self, hooks) -> None:
+        """A static-index sampler anchors its epoch (the first edge whose history is visible) at the first batch it sees after
+        ``reset_state``; rank r of a batch-sharded loader first sees batch r, so the anchor is handed over: the schedule's first edge."""
+        if self._event_fast:
+            first = self._first_start
+        else:
+            first = self._slice_op(self._first_start, self._first_start + self._batch_size)._edge_range[0]
+        for h in hooks:
+            anchor = getattr(h, '_anchor_epoch', None)
+            if anchor is not None:
+                anchor(first)
+
     @staticmethod
     def _settle_for(batch: DGBatch, h: Any) -> None:
         """Batch attributes whose SIZE is learnt from the device are published by finalizers that a prefetching loader runs one
@@ -187,6 +239,9 @@ class DGDataLoader(torch.utils.data.DataLoader):
         return n == 0
 
     def __iter__(self) -> Iterator[DGBatch]:
+        if self._batch_shard is not None:
+            yield from self._iter_sharded()
+            return
         if self._prefetch > 0:
             yield from self._iter_prefetch()
             return
@@ -197,6 +252,32 @@ class DGDataLoader(torch.utils.data.DataLoader):
                     raise EmptyBatchError('Empty batch encountered')
                 continue
             yield batch
+
+    def _iter_sharded(self) -> Iterator[DGBatch]:
+        """One pass over this rank's batches; afterwards the negative samplers' call counters stand where the unsharded pass leaves them
+        (the next pass -- another epoch, the validation loader -- then draws what a single process would)."""
+        self._neg_base = {}
+        total = len(range(self._first_start, self._starts.stop, self._batch_size))
+        src = self._iter_prefetch() if self._prefetch > 0 else None
+        try:
+            if src is not None:
+                yield from src
+            else:
+                for s in self._starts:
+                    batch = self(s)
+                    if self._on_empty is not None and self._is_batch_empty(batch):
+                        if self._on_empty == 'raise':
+                            raise EmptyBatchError('Empty batch encountered')
+                        continue
+                    yield batch
+        finally:
+            hm = self._hook_manager
+            if hm is not None and hasattr(hm, 'active_hooks'):
+                for h in hm.active_hooks():
+                    base = self._neg_base.get(id(h))
+                    if base is not None:
+                        h._calls = base + total
+            self._neg_base = {}
 
     def _iter_prefetch(self) -> Iterator[DGBatch]:
         from collections import deque

@@ -201,6 +201,18 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
         else:
             self._epoch_lo = None  # re-anchored at the next batch's first edge
 
+    @property
+    def batches_are_independent(self) -> bool:
+        """Over the static index a batch's result is a function of (index, batch start, epoch start) alone: a loader may
+        hand this hook any subset of the schedule's batches (``DGDataLoader(batch_shard=(rank, world))``).  Streaming rings: no."""
+        return self._mode == 'csr'
+
+    def _anchor_epoch(self, first_edge: int) -> None:
+        """The epoch starts at edge ``first_edge`` unless it has started already (a batch-sharded loader: this rank's first batch is not
+        the schedule's first)."""
+        if self._mode == 'csr' and self._epoch_lo is None:
+            self._epoch_lo = int(first_edge)
+
     def _refresh_ts_bound(self, dg: DGraph) -> None:
         """The store is time-sorted and keeps a host copy of the timestamps: [0, last] bounds every batch of this graph
         (lets the large-batch update sort only the key bits that can be set); unknown / negative times: no promise."""
@@ -396,10 +408,18 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
 
     # ------------------------------------------------------------------
     def _publish(self, batch: DGBatch, seed_n, seed_t, out_n, out_t, out_x, seed_mask) -> DGBatch:
-        self.add_batch_attribute(batch, 'seed_nids', seed_n)
-        self.add_batch_attribute(batch, 'seed_times', seed_t)
-        self.add_batch_attribute(batch, 'nbr_nids', out_n)
-        self.add_batch_attribute(batch, 'nbr_edge_time', out_t)
+        # the lists of one call carry its tag (plain lists otherwise): tgm_amd.nn.TGAT recognises hops sampled for one another by it
+        from ..core.lazy import EdgeFeaturesById, SampledHops, SamplerCallTag
+
+        tag = SamplerCallTag(out_n, out_t)
+        if isinstance(out_x, EdgeFeaturesById):
+            out_x.tag = tag
+        else:
+            out_x = SampledHops(out_x, tag)
+        self.add_batch_attribute(batch, 'seed_nids', SampledHops(seed_n, tag))
+        self.add_batch_attribute(batch, 'seed_times', SampledHops(seed_t, tag))
+        self.add_batch_attribute(batch, 'nbr_nids', SampledHops(out_n, tag))
+        self.add_batch_attribute(batch, 'nbr_edge_time', SampledHops(out_t, tag))
         self.add_batch_attribute(batch, 'nbr_edge_x', out_x)
         self.add_batch_attribute(batch, 'seed_node_nbr_mask', seed_mask)
         return batch

@@ -53,7 +53,7 @@ class MergeLayer(nn.Module):
 
 
 class TGAT(TransientCaches, nn.Module):
-    _TRANSIENT = ('_desc_cache', '_desc_struct', '_fold_keep', '_workspace')
+    _TRANSIENT = ('_desc_cache', '_desc_struct', '_fold_keep', '_workspace', '_last_hops')
 
     def __init__(self, node_dim: int, edge_dim: int, time_dim: int, embed_dim: int, num_layers: int, n_heads: int = 2,
                  dropout: float = 0.1) -> None:  # fmt: skip
@@ -221,6 +221,15 @@ class TGAT(TransientCaches, nn.Module):
         # composed from Python, TGMX_TGAT_BWD=py) gather the rows first
         by_id = (isinstance(nbr_edge_x, EdgeFeaturesById) and not getattr(self, '_by_id_unsupported', False)
                  and not (saving and os.environ.get('TGMX_TGAT_BWD', '') == 'py'))
+        # Hops sampled FOR one another by one sampler call (the lists carry its tag, every deeper hop's seeds ARE the hop above's
+        # flattened outputs): slots with equal (id, time) are then the same row of every deeper level, and inference computes each
+        # distinct row once (tgmx_tgat_hop_t.seed_keyed).  Anything else -- hand-made tensors, replaced items, tensors modified in
+        # place -- gets the row-per-slot computation.
+        tag = getattr(nbr_nids, 'tag', None)
+        keyed = (L > 1 and tag is not None and getattr(nbr_edge_time, 'tag', None) is tag and getattr(seed_times, 'tag', None) is tag
+                 and getattr(seed_nids, 'tag', None) is tag and getattr(nbr_edge_x, 'tag', None) is tag and tag.matches(nbr_nids, nbr_edge_time)
+                 and all(seed_nids[i].data_ptr() == nbr_nids[i - 1].data_ptr() and seed_times[i].data_ptr() == nbr_edge_time[i - 1].data_ptr()
+                         and seed_nids[i].numel() == nbr_nids[i - 1].numel() == seed_times[i].numel() for i in range(1, L)))  # fmt: skip
         for i in range(L):
             nid, nt, st = c(nbr_nids[i]), c(nbr_edge_time[i]), c(seed_times[i])
             ex = None if by_id else c(nbr_edge_x[i])
@@ -231,6 +240,7 @@ class TGAT(TransientCaches, nn.Module):
             h = hops[i]
             h.seed_t, h.nbr_id, h.nbr_t, h.edge_x, h.k = st.data_ptr(), nid.data_ptr(), nt.data_ptr(), _native.ptr(ex), nid.shape[-1]
             h.nbr_eid, h.edge_table = _native.ptr(eid), _native.ptr(table)
+            h.seed_keyed = 1 if (keyed and i >= 1) else 0
             rows *= nid.shape[-1]
         if saving:
             # training: same native forward with every intermediate kept, hand-written backward (nn/_tgat_train.py);
@@ -253,6 +263,7 @@ class TGAT(TransientCaches, nn.Module):
         out = torch.empty((S0, self.embed_dim), dtype=torch.float32, device=dev)
         if S0 == 0:
             return out
+        self._last_hops = hops  # (tests / diagnostics: what the last inference call was given)
         self._ensure_fold(model, _keep)
         need = lib.tgmx_tgat_workspace_bytes(model, S0, hops)
         ws = getattr(self, '_workspace', None)

@@ -66,6 +66,7 @@ _ROLE_KEYS = {
 
 
 _STATUS_READ_EVERY = 512  # batches between reads of the device status word when the store vouches for the seeds (validate='sync')
+_TAGGED = frozenset(('seed_nids', 'seed_times', 'nbr_nids', 'nbr_edge_time', 'nbr_edge_x'))
 _MAX_AUTO_SETS = 4  # output sets kept by the liveness-checked pool (output_pool=None); a batch beyond that gets an unpooled set
 _storage_uses = torch._C._storage_Use_Count
 
@@ -528,18 +529,20 @@ class CompiledPipeline:
             d['shard_dst'] = arr.dst.narrow(0, lo + s_lo, s_hi - s_lo)
             d['shard_time'] = arr.ts.narrow(0, lo + s_lo, s_hi - s_lo)
             d['shard_lo'] = s_lo
-        if nbr._by_id and nbr._edge_x_dim:
-            from .core.lazy import EdgeFeaturesById
+        from .core.lazy import EdgeFeaturesById, SampledHops, SamplerCallTag
 
-            d_eids = slot.attrs['nbr_edge_x']
-        if self._safe:
-            # the batch owns its containers (a consumer may append to / reorder them); the tensors inside are the set's views
-            for key, v in slot.attrs.items():
-                d[key] = list(v) if type(v) is list else (dict(v) if type(v) is dict else v)
-        else:
-            d.update(slot.attrs)
         if nbr._by_id and nbr._edge_x_dim:
-            d['nbr_edge_x'] = EdgeFeaturesById(d_eids, self._arr.edge_x)  # per batch: it caches what it materializes
+            d_eids = slot.attrs['nbr_edge_x']
+        # the per-hop lists carry the call's tag (tgm_amd.nn.TGAT recognises hops sampled for one another by it); the batch owns its
+        # containers (a consumer may append to / reorder them), the tensors inside are the set's views
+        tag = SamplerCallTag(slot.attrs['nbr_nids'], slot.attrs['nbr_edge_time'])
+        for key, v in slot.attrs.items():
+            if type(v) is list:
+                d[key] = SampledHops(v, tag) if key in _TAGGED else (list(v) if self._safe else v)
+            else:
+                d[key] = dict(v) if (self._safe and type(v) is dict) else v
+        if nbr._by_id and nbr._edge_x_dim:
+            d['nbr_edge_x'] = EdgeFeaturesById(d_eids, self._arr.edge_x, tag)  # per batch: it caches what it materializes
         if slot.post is not None:
             self._defer_post(batch, slot)
         return True
