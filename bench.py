@@ -56,7 +56,10 @@ def parse_args():
     p.add_argument('--num-nbrs', type=int, nargs='+', default=None)
     p.add_argument('--mode', default='ring', choices=['ring', 'csr'])
     p.add_argument('--cpu-batches', type=int, default=8, help='batches of the CPU-baseline sample PER thread setting (0 = skip); ~0.1-0.3 s each')
-    p.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
+    p.add_argument('--scaling', default='weak', choices=['weak', 'strong', 'batch'],
+                   help="N > 1: 'weak' = global batch N x bs, rank r seeds from its slice; 'strong' = global batch bs, split N ways; 'batch' = "
+                   "the single-GPU schedule of bs-edge batches dealt round-robin to the ranks (DGDataLoader(batch_shard=), static index only: "
+                   "the batches -- and therefore the sampled neighbours -- are exactly the single-GPU run's)")
     p.add_argument('--pool', type=int, default=1, help='DGDataLoader(output_pool=): ring of preallocated output sets, one native call per batch; '
                    '0 = hook-by-hook path with fresh tensors per batch (the reference-semantics default of the library)')
     p.add_argument('--validate', default='deferred', choices=['deferred', 'sync', 'off'], help="seed validation mode of the hook ('sync' = its default: a device->host read per batch)")
@@ -72,7 +75,7 @@ def parse_args():
 DEFAULTS = {'wiki': (200, [20, 20]), 'review': (512, [10, 10]), 'comment': (4096, [20, 20])}
 
 
-def build_pipeline(stream, rank, world, global_bs, num_nbrs, mode, device, pool=0, validate='deferred', edge_features='dense'):
+def build_pipeline(stream, rank, world, global_bs, num_nbrs, mode, device, pool=0, validate='deferred', edge_features='dense', batch_shard=False):
     from tgm_amd import DGData, DGDataLoader, DGraph
     from tgm_amd.dist import EdgeShardHook
     from tgm_amd.hooks import HookManager, RandomNegativeEdgeSamplerHook, RecencyNeighborHook
@@ -81,7 +84,7 @@ def build_pipeline(stream, rank, world, global_bs, num_nbrs, mode, device, pool=
     dg = DGraph(data, device=device)
     hm = HookManager(keys=['bench'])
     lo_dst = int(stream.dst.min())
-    if world > 1:
+    if world > 1 and not batch_shard:
         hm.register('bench', EdgeShardHook(rank, world))
         keys, tkeys = ['shard_src', 'shard_dst', 'neg'], ['shard_time', 'shard_time', 'neg_time']
         hm.register('bench', RandomNegativeEdgeSamplerHook(lo_dst, stream.num_nodes, like='shard_dst', time_key='shard_time'))
@@ -93,10 +96,11 @@ def build_pipeline(stream, rank, world, global_bs, num_nbrs, mode, device, pool=
         kw['edge_features'] = edge_features
     hook = RecencyNeighborHook(stream.num_nodes, num_nbrs, keys, tkeys, mode=mode, batch_size=global_bs if mode == 'csr' else None, **kw)
     hm.register('bench', hook)
+    kw_l = {'batch_shard': (rank, world)} if (batch_shard and world > 1) else {}
     if pool is None:  # the loader's own default: what an unmodified TGM script gets
-        loader = DGDataLoader(dg, batch_size=global_bs, hook_manager=hm)
+        loader = DGDataLoader(dg, batch_size=global_bs, hook_manager=hm, **kw_l)
     else:
-        loader = DGDataLoader(dg, batch_size=global_bs, hook_manager=hm, output_pool=pool)
+        loader = DGDataLoader(dg, batch_size=global_bs, hook_manager=hm, output_pool=pool, **kw_l)
     return dg, hm, hook, loader
 
 
@@ -233,13 +237,18 @@ def main():
     bs = args.batch_size or bs
     num_nbrs = args.num_nbrs or num_nbrs
     # weak: every rank seeds from bs edges of a (world x bs)-edge global batch; strong: the global batch stays bs edges
+    by_batch = args.scaling == 'batch'
+    if by_batch and args.mode != 'csr':
+        raise SystemExit("bench.py: --scaling batch needs --mode csr (whole batches are independent units only over the static index; "
+                         'streaming rings carry state from batch to batch)')
     global_bs = bs * world if args.scaling == 'weak' else bs
     lo_r, hi_r = (global_bs * rank) // world, (global_bs * (rank + 1)) // world
-    bs_rank = hi_r - lo_r  # this rank's seeds edges per full batch
+    bs_rank = global_bs if by_batch else hi_r - lo_r  # this rank's seed edges per full batch
     # small shapes are generated on the host (bit-stable stream shared with the fixtures), big ones on the device
     gen_dev = 'cpu' if args.workload == 'wiki' else device
     stream = make_stream(args.workload, seed=args.seed, device=gen_dev)
-    dg, hm, hook, loader = build_pipeline(stream, rank, world, global_bs, num_nbrs, args.mode, device, pool=args.pool, validate=args.validate)
+    dg, hm, hook, loader = build_pipeline(stream, rank, world, global_bs, num_nbrs, args.mode, device, pool=args.pool, validate=args.validate,
+                                          batch_shard=by_batch)
     D = stream.edge_dim
     n_batches = len(loader)
     last_hop = len(num_nbrs) - 1
@@ -359,9 +368,10 @@ def main():
         if it == n_batches:
             it = 0
         n_e = min(global_bs, stream.num_edges - starts[it])
-        total_events += n_e
+        total_events += n_e * (world if (by_batch and not args.emulate_world) else 1)
         for r in (range(world) if not args.emulate_world else [rank]):
-            total_units += slots_of((n_e * (r + 1)) // world - (n_e * r) // world)
+            # by batch: every rank's step is a full batch of the schedule (the ragged last one is never reached by the default step count)
+            total_units += slots_of(n_e if by_batch else (n_e * (r + 1)) // world - (n_e * r) // world)
         it += 1
 
     # ---- roofline of the dominant kernel (last hop's lookup + gather launch) -----------
@@ -403,7 +413,7 @@ def main():
         'warmup': args.warmup,
         'ms_per_step': 1e3 * elapsed / steps,
         'higher_is_better': True,
-        'scaling': args.scaling,
+        'scaling': 'weak' if by_batch else args.scaling,  # by batch: every rank's timed region is `steps` full batches (per-GPU work fixed)
         'vs_baseline': None,
         'dtype': 'int32/int64 indices + f32 feature rows (copied, no arithmetic)',
         'data': 'synthetic',
@@ -421,7 +431,10 @@ def main():
             'slots_per_step_per_rank': slots_of(bs_rank),
             'profile_key': pkey,
             'events_per_s': total_events / elapsed,
-            'parallelism': f'edge-batch sharding x{world} ({args.scaling} scaling), replicated stream, no data-path collective'
+            'parallelism': (f'batch-level sharding x{world}: the single-GPU schedule of {global_bs}-edge batches dealt round-robin to the ranks '
+                            '(rank r takes batches r, r + N, ...; same batches, same sampled neighbours as one GPU), static index, replicated stream, '
+                            'no data-path collective' if by_batch else
+                            f'edge-batch sharding x{world} ({args.scaling} scaling), replicated stream, no data-path collective')
             + (f' -- EMULATED: this is rank {rank} of {world} alone on one GPU (value = that rank\'s units only)' if args.emulate_world else ''),
         },
         'roofline': {

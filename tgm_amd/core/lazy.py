@@ -20,21 +20,23 @@ class SamplerCallTag:
 
     ``tgm_amd.nn.TGAT`` uses it to recognise inputs whose deeper hops were sampled FOR the shallower hops' outputs by one call --
     then slots with the same (neighbor id, time) are the same row of every deeper level and inference computes each distinct row
-    once (``tgmx_tgat_hop_t.seed_keyed``).  The stamp records every output tensor's (address, version, rows): a list whose items
+    once (``tgmx_tgat_hop_t.seed_keyed``).  The stamp records every output tensor's (address, version, rows) -- ids, times and edge features (or, by id, the edge ids): a list whose items
     were replaced, or a tensor modified in place through torch, no longer matches and gets the row-per-slot computation."""
 
     __slots__ = ('stamp',)
 
-    def __init__(self, nbr_nids: List[Tensor], nbr_edge_time: List[Tensor]) -> None:
-        self.stamp = self._of(nbr_nids, nbr_edge_time)
+    def __init__(self, nbr_nids: List[Tensor], nbr_edge_time: List[Tensor], nbr_edge_x=None) -> None:
+        self.stamp = self._of(nbr_nids, nbr_edge_time, nbr_edge_x)
 
     @staticmethod
-    def _of(nbr_nids, nbr_edge_time) -> tuple:
-        return tuple((t.data_ptr(), t._version, t.shape[0]) for t in (*nbr_nids, *nbr_edge_time))
+    def _of(nbr_nids, nbr_edge_time, nbr_edge_x=None) -> tuple:
+        # edge features: the dense copies themselves, or (by id) the edge ids the rows are read through
+        feats = () if nbr_edge_x is None else (nbr_edge_x.eids if hasattr(nbr_edge_x, 'eids') else tuple(nbr_edge_x))
+        return tuple((t.data_ptr(), t._version, t.shape[0]) for t in (*nbr_nids, *nbr_edge_time, *feats) if t is not None)
 
-    def matches(self, nbr_nids, nbr_edge_time) -> bool:
+    def matches(self, nbr_nids, nbr_edge_time, nbr_edge_x=None) -> bool:
         try:
-            return self._of(nbr_nids, nbr_edge_time) == self.stamp
+            return self._of(nbr_nids, nbr_edge_time, nbr_edge_x) == self.stamp
         except (AttributeError, IndexError, TypeError):
             return False
 

@@ -411,7 +411,7 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
         # the lists of one call carry its tag (plain lists otherwise): tgm_amd.nn.TGAT recognises hops sampled for one another by it
         from ..core.lazy import EdgeFeaturesById, SampledHops, SamplerCallTag
 
-        tag = SamplerCallTag(out_n, out_t)
+        tag = SamplerCallTag(out_n, out_t, out_x)
         if isinstance(out_x, EdgeFeaturesById):
             out_x.tag = tag
         else:

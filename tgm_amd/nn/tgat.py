@@ -227,7 +227,7 @@ class TGAT(TransientCaches, nn.Module):
         # place -- gets the row-per-slot computation.
         tag = getattr(nbr_nids, 'tag', None)
         keyed = (L > 1 and tag is not None and getattr(nbr_edge_time, 'tag', None) is tag and getattr(seed_times, 'tag', None) is tag
-                 and getattr(seed_nids, 'tag', None) is tag and getattr(nbr_edge_x, 'tag', None) is tag and tag.matches(nbr_nids, nbr_edge_time)
+                 and getattr(seed_nids, 'tag', None) is tag and getattr(nbr_edge_x, 'tag', None) is tag and tag.matches(nbr_nids, nbr_edge_time, nbr_edge_x)
                  and all(seed_nids[i].data_ptr() == nbr_nids[i - 1].data_ptr() and seed_times[i].data_ptr() == nbr_edge_time[i - 1].data_ptr()
                          and seed_nids[i].numel() == nbr_nids[i - 1].numel() == seed_times[i].numel() for i in range(1, L)))  # fmt: skip
         for i in range(L):

@@ -535,7 +535,7 @@ class CompiledPipeline:
             d_eids = slot.attrs['nbr_edge_x']
         # the per-hop lists carry the call's tag (tgm_amd.nn.TGAT recognises hops sampled for one another by it); the batch owns its
         # containers (a consumer may append to / reorder them), the tensors inside are the set's views
-        tag = SamplerCallTag(slot.attrs['nbr_nids'], slot.attrs['nbr_edge_time'])
+        tag = SamplerCallTag(slot.attrs['nbr_nids'], slot.attrs['nbr_edge_time'], slot.attrs.get('nbr_edge_x'))  # (by id: the edge ids)
         for key, v in slot.attrs.items():
             if type(v) is list:
                 d[key] = SampledHops(v, tag) if key in _TAGGED else (list(v) if self._safe else v)

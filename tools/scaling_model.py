@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Modelled multi-GPU scaling from ONE GPU: run the slowest rank's exact step of a W-rank job (bench.py --emulate-world W)
 for W = 1, 2, 4, 8.  There is no collective on the sampling data path, so the emulated rank misses nothing; what it cannot
-show is interference between processes on a shared host.  Writes profiles/r03_scaling_model.json (the model's inputs -- every emulated run's own numbers -- are the rows of that file).
+show is interference between processes on a shared host.  Writes profiles/r04_scaling_model.json (the model's inputs -- every emulated run's own numbers -- are the rows of that file).
 
     python tools/scaling_model.py            (on the GPU box, from the repo root)
 """
@@ -13,7 +13,9 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = {}
 CASES = (('wiki', 'weak', 'ring', []), ('comment', 'weak', 'ring', ['--steps', '200']), ('comment', 'strong', 'ring', ['--steps', '200']),
-         ('comment', 'weak', 'csr', ['--steps', '200']), ('comment', 'strong', 'csr', ['--steps', '200']))
+         ('comment', 'weak', 'csr', ['--steps', '200']), ('comment', 'strong', 'csr', ['--steps', '200']),
+         # round 4: the bs=4096 schedule itself dealt round-robin to the ranks (DGDataLoader(batch_shard=)): same batches, same sampled neighbours
+         ('comment', 'batch', 'csr', ['--steps', '200']), ('wiki', 'batch', 'csr', []))
 for workload, scaling, mode, extra in CASES:
     rows = []
     for W in (1, 2, 4, 8):
@@ -31,10 +33,10 @@ for workload, scaling, mode, extra in CASES:
     base = rows[0].get('ms_per_step')
     for r in rows:
         if 'ms_per_step' in r and base:
-            # weak: per-rank work fixed -> efficiency = t1 / tW, speed-up = W * efficiency; strong: total work fixed -> speed-up = t1 / tW
-            r['modelled_speedup'] = (r['world'] * base / r['ms_per_step']) if scaling == 'weak' else base / r['ms_per_step']
+            # weak / batch: per-rank work fixed (batch: W ranks work through the SAME schedule W batches at a time) -> efficiency = t1 / tW, speed-up = W * efficiency; strong: total work fixed -> speed-up = t1 / tW
+            r['modelled_speedup'] = (r['world'] * base / r['ms_per_step']) if scaling in ('weak', 'batch') else base / r['ms_per_step']
             r['modelled_efficiency'] = r['modelled_speedup'] / r['world']
     out[f'{workload}_{scaling}_{mode}'] = rows
     print(workload, scaling, mode, json.dumps(rows), flush=True)
 json.dump({'method': 'bench.py --emulate-world W --emulate-rank W-1 on one MI355X (the last rank; all ranks do the same amount of work); '
-           'no hardware multi-GPU curve exists yet (SCALE was skipped in rounds 1-2)', 'results': out}, open(os.path.join(ROOT, 'profiles', 'r03_scaling_model.json'), 'w'), indent=1)
+           'no hardware multi-GPU curve exists yet (SCALE was skipped in rounds 1-3)', 'results': out}, open(os.path.join(ROOT, 'profiles', 'r04_scaling_model.json'), 'w'), indent=1)
