@@ -68,6 +68,9 @@ def parse_args():
     p.add_argument('--seed', type=int, default=1337)
     p.add_argument('--emulate-world', type=int, default=0, help='single process: run the step of rank --emulate-rank of a W-rank job (there is no data-path collective, so nothing is missing from it); modelling aid, n_gpus stays 1')
     p.add_argument('--emulate-rank', type=int, default=0)
+    p.add_argument('--extras', default='auto', choices=['auto', 'on', 'off'],
+                   help="the blocks next to the contract's fields -- the same launch with full feature writes / an output pool of two, the "
+                   "HBM-bound comment-shaped lookup (roofline_hbm_bound), the TGAT aggregation block: 'auto' = at N = 1 on the wiki workload")
     p.add_argument('--no-default-path', action='store_true', help="skip the second timed region (the same steps through DGDataLoader / RecencyNeighborHook with their DEFAULT arguments)")
     return p.parse_args()
 
@@ -169,10 +172,10 @@ def profile_key(args, bs, num_nbrs, steps, world=1):
 
 
 def committed_profile(key):
-    """(pmc json, its path) of the committed round-3 profile taken with exactly these arguments (tools/gpu_profile_r3.sh), or (None, None)."""
+    """(pmc json, its path) of the newest committed profile taken with exactly these arguments (tools/gpu_profile_r4.sh), or (None, None)."""
     import glob
 
-    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r03_*_pmc.json'))):
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_*_pmc.json')), reverse=True):  # the newest round's first
         try:
             with open(path) as f:
                 p = json.load(f)
@@ -185,7 +188,7 @@ def committed_profile(key):
 
 def pmc_traffic(key):
     """HBM-side bytes per TIMED launch of the dominant kernel from the committed PMC passes of this very command (rocprofv3 --pmc
-    FETCH_SIZE / WRITE_SIZE, separate runs, averaged over the timed launches only: tools/gpu_profile_r3.sh).  FETCH_SIZE is doubled:
+    FETCH_SIZE / WRITE_SIZE, separate runs, averaged over the timed launches only: tools/gpu_profile_r4.sh).  FETCH_SIZE is doubled:
     the gfx950 correction of MI355X_MICROARCH.md for wide coalesced reads.  None when no profile of these arguments exists."""
     p, path = committed_profile(key)
     if p is None:
@@ -198,7 +201,7 @@ def pmc_traffic(key):
 
 def rocprof_kernel_us(key):
     """Average duration of the dominant kernel over the TIMED launches in the committed rocprofv3 --kernel-trace --stats summary taken
-    with exactly these arguments (profiles/r03_<tag>_rocprof_summary.md next to the matching r03_<tag>_pmc.json).  Cross-check of
+    with exactly these arguments (profiles/r0N_<tag>_rocprof_summary.md next to the matching r0N_<tag>_pmc.json).  Cross-check of
     the figure measured live (the dispatch's own begin / end timestamps through hipExtLaunchKernelGGL); a separate run."""
     p, path = committed_profile(key)
     if p is None:
@@ -214,6 +217,165 @@ def rocprof_kernel_us(key):
             except (ValueError, IndexError):
                 return None
     return None
+
+
+def slots_of_shape(edges, num_nbrs):
+    total, S = 0, 3 * edges
+    for k in num_nbrs:
+        total += S * k
+        S *= k
+    return total
+
+
+def launch_stats(log, D):
+    """Per-launch averages over the timed launches of the dominant kernel (hook.profile_log): duration, shape, and the VALID-AWARE
+    algorithmic bytes: every slot's id 4 + ts 8 is written, a feature row (4D) for every slot that has to
+    change; only valid slots read their 16-byte record and 4D-byte feature row (pads are zeros written without reading anything);
+    68 B of index traffic per seed (+ 8 B of valid-count read / write per row with delta writes).  Also SURVEY 8(d)'s figure taken
+    LITERALLY -- (28 + 8D) per slot + 68 per seed, pads charged a record + feature read they never make."""
+    ker_ms = [e[0].elapsed_ms() for e in log]
+    avg_ms = sum(ker_ms) / len(ker_ms)
+    # the timed launch covers one hop, or hop 0 + hop 1 when tgmx_recency_step runs them as one launch
+    seeds_l = sum(sum(seeds for seeds, _ in e[1]) for e in log) / len(log)
+    total_slots = sum(sum(seeds * k for seeds, k in e[1]) for e in log) / len(log)
+    valid = sum(int(e[2].sum().item()) for e in log) / len(log)
+    delta = all(e[3] is not None for e in log)
+    # feature rows written per launch: every slot, or -- pooled outputs with delta writes (tgmx_recency_step_t.out_valid) -- the
+    # slots from the first one that changes on, max(valid before, valid now) per row, measured on the timed launches
+    feat_slots = (sum(int(e[3].sum().item()) for e in log) / len(log)) if delta else total_slots
+    algo = total_slots * 12 + feat_slots * 4 * D + valid * (16 + 4 * D) + seeds_l * (68 + (8 if delta else 0))
+    full = total_slots * (12 + 4 * D) + valid * (16 + 4 * D) + seeds_l * 68
+    literal = total_slots * (28 + 8 * D) + seeds_l * 68
+    return dict(avg_ms=avg_ms, ker_ms=ker_ms, seeds=seeds_l, slots=total_slots, valid=valid, delta=delta, feat_slots=feat_slots, algo_bytes=algo,
+                full_write_bytes=full, literal_8d_bytes=literal, shape=log[0][1])
+
+
+def probe_variant(stream, bs, num_nbrs, mode, device, first_timed, n_steps, pool, env=None):
+    """The dominant launch of the SAME timed batches under another configuration (full feature writes, an output pool of two, another
+    stream shape ...): a fresh pipeline replays the stream up to the timed region untimed, then `n_steps` steps, ~8 of them timed."""
+    from tgm_amd._native import KernelTimer
+
+    old = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})
+    try:
+        dg, hm, hook, loader = build_pipeline(stream, 0, 1, bs, num_nbrs, mode, device, pool=pool, validate='deferred')
+        starts = loader._starts
+        first_timed = min(first_timed, len(starts) - n_steps - 1)
+        with hm.activate('bench'):
+            warm = min(20, first_timed)
+            for i in range(first_timed - warm):
+                loader(starts[i])
+            every = max(1, n_steps // 8)
+            hook.profile_hop, hook.profile_every, hook.profile_log = len(num_nbrs) - 1, max(1, warm // 2), []
+            hook.profile_pool = [KernelTimer() for _ in range(4)]
+            for i in range(first_timed - warm, first_timed):
+                loader(starts[i])
+            hook.check()
+            hook.profile_every, hook.profile_log, hook._calls = every, [], 0
+            hook.profile_pool = [KernelTimer() for _ in range(n_steps // every + 1)]
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(first_timed, first_timed + n_steps):
+                loader(starts[i])
+            torch.cuda.synchronize()
+            wall = time.perf_counter() - t0
+            hook.check()
+            st = launch_stats(hook.profile_log, stream.edge_dim)
+            hook.profile_hop = None
+        st['us_per_step'] = 1e6 * wall / n_steps
+        st['first_timed'] = first_timed
+        return st
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def tgat_gflop_folded(S0, num_nbrs, node_dim=1, edge_dim=172, time_dim=100, embed_dim=172, heads=2):
+    """Multiply-adds x 2 of the FOLDED inference forward at the reference example's widths: per row of layer j
+    d H C (folded queries) + 2 k H C (scores + weighted mean) + O C (W_V, all heads) + O^2 (W_O) + emb (O + d0) (fc1) + emb^2 (fc2)."""
+    L = len(num_nbrs)
+    rows = [S0]
+    for k in num_nbrs:
+        rows.append(rows[-1] * k)
+    total = 0.0
+    for j in range(1, L + 1):
+        d = node_dim if j == 1 else embed_dim
+        C = d + edge_dim + time_dim
+        O = d + time_dim
+        O += (-O) % heads
+        R = sum(rows[: L - j + 1])
+        k = num_nbrs[j - 1]
+        total += R * (d * heads * C + 2 * k * heads * C + O * C + O * O + embed_dim * (O + node_dim) + embed_dim * embed_dim)
+    return 2.0 * total / 1e9
+
+
+def committed_mfma():
+    """MFMA-busy fractions of the forward from the committed counter pass (profiles/r04_tgat_mfma_pmc.json: rocprofv3 --pmc
+    SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE over tools/bench_tgat.py, a separate run), or Nones."""
+    path = os.path.join(ROOT, 'profiles', 'r04_tgat_mfma_pmc.json')
+    try:
+        with open(path) as f:
+            p = json.load(f)
+        return p.get('mfma_busy_frac_forward'), p.get('mfma_busy_frac_tail_kernel'), os.path.relpath(path, ROOT)
+    except Exception:
+        return None, None, None
+
+
+def aggregation_block(stream, bs, num_nbrs, device, n_batches, first):
+    """The other half of BASELINE.json's path: TGAT eval forward (reference example widths: node 1 / edge 172 / time 100 / embed 172,
+    2 heads, one layer per hop) on the sampler's outputs at the headline batch shape -- RecencyNeighborHook(edge_features='by_id')
+    feeding tgm_amd.nn.TGAT, random-init weights.  forward_us: median of 5 x 20 back-to-back forwards on one batch (HIP events);
+    sampler_plus_forward_us: wall clock per batch over `n_batches` batches of loader + forward, synchronized at the end."""
+    from tgm_amd.nn import TGAT
+
+    dg, hm, hook, loader = build_pipeline(stream, 0, 1, bs, num_nbrs, 'ring', device, pool=1, edge_features='by_id')
+    torch.manual_seed(0)
+    d0 = int(stream.node_x.shape[1])
+    enc = TGAT(node_dim=d0, edge_dim=stream.edge_dim, time_dim=100, embed_dim=172, num_layers=len(num_nbrs)).to(device).eval()
+    starts = loader._starts
+    node_x = dg.static_node_x
+    first = max(1, min(first, len(starts) - n_batches - 1))
+    with hm.activate('bench'), torch.no_grad():
+        for i in range(first):
+            b = loader(starts[i])
+        for _ in range(10):  # the first forwards pay one-off costs (weight fold, code-object load)
+            enc(node_x, b.seed_nids, b.seed_times, b.nbr_nids, b.nbr_edge_x, b.nbr_edge_time)
+        torch.cuda.synchronize()
+        reps = []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                enc(node_x, b.seed_nids, b.seed_times, b.nbr_nids, b.nbr_edge_x, b.nbr_edge_time)
+            e1.record()
+            torch.cuda.synchronize()
+            reps.append(e0.elapsed_time(e1) / 20 * 1000)
+        S0 = int(b.seed_nids[0].numel())
+        t0 = time.perf_counter()
+        for i in range(first, first + n_batches):
+            b = loader(starts[i])
+            enc(node_x, b.seed_nids, b.seed_times, b.nbr_nids, b.nbr_edge_x, b.nbr_edge_time)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        hook.check()
+    fwd = sorted(reps)[len(reps) // 2]
+    gflop = tgat_gflop_folded(S0, num_nbrs, d0, stream.edge_dim)
+    busy_fwd, busy_tail, src = committed_mfma()
+    return {
+        'what': f"TGAT eval forward on the sampler's outputs (edge features by id), example widths node {d0} / edge {stream.edge_dim} / time 100 / embed 172, "
+                f'2 heads, {len(num_nbrs)} layers, {S0} seeds, k={num_nbrs}; random-init weights; f32 (exact-fp32 MFMA for the dense contractions)',
+        'forward_us': fwd, 'forward_us_min_max': [min(reps), max(reps)],
+        'forward_repeats': '5 x 20 back-to-back forwards on one batch, HIP events on the launch stream; median',
+        'sampler_plus_forward_us': 1e6 * (t1 - t0) / n_batches, 'batches': n_batches,
+        'gflop_folded': gflop, 'tflops_folded': gflop / fwd * 1e3, 'mfma_peak_tflops_fp32': 157.3,
+        'mfma_busy_frac': busy_fwd, 'mfma_busy_frac_tail_kernel': busy_tail,
+        'source': 'forward_us / sampler_plus_forward_us: this process; mfma_busy_frac: '
+                  + (f'{src} (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE over tools/bench_tgat.py, a separate run: busy / (32 x cycles) '
+                     'over the whole forward, and over the one-kernel tail of layer 1 alone)' if src else 'no committed counter pass'),
+    }
 
 
 def main():
@@ -379,24 +541,11 @@ def main():
     hook.profile_hop = None
     if not log:
         raise SystemExit('bench.py: no launch of the dominant kernel was timed (steps too small for --profile-every?)')
-    ker_ms = [e[0].elapsed_ms() for e in log]
-    avg_ms = sum(ker_ms) / len(ker_ms)
-    # the timed launch covers one hop, or hop 0 + hop 1 when tgmx_recency_step runs them as one launch; average the
-    # per-launch figures over the timed launches (shapes only differ for the ragged last batch of an epoch)
-    seeds_l = sum(sum(seeds for seeds, _ in e[1]) for e in log) / len(log)
-    total_slots = sum(sum(seeds * k for seeds, k in e[1]) for e in log) / len(log)
-    valid = sum(int(e[2].sum().item()) for e in log) / len(log)
-    delta = all(e[3] is not None for e in log)
-    # feature rows written per launch: every slot, or -- pooled outputs with delta writes (tgmx_recency_step_t.out_valid) -- the
-    # slots from the first one that changes on, max(valid before, valid now) per row, measured on the timed launches
-    feat_slots = (sum(int(e[3].sum().item()) for e in log) / len(log)) if delta else total_slots
-    # algorithmic bytes per launch, VALID-AWARE: every slot's id 4 + ts 8 is written, a feature row (4D) for
-    # every slot that has to change; only valid slots read their 16-byte record and 4D-byte feature row (pads are zeros written
-    # without reading anything -- charging SURVEY 8(d)'s 28 + 8D per slot to pad slots too would report more than the HBM peak);
-    # 68 B of index traffic per seed (+ 8 B of valid-count read / write per row with delta writes)
-    algo_bytes = total_slots * 12 + feat_slots * 4 * D + valid * (16 + 4 * D) + seeds_l * (68 + (8 if delta else 0))
+    ls = launch_stats(log, D)
+    avg_ms, ker_ms, seeds_l, total_slots, valid, delta, feat_slots, algo_bytes = (ls['avg_ms'], ls['ker_ms'], ls['seeds'], ls['slots'], ls['valid'],
+                                                                                   ls['delta'], ls['feat_slots'], ls['algo_bytes'])
     achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
-    shape = log[0][1]
+    shape = ls['shape']
     fused = len(shape) > 1
     kernel_name = ('recency_lookup_fused01_kernel (hop 0 + hop 1 in one launch: ' if fused else f'recency_lookup_kernel (hop {last_hop}: ') + \
         ' + '.join(f'{seeds} seeds x k={k}' for seeds, k in shape) + ')'
@@ -456,6 +605,54 @@ def main():
             if delta else 'valid-aware: slots x (12 + 4D) written + valid slots x (16 + 4D) read + 68 B per seed',
         },
     }
+    # ---- what the headline fraction does NOT say, measured in this process on the same timed batches (N = 1, wiki) --------------
+    extras = args.extras == 'on' or (args.extras == 'auto' and real_world == 1 and not args.emulate_world and args.workload == 'wiki' and args.mode == 'ring'
+                                     and args.pool == 1)
+    rl = out['roofline']
+    rl['literal_8d_bytes'] = ls['literal_8d_bytes']
+    rl['literal_8d_frac'] = ls['literal_8d_bytes'] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+    rl['literal_8d_note'] = ('SURVEY 8(d) read literally: (28 + 8D) B per output slot + 68 B per seed.  It charges every PAD slot a 16-byte record read, a '
+                             '4D-byte feature-row read and a feature-row write; pad slots (1 - valid_slot_fraction of them) read nothing, and with delta '
+                             'writes most of them are not rewritten either, so this figure exceeds what the launch moves (traffic) and can exceed the HBM peak')
+    rl['cache_note'] = ('wiki-shaped working set: ring_x 127 MB read + ONE 177 MB output set rewritten every batch (pool of one) -- mostly resident in the 256 MiB '
+                        'Infinity Cache, and FETCH_SIZE / WRITE_SIZE count L2<->fabric bytes, not DRAM bytes: the fraction above is MALL-assisted.  '
+                        'roofline_hbm_bound (comment-shaped, working set >> MALL) is the HBM-honest figure; variants.pool2 / full_write show this launch '
+                        'without the cache residency / without delta writes')
+    if extras:
+        n_probe = 64
+        fw = probe_variant(stream, bs, num_nbrs, args.mode, device, first_timed, n_probe, pool=1, env={'TGMX_DELTA_WRITES': '0'})
+        p2 = probe_variant(stream, bs, num_nbrs, args.mode, device, first_timed, n_probe, pool=2)
+        rl['variants'] = {
+            'full_write': {'avg_kernel_ms': fw['avg_ms'], 'algorithmic_bytes_per_launch': fw['algo_bytes'], 'frac': fw['algo_bytes'] / (fw['avg_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           'us_per_step': fw['us_per_step'], 'launches_timed': len(fw['ker_ms']),
+                           'what': 'TGMX_DELTA_WRITES=0, pool of one: every slot of every feature row rewritten (slots x (12 + 4D) + valid x (16 + 4D) + 68 B per seed)'},
+            'pool2': {'avg_kernel_ms': p2['avg_ms'], 'algorithmic_bytes_per_launch': p2['algo_bytes'], 'frac': p2['algo_bytes'] / (p2['avg_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                      'us_per_step': p2['us_per_step'], 'launches_timed': len(p2['ker_ms']),
+                      'what': 'output_pool=2, delta writes: two 177 MB output sets alternate, so a set has left the Infinity Cache when it is written again'},
+        }
+        # the HBM-bound shape: comment-shaped stream (N = 1 M, E = 44 M, D = 16), bs 4096, k = [20, 20] -- working set >> 256 MiB MALL
+        t_c = time.perf_counter()
+        cs = make_stream('comment', seed=args.seed, device=device)
+        cbs, cnb = DEFAULTS['comment']
+        n_cb = (cs.num_edges + cbs - 1) // cbs
+        hb = {}
+        for cmode in ('ring', 'csr'):
+            st_c = probe_variant(cs, cbs, cnb, cmode, device, n_cb // 2, 48, pool=1)
+            hb[cmode] = {'kernel': 'lookup_tile_kernel (hop 1: %d seeds x k=%d)' % (st_c['shape'][-1][0], st_c['shape'][-1][1]),
+                         'achieved': st_c['algo_bytes'] / (st_c['avg_ms'] * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': st_c['algo_bytes'] / (st_c['avg_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 'avg_kernel_ms': st_c['avg_ms'],
+                         'min_max_kernel_ms': [min(st_c['ker_ms']), max(st_c['ker_ms'])], 'launches_timed': len(st_c['ker_ms']),
+                         'algorithmic_bytes_per_launch': st_c['algo_bytes'], 'valid_slot_fraction': st_c['valid'] / max(st_c['slots'], 1),
+                         'us_per_step': st_c['us_per_step'], 'sampled_edges_per_s': slots_of_shape(cbs, cnb) / (st_c['us_per_step'] * 1e-6),
+                         'timed_batches': f"{st_c['first_timed']}..{st_c['first_timed'] + 47} of {n_cb}"}
+        del cs
+        torch.cuda.empty_cache()
+        out['roofline_hbm_bound'] = {'workload': 'tgbl-comment-shaped synthetic stream: N=1000000, E=44000000, D=16; bs=4096, k=[20, 20], pool of one, delta writes; '
+                                                 'rings (mode=ring) and the static index (mode=csr); the narrow-row lookup of hop 1, same byte model as roofline',
+                                     'bound': 'hbm', **{('static_index' if m == 'csr' else 'rings'): v for m, v in hb.items()},
+                                     'seconds_spent': time.perf_counter() - t_c,
+                                     'traffic': 'profiles/r04_comment_{ring,csr}_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of `bench.py --workload comment`, separate runs)'}
+        out['aggregation'] = aggregation_block(stream, bs, num_nbrs, device, 100, first_timed)
     if rccl is not None:
         out['rccl'] = rccl
     out['valid_edges_per_s'] = out['value'] * out['roofline']['valid_slot_fraction']  # sampled slots that hold a neighbor (pads excluded)

@@ -83,6 +83,7 @@ def test_compact_rows_equal_row_per_slot_at_the_headline_dims(mode, features):
     dg, hm, loader = _pipeline(st, [20, 20], mode, features)
     torch.manual_seed(0)
     enc = TGAT(node_dim=1, edge_dim=172, time_dim=100, embed_dim=172, num_layers=2).to(DEV).eval()
+    enc.compact_rows = True
     with torch.no_grad():
         for p in enc.parameters():
             p.add_(0.03 * torch.randn_like(p))
@@ -113,6 +114,7 @@ def test_compact_rows_three_layers_and_narrow_k():
     dg, hm, loader = _pipeline(st, [5, 5, 5], 'ring', 'dense', bs=150)
     torch.manual_seed(1)
     enc = TGAT(node_dim=8, edge_dim=12, time_dim=16, embed_dim=32, num_layers=3).to(DEV).eval()
+    enc.compact_rows = True
     node_x = dg.static_node_x
     with hm.activate('k'), torch.no_grad():
         for n, b in enumerate(loader):
@@ -135,6 +137,7 @@ def test_untagged_or_modified_inputs_get_the_row_per_slot_computation():
     dg, hm, loader = _pipeline(st, [4, 4], 'ring', 'dense', bs=100, pool=0)
     torch.manual_seed(2)
     enc = TGAT(node_dim=1, edge_dim=8, time_dim=8, embed_dim=16, num_layers=2).to(DEV).eval()
+    enc.compact_rows = True
     node_x = dg.static_node_x
     with hm.activate('k'), torch.no_grad():
         for n, b in enumerate(loader):

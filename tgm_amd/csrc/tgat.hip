@@ -1097,6 +1097,7 @@ struct AttnArgs {
   const int32_t* seg_nidx[TGMX_TGAT_MAX_LAYERS];
   const float* seg_ntab[TGMX_TGAT_MAX_LAYERS];
   long long seg_npad[TGMX_TGAT_MAX_LAYERS];
+  int full_span;              // != 0: the register kernel runs every row through its all-slots body (A/B knob TGMX_ATTN_SPAN=0)
 };
 
 // the level (segment) of row r: wave-uniform, so this is scalar code
@@ -1170,6 +1171,68 @@ __device__ __forceinline__ float reduce_scatter64(float (&P)[64], int lane) {
   reduce_scatter_step<4>(P, lane);
   reduce_scatter_step<2>(P, lane);
   reduce_scatter_step<1>(P, lane);
+  return P[0];
+}
+
+// The same sums for N <= 64 live entries (N a power of two, P[0 .. N)): the steps whose stride is >= N cannot scatter (there is nothing
+// left to split), so both partners add and keep all N entries; from stride N / 2 down it is the reduce-scatter above.  Every entry
+// is summed over the 64 lanes in the order xor 32, 16, 8, 4, 2, 1 -- a + b == b + a, so WHICH lane accumulates does not matter and the
+// sums are bit-identical to reduce_scatter64's.  Afterwards lane L holds entry L mod N.
+template <int HALF, int N>
+__device__ __forceinline__ void all_reduce_step(float (&P)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    if constexpr (HALF == 32) {
+      const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(P[i]), __float_as_uint(P[i]), false, false);
+      P[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    } else if constexpr (HALF == 16) {
+      const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(P[i]), __float_as_uint(P[i]), false, false);
+      P[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    } else {
+      P[i] = P[i] + __shfl_xor(P[i], HALF);
+    }
+  }
+}
+template <int HALF, int N>
+__device__ __forceinline__ void scatter_step_n(float (&P)[N], int lane) {
+  static_assert(2 * HALF <= N, "a scatter step halves 2 * HALF live entries");
+  if constexpr (HALF == 32) {
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(P[i]), __float_as_uint(P[i + 32]), false, false);
+      P[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+  } else if constexpr (HALF == 16) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(P[i]), __float_as_uint(P[i + 16]), false, false);
+      P[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+  } else {
+    const bool upper = (lane & HALF) != 0;
+#pragma unroll
+    for (int i = 0; i < HALF; ++i) {
+      const float send = upper ? P[i] : P[i + HALF];
+      const float recv = __shfl_xor(send, HALF);
+      const float keep = upper ? P[i + HALF] : P[i];
+      P[i] = keep + recv;
+    }
+  }
+}
+template <int HALF, int N>
+__device__ __forceinline__ void reduce_step_n(float (&P)[N], int lane) {
+  if constexpr (HALF >= N) all_reduce_step<HALF, N>(P);
+  else scatter_step_n<HALF, N>(P, lane);
+}
+template <int N>
+__device__ __forceinline__ float reduce_scatter_n(float (&P)[N], int lane) {
+  static_assert(N == 4 || N == 8 || N == 16 || N == 32 || N == 64, "N must be a power of two in [4, 64]");
+  reduce_step_n<32, N>(P, lane);
+  reduce_step_n<16, N>(P, lane);
+  reduce_step_n<8, N>(P, lane);
+  reduce_step_n<4, N>(P, lane);
+  reduce_step_n<2, N>(P, lane);
+  reduce_step_n<1, N>(P, lane);
   return P[0];
 }
 
@@ -1416,171 +1479,201 @@ __global__ __launch_bounds__(256) void tgat_attn_reduce_reg_kernel(const AttnArg
     }
   }
 
-  // ---- the row's features, straight into registers (all loads independent) ----
-  float4 ze[G];
-#pragma unroll
-  for (int s = 0; s < G; ++s) {
-    const int sl = s < k ? s : k - 1;
-    if (lv.eid) {  // wave-uniform: the slot's row of the resident store (scalar base + lane offset), zeros for a pad slot
-      const int e = __builtin_amdgcn_readlane(my_eid, sl);
-      ze[s] = (e_on && e >= 0) ? table4[(long long)e * D4 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
-    } else {
-      ze[s] = e_on ? ex4[sl * D4 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  }
-  float4 zn[NBV ? G : 1];
-  float zs[NBV ? 1 : G];
-  if (NBV) {
-#pragma unroll
-    for (int s = 0; s < G; ++s) {
-      const int sl = s < k ? s : k - 1;
-      zn[NBV ? s : 0] = lane < d4 ? reinterpret_cast<const float4*>(nrow(sl))[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  } else {
-#pragma unroll
-    for (int s = 0; s < G; ++s) {
-      const int sl = s < k ? s : k - 1;
-      zs[NBV ? 0 : s] = lane < d ? nrow(sl)[lane] : 0.f;
-    }
-  }
-  // folded query columns of this lane
-  float4 qe[H], qn4[H];
-  float qn[H], qt0[H], qt1[H];
-  const bool t0_on = lane < T, t1_on = lane + kWave < T;
-#pragma unroll
-  for (int h = 0; h < H; ++h) {
-    const float* qh = q + h * a.Cs;
-    qe[h] = e_on ? make_float4(qh[d + 4 * lane], qh[d + 4 * lane + 1], qh[d + 4 * lane + 2], qh[d + 4 * lane + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
-    if (NBV) qn4[h] = lane < d4 ? make_float4(qh[4 * lane], qh[4 * lane + 1], qh[4 * lane + 2], qh[4 * lane + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
-    else qn[h] = lane < d ? qh[lane] : 0.f;
-    qt0[h] = t0_on ? qh[d + D + lane] : 0.f;
-    qt1[h] = t1_on ? qh[d + D + lane + kWave] : 0.f;
-  }
-  const float w0 = t0_on ? a.tw[lane] : 0.f, b0 = t0_on ? a.tb[lane] : 0.f;
-  const float w1 = t1_on ? a.tw[lane + kWave] : 0.f, b1 = t1_on ? a.tb[lane + kWave] : 0.f;
-
-  // ---- Time2Vec columns + partial scores ----
-  float tz0[G], tz1[G], P[64];
-#pragma unroll
-  for (int j = 0; j < 64; ++j) P[j] = 0.f;
-  // rows whose k slots all carry the same time delta (every padded seed of a deeper hop: nbr_t = 0 in all slots) need
-  // ONE Time2Vec evaluation per column, not k -- identical arithmetic, ~3/4 of the layer-1 rows at the headline shape
-  const bool same_dt = __all(lane >= k || my_dt == lane_bcast(my_dt, 0));
-  // The cosine's reduction path (float for |x| < 8e6, double beyond) is chosen ONCE per row, and the evaluations run
-  // as straight-line code: with the choice (a wave vote and a branch) inside every evaluation the 40 evaluations of a
-  // row cost 23 of the kernel's 73 us.  Lanes past T carry w = b = 0: their cos(0) meets a zero query weight below and
-  // is never stored.
-  // A masked slot of a row that has a valid one gets attention weight exactly 0: its Time2Vec columns never reach the output, so
-  // they are not evaluated (zeros stand in).  63 % of the slots are pads at the headline shape and the cosines are this kernel's
-  // largest single cost.  A row with NO valid slot attends uniformly over all of them (attention.py:114-118): everything is needed.
+  // ---- the slots that matter ----
+  // A masked slot of a row that has a valid one gets attention weight exactly 0 (exp(-1e10 - max) == 0): it adds 0 to the softmax's
+  // sum and fma(0, z, acc) == acc to the weighted mean, so the slots LEFT of the row's first valid one need not be read, scored or
+  // summed at all.  The sampler right-aligns a window (pads on the left) and at the headline shape a real row holds ~7 of 20: the body
+  // below is instantiated for the last GS = 4, 8, 12, 16 and all G slots and the row takes the smallest that covers its span.  Scores
+  // travel back to the lane of their ORIGINAL slot before the softmax, every sum keeps its order: bit-identical to the all-slots body.
+  // A row with NO valid slot attends uniformly over all of them (attention.py:114-118): all G.
   const unsigned long long okm = __ballot(my_ok);
-  const unsigned long long need = okm ? okm : ~0ull;
-  bool small = true;
+  const int span = okm ? k - (__ffsll((long long)okm) - 1) : k;  // slots from the first valid one to the end
+  // rows whose k slots all carry the same time delta need ONE Time2Vec evaluation per column, not k -- identical arithmetic
+  const bool same_dt = __all(lane >= k || my_dt == lane_bcast(my_dt, 0));
+  const bool e_on2 = e_on;
+  auto body = [&](auto gsc) __attribute__((always_inline)) {
+    constexpr int GS = decltype(gsc)::value;
+    constexpr int NV = GS * H, NVp = NV <= 4 ? 4 : NV <= 8 ? 8 : NV <= 16 ? 16 : NV <= 32 ? 32 : 64;
+    const int s0 = k > GS ? k - GS : 0;  // first slot this body looks at (wave-uniform)
+    // ---- the row's features, straight into registers (all loads independent) ----
+    float4 ze[GS];
 #pragma unroll
-  for (int s = 0; s < G; ++s) {
-    const float dt = lane_bcast(my_dt, s);
-    small = small && fabsf(__fmaf_rn(dt, w0, b0)) < kCosSmallLimit && fabsf(__fmaf_rn(dt, w1, b1)) < kCosSmallLimit;
-  }
-  const bool row_small = __all(small);
-  if (same_dt) {
-    const float dt = lane_bcast(my_dt, 0);
-    const float c0 = row_small ? cos_t2v_small(__fmaf_rn(dt, w0, b0)) : cos_t2v_big(__fmaf_rn(dt, w0, b0));
-    const float c1 = row_small ? cos_t2v_small(__fmaf_rn(dt, w1, b1)) : cos_t2v_big(__fmaf_rn(dt, w1, b1));
-#pragma unroll
-    for (int s = 0; s < G; ++s) {
-      tz0[s] = c0;
-      tz1[s] = c1;
-    }
-  } else if (row_small) {
-#pragma unroll
-    for (int s = 0; s < G; ++s) {
-      tz0[s] = tz1[s] = 0.f;
-      if ((need >> s) & 1) {  // wave-uniform
-        const float dt = lane_bcast(my_dt, s);
-        tz0[s] = cos_t2v_small(__fmaf_rn(dt, w0, b0));
-        tz1[s] = cos_t2v_small(__fmaf_rn(dt, w1, b1));
+    for (int s = 0; s < GS; ++s) {
+      const int sl = s0 + s < k ? s0 + s : k - 1;
+      if (lv.eid) {  // wave-uniform: the slot's row of the resident store (scalar base + lane offset), zeros for a pad slot
+        const int e = __builtin_amdgcn_readlane(my_eid, sl);
+        ze[s] = (e_on2 && e >= 0) ? table4[(long long)e * D4 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        ze[s] = e_on2 ? ex4[sl * D4 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
-  } else {
+    float4 zn[NBV ? GS : 1];
+    float zs[NBV ? 1 : GS];
+    if (NBV) {
 #pragma unroll
-    for (int s = 0; s < G; ++s) {
-      tz0[s] = tz1[s] = 0.f;
-      if ((need >> s) & 1) {
-        const float dt = lane_bcast(my_dt, s);
-        tz0[s] = cos_t2v_big(__fmaf_rn(dt, w0, b0));
-        tz1[s] = cos_t2v_big(__fmaf_rn(dt, w1, b1));
+      for (int s = 0; s < GS; ++s) {
+        const int sl = s0 + s < k ? s0 + s : k - 1;
+        zn[NBV ? s : 0] = lane < d4 ? reinterpret_cast<const float4*>(nrow(sl))[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < GS; ++s) {
+        const int sl = s0 + s < k ? s0 + s : k - 1;
+        zs[NBV ? 0 : s] = lane < d ? nrow(sl)[lane] : 0.f;
       }
     }
-  }
-#pragma unroll
-  for (int s = 0; s < G; ++s) {
+    // folded query columns of this lane
+    float4 qe[H], qn4[H];
+    float qn[H], qt0[H], qt1[H];
+    const bool t0_on = lane < T, t1_on = lane + kWave < T;
 #pragma unroll
     for (int h = 0; h < H; ++h) {
-      float p = qe[h].x * ze[s].x;
-      p = __fmaf_rn(qe[h].y, ze[s].y, p);
-      p = __fmaf_rn(qe[h].z, ze[s].z, p);
-      p = __fmaf_rn(qe[h].w, ze[s].w, p);
-      if (NBV) {
-        p = __fmaf_rn(qn4[h].x, zn[NBV ? s : 0].x, p);
-        p = __fmaf_rn(qn4[h].y, zn[NBV ? s : 0].y, p);
-        p = __fmaf_rn(qn4[h].z, zn[NBV ? s : 0].z, p);
-        p = __fmaf_rn(qn4[h].w, zn[NBV ? s : 0].w, p);
-      } else {
-        p = __fmaf_rn(qn[h], zs[NBV ? 0 : s], p);
-      }
-      p = __fmaf_rn(qt0[h], tz0[s], p);
-      p = __fmaf_rn(qt1[h], tz1[s], p);
-      P[s * H + h] = p;
+      const float* qh = q + h * a.Cs;
+      qe[h] = e_on2 ? make_float4(qh[d + 4 * lane], qh[d + 4 * lane + 1], qh[d + 4 * lane + 2], qh[d + 4 * lane + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (NBV) qn4[h] = lane < d4 ? make_float4(qh[4 * lane], qh[4 * lane + 1], qh[4 * lane + 2], qh[4 * lane + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      else qn[h] = lane < d ? qh[lane] : 0.f;
+      qt0[h] = t0_on ? qh[d + D + lane] : 0.f;
+      qt1[h] = t1_on ? qh[d + D + lane + kWave] : 0.f;
     }
-  }
-  float sc = reduce_scatter64(P, lane);  // lane j = s*H + h holds score(s, h)
+    const float w0 = t0_on ? a.tw[lane] : 0.f, b0 = t0_on ? a.tb[lane] : 0.f;
+    const float w1 = t1_on ? a.tw[lane + kWave] : 0.f, b1 = t1_on ? a.tb[lane + kWave] : 0.f;
 
-  // ---- masked softmax over the slots of each head: lanes j, j +- H, ... share a head ----
-  const int js = lane / H;
-  const bool live = js < k;
-  const bool ok = __shfl(my_ok ? 1 : 0, js < k ? js : 0) != 0;
-  sc = live ? (ok ? sc * a.scale : -1e10f) : -__builtin_inff();
-  float mx = sc;
+    // ---- Time2Vec columns + partial scores ----
+    float tz0[GS], tz1[GS], P[NVp];
 #pragma unroll
-  for (int o = H; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-  float ev = live ? expf(sc - mx) : 0.f;
-  float sum = ev;
-#pragma unroll
-  for (int o = H; o < 64; o <<= 1) sum += __shfl_xor(sum, o);
-  float A = ev / sum;
-  if (a.probs && live) a.probs[r * (long long)H * k + (lane - js * H) * k + js] = A;
-  if (a.drop.thresh && live) A *= dropout_scale(a.drop, (unsigned long long)(a.drop_row0 + r) * (H * k) + (lane - js * H) * k + js);
-
-  // ---- zbar[h] = sum_s A[h][s] z[s], from registers ----
-  float* __restrict__ zb = a.zbar + r * (long long)H * a.Cs;
-#pragma unroll
-  for (int h = 0; h < H; ++h) {
-    float4 ae = make_float4(0.f, 0.f, 0.f, 0.f), an4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float an = 0.f, at0 = 0.f, at1 = 0.f;
+    for (int j = 0; j < NVp; ++j) P[j] = 0.f;
+    // The cosine's reduction path (float for |x| < 8e6, double beyond) is chosen ONCE per row (over ALL k slots, whatever GS: the
+    // choice must not depend on the body), and the evaluations run as straight-line code: with the choice (a wave vote and a branch)
+    // inside every evaluation the 40 evaluations of a row cost 23 of the kernel's 73 us.  Lanes past T carry w = b = 0: their
+    // cos(0) meets a zero query weight below and is never stored.
+    // A masked slot of a row that has a valid one: its Time2Vec columns never reach the output, so they are not evaluated (zeros
+    // stand in).  A row with NO valid slot attends uniformly over all of them: everything is needed.
+    const unsigned long long need = okm ? okm : ~0ull;
+    bool small = true;
 #pragma unroll
     for (int s = 0; s < G; ++s) {
-      const float w = lane_bcast(A, s * H + h);  // 0 for s >= k
-      ae.x = __fmaf_rn(w, ze[s].x, ae.x); ae.y = __fmaf_rn(w, ze[s].y, ae.y);
-      ae.z = __fmaf_rn(w, ze[s].z, ae.z); ae.w = __fmaf_rn(w, ze[s].w, ae.w);
-      if (NBV) {
-        an4.x = __fmaf_rn(w, zn[NBV ? s : 0].x, an4.x); an4.y = __fmaf_rn(w, zn[NBV ? s : 0].y, an4.y);
-        an4.z = __fmaf_rn(w, zn[NBV ? s : 0].z, an4.z); an4.w = __fmaf_rn(w, zn[NBV ? s : 0].w, an4.w);
-      } else {
-        an = __fmaf_rn(w, zs[NBV ? 0 : s], an);
+      const float dt = lane_bcast(my_dt, s);
+      small = small && fabsf(__fmaf_rn(dt, w0, b0)) < kCosSmallLimit && fabsf(__fmaf_rn(dt, w1, b1)) < kCosSmallLimit;
+    }
+    const bool row_small = __all(small);
+    if (same_dt) {
+      const float dt = lane_bcast(my_dt, 0);
+      const float c0 = row_small ? cos_t2v_small(__fmaf_rn(dt, w0, b0)) : cos_t2v_big(__fmaf_rn(dt, w0, b0));
+      const float c1 = row_small ? cos_t2v_small(__fmaf_rn(dt, w1, b1)) : cos_t2v_big(__fmaf_rn(dt, w1, b1));
+#pragma unroll
+      for (int s = 0; s < GS; ++s) {
+        tz0[s] = c0;
+        tz1[s] = c1;
       }
-      at0 = __fmaf_rn(w, tz0[s], at0);
-      at1 = __fmaf_rn(w, tz1[s], at1);
+    } else if (row_small) {
+#pragma unroll
+      for (int s = 0; s < GS; ++s) {
+        tz0[s] = tz1[s] = 0.f;
+        const int sl = s0 + s < k ? s0 + s : k - 1;
+        if ((need >> sl) & 1) {  // wave-uniform
+          const float dt = lane_bcast(my_dt, sl);
+          tz0[s] = cos_t2v_small(__fmaf_rn(dt, w0, b0));
+          tz1[s] = cos_t2v_small(__fmaf_rn(dt, w1, b1));
+        }
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < GS; ++s) {
+        tz0[s] = tz1[s] = 0.f;
+        const int sl = s0 + s < k ? s0 + s : k - 1;
+        if ((need >> sl) & 1) {
+          const float dt = lane_bcast(my_dt, sl);
+          tz0[s] = cos_t2v_big(__fmaf_rn(dt, w0, b0));
+          tz1[s] = cos_t2v_big(__fmaf_rn(dt, w1, b1));
+        }
+      }
     }
-    float* zh = zb + h * a.Cs;
-    if (NBV) {
-      if (lane < d4) { zh[4 * lane] = an4.x; zh[4 * lane + 1] = an4.y; zh[4 * lane + 2] = an4.z; zh[4 * lane + 3] = an4.w; }
-    } else if (lane < d) {
-      zh[lane] = an;
+#pragma unroll
+    for (int s = 0; s < GS; ++s) {
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        float p = qe[h].x * ze[s].x;
+        p = __fmaf_rn(qe[h].y, ze[s].y, p);
+        p = __fmaf_rn(qe[h].z, ze[s].z, p);
+        p = __fmaf_rn(qe[h].w, ze[s].w, p);
+        if (NBV) {
+          p = __fmaf_rn(qn4[h].x, zn[NBV ? s : 0].x, p);
+          p = __fmaf_rn(qn4[h].y, zn[NBV ? s : 0].y, p);
+          p = __fmaf_rn(qn4[h].z, zn[NBV ? s : 0].z, p);
+          p = __fmaf_rn(qn4[h].w, zn[NBV ? s : 0].w, p);
+        } else {
+          p = __fmaf_rn(qn[h], zs[NBV ? 0 : s], p);
+        }
+        p = __fmaf_rn(qt0[h], tz0[s], p);
+        p = __fmaf_rn(qt1[h], tz1[s], p);
+        P[s * H + h] = p;
+      }
     }
-    if (e_on) { zh[d + 4 * lane] = ae.x; zh[d + 4 * lane + 1] = ae.y; zh[d + 4 * lane + 2] = ae.z; zh[d + 4 * lane + 3] = ae.w; }
-    if (t0_on) zh[d + D + lane] = at0;
-    if (t1_on) zh[d + D + lane + kWave] = at1;
+    // every lane L ends up with entry L mod NVp (summed over the 64 lanes in the order xor 32, 16, 8, 4, 2, 1 whatever NVp is)
+    float sc = reduce_scatter_n<NVp>(P, lane);
+    // ... and lane j = slot * H + h of the ORIGINAL numbering takes entry j - s0 * H
+    if (GS < G) sc = __shfl(sc, (lane - s0 * H) & (NVp - 1));
+
+    // ---- masked softmax over the slots of each head: lanes j, j +- H, ... share a head ----
+    const int js = lane / H;
+    const bool live = js < k;
+    const bool ok = __shfl(my_ok ? 1 : 0, js < k ? js : 0) != 0;
+    sc = live ? (ok ? sc * a.scale : -1e10f) : -__builtin_inff();
+    float mx = sc;
+#pragma unroll
+    for (int o = H; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float ev = live ? expf(sc - mx) : 0.f;
+    float sum = ev;
+#pragma unroll
+    for (int o = H; o < 64; o <<= 1) sum += __shfl_xor(sum, o);
+    float A = ev / sum;
+    if (a.probs && live) a.probs[r * (long long)H * k + (lane - js * H) * k + js] = A;
+    if (a.drop.thresh && live) A *= dropout_scale(a.drop, (unsigned long long)(a.drop_row0 + r) * (H * k) + (lane - js * H) * k + js);
+
+    // ---- zbar[h] = sum_s A[h][s] z[s], from registers ----
+    float* __restrict__ zb = a.zbar + r * (long long)H * a.Cs;
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      float4 ae = make_float4(0.f, 0.f, 0.f, 0.f), an4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      float an = 0.f, at0 = 0.f, at1 = 0.f;
+#pragma unroll
+      for (int s = 0; s < GS; ++s) {
+        // (k < G: the clamped duplicate slots past k carry weight 0 -- lane (s0 + s) * H + h is not live)
+        const float w = lane_bcast(A, (s0 + s) * H + h);
+        ae.x = __fmaf_rn(w, ze[s].x, ae.x); ae.y = __fmaf_rn(w, ze[s].y, ae.y);
+        ae.z = __fmaf_rn(w, ze[s].z, ae.z); ae.w = __fmaf_rn(w, ze[s].w, ae.w);
+        if (NBV) {
+          an4.x = __fmaf_rn(w, zn[NBV ? s : 0].x, an4.x); an4.y = __fmaf_rn(w, zn[NBV ? s : 0].y, an4.y);
+          an4.z = __fmaf_rn(w, zn[NBV ? s : 0].z, an4.z); an4.w = __fmaf_rn(w, zn[NBV ? s : 0].w, an4.w);
+        } else {
+          an = __fmaf_rn(w, zs[NBV ? 0 : s], an);
+        }
+        at0 = __fmaf_rn(w, tz0[s], at0);
+        at1 = __fmaf_rn(w, tz1[s], at1);
+      }
+      float* zh = zb + h * a.Cs;
+      if (NBV) {
+        if (lane < d4) { zh[4 * lane] = an4.x; zh[4 * lane + 1] = an4.y; zh[4 * lane + 2] = an4.z; zh[4 * lane + 3] = an4.w; }
+      } else if (lane < d) {
+        zh[lane] = an;
+      }
+      if (e_on2) { zh[d + 4 * lane] = ae.x; zh[d + 4 * lane + 1] = ae.y; zh[d + 4 * lane + 2] = ae.z; zh[d + 4 * lane + 3] = ae.w; }
+      if (t0_on) zh[d + D + lane] = at0;
+      if (t1_on) zh[d + D + lane + kWave] = at1;
+    }
+  };
+  // (a.full_span: the A/B knob TGMX_ATTN_SPAN=0 -- every row through the all-slots body)
+  const int want = a.full_span ? G : span;
+  if constexpr (G > 16) {
+    if (want <= 4) return body(std::integral_constant<int, 4>{});
+    if (want <= 8) return body(std::integral_constant<int, 8>{});
+    if (want <= 12) return body(std::integral_constant<int, 12>{});
+    if (want <= 16) return body(std::integral_constant<int, 16>{});
+  } else if constexpr (G > 8) {
+    if (want <= 4) return body(std::integral_constant<int, 4>{});
+    if (want <= 8) return body(std::integral_constant<int, 8>{});
   }
+  body(std::integral_constant<int, G>{});
 }
 
 template <int H, int G>
@@ -1747,7 +1840,10 @@ __global__ __launch_bounds__(256) void tgat_qfold_small_kernel(const float* __re
 }
 
 // shared by the C entry point and the forward driver (which may pass queries folded onto the row input)
-static int attn_reduce_impl(const AttnArgs& a, int H, hipStream_t st) {
+static int attn_reduce_impl(const AttnArgs& a_in, int H, hipStream_t st) {
+  static const bool span_off = [] { const char* e = getenv("TGMX_ATTN_SPAN"); return e && atoi(e) == 0; }();  // A/B knob
+  AttnArgs a = a_in;
+  a.full_span = span_off ? 1 : 0;
   TGMX_REQUIRE(H == 1 || H == 2 || H == 4 || H == 8, "tgat_attn_reduce: the attention kernels are built for n_heads in {1, 2, 4, 8} (got %d)", H);
   const int k = a.k, T = a.T;
   const long long R = a.R;
@@ -1872,9 +1968,16 @@ extern "C" int tgmx_pair_dedup(const int32_t* ids, const int64_t* times, int64_t
 
 // Inference over the DISTINCT rows of every level (tgmx_tgat_hop_t.seed_keyed): at least two layers (a one-layer model has no level that
 // is both a row batch and somebody's neighbors), every hop >= 1 marked, and every layer's attention on the register-resident kernel
-// (the only one that reads rows and neighbor features by index).  TGMX_TGAT_COMPACT=0 is the A/B knob.
+// (the only one that reads rows and neighbor features by index).
+// OPT-IN -- the caller marks the hops (tgm_amd.nn.TGAT(...).compact_rows = True, or TGMX_TGAT_COMPACT=1 in its environment) -- since it was measured (round 4, headline shape, edge features by id, one box, us per forward):
+//   row per slot 192.3 | compact rows 201.9 (pair table in global memory) / 205.0 (one workgroup, table in LDS).
+// 12 000 level-1 rows hold ~6 300 distinct pairs, but (i) finding them costs 19-21 us (a memset + two launches of dependent global
+// atomics, or one workgroup's serialized LDS atomics) + 5 us for the row maps against 4.8 us for the plain leaf gather, (ii) the one-kernel
+// tail is ONE round of 197 workgroups on 256 CUs whose duration is a single workgroup's latency (58.5 us with 109 live workgroups as with
+// 197), (iii) the attention launch gains 4-10 us (58 -> 48-54: the all-pad rows it drops were cheap already) and the 600-row layer's
+// attention LOSES 2-3 us reading its neighbors through the row map.  It pays from ~2 rounds of tail workgroups on (>= 33 k rows per layer).
 static bool compact_wanted(const tgmx_tgat_model_t* m, const tgmx_tgat_hop_t* hops, int save) {
-  static const bool off = [] { const char* e = getenv("TGMX_TGAT_COMPACT"); return e && atoi(e) == 0; }();
+  static const bool off = [] { const char* e = getenv("TGMX_TGAT_COMPACT"); return e && atoi(e) == 0; }();  // kill switch
   const int L = m->num_layers;
   if (off || save || L < 2) return false;
   for (int i = 1; i < L; ++i)

@@ -59,6 +59,10 @@ class TGAT(TransientCaches, nn.Module):
                  dropout: float = 0.1) -> None:  # fmt: skip
         super().__init__()
         self.num_layers, self.embed_dim, self.node_dim = num_layers, embed_dim, node_dim
+        # inference over the DISTINCT (id, time) rows of every level (tgmx_tgat_hop_t.seed_keyed; bit-identical embeddings).  Opt-in: at the
+        # headline shape finding the distinct rows costs more than computing them (csrc/tgat.hip compact_wanted has the numbers); it pays
+        # for batches of >= ~33 k rows per layer
+        self.compact_rows = os.environ.get('TGMX_TGAT_COMPACT', '0') not in ('', '0')
         self.time_encoder = Time2Vec(time_dim=time_dim)
         self.attn, self.merge_layers = nn.ModuleList(), nn.ModuleList()
         for i in range(num_layers):
@@ -226,7 +230,7 @@ class TGAT(TransientCaches, nn.Module):
         # distinct row once (tgmx_tgat_hop_t.seed_keyed).  Anything else -- hand-made tensors, replaced items, tensors modified in
         # place -- gets the row-per-slot computation.
         tag = getattr(nbr_nids, 'tag', None)
-        keyed = (L > 1 and tag is not None and getattr(nbr_edge_time, 'tag', None) is tag and getattr(seed_times, 'tag', None) is tag
+        keyed = (self.compact_rows and L > 1 and tag is not None and getattr(nbr_edge_time, 'tag', None) is tag and getattr(seed_times, 'tag', None) is tag
                  and getattr(seed_nids, 'tag', None) is tag and getattr(nbr_edge_x, 'tag', None) is tag and tag.matches(nbr_nids, nbr_edge_time, nbr_edge_x)
                  and all(seed_nids[i].data_ptr() == nbr_nids[i - 1].data_ptr() and seed_times[i].data_ptr() == nbr_edge_time[i - 1].data_ptr()
                          and seed_nids[i].numel() == nbr_nids[i - 1].numel() == seed_times[i].numel() for i in range(1, L)))  # fmt: skip

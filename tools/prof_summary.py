@@ -2,6 +2,7 @@
 """Summarise rocprofv3 output (the rocpd SQLite database this image's rocprofv3 writes) as markdown / JSON.
 
     python tools/prof_summary.py trace <dir-or-db> [--title "..."]      per-kernel table of a --kernel-trace --stats run
+    python tools/prof_summary.py byname <dir-or-db> [--steps N]         the same grouped by kernel name only (+ launches / us per step)
     python tools/prof_summary.py gaps  <dir-or-db> --kernel <substr>    launch-to-launch gaps on the stream around one kernel
     python tools/prof_summary.py pmc   <dir-or-db> [--kernel <substr>]  per-kernel average of every collected counter
 
@@ -37,6 +38,24 @@ def trace(db, title):
     print('|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|')
     for name, grid, n, tot, avg, mn, mx, vg, lds in rows[:30]:
         print(f'| `{short(name)}` | {grid} | {n} | {tot / 1e6:.3f} | {avg / 1e3:.2f} | {mn / 1e3:.2f} | {mx / 1e3:.2f} | {vg} | {lds} | {100 * tot / total:.1f} |')
+
+
+def byname(db, title, steps):
+    """per-kernel-NAME table (all grid sizes of one kernel together): launches and microseconds per step when --steps is given.  For pipelines
+    whose launch shapes change from batch to batch (TGN: the number of unique nodes), where the per-(name, grid) table is mostly tail."""
+    rows = db.execute('select name, count(*), sum(duration), avg(duration), min(duration), max(duration), max(vgpr_count), max(lds_size) '
+                      'from kernels group by name order by sum(duration) desc').fetchall()
+    total = sum(r[2] for r in rows) or 1
+    n_all = sum(r[1] for r in rows)
+    print(f'# {title}')
+    if steps:
+        print(f'# {n_all} launches, {total / 1e6:.3f} ms of kernels over {steps} steps: {n_all / steps:.1f} launches and {total / 1e3 / steps:.1f} us of kernel time per step')
+    print('| kernel | calls | per step | total ms | us per step | avg us | min us | max us | VGPR | LDS B | % |')
+    print('|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|')
+    for name, n, tot, avg, mn, mx, vg, lds in rows[:40]:
+        ps = f'{n / steps:.2f}' if steps else ''
+        us = f'{tot / 1e3 / steps:.2f}' if steps else ''
+        print(f'| `{short(name)}` | {n} | {ps} | {tot / 1e6:.3f} | {us} | {avg / 1e3:.2f} | {mn / 1e3:.2f} | {mx / 1e3:.2f} | {vg} | {lds} | {100 * tot / total:.1f} |')
 
 
 def gaps(db, kernel):
@@ -106,12 +125,13 @@ def pmctail(db, kernel, last):
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
-    ap.add_argument('what', choices=['trace', 'gaps', 'pmc', 'tail', 'pmctail'])
+    ap.add_argument('what', choices=['trace', 'byname', 'gaps', 'pmc', 'tail', 'pmctail'])
     ap.add_argument('--last', type=int, default=393)
     ap.add_argument('path')
     ap.add_argument('--title', default='rocprofv3 --kernel-trace --stats')
     ap.add_argument('--kernel', default='')
+    ap.add_argument('--steps', type=int, default=0)
     a = ap.parse_args()
     db = open_db(a.path)
-    {'trace': lambda: trace(db, a.title), 'gaps': lambda: gaps(db, a.kernel), 'pmc': lambda: pmc(db, a.kernel), 'tail': lambda: tail(db, a.kernel, a.last),
+    {'trace': lambda: trace(db, a.title), 'byname': lambda: byname(db, a.title, a.steps), 'gaps': lambda: gaps(db, a.kernel), 'pmc': lambda: pmc(db, a.kernel), 'tail': lambda: tail(db, a.kernel, a.last),
      'pmctail': lambda: pmctail(db, a.kernel, a.last)}[a.what]()

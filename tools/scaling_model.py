@@ -19,7 +19,7 @@ CASES = (('wiki', 'weak', 'ring', []), ('comment', 'weak', 'ring', ['--steps', '
 for workload, scaling, mode, extra in CASES:
     rows = []
     for W in (1, 2, 4, 8):
-        cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--workload', workload, '--scaling', scaling, '--mode', mode, '--cpu-batches', '0', '--no-default-path'] + extra
+        cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--workload', workload, '--scaling', scaling, '--mode', mode, '--cpu-batches', '0', '--no-default-path', '--extras', 'off'] + extra
         if W > 1:
             cmd += ['--emulate-world', str(W), '--emulate-rank', str(W - 1)]
         r = subprocess.run(cmd, capture_output=True, text=True)
