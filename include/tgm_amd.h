@@ -633,7 +633,8 @@ int tgmx_tgn_store_batch(const int32_t* src, const int32_t* dst, const int64_t* 
 /* TGNMemory._get_updated_memory (tgn.py:191-216) and GraphAttentionEmbedding.forward (tgn.py:30-40, PyG TransformerConv) as
  * ONE call each (inference / no-grad paths): the same launches, in the same order, as the building blocks above composed by
  * the host -- aggregate, gather, the two GRU GEMMs, gates; four stacked projections, edge encoding, lin_edge GEMM, segment
- * sort, attention.  Every buffer is the caller's.  qkvs is [4, U, H*C]: query | key | value | skip; the result is its 4th
+ * sort (or, with tgt_count / cursor / order_big, a counting grouping: histogram inside the edge encoding's launch, one scan, one placement
+ * launch, segments sorted by edge id where the attention reads them -- same results), attention.  Every buffer is the caller's.  qkvs is [4, U, H*C]: query | key | value | skip; the result is its 4th
  * block (skip + attention). */
 typedef struct tgmx_tgn_memory_fwd {
   const int32_t* nodes; int64_t R;
@@ -658,6 +659,9 @@ typedef struct tgmx_tconv_fwd {
   float* edge_attr; float* qkvs; float* eproj;         /* [E, T + D], [4, U, H*C], [E, H*C] */
   int64_t* order; int64_t* seg_lo; int64_t* seg_hi;    /* [E], [U], [U] */
   void* sort_ws; size_t sort_ws_bytes; int32_t* status;
+  /* optional (all three, or NULL: the segment-sort path): the counting grouping of the edges by target.  tgt_count [U] int32 must be
+   * ZERO on entry and is left zero (the caller keeps it between calls: allocate once, zeroed); cursor [U], order_big [E] are scratch. */
+  int32_t* tgt_count; int64_t* cursor; int64_t* order_big;
 } tgmx_tconv_fwd_t;
 int tgmx_tconv_forward(const tgmx_tconv_fwd_t* args, tgmx_stream_t stream);
 

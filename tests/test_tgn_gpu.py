@@ -122,6 +122,40 @@ def test_graph_attention_embedding_matches_restatement(inference):
     close(out.cpu(), ref, 'graph attention embedding')
 
 
+@pytest.mark.parametrize('U,E,hubs', [(300, 4000, 40), (7000, 15000, 0), (50, 6000, 2), (1, 7, 0), (9000, 3, 0)])
+def test_counting_grouping_equals_the_segment_sort_path(U, E, hubs, monkeypatch):
+    """tgmx_tconv_forward groups a batch's edges by target with counts + an atomic cursor and lets the attention sort every segment
+    by edge id (ascending edge id = the stable order of a sort by target): the embedding must equal the segment-sort path's BIT FOR
+    BIT, also for hubs with more incoming edges than the attention's LDS buffer holds (> 1024: ranked against global memory),
+    repeatedly (the count buffer is left zero), and after the batch shape changed."""
+    from tgm_amd.nn import GraphAttentionEmbedding, Time2Vec
+
+    torch.manual_seed(U + E)
+    M, D, T_, emb = 100, 16, 100, 100
+    enc = GraphAttentionEmbedding(M, emb, D, Time2Vec(T_)).to(DEV).eval()
+
+    def inputs(U, E, hubs, seed):
+        g = torch.Generator().manual_seed(seed)
+        x = torch.randn(U, M, generator=g)
+        lu = torch.randint(1_000_000, 2_000_000, (U,), generator=g)
+        tgt = torch.randint(0, hubs, (E,), generator=g) if hubs else torch.randint(0, U, (E,), generator=g)
+        if hubs and E > 500:
+            tgt[:500] = torch.randint(0, U, (500,), generator=g)
+        ei = torch.stack([torch.randint(0, U, (E,), generator=g), tgt])
+        return [v.to(DEV) for v in (x, lu, ei, torch.randint(0, 1_000_000, (E,), generator=g), torch.rand(E, D, generator=g))]
+
+    with torch.no_grad():
+        for rep, (u, e, h) in enumerate([(U, E, hubs), (U, E, hubs), (max(U // 2, 1), max(E // 3, 1), hubs and 1), (U, E, hubs)]):
+            args = inputs(u, e, h, 7 * rep + 1)
+            monkeypatch.setenv('TGMX_TCONV_COUNTING', '1')
+            z = enc(*args)
+            monkeypatch.setenv('TGMX_TCONV_COUNTING', '0')
+            z_ref = enc(*args)
+            assert torch.equal(z, z_ref), f'round {rep}: max |d| = {(z - z_ref).abs().max().item():.3e}'
+            cnt = enc.conv._tgt_count
+            assert int(cnt.abs().sum().item()) == 0, 'the per-target counts must be left zero'
+
+
 @pytest.mark.parametrize('one_launch', ['1', '0'])
 @pytest.mark.parametrize('U,E', [(1, 1), (5, 0), (300, 40), (7000, 15000), (40_000, 3), (32768, 16384), (3, 16385)])
 def test_segment_sort_matches_stable_argsort(U, E, one_launch, monkeypatch):

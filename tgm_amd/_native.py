@@ -209,6 +209,7 @@ class TconvFwd(ctypes.Structure):
         ('tw', c_void_p), ('tb', c_void_p), ('W4', c_void_p), ('b4', c_void_p), ('W_edge', c_void_p), ('H', c_int32), ('C', c_int32),
         ('edge_attr', c_void_p), ('qkvs', c_void_p), ('eproj', c_void_p), ('order', c_void_p), ('seg_lo', c_void_p), ('seg_hi', c_void_p),
         ('sort_ws', c_void_p), ('sort_ws_bytes', c_size_t), ('status', c_void_p),
+        ('tgt_count', c_void_p), ('cursor', c_void_p), ('order_big', c_void_p),
     ]  # fmt: skip
 
 

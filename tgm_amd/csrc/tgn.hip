@@ -78,6 +78,7 @@ struct AggrArgs {
   int M, D, T, N, mean;
   int64_t* assoc;           // optional [N]: assoc[node] = (stamp << 32) | row  (tgn.py:193: self._assoc[n_id] = arange)
   long long stamp;
+  float* h_out;             // optional [R, M]: h_out[row] = memory[nodes[row]] (the GRU's hidden-state operand: no gather launch)
 };
 
 __device__ __forceinline__ void tgn_message_cols(const AggrArgs& a, int lane, const float* mem_v, long long ev, long long lu_v,
@@ -111,6 +112,8 @@ __global__ __launch_bounds__(256) void tgn_aggregate_kernel(const AggrArgs a) {
   const long long lo0 = a.st_lo[0][v], lo1 = a.st_lo[1][v];
   const int c0 = a.st_cnt[0][v], c1 = a.st_cnt[1][v];
   const int total = c0 + c1;
+  if (a.h_out)
+    for (int c = lane; c < a.M; c += kWave) a.h_out[row * a.M + c] = mem_v[c];
   if (total == 0) {
     for (int c = lane; c < W; c += kWave) out[c] = 0.f;
     if (lane == 0) a.new_lu[row] = 0;
@@ -189,16 +192,27 @@ __global__ __launch_bounds__(256) void tgn_commit_kernel(const int32_t* __restri
 //   heads concatenated, plus the root/skip projection (added by the caller's GEMM epilogue).
 // ---------------------------------------------------------------------------
 // edge_attr[e] = [cos(fma(float(last_update[src_local[e]] - t[e]), w, b)) | msg[e, :]]
+// tgt / tgt_count (optional): the thread that writes an edge's first column also counts the edge for its target (the first pass of
+// the counting grouping in tgmx_tconv_forward); a target outside [0, U) is clamped and flagged like tgmx_segment_sort does.
 __global__ __launch_bounds__(256) void tconv_edge_attr_kernel(const int64_t* __restrict__ lu_local, const int64_t* __restrict__ src,
                                                               const int64_t* __restrict__ t, const float* __restrict__ msg,
                                                               const float* __restrict__ tw, const float* __restrict__ tb, int T,
-                                                              int D, long long E, float* __restrict__ out) {
+                                                              int D, long long E, float* __restrict__ out, const int64_t* __restrict__ tgt,
+                                                              int32_t* __restrict__ tgt_count, long long U, int32_t* status) {
   const int W = T + D;
   const long long total = E * W;
   const long long step = (long long)gridDim.x * blockDim.x;
   for (long long x = (long long)blockIdx.x * blockDim.x + threadIdx.x; x < total; x += step) {
     const long long e = x / W;
     const int c = (int)(x - e * W);
+    if (c == 0 && tgt_count) {
+      long long i = tgt[e];
+      if (i < 0 || i >= U) {
+        atomicOr(status, TGMX_ST_EDGE_RANGE);
+        i = i < 0 ? 0 : U - 1;
+      }
+      atomicAdd(&tgt_count[i], 1);
+    }
     float v;
     if (c < T) v = cos_t2v(__fmaf_rn((float)(lu_local[src[e]] - t[e]), tw[c], tb[c]));
     else v = msg[e * D + (c - T)];
@@ -220,7 +234,14 @@ struct TconvArgs {
   int H, C;
   float scale;
   DropoutArgs drop;  // training: dropout on the attention coefficients after the softmax (PyG TransformerConv), element e * H + h
+  // counting grouping (tgmx_tconv_forward): `order` holds every target's incoming edge ids in NO particular order (placed with
+  // atomics); the workgroup sorts its segment by edge id first -- ascending edge id IS the stable order a sort by target gives --
+  // in LDS, or for a segment longer than kTconvSegLds into order_big[lo .. hi)
+  int unsorted;
+  int64_t* order_big;
 };
+
+constexpr int kTconvSegLds = 1024;
 
 // online softmax over a target's incoming edges, head by head
 __global__ __launch_bounds__(256) void tconv_attend_kernel(const TconvArgs a) {
@@ -236,6 +257,34 @@ __global__ __launch_bounds__(256) void tconv_attend_kernel(const TconvArgs a) {
   const long long lo = a.seg_lo[i], hi = a.seg_hi[i];
   if (hi <= lo) return;  // no incoming edge: only the skip term
   const int HC = a.H * a.C;
+  __shared__ int s_raw[kTconvSegLds], s_sorted[kTconvSegLds];  // (edge ids of one batch: far below 2^31)
+  const int64_t* __restrict__ ord = a.order + lo;  // position p of the segment reads ord[p - lo] / s_sorted[p - lo]
+  bool in_lds = false;
+  if (a.unsorted && hi - lo > 1) {
+    const long long n = hi - lo;
+    if (n <= kTconvSegLds) {  // rank = number of smaller ids (ids are distinct): O(n^2 / 256) LDS reads, n is 1-3 for most targets
+      for (int p = threadIdx.x; p < n; p += blockDim.x) s_raw[p] = (int)a.order[lo + p];
+      __syncthreads();
+      for (int p = threadIdx.x; p < n; p += blockDim.x) {
+        const int id = s_raw[p];
+        int rank = 0;
+        for (int q = 0; q < n; ++q) rank += s_raw[q] < id;
+        s_sorted[rank] = id;
+      }
+      __syncthreads();
+      in_lds = true;
+    } else {  // a hub with more than kTconvSegLds incoming edges: the same ranking against global memory
+      for (long long p = threadIdx.x; p < n; p += blockDim.x) {
+        const long long id = a.order[lo + p];
+        long long rank = 0;
+        for (long long q = 0; q < n; ++q) rank += a.order[lo + q] < id;
+        a.order_big[lo + rank] = id;
+      }
+      __threadfence_block();
+      __syncthreads();
+      ord = a.order_big + lo;
+    }
+  }
   for (int h = 0; h < a.H; ++h) {
     for (int c0 = 0; c0 < a.C; c0 += kWave) {  // output columns of this head handled by this lane
       // (C <= 64 in practice: one pass; for larger C the scores are recomputed per column chunk)
@@ -246,7 +295,7 @@ __global__ __launch_bounds__(256) void tconv_attend_kernel(const TconvArgs a) {
         const long long my_p = p0 + (long long)kWavesPerTarget * lane;
         long long my_e = 0, my_j = 0;
         if (my_p < hi) {
-          my_e = a.order[my_p];
+          my_e = in_lds ? s_sorted[my_p - lo] : ord[my_p - lo];
           my_j = a.src[my_e];
         }
         const long long left = (hi - p0 + kWavesPerTarget - 1) / kWavesPerTarget;
@@ -429,6 +478,65 @@ __global__ __launch_bounds__(1024) void tgn_store_batch_kernel(const StoreBatchA
   }
 }
 
+// ---- counting grouping of a batch's edges by target (tgmx_tconv_forward) -----------------------------------------------------
+// count[U] (zero on entry: the histogram pass rode tconv_edge_attr_kernel) -> seg_lo / seg_hi / cursor = exclusive prefix sums, and
+// count is zeroed again for the next call.  One workgroup, 16 consecutive counts per thread and pass (16 K targets per pass).
+__global__ __launch_bounds__(1024) void tconv_group_scan_kernel(int32_t* __restrict__ count, long long U, int64_t* __restrict__ seg_lo,
+                                                                int64_t* __restrict__ seg_hi, int64_t* __restrict__ cursor) {
+  constexpr int kPer = 16;
+  __shared__ long long wave_tot[16];
+  __shared__ long long carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (long long u0 = 0; u0 < U; u0 += 1024 * kPer) {
+    const long long ub = u0 + (long long)tid * kPer;
+    int c[kPer];
+    long long v = 0;
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) {
+      c[q] = ub + q < U ? count[ub + q] : 0;
+      v += c[q];
+    }
+    long long incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const long long o = __shfl_up(incl, off);
+      if (lane >= off) incl += o;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    long long before = carry_s;
+    for (int q = 0; q < wave; ++q) before += wave_tot[q];
+    long long pos = before + incl - v;
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) {
+      if (ub + q < U) {
+        seg_lo[ub + q] = pos;
+        cursor[ub + q] = pos;
+        pos += c[q];
+        seg_hi[ub + q] = pos;
+        if (c[q]) count[ub + q] = 0;
+      }
+    }
+    __syncthreads();
+    if (tid == 1023) carry_s = before + incl;
+    __syncthreads();
+  }
+}
+
+// order[cursor[tgt[e]]++] = e: every target's incoming edge ids land in its segment, in the order the atomics resolve
+// (tconv_attend_kernel sorts a segment before it walks it)
+__global__ __launch_bounds__(256) void tconv_group_place_kernel(const int64_t* __restrict__ tgt, long long E, long long U,
+                                                                int64_t* __restrict__ cursor, int64_t* __restrict__ order) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  long long i = tgt[e];
+  i = i < 0 ? 0 : (i >= U ? U - 1 : i);
+  const unsigned long long p = atomicAdd(reinterpret_cast<unsigned long long*>(&cursor[i]), 1ull);
+  order[p] = e;
+}
+
 // ---- the sampled edge list of one hop, as the reference's TGN loop builds it (examples/linkproppred/tgn.py:80-92) ------
 //   mask = nbr != -1;  edge_index = [global_to_local(seed.repeat_interleave(k)[mask]); global_to_local(nbr[mask])]
 //   edge_t = nbr_t[mask];  edge_x = nbr_x[mask]     -- order = slot order, local ids = position in the sorted unique ids
@@ -538,11 +646,11 @@ extern "C" int tgmx_tgn_store(const int64_t* perm, const int32_t* node_sorted, c
   return TGMX_OK;
 }
 
-extern "C" int tgmx_tgn_aggregate(const int32_t* nodes, int64_t R, const float* memory, const int64_t* last_update, int32_t M,
-                                  int32_t num_nodes, const int64_t* st_lo_s, const int32_t* st_cnt_s, const int64_t* st_lo_d,
-                                  const int32_t* st_cnt_d, const int32_t* log_other, const int64_t* log_t, const float* log_raw,
-                                  int32_t D, const float* tw, const float* tb, int32_t T, int32_t mean, float* aggr, int64_t* new_lu,
-                                  int64_t* assoc, int64_t stamp, tgmx_stream_t stream) {
+static int tgn_aggregate_impl(const int32_t* nodes, int64_t R, const float* memory, const int64_t* last_update, int32_t M,
+                              int32_t num_nodes, const int64_t* st_lo_s, const int32_t* st_cnt_s, const int64_t* st_lo_d,
+                              const int32_t* st_cnt_d, const int32_t* log_other, const int64_t* log_t, const float* log_raw,
+                              int32_t D, const float* tw, const float* tb, int32_t T, int32_t mean, float* aggr, int64_t* new_lu,
+                              int64_t* assoc, int64_t stamp, float* h_out, tgmx_stream_t stream) {
   TGMX_REQUIRE(R >= 0 && M > 0 && D >= 0 && T > 0 && num_nodes > 0, "tgn_aggregate: bad sizes");
   if (R == 0) return TGMX_OK;
   TGMX_REQUIRE(nodes && memory && last_update && st_lo_s && st_cnt_s && st_lo_d && st_cnt_d && tw && tb && aggr && new_lu,
@@ -552,10 +660,19 @@ extern "C" int tgmx_tgn_aggregate(const int32_t* nodes, int64_t R, const float* 
   a.st_lo[0] = st_lo_s; a.st_lo[1] = st_lo_d; a.st_cnt[0] = st_cnt_s; a.st_cnt[1] = st_cnt_d;
   a.log_other = log_other; a.log_t = log_t; a.log_raw = log_raw; a.tw = tw; a.tb = tb; a.aggr = aggr; a.new_lu = new_lu;
   a.R = R; a.M = M; a.D = D; a.T = T; a.N = num_nodes; a.mean = mean;
-  a.assoc = assoc; a.stamp = stamp;
+  a.assoc = assoc; a.stamp = stamp; a.h_out = h_out;
   hipLaunchKernelGGL(tgn_aggregate_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
   TGMX_CHECK_LAUNCH("tgn_aggregate");
   return TGMX_OK;
+}
+
+extern "C" int tgmx_tgn_aggregate(const int32_t* nodes, int64_t R, const float* memory, const int64_t* last_update, int32_t M,
+                                  int32_t num_nodes, const int64_t* st_lo_s, const int32_t* st_cnt_s, const int64_t* st_lo_d,
+                                  const int32_t* st_cnt_d, const int32_t* log_other, const int64_t* log_t, const float* log_raw,
+                                  int32_t D, const float* tw, const float* tb, int32_t T, int32_t mean, float* aggr, int64_t* new_lu,
+                                  int64_t* assoc, int64_t stamp, tgmx_stream_t stream) {
+  return tgn_aggregate_impl(nodes, R, memory, last_update, M, num_nodes, st_lo_s, st_cnt_s, st_lo_d, st_cnt_d, log_other, log_t, log_raw, D, tw, tb, T,
+                            mean, aggr, new_lu, assoc, stamp, nullptr, stream);
 }
 
 extern "C" int tgmx_tgn_gru_gate(const float* gi, const float* gh, const float* h, int32_t M, int64_t R, float* out,
@@ -590,7 +707,7 @@ extern "C" int tgmx_tconv_edge_attr(const int64_t* last_update_local, const int6
   long long blocks = (E * (T + D) + 255) / 256;
   if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(tconv_edge_attr_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, last_update_local, src, t,
-                     msg, tw, tb, T, D, (long long)E, out);
+                     msg, tw, tb, T, D, (long long)E, out, (const int64_t*)nullptr, (int32_t*)nullptr, 0ll, (int32_t*)nullptr);
   TGMX_CHECK_LAUNCH("tconv_edge_attr");
   return TGMX_OK;
 }
@@ -603,6 +720,8 @@ extern "C" int tgmx_tconv_attend(const float* q, const float* k, const float* v,
   TGMX_REQUIRE(q && k && v && eproj && order && src && seg_lo && seg_hi && out, "tconv_attend: null pointer");
   TconvArgs a{q, k, v, eproj, order, src, seg_lo, seg_hi, out, U, H, C, scale};
   a.drop = make_dropout(drop);
+  a.unsorted = 0;
+  a.order_big = nullptr;
   hipLaunchKernelGGL(tconv_attend_kernel, dim3((unsigned)U), dim3(256), 0, (hipStream_t)stream, a);
   TGMX_CHECK_LAUNCH("tconv_attend");
   return TGMX_OK;
@@ -747,11 +866,11 @@ extern "C" int tgmx_tgn_memory_forward(const tgmx_tgn_memory_fwd_t* a, tgmx_stre
   if (R == 0) return TGMX_OK;
   const int M = a->M, W = 2 * a->M + a->D + a->T;
   TGMX_REQUIRE(a->ws_aggr && a->ws_h && a->ws_gi && a->ws_gh && a->out_mem && a->out_lu && a->W_ih && a->W_hh, "tgn_memory_forward: null pointer");
-  int rc = tgmx_tgn_aggregate(a->nodes, R, a->memory, a->last_update, M, a->num_nodes, a->st_lo_s, a->st_cnt_s, a->st_lo_d, a->st_cnt_d,
+  // (the aggregation's launch also writes the hidden-state rows h = memory[nodes]: one launch less than a separate gather)
+  int rc = tgn_aggregate_impl(a->nodes, R, a->memory, a->last_update, M, a->num_nodes, a->st_lo_s, a->st_cnt_s, a->st_lo_d, a->st_cnt_d,
                               a->log_other, a->log_t, a->log_raw, a->D, a->tw, a->tb, a->T, a->mean, a->ws_aggr, a->out_lu, a->assoc, a->stamp,
-                              stream);
+                              a->ws_h, stream);
   if (rc) return rc;
-  if ((rc = tgmx_gather_rows(a->memory, a->num_nodes, M, a->nodes, R, a->ws_h, M, stream))) return rc;
   // GRUCell: gi = aggr W_ih^T + b_ih, gh = h W_hh^T + b_hh, gates
   if ((rc = tgmx_sgemm_nt(a->ws_aggr, W, a->W_ih, W, a->ws_gi, 3 * M, R, 3 * M, W, a->b_ih, 0, 1, 0, 0, 0, stream))) return rc;
   if ((rc = tgmx_sgemm_nt(a->ws_h, M, a->W_hh, M, a->ws_gh, 3 * M, R, 3 * M, M, a->b_hh, 0, 1, 0, 0, 0, stream))) return rc;
@@ -767,12 +886,38 @@ extern "C" int tgmx_tconv_forward(const tgmx_tconv_fwd_t* a, tgmx_stream_t strea
   // query / key / value / skip projections of the same x: ONE batched launch over the stacked weights
   int rc = tgmx_sgemm_nt(a->x, a->in_ch, a->W4, a->in_ch, a->qkvs, HC, U, HC, a->in_ch, a->b4, 0, 4, 0, (int64_t)HC * a->in_ch, U * HC, stream);
   if (rc || E == 0) return rc;
-  TGMX_REQUIRE(a->src && a->tgt && a->t && a->edge_attr && a->eproj && a->order && a->seg_lo && a->seg_hi && a->sort_ws && a->status,
-               "tconv_forward: null pointer");
+  TGMX_REQUIRE(a->src && a->tgt && a->t && a->edge_attr && a->eproj && a->order && a->seg_lo && a->seg_hi && a->status, "tconv_forward: null pointer");
+  float* out = a->qkvs + 3 * U * HC;  // the skip projection; the attention output is added to it
+  const char* knob = getenv("TGMX_TCONV_COUNTING");  // A/B knob, read per call (the tests switch it)
+  const bool count_off = knob && atoi(knob) == 0;
+  if (a->tgt_count && a->cursor && a->order_big && !count_off) {
+    // Counting grouping: the edge encoding's launch also counts the edges per target, one workgroup scans the counts into the segments,
+    // one small launch places every edge id with an atomic cursor, and the attention sorts a segment (1-3 ids for most targets) before
+    // walking it -- ascending edge id is the order a stable sort by target gives, so the result equals the sorted path's bit for bit.
+    // 3 launches less work than: keys + 4-5 radix-sort launches + the library's copy-back + bounds (~50 us of a 264 us batch, round 4).
+    hipStream_t st = (hipStream_t)stream;
+    long long blocks = (E * Wd + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(tconv_edge_attr_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a->last_update_local, a->src, a->t, a->msg, a->tw, a->tb,
+                       a->T, a->D, (long long)E, a->edge_attr, a->tgt, a->tgt_count, (long long)U, a->status);
+    hipLaunchKernelGGL(tconv_group_scan_kernel, dim3(1), dim3(1024), 0, st, a->tgt_count, (long long)U, a->seg_lo, a->seg_hi, a->cursor);
+    hipLaunchKernelGGL(tconv_group_place_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, a->tgt, (long long)E, (long long)U, a->cursor,
+                       a->order);
+    TGMX_CHECK_LAUNCH("tconv_forward(grouping)");
+    if ((rc = tgmx_sgemm_nt(a->edge_attr, Wd, a->W_edge, Wd, a->eproj, HC, E, HC, Wd, nullptr, 0, 1, 0, 0, 0, stream))) return rc;
+    TconvArgs t{a->qkvs, a->qkvs + U * HC, a->qkvs + 2 * U * HC, a->eproj, a->order, a->src, a->seg_lo, a->seg_hi, out, U, a->H, a->C,
+                1.0f / sqrtf((float)a->C)};
+    t.drop = make_dropout(nullptr);
+    t.unsorted = 1;
+    t.order_big = a->order_big;
+    hipLaunchKernelGGL(tconv_attend_kernel, dim3((unsigned)U), dim3(256), 0, st, t);
+    TGMX_CHECK_LAUNCH("tconv_attend");
+    return TGMX_OK;
+  }
+  TGMX_REQUIRE(a->sort_ws, "tconv_forward: null pointer");
   if ((rc = tgmx_tconv_edge_attr(a->last_update_local, a->src, a->t, a->msg, a->tw, a->tb, a->T, a->D, E, a->edge_attr, stream))) return rc;
   if ((rc = tgmx_sgemm_nt(a->edge_attr, Wd, a->W_edge, Wd, a->eproj, HC, E, HC, Wd, nullptr, 0, 1, 0, 0, 0, stream))) return rc;
   if ((rc = tgmx_segment_sort(a->tgt, E, (int32_t)U, a->order, a->seg_lo, a->seg_hi, a->sort_ws, a->sort_ws_bytes, a->status, stream))) return rc;
-  float* out = a->qkvs + 3 * U * HC;  // the skip projection; the attention output is added to it
   return tgmx_tconv_attend(a->qkvs, a->qkvs + U * HC, a->qkvs + 2 * U * HC, a->eproj, a->order, a->src, a->seg_lo, a->seg_hi, U, a->H, a->C,
                            1.0f / sqrtf((float)a->C), out, nullptr, stream);
 }

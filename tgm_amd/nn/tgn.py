@@ -476,7 +476,7 @@ class TransformerConv(TransientCaches, nn.Module):
     dropout after the softmax like PyG's (``F.dropout(alpha, p=self.dropout)``): a counter-based mask per (edge, head),
     seeded from ``torch.initial_seed()``, a fresh stream per forward call, regenerated by the backward."""
 
-    _TRANSIENT = ('_fwd_args', '_seg_ws', '_stacked')
+    _TRANSIENT = ('_fwd_args', '_seg_ws', '_stacked', '_tgt_count')
 
     def __init__(self, in_channels: int, out_channels: int, heads: int = 1, dropout: float = 0.0, edge_dim: Optional[int] = None) -> None:
         super().__init__()
@@ -552,7 +552,11 @@ class TransformerConv(TransientCaches, nn.Module):
             if wsd is None or wsd[0].device != dev or wsd[0].numel() < need:
                 wsd = self._seg_ws = (torch.empty(need, dtype=torch.uint8, device=dev), torch.zeros(1, dtype=torch.int32, device=dev))
             fl = torch.empty(E * (T + D + HC), **f32)  # edge_attr [E, T + D] | eproj [E, HC]
-            ints = torch.empty(E + 2 * U, dtype=torch.int64, device=dev)  # order [E] | seg_lo [U] | seg_hi [U]
+            ints = torch.empty(2 * E + 3 * U, dtype=torch.int64, device=dev)  # order [E] | seg_lo [U] | seg_hi [U] | cursor [U] | order_big [E]
+            # per-target edge counts of the counting grouping: zero on entry, left zero by the call -- kept between calls
+            cnt = getattr(self, '_tgt_count', None)
+            if cnt is None or cnt.device != dev or cnt.numel() < U:
+                cnt = self._tgt_count = torch.zeros(max(2 * U, 1 << 14), dtype=torch.int32, device=dev)
             a = getattr(self, '_fwd_args', None)
             if a is None:
                 a = self._fwd_args = _native.TconvFwd()
@@ -562,6 +566,7 @@ class TransformerConv(TransientCaches, nn.Module):
             a.edge_attr, a.qkvs, a.eproj = fl.data_ptr(), qkvs.data_ptr(), fl.data_ptr() + 4 * E * (T + D)
             a.order, a.seg_lo, a.seg_hi = ints.data_ptr(), ints.data_ptr() + 8 * E, ints.data_ptr() + 8 * (E + U)
             a.sort_ws, a.sort_ws_bytes, a.status = wsd[0].data_ptr(), wsd[0].numel(), wsd[1].data_ptr()
+            a.tgt_count, a.cursor, a.order_big = cnt.data_ptr(), ints.data_ptr() + 8 * (E + 2 * U), ints.data_ptr() + 8 * (E + 3 * U)
             _native.check(lib.tgmx_tconv_forward(a, _native.stream_ptr()), 'tgmx_tconv_forward')
             return qkvs[3]
         self._edge_ctx = None
