@@ -15,6 +15,7 @@ Fixture families:
   g3_*   wiki-shaped medium stream, k=[20,20], bs=200: SHA-256 of every output
   g4_*   epoch boundary (reset_state) and train -> val carry-over
   g5_*   TemporalAttention / TGAT eval-mode forward
+  g5_self_noise.json  the reference against itself on the g5 fixtures (thread count, float64): the scale of the float bar
   g6_*   Time2Vec on int64 deltas up to 2^31
   g7_*   DeduplicationHook
   g9_*   DGData.discretize
@@ -287,6 +288,72 @@ def g5_cases():
         arrays['meta'] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
         np.savez_compressed(os.path.join(HERE, f'g5_tgat_{name}.npz'), **arrays)
         print(f'g5_tgat_{name}: z {tuple(z.shape)}  |z|max {z.abs().max():.3f}')
+
+
+def g5_self_noise():
+    """How far is the REFERENCE from itself on the g5 fixtures?  Replays every committed g5 fixture (same weights, same inputs) through the
+    reference three ways -- the default thread count (must reproduce the stored output bit for bit), ONE thread (another summation order
+    inside the BLAS calls), and float64 arithmetic (module.double(), Time2Vec kept in float32: its float32 rounding is part of the
+    function at unix-scale time deltas) -- and stores, per fixture, the float32 run's distance to both.
+    tests/test_tgat_gpu.py prints a parity error as a multiple of these next to its multiple of the bound.  Data only (a JSON file)."""
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    import golden_util as gu
+
+    def stats(a, b):
+        a, b = a.double(), b.double()
+        err = (a - b).abs()
+        big = b.abs() >= 1e-2
+        return dict(max_abs=float(err.max()), worst_multiple_of_bound=float((err / (1e-5 * b.abs().clamp(min=1.0))).max()),
+                    worst_relative_where_ref_ge_1e_2=float((err[big] / b.abs()[big]).max()) if bool(big.any()) else 0.0)
+
+    def double_but_time2vec(enc):
+        """enc.double(), except that Time2Vec stays what the reference defines it to be -- cos of a FLOAT32 fma over a float32 time delta
+        (at unix-scale deltas the float32 rounding of w * dt IS the function: in float64 the cosine's argument is another number) -- and
+        hands its float32 result over as float64."""
+        enc = enc.double()
+        te = enc.time_encoder.float()
+        fwd = te.forward
+        te.forward = lambda x: fwd(x).double()
+        return enc
+
+    out = {}
+    n_threads = torch.get_num_threads()
+    for case in gu.ATTN_CASES:
+        meta, a = gu.load(case)
+        T = lambda k: torch.from_numpy(a[k])
+        m = TemporalAttention(meta['n_heads'], meta['node_dim'], meta['edge_dim'], meta['time_dim'], dropout=0.1).eval()
+        m.load_state_dict({k[2:]: torch.from_numpy(v) for k, v in a.items() if k.startswith('w_')})
+        kw = dict(node_x=T('node_x'), time_feat=T('time_feat'), edge_feat=T('edge_feat'), nbr_node_feat=T('nbr_node_feat'),
+                  nbr_time_feat=T('nbr_time_feat'), valid_nbr_mask=T('mask'))  # fmt: skip
+        with torch.no_grad():
+            z = m(**kw)
+            torch.set_num_threads(1)
+            z1 = m(**kw)
+            torch.set_num_threads(n_threads)
+            z64 = m.double()(**{k: (v.double() if v.dtype == torch.float32 else v) for k, v in kw.items()})
+        out[case] = dict(reproduces_fixture=bool(torch.equal(z, T('out'))), threads=[n_threads, 1], one_thread_vs_default=stats(z1, z),
+                         float32_vs_float64=stats(z, z64), max_abs_ref=float(z.abs().max()))
+        print(case, out[case])
+    for case in gu.TGAT_CASES:
+        meta, params, inputs, z_ref = gu.tgat_case(case)
+        enc = TGAT(edge_dim=meta['edge_dim'], num_layers=len(meta['num_nbrs']), dropout=0.1, **meta['dims']).eval()
+        enc.load_state_dict(params)
+        args = [inputs[k] for k in ('node_x', 'seed_nids', 'seed_times', 'nbr_nids', 'nbr_edge_x', 'nbr_edge_time')]
+        with torch.no_grad():
+            z = enc(*args)
+            torch.set_num_threads(1)
+            z1 = enc(*args)
+            torch.set_num_threads(n_threads)
+            d = lambda v: [d(x) for x in v] if isinstance(v, list) else (v.double() if v.dtype == torch.float32 else v)
+            z64 = double_but_time2vec(enc)(*[d(v) for v in args])
+        out[case] = dict(reproduces_fixture=bool(torch.equal(z, z_ref)), threads=[n_threads, 1], one_thread_vs_default=stats(z1, z),
+                         float32_vs_float64=stats(z, z64), max_abs_ref=float(z.abs().max()))
+        print(case, out[case])
+    out['_what'] = ('the reference (tgm.nn TemporalAttention / TGAT, eval mode, torch-CPU float32) against ITSELF on the g5 fixtures: one BLAS thread vs the '
+                    'default, and float32 vs float64 arithmetic; max_abs = max |a - b|, worst_multiple_of_bound = max |a - b| / (1e-5 max(1, |b|)), '
+                    'worst_relative_where_ref_ge_1e_2 = max |a - b| / |b| over |b| >= 1e-2.  Written by tests/golden/make_golden.py g5n in the build container.')
+    with open(os.path.join(HERE, 'g5_self_noise.json'), 'w') as f:
+        json.dump(out, f, indent=1)
 
 
 def g6_case():
@@ -562,6 +629,6 @@ if __name__ == '__main__':
 
     warnings.filterwarnings('ignore')
     only = sys.argv[1:]
-    for fam, fn in [('g1', g1_cases), ('g2', g2_cases), ('g3', g3_case), ('g4', g4_case), ('g5', g5_cases), ('g6', g6_case), ('g7', g7_case), ('g8', g8_cases), ('g9', g9_case), ('g10', g10_case), ('g11', g11_cases), ('g12', g12_case)]:
+    for fam, fn in [('g1', g1_cases), ('g2', g2_cases), ('g3', g3_case), ('g4', g4_case), ('g5', g5_cases), ('g5n', g5_self_noise), ('g6', g6_case), ('g7', g7_case), ('g8', g8_cases), ('g9', g9_case), ('g10', g10_case), ('g11', g11_cases), ('g12', g12_case)]:
         if not only or fam in only:
             fn()

@@ -3,6 +3,12 @@ C ABI, against the reference's outputs (goldens g5 / g6) and the torch-fp32 orac
 
 Tolerance (fp32 path; BASELINE north_star: 1e-5 relative):
     |got - ref| <= 1e-5 * max(1, |ref|)   element-wise.
+Why not a pure relative 1e-5: the REFERENCE is not that close to itself.  tests/golden/g5_self_noise.json (written by make_golden.py in
+the build container) holds, per g5 fixture, the distance between the reference's float32 forward and the same forward in float64
+arithmetic: at the example widths max |d| = 1.2e-6 and a worst pure relative error of 3.5e-5 on elements with |ref| >= 1e-2 -- the
+float32 rounding of the reference's own summation order.  A different (equally valid) order, like the folded attention here, lands
+at the same distance from the reference (1.2e-6 / 4.7e-5), which a pure 1e-5 relative bar would call a failure.  Every check prints its
+error as a multiple of the bound AND of the reference's own float32 error for the matching fixture.
 """
 import json
 import os
@@ -18,6 +24,27 @@ DEV = 'cuda'
 RTOL = 1e-5
 
 
+def _self_noise(tag):
+    """(max abs, worst relative) distance of the reference's float32 forward from float64 arithmetic on the fixture `tag` belongs to
+    (the example-width fixture for the headline-shape checks), or None for checks without a fixture."""
+    global _NOISE
+    try:
+        _NOISE
+    except NameError:
+        try:
+            with open(os.path.join(gu.GOLDEN_DIR, 'g5_self_noise.json')) as f:
+                _NOISE = json.load(f)
+        except OSError:
+            _NOISE = {}
+    key = next((k for k in _NOISE if not k.startswith('_') and tag.startswith(k)), None)
+    if key is None and ('headline' in tag or 'example' in tag):
+        key = 'g5_tgat_example_dims'
+    if key is None or key not in _NOISE:
+        return None
+    n = _NOISE[key]['float32_vs_float64']
+    return n['max_abs'], n['worst_relative_where_ref_ge_1e_2']
+
+
 def close(got, ref, tag):
     got, ref = got.detach().cpu(), ref.detach().cpu()
     assert got.shape == ref.shape and got.dtype == torch.float32, f'{tag}: {got.shape} {got.dtype} vs {ref.shape}'
@@ -29,11 +56,15 @@ def close(got, ref, tag):
     # meaningful).  TGMX_PARITY_STATS=<file>: also record the worst PURE relative error over the elements with |ref| >= 1e-2.
     big = ref.abs() >= 1e-2
     rel = (err[big] / ref.abs()[big]).max().item() if bool(big.any()) else 0.0
-    print(f'[parity] {tag}: max abs err {err.max().item():.3e}, worst relative err (|ref| >= 1e-2) {rel:.3e}, {worst:.2f}x the bound')  # pytest -rP
+    noise = _self_noise(tag)
+    vs_ref = (f"; {err.max().item() / noise[0]:.1f}x / {rel / noise[1] if noise[1] else 0:.1f}x the reference's own float32-vs-float64 error "
+              f'({noise[0]:.1e} abs / {noise[1]:.1e} rel)') if noise else ''
+    print(f'[parity] {tag}: max abs err {err.max().item():.3e}, worst relative err (|ref| >= 1e-2) {rel:.3e}, {worst:.2f}x the bound{vs_ref}')  # pytest -rP
     if os.environ.get('TGMX_PARITY_STATS'):
         with open(os.environ['TGMX_PARITY_STATS'], 'a') as f:
             f.write(json.dumps({'case': tag, 'elements': got.numel(), 'max_abs_err': err.max().item(), 'worst_multiple_of_bound': worst,
-                                'worst_relative_err_where_ref_ge_1e-2': rel, 'max_abs_ref': ref.abs().max().item()}) + '\n')
+                                'worst_relative_err_where_ref_ge_1e-2': rel, 'max_abs_ref': ref.abs().max().item(),
+                                'reference_float32_vs_float64': None if noise is None else {'max_abs': noise[0], 'worst_relative_where_ref_ge_1e-2': noise[1]}}) + '\n')
     assert worst <= 1.0, f'{tag}: worst error {worst:.2f}x the 1e-5 bound (max abs err {err.max().item():.3e})'
 
 

@@ -49,3 +49,23 @@ def test_tgat_forward_matches_reference(case, impl):
     z = fn(params, meta['dims']['n_heads'], **inputs)
     assert z.shape == z_ref.shape and z.dtype == torch.float32
     close(z, z_ref, f'{case}/{impl}')
+
+
+def test_reference_self_noise_fixture_is_consistent():
+    """tests/golden/g5_self_noise.json (make_golden.py g5n, build container): the replay that measured the reference against itself
+    reproduced every stored g5 output bit for bit, and the reference's own float32-vs-float64 distance -- the scale the GPU parity
+    checks print their errors against -- is what the float bar's docstring says it is (pure relative 1e-5 is BELOW it)."""
+    import json
+    import os
+
+    import golden_util as gu
+
+    with open(os.path.join(gu.GOLDEN_DIR, 'g5_self_noise.json')) as f:
+        noise = json.load(f)
+    cases = [k for k in noise if not k.startswith('_')]
+    assert set(cases) == set(gu.ATTN_CASES) | set(gu.TGAT_CASES)
+    for k in cases:
+        assert noise[k]['reproduces_fixture'], k
+        n = noise[k]['float32_vs_float64']
+        assert 0 < n['max_abs'] < 1e-5 and n['worst_multiple_of_bound'] < 1.0, (k, n)  # the hybrid bound holds for the reference itself
+    assert noise['g5_tgat_example_dims']['float32_vs_float64']['worst_relative_where_ref_ge_1e_2'] > 1e-5
