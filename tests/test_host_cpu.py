@@ -338,3 +338,28 @@ def test_modules_deep_copy_and_pickle_without_their_derived_caches():
     twin = copy.deepcopy(enc)
     assert twin._desc_cache is None and twin._desc_struct is None and twin._workspace is None and '_tgmx_plist' not in twin.__dict__
     assert enc._desc_cache is not None  # the original keeps its own
+
+
+def test_rings_under_a_process_group_warn_once_and_name_the_static_index(monkeypatch):
+    """RecencyNeighborHook(mode='ring') under torch.distributed with more than one rank: one UserWarning that names mode='csr' and
+    batch_shard (the multi-GPU mode); nothing for a single rank."""
+    import warnings
+
+    import torch.distributed as dist
+
+    from tgm_amd.hooks import RecencyNeighborHook
+
+    hook = RecencyNeighborHook(10, [2], ['edge_src'], ['edge_time'])
+    monkeypatch.setattr(RecencyNeighborHook, '_warned_world', False, raising=False)
+    monkeypatch.setattr(dist, 'is_initialized', lambda: True)
+    monkeypatch.setattr(dist, 'get_world_size', lambda *a, **k: 1)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        hook._warn_rings_under_world()
+    assert not w
+    monkeypatch.setattr(dist, 'get_world_size', lambda *a, **k: 8)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        hook._warn_rings_under_world()
+        hook._warn_rings_under_world()
+    assert len(w) == 1 and "mode='csr'" in str(w[0].message) and 'batch_shard' in str(w[0].message)

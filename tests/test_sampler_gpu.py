@@ -200,6 +200,17 @@ def test_ring_step_variants(N, E, D, tmax, num_nbrs, bs, validate):
     _check_ring_against_oracle(N, E, D, tmax, num_nbrs, bs, False, 'int32', validate=validate)
 
 
+@pytest.mark.skipif(any(os.environ.get(k) for k in ('TGMX_NO_RIDE', 'TGMX_NO_FUSE')), reason='the A/B knob removes the riders')
+@pytest.mark.parametrize('D', [64, 4])
+def test_riders_in_a_launch_many_times_larger_than_residency(D):
+    """The riders' barrier (include/tgm_amd.h, "Riders and workgroup dispatch order") assumes that the riders -- the FIRST <= 16
+    workgroups of a lookup launch -- are resident together, which in-order workgroup dispatch guarantees however large the grid is.
+    Here the launch that carries them is 7 x what the chip holds at once: 60 000 hop-1 seeds (15 000 four-wave workgroups against
+    ~2 048 resident) behind an m = 2 000 update (eight chunk riders, their barrier, the merge), wide rows (hops 0 + 1 fused) and narrow
+    ones (hop 0's launch carries them).  Bit-exact against the oracle on every batch, no status bit, no timeout."""
+    _check_ring_against_oracle(20_000, 12_000, D, 2_600_000, [20, 4], 1000, False, 'int32', validate='deferred')
+
+
 def _check_ring_against_oracle(N, E, D, tmax, num_nbrs, bs, directed, key_arith, **hook_kw):
     from oracle.ring_port import RingSamplerCPU
 

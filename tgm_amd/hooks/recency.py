@@ -256,6 +256,25 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
             raise RuntimeError('tgmx_recency_step: the update scratch was not zero-initialised (internal error)')
 
     # ------------------------------------------------------------------
+    def _warn_rings_under_world(self) -> None:
+        """One process per GPU with streaming rings: every rank has to replay the WHOLE global batch's update on its ring replica
+        (the serial fraction: at 8 ranks and 4096 edges per rank that is a 65 536-entry update per step, modelled 4.6-4.8 x instead
+        of 7.6 x at 8 GPUs).  The static index has no state to replicate: say so once."""
+        try:
+            import torch.distributed as dist
+
+            world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        except Exception:
+            world = 1
+        if world > 1 and not getattr(RecencyNeighborHook, '_warned_world', False):
+            RecencyNeighborHook._warned_world = True
+            warnings.warn(
+                f"RecencyNeighborHook(mode='ring') under torch.distributed (world size {world}): every rank replays the whole global batch's "
+                "ring update, which does not shrink with the number of GPUs.  For multi-GPU jobs build the static index instead -- "
+                "RecencyNeighborHook(..., mode='csr', batch_size=<loader batch size>): same sampled neighbours, no per-batch state, and whole "
+                'batches can be dealt to ranks with DGDataLoader(batch_shard=(rank, world)).  (INTEGRATION.md section 4)',
+                UserWarning, stacklevel=3)
+
     def _ensure_state(self, dg: DGraph, device: torch.device) -> None:
         if self._edge_x_dim is None:
             self._edge_x_dim = dg.edge_x_dim or 0
@@ -274,6 +293,7 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
             self._status = torch.zeros(1, dtype=torch.int32, device=device)
         if self._mode == 'ring':
             if self._ring is None:
+                self._warn_rings_under_world()
                 self._ring = torch.empty((N * B, 2), dtype=torch.int64, device=device)
                 self._ring_x = torch.empty((N * B, max(D, 1)), dtype=torch.float32, device=device) if D else None
                 self._write_pos = torch.empty(N, dtype=torch.int32, device=device)
