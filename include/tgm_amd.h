@@ -150,6 +150,23 @@ int tgmx_ring_update(tgmx_adj_t* ring, int32_t* write_pos, float* ring_x, int32_
  * follow the last lookup.  Hop 0 and hop 1 are one launch when tgmx_recency_step_plan says so (hop 1's waves re-derive
  * their seed from the unchanged rings instead of waiting for hop 0's output).
  *   timed_hop = 0 or 1 then times that one launch.
+ *
+ * Riders and workgroup dispatch order (what the in-kernel cross-workgroup waits rely on).  The update workgroups that ride a
+ * lookup launch ("riders": one per 256-entry chunk of the batch, at most 16) meet at a barrier inside that launch: two
+ * words at the head of `scratch` (arrivals, generation; self-resetting, hence "zero at first use").  A barrier between
+ * workgroups of one launch is only safe if all of them are resident at the same time.  The riders are therefore the launch's
+ * FIRST workgroups (blockIdx 0 .. riders - 1), and the library relies on the hardware dispatching the workgroups of a launch in
+ * ascending blockIdx order: the first 16 workgroups of any launch fit the chip together (one per CU is enough), so they are
+ * all dispatched before any lookup workgroup behind them can occupy a slot, whatever the grid size (tests/test_sampler_gpu.py
+ * runs them in a launch 7 x larger than what the chip holds at once).  Nothing else waits across workgroups by default: the
+ * opt-in tail commit (environment TGMX_TAIL=1: the LAST workgroups of a launch wait for every earlier one, counted at scratch
+ * words 2.., then write the rings) relies on the same order -- the workgroups a tail waits for all precede it in dispatch order,
+ * so they are running or finished by the time it is resident.  If either wait ever fails to complete -- a scratch head that was
+ * not zero at first use, or a device that dispatched out of order -- it gives up after about a second of polling, sets
+ * TGMX_ST_SCRATCH in `status` and the call's update is skipped or incomplete (the rings of that batch are then unspecified;
+ * the lookups' outputs are unaffected): a reported error, never a hang (test_dirty_scratch_head_is_reported_not_hung).
+ * TGMX_NO_RIDE=1 runs the same update as launches of its own (no in-kernel wait at all).
+ *
  *   n_groups = 0: hop-0 seeds are already in seed_nid0 / seed_ts0 (S0 of them).
  *   n_hops   = 0: update only.          n = 0: lookups only.
  *   timed_hop >= 0: ev_start / ev_stop are recorded around that hop's lookup launch. */
@@ -630,6 +647,15 @@ int tgmx_tgn_store_batch(const int32_t* src, const int32_t* dst, const int64_t* 
                          int64_t base, int32_t* log_other, int64_t* log_t, float* log_raw, int64_t* st_lo_s,
                          int32_t* st_cnt_s, int64_t* st_lo_d, int32_t* st_cnt_d, tgmx_stream_t stream);
 
+/* Compaction of TGNMemory's append-only message log (ours: the reference keeps a Python dict of per-node tensors, tgn.py:218-229): the live
+ * windows -- (st_lo, st_cnt) per role and node -- are packed, in (role, node) order, to the front of the fresh log tensors new_*, and
+ * st_lo_* are re-pointed (0 for an empty window).  The caller knows the total (the sum of the counts) and sizes new_* for it.
+ * workspace >= tgmx_tgn_compact_workspace_bytes(num_nodes).  One scan + one move launch. */
+size_t tgmx_tgn_compact_workspace_bytes(int32_t num_nodes);
+int tgmx_tgn_compact(int64_t* st_lo_s, const int32_t* st_cnt_s, int64_t* st_lo_d, const int32_t* st_cnt_d, int32_t num_nodes,
+                     const int32_t* old_other, const int64_t* old_t, const float* old_raw, int32_t D, int32_t* new_other, int64_t* new_t,
+                     float* new_raw, void* workspace, size_t workspace_bytes, tgmx_stream_t stream);
+
 /* TGNMemory._get_updated_memory (tgn.py:191-216) and GraphAttentionEmbedding.forward (tgn.py:30-40, PyG TransformerConv) as
  * ONE call each (inference / no-grad paths): the same launches, in the same order, as the building blocks above composed by
  * the host -- aggregate, gather, the two GRU GEMMs, gates; four stacked projections, edge encoding, lin_edge GEMM, segment
@@ -674,6 +700,12 @@ int tgmx_tgn_edge_list(const int32_t* seed, const int32_t* nbr, const int64_t* n
                        int32_t D, const int32_t* uniq, int64_t U, const int64_t* uniq_count /* device-side U, NULL = use U */,
                        int64_t cap, int64_t* row_off, int64_t* edge_index, int64_t* edge_t, float* edge_x, int64_t* count,
                        tgmx_stream_t stream);
+/* The same with edge features BY ID (RecencyNeighborHook(edge_features='by_id'): the sampler publishes the store id of the edge behind every
+ * slot, tgmx_recency_step_t.out_eid, instead of copying its feature row): edge_x[e] = edge_table[nbr_eid of the slot] -- the dense
+ * [S, k, D] copies of recency.py:287-319 are never made (at the review shape: 11 MB per batch that the TGN model never reads beyond hop 0). */
+int tgmx_tgn_edge_list_by_id(const int32_t* seed, const int32_t* nbr, const int64_t* nbr_t, const int32_t* nbr_eid, const float* edge_table,
+                             int64_t S, int32_t k, int32_t D, const int32_t* uniq, int64_t U, const int64_t* uniq_count, int64_t cap,
+                             int64_t* row_off, int64_t* edge_index, int64_t* edge_t, float* edge_x, int64_t* count, tgmx_stream_t stream);
 
 /* torch.nn.GRUCell gates from gi = x W_ih^T + b_ih and gh = h W_hh^T + b_hh ([R, 3M], r|z|n). */
 int tgmx_tgn_gru_gate(const float* gi, const float* gh, const float* h, int32_t M, int64_t R,
@@ -737,6 +769,16 @@ int tgmx_tgcn_concat(const float* a, int64_t lda, const float* b, const float* g
 /* out = sigmoid(u_pre) * H + (1 - sigmoid(u_pre)) * tanh(c_pre), n elements       tgcn.py:151-156 */
 int tgmx_tgcn_output(const float* u_pre, const float* c_pre, const float* H, int64_t n, float* out,
                      tgmx_stream_t stream);
+
+/* Backward of the TGCN cell (tgcn.py:151-156 under loss.backward(), examples/nodeproppred/tgcn.py:92).  out = U H + (1 - U) tanh(c_pre),
+ * U = sigmoid(u_pre):  du_pre = dout (H - Cc) U (1 - U), dc_pre = dout (1 - U) (1 - Cc^2), dH = dout U (n = N * C elements each). */
+int tgmx_tgcn_gate_backward(const float* dout, const float* u_pre, const float* c_pre, const float* H, int64_t n, float* du_pre,
+                            float* dc_pre, float* dH, tgmx_stream_t stream);
+/* The gates' contributions to dH and the reset gate's pre-activation gradient.  dcat_x = dx_pre W_x are [N, 2C] (the gradient of the
+ * gate's input [conv_x(X) | H] resp. [conv_c(X) | H R]); any of the three may be NULL (skipped):
+ *   dcat_c: dr_pre = dcat_c[:, C:] H R (1 - R) (written when dr_pre != NULL), dH += dcat_c[:, C:] R;   dcat_u, dcat_r: dH += dcat[:, C:]. */
+int tgmx_tgcn_reset_backward(const float* dcat_c, const float* dcat_u, const float* dcat_r, const float* r_pre, const float* H, int32_t C,
+                             int64_t N, float* dr_pre, float* dH, tgmx_stream_t stream);
 
 /* RandomNegativeEdgeSamplerHook (tgm/hooks/negatives/sampler.py:45-65): out_neg[i] uniform in [low, high), out_time =
  * copy of time_in (the reference: torch.randint + edge_time.clone()), one launch.  Counter-based generator keyed by

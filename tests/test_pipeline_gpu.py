@@ -392,9 +392,10 @@ def test_lowered_tgn_tail_dedup_and_edge_list():
 
 
 def test_edge_features_by_id_with_the_tgn_tail():
-    """ RecencyNeighborHook(edge_features='by_id') in front of DeduplicationHook -> SampledEdgeListHook under the DEFAULT
-    loader: the lowered post block reads the dense [S, k, D] copies, which that mode does not make, so the edge-list hook must
-    stay behind the lowered prefix (3 hooks lowered, not 4) -- and every tensor equals the dense chain's."""
+    """RecencyNeighborHook(edge_features='by_id') in front of DeduplicationHook -> SampledEdgeListHook under the DEFAULT loader
+    (that combination once failed in the lowered post block, which read the dense [S, k, D] copies the mode does not make).
+    Round 4: the whole chain lowers (4 hooks) and the post block writes the list's feature rows from the resident store by edge id
+    (tgmx_tgn_edge_list_by_id); hook by hook the edge-list hook takes the same entry point.  Every tensor equals the dense chain's."""
     from tgm_amd import DGData, DGDataLoader, DGraph
     from tgm_amd.hooks import DeduplicationHook, HookManager, RandomNegativeEdgeSamplerHook, RecencyNeighborHook, SampledEdgeListHook
 
@@ -424,7 +425,7 @@ def test_edge_features_by_id_with_the_tgn_tail():
                 for h in range(2):
                     _same(a.nbr_edge_x[h], other.nbr_edge_x[h], f'batch {n} nbr_edge_x[{h}]')
         assert n == 14
-        assert dense._compiled[1].n_lowered == 4 and by_id._compiled[1].n_lowered == 3
+        assert dense._compiled[1].n_lowered == 4 and by_id._compiled[1].n_lowered == 4
 
 
 # ---- the loader's DEFAULT: lowered chain, fresh-tensor semantics from liveness-checked output sets (round 3) --------------------

@@ -60,6 +60,9 @@ SIGNATURES = {
     'tgmx_tgn_commit_assoc': (c_int32, [_P, _P, c_int64, _P, c_int64, _P, _P, c_int32, c_int32, _P, _P, _P, _P]),
     'tgmx_tgn_store_batch': (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int64, _P, _P, _P, _P, _P, _P, _P, _P]),
     'tgmx_tgn_edge_list': (c_int32, [_P, _P, _P, _P, c_int64, c_int32, c_int32, _P, c_int64, _P, c_int64, _P, _P, _P, _P, _P, _P]),
+    'tgmx_tgn_compact_workspace_bytes': (c_size_t, [c_int32]),
+    'tgmx_tgn_compact': (c_int32, [_P, _P, _P, _P, c_int32, _P, _P, _P, c_int32, _P, _P, _P, _P, c_size_t, _P]),
+    'tgmx_tgn_edge_list_by_id': (c_int32, [_P, _P, _P, _P, _P, c_int64, c_int32, c_int32, _P, c_int64, _P, c_int64, _P, _P, _P, _P, _P, _P]),
     'tgmx_tgn_gru_gate': (c_int32, [_P, _P, _P, c_int32, c_int64, _P, _P]),
     'tgmx_tgn_commit': (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int64, _P, _P, _P]),
     'tgmx_tconv_edge_attr': (c_int32, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int64, _P, _P]),
@@ -67,6 +70,8 @@ SIGNATURES = {
     'tgmx_gcn_norm_dense': (c_int32, [_P, _P, _P, c_int64, c_int64, ctypes.c_float, c_int32, _P, c_int64, _P, _P]),
     'tgmx_tgcn_concat': (c_int32, [_P, c_int64, _P, _P, c_int32, c_int64, _P, _P]),
     'tgmx_tgcn_output': (c_int32, [_P, _P, _P, c_int64, _P, _P]),
+    'tgmx_tgcn_gate_backward': (c_int32, [_P, _P, _P, _P, c_int64, _P, _P, _P, _P]),
+    'tgmx_tgcn_reset_backward': (c_int32, [_P, _P, _P, _P, _P, c_int32, c_int64, _P, _P, _P]),
     'tgmx_sgemm_tn_workspace_bytes': (c_size_t, [c_int64, c_int32, c_int32, c_int32]),
     'tgmx_sgemm_tn': (
         c_int32,

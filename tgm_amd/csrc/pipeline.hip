@@ -35,8 +35,13 @@ static int pipeline_post(const tgmx_pipeline_t* p, const tgmx_recency_step_t& s,
     const int h = post->edge_hop;
     TGMX_REQUIRE(post->dedup && h < s.n_hops, "pipeline_step: the edge list needs the unique ids and a sampled hop");
     const int32_t* seeds = h == 0 ? out->seed_nid0 : s.out_nid[h - 1];
-    const int rc = tgmx_tgn_edge_list(seeds, s.out_nid[h], s.out_ts[h], s.out_x[h], rows[h], s.k[h], s.D, post->uniq_out, 0, post->dev_sizes,
-                                      post->edge_cap, post->row_off, post->edge_index, post->edge_t, post->edge_x, post->dev_sizes + 2, stream);
+    // edge features by id (the lookups published edge ids, no dense copy): the rows come from the resident store where the list is written
+    const bool by_id = !s.out_x[h] && s.out_eid[h] && s.D > 0;
+    const int rc = by_id ? tgmx_tgn_edge_list_by_id(seeds, s.out_nid[h], s.out_ts[h], s.out_eid[h], p->edge_x, rows[h], s.k[h], s.D, post->uniq_out, 0,
+                                                    post->dev_sizes, post->edge_cap, post->row_off, post->edge_index, post->edge_t, post->edge_x,
+                                                    post->dev_sizes + 2, stream)
+                         : tgmx_tgn_edge_list(seeds, s.out_nid[h], s.out_ts[h], s.out_x[h], rows[h], s.k[h], s.D, post->uniq_out, 0, post->dev_sizes,
+                                              post->edge_cap, post->row_off, post->edge_index, post->edge_t, post->edge_x, post->dev_sizes + 2, stream);
     if (rc) return rc;
   }
   if (hipMemcpyAsync(post->host_sizes, post->dev_sizes, 3 * sizeof(int64_t), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||

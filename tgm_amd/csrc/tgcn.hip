@@ -78,9 +78,78 @@ __global__ __launch_bounds__(256) void tgcn_output_kernel(const float* u_pre, co
   }
 }
 
+// ---- backward of the cell (training: examples/nodeproppred/tgcn.py:92 calls loss.backward() through tgcn.py:151-156) ----------------
+// out = U H + (1 - U) Cc,  U = sigmoid(u_pre), Cc = tanh(c_pre):
+//   du_pre = dout (H - Cc) U (1 - U),   dc_pre = dout (1 - U) (1 - Cc^2),   dH = dout U   (the direct term; the gates' terms are added below)
+__global__ __launch_bounds__(256) void tgcn_gate_backward_kernel(const float* __restrict__ dout, const float* __restrict__ u_pre,
+                                                                 const float* __restrict__ c_pre, const float* __restrict__ H, long long n,
+                                                                 float* __restrict__ du_pre, float* __restrict__ dc_pre, float* __restrict__ dH) {
+  const long long step = (long long)gridDim.x * blockDim.x;
+  for (long long x = (long long)blockIdx.x * blockDim.x + threadIdx.x; x < n; x += step) {
+    const float u = 1.f / (1.f + expf(-u_pre[x]));
+    const float cc = tanhf(c_pre[x]);
+    const float g = dout[x];
+    du_pre[x] = g * (H[x] - cc) * u * (1.f - u);
+    dc_pre[x] = g * (1.f - u) * (1.f - cc * cc);
+    dH[x] = g * u;
+  }
+}
+
+// The candidate gate read [conv_c(X) | H R] (R = sigmoid(r_pre)): with dcat_c = dc_pre W_c its right half is d(H R), so
+//   dr_pre = d(HR) H R (1 - R),   dH += d(HR) R  (+ the right halves of dcat_u = du_pre W_u and, when given, dcat_r = dr_pre W_r: the
+// update and reset gates read H itself).  dcat_* are [N, 2C]; a NULL one is skipped; dr_pre NULL: only the accumulation.
+__global__ __launch_bounds__(256) void tgcn_reset_backward_kernel(const float* __restrict__ dcat_c, const float* __restrict__ dcat_u,
+                                                                  const float* __restrict__ dcat_r, const float* __restrict__ r_pre,
+                                                                  const float* __restrict__ H, int C, long long N, float* __restrict__ dr_pre,
+                                                                  float* __restrict__ dH) {
+  const long long total = N * C;
+  const long long step = (long long)gridDim.x * blockDim.x;
+  for (long long x = (long long)blockIdx.x * blockDim.x + threadIdx.x; x < total; x += step) {
+    const long long i = x / C;
+    const int c = (int)(x - i * C);
+    const long long right = i * 2 * C + C + c;
+    float acc = dH[x];
+    if (dcat_c) {
+      const float r = 1.f / (1.f + expf(-r_pre[x]));
+      const float dhr = dcat_c[right];
+      if (dr_pre) dr_pre[x] = dhr * H[x] * r * (1.f - r);
+      acc += dhr * r;
+    }
+    if (dcat_u) acc += dcat_u[right];
+    if (dcat_r) acc += dcat_r[right];
+    dH[x] = acc;
+  }
+}
+
 }  // namespace tgmx
 
 using namespace tgmx;
+
+extern "C" int tgmx_tgcn_gate_backward(const float* dout, const float* u_pre, const float* c_pre, const float* H, int64_t n, float* du_pre,
+                                       float* dc_pre, float* dH, tgmx_stream_t stream) {
+  TGMX_REQUIRE(n >= 0, "tgcn_gate_backward: bad size");
+  if (n == 0) return TGMX_OK;
+  TGMX_REQUIRE(dout && u_pre && c_pre && H && du_pre && dc_pre && dH, "tgcn_gate_backward: null pointer");
+  long long blocks = (n + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(tgcn_gate_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dout, u_pre, c_pre, H, (long long)n, du_pre,
+                     dc_pre, dH);
+  TGMX_CHECK_LAUNCH("tgcn_gate_backward");
+  return TGMX_OK;
+}
+
+extern "C" int tgmx_tgcn_reset_backward(const float* dcat_c, const float* dcat_u, const float* dcat_r, const float* r_pre, const float* H, int32_t C,
+                                        int64_t N, float* dr_pre, float* dH, tgmx_stream_t stream) {
+  TGMX_REQUIRE(C > 0 && N >= 0, "tgcn_reset_backward: bad sizes");
+  if (N == 0) return TGMX_OK;
+  TGMX_REQUIRE(dH && (!dcat_c || (r_pre && H)), "tgcn_reset_backward: null pointer");
+  long long blocks = (N * C + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(tgcn_reset_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dcat_c, dcat_u, dcat_r, r_pre, H, C,
+                     (long long)N, dr_pre, dH);
+  TGMX_CHECK_LAUNCH("tgcn_reset_backward");
+  return TGMX_OK;
+}
 
 extern "C" int tgmx_gcn_norm_dense(const int64_t* src, const int64_t* dst, const float* weight, int64_t E, int64_t N, float fill,
                                    int32_t add_self_loops, float* A, int64_t ld, float* workspace, tgmx_stream_t stream) {

@@ -10,6 +10,9 @@
 // per node row, lanes across the message columns.  The dense GRU contractions reuse
 // sgemm_nt (exact-fp32 MFMA) from tgat.hip.
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
 
 #include "common.h"
 
@@ -478,26 +481,67 @@ __global__ __launch_bounds__(1024) void tgn_store_batch_kernel(const StoreBatchA
   }
 }
 
+// ---- message-log compaction (TGNMemory's append-only log, nn/tgn.py _compact_into) ---------------------------------------------
+// The live windows -- per role and node (lo, cnt) -- move, in (role, node) order, to the front of fresh log tensors.  Host side this was
+// ~25 torch ops over [num_nodes]-sized temporaries, 1.1 ms per compaction at the review shape (every ~75 batches: 15 us of every batch);
+// here: one scan of the 2 N counts and one move launch.
+struct CompactCount {
+  const int32_t* cnt_s;
+  const int32_t* cnt_d;
+  int N;
+  __device__ long long operator()(int i) const { return (long long)(i < N ? cnt_s[i] : cnt_d[i - N]); }
+};
+
+__global__ __launch_bounds__(256) void tgn_compact_move_kernel(int64_t* __restrict__ lo_s, const int32_t* __restrict__ cnt_s, int64_t* __restrict__ lo_d,
+                                                               const int32_t* __restrict__ cnt_d, int N, const long long* __restrict__ pos,
+                                                               const int32_t* __restrict__ old_other, const int64_t* __restrict__ old_t,
+                                                               const float* __restrict__ old_raw, int D, int32_t* __restrict__ new_other,
+                                                               int64_t* __restrict__ new_t, float* __restrict__ new_raw) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // (role, node): role 0's nodes first
+  if (i >= 2 * N) return;
+  const int role = i >= N, v = role ? i - N : i;
+  int64_t* lo = role ? lo_d : lo_s;
+  const int c = role ? cnt_d[v] : cnt_s[v];
+  if (c == 0) {
+    lo[v] = 0;
+    return;
+  }
+  const long long from = lo[v], to = pos[i];
+  for (int j = 0; j < c; ++j) {
+    new_other[to + j] = old_other[from + j];
+    new_t[to + j] = old_t[from + j];
+    for (int d = 0; d < D; ++d) new_raw[(to + j) * D + d] = old_raw[(from + j) * D + d];
+  }
+  lo[v] = to;
+}
+
 // ---- counting grouping of a batch's edges by target (tgmx_tconv_forward) -----------------------------------------------------
 // count[U] (zero on entry: the histogram pass rode tconv_edge_attr_kernel) -> seg_lo / seg_hi / cursor = exclusive prefix sums, and
 // count is zeroed again for the next call.  One workgroup, 16 consecutive counts per thread and pass (16 K targets per pass).
 __global__ __launch_bounds__(1024) void tconv_group_scan_kernel(int32_t* __restrict__ count, long long U, int64_t* __restrict__ seg_lo,
                                                                 int64_t* __restrict__ seg_hi, int64_t* __restrict__ cursor) {
-  constexpr int kPer = 16;
+  constexpr int kPer = 8;  // (8 K targets per pass: a review-shaped batch has ~8 000 unique nodes -- every thread busy, one pass)
   __shared__ long long wave_tot[16];
   __shared__ long long carry_s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) carry_s = 0;
   __syncthreads();
+  const bool vec = ((reinterpret_cast<uintptr_t>(count) | reinterpret_cast<uintptr_t>(seg_lo) | reinterpret_cast<uintptr_t>(seg_hi) |
+                     reinterpret_cast<uintptr_t>(cursor)) & 15) == 0;
   for (long long u0 = 0; u0 < U; u0 += 1024 * kPer) {
     const long long ub = u0 + (long long)tid * kPer;
+    const bool full = vec && ub + kPer <= U;
     int c[kPer];
+    if (full) {
+      const int4 a = reinterpret_cast<const int4*>(count + ub)[0], b = reinterpret_cast<const int4*>(count + ub)[1];
+      c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w; c[4] = b.x; c[5] = b.y; c[6] = b.z; c[7] = b.w;
+    } else {
+#pragma unroll
+      for (int q = 0; q < kPer; ++q) c[q] = ub + q < U ? count[ub + q] : 0;
+    }
     long long v = 0;
 #pragma unroll
-    for (int q = 0; q < kPer; ++q) {
-      c[q] = ub + q < U ? count[ub + q] : 0;
-      v += c[q];
-    }
+    for (int q = 0; q < kPer; ++q) v += c[q];
     long long incl = v;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -508,15 +552,35 @@ __global__ __launch_bounds__(1024) void tconv_group_scan_kernel(int32_t* __restr
     __syncthreads();
     long long before = carry_s;
     for (int q = 0; q < wave; ++q) before += wave_tot[q];
+    long long lo[kPer], hi[kPer];
     long long pos = before + incl - v;
 #pragma unroll
     for (int q = 0; q < kPer; ++q) {
-      if (ub + q < U) {
-        seg_lo[ub + q] = pos;
-        cursor[ub + q] = pos;
-        pos += c[q];
-        seg_hi[ub + q] = pos;
-        if (c[q]) count[ub + q] = 0;
+      lo[q] = pos;
+      pos += c[q];
+      hi[q] = pos;
+    }
+    if (full) {
+#pragma unroll
+      for (int q = 0; q < kPer; q += 2) {
+        const longlong2 l2{lo[q], lo[q + 1]}, h2{hi[q], hi[q + 1]};
+        *reinterpret_cast<longlong2*>(seg_lo + ub + q) = l2;
+        *reinterpret_cast<longlong2*>(cursor + ub + q) = l2;
+        *reinterpret_cast<longlong2*>(seg_hi + ub + q) = h2;
+      }
+      if (v) {
+        reinterpret_cast<int4*>(count + ub)[0] = int4{0, 0, 0, 0};
+        reinterpret_cast<int4*>(count + ub)[1] = int4{0, 0, 0, 0};
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < kPer; ++q) {
+        if (ub + q < U) {
+          seg_lo[ub + q] = lo[q];
+          cursor[ub + q] = lo[q];
+          seg_hi[ub + q] = hi[q];
+          if (c[q]) count[ub + q] = 0;
+        }
       }
     }
     __syncthreads();
@@ -578,7 +642,9 @@ struct EdgeListArgs {
   const int32_t* seed;   // [S]
   const int32_t* nbr;    // [S, k]
   const int64_t* nbr_t;  // [S, k]
-  const float* nbr_x;    // [S, k, D]
+  const float* nbr_x;    // [S, k, D]   (NULL with nbr_eid / table)
+  const int32_t* nbr_eid;  // [S, k] edge id behind every slot (-1 = pad): the feature row is table[eid]   (edge features by id)
+  const float* table;    // [E_store, D] the resident store's edge features
   const int32_t* uniq;   // [U] sorted unique ids
   const int64_t* uniq_count;  // device-side U (overrides the host value when set)
   const int64_t* row_off;
@@ -605,6 +671,7 @@ __global__ __launch_bounds__(256) void edge_list_write_kernel(const EdgeListArgs
   const int lane = lane_id();
   const int k = a.k;
   const int id = lane < k ? a.nbr[r * k + lane] : -1;
+  const int eid = (a.nbr_eid && lane < k) ? a.nbr_eid[r * k + lane] : -1;
   const bool ok = id != -1;
   const unsigned long long m = __ballot(ok);
   if (!m) return;
@@ -622,8 +689,14 @@ __global__ __launch_bounds__(256) void edge_list_write_kernel(const EdgeListArgs
   while (rest) {
     const int s = __ffsll((long long)rest) - 1;
     rest &= rest - 1;
-    const float* __restrict__ x = a.nbr_x + (r * k + s) * (long long)a.D;
-    for (int c = lane; c < a.D; c += kWave) a.ex[out * a.D + c] = x[c];
+    if (a.nbr_eid) {
+      const int e = __shfl(eid, s);  // (a valid slot of a by-id sampler carries its edge's store id)
+      const float* __restrict__ x = a.table + (long long)(e < 0 ? 0 : e) * a.D;
+      for (int c = lane; c < a.D; c += kWave) a.ex[out * a.D + c] = e < 0 ? 0.f : x[c];
+    } else {
+      const float* __restrict__ x = a.nbr_x + (r * k + s) * (long long)a.D;
+      for (int c = lane; c < a.D; c += kWave) a.ex[out * a.D + c] = x[c];
+    }
     ++out;
   }
 }
@@ -838,9 +911,10 @@ extern "C" int tgmx_tgn_store_batch(const int32_t* src, const int32_t* dst, cons
   return TGMX_OK;
 }
 
-extern "C" int tgmx_tgn_edge_list(const int32_t* seed, const int32_t* nbr, const int64_t* nbr_t, const float* nbr_x, int64_t S, int32_t k,
-                                  int32_t D, const int32_t* uniq, int64_t U, const int64_t* uniq_count, int64_t cap, int64_t* row_off,
-                                  int64_t* edge_index, int64_t* edge_t, float* edge_x, int64_t* count, tgmx_stream_t stream) {
+static int tgn_edge_list_impl(const int32_t* seed, const int32_t* nbr, const int64_t* nbr_t, const float* nbr_x, const int32_t* nbr_eid,
+                              const float* table, int64_t S, int32_t k, int32_t D, const int32_t* uniq, int64_t U, const int64_t* uniq_count,
+                              int64_t cap, int64_t* row_off, int64_t* edge_index, int64_t* edge_t, float* edge_x, int64_t* count,
+                              tgmx_stream_t stream) {
   TGMX_REQUIRE(S >= 0 && k > 0 && k <= 64 && D >= 0 && U >= 0 && cap >= S * k, "tgn_edge_list: bad sizes S=%lld k=%d cap=%lld", (long long)S, k,
                (long long)cap);
   TGMX_REQUIRE(count && row_off, "tgn_edge_list: null pointer");
@@ -849,11 +923,57 @@ extern "C" int tgmx_tgn_edge_list(const int32_t* seed, const int32_t* nbr, const
     (void)hipMemsetAsync(count, 0, sizeof(int64_t), st);
     return TGMX_OK;
   }
-  TGMX_REQUIRE(seed && nbr && nbr_t && (D == 0 || (nbr_x && edge_x)) && uniq && edge_index && edge_t, "tgn_edge_list: null pointer");
+  TGMX_REQUIRE(seed && nbr && nbr_t && (D == 0 || ((nbr_x || (nbr_eid && table)) && edge_x)) && uniq && edge_index && edge_t, "tgn_edge_list: null pointer");
   hipLaunchKernelGGL(edge_list_scan_kernel, dim3(1), dim3(1024), 0, st, nbr, (long long)S, k, row_off, count);
-  EdgeListArgs a{seed, nbr, nbr_t, nbr_x, uniq, uniq_count, row_off, edge_index, edge_t, edge_x, S, U, cap, k, D};
+  EdgeListArgs a{seed, nbr, nbr_t, nbr_x, nbr_x ? nullptr : nbr_eid, table, uniq, uniq_count, row_off, edge_index, edge_t, edge_x, S, U, cap, k, D};
   hipLaunchKernelGGL(edge_list_write_kernel, dim3((unsigned)((S + 3) / 4)), dim3(256), 0, st, a);
   TGMX_CHECK_LAUNCH("tgn_edge_list");
+  return TGMX_OK;
+}
+
+extern "C" int tgmx_tgn_edge_list(const int32_t* seed, const int32_t* nbr, const int64_t* nbr_t, const float* nbr_x, int64_t S, int32_t k,
+                                  int32_t D, const int32_t* uniq, int64_t U, const int64_t* uniq_count, int64_t cap, int64_t* row_off,
+                                  int64_t* edge_index, int64_t* edge_t, float* edge_x, int64_t* count, tgmx_stream_t stream) {
+  return tgn_edge_list_impl(seed, nbr, nbr_t, nbr_x, nullptr, nullptr, S, k, D, uniq, U, uniq_count, cap, row_off, edge_index, edge_t, edge_x, count, stream);
+}
+
+extern "C" int tgmx_tgn_edge_list_by_id(const int32_t* seed, const int32_t* nbr, const int64_t* nbr_t, const int32_t* nbr_eid, const float* edge_table,
+                                        int64_t S, int32_t k, int32_t D, const int32_t* uniq, int64_t U, const int64_t* uniq_count, int64_t cap,
+                                        int64_t* row_off, int64_t* edge_index, int64_t* edge_t, float* edge_x, int64_t* count, tgmx_stream_t stream) {
+  return tgn_edge_list_impl(seed, nbr, nbr_t, nullptr, nbr_eid, edge_table, S, k, D, uniq, U, uniq_count, cap, row_off, edge_index, edge_t, edge_x, count,
+                            stream);
+}
+
+extern "C" size_t tgmx_tgn_compact_workspace_bytes(int32_t num_nodes) {
+  if (num_nodes <= 0) return 0;
+  size_t tb = 0;
+  CompactCount cc{nullptr, nullptr, num_nodes};
+  (void)rocprim::exclusive_scan(nullptr, tb, rocprim::make_transform_iterator(rocprim::counting_iterator<int>(0), cc), (long long*)nullptr, 0ll,
+                                (size_t)2 * num_nodes, rocprim::plus<long long>());
+  return ((size_t)2 * num_nodes * sizeof(long long) + 255) / 256 * 256 + tb + 256;
+}
+
+extern "C" int tgmx_tgn_compact(int64_t* st_lo_s, const int32_t* st_cnt_s, int64_t* st_lo_d, const int32_t* st_cnt_d, int32_t num_nodes,
+                                const int32_t* old_other, const int64_t* old_t, const float* old_raw, int32_t D, int32_t* new_other, int64_t* new_t,
+                                float* new_raw, void* workspace, size_t workspace_bytes, tgmx_stream_t stream) {
+  TGMX_REQUIRE(num_nodes > 0 && D >= 0, "tgn_compact: bad sizes");
+  TGMX_REQUIRE(st_lo_s && st_cnt_s && st_lo_d && st_cnt_d && old_other && old_t && (D == 0 || (old_raw && new_raw)) && new_other && new_t && workspace,
+               "tgn_compact: null pointer");
+  TGMX_REQUIRE(workspace_bytes >= tgmx_tgn_compact_workspace_bytes(num_nodes), "tgn_compact: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  char* base = reinterpret_cast<char*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  long long* pos = reinterpret_cast<long long*>(base);
+  char* temp = base + ((size_t)2 * num_nodes * sizeof(long long) + 255) / 256 * 256;
+  size_t tb = workspace_bytes - (size_t)(temp - reinterpret_cast<char*>(workspace));
+  CompactCount cc{st_cnt_s, st_cnt_d, num_nodes};
+  if (rocprim::exclusive_scan(temp, tb, rocprim::make_transform_iterator(rocprim::counting_iterator<int>(0), cc), pos, 0ll, (size_t)2 * num_nodes,
+                              rocprim::plus<long long>(), st) != hipSuccess) {
+    set_error("tgn_compact: scan failed");
+    return TGMX_E_LAUNCH;
+  }
+  hipLaunchKernelGGL(tgn_compact_move_kernel, dim3((unsigned)((2ll * num_nodes + 255) / 256)), dim3(256), 0, st, st_lo_s, st_cnt_s, st_lo_d, st_cnt_d,
+                     (int)num_nodes, pos, old_other, old_t, old_raw, D, new_other, new_t, new_raw);
+  TGMX_CHECK_LAUNCH("tgn_compact");
   return TGMX_OK;
 }
 

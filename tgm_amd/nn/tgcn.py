@@ -5,7 +5,8 @@ Parameter names match the reference / PyG (``conv_{u,r,c}.lin.weight``, ``conv_{
 it is implemented from its published definition (parity unpinned upstream).  The three graph
 convolutions share one dense normalised adjacency and run as two exact-fp32 MFMA GEMMs
 (``A_hat @ (X [W_u|W_r|W_c])``); snapshot graphs on this path are small (tgbn-trade: 255 nodes).
-Forward only.
+With gradients enabled the same arithmetic runs inside ``torch.autograd.Function``s with a hand-written backward
+(``nn/_tgcn_train.py``: the reference trains this cell, examples/nodeproppred/tgcn.py:92).
 """
 from __future__ import annotations
 
@@ -37,6 +38,11 @@ class GCNConv(nn.Module):
     def forward(self, x: Tensor, edge_index: Tensor, edge_weight: Optional[Tensor] = None) -> Tensor:
         x = _ops._f32c(x, 'x')
         A = normalized_adjacency(edge_index, edge_weight, x.shape[0], 2.0 if self.improved else 1.0, self.add_self_loops)
+        if torch.is_grad_enabled() and (x.requires_grad or self.lin.weight.requires_grad or self.bias.requires_grad):
+            from ._tgcn_train import AdjMatmulFn
+            from ._tgn_train import LinearFn
+
+            return AdjMatmulFn.apply(A, LinearFn.apply(x, self.lin.weight, None)) + self.bias
         xwt = torch.empty((self.out_channels, x.shape[0]), dtype=torch.float32, device=x.device)
         _ops.sgemm_nt(self.lin.weight.detach(), x, xwt)  # (X W^T)^T = W X^T
         out = torch.empty((x.shape[0], self.out_channels), dtype=torch.float32, device=x.device)
@@ -82,6 +88,12 @@ class TGCN(nn.Module):
         H = torch.zeros((N, C), **f32) if H is None else _ops._f32c(H, 'H')
         stream = _native.stream_ptr()
         A = normalized_adjacency(edge_index, edge_weight, N, 2.0 if self.improved else 1.0, self.add_self_loops)
+        if torch.is_grad_enabled() and (x.requires_grad or H.requires_grad or any(p.requires_grad for p in self.parameters())):
+            from ._tgcn_train import TGCNCellFn
+
+            gates = (self.conv_u, self.conv_r, self.conv_c), (self.linear_u, self.linear_r, self.linear_c)
+            return TGCNCellFn.apply(x, A, H, *[c.lin.weight for c in gates[0]], *[c.bias for c in gates[0]], *[l.weight for l in gates[1]],
+                                    *[l.bias for l in gates[1]])  # fmt: skip
         # the three convolutions share A_hat: G = A_hat @ (X [W_u | W_r | W_c]^T) + [b_u | b_r | b_c]
         W3 = torch.cat([self.conv_u.lin.weight.detach(), self.conv_r.lin.weight.detach(), self.conv_c.lin.weight.detach()])
         b3 = torch.cat([self.conv_u.bias.detach(), self.conv_r.bias.detach(), self.conv_c.bias.detach()])

@@ -137,29 +137,28 @@ class TGNMemory(TransientCaches, nn.Module):
             if self._log_len:
                 live = int(self._st_cnt[0].sum()) + int(self._st_cnt[1].sum())  # one host read per compaction (rare)
             new_cap = max(2 * (live + extra), self._log_cap_min)
-            self._compact_into(new_cap, dev)
+            self._compact_into(new_cap, dev, live)
 
-    def _compact_into(self, new_cap: int, dev: torch.device) -> None:
+    def _compact_into(self, new_cap: int, dev: torch.device, live: Optional[int] = None) -> None:
         """Pack every live window into new log tensors of ``new_cap`` rows and re-point the windows."""
         other = torch.empty(new_cap, dtype=torch.int32, device=dev)
         t = torch.empty(new_cap, dtype=torch.int64, device=dev)
         raw = torch.empty((new_cap, max(self.raw_msg_dim, 1)), dtype=torch.float32, device=dev)
         base = 0
         if self._log_len:
-            N = self.num_nodes
-            ids = torch.arange(N, device=dev)
-            for r in (0, 1):
-                cnt, lo = self._st_cnt[r].long(), self._st_lo[r]
-                total = int(cnt.sum())
-                new_lo = torch.cumsum(cnt, 0) - cnt + base
-                if total:
-                    node_of = torch.repeat_interleave(ids, cnt, output_size=total)
-                    rows = lo[node_of] + (torch.arange(base, base + total, device=dev) - new_lo[node_of])
-                    other[base : base + total] = self._log_other[rows]
-                    t[base : base + total] = self._log_t[rows]
-                    raw[base : base + total] = self._log_raw[rows]
-                self._st_lo[r] = torch.where(cnt > 0, new_lo, torch.zeros_like(new_lo))
-                base += total
+            # one scan of the 2 N counts + one move launch (tgmx_tgn_compact); the total is the sum the caller sized new_cap from
+            lib = _native.load()
+            base = live if live is not None else int(self._st_cnt[0].sum()) + int(self._st_cnt[1].sum())
+            if base > new_cap:
+                raise RuntimeError(f'TGNMemory: {base} live message rows do not fit the new log of {new_cap}')
+            need = int(lib.tgmx_tgn_compact_workspace_bytes(self.num_nodes))
+            ws = torch.empty(need, dtype=torch.uint8, device=dev)
+            _native.check(
+                lib.tgmx_tgn_compact(self._st_lo[0].data_ptr(), self._st_cnt[0].data_ptr(), self._st_lo[1].data_ptr(), self._st_cnt[1].data_ptr(),
+                                     self.num_nodes, self._log_other.data_ptr(), self._log_t.data_ptr(), self._log_raw.data_ptr(), self.raw_msg_dim,
+                                     other.data_ptr(), t.data_ptr(), raw.data_ptr(), ws.data_ptr(), ws.numel(), _native.stream_ptr()),
+                'tgmx_tgn_compact',
+            )  # fmt: skip
         self._log_other, self._log_t, self._log_raw = other, t, raw
         self._log_len = base
 
@@ -427,14 +426,22 @@ class TGNMemory(TransientCaches, nn.Module):
 def _edge_list_enqueue(batch, hop: int):
     """Enqueue ``tgmx_tgn_edge_list`` for one hop; returns (edge_index [2, cap], edge_t [cap], edge_x [cap, D], count [1] on the device)."""
     lib = _native.load()
+    from ..core.lazy import EdgeFeaturesById
+
     seeds, nbr = batch.seed_nids[hop], batch.nbr_nids[hop]
-    nbr_t, nbr_x = batch.nbr_edge_time[hop], batch.nbr_edge_x[hop]
+    nbr_t = batch.nbr_edge_time[hop]
     _native.require_device(nbr, 'nbr_nids')
     dev = nbr.device
     S, k = nbr.shape
-    D = nbr_x.shape[-1]
     c = lambda t, dt: t if (t.dtype == dt and t.is_contiguous()) else t.to(dt).contiguous()
-    seeds, nbr, nbr_t, nbr_x = c(seeds, torch.int32), c(nbr, torch.int32), c(nbr_t, torch.int64), c(nbr_x, torch.float32)
+    seeds, nbr, nbr_t = c(seeds, torch.int32), c(nbr, torch.int32), c(nbr_t, torch.int64)
+    by_id = isinstance(batch.nbr_edge_x, EdgeFeaturesById)  # the rows come from the resident store by edge id: no dense copy is materialized
+    if by_id:
+        eid, table = c(batch.nbr_edge_x.eids[hop], torch.int32), batch.nbr_edge_x.table
+        D = table.shape[1]
+    else:
+        nbr_x = c(batch.nbr_edge_x[hop], torch.float32)
+        D = nbr_x.shape[-1]
     pending = batch.__dict__.get('_unique_dev')  # DeduplicationHook's device-side result: ids [capacity] + count, no host size needed
     if pending is not None:
         uniq, U, ucount = pending[0], 0, pending[1].data_ptr()
@@ -446,6 +453,14 @@ def _edge_list_enqueue(batch, hop: int):
     et = torch.empty(cap, dtype=torch.int64, device=dev)
     ex = torch.empty((cap, D), dtype=torch.float32, device=dev)
     ws = torch.empty(S + 2, dtype=torch.int64, device=dev)  # row offsets [S + 1] | count
+    if by_id:
+        _native.check(
+            lib.tgmx_tgn_edge_list_by_id(seeds.data_ptr(), nbr.data_ptr(), nbr_t.data_ptr(), eid.data_ptr(), table.data_ptr(), S, k, D, uniq.data_ptr(), U,
+                                         ucount, cap, ws.data_ptr(), ei.data_ptr(), et.data_ptr(), ex.data_ptr(), ws[S + 1 :].data_ptr(),
+                                         _native.stream_ptr()),
+            'tgmx_tgn_edge_list_by_id',
+        )  # fmt: skip
+        return ei, et, ex, ws[S + 1 :]
     _native.check(
         lib.tgmx_tgn_edge_list(seeds.data_ptr(), nbr.data_ptr(), nbr_t.data_ptr(), nbr_x.data_ptr(), S, k, D, uniq.data_ptr(), U, ucount, cap,
                                ws.data_ptr(), ei.data_ptr(), et.data_ptr(), ex.data_ptr(), ws[S + 1 :].data_ptr(), _native.stream_ptr()),
@@ -552,7 +567,8 @@ class TransformerConv(TransientCaches, nn.Module):
             if wsd is None or wsd[0].device != dev or wsd[0].numel() < need:
                 wsd = self._seg_ws = (torch.empty(need, dtype=torch.uint8, device=dev), torch.zeros(1, dtype=torch.int32, device=dev))
             fl = torch.empty(E * (T + D + HC), **f32)  # edge_attr [E, T + D] | eproj [E, HC]
-            ints = torch.empty(2 * E + 3 * U, dtype=torch.int64, device=dev)  # order [E] | seg_lo [U] | seg_hi [U] | cursor [U] | order_big [E]
+            Ep, Up = E + (E & 1), U + (U & 1)  # (every block 16-byte aligned: the scan kernel moves two int64 per access)
+            ints = torch.empty(2 * Ep + 3 * Up, dtype=torch.int64, device=dev)  # order [E] | seg_lo [U] | seg_hi [U] | cursor [U] | order_big [E]
             # per-target edge counts of the counting grouping: zero on entry, left zero by the call -- kept between calls
             cnt = getattr(self, '_tgt_count', None)
             if cnt is None or cnt.device != dev or cnt.numel() < U:
@@ -564,9 +580,9 @@ class TransformerConv(TransientCaches, nn.Module):
             a.src, a.tgt, a.t, a.msg, a.E, a.D, a.T = src.data_ptr(), tgt.data_ptr(), t.data_ptr(), msg.data_ptr(), E, D, T
             a.tw, a.tb, a.W4, a.b4, a.W_edge, a.H, a.C = tw.data_ptr(), tb.data_ptr(), W4.data_ptr(), b4.data_ptr(), self.lin_edge.weight.detach().data_ptr(), H, C
             a.edge_attr, a.qkvs, a.eproj = fl.data_ptr(), qkvs.data_ptr(), fl.data_ptr() + 4 * E * (T + D)
-            a.order, a.seg_lo, a.seg_hi = ints.data_ptr(), ints.data_ptr() + 8 * E, ints.data_ptr() + 8 * (E + U)
+            a.order, a.seg_lo, a.seg_hi = ints.data_ptr(), ints.data_ptr() + 8 * Ep, ints.data_ptr() + 8 * (Ep + Up)
             a.sort_ws, a.sort_ws_bytes, a.status = wsd[0].data_ptr(), wsd[0].numel(), wsd[1].data_ptr()
-            a.tgt_count, a.cursor, a.order_big = cnt.data_ptr(), ints.data_ptr() + 8 * (E + 2 * U), ints.data_ptr() + 8 * (E + 3 * U)
+            a.tgt_count, a.cursor, a.order_big = cnt.data_ptr(), ints.data_ptr() + 8 * (Ep + 2 * Up), ints.data_ptr() + 8 * (Ep + 3 * Up)
             _native.check(lib.tgmx_tconv_forward(a, _native.stream_ptr()), 'tgmx_tconv_forward')
             return qkvs[3]
         self._edge_ctx = None

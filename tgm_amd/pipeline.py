@@ -163,11 +163,9 @@ class CompiledPipeline:
             if extra <= {'neg', 'nbr_nids'} and ('neg' not in extra or neg is not None) and len(nbr._num_nbrs) + 3 <= 16:
                 dedup = hooks[i]
                 i += 1
-                # (edge features by id: the lowered post block reads the dense [S, k, D] copies, which that mode does not make --
-                # the edge-list hook then runs behind the lowered prefix, where indexing EdgeFeaturesById gathers the rows)
-                by_id_rows = nbr._by_id and (dg.edge_x_dim or 0) > 0
-                if (i < len(hooks) and type(hooks[i]) is SampledEdgeListHook and hooks[i]._id is None and hooks[i].hop < len(nbr._num_nbrs)
-                        and not by_id_rows):  # fmt: skip
+                # (edge features by id: the post block writes the list's feature rows straight from the resident store,
+                # tgmx_tgn_edge_list_by_id -- the dense [S, k, D] copies are never made)
+                if i < len(hooks) and type(hooks[i]) is SampledEdgeListHook and hooks[i]._id is None and hooks[i].hop < len(nbr._num_nbrs):
                     edges = hooks[i]
                     i += 1
         return CompiledPipeline(dg, shard, neg, nbr, i, pool, dedup, edges)

@@ -29,7 +29,10 @@ dg = DGraph(DGData.from_raw(st.ts, torch.stack([st.src, st.dst], 1), st.edge_x),
 hm = HookManager(keys=['k'])
 lo_dst = int(st.dst.min())
 hm.register('k', RandomNegativeEdgeSamplerHook(lo_dst, N))
-hook = RecencyNeighborHook(N, ks, ['edge_src', 'edge_dst', 'neg'], ['edge_time', 'edge_time', 'neg_time'], validate='deferred')
+# fast: edge features by id -- the sampler publishes edge ids, the edge list's feature rows come from the resident store (the dense [S, k, D]
+# copies, 11 MB per batch of which the model reads hop 0's 1 MB, are never made); TGMX_BENCH_TGN_DENSE=1: the dense copies as in round 3
+features = 'by_id' if (fast and not os.environ.get('TGMX_BENCH_TGN_DENSE')) else 'dense'
+hook = RecencyNeighborHook(N, ks, ['edge_src', 'edge_dst', 'neg'], ['edge_time', 'edge_time', 'neg_time'], validate='deferred', edge_features=features)
 hm.register('k', hook)
 hm.register('k', DeduplicationHook(seed_nodes_keys=['neg', 'nbr_nids']))
 if fast:
@@ -67,6 +70,23 @@ with hm.activate('k'), torch.no_grad():
     for batch in batches(0, 100):
         z2, b = step(batch)
     torch.cuda.synchronize()
+    if os.environ.get('TGMX_BENCH_TGN_PROFILE'):  # who issues the device copies of a batch?  (torch.profiler over 40 batches, then exit)
+        from torch.profiler import ProfilerActivity, profile
+
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
+            for batch in batches(100, 140):
+                z2, b = step(batch)
+            torch.cuda.synchronize()
+        print(prof.key_averages(group_by_input_shape=True).table(sort_by='cuda_time_total', row_limit=30, max_name_column_width=60))
+        for e in prof.events():
+            if 'emcpy' in e.name or 'emset' in e.name:
+                print('GPU-COPY', e.name, getattr(e, 'device_time', None), [s for s in (e.stack or [])][:4])
+        cpu = [e for e in prof.events() if e.name in ('aten::copy_', 'aten::_to_copy', 'aten::clone', 'aten::contiguous', 'aten::cat', 'aten::index', 'aten::zero_')]
+        from collections import Counter
+        c = Counter((e.name, str(e.input_shapes)[:70], next((s for s in (e.stack or []) if 'tgm_amd' in s or 'bench_tgn' in s), '?')) for e in cpu)
+        for k, v in c.most_common(25):
+            print('CPU-OP', v, k)
+        sys.exit(0)
     t0 = time.perf_counter()
     for batch in batches(100, 100 + n):
         z2, b = step(batch)
@@ -84,7 +104,7 @@ with hm.activate('k'), torch.no_grad():
     t4 = time.perf_counter()
 slots = 3 * bs * k + 3 * bs * k * ks[1]
 print(json.dumps({
-    'variant': variant,
+    'variant': variant, 'edge_features': features,
     'what': 'BASELINE cfg3: review-shaped synthetic (N=350k, E=4.8M, D=16), TGN memory (Last, GRU, 100) + TransformerConv embedding, k=[10,10], bs=512, 1 GPU',
     'pipeline_us_per_batch': 1e6 * (t2 - t0) / n, 'host_us_per_batch': 1e6 * (t1 - t0) / n,
     'events_per_s': bs * n / (t2 - t0), 'sampled_edges_per_s': slots * n / (t2 - t0),

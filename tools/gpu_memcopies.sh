@@ -13,17 +13,7 @@ import glob, os, sqlite3, sys
 dbs = sorted(glob.glob(os.path.join(sys.argv[1], '**', '*.db'), recursive=True))
 db = sqlite3.connect(dbs[-1])
 tabs = [r[0] for r in db.execute("select name from sqlite_master where type in ('table','view')")]
-cand = [t for t in tabs if 'memory_cop' in t.lower() or 'memcpy' in t.lower()]
-print('tables:', cand)
-for t in cand[:3]:
-    cols = [r[1] for r in db.execute(f'pragma table_info({t})')]
-    print(t, cols)
-    try:
-        size_col = next(c for c in cols if 'size' in c.lower() or 'bytes' in c.lower())
-        name_col = next((c for c in cols if c.lower() in ('name', 'kind', 'direction')), cols[0])
-        for r in db.execute(f'select {name_col}, {size_col}, count(*), avg(end - start) from {t} group by {name_col}, {size_col} order by count(*) desc limit 25'):
-            print(r)
-    except Exception as e:
-        print('query failed', e)
+for r in db.execute('select name, size, count(*), avg(duration), min(start) from memory_copies group by name, size order by count(*) desc limit 30'):
+    print(f'{r[0]:28s} size={r[1]:>10} n={r[2]:>6} avg={r[3] / 1e3:8.2f} us')
 PY
 rm -rf "$OUT"
