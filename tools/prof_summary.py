@@ -84,7 +84,7 @@ def gaps(db, kernel):
 def tail(db, kernel, last):
     """average duration of the LAST `last` launches of one kernel: bench.py's timed steps are the end of the run"""
     rows = [r for r in db.execute('select name, start, end, grid_x from kernels order by start').fetchall() if kernel in r[0]]
-    main_grid = max(set(r[3] for r in rows), key=lambda g: sum(1 for r in rows if r[3] == g))
+    main_grid = max(set(r[3] for r in rows), key=lambda g: (sum(1 for r in rows if r[3] == g), g))  # (ties: the larger grid = the last hop)
     rows = [r for r in rows if r[3] == main_grid][-last:]
     d = [(e - s_) / 1e3 for _, s_, e, _ in rows]
     print(f'| timed region: last {len(d)} launches of `{kernel}` | avg {sum(d) / len(d):.2f} us | min {min(d):.2f} | max {max(d):.2f} |')
@@ -112,7 +112,7 @@ def pmctail(db, kernel, last):
     grids = {}
     for d, _, g, _, _ in rows:
         grids.setdefault(g, set()).add(d)
-    main_grid = max(grids, key=lambda g: len(grids[g]))
+    main_grid = max(grids, key=lambda g: (len(grids[g]), g))  # (ties: the larger grid = the last hop)
     ids = sorted(grids[main_grid])[-last:]
     keep = set(ids)
     out = {}
