@@ -47,7 +47,35 @@ for _ in range(reps):
     n = epoch()
 torch.cuda.synchronize()
 t1 = time.perf_counter()
+# training step (round 4: the cell has a backward): forward with gradients + a linear head's loss + backward + Adam, per snapshot, the
+# recurrent state detached between snapshots like examples/nodeproppred/tgcn.py:60-101
+cell.train()
+head = torch.nn.Linear(32, 8).to(dev)
+opt = torch.optim.Adam(list(cell.parameters()) + list(head.parameters()), lr=1e-3)
+target = torch.randn(N, 8, device=dev)
+
+
+def train_epoch():
+    H = None
+    for batch in DGDataLoader(dg, batch_unit='Y'):
+        opt.zero_grad(set_to_none=True)
+        H = cell(dg.static_node_x, torch.stack([batch.edge_src, batch.edge_dst]), None, H)
+        loss = ((head(torch.relu(H)) - target) ** 2).mean()
+        loss.backward()
+        opt.step()
+        H = H.detach()
+    return float(loss)
+
+
+train_epoch()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+for _ in range(reps):
+    last_loss = train_epoch()
+torch.cuda.synchronize()
+t3 = time.perf_counter()
 print(json.dumps({
+    'tgcn_train_step_us_per_snapshot': 1e6 * (t3 - t2) / (reps * n), 'train_loss_last': last_loss,
     'what': 'BASELINE cfg5: tgbn-trade-like (255 nodes, 468k edges, 30 yearly snapshots): discretize + TGCN(16 -> 32) step per snapshot',
     'discretize_ms': 1e3 * t_disc, 'discretized_edges': int(data.edge_index.shape[0]), 'snapshots': n,
     'tgcn_step_us_per_snapshot': 1e6 * (t1 - t0) / (reps * n),

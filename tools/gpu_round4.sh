@@ -29,6 +29,7 @@ python tools/mfma_json.py "$OUT/r04_tgat_mfma_pmc.md" "$OUT/r04_tgat_mfma_pmc.js
 # cfg 3
 for i in 1 2 3; do timeout 300 python tools/bench_tgn.py 400 2>/dev/null | j >> "$OUT/r04_bench_tgn.jsonl"; done
 TGMX_BENCH_TGN_NO_LOADER_PASS=1 tools/gpu_trace_byname.sh tgn 300 python $ROOT/tools/bench_tgn.py 200 > "$OUT/r04_tgn_rocprof_summary.md" 2>/dev/null
+for i in 1 2 3; do timeout 300 python tools/bench_tgcn.py 2>/dev/null | j >> "$OUT/r04_bench_tgcn.jsonl"; done
 if [ -z "$QUICK" ]; then
   for i in 1 2 3; do timeout 300 python tools/bench_tgat_train.py 200 by_id 2>/dev/null | j >> "$OUT/r04_bench_tgat_train_by_id.jsonl"; done
   rm -f "$OUT/r04_tgat_parity_stats.jsonl"
