@@ -1692,7 +1692,16 @@ static bool launch_attn_reg(hipStream_t st, const AttnArgs& a) {
   const bool edge_ok = a.D > 0 && a.D % 4 == 0 && a.D / 4 <= 64 && (ex_bits & 15) == 0;
   const bool nbv = a.d % 4 == 0 && a.d / 4 <= 64 && (nb_bits & 15) == 0;
   if (!edge_ok || a.tfeat || a.T > 128 || !(nbv || a.d <= 64)) return false;
-  const dim3 grid((unsigned)((a.R + 3) / 4)), block(256);
+  // ONE wave per workgroup (TGMX_ATTN_WPB, 1..4, for A/B runs): the kernel shares nothing between the waves of a workgroup, and a
+  // 4-wave workgroup only retires -- and its four wave slots only refill -- when its SLOWEST row is done.  Per-row clock stamps
+  // (round 4) showed under half of the 2048 resident slots busy on average with 4-wave workgroups; with 1-wave workgroups a slot
+  // refills as soon as its own row ends: the 12 600-row launch 56.5 -> 49.6 us.
+  static const int wpb = [] {
+    const char* e = getenv("TGMX_ATTN_WPB");
+    const int v = e ? atoi(e) : 1;
+    return v >= 1 && v <= 4 ? v : 1;
+  }();
+  const dim3 grid((unsigned)((a.R + wpb - 1) / wpb)), block(64 * wpb);
   bool idx = false;
   for (int i = 0; i < TGMX_TGAT_MAX_LAYERS; ++i) idx |= a.seg_uniq[i] || a.seg_live[i] || a.seg_nidx[i];
 #define TGMX_REG(G_)                                                                                        \
