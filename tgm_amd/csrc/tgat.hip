@@ -154,6 +154,65 @@ __global__ __launch_bounds__(256) void sgemm_nt_kernel(const GemmArgs g) {
   }
 }
 
+// The FEW-ROW variant (M <= 2048: the 600-row layer of the headline forward, whose five GEMMs were 41 us of a 185 us forward at ~8 us
+// each for 0.03-0.2 GFLOP).  Such a launch is one dependent chain -- launch, operand latency, MFMAs, reduction, store -- so the
+// kernel is built to make that chain SHORT instead of wide: a workgroup owns one 32 x 32 output block, its 8 waves split K into
+// contiguous slices of STEPS 16-wide steps, and a wave issues EVERY load of its slice before its first MFMA (<= 16 float4 per lane:
+// one memory latency per launch, where sgemm_nt_kernel<SPLIT> pays one per k-step: 4-7 of them).  The 8 partial blocks meet in LDS
+// in wave order (fixed: deterministic).  32-column blocks instead of 64 double the workgroups (114 for a 600 x 172 output).
+template <bool AV, bool BV, int STEPS>
+__global__ __launch_bounds__(512) void sgemm_nt_small_kernel(const GemmArgs g) {
+  constexpr int kW = 8;
+  __shared__ float part[kW][16][kWave];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, half = lane >> 5;
+  const long long m0 = (long long)blockIdx.x * 32;
+  const int n0 = blockIdx.y * 32;
+  const float* __restrict__ A = g.A + (long long)blockIdx.z * g.sA;
+  const float* __restrict__ B = g.B + (long long)blockIdx.z * g.sB;
+  float* __restrict__ C = g.C + (long long)blockIdx.z * g.sC;
+  const long long ra = m0 + i < g.M ? m0 + i : g.M - 1;  // clamped for the loads; never stored
+  const int cb = n0 + i < g.N ? n0 + i : g.N - 1;
+  const float* __restrict__ pa = A + ra * g.lda;
+  const float* __restrict__ pb = B + (long long)cb * g.ldb;
+  const int kbeg = wave * STEPS * 16;
+  float a[STEPS][8], b[STEPS][8];
+#pragma unroll
+  for (int st = 0; st < STEPS; ++st) {
+    const int k0 = kbeg + st * 16;
+    if (k0 < g.K) {
+      load_kn<AV, 8>(pa, k0 + half * 8, g.K, a[st]);
+      load_kn<BV, 8>(pb, k0 + half * 8, g.K, b[st]);
+    }
+  }
+  floatx16 acc = {0};
+#pragma unroll
+  for (int st = 0; st < STEPS; ++st) {
+    if (kbeg + st * 16 < g.K) {
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[st][kk], b[st][kk], acc, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) part[wave][r][lane] = acc[r];
+  __syncthreads();
+  // wave w finishes accumulator registers 2w and 2w + 1 of every lane
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int r = wave * 2 + q;
+    float v = part[0][r][lane];
+#pragma unroll
+    for (int w = 1; w < kW; ++w) v += part[w][r][lane];
+    const long long row = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    const int col = n0 + i;
+    if (row < g.M && col < g.N) {
+      if (g.bias) v += g.bias[(long long)blockIdx.z * g.N + col];
+      if (g.relu) v = v > 0.f ? v : 0.f;
+      C[row * g.ldc + col] = v;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // out[i, :] = table[idx[i] (negative wraps, like Python indexing), :]
 // (tgat.py:128-130: pad id -1 reads the LAST row of node_x)
@@ -1743,6 +1802,25 @@ extern "C" int tgmx_sgemm_nt(const float* A, int64_t lda, const float* B, int64_
   // K-splitting across the 4 waves of a block (4x the waves, each with a quarter of the dependent MFMA chain) wins
   // whenever there is more than one 16-wide k-step to hand out; measured on every GEMM shape of the TGAT path
   // (600 .. 12 600 rows, K = 102 .. 448: 1.1x .. 2.9x) and neutral at 4096^3.
+  static const bool small_knob = [] { const char* e = getenv("TGMX_GEMM_SMALL"); return !(e && e[0] == '0'); }();  // A/B knob
+  if (small_knob && M <= 2048 && K > 16 && K <= 512) {  // few rows: the latency-shaped kernel (see sgemm_nt_small_kernel)
+    const dim3 sgrid((unsigned)((M + 31) / 32), (unsigned)((N + 31) / 32), (unsigned)batch), sblock(512);
+    const int steps = (K + 127) / 128;
+#define TGMX_GEMM_S(AV_, BV_)                                                                              \
+  do {                                                                                                     \
+    if (steps == 1) hipLaunchKernelGGL((sgemm_nt_small_kernel<AV_, BV_, 1>), sgrid, sblock, 0, st, g);      \
+    else if (steps == 2) hipLaunchKernelGGL((sgemm_nt_small_kernel<AV_, BV_, 2>), sgrid, sblock, 0, st, g); \
+    else if (steps == 3) hipLaunchKernelGGL((sgemm_nt_small_kernel<AV_, BV_, 3>), sgrid, sblock, 0, st, g); \
+    else hipLaunchKernelGGL((sgemm_nt_small_kernel<AV_, BV_, 4>), sgrid, sblock, 0, st, g);                 \
+  } while (0)
+    if (av && bv) TGMX_GEMM_S(true, true);
+    else if (av) TGMX_GEMM_S(true, false);
+    else if (bv) TGMX_GEMM_S(false, true);
+    else TGMX_GEMM_S(false, false);
+#undef TGMX_GEMM_S
+    TGMX_CHECK_LAUNCH("sgemm_nt(small)");
+    return TGMX_OK;
+  }
   const bool split = K > 16;
   const dim3 grid = split ? dim3((unsigned)((M + 31) / 32), (unsigned)((N + 63) / 64), (unsigned)batch)
                           : dim3((unsigned)((M + 127) / 128), (unsigned)((N + 63) / 64), (unsigned)batch);
