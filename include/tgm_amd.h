@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TGMX_ABI_VERSION 5
+#define TGMX_ABI_VERSION 6
 
 #define TGMX_OK 0
 #define TGMX_E_INVALID (-1)  /* bad argument (null pointer, size, alignment) */
@@ -462,6 +462,13 @@ typedef struct tgmx_tgat_layer {
   const float* W_O_t16; /* tile16(W_O, O, O)                */
   const float* fc1_t16; /* tile16(fc1.weight, emb, O + d0)  */
   const float* fc2_t16; /* tile16(fc2.weight, emb_out, emb) */
+  /* optional (inference, d == 1 -- a model whose nodes carry ONE feature, like the reference's example configuration): qf_U / qf_v
+   * in the order the register-resident attention kernel's lanes consume them, so that the kernel evaluates qf = qf_v + x * qf_U
+   * itself and the [rows, H * p4(C)] qf buffer is neither written nor read.  [H, 64, 16] floats; entry (h, lane):
+   *   0..3  qf_v of the edge columns d + 4 lane + i      4..7  qf_U of the same columns
+   *   8, 9  qf_v, qf_U of time column d + D + lane       10, 11  the same for time column d + D + lane + 64
+   *   12, 13  qf_v, qf_U of neighbor column `lane`       14, 15  zero;   columns that do not exist: zero.       NULL: qf is a buffer. */
+  const float* qf_lane;
   int32_t d, D, T, O, H, emb, emb_out;
   float ln_eps;
 } tgmx_tgat_layer_t;

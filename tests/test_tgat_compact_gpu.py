@@ -170,3 +170,39 @@ def test_untagged_or_modified_inputs_get_the_row_per_slot_computation():
         assert enc._last_hops[1].seed_keyed == 0 and torch.equal(z_t, z_r)
         enc(node_x, *_plain(b2))
         assert enc._last_hops[1].seed_keyed == 0
+
+
+@pytest.mark.parametrize('features', ['dense', 'by_id'])
+@pytest.mark.parametrize('compact', [False, True])
+def test_in_kernel_folded_queries_equal_the_qf_buffer(features, compact):
+    """ABI v6, ``tgmx_tgat_layer_t.qf_lane``: a layer whose rows carry ONE input feature has its folded queries evaluated inside the
+    attention kernel (no [rows, H * p4(C)] buffer).  Same multiply-then-add per column as the kernel that fills the buffer: the
+    embeddings must be equal bit for bit with the table withheld."""
+    from tgm_amd.nn import TGAT
+    from tgm_amd.synth import make_stream
+
+    st = make_stream('wiki', seed=5, num_edges=8_000, edge_dim=172)
+    dg, hm, loader = _pipeline(st, [20, 20], 'ring', features)
+    torch.manual_seed(2)
+    enc = TGAT(node_dim=1, edge_dim=172, time_dim=100, embed_dim=172, num_layers=2).to(DEV).eval()
+    enc.compact_rows = compact
+    node_x = dg.static_node_x
+    checked = 0
+    with hm.activate('k'), torch.no_grad():
+        for n, b in enumerate(loader):
+            if n % 9:
+                continue
+            args = (node_x, b.seed_nids, b.seed_times, b.nbr_nids, b.nbr_edge_x, b.nbr_edge_time)
+            z = enc(*args)
+            model = enc._desc_cache[1][0]
+            table = model.layers[0].qf_lane
+            assert table, 'node_dim = 1: the lane-ordered table exists'
+            assert not model.layers[1].qf_lane, 'layer 2 reads 172 features per row: a qf buffer'
+            model.layers[0].qf_lane = None
+            try:
+                z_buf = enc(*args)
+            finally:
+                model.layers[0].qf_lane = table
+            assert torch.equal(z, z_buf), f'batch {n}: max |d| = {(z - z_buf).abs().max().item():.3e}'
+            checked += 1
+    assert checked >= 4

@@ -1157,6 +1157,11 @@ struct AttnArgs {
   const float* seg_ntab[TGMX_TGAT_MAX_LAYERS];
   long long seg_npad[TGMX_TGAT_MAX_LAYERS];
   int full_span;              // != 0: the register kernel runs every row through its all-slots body (A/B knob TGMX_ATTN_SPAN=0)
+  // register kernel, a layer whose input is ONE scalar per row (d == 1, inference): qf is NOT a buffer -- qf[r, c] = qv[c] + qx[r] * qU[c],
+  // evaluated by the lane that needs column c from the lane-ordered table tgmx_tgat_layer_t.qf_lane (the same multiply-then-add as
+  // tgat_qfold_small_kernel: bit-identical).  qf is ignored when qlane is set.
+  const float* qlane;         // [H, 64, 16]
+  const float* qx;            // [R] the rows' own feature
 };
 
 // the level (segment) of row r: wave-uniform, so this is scalar code
@@ -1462,7 +1467,7 @@ __global__ __launch_bounds__(256) void tgat_attn_reduce_reg_kernel(const AttnArg
   if (r >= a.R) return;
   const int k = a.k, T = a.T, d = a.d, D = a.D;
   const int D4 = D >> 2, d4 = d >> 2;
-  const float* __restrict__ q = a.qf + r * (long long)H * a.Cs;
+  const float* __restrict__ q = a.qlane ? nullptr : a.qf + r * (long long)H * a.Cs;
   const AttnLevel lv = attn_level(a, r);
   if (IDX && lv.live && r - lv.begin >= (long long)*lv.live) return;  // compact rows: past the level's distinct rows
   // ro: the row of the sampler's outputs this row reads (compact rows: the original row it stands for); qf / zbar / probs live at r
@@ -1585,6 +1590,20 @@ __global__ __launch_bounds__(256) void tgat_attn_reduce_reg_kernel(const AttnArg
     float4 qe[H], qn4[H];
     float qn[H], qt0[H], qt1[H];
     const bool t0_on = lane < T, t1_on = lane + kWave < T;
+    if (a.qlane) {  // wave-uniform: four contiguous 16-byte loads per head from a cache-resident table instead of 7 scattered ones
+      const float x = a.qx[r];
+      const float4* __restrict__ tab = reinterpret_cast<const float4*>(a.qlane) + lane * 4;
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        const float4 v4 = tab[h * 256], u4 = tab[h * 256 + 1], tt = tab[h * 256 + 2], nn = tab[h * 256 + 3];
+        qe[h] = make_float4(__fadd_rn(__fmul_rn(x, u4.x), v4.x), __fadd_rn(__fmul_rn(x, u4.y), v4.y), __fadd_rn(__fmul_rn(x, u4.z), v4.z),
+                            __fadd_rn(__fmul_rn(x, u4.w), v4.w));
+        qt0[h] = __fadd_rn(__fmul_rn(x, tt.y), tt.x);
+        qt1[h] = __fadd_rn(__fmul_rn(x, tt.w), tt.z);
+        if (NBV) qn4[h] = make_float4(0.f, 0.f, 0.f, 0.f);  // (d == 1 is never the float4 neighbor variant)
+        else qn[h] = __fadd_rn(__fmul_rn(x, nn.y), nn.x);
+      }
+    } else
 #pragma unroll
     for (int h = 0; h < H; ++h) {
       const float* qh = q + h * a.Cs;
@@ -1943,6 +1962,10 @@ static int attn_reduce_impl(const AttnArgs& a_in, int H, hipStream_t st) {
   if ((H == 1 && launch_attn_reg<1>(st, a)) || (H == 2 && launch_attn_reg<2>(st, a))) {
     TGMX_CHECK_LAUNCH("tgat_attn_reduce(reg)");
     return TGMX_OK;
+  }
+  if (a.qlane) {  // only the register kernel evaluates the folded queries itself
+    set_error("tgat_attn_reduce: in-kernel folded queries need the register-resident kernel");
+    return TGMX_E_UNSUPPORTED;
   }
   for (int i = 0; i < TGMX_TGAT_MAX_LAYERS; ++i)
     if (a.seg_uniq[i] || a.seg_live[i] || a.seg_nidx[i]) {  // only the register kernel reads rows / neighbor features by index
@@ -2388,6 +2411,13 @@ extern "C" int tgmx_tgat_forward(const tgmx_tgat_model_t* m, const float* node_x
       segs.begin[n_lvl] = off[n_lvl];
     }
     const int dp = (ly.d + 3) / 4 * 4;
+    // one scalar of input per row and the register-resident attention kernel takes the layer (launch_attn_reg's conditions): the
+    // folded queries are evaluated inside that kernel (TGMX_TGAT_QF_INLINE=0: the A/B knob)
+    static const bool qf_knob = [] { const char* e = getenv("TGMX_TGAT_QF_INLINE"); return !(e && e[0] == '0'); }();
+    bool qf_in_kernel = folded && qf_knob && ly.qf_lane && ly.d == 1 && ld_prev == 1 && H <= 2 && k <= 20 && ly.D > 0 && ly.D % 4 == 0 &&
+                        ly.D / 4 <= 64 && ly.T <= 128;
+    for (int i = 0; i < n_lvl && qf_in_kernel; ++i)
+      qf_in_kernel = hops[i].edge_x ? ((uintptr_t)hops[i].edge_x & 15) == 0 : (hops[i].nbr_eid && ((uintptr_t)hops[i].edge_table & 15) == 0);
     if (!folded)  // the residual as a buffer is the Q projection's input; LayerNorm rebuilds it on the fly
       if ((rc = tgmx_tgat_rres(prev, ld_prev, ly.d, m->tb, nullptr, ly.T, O, R, rres, Op, stream))) return rc;
     if (!folded) {
@@ -2396,6 +2426,8 @@ extern "C" int tgmx_tgat_forward(const tgmx_tgat_model_t* m, const float* node_x
       // qf[:, h, :] = Q[:, head h] @ W_K[head h]  via the transposed padded copy W_K_t [C, H*dhp]
       if ((rc = tgmx_sgemm_nt(Q, (long long)H * dhp, ly.W_K_t, (long long)H * dhp, qf, (long long)H * Cp, R, C, dh, nullptr, 0, H, dhp, dhp, Cp, stream)))
         return rc;
+    } else if (qf_in_kernel) {
+      // the attention kernel evaluates its query columns itself (AttnArgs.qlane): no qf buffer, no launch
     } else if (ly.d <= 4) {
       long long blocks = ((R + 15) / 16 * (H * Cp / 4) + 255) / 256;
       if (blocks > 16384) blocks = 16384;
@@ -2410,6 +2442,7 @@ extern "C" int tgmx_tgat_forward(const tgmx_tgat_model_t* m, const float* node_x
       AttnArgs a{};
       bool any_by_id = false;
       a.qf = qf; a.zbar = zbar; a.probs = probs; a.R = off[n_lvl];
+      if (qf_in_kernel) { a.qlane = ly.qf_lane; a.qx = prev; }
       a.tw = m->tw; a.tb = m->tb;
       a.d = ly.d; a.D = ly.D; a.T = ly.T; a.k = k; a.C = C; a.scale = 1.0f / sqrtf((float)dh); a.Cs = Cp;
       a.n_seg = n_lvl;

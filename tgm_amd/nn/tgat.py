@@ -179,6 +179,25 @@ class TGAT(TransientCaches, nn.Module):
                 _ops.sgemm_nt(M[:, O - T_ :], ct, v[h * Cp : h * Cp + C])
             keep += [U, v]
             ly.qf_U, ly.qf_v = U.data_ptr(), v.data_ptr()
+            ly.qf_lane = None
+            D_ = attn.edge_dim
+            if d_in == 1 and D_ > 0 and D_ % 4 == 0 and D_ // 4 <= 64 and T_ <= 128:
+                # the same numbers in the order the attention kernel's lanes take them (tgmx_tgat_layer_t.qf_lane)
+                tab = torch.zeros((H, 64, 16), dtype=torch.float32, device=dev)
+                lanes = torch.arange(64, device=dev)
+                vf, Uf = v.reshape(H, Cp), U[:, 0].reshape(H, Cp)
+
+                def put(slot_v: int, slot_u: int, cols: Tensor, ok: Tensor) -> None:
+                    tab[:, lanes[ok], slot_v] = vf[:, cols[ok]]
+                    tab[:, lanes[ok], slot_u] = Uf[:, cols[ok]]
+
+                for i in range(4):
+                    put(i, 4 + i, d_in + 4 * lanes + i, 4 * lanes + i < D_)
+                put(8, 9, d_in + D_ + lanes, lanes < T_)
+                put(10, 11, d_in + D_ + lanes + 64, lanes + 64 < T_)
+                put(12, 13, lanes, lanes < d_in)
+                keep.append(tab)
+                ly.qf_lane = tab.data_ptr()
             # the tail's weights in the tiled order its one-kernel form streams them in (tgmx_tgat_tile16)
             merge = self.merge_layers[l]
             lib = _native.load()
