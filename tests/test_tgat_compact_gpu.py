@@ -176,7 +176,7 @@ def test_untagged_or_modified_inputs_get_the_row_per_slot_computation():
 @pytest.mark.parametrize('compact', [False, True])
 def test_in_kernel_folded_queries_equal_the_qf_buffer(features, compact):
     """ABI v6, ``tgmx_tgat_layer_t.qf_lane``: a layer whose rows carry ONE input feature has its folded queries evaluated inside the
-    attention kernel (no [rows, H * p4(C)] buffer).  Same multiply-then-add per column as the kernel that fills the buffer: the
+    attention kernel (no [rows, H * p4(C)] buffer).  Same fma per column as the kernel that fills the buffer: the
     embeddings must be equal bit for bit with the table withheld."""
     from tgm_amd.nn import TGAT
     from tgm_amd.synth import make_stream

@@ -1158,7 +1158,7 @@ struct AttnArgs {
   long long seg_npad[TGMX_TGAT_MAX_LAYERS];
   int full_span;              // != 0: the register kernel runs every row through its all-slots body (A/B knob TGMX_ATTN_SPAN=0)
   // register kernel, a layer whose input is ONE scalar per row (d == 1, inference): qf is NOT a buffer -- qf[r, c] = qv[c] + qx[r] * qU[c],
-  // evaluated by the lane that needs column c from the lane-ordered table tgmx_tgat_layer_t.qf_lane (the same multiply-then-add as
+  // evaluated by the lane that needs column c from the lane-ordered table tgmx_tgat_layer_t.qf_lane (the same fma as
   // tgat_qfold_small_kernel: bit-identical).  qf is ignored when qlane is set.
   const float* qlane;         // [H, 64, 16]
   const float* qx;            // [R] the rows' own feature
@@ -1457,6 +1457,26 @@ __device__ __forceinline__ float lane_bcast(float v, int src) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
 }
 
+// Are ALL of a row's Time2Vec arguments fma(dt_s, w_c, b_c) (slots s < G held one per lane in my_dt, this lane's two columns) inside the
+// float reduction's range?  The exact test is G x 2 evaluations per lane (140 instructions a row); a sufficient one comes first --
+// |dt|_max |w| + |b| is below the limit with 1 % to spare, which no rounding of the fma can make up -- and only a row that fails it (time
+// deltas of ~10^6 and more times the largest frequency) takes the exact loop: the answer is the exact test's in every case.
+template <int G>
+__device__ __forceinline__ bool row_args_small(float my_dt, float w0, float b0, float w1, float b1) {
+  float m = fabsf(my_dt);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  const float lim = 0.99f * kCosSmallLimit;
+  if (__all(__fmaf_rn(m, fabsf(w0), fabsf(b0)) < lim && __fmaf_rn(m, fabsf(w1), fabsf(b1)) < lim)) return true;
+  bool small = true;
+#pragma unroll
+  for (int s = 0; s < G; ++s) {
+    const float dt = lane_bcast(my_dt, s);
+    small = small && fabsf(__fmaf_rn(dt, w0, b0)) < kCosSmallLimit && fabsf(__fmaf_rn(dt, w1, b1)) < kCosSmallLimit;
+  }
+  return __all(small);
+}
+
 // IDX: compact rows / neighbor features by index (AttnArgs.seg_uniq, seg_live, seg_nidx) -- a variant of its own so that the plain
 // kernels keep their register budget (7 VGPRs would cost the k <= 10 variants a wave per SIMD)
 template <int H, int G, bool NBV, bool IDX>
@@ -1596,12 +1616,11 @@ __global__ __launch_bounds__(256) void tgat_attn_reduce_reg_kernel(const AttnArg
 #pragma unroll
       for (int h = 0; h < H; ++h) {
         const float4 v4 = tab[h * 256], u4 = tab[h * 256 + 1], tt = tab[h * 256 + 2], nn = tab[h * 256 + 3];
-        qe[h] = make_float4(__fadd_rn(__fmul_rn(x, u4.x), v4.x), __fadd_rn(__fmul_rn(x, u4.y), v4.y), __fadd_rn(__fmul_rn(x, u4.z), v4.z),
-                            __fadd_rn(__fmul_rn(x, u4.w), v4.w));
-        qt0[h] = __fadd_rn(__fmul_rn(x, tt.y), tt.x);
-        qt1[h] = __fadd_rn(__fmul_rn(x, tt.w), tt.z);
+        qe[h] = make_float4(__fmaf_rn(x, u4.x, v4.x), __fmaf_rn(x, u4.y, v4.y), __fmaf_rn(x, u4.z, v4.z), __fmaf_rn(x, u4.w, v4.w));
+        qt0[h] = __fmaf_rn(x, tt.y, tt.x);
+        qt1[h] = __fmaf_rn(x, tt.w, tt.z);
         if (NBV) qn4[h] = make_float4(0.f, 0.f, 0.f, 0.f);  // (d == 1 is never the float4 neighbor variant)
-        else qn[h] = __fadd_rn(__fmul_rn(x, nn.y), nn.x);
+        else qn[h] = __fmaf_rn(x, nn.y, nn.x);
       }
     } else
 #pragma unroll
@@ -1627,13 +1646,7 @@ __global__ __launch_bounds__(256) void tgat_attn_reduce_reg_kernel(const AttnArg
     // A masked slot of a row that has a valid one: its Time2Vec columns never reach the output, so they are not evaluated (zeros
     // stand in).  A row with NO valid slot attends uniformly over all of them: everything is needed.
     const unsigned long long need = okm ? okm : ~0ull;
-    bool small = true;
-#pragma unroll
-    for (int s = 0; s < G; ++s) {
-      const float dt = lane_bcast(my_dt, s);
-      small = small && fabsf(__fmaf_rn(dt, w0, b0)) < kCosSmallLimit && fabsf(__fmaf_rn(dt, w1, b1)) < kCosSmallLimit;
-    }
-    const bool row_small = __all(small);
+    const bool row_small = row_args_small<G>(my_dt, w0, b0, w1, b1);
     if (same_dt) {
       const float dt = lane_bcast(my_dt, 0);
       const float c0 = row_small ? cos_t2v_small(__fmaf_rn(dt, w0, b0)) : cos_t2v_big(__fmaf_rn(dt, w0, b0));
@@ -1754,6 +1767,253 @@ __global__ __launch_bounds__(256) void tgat_attn_reduce_reg_kernel(const AttnArg
   body(std::integral_constant<int, G>{});
 }
 
+// ---------------------------------------------------------------------------
+// The same row on FOUR waves (one workgroup per row): for launches of few rows (the 600-row layer of the headline forward: 600 waves
+// on 1024 SIMDs, so the launch lasts as long as ONE 20-slot row -- 14.6 us).
+// Wave w takes slots [w Q, (w + 1) Q), Q = ceil(G / 4): loads, Time2Vec and partial scores of its slots only (a quarter of the
+// register-resident body's registers and of its serial work).  BIT-IDENTICAL to tgat_attn_reduce_reg_kernel by construction:
+//   * a score is summed over the 64 lanes in the order xor 32, 16, 8, 4, 2, 1 whatever the number of entries (reduce_scatter_n);
+//   * the scores meet in LDS and EVERY wave runs the same softmax butterfly over the k slots;
+//   * the weighted mean is one fma chain over the slots in ascending order: the waves take turns, the running sums travel through
+//     LDS from wave w to wave w + 1 (three hand-offs of 10 H floats per lane), the last wave stores;
+//   * waves whose slots all lie left of the row's first valid slot end at once (their slots carry weight exactly 0, see the span
+//     bodies above) -- a wave that has ended is not counted by s_barrier.
+// No compact rows, attention-weight output or dropout here: the launch code sends those to the one-wave kernel.
+// ---------------------------------------------------------------------------
+template <int H, int G, bool NBV>
+__global__ __launch_bounds__(256) void tgat_attn_reduce_mw_kernel(const AttnArgs a) {
+  constexpr int W = 4, Q = (G + W - 1) / W;
+  constexpr int NV = Q * H, NVp = NV <= 4 ? 4 : NV <= 8 ? 8 : NV <= 16 ? 16 : NV <= 32 ? 32 : 64;
+  static_assert(G * H <= 64, "a score group must fit the 64 lanes");
+  __shared__ float sc_lds[64];
+  __shared__ float acc_lds[H * 10][kWave];
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  const long long r = blockIdx.x;
+  const int k = a.k, T = a.T, d = a.d, D = a.D;
+  const int D4 = D >> 2, d4 = d >> 2;
+  const float* __restrict__ q = a.qlane ? nullptr : a.qf + r * (long long)H * a.Cs;
+  const AttnLevel lv = attn_level(a, r);
+  const float* __restrict__ nb = lv.nbrf + r * (long long)k * d;
+  const float4* __restrict__ ex4 = reinterpret_cast<const float4*>(lv.ex + r * (long long)k * D);
+  float my_dt = 0.f;
+  bool my_ok = false;
+  int my_eid = -1;
+  if (lane < k) {
+    my_dt = (float)(lv.seed_t[r] - lv.nbr_t[r * k + lane]);
+    my_ok = lv.nbr_id[r * k + lane] != -1;
+    if (lv.eid) my_eid = lv.eid[r * k + lane];
+  }
+  const float4* __restrict__ table4 = reinterpret_cast<const float4*>(lv.table);
+  const bool e_on = lane < D4;
+  const bool t0_on = lane < T, t1_on = lane + kWave < T;
+  const unsigned long long okm = __ballot(my_ok);
+  const bool same_dt = __all(lane >= k || my_dt == lane_bcast(my_dt, 0));
+  if (!okm && same_dt) {  // the sampler's all-pad row: the one-wave kernel's shortcut, by wave 0 alone (same arithmetic)
+    if (wave != 0) return;
+    const float dt0 = lane_bcast(my_dt, 0);
+    const float c0 = cos_t2v(__fmaf_rn(dt0, t0_on ? a.tw[lane] : 0.f, t0_on ? a.tb[lane] : 0.f));
+    const float c1 = cos_t2v(__fmaf_rn(dt0, t1_on ? a.tw[lane + kWave] : 0.f, t1_on ? a.tb[lane + kWave] : 0.f));
+    const float4 e = (e_on && !lv.eid) ? ex4[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float* __restrict__ zb0 = a.zbar + r * (long long)H * a.Cs;
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      float* zh = zb0 + h * a.Cs;
+      const float w = 1.f;
+      if (NBV) {
+        if (lane < d4) {
+          const float4 v = reinterpret_cast<const float4*>(nb)[lane];
+          zh[4 * lane] = w * v.x; zh[4 * lane + 1] = w * v.y; zh[4 * lane + 2] = w * v.z; zh[4 * lane + 3] = w * v.w;
+        }
+      } else if (lane < d) {
+        zh[lane] = w * nb[lane];
+      }
+      if (e_on) { zh[d + 4 * lane] = w * e.x; zh[d + 4 * lane + 1] = w * e.y; zh[d + 4 * lane + 2] = w * e.z; zh[d + 4 * lane + 3] = w * e.w; }
+      if (t0_on) zh[d + D + lane] = w * c0;
+      if (t1_on) zh[d + D + lane + kWave] = w * c1;
+    }
+    return;
+  }
+  const int span = okm ? k - (__ffsll((long long)okm) - 1) : k;
+  const int w_first = (k - span) / Q;  // the first wave that owns a slot that matters (workgroup-uniform)
+  if (wave < w_first) return;
+  const int s_lo = wave * Q;
+
+  // ---- this wave's slots, straight into registers ----
+  float4 ze[Q];
+#pragma unroll
+  for (int s = 0; s < Q; ++s) {
+    const int sl = s_lo + s < k ? s_lo + s : k - 1;
+    if (lv.eid) {
+      const int e = __builtin_amdgcn_readlane(my_eid, sl);
+      ze[s] = (e_on && e >= 0) ? table4[(long long)e * D4 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+      ze[s] = e_on ? ex4[sl * D4 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  float4 zn[NBV ? Q : 1];
+  float zs[NBV ? 1 : Q];
+#pragma unroll
+  for (int s = 0; s < Q; ++s) {
+    const int sl = s_lo + s < k ? s_lo + s : k - 1;
+    if (NBV) zn[NBV ? s : 0] = lane < d4 ? reinterpret_cast<const float4*>(nb + (long long)sl * d)[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    else zs[NBV ? 0 : s] = lane < d ? nb[(long long)sl * d + lane] : 0.f;
+  }
+  float4 qe[H], qn4[H];
+  float qn[H], qt0[H], qt1[H];
+  if (a.qlane) {
+    const float x = a.qx[r];
+    const float4* __restrict__ tab = reinterpret_cast<const float4*>(a.qlane) + lane * 4;
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      const float4 v4 = tab[h * 256], u4 = tab[h * 256 + 1], tt = tab[h * 256 + 2], nn = tab[h * 256 + 3];
+      qe[h] = make_float4(__fmaf_rn(x, u4.x, v4.x), __fmaf_rn(x, u4.y, v4.y), __fmaf_rn(x, u4.z, v4.z), __fmaf_rn(x, u4.w, v4.w));
+      qt0[h] = __fmaf_rn(x, tt.y, tt.x);
+      qt1[h] = __fmaf_rn(x, tt.w, tt.z);
+      if (NBV) qn4[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+      else qn[h] = __fmaf_rn(x, nn.y, nn.x);
+    }
+  } else {
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      const float* qh = q + h * a.Cs;
+      qe[h] = e_on ? make_float4(qh[d + 4 * lane], qh[d + 4 * lane + 1], qh[d + 4 * lane + 2], qh[d + 4 * lane + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (NBV) qn4[h] = lane < d4 ? make_float4(qh[4 * lane], qh[4 * lane + 1], qh[4 * lane + 2], qh[4 * lane + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      else qn[h] = lane < d ? qh[lane] : 0.f;
+      qt0[h] = t0_on ? qh[d + D + lane] : 0.f;
+      qt1[h] = t1_on ? qh[d + D + lane + kWave] : 0.f;
+    }
+  }
+  const float w0 = t0_on ? a.tw[lane] : 0.f, b0 = t0_on ? a.tb[lane] : 0.f;
+  const float w1 = t1_on ? a.tw[lane + kWave] : 0.f, b1 = t1_on ? a.tb[lane + kWave] : 0.f;
+
+  // ---- Time2Vec columns + partial scores of this wave's slots (the cosine's reduction path: chosen over ALL k slots, as there) ----
+  float tz0[Q], tz1[Q], P[NVp];
+#pragma unroll
+  for (int j = 0; j < NVp; ++j) P[j] = 0.f;
+  const unsigned long long need = okm ? okm : ~0ull;
+  const bool row_small = row_args_small<G>(my_dt, w0, b0, w1, b1);
+  if (same_dt) {
+    const float dt = lane_bcast(my_dt, 0);
+    const float c0 = row_small ? cos_t2v_small(__fmaf_rn(dt, w0, b0)) : cos_t2v_big(__fmaf_rn(dt, w0, b0));
+    const float c1 = row_small ? cos_t2v_small(__fmaf_rn(dt, w1, b1)) : cos_t2v_big(__fmaf_rn(dt, w1, b1));
+#pragma unroll
+    for (int s = 0; s < Q; ++s) {
+      tz0[s] = c0;
+      tz1[s] = c1;
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < Q; ++s) {
+      tz0[s] = tz1[s] = 0.f;
+      const int sl = s_lo + s < k ? s_lo + s : k - 1;
+      if ((need >> sl) & 1) {  // wave-uniform
+        const float dt = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_dt), sl));
+        if (row_small) {
+          tz0[s] = cos_t2v_small(__fmaf_rn(dt, w0, b0));
+          tz1[s] = cos_t2v_small(__fmaf_rn(dt, w1, b1));
+        } else {
+          tz0[s] = cos_t2v_big(__fmaf_rn(dt, w0, b0));
+          tz1[s] = cos_t2v_big(__fmaf_rn(dt, w1, b1));
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < Q; ++s) {
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      float p = qe[h].x * ze[s].x;
+      p = __fmaf_rn(qe[h].y, ze[s].y, p);
+      p = __fmaf_rn(qe[h].z, ze[s].z, p);
+      p = __fmaf_rn(qe[h].w, ze[s].w, p);
+      if (NBV) {
+        p = __fmaf_rn(qn4[h].x, zn[NBV ? s : 0].x, p);
+        p = __fmaf_rn(qn4[h].y, zn[NBV ? s : 0].y, p);
+        p = __fmaf_rn(qn4[h].z, zn[NBV ? s : 0].z, p);
+        p = __fmaf_rn(qn4[h].w, zn[NBV ? s : 0].w, p);
+      } else {
+        p = __fmaf_rn(qn[h], zs[NBV ? 0 : s], p);
+      }
+      p = __fmaf_rn(qt0[h], tz0[s], p);
+      p = __fmaf_rn(qt1[h], tz1[s], p);
+      P[s * H + h] = p;
+    }
+  }
+  {
+    const float part = reduce_scatter_n<NVp>(P, lane);  // lane L: entry L mod NVp = (slot s_lo + e / H, head e % H)
+    if (lane < NV && s_lo * H + lane < 64) sc_lds[s_lo * H + lane] = part;
+  }
+  __syncthreads();
+  // ---- masked softmax over the slots of each head, every wave the same (entries of ended waves: masked slots, never used) ----
+  const int js = lane / H;
+  const bool live = js < k;
+  const bool ok = __shfl(my_ok ? 1 : 0, js < k ? js : 0) != 0;
+  float sc = sc_lds[lane];
+  sc = live ? (ok ? sc * a.scale : -1e10f) : -__builtin_inff();
+  float mx = sc;
+#pragma unroll
+  for (int o = H; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  const float ev = live ? expf(sc - mx) : 0.f;
+  float sum = ev;
+#pragma unroll
+  for (int o = H; o < 64; o <<= 1) sum += __shfl_xor(sum, o);
+  const float A = ev / sum;
+
+  // ---- zbar[h] = sum_s A[h][s] z[s]: one chain over the slots, the waves in turn ----
+  float* __restrict__ zb = a.zbar + r * (long long)H * a.Cs;
+  for (int w = w_first; w < W; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        float4 ae = make_float4(0.f, 0.f, 0.f, 0.f), an4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        float an = 0.f, at0 = 0.f, at1 = 0.f;
+        if (w > w_first) {
+          const float(*src)[kWave] = acc_lds + h * 10;
+          ae = make_float4(src[0][lane], src[1][lane], src[2][lane], src[3][lane]);
+          if (NBV) an4 = make_float4(src[4][lane], src[5][lane], src[6][lane], src[7][lane]);
+          else an = src[4][lane];
+          at0 = src[8][lane];
+          at1 = src[9][lane];
+        }
+#pragma unroll
+        for (int s = 0; s < Q; ++s) {
+          const int idx = (s_lo + s) * H + h;  // lanes past k * H hold weight 0
+          const float wgt = idx < 64 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(A), idx < 64 ? idx : 0)) : 0.f;
+          ae.x = __fmaf_rn(wgt, ze[s].x, ae.x); ae.y = __fmaf_rn(wgt, ze[s].y, ae.y);
+          ae.z = __fmaf_rn(wgt, ze[s].z, ae.z); ae.w = __fmaf_rn(wgt, ze[s].w, ae.w);
+          if (NBV) {
+            an4.x = __fmaf_rn(wgt, zn[NBV ? s : 0].x, an4.x); an4.y = __fmaf_rn(wgt, zn[NBV ? s : 0].y, an4.y);
+            an4.z = __fmaf_rn(wgt, zn[NBV ? s : 0].z, an4.z); an4.w = __fmaf_rn(wgt, zn[NBV ? s : 0].w, an4.w);
+          } else {
+            an = __fmaf_rn(wgt, zs[NBV ? 0 : s], an);
+          }
+          at0 = __fmaf_rn(wgt, tz0[s], at0);
+          at1 = __fmaf_rn(wgt, tz1[s], at1);
+        }
+        if (w + 1 < W) {
+          float(*dst)[kWave] = acc_lds + h * 10;
+          dst[0][lane] = ae.x; dst[1][lane] = ae.y; dst[2][lane] = ae.z; dst[3][lane] = ae.w;
+          if (NBV) { dst[4][lane] = an4.x; dst[5][lane] = an4.y; dst[6][lane] = an4.z; dst[7][lane] = an4.w; }
+          else dst[4][lane] = an;
+          dst[8][lane] = at0;
+          dst[9][lane] = at1;
+        } else {
+          float* zh = zb + h * a.Cs;
+          if (NBV) {
+            if (lane < d4) { zh[4 * lane] = an4.x; zh[4 * lane + 1] = an4.y; zh[4 * lane + 2] = an4.z; zh[4 * lane + 3] = an4.w; }
+          } else if (lane < d) {
+            zh[lane] = an;
+          }
+          if (e_on) { zh[d + 4 * lane] = ae.x; zh[d + 4 * lane + 1] = ae.y; zh[d + 4 * lane + 2] = ae.z; zh[d + 4 * lane + 3] = ae.w; }
+          if (t0_on) zh[d + D + lane] = at0;
+          if (t1_on) zh[d + D + lane + kWave] = at1;
+        }
+      }
+    }
+    if (w + 1 < W) __syncthreads();
+  }
+}
+
 template <int H, int G>
 static void launch_attn(dim3 grid, dim3 block, size_t lds, hipStream_t st, const AttnArgs& a) {
   if constexpr (G * H <= 64) hipLaunchKernelGGL((tgat_attn_reduce_kernel<H, G>), grid, block, lds, st, a);
@@ -1782,10 +2042,17 @@ static bool launch_attn_reg(hipStream_t st, const AttnArgs& a) {
   const dim3 grid((unsigned)((a.R + wpb - 1) / wpb)), block(64 * wpb);
   bool idx = false;
   for (int i = 0; i < TGMX_TGAT_MAX_LAYERS; ++i) idx |= a.seg_uniq[i] || a.seg_live[i] || a.seg_nidx[i];
+  // few rows: four waves per row (tgat_attn_reduce_mw_kernel; TGMX_ATTN_MW=0: the A/B knob)
+  static const bool mw_knob = [] { const char* e = getenv("TGMX_ATTN_MW"); return !(e && e[0] == '0'); }();
+  const bool mw = mw_knob && a.R <= 2048 && !idx && !a.probs && !a.drop.thresh && !a.mask;
 #define TGMX_REG(G_)                                                                                        \
   if constexpr (G_ * H <= 64) {                                                                             \
     if (a.k <= G_) {                                                                                        \
-      if (idx) {                                                                                            \
+      if (mw) {                                                                                             \
+        const dim3 mgrid((unsigned)a.R), mblock(256);                                                       \
+        if (nbv) hipLaunchKernelGGL((tgat_attn_reduce_mw_kernel<H, G_, true>), mgrid, mblock, 0, st, a);    \
+        else hipLaunchKernelGGL((tgat_attn_reduce_mw_kernel<H, G_, false>), mgrid, mblock, 0, st, a);       \
+      } else if (idx) {                                                                                            \
         if (nbv) hipLaunchKernelGGL((tgat_attn_reduce_reg_kernel<H, G_, true, true>), grid, block, 0, st, a);  \
         else hipLaunchKernelGGL((tgat_attn_reduce_reg_kernel<H, G_, false, true>), grid, block, 0, st, a);     \
       } else if (nbv) {                                                                                     \
@@ -1909,9 +2176,8 @@ extern "C" int tgmx_ln_residual_concat(const float* y, int64_t ldy, const float*
   return ln_residual_concat_impl(y, ldy, res, ldr, gamma, beta, O, eps, z0, d0, R, out, ldo, nullptr, 0, 0, nullptr, 0, stream);
 }
 
-// qf[r, i] = v[i] + sum_{j < d} x[r, j] * U[i, j]  for d <= 4 (U rows padded to 4): the folded queries of a layer with a narrow input
-// as a streaming outer product -- the same fma chain per element as the K = d GEMM it replaces (bit-identical), at the write
-// bandwidth instead of MFMA tiles that are 15/16 padding
+// qf[r, i] = fma(x[r, d-1], U[i, d-1], ... fma(x[r, 0], U[i, 0], v[i]))  for d <= 4 (U rows padded to 4): the folded queries of a layer
+// with a narrow input as a streaming outer product, at the write bandwidth instead of MFMA tiles that are 15/16 padding
 __global__ __launch_bounds__(256) void tgat_qfold_small_kernel(const float* __restrict__ x, long long ldx, int d, const float* __restrict__ U,
                                                                const float* __restrict__ v, int n4, long long R, float* __restrict__ out,
                                                                long long ldo, const RowSegs segs) {
@@ -1931,16 +2197,17 @@ __global__ __launch_bounds__(256) void tgat_qfold_small_kernel(const float* __re
     for (long long r = rb * RB; r < r1; ++r) {
       const float* xr = x + r * ldx;
       const float x0 = xr[0], x1 = d > 1 ? xr[1] : 0.f, x2 = d > 2 ? xr[2] : 0.f, x3 = d > 3 ? xr[3] : 0.f;
+      // one explicit fma chain starting from v (a multiply followed by an add would be the compiler's to contract or not)
       float o[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        float acc = __fmul_rn(x0, w[u].x);
+        float acc = __fmaf_rn(x0, w[u].x, u == 0 ? vv.x : u == 1 ? vv.y : u == 2 ? vv.z : vv.w);
         if (d > 1) acc = __fmaf_rn(x1, w[u].y, acc);
         if (d > 2) acc = __fmaf_rn(x2, w[u].z, acc);
         if (d > 3) acc = __fmaf_rn(x3, w[u].w, acc);
         o[u] = acc;
       }
-      *reinterpret_cast<float4*>(out + r * ldo + i) = make_float4(__fadd_rn(o[0], vv.x), __fadd_rn(o[1], vv.y), __fadd_rn(o[2], vv.z), __fadd_rn(o[3], vv.w));
+      *reinterpret_cast<float4*>(out + r * ldo + i) = make_float4(o[0], o[1], o[2], o[3]);
     }
   }
 }
