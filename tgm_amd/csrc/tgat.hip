@@ -913,7 +913,10 @@ __global__ __launch_bounds__(kC64Threads) void tgat_chain64_kernel(const ChainAr
   float* stat = b2 + 16 * nbEo;                     // [4 tiles][2 halves][16 rows] LayerNorm partial sums
   float* xs = stat + kC64Waves * 16;                // [64, d]  residual feature part
   float* zs = xs + 64 * d;                          // [64, d0] skip features
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tile = wave >> 1, half = wave & 1;
+  // the two waves of a tile own the even / the odd output blocks (ceil vs floor of half the blocks: 912 vs 796 MFMAs a wave at the headline
+  // widths).  Waves w and w + 4 share a SIMD: tiles 2 and 3 swap the roles, so every SIMD carries one heavier and one lighter wave
+  // (59.2 -> 57.9 us)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tile = wave >> 1, half = (wave ^ (wave >> 2)) & 1;
   const int r = lane & 15, rq = lane >> 4;
   const long long w0 = (long long)blockIdx.x * 64;  // first row of the workgroup
   const long long m0 = w0 + tile * 16;              // first row of this wave's tile
@@ -2089,7 +2092,7 @@ extern "C" int tgmx_sgemm_nt(const float* A, int64_t lda, const float* B, int64_
   // whenever there is more than one 16-wide k-step to hand out; measured on every GEMM shape of the TGAT path
   // (600 .. 12 600 rows, K = 102 .. 448: 1.1x .. 2.9x) and neutral at 4096^3.
   static const bool small_knob = [] { const char* e = getenv("TGMX_GEMM_SMALL"); return !(e && e[0] == '0'); }();  // A/B knob
-  if (small_knob && M <= 2048 && K > 16 && K <= 512) {  // few rows: the latency-shaped kernel (see sgemm_nt_small_kernel)
+  if (small_knob && M <= 2048 && K > 16 && K <= 512) {  // (tried up to 64 k rows on the TGN pipeline's GEMMs: no gain past ~2 k)  // few rows: the latency-shaped kernel (see sgemm_nt_small_kernel)
     const dim3 sgrid((unsigned)((M + 31) / 32), (unsigned)((N + 31) / 32), (unsigned)batch), sblock(512);
     const int steps = (K + 127) / 128;
 #define TGMX_GEMM_S(AV_, BV_)                                                                              \
