@@ -469,6 +469,10 @@ typedef struct tgmx_tgat_layer {
    *   8, 9  qf_v, qf_U of time column d + D + lane       10, 11  the same for time column d + D + lane + 64
    *   12, 13  qf_v, qf_U of neighbor column `lane`       14, 15  zero;   columns that do not exist: zero.       NULL: qf is a buffer. */
   const float* qf_lane;
+  /* optional (inference, H == 2 and 2 * ceil(dh / 16) <= 12): both heads' W_V for the one-kernel tail's stage 1 as ONE tiled matrix --
+   * tile16(S, 2 * 16 * ceil(dh / 16), C) where S stacks the heads, head h's dh rows at row h * 16 * ceil(dh / 16), zero rows between:
+   * the stage then runs both heads' output blocks in one pass.  NULL: the per-head images of W_V_t16. */
+  const float* W_V_t16c;
   int32_t d, D, T, O, H, emb, emb_out;
   float ln_eps;
 } tgmx_tgat_layer_t;

@@ -206,3 +206,38 @@ def test_in_kernel_folded_queries_equal_the_qf_buffer(features, compact):
             assert torch.equal(z, z_buf), f'batch {n}: max |d| = {(z - z_buf).abs().max().item():.3e}'
             checked += 1
     assert checked >= 4
+
+
+def test_both_heads_in_one_pass_equal_the_per_head_passes():
+    """ABI v6, ``tgmx_tgat_layer_t.W_V_t16c``: the one-kernel tail's first stage over both heads' output blocks at once (the stacked,
+    per-head padded W_V as one tiled matrix).  Every output block still accumulates its k-steps in ascending order: the embeddings must
+    equal the per-head passes' bit for bit."""
+    from tgm_amd.nn import TGAT
+    from tgm_amd.synth import make_stream
+
+    st = make_stream('wiki', seed=8, num_edges=8_000, edge_dim=172)
+    dg, hm, loader = _pipeline(st, [20, 20], 'ring', 'by_id')
+    torch.manual_seed(4)
+    enc = TGAT(node_dim=1, edge_dim=172, time_dim=100, embed_dim=172, num_layers=2).to(DEV).eval()
+    with torch.no_grad():
+        for p in enc.parameters():
+            p.add_(0.03 * torch.randn_like(p))
+    node_x = dg.static_node_x
+    checked = 0
+    with hm.activate('k'), torch.no_grad():
+        for n, b in enumerate(loader):
+            if n % 9 != 4:
+                continue
+            args = (node_x, b.seed_nids, b.seed_times, b.nbr_nids, b.nbr_edge_x, b.nbr_edge_time)
+            z = enc(*args)
+            model = enc._desc_cache[1][0]
+            image = model.layers[0].W_V_t16c
+            assert image, 'two heads of 51 columns: 2 x 4 blocks fit the 12 a stage may have'
+            model.layers[0].W_V_t16c = None
+            try:
+                z_per_head = enc(*args)
+            finally:
+                model.layers[0].W_V_t16c = image
+            assert torch.equal(z, z_per_head), f'batch {n}: max |d| = {(z - z_per_head).abs().max().item():.3e}'
+            checked += 1
+    assert checked >= 4

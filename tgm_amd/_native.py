@@ -109,7 +109,7 @@ def dropout_desc(p: float, seed: int, stream: int, row0: int = 0):
 
 class TgatLayer(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in ('W_Q', 'W_K_t', 'W_V', 'W_O', 'b_O', 'ln_g', 'ln_b', 'fc1_w', 'fc1_b', 'fc2_w', 'fc2_b', 'qf_U', 'qf_v',
-                                        'W_V_t16', 'W_O_t16', 'fc1_t16', 'fc2_t16', 'qf_lane')] + [
+                                        'W_V_t16', 'W_O_t16', 'fc1_t16', 'fc2_t16', 'qf_lane', 'W_V_t16c')] + [
         (n, c_int32) for n in ('d', 'D', 'T', 'O', 'H', 'emb', 'emb_out')
     ] + [('ln_eps', ctypes.c_float)]
 

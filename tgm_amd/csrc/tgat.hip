@@ -446,6 +446,7 @@ struct ChainArgs {
   const float* tb;    // [T] Time2Vec bias: the residual's time part is cos(tb) (attention.py:93-95)
   const float* z0;    // [R, d0] skip features for the merge layer
   const float *W_V, *W_O, *b_O, *ln_g, *ln_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+  const float* W_Vc;  // chain64, H == 2: both heads' W_V stacked (per head zero-padded to 16-row blocks) and tiled as ONE matrix; NULL: per head
   float* out;         // [R, ldo]
   long long R, ld_zbar, ldx, ldo;
   int d, T, d0, O, H, C, emb, emb_out;
@@ -886,6 +887,82 @@ struct C64Gemm {
       mv = mv_next;
     }
   }
+
+  // run() for stage 1 with BOTH heads' output blocks in one pass (NBT = 2 x blocks per head; block b belongs to head b / (NBT / 2)): the
+  // weights are ONE stream of chunks over the stacked, per-head zero-padded W_V (tgmx_tgat_layer_t.W_V_t16c), the two heads' zbar rows come
+  // from global memory (row0, row1; the first chunk of both in xc0 / xc1 on entry).  Per k-step a wave issues 4 NBW MFMAs in groups of NBW
+  // -- twice the per-head pass's -- against the same per-group bookkeeping, and the stage is half as many chunks.
+  static __device__ __forceinline__ void run_heads(const C64Stream st, int& ck, int& cc, int& cp, int& q, int K, const float* __restrict__ row0,
+                                                   const float* __restrict__ row1, int Kxp, float4 (&xc0)[CK], float4 (&xc1)[CK],
+                                                   float* __restrict__ wbuf, floatx4 (&acc)[NBS], int tid) {
+    static_assert(XG && NBT % 2 == 0, "two heads, activations from global memory");
+    static_assert(4 * CK > CK + kC64Issue, "not enough MFMA groups per chunk to carry the loads");
+    constexpr int Q4 = (NBW + 3) / 4, HBc = NBT / 2;
+    const int lane = tid & 63;
+    const int KB = (K + 15) / 16, nchunks = (KB + CK - 1) / CK;
+#pragma unroll
+    for (int i = 0; i < NBS; ++i) acc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+    float4 w[2][NBS];
+    {
+      const float* wl = wbuf + (q % kC64Ring) * (kC64ChunkTiles * 256) + lane * 4;
+#pragma unroll
+      for (int i = 0; i < NBW; ++i) w[0][i] = *reinterpret_cast<const float4*>(wl + (HALF + 2 * i) * 256);
+    }
+    C64Moves mv = c64_next_moves(st, ck, cc, cp, wbuf, tid);  // position q + 2
+    for (int c = 0; c < nchunks; ++c) {
+      const bool more = c + 1 < nchunks;
+      const int cnext = more ? c + 1 : c;  // (the last chunk refills itself: harmless, keeps the body branch-free)
+      C64Moves mv_next = mv;
+      const float* wl = wbuf + (q % kC64Ring) * (kC64ChunkTiles * 256) + lane * 4;
+      const float* wl_next = wbuf + ((q + 1) % kC64Ring) * (kC64ChunkTiles * 256) + lane * 4;
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s2 = 0; s2 < CK; ++s2) {
+        float4(&wc)[NBS] = w[s2 & 1];
+        float4(&wn)[NBS] = w[(s2 & 1) ^ 1];
+        float4 x0n = xc0[s2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int grp = 4 * s2 + j;
+          if (s2 == CK - 1 && j == 3) {
+            c64_sync<(kC64Ring - 2) * kC64Issue>();
+            if (more) {
+#pragma unroll
+              for (int i = 0; i < NBW; ++i) wn[i] = *reinterpret_cast<const float4*>(wl_next + (HALF + 2 * i) * 256);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+#pragma unroll
+          for (int i = 0; i < NBW; ++i) {
+            const bool h1 = (HALF + 2 * i) >= HBc;  // compile-time per i
+            const float a = j == 0 ? wc[i].x : j == 1 ? wc[i].y : j == 2 ? wc[i].z : wc[i].w;
+            const float b = h1 ? (j == 0 ? xc1[s2].x : j == 1 ? xc1[s2].y : j == 2 ? xc1[s2].z : xc1[s2].w)
+                               : (j == 0 ? xc0[s2].x : j == 1 ? xc0[s2].y : j == 2 ? xc0[s2].z : xc0[s2].w);
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (grp == CK + kC64Issue && more) mv_next = c64_next_moves(st, ck, cc, cp, wbuf, tid);
+          if (grp >= CK && grp < CK + kC64Issue) c64_dma(mv.src[grp - CK], mv.dst[grp - CK]);
+          if (j == 2) x0n = xload(row0, cnext * CK + s2, K, Kxp, lane);  // head 0's vector of the next chunk: parked until step s2 is done with xc0[s2]
+          if (j == 3) {
+            xc1[s2] = xload(row1, cnext * CK + s2, K, Kxp, lane);
+            xc0[s2] = x0n;
+          }
+          if (s2 + 1 < CK) {
+#pragma unroll
+            for (int i = j * Q4; i < (j + 1) * Q4 && i < NBW; ++i) wn[i] = *reinterpret_cast<const float4*>(wl + ((s2 + 1) * NBT + HALF + 2 * i) * 256);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if constexpr ((CK & 1) == 1) {
+#pragma unroll
+        for (int i = 0; i < NBW; ++i) w[0][i] = w[1][i];
+      }
+      ++q;
+      mv = mv_next;
+    }
+  }
 };
 
 // run f(integral_constant<NB>) for the (workgroup-uniform) block count nb in [1, MAXB]
@@ -928,9 +1005,10 @@ __global__ __launch_bounds__(kC64Threads) void tgat_chain64_kernel(const ChainAr
   int q = 0;
   C64Stream st;
   int ck = 0, cc = 0, cp = 0;
-  st.H = H; st.vstride = (long long)HB * KBc * 256;
-  st.W_V = g.W_V; st.W_O = g.W_O; st.W_F1 = g.fc1_w; st.W_F2 = g.fc2_w;
-  c64_geom(HB, g.C, st.CT_V, st.nch_V, st.nt_V);
+  const bool both = g.W_Vc != nullptr;  // stage 1 as one pass over both heads
+  st.H = both ? 1 : H; st.vstride = (long long)HB * KBc * 256;
+  st.W_V = both ? g.W_Vc : g.W_V; st.W_O = g.W_O; st.W_F1 = g.fc1_w; st.W_F2 = g.fc2_w;
+  c64_geom(both ? 2 * HB : HB, g.C, st.CT_V, st.nch_V, st.nt_V);
   c64_geom(nbO, O, st.CT_O, st.nch_O, st.nt_O);
   c64_geom(nbE, O + d0, st.CT_F1, st.nch_F1, st.nt_F1);
   c64_geom(nbEo, g.emb, st.CT_F2, st.nch_F2, st.nt_F2);
@@ -980,6 +1058,35 @@ __global__ __launch_bounds__(kC64Threads) void tgat_chain64_kernel(const ChainAr
     long long grow = m0 + (r < rows ? r : rows - 1);
     grow = grow < g.R ? (grow < 0 ? 0 : grow) : g.R - 1;
     const float* zrow = g.zbar + grow * g.ld_zbar;
+    if (both) {
+      chain64_dispatch<1, kC64MaxB>(2 * HB, [&](auto nbc) __attribute__((always_inline)) {
+        with_half(nbc, [&](auto nbc2, auto hc) __attribute__((always_inline)) {
+          constexpr int NBT = decltype(nbc2)::value, HALF = decltype(hc)::value;
+          if constexpr (NBT % 2 == 0) {
+            using G = C64Gemm<NBT, HALF, true>;
+            float4 xc0[G::CK], xc1[G::CK];
+#pragma unroll
+            for (int s = 0; s < G::CK; ++s) {
+              xc0[s] = G::xload(zrow, s, g.C, g.Cp, lane);
+              xc1[s] = G::xload(zrow + g.Cp, s, g.C, g.Cp, lane);
+            }
+            floatx4 acc[G::NBS];
+            G::run_heads(st, ck, cc, cp, q, g.C, zrow, zrow + g.Cp, g.Cp, xc0, xc1, wbuf, acc, tid);
+            // head 0 writes its dh real columns only: its zero padding would land on head 1's first columns, written in the same pass
+#pragma unroll
+            for (int i = 0; i < G::NBW; ++i) {
+              constexpr int HBc = NBT / 2;
+              const int b = HALF + 2 * i, h = b >= HBc ? 1 : 0, nb = b - h * HBc;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const int cl = 16 * nb + 4 * rq + j;
+                if (h == 1 || cl < dh) slab[r * LD + h * dh + cl] = acc[i][j];
+              }
+            }
+          }
+        });
+      });
+    } else
     chain64_dispatch<1, kC64MaxB>(HB, [&](auto nbc) __attribute__((always_inline)) {
       with_half(nbc, [&](auto nbc2, auto hc) __attribute__((always_inline)) {
         constexpr int NBT = decltype(nbc2)::value, HALF = decltype(hc)::value;
@@ -2558,6 +2665,8 @@ static int launch_chain64(const tgmx_tgat_layer_t& ly, const tgmx_tgat_layer_lay
   g.segs = segs;
   g.zbar = zbar; g.x = x; g.tb = tb; g.z0 = z0;
   g.W_V = ly.W_V_t16; g.W_O = ly.W_O_t16; g.b_O = ly.b_O; g.ln_g = ly.ln_g; g.ln_b = ly.ln_b;
+  static const bool both_knob = [] { const char* e = getenv("TGMX_C64_BOTH_HEADS"); return !(e && e[0] == '0'); }();  // A/B knob
+  g.W_Vc = (both_knob && ly.H == 2 && 2 * blocks[0] <= kC64MaxB) ? ly.W_V_t16c : nullptr;
   g.fc1_w = ly.fc1_t16; g.fc1_b = ly.fc1_b; g.fc2_w = ly.fc2_t16; g.fc2_b = ly.fc2_b;
   g.out = out; g.R = R; g.ld_zbar = (long long)ly.H * lo.Cp; g.ldx = ldx; g.ldo = ldo;
   g.d = ly.d; g.T = ly.T; g.d0 = d0; g.O = ly.O; g.H = ly.H; g.C = ly.d + ly.D + ly.T; g.emb = ly.emb; g.emb_out = ly.emb_out;

@@ -214,6 +214,13 @@ class TGAT(TransientCaches, nn.Module):
                 return out.data_ptr()
 
             ly.W_V_t16, ly.W_O_t16 = tiled(WKV[O:], H), tiled(attn.W_O.weight)
+            ly.W_V_t16c = None
+            hb16 = (dh + 15) // 16 * 16
+            if H == 2 and 2 * hb16 // 16 <= 12:  # both heads stacked, each zero-padded to whole 16-row blocks, tiled as one matrix
+                stack = torch.zeros((2 * hb16, WKV.shape[1]), dtype=torch.float32, device=dev)
+                for h in range(2):
+                    stack[h * hb16 : h * hb16 + dh] = WKV[O + h * dh : O + (h + 1) * dh]
+                ly.W_V_t16c = tiled(stack)
             ly.fc1_t16, ly.fc2_t16 = tiled(merge.fc1.weight), tiled(merge.fc2.weight)
         self._desc_folded = True
 
