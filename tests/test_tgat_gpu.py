@@ -302,11 +302,14 @@ def test_tgat_headline_shape_vs_oracle():
 
 @pytest.mark.parametrize('nd,ed,td,emb,H,ks,S0,L', [(8, 12, 16, 32, 4, [16, 16], 144, 2), (3, 8, 10, 20, 1, [30], 2100, 1), (16, 4, 6, 24, 2, [8, 8, 8], 40, 3),
                                                    (1, 16, 12, 16, 8, [20, 20], 110, 2), (40, 60, 88, 190, 4, [6], 2100, 1),
-                                                   (21, 9, 30, 76, 4, [5, 5], 400, 2), (8, 12, 200, 200, 4, [8], 2100, 1)])
+                                                   (21, 9, 30, 76, 4, [5, 5], 400, 2), (8, 12, 200, 200, 4, [8], 2100, 1),
+                                                   (1, 172, 100, 172, 2, [20, 20], 40, 2), (1, 16, 12, 16, 2, [10, 10], 15, 2), (1, 8, 8, 16, 1, [20], 3000, 1)])
 def test_tgat_fused_inference_paths_vs_oracle(nd, ed, td, emb, H, ks, S0, L):
     """Shapes that take the fused row-tile chain (>= 2048 rows in a layer) and the folded-query GEMM with other head
     counts, widths, depths and k than the example dims; random hop trees with pads (-1 ids, zero times / features).
-    The last shape is wider than the 16-row-tile kernel takes (208 / 200 columns > 192): the 32-row-tile kernel runs."""
+    The shape of 200 / 208 columns is wider than the 16-row-tile kernel takes (> 192): the 32-row-tile kernel runs.  The last three
+    have one node feature: the folded queries are evaluated inside the attention kernel (``qf_lane``) -- on four waves per row (layers
+    of at most 2048 rows), with k = 10, and with one head on the one-wave kernel."""
     from oracle import tgat_ref
     from tgm_amd.nn import TGAT
 
