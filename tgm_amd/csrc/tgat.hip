@@ -1308,6 +1308,50 @@ __device__ __forceinline__ AttnLevel attn_level(const AttnArgs& a, long long r) 
   return v;
 }
 
+// The value of lane (lane ^ O), O a power of two, WITHOUT the LDS crossbar: __shfl_xor is a ds_bpermute_b32 (an LDS-pipeline round trip,
+// ~150 cycles), and a row of this kernel runs ~25 of them in dependent chains -- the score reduction's last four levels, the softmax's two
+// butterflies -- with two waves per SIMD to hide them behind.  Data parallel primitives instead (a few cycles each): quad permutes for
+// 1 and 2, half-row mirror + quad reverse for 4 (i ^ 7 ^ 3), a row rotation by 8, and the gfx950 row-pair / half-wave swaps for 16 and 32.
+// Pure data movement: every sum and maximum keeps its operands and their order.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+template <int O>
+__device__ __forceinline__ float lane_xor(float v) {
+  static_assert(O == 1 || O == 2 || O == 4 || O == 8 || O == 16 || O == 32, "a power of two below the wave size");
+  if constexpr (O == 1) return dpp_mov<0xB1>(v);                      // quad_perm [1, 0, 3, 2]
+  else if constexpr (O == 2) return dpp_mov<0x4E>(v);                 // quad_perm [2, 3, 0, 1]
+  else if constexpr (O == 4) return dpp_mov<0x1B>(dpp_mov<0x141>(v));  // row_half_mirror (i ^ 7), then quad_perm [3, 2, 1, 0] (i ^ 3)
+  else if constexpr (O == 8) return dpp_mov<0x128>(v);                // row_ror:8
+  else if constexpr (O == 16) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float((lane_id() & 16) ? r[0] : r[1]);
+  } else {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float((lane_id() & 32) ? r[0] : r[1]);
+  }
+}
+// max / sum over the lanes that differ in the bits >= LO (LO = H: the slots of one head), as the xor butterfly LO, 2 LO, ..., 32
+template <int LO>
+__device__ __forceinline__ float butterfly_max(float v) {
+  if constexpr (LO <= 1) v = fmaxf(v, lane_xor<1>(v));
+  if constexpr (LO <= 2) v = fmaxf(v, lane_xor<2>(v));
+  if constexpr (LO <= 4) v = fmaxf(v, lane_xor<4>(v));
+  if constexpr (LO <= 8) v = fmaxf(v, lane_xor<8>(v));
+  if constexpr (LO <= 16) v = fmaxf(v, lane_xor<16>(v));
+  return fmaxf(v, lane_xor<32>(v));
+}
+template <int LO>
+__device__ __forceinline__ float butterfly_sum(float v) {
+  if constexpr (LO <= 1) v += lane_xor<1>(v);
+  if constexpr (LO <= 2) v += lane_xor<2>(v);
+  if constexpr (LO <= 4) v += lane_xor<4>(v);
+  if constexpr (LO <= 8) v += lane_xor<8>(v);
+  if constexpr (LO <= 16) v += lane_xor<16>(v);
+  return v + lane_xor<32>(v);
+}
+
 // sum over the 64 lanes of P[j], delivered to lane j: 63 shuffles instead of 64 * 6.
 // (template steps: every register index must be a compile-time constant, or P spills to scratch)
 template <int HALF>
@@ -1363,7 +1407,7 @@ __device__ __forceinline__ void all_reduce_step(float (&P)[N]) {
       const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(P[i]), __float_as_uint(P[i]), false, false);
       P[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
     } else {
-      P[i] = P[i] + __shfl_xor(P[i], HALF);
+      P[i] = P[i] + lane_xor<HALF>(P[i]);
     }
   }
 }
@@ -1387,7 +1431,7 @@ __device__ __forceinline__ void scatter_step_n(float (&P)[N], int lane) {
 #pragma unroll
     for (int i = 0; i < HALF; ++i) {
       const float send = upper ? P[i] : P[i + HALF];
-      const float recv = __shfl_xor(send, HALF);
+      const float recv = lane_xor<HALF>(send);
       const float keep = upper ? P[i + HALF] : P[i];
       P[i] = keep + recv;
     }
@@ -1820,13 +1864,9 @@ __global__ __launch_bounds__(256) void tgat_attn_reduce_reg_kernel(const AttnArg
     const bool live = js < k;
     const bool ok = __shfl(my_ok ? 1 : 0, js < k ? js : 0) != 0;
     sc = live ? (ok ? sc * a.scale : -1e10f) : -__builtin_inff();
-    float mx = sc;
-#pragma unroll
-    for (int o = H; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    const float mx = butterfly_max<H>(sc);
     float ev = live ? expf(sc - mx) : 0.f;
-    float sum = ev;
-#pragma unroll
-    for (int o = H; o < 64; o <<= 1) sum += __shfl_xor(sum, o);
+    const float sum = butterfly_sum<H>(ev);
     float A = ev / sum;
     if (a.probs && live) a.probs[r * (long long)H * k + (lane - js * H) * k + js] = A;
     if (a.drop.thresh && live) A *= dropout_scale(a.drop, (unsigned long long)(a.drop_row0 + r) * (H * k) + (lane - js * H) * k + js);
@@ -2060,13 +2100,9 @@ __global__ __launch_bounds__(256) void tgat_attn_reduce_mw_kernel(const AttnArgs
   const bool ok = __shfl(my_ok ? 1 : 0, js < k ? js : 0) != 0;
   float sc = sc_lds[lane];
   sc = live ? (ok ? sc * a.scale : -1e10f) : -__builtin_inff();
-  float mx = sc;
-#pragma unroll
-  for (int o = H; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  const float mx = butterfly_max<H>(sc);
   const float ev = live ? expf(sc - mx) : 0.f;
-  float sum = ev;
-#pragma unroll
-  for (int o = H; o < 64; o <<= 1) sum += __shfl_xor(sum, o);
+  const float sum = butterfly_sum<H>(ev);
   const float A = ev / sum;
 
   // ---- zbar[h] = sum_s A[h][s] z[s]: one chain over the slots, the waves in turn ----
