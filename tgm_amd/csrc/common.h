@@ -216,4 +216,55 @@ __device__ __forceinline__ float sin_t2v(float x) {
   return (q >= 2) ? -v : v;
 }
 
+// ---- the sampled edge list's row scan (examples/linkproppred/tgn.py:80-92; csrc/tgn.hip) as a device function: ONE workgroup (any size that
+// is a multiple of 64, <= 1024) counts a seed row's valid slots and scans the counts.  Its own launch in tgmx_tgn_edge_list; in the lowered
+// chain it RIDES the unique-ids marking launch as one more workgroup (it reads the sampler's outputs only), so the list's write launch
+// finds the offsets ready -- one single-workgroup launch (6 us of pure latency per batch) less on the critical path.
+__device__ __forceinline__ void edge_list_scan_body(const int32_t* __restrict__ nbr, long long S, int k, int64_t* __restrict__ row_off,
+                                                    int64_t* __restrict__ count) {
+  __shared__ long long els_wave_tot[16];
+  __shared__ long long els_carry;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, P = blockDim.x;
+  if (tid == 0) els_carry = 0;
+  __syncthreads();
+  for (long long r0 = 0; r0 < S; r0 += P) {
+    const long long r = r0 + tid;
+    long long c = 0;
+    if (r < S)
+      for (int s = 0; s < k; ++s) c += nbr[r * k + s] != -1;
+    long long incl = c;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+      const long long o = __shfl_up(incl, off);
+      if (lane >= off) incl += o;
+    }
+    if (lane == kWave - 1) els_wave_tot[wave] = incl;
+    __syncthreads();
+    long long before = els_carry;
+    for (int w = 0; w < wave; ++w) before += els_wave_tot[w];
+    if (r < S) row_off[r] = before + incl - c;
+    __syncthreads();
+    if (tid == P - 1) els_carry = before + incl;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    row_off[S] = els_carry;
+    *count = els_carry;
+  }
+}
+struct EdgeListScan {  // the rider's arguments (nbr == NULL: none)
+  const int32_t* nbr;
+  long long S;
+  int k;
+  int64_t* row_off;
+  int64_t* count;
+};
+}  // namespace tgmx
+// the lowered chain's entries (csrc/pipeline.hip): the unique ids with the edge list's scan riding along, and the list with its scan done
+int tgmx_internal_unique_ids(const int32_t* const* parts, const int64_t* part_sizes, int32_t num_parts, int32_t num_nodes, void* workspace,
+                             int32_t* out_ids, int64_t* out_count, int32_t* status, const tgmx::EdgeListScan* rider, tgmx_stream_t stream);
+int tgmx_internal_edge_list(const int32_t* seed, const int32_t* nbr, const int64_t* nbr_t, const float* nbr_x, const int32_t* nbr_eid, const float* table,
+                            int64_t S, int32_t k, int32_t D, const int32_t* uniq, int64_t U, const int64_t* uniq_count, int64_t cap, int64_t* row_off,
+                            int64_t* edge_index, int64_t* edge_t, float* edge_x, int64_t* count, bool scan_done, tgmx_stream_t stream);
+namespace tgmx {
 }  // namespace tgmx

@@ -15,11 +15,16 @@ struct MarkArgs {
   unsigned int* bitmap;
   int32_t* status;
   int parts, N;
+  EdgeListScan rider;  // nbr != NULL: the LAST workgroup of the launch scans the edge list's rows instead of marking (common.h)
 };
 
 __global__ __launch_bounds__(256) void dedup_mark_kernel(const MarkArgs a) {
+  if (a.rider.nbr && blockIdx.x == gridDim.x - 1) {
+    edge_list_scan_body(a.rider.nbr, a.rider.S, a.rider.k, a.rider.row_off, a.rider.count);
+    return;
+  }
   const long long total = a.end[a.parts - 1];
-  const long long step = (long long)gridDim.x * blockDim.x;
+  const long long step = (long long)(gridDim.x - (a.rider.nbr ? 1 : 0)) * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
     const int32_t* p = a.part[0];
     long long base = 0;
@@ -125,6 +130,11 @@ extern "C" size_t tgmx_unique_ids_workspace_bytes(int32_t num_nodes) {
 
 extern "C" int tgmx_unique_ids(const int32_t* const* parts, const int64_t* part_sizes, int32_t num_parts, int32_t num_nodes,
                                void* workspace, int32_t* out_ids, int64_t* out_count, int32_t* status, tgmx_stream_t stream) {
+  return tgmx_internal_unique_ids(parts, part_sizes, num_parts, num_nodes, workspace, out_ids, out_count, status, nullptr, stream);
+}
+
+int tgmx_internal_unique_ids(const int32_t* const* parts, const int64_t* part_sizes, int32_t num_parts, int32_t num_nodes, void* workspace,
+                             int32_t* out_ids, int64_t* out_count, int32_t* status, const EdgeListScan* rider, tgmx_stream_t stream) {
   TGMX_REQUIRE(num_parts > 0 && num_parts <= kMaxParts && num_nodes > 0, "unique_ids: %d parts (1..%d), num_nodes=%d", num_parts, kMaxParts,
                num_nodes);
   TGMX_REQUIRE(parts && part_sizes && workspace && out_ids && out_count && status, "unique_ids: null pointer");
@@ -141,10 +151,12 @@ extern "C" int tgmx_unique_ids(const int32_t* const* parts, const int64_t* part_
     m.end[p] = total;
   }
   m.bitmap = bitmap; m.status = status; m.parts = num_parts; m.N = num_nodes;
-  if (total > 0) {
+  const bool ride = rider && rider->nbr && rider->S > 0;
+  if (ride) m.rider = *rider;
+  if (total > 0 || ride) {
     long long blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(dedup_mark_kernel, dim3((unsigned)blocks), dim3(256), 0, st, m);
+    hipLaunchKernelGGL(dedup_mark_kernel, dim3((unsigned)blocks + (ride ? 1u : 0u)), dim3(256), 0, st, m);
   }
   hipLaunchKernelGGL(dedup_scan_compact_kernel, dim3(1), dim3(1024), 0, st, bitmap, words, out_ids, out_count);
   TGMX_CHECK_LAUNCH("unique_ids");

@@ -17,6 +17,7 @@ static int pipeline_post(const tgmx_pipeline_t* p, const tgmx_recency_step_t& s,
   long long rows[TGMX_MAX_HOPS + 1];  // rows[h] = seeds of hop h
   rows[0] = share * p->n_roles;
   for (int h = 0; h < s.n_hops; ++h) rows[h + 1] = rows[h] * s.k[h];
+  bool scan_rides = false;
   if (post->dedup) {
     TGMX_REQUIRE(post->dedup_ws && post->uniq_out, "pipeline_step: null dedup buffer");
     const int32_t* parts[16];
@@ -27,8 +28,17 @@ static int pipeline_post(const tgmx_pipeline_t* p, const tgmx_recency_step_t& s,
     if (post->dedup_neg && s.neg_out) { parts[np] = s.neg_out; sizes[np++] = share; }
     if (post->dedup_nbr)
       for (int h = 0; h < s.n_hops && np < 16; ++h) { parts[np] = s.out_nid[h]; sizes[np++] = rows[h + 1]; }
-    const int rc = tgmx_unique_ids(parts, sizes, np, post->num_nodes, post->dedup_ws, post->uniq_out, post->dev_sizes,
-                                   reinterpret_cast<int32_t*>(post->dev_sizes + 1), stream);
+    // the edge list's row scan reads the sampler's outputs only: it rides the marking launch as one more workgroup
+    // (TGMX_EDGE_SCAN_RIDE=0: its own launch, the A/B knob)
+    static const bool ride_knob = [] { const char* e = getenv("TGMX_EDGE_SCAN_RIDE"); return !(e && e[0] == '0'); }();
+    EdgeListScan rider{};
+    if (ride_knob && post->edge_hop >= 0 && post->edge_hop < s.n_hops && rows[post->edge_hop] > 0 && post->row_off) {
+      const int h = post->edge_hop;
+      rider = EdgeListScan{s.out_nid[h], rows[h], s.k[h], post->row_off, post->dev_sizes + 2};
+      scan_rides = true;
+    }
+    const int rc = tgmx_internal_unique_ids(parts, sizes, np, post->num_nodes, post->dedup_ws, post->uniq_out, post->dev_sizes,
+                                            reinterpret_cast<int32_t*>(post->dev_sizes + 1), scan_rides ? &rider : nullptr, stream);
     if (rc) return rc;
   }
   if (post->edge_hop >= 0) {
@@ -37,11 +47,9 @@ static int pipeline_post(const tgmx_pipeline_t* p, const tgmx_recency_step_t& s,
     const int32_t* seeds = h == 0 ? out->seed_nid0 : s.out_nid[h - 1];
     // edge features by id (the lookups published edge ids, no dense copy): the rows come from the resident store where the list is written
     const bool by_id = !s.out_x[h] && s.out_eid[h] && s.D > 0;
-    const int rc = by_id ? tgmx_tgn_edge_list_by_id(seeds, s.out_nid[h], s.out_ts[h], s.out_eid[h], p->edge_x, rows[h], s.k[h], s.D, post->uniq_out, 0,
-                                                    post->dev_sizes, post->edge_cap, post->row_off, post->edge_index, post->edge_t, post->edge_x,
-                                                    post->dev_sizes + 2, stream)
-                         : tgmx_tgn_edge_list(seeds, s.out_nid[h], s.out_ts[h], s.out_x[h], rows[h], s.k[h], s.D, post->uniq_out, 0, post->dev_sizes,
-                                              post->edge_cap, post->row_off, post->edge_index, post->edge_t, post->edge_x, post->dev_sizes + 2, stream);
+    const int rc = tgmx_internal_edge_list(seeds, s.out_nid[h], s.out_ts[h], by_id ? nullptr : s.out_x[h], by_id ? s.out_eid[h] : nullptr,
+                                           by_id ? p->edge_x : nullptr, rows[h], s.k[h], s.D, post->uniq_out, 0, post->dev_sizes, post->edge_cap,
+                                           post->row_off, post->edge_index, post->edge_t, post->edge_x, post->dev_sizes + 2, scan_rides, stream);
     if (rc) return rc;
   }
   if (hipMemcpyAsync(post->host_sizes, post->dev_sizes, 3 * sizeof(int64_t), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||

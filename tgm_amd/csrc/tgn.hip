@@ -607,35 +607,7 @@ __global__ __launch_bounds__(256) void tconv_group_place_kernel(const int64_t* _
 // Two launches: per-row valid counts + exclusive scan (one workgroup), then a wave per seed row writes its valid slots.
 __global__ __launch_bounds__(1024) void edge_list_scan_kernel(const int32_t* __restrict__ nbr, long long S, int k, int64_t* __restrict__ row_off,
                                                               int64_t* __restrict__ count) {
-  __shared__ long long wave_tot[16];
-  __shared__ long long carry_s;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) carry_s = 0;
-  __syncthreads();
-  for (long long r0 = 0; r0 < S; r0 += 1024) {
-    const long long r = r0 + tid;
-    long long c = 0;
-    if (r < S)
-      for (int s = 0; s < k; ++s) c += nbr[r * k + s] != -1;
-    long long incl = c;
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-      const long long o = __shfl_up(incl, off);
-      if (lane >= off) incl += o;
-    }
-    if (lane == kWave - 1) wave_tot[wave] = incl;
-    __syncthreads();
-    long long before = carry_s;
-    for (int w = 0; w < wave; ++w) before += wave_tot[w];
-    if (r < S) row_off[r] = before + incl - c;
-    __syncthreads();
-    if (tid == 1023) carry_s = before + incl;
-    __syncthreads();
-  }
-  if (tid == 0) {
-    row_off[S] = carry_s;
-    *count = carry_s;
-  }
+  edge_list_scan_body(nbr, S, k, row_off, count);
 }
 
 struct EdgeListArgs {
@@ -914,7 +886,7 @@ extern "C" int tgmx_tgn_store_batch(const int32_t* src, const int32_t* dst, cons
 static int tgn_edge_list_impl(const int32_t* seed, const int32_t* nbr, const int64_t* nbr_t, const float* nbr_x, const int32_t* nbr_eid,
                               const float* table, int64_t S, int32_t k, int32_t D, const int32_t* uniq, int64_t U, const int64_t* uniq_count,
                               int64_t cap, int64_t* row_off, int64_t* edge_index, int64_t* edge_t, float* edge_x, int64_t* count,
-                              tgmx_stream_t stream) {
+                              tgmx_stream_t stream, bool scan_done = false) {
   TGMX_REQUIRE(S >= 0 && k > 0 && k <= 64 && D >= 0 && U >= 0 && cap >= S * k, "tgn_edge_list: bad sizes S=%lld k=%d cap=%lld", (long long)S, k,
                (long long)cap);
   TGMX_REQUIRE(count && row_off, "tgn_edge_list: null pointer");
@@ -924,7 +896,7 @@ static int tgn_edge_list_impl(const int32_t* seed, const int32_t* nbr, const int
     return TGMX_OK;
   }
   TGMX_REQUIRE(seed && nbr && nbr_t && (D == 0 || ((nbr_x || (nbr_eid && table)) && edge_x)) && uniq && edge_index && edge_t, "tgn_edge_list: null pointer");
-  hipLaunchKernelGGL(edge_list_scan_kernel, dim3(1), dim3(1024), 0, st, nbr, (long long)S, k, row_off, count);
+  if (!scan_done) hipLaunchKernelGGL(edge_list_scan_kernel, dim3(1), dim3(1024), 0, st, nbr, (long long)S, k, row_off, count);
   EdgeListArgs a{seed, nbr, nbr_t, nbr_x, nbr_x ? nullptr : nbr_eid, table, uniq, uniq_count, row_off, edge_index, edge_t, edge_x, S, U, cap, k, D};
   hipLaunchKernelGGL(edge_list_write_kernel, dim3((unsigned)((S + 3) / 4)), dim3(256), 0, st, a);
   TGMX_CHECK_LAUNCH("tgn_edge_list");
@@ -942,6 +914,13 @@ extern "C" int tgmx_tgn_edge_list_by_id(const int32_t* seed, const int32_t* nbr,
                                         int64_t* row_off, int64_t* edge_index, int64_t* edge_t, float* edge_x, int64_t* count, tgmx_stream_t stream) {
   return tgn_edge_list_impl(seed, nbr, nbr_t, nullptr, nbr_eid, edge_table, S, k, D, uniq, U, uniq_count, cap, row_off, edge_index, edge_t, edge_x, count,
                             stream);
+}
+
+int tgmx_internal_edge_list(const int32_t* seed, const int32_t* nbr, const int64_t* nbr_t, const float* nbr_x, const int32_t* nbr_eid, const float* table,
+                            int64_t S, int32_t k, int32_t D, const int32_t* uniq, int64_t U, const int64_t* uniq_count, int64_t cap, int64_t* row_off,
+                            int64_t* edge_index, int64_t* edge_t, float* edge_x, int64_t* count, bool scan_done, tgmx_stream_t stream) {
+  return tgn_edge_list_impl(seed, nbr, nbr_t, nbr_x, nbr_eid, table, S, k, D, uniq, U, uniq_count, cap, row_off, edge_index, edge_t, edge_x, count, stream,
+                            scan_done && S > 0);
 }
 
 extern "C" size_t tgmx_tgn_compact_workspace_bytes(int32_t num_nodes) {
