@@ -71,6 +71,8 @@ def parse_args():
     p.add_argument('--extras', default='auto', choices=['auto', 'on', 'off'],
                    help="the blocks next to the contract's fields -- the same launch with full feature writes / an output pool of two, the "
                    "HBM-bound comment-shaped lookup (roofline_hbm_bound), the TGAT aggregation block: 'auto' = at N = 1 on the wiki workload")
+    p.add_argument('--scale-comment', default='on', choices=['on', 'off'],
+                   help='N > 1: also measure the comment-shaped stream over the static index, batch-sharded and weak, in the same job (scale_comment)')
     p.add_argument('--no-default-path', action='store_true', help="skip the second timed region (the same steps through DGDataLoader / RecencyNeighborHook with their DEFAULT arguments)")
     return p.parse_args()
 
@@ -250,17 +252,19 @@ def launch_stats(log, D):
                 full_write_bytes=full, literal_8d_bytes=literal, shape=log[0][1])
 
 
-def probe_variant(stream, bs, num_nbrs, mode, device, first_timed, n_steps, pool, env=None):
+def probe_variant(stream, bs, num_nbrs, mode, device, first_timed, n_steps, pool, env=None, rank=0, world=1, batch_shard=False, barrier=False):
     """The dominant launch of the SAME timed batches under another configuration (full feature writes, an output pool of two, another
-    stream shape ...): a fresh pipeline replays the stream up to the timed region untimed, then `n_steps` steps, ~8 of them timed."""
+    stream shape, a rank's share of a multi-rank job ...): a fresh pipeline replays the stream up to the timed region untimed, then
+    `n_steps` steps, ~8 of them timed.  `bs` is the GLOBAL batch; with world > 1 this rank takes its slice of every batch, or
+    (batch_shard) every world-th batch of the schedule, and `barrier` brackets the timed region with the process group's barrier."""
     from tgm_amd._native import KernelTimer
 
     old = {k: os.environ.get(k) for k in (env or {})}
     os.environ.update(env or {})
     try:
-        dg, hm, hook, loader = build_pipeline(stream, 0, 1, bs, num_nbrs, mode, device, pool=pool, validate='deferred')
+        dg, hm, hook, loader = build_pipeline(stream, rank, world, bs, num_nbrs, mode, device, pool=pool, validate='deferred', batch_shard=batch_shard)
         starts = loader._starts
-        first_timed = min(first_timed, len(starts) - n_steps - 1)
+        first_timed = max(0, min(first_timed, len(starts) - n_steps - 1))
         with hm.activate('bench'):
             warm = min(20, first_timed)
             for i in range(first_timed - warm):
@@ -274,16 +278,23 @@ def probe_variant(stream, bs, num_nbrs, mode, device, first_timed, n_steps, pool
             hook.profile_every, hook.profile_log, hook._calls = every, [], 0
             hook.profile_pool = [KernelTimer() for _ in range(n_steps // every + 1)]
             torch.cuda.synchronize()
+            if barrier:
+                torch.distributed.barrier()
             t0 = time.perf_counter()
             for i in range(first_timed, first_timed + n_steps):
                 loader(starts[i])
             torch.cuda.synchronize()
+            wall_own = time.perf_counter() - t0
+            if barrier:
+                torch.distributed.barrier()
             wall = time.perf_counter() - t0
             hook.check()
             st = launch_stats(hook.profile_log, stream.edge_dim)
             hook.profile_hop = None
         st['us_per_step'] = 1e6 * wall / n_steps
+        st['us_per_step_own'] = 1e6 * wall_own / n_steps
         st['first_timed'] = first_timed
+        st['edges_timed'] = sum(min(bs, stream.num_edges - starts[i]) for i in range(first_timed, first_timed + n_steps))
         return st
     finally:
         for k, v in old.items():
@@ -291,6 +302,53 @@ def probe_variant(stream, bs, num_nbrs, mode, device, first_timed, n_steps, pool
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+def scale_comment_block(args, rank, world, device, n_steps=48):
+    """N > 1: north_star's scaling shape measured in the same job -- comment-shaped stream (N = 1 M, E = 44 M, D = 16; replicated in
+    every GPU's HBM), bs = 4096, k = [20, 20], static index (the multi-GPU mode: no per-batch state, no data-path collective).
+    'batch': the single-GPU schedule of 4096-edge batches dealt round-robin to the ranks (DGDataLoader(batch_shard=)) -- the sampled
+    neighbours are the single-GPU run's; 'weak': a global batch of N x 4096 edges, rank r seeding from its slice (EdgeShardHook).
+    Both: every rank runs `n_steps` steps between two barriers; aggregate = all ranks' sampled slots / the slowest rank's wall time."""
+    import torch.distributed as dist
+
+    from tgm_amd.synth import make_stream
+
+    t_c = time.perf_counter()
+    edges = int(os.environ.get('TGMX_SCALE_COMMENT_EDGES', 0)) or None  # tests shrink the stream; the bench does not
+    cs = make_stream('comment', seed=args.seed, device=device, num_edges=edges)
+    cbs, cnb = DEFAULTS['comment']
+    D = cs.edge_dim
+    out = {'workload': f'tgbl-comment-shaped synthetic stream: N={cs.num_nodes}, E={cs.num_edges}, D={D}; bs={cbs}, k={cnb}, static index '
+                       f'(mode=csr), pool of one, delta writes; {world} ranks, replicated stream, no data-path collective; {n_steps} timed steps per rank '
+                       'from the middle of the stream, barrier on both sides'}
+    for scaling in ('batch', 'weak'):
+        by_batch = scaling == 'batch'
+        gbs = cbs if by_batch else cbs * world
+        n_sched = (cs.num_edges + gbs - 1) // gbs
+        n_own = len(range(rank, n_sched, world)) if by_batch else n_sched
+        steps_r = min(n_steps, max(1, n_own // 2 - 2))  # the same on every rank (+-1 batch of n_own never reaches it at these sizes)
+        st = probe_variant(cs, gbs, cnb, 'csr', device, n_own // 2, steps_r, pool=1, rank=rank, world=world, batch_shard=by_batch, barrier=True)
+        # this rank's seed edges over its timed steps (full batches in the middle of the stream): whole batches, or its slice of each
+        own_edges = st['edges_timed'] if by_batch else steps_r * ((gbs * (rank + 1)) // world - (gbs * rank) // world)
+        mine = {'rank': rank, 'slots': slots_of_shape(own_edges, cnb),
+                'us_per_step_own': st['us_per_step_own'], 'wall_us_per_step': st['us_per_step'], 'steps': steps_r,
+                'hop1_kernel_ms': st['avg_ms'], 'hop1_algorithmic_bytes': st['algo_bytes'],
+                'hop1_hbm_frac': st['algo_bytes'] / (st['avg_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        ranks = [None] * world
+        dist.all_gather_object(ranks, mine)
+        wall_s = max(r['wall_us_per_step'] * r['steps'] for r in ranks) * 1e-6
+        out[scaling] = {
+            'global_batch': gbs, 'aggregate_sampled_edges_per_s': sum(r['slots'] for r in ranks) / wall_s,
+            'per_rank_sampled_edges_per_s': [r['slots'] / (r['us_per_step_own'] * r['steps'] * 1e-6) for r in ranks],
+            'per_rank_us_per_step': [r['us_per_step_own'] for r in ranks],
+            'per_rank_hop1_hbm_frac': [r['hop1_hbm_frac'] for r in ranks], 'per_rank_hop1_kernel_ms': [r['hop1_kernel_ms'] for r in ranks],
+            'kernel': 'lookup_tile_kernel (hop 1: %d seeds x k=%d per rank)' % (st['shape'][-1][0], st['shape'][-1][1]),
+        }
+    del cs
+    torch.cuda.empty_cache()
+    out['seconds_spent'] = time.perf_counter() - t_c
+    return out
 
 
 def tgat_gflop_folded(S0, num_nbrs, node_dim=1, edge_dim=172, time_dim=100, embed_dim=172, heads=2):
@@ -378,13 +436,34 @@ def aggregation_block(stream, bs, num_nbrs, device, n_batches, first):
     }
 
 
+def self_launch(n):
+    """`python bench.py --gpus N ...` started bare (no WORLD_SIZE in the environment): re-run this very command line as N ranks of ONE
+    node under torch.distributed.run (one process per GPU, RCCL; rendezvous on 127.0.0.1 at a free port), pass rank 0's JSON line through
+    and exit with the job's status.  Under the driver's own `python -m torch.distributed.run ... bench.py --gpus N` WORLD_SIZE is set
+    and this is never reached."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')  # the host driver only supports dmabuf IPC (RCCL across processes)
+    env.setdefault('OMP_NUM_THREADS', '8')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ and not args.emulate_world:
+        raise SystemExit(self_launch(args.gpus))
     from tgm_amd.dist import init_process_group
     from tgm_amd.synth import make_stream
 
     rank, world, local = init_process_group()
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)'
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     real_world = world
     if args.emulate_world:
         assert world == 1, '--emulate-world is a single-process modelling aid'
@@ -672,6 +751,12 @@ def main():
         guarded('aggregation', _aggregation)
     if rccl is not None:
         out['rccl'] = rccl
+    if real_world > 1 and args.scale_comment != 'off':
+        try:
+            out['scale_comment'] = scale_comment_block(args, rank, world, device)
+            out['scale_comment']['rccl_ranks_seen'] = rccl['ranks_seen']
+        except Exception as exc:  # noqa: BLE001 -- every rank takes the same path (the block's collectives are symmetric)
+            out['scale_comment'] = {'error': f'{type(exc).__name__}: {exc}'[:300]}
     out['valid_edges_per_s'] = out['value'] * out['roofline']['valid_slot_fraction']  # sampled slots that hold a neighbor (pads excluded)
     if default_elapsed is not None:
         out['default_path'] = {

@@ -363,3 +363,22 @@ def test_rings_under_a_process_group_warn_once_and_name_the_static_index(monkeyp
         hook._warn_rings_under_world()
         hook._warn_rings_under_world()
     assert len(w) == 1 and "mode='csr'" in str(w[0].message) and 'batch_shard' in str(w[0].message)
+
+
+def test_sampler_call_tag_survives_inference_tensors():
+    """``Tensor._version`` raises on inference tensors; a sampler call made under ``torch.inference_mode()`` must still publish (its tag
+    then matches nothing, i.e. the consumer takes the row-per-slot computation)."""
+    import torch
+
+    from tgm_amd.core.lazy import SampledHops, SamplerCallTag
+
+    with torch.inference_mode():
+        ids, times = [torch.zeros(4, 2, dtype=torch.int32)], [torch.zeros(4, 2, dtype=torch.int64)]
+        tag = SamplerCallTag(ids, times)
+        assert not tag.matches(ids, times)
+        assert SampledHops(ids, tag).copy().tag is tag
+    ids, times = [torch.zeros(4, 2, dtype=torch.int32)], [torch.zeros(4, 2, dtype=torch.int64)]
+    tag = SamplerCallTag(ids, times)
+    assert tag.matches(ids, times)
+    ids[0].add_(1)
+    assert not tag.matches(ids, times)

@@ -95,7 +95,18 @@ def test_two_rank_strong_scaling_concat_equals_single_rank(tmp_path, mode, pool)
 
 
 # ---- batch-level sharding (round 4): rank r takes batches r, r + world, ... of the SAME schedule -------------------------------------
-def _run_batches(rank, world, port, out, pool, epochs):
+def _tie_stream(num_edges=E, n=40, seed=5):
+    """Non-bipartite, few nodes, every timestamp shared by ~37 consecutive events: runs of equal time cross the bs = 200 boundaries and
+    most nodes appear in both roles inside a run -- the case in which the static index's order depends on where the batches start."""
+    g = torch.Generator().manual_seed(seed)
+    src = torch.randint(0, n, (num_edges,), generator=g, dtype=torch.int32)
+    dst = torch.randint(0, n, (num_edges,), generator=g, dtype=torch.int32)
+    ts = (torch.arange(num_edges, dtype=torch.int64) // 37) * 10
+    x = torch.randn(num_edges, D, generator=g)
+    return src, dst, ts, x, n
+
+
+def _run_batches(rank, world, port, out, pool, epochs, ties=False):
     import torch.distributed as dist
 
     from tgm_amd import DGData, DGDataLoader, DGraph
@@ -105,11 +116,15 @@ def _run_batches(rank, world, port, out, pool, epochs):
     if world > 1:
         os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
         dist.init_process_group('gloo', rank=rank, world_size=world)
-    st = make_stream('comment', seed=9, num_edges=E, edge_dim=D, n_src=300)
-    dg = DGraph(DGData.from_raw(st.ts, torch.stack([st.src, st.dst], 1), st.edge_x), device='cuda')
+    if ties:
+        src, dst, ts, x, num_nodes = _tie_stream()
+    else:
+        st = make_stream('comment', seed=9, num_edges=E, edge_dim=D, n_src=300)
+        src, dst, ts, x, num_nodes = st.src, st.dst, st.ts, st.edge_x, st.num_nodes
+    dg = DGraph(DGData.from_raw(ts, torch.stack([src, dst], 1), x), device='cuda')
     hm = HookManager(keys=['k'])
-    hm.register('k', RandomNegativeEdgeSamplerHook(0, st.num_nodes, seed=17))
-    hm.register('k', RecencyNeighborHook(st.num_nodes, KS, ['edge_src', 'edge_dst', 'neg'], ['edge_time', 'edge_time', 'neg_time'], mode='csr',
+    hm.register('k', RandomNegativeEdgeSamplerHook(0, num_nodes, seed=17))
+    hm.register('k', RecencyNeighborHook(num_nodes, KS, ['edge_src', 'edge_dst', 'neg'], ['edge_time', 'edge_time', 'neg_time'], mode='csr',
                                          batch_size=BS))  # fmt: skip
     loader = DGDataLoader(dg, batch_size=BS, hook_manager=hm, output_pool=pool, batch_shard=(rank, world) if world > 1 else None)
     got = []
@@ -123,6 +138,30 @@ def _run_batches(rank, world, port, out, pool, epochs):
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize('pool', [None, 0])
+def test_three_rank_batch_sharding_with_time_ties_across_batch_boundaries(tmp_path, pool):
+    """world = 3 on a tie-heavy non-bipartite stream: rank 2's first batch is batch 2, and an index whose leading batch merged batches
+    0 and 1 would order an equal-time (src role, dst role) pair that straddles the 200-edge boundary differently from the single-process
+    index (csr.hip clamps equal-time runs to a batch).  The index is built from the SCHEDULE's first edge on every rank."""
+    out = str(tmp_path / 'o')
+    _run_batches(0, 1, 0, out, pool, 1, True)
+    mp.spawn(_run_batches, args=(3, _free_port(), out, pool, 1, True), nprocs=3, join=True)
+    one = torch.load(f'{out}.b.{pool}.1.0')
+    three = [torch.load(f'{out}.b.{pool}.3.{r}') for r in range(3)]
+    nb = -(-E // BS)
+    assert len(one) == nb and sum(len(t) for t in three) == nb
+    n_valid = 0
+    for j, ref in enumerate(one):
+        got = three[j % 3][j // 3]
+        assert got['lo'] == ref['lo'] == j * BS
+        for h in range(len(KS)):
+            for name in ('seed_nids', 'nbr_nids', 'nbr_edge_time', 'nbr_edge_x'):
+                assert torch.equal(got[name][h], ref[name][h]), f'batch {j} (rank {j % 3}) hop {h} {name}'
+            n_valid += int((ref['nbr_nids'][h] >= 0).sum())
+    assert n_valid > 2000
 
 
 @pytest.mark.timeout(600)

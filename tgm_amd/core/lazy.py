@@ -32,12 +32,17 @@ class SamplerCallTag:
     def _of(nbr_nids, nbr_edge_time, nbr_edge_x=None) -> tuple:
         # edge features: the dense copies themselves, or (by id) the edge ids the rows are read through
         feats = () if nbr_edge_x is None else (nbr_edge_x.eids if hasattr(nbr_edge_x, 'eids') else tuple(nbr_edge_x))
-        return tuple((t.data_ptr(), t._version, t.shape[0]) for t in (*nbr_nids, *nbr_edge_time, *feats) if t is not None)
+        try:
+            return tuple((t.data_ptr(), t._version, t.shape[0]) for t in (*nbr_nids, *nbr_edge_time, *feats) if t is not None)
+        except RuntimeError:
+            # inference tensors keep no version counter ("Inference tensors do not track version counter"): an in-place change could
+            # not be seen, so such a call gets a stamp that matches nothing -- the row-per-slot computation, never the compact one
+            return (object(),)
 
     def matches(self, nbr_nids, nbr_edge_time, nbr_edge_x=None) -> bool:
         try:
             return self._of(nbr_nids, nbr_edge_time, nbr_edge_x) == self.stamp
-        except (AttributeError, IndexError, TypeError):
+        except (AttributeError, IndexError, TypeError, RuntimeError):
             return False
 
 

@@ -324,7 +324,9 @@ class RecencyNeighborHook(StatefulHook, SeedableHook):
         store = dg._storage
         if self._csr is None or self._csr_store is not store or self._csr.device != self._device:
             arr = store.on(self._device)
-            first = first_edge or 0
+            # the index merges everything before ``first`` into one leading batch (csr.hip): ``first`` must be the SCHEDULE's first
+            # edge -- the epoch anchor a batch-sharded loader hands over -- not the first batch this rank happens to take
+            first = self._epoch_lo if self._epoch_lo is not None else (first_edge or 0)
             self._csr_first = first
             self._csr_bounds = None if self._batch_starts is None else frozenset(int(b) for b in self._batch_starts)
             self._csr = build_csr(
