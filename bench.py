@@ -188,14 +188,34 @@ def committed_profile(key):
     return None, None
 
 
-def pmc_traffic(key):
+def kernel_src_sha():
+    """Identity of the sampler's kernel sources in THIS tree (there is no .git on the GPU box): a committed counter profile describes the
+    running kernels only if it was taken from the same sources (tools/gpu_profile_r5.sh records this value)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for name in ('recency.hip', 'pipeline.hip', 'common.h'):
+        with open(os.path.join(ROOT, 'tgm_amd', 'csrc', name), 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(key, note=None):
     """HBM-side bytes per TIMED launch of the dominant kernel from the committed PMC passes of this very command (rocprofv3 --pmc
-    FETCH_SIZE / WRITE_SIZE, separate runs, averaged over the timed launches only: tools/gpu_profile_r4.sh).  FETCH_SIZE is doubled:
-    the gfx950 correction of MI355X_MICROARCH.md for wide coalesced reads.  None when no profile of these arguments exists."""
+    FETCH_SIZE / WRITE_SIZE, separate runs, averaged over the timed launches only: tools/gpu_profile_r5.sh).  FETCH_SIZE is doubled:
+    the gfx950 correction of MI355X_MICROARCH.md for wide coalesced reads.  None when no profile of these arguments exists, or when
+    the newest one was taken from other kernel sources than this tree's (`note` then says which file was passed over and why)."""
     p, path = committed_profile(key)
     if p is None:
         return None
-    return {'bytes': 2 * 1024 * p['fetch_kb'] + 1024 * p['write_kb'], 'fetch_kb_x2': 2 * p['fetch_kb'], 'write_kb': p['write_kb'],
+    sha = kernel_src_sha()
+    if p.get('kernel_src_sha') != sha:
+        if note is not None:
+            note['traffic_omitted'] = (f'{os.path.relpath(path, ROOT)} was taken from kernel sources {p.get("kernel_src_sha") or "(unrecorded: a round-4 profile)"}, '
+                                       f'this tree is {sha}: its counters do not describe the launches timed here')
+        return None
+    return {'profile_file': os.path.relpath(path, ROOT), 'profile_kernel_src_sha': p.get('kernel_src_sha'), 'profile_taken': p.get('taken'),
+            'running_kernel_src_sha': sha,'bytes': 2 * 1024 * p['fetch_kb'] + 1024 * p['write_kb'], 'fetch_kb_x2': 2 * p['fetch_kb'], 'write_kb': p['write_kb'],
             'dispatches_counted': p.get('dispatches_counted'),
             'source': f'{os.path.relpath(path, ROOT)}: rocprofv3 --pmc in separate passes of `python bench.py {p.get("bench_args")}`, {p.get("which")} '
                       '(a separate run of the same command, not this process)'}
@@ -371,13 +391,25 @@ def tgat_gflop_folded(S0, num_nbrs, node_dim=1, edge_dim=172, time_dim=100, embe
 
 
 def committed_mfma():
-    """MFMA-busy fractions of the forward from the committed counter pass (profiles/r04_tgat_mfma_pmc.json: rocprofv3 --pmc
-    SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE over tools/bench_tgat.py, a separate run), or Nones."""
-    path = os.path.join(ROOT, 'profiles', 'r04_tgat_mfma_pmc.json')
+    """MFMA-busy fractions of the forward from the newest committed counter pass (profiles/r0N_tgat_mfma_pmc.json: rocprofv3 --pmc
+    SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE over tools/bench_tgat.py, a separate run), or Nones.  The file records the hash of
+    csrc/tgat.hip it was taken from; a pass over other sources is named as such in the source string."""
+    import glob
+    import hashlib
+
+    paths = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_tgat_mfma_pmc.json')), reverse=True)
+    if not paths:
+        return None, None, None
+    path = paths[0]
     try:
         with open(path) as f:
             p = json.load(f)
-        return p.get('mfma_busy_frac_forward'), p.get('mfma_busy_frac_tail_kernel'), os.path.relpath(path, ROOT)
+        with open(os.path.join(ROOT, 'tgm_amd', 'csrc', 'tgat.hip'), 'rb') as f:
+            sha = hashlib.sha256(f.read()).hexdigest()[:16]
+        rel = os.path.relpath(path, ROOT)
+        if p.get('tgat_src_sha') != sha:
+            rel += f' [taken from csrc/tgat.hip {p.get("tgat_src_sha") or "(unrecorded)"}; this tree is {sha}: an OLDER kernel]'
+        return p.get('mfma_busy_frac_forward'), p.get('mfma_busy_frac_tail_kernel'), rel
     except Exception:
         return None, None, None
 
@@ -672,7 +704,7 @@ def main():
             'peak': HBM_PEAK_GBS,
             'unit': 'GB/s',
             'frac': achieved / HBM_PEAK_GBS,
-            'traffic': pmc_traffic(pkey),
+            'traffic': None,
             'avg_kernel_ms': avg_ms,
             'rocprof_avg_kernel_us': rocprof_kernel_us(pkey) if world == 1 else None,
             'launches_timed': len(ker_ms),
@@ -688,6 +720,7 @@ def main():
     extras = args.extras == 'on' or (args.extras == 'auto' and real_world == 1 and not args.emulate_world and args.workload == 'wiki' and args.mode == 'ring'
                                      and args.pool == 1)
     rl = out['roofline']
+    rl['traffic'] = pmc_traffic(pkey, rl)
     rl['literal_8d_bytes'] = ls['literal_8d_bytes']
     rl['literal_8d_frac'] = ls['literal_8d_bytes'] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
     rl['literal_8d_note'] = ('SURVEY 8(d) read literally: (28 + 8D) B per output slot + 68 B per seed.  It charges every PAD slot a 16-byte record read, a '
@@ -741,7 +774,7 @@ def main():
                                                      'rings (mode=ring) and the static index (mode=csr); the narrow-row lookup of hop 1, same byte model as roofline',
                                          'bound': 'hbm', **{('static_index' if m == 'csr' else 'rings'): v for m, v in hb.items()},
                                          'seconds_spent': time.perf_counter() - t_c,
-                                         'traffic': 'profiles/r04_comment_{ring,csr}_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of `bench.py --workload comment`, separate runs)'}
+                                         'traffic': 'profiles/r0N_comment_{ring,csr}_pmc.json, newest round (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of `bench.py --workload comment`, separate runs)'}
 
         def _aggregation():
             out['aggregation'] = aggregation_block(stream, bs, num_nbrs, device, 100, first_timed)

@@ -143,3 +143,9 @@ def test_batch_shard_argument_checks():
         DGDataLoader(dg, batch_size=4, batch_unit='s', batch_shard=(0, 2))
     assert [int(b._edge_lo) for b in DGDataLoader(dg, batch_size=4, batch_shard=(1, 3))] == [4, 16]
     assert [int(b._edge_lo) for b in DGDataLoader(dg, batch_size=4, batch_shard=(0, 3), drop_last=True)] == [0, 12]
+    # 5 batches over 3 ranks: 2 / 2 / 1 without shard_even, 1 / 1 / 1 with it (every rank the same length: no collective is left waiting)
+    assert [len(DGDataLoader(dg, batch_size=4, batch_shard=(r, 3))) for r in range(3)] == [2, 2, 1]
+    even = [DGDataLoader(dg, batch_size=4, batch_shard=(r, 3), shard_even=True) for r in range(3)]
+    assert [len(ld) for ld in even] == [1, 1, 1]
+    assert [[int(b._edge_lo) for b in ld] for ld in even] == [[0], [4], [8]]
+    assert [len(DGDataLoader(dg, batch_size=4, batch_shard=(r, 5), shard_even=True)) for r in range(5)] == [1] * 5

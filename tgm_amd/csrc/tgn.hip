@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void tconv_attend_kernel(const TconvArgs a) {
   if (hi <= lo) return;  // no incoming edge: only the skip term
   const int HC = a.H * a.C;
   __shared__ int s_raw[kTconvSegLds], s_sorted[kTconvSegLds];  // (edge ids of one batch: far below 2^31)
-  const int64_t* __restrict__ ord = a.order + lo;  // position p of the segment reads ord[p - lo] / s_sorted[p - lo]
+  const int64_t* ord = a.order + lo;  // position p of the segment reads ord[p - lo] / s_sorted[p - lo] (no __restrict__: the hub path writes what it reads)
   bool in_lds = false;
   if (a.unsorted && hi - lo > 1) {
     const long long n = hi - lo;
@@ -276,16 +276,51 @@ __global__ __launch_bounds__(256) void tconv_attend_kernel(const TconvArgs a) {
       }
       __syncthreads();
       in_lds = true;
-    } else {  // a hub with more than kTconvSegLds incoming edges: the same ranking against global memory
-      for (long long p = threadIdx.x; p < n; p += blockDim.x) {
-        const long long id = a.order[lo + p];
-        long long rank = 0;
-        for (long long q = 0; q < n; ++q) rank += a.order[lo + q] < id;
-        a.order_big[lo + rank] = id;
+    } else {
+      // a hub with more than kTconvSegLds incoming edges: runs of kTconvSegLds ids ranked in LDS like above, then merged pairwise --
+      // an id's place in the merged run is its place in its own run + the number of smaller ids in the sibling run (binary search;
+      // ids are distinct) -- ping-pong between this target's slice of `order` (this workgroup's alone) and of order_big:
+      // O(n log n) instead of the O(n^2) ranking a 20 k-edge hub would spend hundreds of milliseconds in.
+      int64_t* src_buf = const_cast<int64_t*>(a.order) + lo;
+      int64_t* dst_buf = a.order_big + lo;
+      for (long long c0 = 0; c0 < n; c0 += kTconvSegLds) {
+        const int m = (int)((n - c0) < kTconvSegLds ? (n - c0) : kTconvSegLds);
+        for (int p = threadIdx.x; p < m; p += blockDim.x) s_raw[p] = (int)src_buf[c0 + p];
+        __syncthreads();
+        for (int p = threadIdx.x; p < m; p += blockDim.x) {
+          const int id = s_raw[p];
+          int rank = 0;
+          for (int q = 0; q < m; ++q) rank += s_raw[q] < id;
+          s_sorted[rank] = id;
+        }
+        __syncthreads();
+        for (int p = threadIdx.x; p < m; p += blockDim.x) dst_buf[c0 + p] = s_sorted[p];
+        __syncthreads();
+      }
+      int64_t* t = src_buf; src_buf = dst_buf; dst_buf = t;  // src_buf: sorted runs of kTconvSegLds
+      for (long long run = kTconvSegLds; run < n; run *= 2) {
+        __threadfence_block();
+        __syncthreads();
+        for (long long p = threadIdx.x; p < n; p += blockDim.x) {
+          const long long base = p / (2 * run) * (2 * run);
+          const bool right = p - base >= run;
+          const long long own_lo = right ? base + run : base;
+          long long sl = right ? base : base + run, sh = sl + run;
+          if (sl > n) sl = n;
+          if (sh > n) sh = n;
+          const int64_t id = src_buf[p];
+          long long b = sl, e = sh;  // first position of the sibling run whose id is not smaller
+          while (b < e) {
+            const long long mid = (b + e) >> 1;
+            if (src_buf[mid] < id) b = mid + 1; else e = mid;
+          }
+          dst_buf[base + (p - own_lo) + (b - sl)] = id;
+        }
+        t = src_buf; src_buf = dst_buf; dst_buf = t;
       }
       __threadfence_block();
       __syncthreads();
-      ord = a.order_big + lo;
+      ord = src_buf;
     }
   }
   for (int h = 0; h < a.H; ++h) {

@@ -39,6 +39,7 @@ class DGDataLoader(torch.utils.data.DataLoader):
         output_pool: Optional[int] = None,
         prefetch: int = 0,
         batch_shard: Optional[tuple] = None,
+        shard_even: bool = False,
         **kwargs: Any,
     ) -> None:
         if batch_size <= 0:
@@ -106,7 +107,14 @@ class DGDataLoader(torch.utils.data.DataLoader):
             if not 0 <= rank < world:
                 raise ValueError(f'batch_shard: rank {rank} outside [0, {world})')
             self._batch_shard = (rank, world)
-            self._starts = range(start + rank * batch_size, stop, batch_size * world)
+            # The schedule's batch count is rarely a multiple of ``world``: ranks then yield ceil or floor(total / world) batches and
+            # ``len(loader)`` differs per rank.  A loop with a per-step collective (DDP's gradient all-reduce, TGNMemory(shard_commits=True)'s
+            # all-gather) would hang at the end of the epoch: ``shard_even=True`` stops EVERY rank after floor(total / world) batches (the
+            # schedule's last total % world batches are dropped, like ``drop_last``); without it wrap the loop in
+            # ``torch.distributed.algorithms.Join`` or keep it collective-free.
+            total = len(range(start, stop, batch_size))
+            hi = start + (total // world) * world * batch_size if shard_even else stop
+            self._starts = range(start + rank * batch_size, min(stop, hi), batch_size * world)
         else:
             self._starts = range(start, stop, batch_size)
         # the reference's base-class call (loader.py:147-149): torch validates the keyword arguments; unknown ones raise TypeError

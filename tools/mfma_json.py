@@ -34,5 +34,9 @@ out['mfma_busy_frac_forward'] = busy_all / cyc_all if cyc_all else None
 out['mfma_busy_frac_tail_kernel'] = tail
 out['method'] = ('rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- python tools/bench_tgat.py 60 by_id (a counter-only pass); per kernel busy / (32 x cycles); '
                  'forward = launch-weighted over the TGAT forward kernels (the sampler kernels excluded)')
+import hashlib, os, time
+_root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out['tgat_src_sha'] = hashlib.sha256(open(os.path.join(_root, 'tgm_amd', 'csrc', 'tgat.hip'), 'rb').read()).hexdigest()[:16]  # bench.py labels an older pass as such
+out['taken'] = time.strftime('%Y-%m-%d %H:%M:%S UTC', time.gmtime())
 json.dump(out, open(sys.argv[2], 'w'), indent=1)
 print(json.dumps({k: out[k] for k in ('mfma_busy_frac_forward', 'mfma_busy_frac_tail_kernel')}))
