@@ -267,4 +267,20 @@ int tgmx_internal_edge_list(const int32_t* seed, const int32_t* nbr, const int64
                             int64_t S, int32_t k, int32_t D, const int32_t* uniq, int64_t U, const int64_t* uniq_count, int64_t cap, int64_t* row_off,
                             int64_t* edge_index, int64_t* edge_t, float* edge_x, int64_t* count, bool scan_done, tgmx_stream_t stream);
 namespace tgmx {
+// one C = act(A B^T + bias) problem of tgmx_sgemm_nt's argument list (tgmx_internal_sgemm_nt_pair, csrc/tgat.hip)
+struct GemmCall {
+  const float* A;
+  long long lda;
+  const float* B;
+  long long ldb;
+  float* C;
+  long long ldc, M;
+  int N, K;
+  const float* bias;
+  int relu, batch;
+  long long sA, sB, sC;
+};
 }  // namespace tgmx
+// two independent GEMMs as one launch (bit for bit what two tgmx_sgemm_nt calls give; falls back to them when either problem would not
+// take the K-split kernel on its own)
+int tgmx_internal_sgemm_nt_pair(const tgmx::GemmCall& c0, const tgmx::GemmCall& c1, tgmx_stream_t stream);

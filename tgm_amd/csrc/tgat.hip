@@ -64,15 +64,15 @@ __device__ __forceinline__ void load_kn(const float* __restrict__ row, int kb, i
 // SPLIT = true (few tiles): the 4 waves share ONE 32 x 64 tile, wave w takes k-steps w, w + 4, ... and the
 // partial tiles meet in LDS (fixed summation order: deterministic).
 template <bool AV, bool BV, bool SPLIT, int kGemmK>
-__global__ __launch_bounds__(256) void sgemm_nt_kernel(const GemmArgs g) {
+__device__ __forceinline__ void sgemm_nt_body(const GemmArgs& g, const unsigned bx, const unsigned by, const unsigned bz) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 31, half = lane >> 5;
-  const long long m0 = SPLIT ? (long long)blockIdx.x * 32 : (long long)blockIdx.x * 128 + wave * 32;
+  const long long m0 = SPLIT ? (long long)bx * 32 : (long long)bx * 128 + wave * 32;
   if (!SPLIT && m0 >= g.M) return;  // whole wave out of range (no block-level sync on this path)
-  const int n0 = blockIdx.y * 64;
-  const float* __restrict__ A = g.A + (long long)blockIdx.z * g.sA;
-  const float* __restrict__ B = g.B + (long long)blockIdx.z * g.sB;
-  float* __restrict__ C = g.C + (long long)blockIdx.z * g.sC;
+  const int n0 = by * 64;
+  const float* __restrict__ A = g.A + (long long)bz * g.sA;
+  const float* __restrict__ B = g.B + (long long)bz * g.sB;
+  float* __restrict__ C = g.C + (long long)bz * g.sC;
   // rows / columns past the edge are clamped for the loads; their results are never stored
   const long long ra = m0 + i < g.M ? m0 + i : g.M - 1;
   const int c0 = n0 + i < g.N ? n0 + i : g.N - 1;
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void sgemm_nt_kernel(const GemmArgs g) {
       const long long row = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
       const int col = n0 + t * 32 + i;
       if (row < g.M && col < g.N) {
-        if (g.bias) v += g.bias[(long long)blockIdx.z * g.N + col];  // batch b adds row b of a [batch, N] bias
+        if (g.bias) v += g.bias[(long long)bz * g.N + col];  // batch b adds row b of a [batch, N] bias
         if (g.relu) v = v > 0.f ? v : 0.f;
         C[row * g.ldc + col] = v;
       }
@@ -146,12 +146,33 @@ __global__ __launch_bounds__(256) void sgemm_nt_kernel(const GemmArgs g) {
       const int col = n0 + t * 32 + i;
       if (col < g.N) {
         float v = t ? acc1[r] : acc0[r];
-        if (g.bias) v += g.bias[(long long)blockIdx.z * g.N + col];  // batch b adds row b of a [batch, N] bias
+        if (g.bias) v += g.bias[(long long)bz * g.N + col];  // batch b adds row b of a [batch, N] bias
         if (g.relu) v = v > 0.f ? v : 0.f;
         C[row * g.ldc + col] = v;
       }
     }
   }
+}
+
+template <bool AV, bool BV, bool SPLIT, int kGemmK>
+__global__ __launch_bounds__(256) void sgemm_nt_kernel(const GemmArgs g) {
+  sgemm_nt_body<AV, BV, SPLIT, kGemmK>(g, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// TWO independent GEMMs in one launch (the K-split kernel's body, unchanged: each problem's result is bit for bit what its own launch gives).
+// Workgroups [0, tiles0) of the x dimension belong to problem 0, the rest to problem 1; the y / z extents are the larger of the two
+// problems' (a workgroup outside its problem's extent returns at once).  For pairs that do not depend on each other and are each too
+// small to fill the chip -- the GRU's gi / gh, TransformerConv's node projections / edge projection (cfg 3: four launches of ~14 us -> two).
+struct GemmPairArgs {
+  GemmArgs g[2];
+  unsigned tiles0, ny[2], nz[2];
+};
+
+__global__ __launch_bounds__(256) void sgemm_nt_pair_kernel(const GemmPairArgs p) {
+  const unsigned which = blockIdx.x >= p.tiles0;
+  if (blockIdx.y >= p.ny[which] || blockIdx.z >= p.nz[which]) return;
+  if (which) sgemm_nt_body<true, true, true, 8>(p.g[1], blockIdx.x - p.tiles0, blockIdx.y, blockIdx.z);
+  else sgemm_nt_body<true, true, true, 8>(p.g[0], blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // The FEW-ROW variant (M <= 2048: the 600-row layer of the headline forward, whose five GEMMs were 41 us of a 185 us forward at ~8 us
@@ -2267,6 +2288,39 @@ extern "C" int tgmx_sgemm_nt(const float* A, int64_t lda, const float* B, int64_
   else TGMX_GEMM(false, false);
 #undef TGMX_GEMM
   TGMX_CHECK_LAUNCH("sgemm_nt");
+  return TGMX_OK;
+}
+
+// internal (csrc/tgn.hip): two independent C = A B^T (+ bias) problems as ONE launch of the K-split kernel; falls back to two launches
+// when a problem takes another kernel on its own (few rows, K <= 16, unaligned operands) so that results never depend on the pairing.
+int tgmx_internal_sgemm_nt_pair(const GemmCall& c0, const GemmCall& c1, tgmx_stream_t stream) {
+  auto solo = [&](const GemmCall& c) {
+    return tgmx_sgemm_nt(c.A, c.lda, c.B, c.ldb, c.C, c.ldc, c.M, c.N, c.K, c.bias, c.relu, c.batch, c.sA, c.sB, c.sC, stream);
+  };
+  auto vec_ok = [](const float* p, long long ld, long long stride) { return ((uintptr_t)p & 15) == 0 && ld % 4 == 0 && stride % 4 == 0; };
+  static const bool small_knob = [] { const char* e = getenv("TGMX_GEMM_SMALL"); return !(e && e[0] == '0'); }();
+  static const bool pair_knob = [] { const char* e = getenv("TGMX_GEMM_PAIR"); return !(e && e[0] == '0'); }();  // A/B knob
+  auto pairable = [&](const GemmCall& c) {
+    return c.M > 0 && c.K > 16 && !(small_knob && c.M <= 2048 && c.K <= 512) && vec_ok(c.A, c.lda, c.sA) && vec_ok(c.B, c.ldb, c.sB) && c.batch > 0;
+  };
+  if (!pair_knob || !pairable(c0) || !pairable(c1)) {
+    if (int rc = solo(c0)) return rc;
+    return solo(c1);
+  }
+  GemmPairArgs p;
+  const GemmCall* cs[2] = {&c0, &c1};
+  for (int q = 0; q < 2; ++q) {
+    const GemmCall& c = *cs[q];
+    TGMX_REQUIRE(c.A && c.B && c.C && c.N > 0 && c.lda >= c.K && c.ldb >= c.K && c.ldc >= c.N, "sgemm_nt_pair: bad problem %d", q);
+    p.g[q] = GemmArgs{c.A, c.B, c.C, c.bias, c.lda, c.ldb, c.ldc, c.sA, c.sB, c.sC, c.M, c.N, c.K, c.relu};
+    p.ny[q] = (unsigned)((c.N + 63) / 64);
+    p.nz[q] = (unsigned)c.batch;
+  }
+  p.tiles0 = (unsigned)((c0.M + 31) / 32);
+  const unsigned tiles1 = (unsigned)((c1.M + 31) / 32);
+  const dim3 grid(p.tiles0 + tiles1, p.ny[0] > p.ny[1] ? p.ny[0] : p.ny[1], p.nz[0] > p.nz[1] ? p.nz[0] : p.nz[1]);
+  hipLaunchKernelGGL(sgemm_nt_pair_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+  TGMX_CHECK_LAUNCH("sgemm_nt_pair");
   return TGMX_OK;
 }
 

@@ -1006,8 +1006,10 @@ extern "C" int tgmx_tgn_memory_forward(const tgmx_tgn_memory_fwd_t* a, tgmx_stre
                               a->ws_h, stream);
   if (rc) return rc;
   // GRUCell: gi = aggr W_ih^T + b_ih, gh = h W_hh^T + b_hh, gates
-  if ((rc = tgmx_sgemm_nt(a->ws_aggr, W, a->W_ih, W, a->ws_gi, 3 * M, R, 3 * M, W, a->b_ih, 0, 1, 0, 0, 0, stream))) return rc;
-  if ((rc = tgmx_sgemm_nt(a->ws_h, M, a->W_hh, M, a->ws_gh, 3 * M, R, 3 * M, M, a->b_hh, 0, 1, 0, 0, 0, stream))) return rc;
+  // (one launch for the two: they share nothing but the stream, and neither fills the chip)
+  const GemmCall gi{a->ws_aggr, W, a->W_ih, W, a->ws_gi, 3 * M, R, 3 * M, W, a->b_ih, 0, 1, 0, 0, 0};
+  const GemmCall gh{a->ws_h, M, a->W_hh, M, a->ws_gh, 3 * M, R, 3 * M, M, a->b_hh, 0, 1, 0, 0, 0};
+  if ((rc = tgmx_internal_sgemm_nt_pair(gi, gh, stream))) return rc;
   return tgmx_tgn_gru_gate(a->ws_gi, a->ws_gh, a->ws_h, M, R, a->out_mem, stream);
 }
 
@@ -1017,9 +1019,13 @@ extern "C" int tgmx_tconv_forward(const tgmx_tconv_fwd_t* a, tgmx_stream_t strea
   if (U == 0) return TGMX_OK;
   const int HC = a->H * a->C, Wd = a->T + a->D;
   TGMX_REQUIRE(a->x && a->W4 && a->b4 && a->qkvs, "tconv_forward: null pointer");
-  // query / key / value / skip projections of the same x: ONE batched launch over the stacked weights
-  int rc = tgmx_sgemm_nt(a->x, a->in_ch, a->W4, a->in_ch, a->qkvs, HC, U, HC, a->in_ch, a->b4, 0, 4, 0, (int64_t)HC * a->in_ch, U * HC, stream);
-  if (rc || E == 0) return rc;
+  // query / key / value / skip projections of the same x: ONE batched problem over the stacked weights
+  const GemmCall proj{a->x, a->in_ch, a->W4, a->in_ch, a->qkvs, HC, U, HC, a->in_ch, a->b4, 0, 4, 0, (long long)HC * a->in_ch, U * HC};
+  auto run = [&](const GemmCall& c) {
+    return tgmx_sgemm_nt(c.A, c.lda, c.B, c.ldb, c.C, c.ldc, c.M, c.N, c.K, c.bias, c.relu, c.batch, c.sA, c.sB, c.sC, stream);
+  };
+  int rc = 0;
+  if (E == 0) return run(proj);
   TGMX_REQUIRE(a->src && a->tgt && a->t && a->edge_attr && a->eproj && a->order && a->seg_lo && a->seg_hi && a->status, "tconv_forward: null pointer");
   float* out = a->qkvs + 3 * U * HC;  // the skip projection; the attention output is added to it
   const char* knob = getenv("TGMX_TCONV_COUNTING");  // A/B knob, read per call (the tests switch it)
@@ -1038,7 +1044,9 @@ extern "C" int tgmx_tconv_forward(const tgmx_tconv_fwd_t* a, tgmx_stream_t strea
     hipLaunchKernelGGL(tconv_group_place_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, a->tgt, (long long)E, (long long)U, a->cursor,
                        a->order);
     TGMX_CHECK_LAUNCH("tconv_forward(grouping)");
-    if ((rc = tgmx_sgemm_nt(a->edge_attr, Wd, a->W_edge, Wd, a->eproj, HC, E, HC, Wd, nullptr, 0, 1, 0, 0, 0, stream))) return rc;
+    // the node projections (x -> q, k, v, skip) and the edge projection (edge_attr -> eproj) do not depend on each other: one launch
+    const GemmCall eproj{a->edge_attr, Wd, a->W_edge, Wd, a->eproj, HC, E, HC, Wd, nullptr, 0, 1, 0, 0, 0};
+    if ((rc = tgmx_internal_sgemm_nt_pair(proj, eproj, stream))) return rc;
     TconvArgs t{a->qkvs, a->qkvs + U * HC, a->qkvs + 2 * U * HC, a->eproj, a->order, a->src, a->seg_lo, a->seg_hi, out, U, a->H, a->C,
                 1.0f / sqrtf((float)a->C)};
     t.drop = make_dropout(nullptr);
@@ -1049,6 +1057,7 @@ extern "C" int tgmx_tconv_forward(const tgmx_tconv_fwd_t* a, tgmx_stream_t strea
     return TGMX_OK;
   }
   TGMX_REQUIRE(a->sort_ws, "tconv_forward: null pointer");
+  if ((rc = run(proj))) return rc;
   if ((rc = tgmx_tconv_edge_attr(a->last_update_local, a->src, a->t, a->msg, a->tw, a->tb, a->T, a->D, E, a->edge_attr, stream))) return rc;
   if ((rc = tgmx_sgemm_nt(a->edge_attr, Wd, a->W_edge, Wd, a->eproj, HC, E, HC, Wd, nullptr, 0, 1, 0, 0, 0, stream))) return rc;
   if ((rc = tgmx_segment_sort(a->tgt, E, (int32_t)U, a->order, a->seg_lo, a->seg_hi, a->sort_ws, a->sort_ws_bytes, a->status, stream))) return rc;

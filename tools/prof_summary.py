@@ -102,6 +102,20 @@ def pmc(db, kernel):
         print(f'| `{short(name, 60)}` | {cn} | {grid} | {n} | {avg:.1f} | {mn:.1f} | {mx:.1f} |')
 
 
+def pmcsum(db, kernel):
+    """per kernel NAME and counter: the per-dispatch SUM over the counter's instances (XCDs / shader engines), averaged over the dispatches; JSON lines"""
+    rows = db.execute('select k.name, k.dispatch_id, p.counter_name, sum(p.counter_value), count(*) from pmc_events p join kernels k on k.dispatch_id = p.dispatch_id '
+                      'group by k.name, k.dispatch_id, p.counter_name').fetchall()
+    acc = {}
+    for name, _, c, v, n in rows:
+        if kernel and kernel not in name:
+            continue
+        acc.setdefault((name, c), []).append((v, n))
+    for (name, c), vs in sorted(acc.items()):
+        print(json.dumps({'kernel': short(name, 80), 'counter': c, 'dispatches': len(vs), 'avg_sum_per_dispatch': sum(v for v, _ in vs) / len(vs),
+                          'instances_per_dispatch': vs[0][1]}))
+
+
 def pmctail(db, kernel, last):
     """per-counter average over the LAST `last` dispatches of one kernel (bench.py's timed steps are the end of the run: the
     whole-run average also covers the untimed ring fill, whose launches move far fewer bytes); one JSON object"""
@@ -125,7 +139,7 @@ def pmctail(db, kernel, last):
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
-    ap.add_argument('what', choices=['trace', 'byname', 'gaps', 'pmc', 'tail', 'pmctail'])
+    ap.add_argument('what', choices=['trace', 'byname', 'gaps', 'pmc', 'pmcsum', 'tail', 'pmctail'])
     ap.add_argument('--last', type=int, default=393)
     ap.add_argument('path')
     ap.add_argument('--title', default='rocprofv3 --kernel-trace --stats')
@@ -133,5 +147,5 @@ if __name__ == '__main__':
     ap.add_argument('--steps', type=int, default=0)
     a = ap.parse_args()
     db = open_db(a.path)
-    {'trace': lambda: trace(db, a.title), 'byname': lambda: byname(db, a.title, a.steps), 'gaps': lambda: gaps(db, a.kernel), 'pmc': lambda: pmc(db, a.kernel), 'tail': lambda: tail(db, a.kernel, a.last),
+    {'trace': lambda: trace(db, a.title), 'byname': lambda: byname(db, a.title, a.steps), 'gaps': lambda: gaps(db, a.kernel), 'pmc': lambda: pmc(db, a.kernel), 'pmcsum': lambda: pmcsum(db, a.kernel), 'tail': lambda: tail(db, a.kernel, a.last),
      'pmctail': lambda: pmctail(db, a.kernel, a.last)}[a.what]()
