@@ -811,6 +811,13 @@ def main():
         guarded('aggregation', _aggregation)
     if rccl is not None:
         out['rccl'] = rccl
+    if real_world > 1:
+        out['multi_gpu_note'] = (
+            "the headline fields of this line are the wiki-shaped stream with STREAMING RINGS (the single-GPU default, so that the 1 -> N curve starts "
+            "at BENCH's N = 1 figure): under N > 1 rings are REPLICAS -- every rank replays the whole global batch's ring update (N x bs edges; a chain "
+            "that does not shrink with N), only the lookups are sharded.  The multi-GPU mode of this library is the static index "
+            "(RecencyNeighborHook(mode='csr'): no per-batch state, no replicated update, no data-path collective): scale_comment below measures it on "
+            "north_star's scaling shape in this same job, batch-sharded (DGDataLoader(batch_shard=)) and weak (EdgeShardHook).")
     if real_world > 1 and args.scale_comment != 'off':
         try:
             out['scale_comment'] = scale_comment_block(args, rank, world, device)

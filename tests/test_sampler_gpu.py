@@ -565,7 +565,7 @@ def test_csr_mode_fuzz(seed):
 
 
 # ---- the BASELINE.json configurations at their own shapes (close the gaps) -----------------------------------
-def _pooled_pipeline(st, bs, ks, mode='ring', pool=3, key_arith='int32', neg_seed=3, dg=None):
+def _pooled_pipeline(st, bs, ks, mode='ring', pool=3, key_arith='int32', neg_seed=3, dg=None, edge_features='dense'):
     """negatives -> recency sampler through DGDataLoader(output_pool=): the path bench.py times."""
     from tgm_amd import DGData, DGDataLoader, DGraph
     from tgm_amd.hooks import HookManager, RandomNegativeEdgeSamplerHook, RecencyNeighborHook
@@ -575,7 +575,7 @@ def _pooled_pipeline(st, bs, ks, mode='ring', pool=3, key_arith='int32', neg_see
     hm = HookManager(keys=['k'])
     hm.register('k', RandomNegativeEdgeSamplerHook(int(st.dst.min()), st.num_nodes, seed=neg_seed))
     hook = RecencyNeighborHook(st.num_nodes, ks, ['edge_src', 'edge_dst', 'neg'], ['edge_time', 'edge_time', 'neg_time'], mode=mode,
-                               key_arith=key_arith, validate='deferred', batch_size=bs if mode == 'csr' else None)  # fmt: skip
+                               key_arith=key_arith, validate='deferred', batch_size=bs if mode == 'csr' else None, edge_features=edge_features)  # fmt: skip
     hm.register('k', hook)
     return dg, hm, hook, DGDataLoader(dg, batch_size=bs, hook_manager=hm, output_pool=pool)
 
@@ -618,6 +618,51 @@ def test_cfg3_review_shape_two_hops_vs_oracle():
     from tgm_amd.synth import make_stream
 
     _against_oracle(make_stream('review', seed=21, num_edges=30_000, n_src=30_000, n_dst=5_000), 512, [10, 10], 1000)
+
+
+def test_cfg3_review_full_size_midstream_properties():
+    """BASELINE cfg 3's sampler at FULL size (N = 350 k, E = 4.8 M, D = 16, bs = 512, k = [10, 10]): an epoch opened mid-stream at
+    edge 2.4 M and followed for 300 batches -- the streaming rings (hop 1 through the packed 16-lane-group kernel with the update's
+    m = 1024 placement riding, dense copies AND edge ids) and the static index over the whole 4.8 M-edge store agree bit for bit on
+    every batch, the published edge ids address exactly the copied feature rows, and every row satisfies the sampler's invariants
+    (strictly earlier than the seed, right-aligned, oldest -> newest, pads zero)."""
+    from tgm_amd import DGData, DGraph
+    from tgm_amd.synth import make_stream
+
+    st = make_stream('review', seed=1337, device=DEV)
+    assert st.num_nodes > 300_000 and st.num_edges > 4_000_000
+    bs, ks, first, nb = 512, [10, 10], 2_400_000 // 512 * 512, 300
+    dg = DGraph(DGData.from_raw(st.ts, torch.stack([st.src, st.dst], 1), st.edge_x), device=DEV)
+    view = dg.slice_events(first, first + nb * bs)
+    _, hm_r, hook_r, ld_r = _pooled_pipeline(st, bs, ks, mode='ring', key_arith='int64', dg=view)
+    _, hm_c, hook_c, ld_c = _pooled_pipeline(st, bs, ks, mode='csr', dg=view)
+    _, hm_i, hook_i, ld_i = _pooled_pipeline(st, bs, ks, mode='ring', key_arith='int64', dg=view, edge_features='by_id')
+    table = dg._storage.on(torch.device(DEV)).edge_x
+    n_seen, n_valid = 0, 0
+    with hm_r.activate('k'), hm_c.activate('k'), hm_i.activate('k'):
+        for br, bc, bi in zip(ld_r, ld_c, ld_i):
+            assert br._edge_lo == bc._edge_lo == bi._edge_lo == first + n_seen * bs
+            assert torch.equal(br.neg, bc.neg) and torch.equal(br.neg, bi.neg)
+            for h in range(2):
+                n, t, x = br.nbr_nids[h], br.nbr_edge_time[h], br.nbr_edge_x[h]
+                assert torch.equal(n, bc.nbr_nids[h]) and torch.equal(t, bc.nbr_edge_time[h]) and torch.equal(x, bc.nbr_edge_x[h]), (n_seen, h)
+                assert torch.equal(n, bi.nbr_nids[h]) and torch.equal(t, bi.nbr_edge_time[h]), (n_seen, h, 'by id')
+                valid = n >= 0
+                eid = bi.nbr_edge_x.eids[h]
+                assert bool((eid[~valid] == -1).all()) and bool((eid[valid] >= 0).all())
+                assert torch.equal(table[eid[valid].long()], x[valid]), (n_seen, h, 'edge ids address the copied rows')
+                q = br.seed_times[h][:, None]
+                assert bool(((t < q) | ~valid).all()) and bool((valid[:, 1:] | ~valid[:, :-1]).all())
+                assert bool(((t[:, 1:] >= t[:, :-1]) | ~valid[:, :-1]).all())
+                assert bool((t[~valid] == 0).all()) and bool((x[~valid] == 0).all())
+                if h == 1:
+                    n_valid += int(valid.sum())
+            assert torch.equal(br.seed_nids[1], br.nbr_nids[0].reshape(-1))
+            n_seen += 1
+    hook_r.check()
+    hook_c.check()
+    hook_i.check()
+    assert n_seen == nb and n_valid > 100_000
 
 
 def test_cfg4_comment_shape_reduced_vs_oracle():
