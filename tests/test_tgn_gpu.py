@@ -122,13 +122,15 @@ def test_graph_attention_embedding_matches_restatement(inference):
     close(out.cpu(), ref, 'graph attention embedding')
 
 
-@pytest.mark.parametrize('U,E,hubs', [(300, 4000, 40), (7000, 15000, 0), (50, 6000, 2), (1, 7, 0), (9000, 3, 0), (40, 23000, 1)])
+@pytest.mark.parametrize('U,E,hubs', [(300, 4000, 40), (7000, 15000, 0), (50, 6000, 2), (1, 7, 0), (9000, 3, 0), (40, 23000, 1), (5000, 30000, 3), (2049, 70000, 0)])
 def test_counting_grouping_equals_the_segment_sort_path(U, E, hubs, monkeypatch):
     """tgmx_tconv_forward groups a batch's edges by target with counts + an atomic cursor and lets the attention sort every segment
     by edge id (ascending edge id = the stable order of a sort by target): the embedding must equal the segment-sort path's BIT FOR
     BIT, also for hubs with more incoming edges than the attention's LDS buffer holds (> 1024: runs ranked in LDS, then merged pairwise --
     3 000 edges = 2 passes, 22 500 = 5 passes over a ragged last run),
-    repeatedly (the count buffer is left zero), and after the batch shape changed."""
+    repeatedly (the count buffer is left zero), and after the batch shape changed.  U > 2048 takes the round-5 arrangement -- the edge
+    encoding + ranks ride the node-projection GEMM, scan + placement ride the edge-projection GEMM -- smaller U the three small launches;
+    (5000, 30000, 3): 10 000-edge hubs through the riding path."""
     from tgm_amd.nn import GraphAttentionEmbedding, Time2Vec
 
     torch.manual_seed(U + E)
