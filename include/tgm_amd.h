@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TGMX_ABI_VERSION 6
+#define TGMX_ABI_VERSION 7
 
 #define TGMX_OK 0
 #define TGMX_E_INVALID (-1)  /* bad argument (null pointer, size, alignment) */
@@ -67,6 +67,15 @@ int tgmx_event_create(tgmx_event_t* ev);
 int tgmx_event_destroy(tgmx_event_t ev);
 int tgmx_event_elapsed_ms(tgmx_event_t start, tgmx_event_t stop, float* ms);
 int tgmx_event_synchronize(tgmx_event_t ev); /* host wait until the work recorded before `ev` is done */
+/* ABI v7 -- ORDERING between two streams of one process (the loader's chain on a side stream beside the model's chain: DESIGN.md 3.3c,
+ * DGDataLoader(side_stream=True)).  The reference has no counterpart: tgm/data/loader.py:158-170 runs hooks and model on one stream.
+ * tgmx_event_create_sync: an event without timing (cheaper to record).  tgmx_event_record: everything enqueued on `stream` so far.
+ * tgmx_stream_wait_event: work enqueued on `stream` from now on starts after the recorded work (no host wait).
+ * tgmx_stream_handoff = record(ev, from) + wait(to, ev) in one call. */
+int tgmx_event_create_sync(tgmx_event_t* ev);
+int tgmx_event_record(tgmx_event_t ev, tgmx_stream_t stream);
+int tgmx_stream_wait_event(tgmx_stream_t stream, tgmx_event_t ev);
+int tgmx_stream_handoff(tgmx_stream_t from, tgmx_stream_t to, tgmx_event_t ev);
 
 /* ------------------------------------------------------------------------
  * k-most-recent neighbor lookup over a static per-node index (CSR).
@@ -326,6 +335,16 @@ typedef struct tgmx_pipeline_post {
   tgmx_event_t sizes_ready;
 } tgmx_pipeline_post_t;
 
+/* ABI v7 -- a LAUNCH WORKER: one host thread of the library that issues tgmx_pipeline_step for the caller, in submission order, on the
+ * stream the caller names (the loader's side stream), bracketed by `wait_ev` (NULL or: the stream first waits for it) and `record_ev`
+ * (NULL or: recorded behind the step's last launch).  The argument blocks are COPIED at submission.  tgmx_worker_wait blocks until
+ * the job with that ticket has been issued (not until the device has run it) and returns ITS status (tgmx_last_error of the calling
+ * thread then holds its text).  A host-side convenience with no counterpart in the reference (its loader runs in the caller's
+ * thread, tgm/data/loader.py:158-170): DGDataLoader(side_stream=True) uses it so that the consumer's thread does not pay for the
+ * producer's launches.  The worker issues on the device that was current when it was created. */
+typedef void* tgmx_worker_t;
+int tgmx_worker_create(tgmx_worker_t* w);
+int tgmx_worker_destroy(tgmx_worker_t w); /* finishes the pending jobs, joins the thread */
 /* Byte accounting of one lookup launch (bench / profiling), as TGMX_ACCOUNTING_PARTIALS partial triples that the caller adds
  * up whenever it likes (one launch, nothing to zero): column 0 = non-pad slots of ids[0 .. slots), column 1 = sum over rows of
  * max(span_prev, span_cur) (slots whose feature row was rewritten), column 2 = sum of span_cur.  counts: device,
@@ -333,6 +352,10 @@ typedef struct tgmx_pipeline_post {
 #define TGMX_ACCOUNTING_PARTIALS 1024
 int tgmx_lookup_accounting(const int32_t* ids, int64_t slots, const int32_t* span_prev, const int32_t* span_cur, int64_t rows,
                            int64_t* counts, tgmx_stream_t stream);
+int tgmx_worker_pipeline_step(tgmx_worker_t w, const tgmx_pipeline_t* pipe, int64_t edge_lo, int64_t n_edges, uint64_t neg_call,
+                              const tgmx_pipeline_out_t* out, const tgmx_pipeline_post_t* post /* NULL: none */, tgmx_stream_t stream,
+                              tgmx_event_t wait_ev, tgmx_event_t record_ev, uint64_t* ticket);
+int tgmx_worker_wait(tgmx_worker_t w, uint64_t ticket);
 int tgmx_pipeline_step(const tgmx_pipeline_t* pipe, int64_t edge_lo, int64_t n_edges, uint64_t neg_call,
                        const tgmx_pipeline_out_t* out, const tgmx_pipeline_post_t* post /* NULL: none */, tgmx_stream_t stream);
 

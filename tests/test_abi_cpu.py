@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f'{name} declared in tgm_amd.h but not exported by libtgm_amd.so'
     # and the ctypes signature table covers the same set
     assert sorted(_native.SIGNATURES) == declared_symbols()
-    assert _native.load().tgmx_version() == 6
+    assert _native.load().tgmx_version() == 7
 
 
 def test_no_cpu_fallback():

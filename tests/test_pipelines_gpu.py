@@ -85,6 +85,74 @@ def test_cfg3_tgn_pipeline():
     close(mem.memory.cpu(), ref_mem.memory, 'final memory')
 
 
+@pytest.mark.parametrize('features', ['by_id', 'dense'])
+def test_side_stream_loader_gives_the_single_stream_results(features):
+    """DGDataLoader(side_stream=True): the hooks' chain of batch i + 1 runs on the loader's own stream beside the model's chain of
+    batch i, ordered by events only.  Every batch attribute and every model output must equal the single-stream pass's bit for bit
+    (TGN loop: sampler -> dedup -> edge list -> memory -> embedding -> update_state, two passes over the stream with a reset between),
+    including what a racy ordering would break: the sampler's rings, the recycled output sets (pool of two), the final memory."""
+    from tgm_amd import DGData, DGDataLoader, DGraph
+    from tgm_amd.hooks import DeduplicationHook, HookManager, RandomNegativeEdgeSamplerHook, RecencyNeighborHook, SampledEdgeListHook
+    from tgm_amd.nn import GraphAttentionEmbedding, IdentityMessage, LastAggregator, TGNMemory
+    from tgm_amd.synth import make_stream
+
+    st = make_stream('review', seed=8, num_edges=20 * 512 + 77, n_src=3000, n_dst=400)
+    N, D, M, T_, bs = st.num_nodes, 16, 100, 100, 512
+
+    def run(side):
+        dg = DGraph(DGData.from_raw(st.ts, torch.stack([st.src, st.dst], 1), st.edge_x), device=DEV)
+        hm = HookManager(keys=['k'])
+        hm.register('k', RandomNegativeEdgeSamplerHook(3000, N, seed=4))
+        hook = RecencyNeighborHook(N, [10, 10], ['edge_src', 'edge_dst', 'neg'], ['edge_time', 'edge_time', 'neg_time'], validate='deferred',
+                                   edge_features=features)
+        hm.register('k', hook)
+        hm.register('k', DeduplicationHook(seed_nodes_keys=['neg', 'nbr_nids']))
+        hm.register('k', SampledEdgeListHook(hop=0))
+        torch.manual_seed(0)
+        mem = TGNMemory(N, D, M, T_, IdentityMessage(D, M, T_), LastAggregator()).to(DEV).train()
+        mem.reuse_forward = True
+        enc = GraphAttentionEmbedding(M, 100, D, mem.time_enc).to(DEV).eval()
+        out = []
+        with hm.activate('k'), torch.no_grad():
+            for ep in range(2):
+                hm.reset_state()
+                for batch in DGDataLoader(dg, batch_size=bs, hook_manager=hm, output_pool=2, prefetch=1, side_stream=side):
+                    z, lu = mem(batch.unique_nids)
+                    z2 = enc(z, lu, batch.sampled_edge_index, batch.sampled_edge_time, batch.sampled_edge_x)
+                    mem.update_state(batch.edge_src, batch.edge_dst, batch.edge_time, batch.edge_x)
+                    out.append([t.clone() for t in (batch.neg, batch.unique_nids, batch.nbr_nids[0], batch.nbr_nids[1], batch.nbr_edge_time[1],
+                                                    batch.sampled_edge_index, batch.sampled_edge_time, batch.sampled_edge_x, z, lu, z2)])
+            hook.check()
+            mem.check()
+        torch.cuda.synchronize()
+        return out, mem.memory.clone(), mem.last_update.clone()
+
+    one, mem1, lu1 = run(False)
+    two, mem2, lu2 = run(True)
+    assert len(one) == len(two) == 2 * 21
+    for b, (x, y) in enumerate(zip(one, two)):
+        for i, (u, v) in enumerate(zip(x, y)):
+            assert torch.equal(u, v), f'batch {b} item {i}'
+    assert torch.equal(mem1, mem2) and torch.equal(lu1, lu2)
+
+
+def test_side_stream_argument_checks():
+    from tgm_amd import DGData, DGDataLoader, DGraph
+
+    ts = torch.arange(40)
+    dg = DGraph(DGData.from_raw(ts, torch.randint(0, 5, (40, 2), dtype=torch.int32)), device=DEV)
+    with pytest.raises(ValueError, match='side_stream'):
+        DGDataLoader(dg, batch_size=4, side_stream=True)
+    with pytest.raises(ValueError, match='output_pool'):
+        DGDataLoader(dg, batch_size=4, side_stream=True, prefetch=1, output_pool=1)
+    with pytest.raises(ValueError, match='side_stream'):
+        DGDataLoader(dg, batch_size=4, side_stream=True, prefetch=1)  # fresh-tensor sets (output_pool=None) are not a recycled pool
+    assert len(list(DGDataLoader(dg, batch_size=4, side_stream=True, prefetch=1, output_pool=2))) == 10  # no hooks: batches are views
+    it = iter(DGDataLoader(dg, batch_size=4, side_stream=True, prefetch=1, output_pool=2))  # a consumer that stops early
+    next(it), next(it)
+    it.close()
+
+
 def test_cfg5_snapshots_tgcn():
     """tgbn-trade-like: seconds -> discretize to years -> one snapshot per batch -> TGCN with carried state."""
     from oracle.tgcn_ref import tgcn_cell_ref

@@ -265,6 +265,15 @@ SIGNATURES['tgmx_recency_step'] = (c_int32, [ctypes.POINTER(RecencyStep), _P])
 SIGNATURES['tgmx_recency_step_plan'] = (c_int32, [ctypes.POINTER(RecencyStep)])
 SIGNATURES['tgmx_pipeline_step'] = (c_int32, [ctypes.POINTER(Pipeline), c_int64, c_int64, ctypes.c_uint64, ctypes.POINTER(PipelineOut), ctypes.POINTER(PipelinePost), _P])
 SIGNATURES['tgmx_event_synchronize'] = (c_int32, [_P])
+SIGNATURES['tgmx_event_create_sync'] = (c_int32, [ctypes.POINTER(c_void_p)])
+SIGNATURES['tgmx_event_record'] = (c_int32, [_P, _P])
+SIGNATURES['tgmx_stream_wait_event'] = (c_int32, [_P, _P])
+SIGNATURES['tgmx_stream_handoff'] = (c_int32, [_P, _P, _P])
+SIGNATURES['tgmx_worker_create'] = (c_int32, [ctypes.POINTER(c_void_p)])
+SIGNATURES['tgmx_worker_destroy'] = (c_int32, [_P])
+SIGNATURES['tgmx_worker_pipeline_step'] = (c_int32, [_P, ctypes.POINTER(Pipeline), c_int64, c_int64, ctypes.c_uint64, ctypes.POINTER(PipelineOut),
+                                                     ctypes.POINTER(PipelinePost), _P, _P, _P, ctypes.POINTER(ctypes.c_uint64)])
+SIGNATURES['tgmx_worker_wait'] = (c_int32, [_P, ctypes.c_uint64])
 SIGNATURES['tgmx_slice'] = (c_int32, [_P, c_int64, c_int32, c_int64, c_int32, c_int64, c_int64, c_int64, ctypes.POINTER(c_int64), ctypes.POINTER(c_int64)])
 SIGNATURES['tgmx_discretize_workspace_bytes'] = (c_size_t, [c_int64])
 SIGNATURES['tgmx_discretize_keep'] = (c_int32, [_P, _P, _P, c_int64, ctypes.c_double, _P, _P, _P, _P, c_size_t, _P])

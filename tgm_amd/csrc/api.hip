@@ -56,6 +56,40 @@ extern "C" int tgmx_event_create(tgmx_event_t* ev) {
   return TGMX_OK;
 }
 
+extern "C" int tgmx_event_create_sync(tgmx_event_t* ev) {
+  TGMX_REQUIRE(ev, "event_create_sync: null pointer");
+  hipEvent_t e;
+  if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+    tgmx::set_error("event_create_sync: hipEventCreateWithFlags failed");
+    return TGMX_E_LAUNCH;
+  }
+  *ev = (tgmx_event_t)e;
+  return TGMX_OK;
+}
+
+extern "C" int tgmx_event_record(tgmx_event_t ev, tgmx_stream_t stream) {
+  TGMX_REQUIRE(ev, "event_record: null event");
+  if (hipEventRecord((hipEvent_t)ev, (hipStream_t)stream) != hipSuccess) {
+    tgmx::set_error("event_record: hipEventRecord failed");
+    return TGMX_E_LAUNCH;
+  }
+  return TGMX_OK;
+}
+
+extern "C" int tgmx_stream_wait_event(tgmx_stream_t stream, tgmx_event_t ev) {
+  TGMX_REQUIRE(ev, "stream_wait_event: null event");
+  if (hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)ev, 0) != hipSuccess) {
+    tgmx::set_error("stream_wait_event: hipStreamWaitEvent failed");
+    return TGMX_E_LAUNCH;
+  }
+  return TGMX_OK;
+}
+
+extern "C" int tgmx_stream_handoff(tgmx_stream_t from, tgmx_stream_t to, tgmx_event_t ev) {
+  if (int rc = tgmx_event_record(ev, from)) return rc;
+  return tgmx_stream_wait_event(to, ev);
+}
+
 extern "C" int tgmx_event_destroy(tgmx_event_t ev) {
   if (ev) (void)hipEventDestroy((hipEvent_t)ev);
   return TGMX_OK;

@@ -20,6 +20,7 @@ tensors).  ``0``: never lower; hooks run one by one and allocate per batch.
 """
 from __future__ import annotations
 
+import os
 from typing import Any, Iterator, Literal, Optional
 
 import torch.utils.data
@@ -40,6 +41,7 @@ class DGDataLoader(torch.utils.data.DataLoader):
         prefetch: int = 0,
         batch_shard: Optional[tuple] = None,
         shard_even: bool = False,
+        side_stream: bool = False,
         **kwargs: Any,
     ) -> None:
         if batch_size <= 0:
@@ -75,6 +77,18 @@ class DGDataLoader(torch.utils.data.DataLoader):
             raise ValueError(f'prefetch must be 0, 1 or 2 (hooks keep 4 size mirrors in flight), got {prefetch}')
         if self._prefetch and self._output_pool is not None and 0 < self._output_pool <= self._prefetch:
             raise ValueError(f'prefetch={prefetch} keeps {prefetch + 1} batches alive: output_pool must be 0 (fresh tensors) or > prefetch')
+        # side_stream=True (ours; needs prefetch >= 1 and a recycled pool: output_pool > prefetch): the hooks' work for batch i + p is
+        # enqueued on a stream of the loader's own while the consumer's work for batch i runs on the caller's stream -- the sampler /
+        # dedup / edge-list chain of a TGN batch is a dozen small latency-bound launches that fit beside the model's.
+        # Ordering is by events, never by the host: the consumer's stream waits for its batch's production; the production that
+        # rewrites an output set waits for everything the consumer had enqueued when it was asked for (which covers its reads of
+        # that set: the pool is deeper than the look-ahead).  Hook state lives on the side stream for the whole pass; the pass ends
+        # by handing everything back to the caller's stream.
+        self._side_stream = bool(side_stream)
+        if self._side_stream and not (self._prefetch >= 1 and self._output_pool is not None and self._output_pool > self._prefetch):
+            raise ValueError('side_stream=True needs prefetch >= 1 and output_pool > prefetch (the sets the consumer reads and the set being '
+                             'written must be different ones)')
+        self._side = None  # (torch.cuda.Stream, [events])
         self._compiled = None  # (hook list identity, CompiledPipeline or None)
         self._event_fast = False
 
@@ -119,6 +133,17 @@ class DGDataLoader(torch.utils.data.DataLoader):
             self._starts = range(start, stop, batch_size)
         # the reference's base-class call (loader.py:147-149): torch validates the keyword arguments; unknown ones raise TypeError
         super().__init__(self._starts, 1, shuffle=False, collate_fn=self, **kwargs)
+
+    def __del__(self) -> None:
+        side = getattr(self, '_side', None)
+        if side is not None and len(side) > 2 and side[2]:
+            try:
+                from .. import _native
+
+                _native.load().tgmx_worker_destroy(side[2])  # finishes pending jobs, joins the library's launch thread
+            except Exception:  # noqa: BLE001 -- interpreter shutdown
+                pass
+            self._side = None
 
     @property
     def dgraph(self) -> DGraph:
@@ -290,6 +315,9 @@ class DGDataLoader(torch.utils.data.DataLoader):
     def _iter_prefetch(self) -> Iterator[DGBatch]:
         from collections import deque
 
+        if self._side_stream:
+            yield from self._iter_side_stream()
+            return
         ahead: deque = deque()
         for s in self._starts:
             batch = self(s, _deferred=True)
@@ -303,3 +331,105 @@ class DGDataLoader(torch.utils.data.DataLoader):
                 yield ahead.popleft()._finalize()
         while ahead:
             yield ahead.popleft()._finalize()
+
+    def _iter_side_stream(self) -> Iterator[DGBatch]:
+        """``_iter_prefetch`` with the production on the loader's own stream (see ``side_stream`` in ``__init__``).  When the whole hook
+        chain is lowered (one native call per batch) that call is issued by the library's launch worker (``tgmx_worker_pipeline_step``:
+        a host thread of the library, no GIL), so this thread pays for the hooks' Python only, not for their launches."""
+        import ctypes
+        from collections import deque
+
+        import torch
+
+        from .. import _native
+
+        dev = self._dg._device
+        if dev.type != 'cuda':
+            raise ValueError('side_stream=True needs a device-resident graph (DGraph(..., device="cuda"))')
+        lib = _native.load()
+        if self._side is None or self._side[0].device != dev:
+            n_ev = 2 * (self._prefetch + 2)
+            evs = []
+            for _ in range(n_ev):
+                e = ctypes.c_void_p()
+                _native.check(lib.tgmx_event_create_sync(ctypes.byref(e)), 'tgmx_event_create_sync')
+                evs.append(e)
+            with torch.cuda.device(dev):
+                w = ctypes.c_void_p()
+                _native.check(lib.tgmx_worker_create(ctypes.byref(w)), 'tgmx_worker_create')
+            self._side = (torch.cuda.Stream(device=dev), evs, w)
+        side, evs, worker = self._side
+        main = torch.cuda.current_stream(dev)
+        side_p, main_p = side.cuda_stream, main.cuda_stream
+        record, wait, handoff, wwait = lib.tgmx_event_record, lib.tgmx_stream_wait_event, lib.tgmx_stream_handoff, lib.tgmx_worker_wait
+        set_stream = torch.cuda.set_stream
+        n_prod = len(evs) // 2
+        use_worker = os.environ.get('TGMX_LOADER_WORKER', '1') != '0'  # A/B knob: 0 = this thread issues the loader's launches itself
+        ahead: deque = deque()
+        j = 0
+        last_ticket = 0
+        # the hooks' state was last touched on the caller's stream (reset_state, an earlier pass): the side stream starts behind it
+        _native.check(handoff(main_p, side_p, evs[n_prod]), 'tgmx_stream_handoff')
+        try:
+            for s in self._starts:
+                hz = None
+                if j:
+                    # this production may rewrite the set of a batch the consumer has finished ENQUEUING work for: after that work
+                    hz = evs[n_prod + j % n_prod]
+                    _native.check(record(hz, main_p), 'tgmx_event_record')
+                ev = evs[j % n_prod]
+                pipe = self._compiled[1] if self._compiled is not None else None
+                hm = self._hook_manager
+                lowered = (use_worker and pipe is not None and hm is not None and pipe.n_lowered == len(hm.active_hooks()) and pipe._shard is None
+                           and self._compiled[0] is hm.active_hooks())
+                if lowered:
+                    pipe._async = (worker, hz, ev)  # the worker waits for hz on the side stream, issues the step, records ev
+                else:
+                    if last_ticket:  # earlier jobs are issued before this thread enqueues on the same stream
+                        _native.check(wwait(worker, last_ticket), 'tgmx_worker_wait')
+                    if hz is not None:
+                        _native.check(wait(side_p, hz), 'tgmx_stream_wait_event')
+                set_stream(side)
+                try:
+                    batch = self(s, _deferred=True)
+                finally:
+                    set_stream(main)
+                    if lowered:
+                        pipe._async = None
+                ticket = batch.__dict__.pop('_ticket', None)
+                if ticket is not None:
+                    last_ticket = ticket
+                else:
+                    if lowered:
+                        # the lowered call left this batch to the hooks (it submitted no job): what they enqueued from this thread is
+                        # ordered by hand -- behind the worker's earlier jobs would have been too late for the hazard, so drain and accept
+                        # that such batches (empty shares) are rare
+                        if last_ticket:
+                            _native.check(wwait(worker, last_ticket), 'tgmx_worker_wait')
+                    _native.check(record(ev, side_p), 'tgmx_event_record')
+                if self._on_empty is not None and self._is_batch_empty(batch):
+                    if self._on_empty == 'raise':
+                        raise EmptyBatchError('Empty batch encountered')
+                    if ticket is not None:
+                        _native.check(wwait(worker, ticket), 'tgmx_worker_wait')
+                    batch._finalize()
+                    continue
+                j += 1
+                ahead.append((batch, ev, ticket))
+                if len(ahead) > self._prefetch:
+                    b, e, tk = ahead.popleft()
+                    if tk is not None:  # (normally issued long ago) its events must have been recorded before anybody waits on them
+                        _native.check(wwait(worker, tk), 'tgmx_worker_wait')
+                    _native.check(wait(main_p, e), 'tgmx_stream_wait_event')
+                    yield b._finalize()
+            while ahead:
+                b, e, tk = ahead.popleft()
+                if tk is not None:
+                    _native.check(wwait(worker, tk), 'tgmx_worker_wait')
+                _native.check(wait(main_p, e), 'tgmx_stream_wait_event')
+                yield b._finalize()
+        finally:
+            # whatever comes next on the caller's stream (another pass, reset_state, hook.check()) sees the side stream's work
+            if last_ticket:
+                wwait(worker, last_ticket)
+            handoff(side_p, main_p, evs[n_prod])

@@ -122,6 +122,7 @@ class CompiledPipeline:
         self._roles = [_ROLE_KEYS[shard is not None][k][0] for k in nbr._seed_nodes_keys]
         self._static_ok: Optional[tuple] = None  # host-side seed validation of the resident store (validate='sync')
         self._since_check = 0
+        self._async = None  # (worker, wait event or None, record event): DGDataLoader(side_stream=True) sets it around a call
 
     # -- lowering ---------------------------------------------------------------
     @staticmethod
@@ -507,9 +508,23 @@ class CompiledPipeline:
         if nbr.profile_hop is not None and nbr._calls % nbr.profile_every == 0 and nbr.profile_pool:
             timer = nbr.profile_pool.pop()
             out.timed_hop, out.ev_start, out.ev_stop = nbr.profile_hop, timer.start, timer.stop
-        rc = self._lib.tgmx_pipeline_step(pipe, lo, n, call, out, slot.post, _native.stream_ptr(self._device.index))
-        if rc:
-            _native.check(rc, 'tgmx_pipeline_step')
+        asy = self._async
+        if asy is not None and timer is None:
+            # DGDataLoader(side_stream=True): the library's launch worker issues this step (argument blocks copied now) on the current
+            # -- the loader's own -- stream, after `asy[1]` and in front of `asy[2]`; the loader collects the ticket
+            tk = ctypes.c_uint64()
+            rc = self._lib.tgmx_worker_pipeline_step(asy[0], pipe, lo, n, call, out, slot.post, _native.stream_ptr(self._device.index), asy[1], asy[2],
+                                                     ctypes.byref(tk))
+            if rc:
+                _native.check(rc, 'tgmx_worker_pipeline_step')
+            batch.__dict__['_ticket'] = tk.value
+        else:
+            stream = _native.stream_ptr(self._device.index)
+            if asy is not None and asy[1]:  # (a timed launch under side_stream: issued from this thread, ordered the same way)
+                self._lib.tgmx_stream_wait_event(stream, asy[1])
+            rc = self._lib.tgmx_pipeline_step(pipe, lo, n, call, out, slot.post, stream)
+            if rc:
+                _native.check(rc, 'tgmx_pipeline_step')
         if timer is not None:
             out.timed_hop = -1
             self._log_timed(timer, slot)

@@ -45,7 +45,45 @@ k = ks[0]
 
 def batches(lo, hi):
     """batches lo .. hi - 1 of the stream (a view of the resident store; the sampler state carries over)"""
-    return DGDataLoader(dg.slice_events(lo * bs, hi * bs), batch_size=bs, hook_manager=hm, output_pool=2 if fast else 0, prefetch=1 if fast else 0)
+    if os.environ.get('TGMX_BENCH_TGN_STREAMS') == 'script':
+        return two_stream_batches(lo, hi)
+    side = fast and os.environ.get('TGMX_BENCH_TGN_STREAMS', '1') != '0'  # the loader's chain beside the model's (DGDataLoader(side_stream=))
+    return DGDataLoader(dg.slice_events(lo * bs, hi * bs), batch_size=bs, hook_manager=hm, output_pool=2 if fast else 0, prefetch=1 if fast else 0,
+                        side_stream=side)
+
+
+_side = torch.cuda.Stream(device=dev) if os.environ.get('TGMX_BENCH_TGN_STREAMS') == 'script' else None
+
+
+def two_stream_batches(lo, hi):
+    """EXPERIMENT (TGMX_BENCH_TGN_STREAMS=script; the library form is DGDataLoader(side_stream=True)): the loader's chain of batch i + 1 on a side stream beside the model's chain of batch i --
+    2 event records + 2 stream waits per batch order the two (a set is rewritten only after the model that read it was enqueued AND its
+    event passed; the model waits for its batch's production)."""
+    from collections import deque
+
+    pool = int(os.environ.get('TGMX_BENCH_TGN_POOL', 3))
+    ld = DGDataLoader(dg.slice_events(lo * bs, hi * bs), batch_size=bs, hook_manager=hm, output_pool=pool, prefetch=0)
+    main = torch.cuda.current_stream(dev)
+    ahead = deque()
+    done = None
+    for s in ld._starts:
+        with torch.cuda.stream(_side):
+            if done is not None:
+                _side.wait_event(done)
+            b = ld(s, _deferred=True)
+            ev = torch.cuda.Event()
+            ev.record(_side)
+        ahead.append((b, ev))
+        if len(ahead) > 1:
+            b0, e0 = ahead.popleft()
+            main.wait_event(e0)
+            yield b0._finalize()
+            done = torch.cuda.Event()
+            done.record(main)
+    while ahead:
+        b0, e0 = ahead.popleft()
+        main.wait_event(e0)
+        yield b0._finalize()
 
 
 def step(batch):
@@ -104,6 +142,36 @@ with hm.activate('k'), torch.no_grad():
         c = Counter((e.name, str(e.input_shapes)[:70], next((s for s in (e.stack or []) if 'tgm_amd' in s or 'bench_tgn' in s), '?')) for e in cpu)
         for k, v in c.most_common(25):
             print('CPU-OP', v, k)
+        sys.exit(0)
+    if os.environ.get('TGMX_BENCH_TGN_PHASES'):  # host microseconds per phase of the loop (perf_counter around each call; then exit)
+        ph = {'next(loader)': 0.0, 'mem()': 0.0, 'enc()': 0.0, 'update_state()': 0.0}
+        it = iter(batches(100, 100 + n))
+        cnt = 0
+        gpu_ev = []  # (start, end) of every model step on the caller's stream: the device-side duration of the model's chain
+        while True:
+            a0 = time.perf_counter()
+            try:
+                batch = next(it)
+            except StopIteration:
+                break
+            a1 = time.perf_counter()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            z, lu = mem(batch.unique_nids)
+            a2 = time.perf_counter()
+            z2 = enc(z, lu, batch.sampled_edge_index, batch.sampled_edge_time, batch.sampled_edge_x)
+            a3 = time.perf_counter()
+            mem.update_state(batch.edge_src, batch.edge_dst, batch.edge_time, batch.edge_x)
+            a4 = time.perf_counter()
+            e1.record()
+            gpu_ev.append((e0, e1))
+            ph['next(loader)'] += a1 - a0; ph['mem()'] += a2 - a1; ph['enc()'] += a3 - a2; ph['update_state()'] += a4 - a3
+            cnt += 1
+        torch.cuda.synchronize()
+        chain = [1e3 * a.elapsed_time(b_) for a, b_ in gpu_ev[20:]]
+        idle = [1e3 * gpu_ev[i][1].elapsed_time(gpu_ev[i + 1][0]) for i in range(20, len(gpu_ev) - 1)]
+        print(json.dumps({'host_us_per_phase': {k: 1e6 * v / cnt for k, v in ph.items()}, 'waiting_in_next_us': 1e6 * _waited[0] / cnt, 'batches': cnt,
+                          'model_chain_on_device_us': sum(chain) / len(chain), 'caller_stream_idle_between_model_steps_us': sum(idle) / len(idle)}))
         sys.exit(0)
     _waited[0] = 0.0
     t0 = time.perf_counter()

@@ -102,6 +102,26 @@ def pmc(db, kernel):
         print(f'| `{short(name, 60)}` | {cn} | {grid} | {n} | {avg:.1f} | {mn:.1f} | {mx:.1f} |')
 
 
+def union(db, last_frac):
+    """sum of kernel durations vs the length of the UNION of their [start, end) intervals over the last `last_frac` of the run's launches
+    (two-stream pipelines: how much of the kernel time actually overlaps on the device), and the wall span they cover"""
+    rows = db.execute('select start, end from kernels order by start').fetchall()
+    rows = rows[int(len(rows) * (1.0 - last_frac)):]
+    total = sum(e - s for s, e in rows)
+    cover, cur_s, cur_e = 0, None, None
+    for s, e in rows:
+        if cur_e is None or s > cur_e:
+            if cur_e is not None:
+                cover += cur_e - cur_s
+            cur_s, cur_e = s, e
+        else:
+            cur_e = max(cur_e, e)
+    cover += cur_e - cur_s
+    span = max(e for _, e in rows) - rows[0][0]
+    print(json.dumps({'launches': len(rows), 'sum_of_kernel_ms': total / 1e6, 'union_ms': cover / 1e6, 'span_ms': span / 1e6,
+                      'overlap_saved_frac': 1 - cover / total, 'device_busy_frac_of_span': cover / span}))
+
+
 def pmcsum(db, kernel):
     """per kernel NAME and counter: the per-dispatch SUM over the counter's instances (XCDs / shader engines), averaged over the dispatches; JSON lines"""
     rows = db.execute('select k.name, k.dispatch_id, p.counter_name, sum(p.counter_value), count(*) from pmc_events p join kernels k on k.dispatch_id = p.dispatch_id '
@@ -139,7 +159,7 @@ def pmctail(db, kernel, last):
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
-    ap.add_argument('what', choices=['trace', 'byname', 'gaps', 'pmc', 'pmcsum', 'tail', 'pmctail'])
+    ap.add_argument('what', choices=['trace', 'byname', 'gaps', 'pmc', 'pmcsum', 'tail', 'pmctail', 'union'])
     ap.add_argument('--last', type=int, default=393)
     ap.add_argument('path')
     ap.add_argument('--title', default='rocprofv3 --kernel-trace --stats')
@@ -147,5 +167,5 @@ if __name__ == '__main__':
     ap.add_argument('--steps', type=int, default=0)
     a = ap.parse_args()
     db = open_db(a.path)
-    {'trace': lambda: trace(db, a.title), 'byname': lambda: byname(db, a.title, a.steps), 'gaps': lambda: gaps(db, a.kernel), 'pmc': lambda: pmc(db, a.kernel), 'pmcsum': lambda: pmcsum(db, a.kernel), 'tail': lambda: tail(db, a.kernel, a.last),
+    {'trace': lambda: trace(db, a.title), 'byname': lambda: byname(db, a.title, a.steps), 'gaps': lambda: gaps(db, a.kernel), 'pmc': lambda: pmc(db, a.kernel), 'pmcsum': lambda: pmcsum(db, a.kernel), 'union': lambda: union(db, 0.5), 'tail': lambda: tail(db, a.kernel, a.last),
      'pmctail': lambda: pmctail(db, a.kernel, a.last)}[a.what]()
