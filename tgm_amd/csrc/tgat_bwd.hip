@@ -11,6 +11,8 @@
 // The "NN" products (dX = dY W) reuse sgemm_nt with transposed weight copies.
 #include "common.h"
 
+#include <type_traits>
+
 namespace tgmx {
 
 using floatx16 = __attribute__((__vector_size__(16 * sizeof(float)))) float;
@@ -251,9 +253,40 @@ __device__ __forceinline__ void bwd_reduce_scatter_step(float (&P)[64], int lane
   }
 }
 
-template <int H>
-__global__ __launch_bounds__(256) void tgat_attn_backward_kernel(const AttnBwdArgs a) {
-  constexpr int G = 64 / H;
+// The same reduce-scatter over the first NVp (a power of two) entries only: the steps whose stride is >= NVp cannot scatter -- both
+// partners add (a + b == b + a: the value the full version leaves in the lane that keeps the entry) -- the rest are the steps above.
+// Lane j ends up with entry j mod NVp, summed over the 64 lanes in the order xor 32, 16, 8, 4, 2, 1 whatever NVp is.
+template <int NVp, int HALF>
+__device__ __forceinline__ void bwd_reduce_n_step(float (&P)[NVp], int lane) {
+  if constexpr (HALF >= NVp) {
+#pragma unroll
+    for (int i = 0; i < NVp; ++i) P[i] += __shfl_xor(P[i], HALF);
+  } else {
+    const bool upper = (lane & HALF) != 0;
+#pragma unroll
+    for (int i = 0; i < HALF; ++i) {
+      const float send = upper ? P[i] : P[i + HALF];
+      const float recv = __shfl_xor(send, HALF);
+      const float keep = upper ? P[i + HALF] : P[i];
+      P[i] = keep + recv;
+    }
+  }
+}
+template <int NVp>
+__device__ __forceinline__ void bwd_reduce_scatter_n(float (&P)[NVp], int lane) {
+  bwd_reduce_n_step<NVp, 32>(P, lane);
+  bwd_reduce_n_step<NVp, 16>(P, lane);
+  bwd_reduce_n_step<NVp, 8>(P, lane);
+  bwd_reduce_n_step<NVp, 4>(P, lane);
+  bwd_reduce_n_step<NVp, 2>(P, lane);
+  bwd_reduce_n_step<NVp, 1>(P, lane);
+}
+
+// KMAX: the most slots a row of this launch can have (k <= KMAX): the widest body instantiated -- the register allocation of the kernel
+// is its widest body's, and k <= 20 (every example configuration) should not pay for a 32-slot one
+template <int H, int KMAX>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void tgat_attn_backward_kernel(const AttnBwdArgs a) {
+  constexpr int G = (64 / H) < KMAX ? (64 / H) : KMAX;
   extern __shared__ __attribute__((aligned(16))) float lds_all[];
   const int lane = lane_id(), wave = threadIdx.x >> 6;
   const int k = a.k, T = a.T, d = a.d, D = a.D, Cs = a.Cs;
@@ -284,24 +317,47 @@ __global__ __launch_bounds__(256) void tgat_attn_backward_kernel(const AttnBwdAr
   }
   const float* __restrict__ nb = lv_nbrf + r * (long long)k * d;
   const float* __restrict__ ex = lv_ex ? lv_ex + r * (long long)k * D : nullptr;
+  float* __restrict__ dq = a.dqf + r * (long long)H * Cs;
 
+  // ---- rows without upstream gradient: nothing to compute ----
+  // A level-1 row that layer 2 consumed through a MASKED slot (a pad seed: ~1/4 of the layer-1 rows at the headline shape) receives
+  // dzs = A' dzbar + scale ds q = 0 exactly, and zero rows stay zero through the tail's backward (GEMMs, LayerNorm, ReLU mask): its dzbar
+  // is all zeros, so dA = 0, ds = 0 and every output of this row is 0 -- written as such, without reading a feature.
+  {
+    bool nz = false;
+    for (int c = lane; c < a.C; c += kWave) {
+#pragma unroll
+      for (int h = 0; h < H; ++h) nz = nz || dz[h * Cs + c] != 0.f;
+    }
+    if (!__any(nz)) {
+      for (int c = lane; c < H * Cs; c += kWave) dq[c] = 0.f;
+      for (int c = lane; c < 2 * T; c += kWave) a.dtime[r * 2LL * T + c] = 0.f;
+      return;
+    }
+  }
+  // ---- the slots that carry gradient ----
+  // lane j = s * H + h holds (slot s, head h).  A masked slot of a row that has a valid one has A == 0 in every head (exp(-1e10 - max)
+  // underflows): its ds = A (dA - dot) is 0 whatever dA is, and with it every contribution of the slot to dqf, dnbr and the Time2Vec
+  // gradient.  The sampler right-aligns a window (pads on the left; ~7 of 20 slots of a real row hold a neighbor at the headline
+  // shape), so the slots LEFT of the first one with A != 0 are not read, scored or differentiated at all: the body below is
+  // instantiated for the last GS = 4, 8, 12, 16, 20, 24 and all G slot positions and a row takes the smallest that covers its span
+  // (straight-line code per body: guards that skip single slots serialise the loads -- measured, 241 -> 340 us).  A dead slot
+  // INSIDE the span (an interior pad, an explicit mask) is computed like before: A = 0 makes its contributions exact zeros.  A row with
+  // no valid slot attends uniformly (A = 1/k): its span is all k slots.  Every sum keeps its order: results equal the all-slots body's.
   const long long st = lv_seed_t[r];
   for (int s = lane; s < k; s += kWave) {
     s_dt[s] = (float)(st - lv_nbr_t[r * k + s]);
     if (lv_eid) s_eid[s] = lv_eid[r * k + s];
   }
-  __builtin_amdgcn_wave_barrier();
-  for (int e = lane; e < k * T; e += kWave) {
-    const int s = e / T, t = e - s * T;
-    const float arg = __fmaf_rn(s_dt[s], a.tw[t], a.tb[t]);
-    s_cos[e] = cos_t2v(arg);
+  int span;
+  {
+    const int js0 = lane / H, jh0 = lane - js0 * H;
+    const float A0 = js0 < k ? a.probs[r * (long long)H * k + jh0 * k + js0] : 0.f;
+    const unsigned long long amask = __ballot(A0 != 0.f);
+    const int first = amask ? (__ffsll((long long)amask) - 1) / H : 0;
+    span = k - first;
   }
   __builtin_amdgcn_wave_barrier();
-
-  // ---- dA[h][s] = dzbar[h] . z[s] ----
-  float P[64];
-#pragma unroll
-  for (int j = 0; j < 64; ++j) P[j] = 0.f;
   // feature c of slot sl: a strided block of the row's own slots, or (edge features by id) row eid[sl] of the resident store --
   // the id is the same in every lane (a scalar base for the load); a pad slot (-1) reads zeros like the dense copy holds them
   auto dense = [](const float* __restrict__ base, long long slot_stride) {
@@ -311,81 +367,141 @@ __global__ __launch_bounds__(256) void tgat_attn_backward_kernel(const AttnBwdAr
     const int e = __builtin_amdgcn_readfirstlane(s_eid[sl]);
     return e >= 0 ? lv_table[(long long)e * D + c] : 0.f;
   };
-  auto accumulate = [&](auto&& load, int dim, int col0) {
-    for (int c = lane; c < dim; c += kWave) {
-      float gv[H];
-#pragma unroll
-      for (int h = 0; h < H; ++h) gv[h] = dz[h * Cs + col0 + c];
-#pragma clang loop unroll(full)
-      for (int s = 0; s < G; ++s) {
-        const int sl = s < k ? s : k - 1;
-        const float z = load(sl, c);
-#pragma unroll
-        for (int h = 0; h < H; ++h) P[s * H + h] = __fmaf_rn(gv[h], z, P[s * H + h]);
-      }
+  auto body = [&](auto gsc) __attribute__((always_inline)) {
+    constexpr int GS = decltype(gsc)::value;  // slot positions this body covers: slots [k - GS, k), those below 0 do not exist
+    const int sb = k - GS;
+    for (int i = 0; i < GS; ++i) {  // the cosines of the covered slots
+      const int sl = sb + i;
+      if (sl < 0) continue;
+      const float dts = s_dt[sl];
+      for (int t = lane; t < T; t += kWave) s_cos[sl * T + t] = cos_t2v(__fmaf_rn(dts, a.tw[t], a.tb[t]));
     }
-  };
-  accumulate(dense(nb, d), d, 0);
-  if (D > 0) {
-    if (ex) accumulate(dense(ex, D), D, d);
-    else accumulate(by_id, D, d);
-  }
-  accumulate(dense(s_cos, T), T, d + D);
-  bwd_reduce_scatter_step<32>(P, lane);
-  bwd_reduce_scatter_step<16>(P, lane);
-  bwd_reduce_scatter_step<8>(P, lane);
-  bwd_reduce_scatter_step<4>(P, lane);
-  bwd_reduce_scatter_step<2>(P, lane);
-  bwd_reduce_scatter_step<1>(P, lane);
-  const int js = lane / H, jh = lane - js * H;
-  const bool live = js < k;
-  // zbar used A' = A * mk (dropout on the softmax output, attention.py:119): dA = dA' * mk, and the slot gradients below take A'
-  const float mk = live ? dropout_scale(a.drop, (unsigned long long)(a.drop_row0 + r) * (H * k) + jh * k + js) : 0.f;
-  const float dA = P[0] * mk;  // lane j = s*H + h
-  const float A = live ? a.probs[r * (long long)H * k + jh * k + js] : 0.f;
-  float dot = A * dA;
+    __builtin_amdgcn_wave_barrier();
+    // ---- dA[h][s] = dzbar[h] . z[s] ----
+    // (position, head) pairs 0 .. 31 in one reduce-scatter of <= 32 entries, the rest (k = 20, two heads: 8 more) in a second, small one:
+    // 40 registers of partial sums instead of 64 -- the body must stay under the two-waves-per-SIMD register budget
+    constexpr int NV = GS * H, NV1 = NV < 32 ? NV : 32, NV2 = NV - NV1;
+    constexpr int NVp = NV1 <= 2 ? 2 : NV1 <= 4 ? 4 : NV1 <= 8 ? 8 : NV1 <= 16 ? 16 : 32;
+    constexpr int NVq = NV2 <= 0 ? 1 : NV2 <= 2 ? 2 : NV2 <= 4 ? 4 : NV2 <= 8 ? 8 : NV2 <= 16 ? 16 : 32;
+    float P[NVp], Q[NVq];
 #pragma unroll
-  for (int o = H; o < 64; o <<= 1) dot += __shfl_xor(dot, o);
-  const float ds = A * (dA - dot);  // softmax backward; masked slots have A == 0
-  if (live) {
-    s_A[jh * k + js] = A * mk;
-    s_ds[jh * k + js] = ds;
-  }
-  __builtin_amdgcn_wave_barrier();
+    for (int j = 0; j < NVp; ++j) P[j] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NVq; ++j) Q[j] = 0.f;
+    // A section of `dim` columns (neighbor features, edge features, time encoding) takes ceil(dim / 64) column chunks per lane.  Up to
+    // three chunks (dim <= 192) are ONE straight-line block: the chunks' loads are all issued before the first product -- a chunk loop
+    // is a dependent round trip per chunk (a row of this kernel was a chain of ~12 of them: 45 us of wave life per row).  A column past
+    // the section reads column 0 with a zero multiplier.  Per accumulator the products still arrive in chunk order.
+    auto accumulate = [&](auto&& load, int dim, int col0) {
+      auto run = [&](auto nch) __attribute__((always_inline)) {
+        constexpr int NCH = decltype(nch)::value;
+        float gv[NCH][H];
+        int cc[NCH];
+#pragma unroll
+        for (int u = 0; u < NCH; ++u) {
+          const int c = lane + u * kWave;
+          const bool ok = c < dim;
+          cc[u] = ok ? c : 0;
+#pragma unroll
+          for (int h = 0; h < H; ++h) {
+            const float g = dz[h * Cs + col0 + cc[u]];
+            gv[u][h] = ok ? g : 0.f;
+          }
+        }
+#pragma clang loop unroll(full)
+        for (int i = 0; i < GS; ++i) {
+          const int sl = sb + i > 0 ? sb + i : 0;  // (a position below slot 0 re-reads slot 0: its lanes are not live)
+#pragma unroll
+          for (int u = 0; u < NCH; ++u) {
+            const float z = load(sl, cc[u]);
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+              if (i * H + h < 32) P[(i * H + h) & (NVp - 1)] = __fmaf_rn(gv[u][h], z, P[(i * H + h) & (NVp - 1)]);  // (compile-time indices)
+              else Q[(i * H + h - 32) & (NVq - 1)] = __fmaf_rn(gv[u][h], z, Q[(i * H + h - 32) & (NVq - 1)]);
+            }
+          }
+        }
+      };
+      if (dim <= kWave) run(std::integral_constant<int, 1>{});
+      else if (dim <= 2 * kWave) run(std::integral_constant<int, 2>{});
+      else if (dim <= 3 * kWave) run(std::integral_constant<int, 3>{});
+      else {
+        for (int c0 = 0; c0 < dim; c0 += kWave) {  // wide sections: chunk by chunk
+          const int c = c0 + lane;
+          const bool ok = c < dim;
+          const int ce = ok ? c : 0;
+          float gv[H];
+#pragma unroll
+          for (int h = 0; h < H; ++h) gv[h] = ok ? dz[h * Cs + col0 + ce] : 0.f;
+#pragma clang loop unroll(full)
+          for (int i = 0; i < GS; ++i) {
+            const float z = load(sb + i > 0 ? sb + i : 0, ce);
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+              if (i * H + h < 32) P[(i * H + h) & (NVp - 1)] = __fmaf_rn(gv[h], z, P[(i * H + h) & (NVp - 1)]);
+              else Q[(i * H + h - 32) & (NVq - 1)] = __fmaf_rn(gv[h], z, Q[(i * H + h - 32) & (NVq - 1)]);
+            }
+          }
+        }
+      }
+    };
+    accumulate(dense(nb, d), d, 0);
+    if (D > 0) {
+      if (ex) accumulate(dense(ex, D), D, d);
+      else accumulate(by_id, D, d);
+    }
+    accumulate(dense(s_cos, T), T, d + D);
+    bwd_reduce_scatter_n<NVp>(P, lane);
+    if constexpr (NV2 > 0) bwd_reduce_scatter_n<NVq>(Q, lane);  // lane 32 + j (j < NV2 <= NVq) ends up with entry 32 + j
+    const int ji = lane / H, jh = lane - ji * H;  // lane j = i * H + h (j < NV) holds position i of the body, head h
+    const int js = sb + ji;
+    const bool live = ji < GS && js >= 0;
+    // zbar used A' = A * mk (dropout on the softmax output, attention.py:119): dA = dA' * mk, and the slot gradients below take A'
+    const float mk = live ? dropout_scale(a.drop, (unsigned long long)(a.drop_row0 + r) * (H * k) + jh * k + js) : 0.f;
+    const float dA = ((NV2 > 0 && lane >= 32) ? Q[0] : P[0]) * mk;
+    const float A = live ? a.probs[r * (long long)H * k + jh * k + js] : 0.f;
+    float dot = A * dA;
+#pragma unroll
+    for (int o = H; o < 64; o <<= 1) dot += __shfl_xor(dot, o);
+    const float ds = A * (dA - dot);  // softmax backward; masked slots have A == 0
+    if (live) {
+      s_A[jh * k + js] = A * mk;
+      s_ds[jh * k + js] = ds;
+    }
+    __builtin_amdgcn_wave_barrier();
 
-  // ---- dqf[h][c] = scale * sum_s ds[h][s] z[s][c];  dz[s][c] = sum_h A dzbar + scale * ds * qf ----
-  float* __restrict__ dq = a.dqf + r * (long long)H * Cs;
-  auto columns = [&](auto&& load, int dim, int col0, int part) {
-    for (int c = lane; c < dim; c += kWave) {
+    // ---- dqf[h][c] = scale * sum_s ds[h][s] z[s][c];  dz[s][c] = sum_h A dzbar + scale * ds * qf ----
+    // one column of one section: the covered slots' values of that column (all loaded first), then the slot loop
+    auto column = [&](auto&& load, int c, bool ok, int col0, int part) __attribute__((always_inline)) {
+      const int ce = ok ? c : 0;
       float acc[H], gv[H], qv[H];
 #pragma unroll
       for (int h = 0; h < H; ++h) {
         acc[h] = 0.f;
-        gv[h] = dz[h * Cs + col0 + c];
-        qv[h] = q[h * Cs + col0 + c];
+        gv[h] = dz[h * Cs + col0 + ce];
+        qv[h] = q[h * Cs + col0 + ce];
       }
       float dw = 0.f, db = 0.f;
-      const float tw_c = part == 2 ? a.tw[c] : 0.f, tb_c = part == 2 ? a.tb[c] : 0.f;
-      float zs[G];  // the column of every slot first: G independent loads in flight instead of one per iteration
+      const float tw_c = part == 2 ? a.tw[ce] : 0.f, tb_c = part == 2 ? a.tb[ce] : 0.f;
+      float zs[GS];
 #pragma clang loop unroll(full)
-      for (int s = 0; s < G; ++s) {
-        const int sl = s < k ? s : k - 1;
-        zs[s] = load(sl, c);
-      }
+      for (int i = 0; i < GS; ++i) zs[i] = load(sb + i > 0 ? sb + i : 0, ce);
+      if (!ok) return;  // (a lane without a column in this chunk: its loads above keep the chunk one block of loads; nothing to store)
 #pragma clang loop unroll(full)
-      for (int s = 0; s < G; ++s) {
-        if (s < k) {
-          const float z = zs[s];
+      for (int i = 0; i < GS; ++i) {
+        const int sl = sb + i;
+        if (sl >= 0) {  // (wave-uniform)
+          const float z = zs[i];
           float dzs = 0.f;
 #pragma unroll
           for (int h = 0; h < H; ++h) {
-            acc[h] = __fmaf_rn(s_ds[h * k + s], z, acc[h]);
-            dzs += s_A[h * k + s] * gv[h] + a.scale * s_ds[h * k + s] * qv[h];
+            acc[h] = __fmaf_rn(s_ds[h * k + sl], z, acc[h]);
+            dzs += s_A[h * k + sl] * gv[h] + a.scale * s_ds[h * k + sl] * qv[h];
           }
-          if (part == 0 && lv_dnbr) lv_dnbr[(r * k + s) * (long long)d + c] += dzs;
+          if (part == 0 && lv_dnbr) lv_dnbr[(r * k + sl) * (long long)d + c] += dzs;
           if (part == 2) {
-            const float g = -sin_t2v(__fmaf_rn(s_dt[s], tw_c, tb_c)) * dzs;  // d cos(arg) / d arg (the argument the cosine above took)
-            dw = __fmaf_rn(g, s_dt[s], dw);
+            const float g = -sin_t2v(__fmaf_rn(s_dt[sl], tw_c, tb_c)) * dzs;  // d cos(arg) / d arg (the argument the cosine above took)
+            dw = __fmaf_rn(g, s_dt[sl], dw);
             db += g;
           }
         }
@@ -396,14 +512,32 @@ __global__ __launch_bounds__(256) void tgat_attn_backward_kernel(const AttnBwdAr
         a.dtime[r * 2LL * T + c] = dw;
         a.dtime[r * 2LL * T + T + c] = db;
       }
+    };
+    auto columns = [&](auto&& load, int dim, int col0, int part) {
+      for (int c0 = 0; c0 < dim; c0 += kWave) column(load, c0 + lane, c0 + lane < dim, col0, part);
+    };
+    columns(dense(nb, d), d, 0, 0);
+    if (D > 0) {
+      if (ex) columns(dense(ex, D), D, d, 1);
+      else columns(by_id, D, d, 1);
     }
+    columns(dense(s_cos, T), T, d + D, 2);
   };
-  columns(dense(nb, d), d, 0, 0);
-  if (D > 0) {
-    if (ex) columns(dense(ex, D), D, d, 1);
-    else columns(by_id, D, d, 1);
-  }
-  columns(dense(s_cos, T), T, d + D, 2);
+  // (body sizes up to what the heads and the launch's k leave room for: G positions)
+  auto run = [&](auto n) __attribute__((always_inline)) {
+    constexpr int N = decltype(n)::value;
+    if constexpr (N <= G) {
+      if (span <= N) {
+        body(std::integral_constant<int, N>{});
+        return true;
+      }
+    }
+    return false;
+  };
+  if (run(std::integral_constant<int, 4>{}) || run(std::integral_constant<int, 8>{}) || run(std::integral_constant<int, 12>{}) ||
+      run(std::integral_constant<int, 16>{}) || run(std::integral_constant<int, 20>{}) || run(std::integral_constant<int, 24>{}))
+    return;
+  body(std::integral_constant<int, G>{});
 }
 
 }  // namespace tgmx
@@ -537,12 +671,18 @@ static int launch_attn_backward(const AttnBwdArgs& a, int H, tgmx_stream_t strea
   TGMX_REQUIRE(per_wave * waves <= 64 * 1024, "tgat_attn_backward: k*T=%d too large for LDS", k * T);
   const dim3 grid((unsigned)((R + waves - 1) / waves)), block(waves * kWave);
   hipStream_t st = (hipStream_t)stream;
+#define TGMX_ATTN_BWD(H_)                                                                                        \
+  do {                                                                                                          \
+    if (k <= 20) hipLaunchKernelGGL((tgat_attn_backward_kernel<H_, 20>), grid, block, per_wave * waves, st, a); \
+    else hipLaunchKernelGGL((tgat_attn_backward_kernel<H_, 64>), grid, block, per_wave * waves, st, a);          \
+  } while (0)
   switch (H) {
-    case 1: hipLaunchKernelGGL(tgat_attn_backward_kernel<1>, grid, block, per_wave * waves, st, a); break;
-    case 2: hipLaunchKernelGGL(tgat_attn_backward_kernel<2>, grid, block, per_wave * waves, st, a); break;
-    case 4: hipLaunchKernelGGL(tgat_attn_backward_kernel<4>, grid, block, per_wave * waves, st, a); break;
-    default: hipLaunchKernelGGL(tgat_attn_backward_kernel<8>, grid, block, per_wave * waves, st, a); break;
+    case 1: TGMX_ATTN_BWD(1); break;
+    case 2: TGMX_ATTN_BWD(2); break;
+    case 4: hipLaunchKernelGGL((tgat_attn_backward_kernel<4, 64>), grid, block, per_wave * waves, st, a); break;
+    default: hipLaunchKernelGGL((tgat_attn_backward_kernel<8, 64>), grid, block, per_wave * waves, st, a); break;
   }
+#undef TGMX_ATTN_BWD
   TGMX_CHECK_LAUNCH("tgat_attn_backward");
   return TGMX_OK;
 }
