@@ -472,7 +472,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void t
 
     // ---- dqf[h][c] = scale * sum_s ds[h][s] z[s][c];  dz[s][c] = sum_h A dzbar + scale * ds * qf ----
     // one column of one section: the covered slots' values of that column (all loaded first), then the slot loop
-    auto column = [&](auto&& load, int c, bool ok, int col0, int part) __attribute__((always_inline)) {
+    auto column = [&](auto&& load, int c, bool ok, int col0, auto partc) __attribute__((always_inline)) {
+      constexpr int part = decltype(partc)::value;  // 0: neighbor features (gradient flows on: dnbr), 1: edge features (none), 2: time encoding
       const int ce = ok ? c : 0;
       float acc[H], gv[H], qv[H];
 #pragma unroll
@@ -486,6 +487,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void t
       float zs[GS];
 #pragma clang loop unroll(full)
       for (int i = 0; i < GS; ++i) zs[i] = load(sb + i > 0 ? sb + i : 0, ce);
+      // dnbr is ACCUMULATED into: its old values are read here, all at once -- `dnbr[...] += dzs` inside the slot loop is a load the
+      // compiler must order behind the previous slot's store (it cannot prove the rows distinct): GS dependent round trips per column
+      // chunk, 60 per row of a 172-feature layer -- most of that launch's 53 us
+      float dn[part == 0 ? GS : 1];
+      const bool dn_on = part == 0 && lv_dnbr != nullptr;
+      if constexpr (part == 0) {
+#pragma clang loop unroll(full)
+        for (int i = 0; i < GS; ++i) dn[i] = dn_on ? lv_dnbr[(r * k + (sb + i > 0 ? sb + i : 0)) * (long long)d + ce] : 0.f;
+      }
       if (!ok) return;  // (a lane without a column in this chunk: its loads above keep the chunk one block of loads; nothing to store)
 #pragma clang loop unroll(full)
       for (int i = 0; i < GS; ++i) {
@@ -498,30 +508,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void t
             acc[h] = __fmaf_rn(s_ds[h * k + sl], z, acc[h]);
             dzs += s_A[h * k + sl] * gv[h] + a.scale * s_ds[h * k + sl] * qv[h];
           }
-          if (part == 0 && lv_dnbr) lv_dnbr[(r * k + sl) * (long long)d + c] += dzs;
-          if (part == 2) {
+          if constexpr (part == 0) dn[i] += dzs;
+          if constexpr (part == 2) {
             const float g = -sin_t2v(__fmaf_rn(s_dt[sl], tw_c, tb_c)) * dzs;  // d cos(arg) / d arg (the argument the cosine above took)
             dw = __fmaf_rn(g, s_dt[sl], dw);
             db += g;
           }
         }
       }
+      if constexpr (part == 0) {
+        if (dn_on) {
+#pragma clang loop unroll(full)
+          for (int i = 0; i < GS; ++i)
+            if (sb + i >= 0) lv_dnbr[(r * k + sb + i) * (long long)d + c] = dn[i];
+        }
+      }
 #pragma unroll
       for (int h = 0; h < H; ++h) dq[h * Cs + col0 + c] = acc[h] * a.scale;
-      if (part == 2) {
+      if constexpr (part == 2) {
         a.dtime[r * 2LL * T + c] = dw;
         a.dtime[r * 2LL * T + T + c] = db;
       }
     };
-    auto columns = [&](auto&& load, int dim, int col0, int part) {
-      for (int c0 = 0; c0 < dim; c0 += kWave) column(load, c0 + lane, c0 + lane < dim, col0, part);
+    auto columns = [&](auto&& load, int dim, int col0, auto partc) {
+      for (int c0 = 0; c0 < dim; c0 += kWave) column(load, c0 + lane, c0 + lane < dim, col0, partc);
     };
-    columns(dense(nb, d), d, 0, 0);
+    columns(dense(nb, d), d, 0, std::integral_constant<int, 0>{});
     if (D > 0) {
-      if (ex) columns(dense(ex, D), D, d, 1);
-      else columns(by_id, D, d, 1);
+      if (ex) columns(dense(ex, D), D, d, std::integral_constant<int, 1>{});
+      else columns(by_id, D, d, std::integral_constant<int, 1>{});
     }
-    columns(dense(s_cos, T), T, d + D, 2);
+    columns(dense(s_cos, T), T, d + D, std::integral_constant<int, 2>{});
   };
   // (body sizes up to what the heads and the launch's k leave room for: G positions)
   auto run = [&](auto n) __attribute__((always_inline)) {
@@ -666,7 +683,10 @@ static int launch_attn_backward(const AttnBwdArgs& a, int H, tgmx_stream_t strea
   const int k = a.k, T = a.T;
   const long long R = a.R;
   const size_t per_wave = ((size_t)k * T + 2 * (size_t)k + 2 * (size_t)H * k) * sizeof(float);
-  int waves = 4;
+  static const int waves_knob = [] { const char* e = getenv("TGMX_ATTN_BWD_WPB"); const int v = e ? atoi(e) : 0; return (v == 1 || v == 2 || v == 4) ? v : 1; }();
+  // one wave per workgroup: the waves share nothing, and a multi-wave workgroup's wave slots only refill when its SLOWEST row is done
+  // (rows differ 10 x in cost: zero-upstream rows end at once); TGMX_ATTN_BWD_WPB = 2 / 4 is the A/B knob
+  int waves = waves_knob;
   while (waves > 1 && per_wave * waves > 64 * 1024) waves >>= 1;
   TGMX_REQUIRE(per_wave * waves <= 64 * 1024, "tgat_attn_backward: k*T=%d too large for LDS", k * T);
   const dim3 grid((unsigned)((R + waves - 1) / waves)), block(waves * kWave);
