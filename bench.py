@@ -806,9 +806,32 @@ def main():
         def _aggregation():
             out['aggregation'] = aggregation_block(stream, bs, num_nbrs, device, 100, first_timed)
 
+        def _cfg3():
+            # BASELINE cfg 3 (review-shaped stream, TGN memory + TransformerConv embedding, k = [10, 10], bs = 512): the whole per-batch pipeline
+            # -- sampler -> dedup -> edge list -> memory -> embedding -> update_state -- as tools/bench_tgn.py measures it (its own process:
+            # the script owns its graph and modules), with the loader's chain on its own stream beside the model's (DGDataLoader(side_stream=True),
+            # DESIGN.md 3.3c) and on one stream
+            import subprocess
+
+            t_c = time.perf_counter()
+            res = {}
+            for name, env in (('two_streams', {}), ('one_stream', {'TGMX_BENCH_TGN_STREAMS': '0'})):
+                r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'bench_tgn.py'), '300'], env=dict(os.environ, TGMX_BENCH_TGN_NO_LOADER_PASS='1', **env),
+                                   capture_output=True, text=True, timeout=240)
+                line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+                if r.returncode or not line:
+                    raise RuntimeError(f'tools/bench_tgn.py ({name}) failed: {r.stderr[-200:]}')
+                d = json.loads(line[-1])
+                res[name] = {k: d[k] for k in ('pipeline_us_per_batch', 'host_busy_us_per_batch', 'host_waiting_for_the_device_us_per_batch', 'events_per_s',
+                                               'sampled_edges_per_s')}
+            out['pipeline_cfg3'] = {'what': 'BASELINE cfg 3: review-shaped synthetic (N = 350 k, E = 4.8 M, D = 16), TGN memory (Last, GRU, 100) + TransformerConv embedding, '
+                                            'k = [10, 10], bs = 512; 300 batches after 100 of warm-up; tools/bench_tgn.py in its own process on this GPU', **res,
+                                    'seconds_spent': time.perf_counter() - t_c}
+
         guarded('variants', _variants)
         guarded('roofline_hbm_bound', _hbm_bound)
         guarded('aggregation', _aggregation)
+        guarded('pipeline_cfg3', _cfg3)
     if rccl is not None:
         out['rccl'] = rccl
     if real_world > 1:
