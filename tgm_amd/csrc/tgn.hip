@@ -500,19 +500,34 @@ __global__ __launch_bounds__(1024) void tgn_store_batch_kernel(const StoreBatchA
   __syncthreads();
   const long long base = a.base + (long long)role * n;
   if (tid < n) {
-    if (opens) {  // one writer per node: the run's (lo, cnt)
-      int hi = tid + 1;
-      while (hi < n && s_start[hi] == incl) ++hi;
+    // one writer per node: the LAST entry of the run knows both ends (its own position and the run's start) -- the first entry would have
+    // to walk to the end of the run (a hub's run of 50+ entries, read one by one)
+    if (tid == n - 1 || s_id[tid + 1] != id) {
       a.st_lo[role][id] = base + incl;
-      a.st_cnt[role][id] = hi - incl;
+      a.st_cnt[role][id] = tid + 1 - incl;
     }
     a.log_other[base + tid] = oth[pay];
     a.log_t[base + tid] = a.t[pay];
   }
-  // raw rows in sorted order: one element per thread and step (all independent)
-  for (int x = tid; x < n * a.D; x += P) {
-    const int p = x / a.D, c = x - p * a.D;
-    a.log_raw[(base + p) * a.D + c] = a.raw[(long long)s_perm[p] * a.D + c];
+  // raw rows in sorted order: four independent elements per thread and trip, all loaded before the first is stored (the source and
+  // the log may alias as far as the compiler knows: a load behind a store waits for it -- one round trip per element otherwise)
+  const float* __restrict__ raw = a.raw;
+  float* __restrict__ log_raw = a.log_raw;
+  const int total = n * a.D;
+  for (int x0 = 0; x0 < total; x0 += 4 * P) {
+    float v[4];
+    int xs[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int x = x0 + u * P + tid;
+      xs[u] = x;
+      const int xc = x < total ? x : 0;
+      const int p = xc / a.D, c = xc - p * a.D;
+      v[u] = raw[(long long)s_perm[p] * a.D + c];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (xs[u] < total) log_raw[base * a.D + xs[u]] = v[u];
   }
 }
 
