@@ -55,7 +55,8 @@ typedef struct tgmx_adj {
 int tgmx_version(void);
 /* sizeof of the argument structs as this library was compiled (a binding checks its own mirror against it):
  * 0 tgmx_adj_t, 1 tgmx_recency_step_t, 2 tgmx_tgat_layer_t, 3 tgmx_tgat_model_t, 4 tgmx_tgat_hop_t, 5 tgmx_tgat_layout_t,
- * 6 tgmx_pipeline_t, 7 tgmx_pipeline_out_t, 8 tgmx_dropout_t, 9 tgmx_tgn_memory_fwd_t, 10 tgmx_tconv_fwd_t */
+ * 6 tgmx_pipeline_t, 7 tgmx_pipeline_out_t, 8 tgmx_dropout_t, 9 tgmx_tgn_memory_fwd_t, 10 tgmx_tconv_fwd_t, 11 tgmx_pipeline_post_t,
+ * 12 tgmx_tgn_step_t */
 size_t tgmx_abi_sizeof(int32_t which);
 const char* tgmx_last_error(void);
 
@@ -730,6 +731,22 @@ typedef struct tgmx_tconv_fwd {
   int32_t* tgt_count; int64_t* cursor; int64_t* order_big;
 } tgmx_tconv_fwd_t;
 int tgmx_tconv_forward(const tgmx_tconv_fwd_t* args, tgmx_stream_t stream);
+
+/* ABI v7 -- the model side of one TGN batch as ONE call (examples/linkproppred/tgn.py:96-116 in inference order: memory(n_id) ->
+ * GraphAttentionEmbedding -> memory.update_state): tgmx_tgn_memory_forward(mem), tgmx_tconv_forward(conv) with conv->x = mem->out_mem and
+ * conv->last_update_local = mem->out_lu, then update_state with the rows `mem` just produced (TGNMemory.reuse_forward: tgmx_tgn_commit_assoc
+ * over the batch's endpoints, mem->assoc / mem->stamp must be set) and tgmx_tgn_store_batch for the batch's n <= 1024 events.  The same
+ * launches in the same order as the three module calls -- identical results -- issued back to back from C (the host side of a TGN batch
+ * is ~10 us per launch when every launch is its own Python-mediated call). */
+typedef struct tgmx_tgn_step {
+  const tgmx_tgn_memory_fwd_t* mem;
+  const tgmx_tconv_fwd_t* conv;                         /* NULL: no embedding (memory + update only) */
+  const int32_t* src; const int32_t* dst; const int64_t* t; const float* raw; int32_t n;   /* the batch's events; raw [n, mem->D] */
+  float* memory; int64_t* last_update; int32_t* reuse_status;                              /* written by the commit */
+  int64_t log_base; int32_t* log_other; int64_t* log_t; float* log_raw;                    /* message log, rows [log_base, log_base + 2 n) */
+  int64_t* st_lo_s; int32_t* st_cnt_s; int64_t* st_lo_d; int32_t* st_cnt_d;
+} tgmx_tgn_step_t;
+int tgmx_tgn_step(const tgmx_tgn_step_t* args, tgmx_stream_t stream);
 
 /* The sampled edge list of one hop as the reference's TGN loop assembles it from torch ops
  * (examples/linkproppred/tgn.py:80-92): for every valid slot (nbr != -1), in slot order,

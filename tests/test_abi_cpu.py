@@ -76,7 +76,7 @@ def test_struct_mirrors_have_the_library_s_sizes():
     lib = _native.load()
     mirrors = {1: _native.RecencyStep, 2: _native.TgatLayer, 3: _native.TgatModel, 4: _native.TgatHop, 5: _native.TgatLayout,
                6: _native.Pipeline, 7: _native.PipelineOut, 8: _native.Dropout, 9: _native.TgnMemoryFwd,
-               10: _native.TconvFwd, 11: _native.PipelinePost}
+               10: _native.TconvFwd, 11: _native.PipelinePost, 12: _native.TgnStep}
     assert lib.tgmx_abi_sizeof(0) == 16
     for which, cls in mirrors.items():
         assert lib.tgmx_abi_sizeof(which) == ctypes.sizeof(cls), cls.__name__

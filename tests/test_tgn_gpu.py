@@ -322,3 +322,63 @@ def test_group_ids_large_matches_torch(n):
     _native.check(lib.tgmx_group_ids_large(ids.data_ptr(), n, None, None, None, None, first.data_ptr(), ws.data_ptr(), ws.numel(), _native.stream_ptr()),
                   'tgmx_group_ids_large')
     assert torch.equal(first, ref_first)
+
+
+@pytest.mark.parametrize('aggr', ['last', 'mean'])
+def test_tgn_step_equals_the_three_module_calls(aggr):
+    """TGNStep (tgmx_tgn_step: memory look-ahead -> embedding -> update_state as ONE native call) against memory(n_id), embedding(...),
+    memory.update_state(...) on twin modules: z, last_update, z2 of every batch and the final memory / last_update tables equal BIT FOR BIT
+    over 40 batches of a review-shaped stream, with a small message log so that compactions fall at different points of the sequence
+    (before the forward here, between commit and store there), and the fallback (an evaluation-mode memory) gives the module path's results."""
+    from tgm_amd import DGData, DGDataLoader, DGraph
+    from tgm_amd.hooks import DeduplicationHook, HookManager, RandomNegativeEdgeSamplerHook, RecencyNeighborHook, SampledEdgeListHook
+    from tgm_amd.nn import GraphAttentionEmbedding, IdentityMessage, LastAggregator, MeanAggregator, TGNMemory, TGNStep
+    from tgm_amd.synth import make_stream
+
+    st = make_stream('review', seed=11, num_edges=40 * 256, n_src=1500, n_dst=200)
+    N, D, M, T_, bs = st.num_nodes, 16, 100, 100, 256
+
+    def build():
+        torch.manual_seed(3)
+        mem = TGNMemory(N, D, M, T_, IdentityMessage(D, M, T_), LastAggregator() if aggr == 'last' else MeanAggregator()).to(DEV).train()
+        mem.reuse_forward = True
+        mem._log_cap_min = 1500  # (a batch stores 512 rows: a compaction every few batches)
+        enc = GraphAttentionEmbedding(M, 100, D, mem.time_enc).to(DEV).eval()
+        return mem, enc
+
+    def loader():
+        dg = DGraph(DGData.from_raw(st.ts, torch.stack([st.src, st.dst], 1), st.edge_x), device=DEV)
+        hm = HookManager(keys=['k'])
+        hm.register('k', RandomNegativeEdgeSamplerHook(1500, N, seed=4))
+        hm.register('k', RecencyNeighborHook(N, [10], ['edge_src', 'edge_dst', 'neg'], ['edge_time', 'edge_time', 'neg_time'], validate='deferred',
+                                             edge_features='by_id'))
+        hm.register('k', DeduplicationHook(seed_nodes_keys=['neg', 'nbr_nids']))
+        hm.register('k', SampledEdgeListHook(hop=0))
+        return hm, DGDataLoader(dg, batch_size=bs, hook_manager=hm)
+
+    (mem_a, enc_a), (mem_b, enc_b) = build(), build()
+    step = TGNStep(mem_b, enc_b)
+    hm, ld = loader()
+    with hm.activate('k'), torch.no_grad():
+        for b, batch in enumerate(ld):
+            z, lu = mem_a(batch.unique_nids)
+            z2 = enc_a(z, lu, batch.sampled_edge_index, batch.sampled_edge_time, batch.sampled_edge_x)
+            mem_a.update_state(batch.edge_src, batch.edge_dst, batch.edge_time, batch.edge_x)
+            y2, y, ylu = step.batch(batch)
+            assert torch.equal(z, y) and torch.equal(lu, ylu) and torch.equal(z2, y2), f'batch {b}'
+        mem_a.check()
+        mem_b.check()
+    # (the stream's first batch samples no neighbour yet: an empty edge list takes the module calls)
+    assert step.fast_calls + step.fallback_calls == 40 and step.fast_calls >= 38
+    assert torch.equal(mem_a.memory, mem_b.memory) and torch.equal(mem_a.last_update, mem_b.last_update)
+    # the fallback: evaluation mode takes the three module calls
+    mem_a.eval(), mem_b.eval()
+    hm, ld = loader()
+    with hm.activate('k'), torch.no_grad():
+        batch = next(iter(ld))
+        z, lu = mem_a(batch.unique_nids)
+        z2 = enc_a(z, lu, batch.sampled_edge_index, batch.sampled_edge_time, batch.sampled_edge_x)
+        mem_a.update_state(batch.edge_src, batch.edge_dst, batch.edge_time, batch.edge_x)
+        y2, y, ylu = step.batch(batch)
+    assert step.fast_calls + step.fallback_calls == 41 and torch.equal(z2, y2) and torch.equal(mem_a.memory, mem_b.memory)
+

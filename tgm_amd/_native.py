@@ -205,6 +205,18 @@ class TgnMemoryFwd(ctypes.Structure):
     ]  # fmt: skip
 
 
+class TgnStep(ctypes.Structure):
+    """tgmx_tgn_step_t (include/tgm_amd.h)."""
+
+    _fields_ = [
+        ('mem', c_void_p), ('conv', c_void_p),
+        ('src', c_void_p), ('dst', c_void_p), ('t', c_void_p), ('raw', c_void_p), ('n', c_int32),
+        ('memory', c_void_p), ('last_update', c_void_p), ('reuse_status', c_void_p),
+        ('log_base', c_int64), ('log_other', c_void_p), ('log_t', c_void_p), ('log_raw', c_void_p),
+        ('st_lo_s', c_void_p), ('st_cnt_s', c_void_p), ('st_lo_d', c_void_p), ('st_cnt_d', c_void_p),
+    ]  # fmt: skip
+
+
 class TconvFwd(ctypes.Structure):
     """tgmx_tconv_fwd_t (include/tgm_amd.h)."""
 
@@ -279,6 +291,7 @@ SIGNATURES['tgmx_discretize_workspace_bytes'] = (c_size_t, [c_int64])
 SIGNATURES['tgmx_discretize_keep'] = (c_int32, [_P, _P, _P, c_int64, ctypes.c_double, _P, _P, _P, _P, c_size_t, _P])
 SIGNATURES['tgmx_tgn_memory_forward'] = (c_int32, [ctypes.POINTER(TgnMemoryFwd), _P])
 SIGNATURES['tgmx_tconv_forward'] = (c_int32, [ctypes.POINTER(TconvFwd), _P])
+SIGNATURES['tgmx_tgn_step'] = (c_int32, [ctypes.POINTER(TgnStep), _P])
 SIGNATURES['tgmx_segment_sort_workspace_bytes'] = (c_size_t, [c_int64])
 SIGNATURES['tgmx_segment_sort'] = (c_int32, [_P, c_int64, c_int32, _P, _P, _P, _P, c_size_t, _P, _P])
 SIGNATURES['tgmx_tgat_tile16_floats'] = (c_size_t, [c_int32, c_int32])

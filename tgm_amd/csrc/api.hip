@@ -31,6 +31,7 @@ extern "C" size_t tgmx_abi_sizeof(int32_t which) {
     case 9: return sizeof(tgmx_tgn_memory_fwd_t);
     case 10: return sizeof(tgmx_tconv_fwd_t);
     case 11: return sizeof(tgmx_pipeline_post_t);
+    case 12: return sizeof(tgmx_tgn_step_t);
     default: return 0;
   }
 }

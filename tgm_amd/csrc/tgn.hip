@@ -1079,3 +1079,20 @@ extern "C" int tgmx_tconv_forward(const tgmx_tconv_fwd_t* a, tgmx_stream_t strea
   return tgmx_tconv_attend(a->qkvs, a->qkvs + U * HC, a->qkvs + 2 * U * HC, a->eproj, a->order, a->src, a->seg_lo, a->seg_hi, U, a->H, a->C,
                            1.0f / sqrtf((float)a->C), out, nullptr, stream);
 }
+
+// the model side of one TGN batch: memory forward -> embedding -> update_state (commit of the rows just computed + the batch's store)
+extern "C" int tgmx_tgn_step(const tgmx_tgn_step_t* a, tgmx_stream_t stream) {
+  TGMX_REQUIRE(a && a->mem, "tgn_step: null argument block");
+  const tgmx_tgn_memory_fwd_t* m = a->mem;
+  TGMX_REQUIRE(a->n >= 0 && a->n <= 1024, "tgn_step: n=%d (at most 1024 events per call)", a->n);
+  TGMX_REQUIRE(m->assoc && a->memory && a->last_update && a->reuse_status, "tgn_step: the commit needs mem->assoc / memory / last_update / reuse_status");
+  int rc = tgmx_tgn_memory_forward(m, stream);
+  if (rc) return rc;
+  if (a->conv && (rc = tgmx_tconv_forward(a->conv, stream))) return rc;
+  if (a->n == 0) return TGMX_OK;
+  if ((rc = tgmx_tgn_commit_assoc(a->src, a->dst, a->n, m->assoc, m->stamp, m->out_mem, m->out_lu, m->M, m->num_nodes, a->memory, a->last_update,
+                                  a->reuse_status, stream)))
+    return rc;
+  return tgmx_tgn_store_batch(a->src, a->dst, a->t, a->raw, m->D, a->n, a->log_base, a->log_other, a->log_t, a->log_raw, a->st_lo_s, a->st_cnt_s,
+                              a->st_lo_d, a->st_cnt_d, stream);
+}

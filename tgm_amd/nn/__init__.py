@@ -3,10 +3,10 @@ from .attention import TemporalAttention
 from .base import EncoderModule
 from .tgat import TGAT, MergeLayer
 from .tgcn import TGCN, GCNConv
-from .tgn import GraphAttentionEmbedding, IdentityMessage, LastAggregator, MeanAggregator, TGNMemory, TransformerConv, sampled_edge_list
+from .tgn import GraphAttentionEmbedding, IdentityMessage, LastAggregator, MeanAggregator, TGNMemory, TGNStep, TransformerConv, sampled_edge_list
 from .time_encoding import Time2Vec
 
 __all__ = [
     'EncoderModule', 'GCNConv', 'GraphAttentionEmbedding', 'IdentityMessage', 'LastAggregator', 'MeanAggregator', 'MergeLayer', 'TGAT', 'TGCN',
-    'TGNMemory', 'TemporalAttention', 'Time2Vec', 'TransformerConv', 'invalidate_parameter_caches', 'sampled_edge_list',
+    'TGNMemory', 'TGNStep', 'TemporalAttention', 'Time2Vec', 'TransformerConv', 'invalidate_parameter_caches', 'sampled_edge_list',
 ]  # fmt: skip

@@ -18,6 +18,7 @@ unspecified there; here it is the earlier edge of the batch.
 from __future__ import annotations
 
 import copy
+import ctypes
 import os
 from typing import Callable, Optional, Tuple
 
@@ -660,3 +661,143 @@ class GraphAttentionEmbedding(nn.Module):
             'tgmx_tconv_edge_attr',
         )  # fmt: skip
         return self.conv(x, edge_index, edge_attr)
+
+
+class TGNStep:
+    """The model side of one TGN batch as ONE native call (``tgmx_tgn_step``), for the inference / evaluation loop of
+    examples/linkproppred/tgn.py:96-116::
+
+        z, last_update = memory(n_id)                                  # train-mode look-ahead (tgn.py:157-163)
+        z2 = embedding(z, last_update, edge_index, edge_t, edge_x)     # GraphAttentionEmbedding (tgn.py:14-40)
+        memory.update_state(src, dst, t, raw_msg)                      # tgn.py:165-177
+
+    ``step(n_id, edge_index, edge_t, edge_x, src, dst, t, raw_msg)`` returns ``(z2, z, last_update)`` -- the same launches in the same order
+    with the same arguments as the three module calls (identical results, ``tests/test_tgn_gpu.py``), issued back to back from C with
+    one pass of argument marshalling instead of three: a cfg 3 batch is ~11 launches on the model side and the host pays ~10 us for each
+    when every module call is its own Python-mediated sequence.  The fast path needs what the fast paths of the modules need -- no
+    autograd, ``memory.training`` with ``memory.reuse_forward``, no attention dropout, 0 < n <= 1024 events, one process (no sharded
+    commit) -- and falls back to the three calls otherwise.  ``step.batch(batch)`` takes the attributes of a TGN loader batch
+    (``unique_nids``, ``sampled_edge_*`` from ``SampledEdgeListHook``, the batch's edges)."""
+
+    def __init__(self, memory: 'TGNMemory', embedding: 'GraphAttentionEmbedding') -> None:
+        self.memory, self.embedding = memory, embedding
+        self._args = _native.TgnStep()
+        self._ws = self._fl = self._ints = None
+        self._wkey = None
+        self.fast_calls = self.fallback_calls = 0
+
+    def batch(self, batch):
+        return self(batch.unique_nids, batch.sampled_edge_index, batch.sampled_edge_time, batch.sampled_edge_x, batch.edge_src, batch.edge_dst,
+                    batch.edge_time, batch.edge_x)
+
+    def _eligible(self, n_id: Tensor, edge_index: Tensor, src: Tensor, raw_msg: Optional[Tensor]) -> bool:
+        mem, conv = self.memory, self.embedding.conv
+        n = src.numel()
+        return (not torch.is_grad_enabled() and not _COMPOSE_IN_PYTHON and mem.training and mem.reuse_forward and n_id.is_cuda and n_id.numel() > 0
+                and 0 < n <= 1024 and edge_index.shape[1] > 0 and not (conv.training and conv.dropout > 0) and not mem._sharded(2 * n)
+                and (raw_msg is not None or mem.raw_msg_dim == 0))
+
+    @staticmethod
+    def _grow(buf: Optional[Tensor], numel: int, dtype, dev) -> Tensor:
+        if buf is None or buf.numel() < numel or buf.device != dev or buf.dtype != dtype:
+            buf = torch.empty(max(numel + numel // 4, 1), dtype=dtype, device=dev)
+        return buf
+
+    def __call__(self, n_id: Tensor, edge_index: Tensor, edge_t: Tensor, edge_x: Tensor, src: Tensor, dst: Tensor, t: Tensor,
+                 raw_msg: Optional[Tensor]) -> Tuple[Tensor, Tensor, Tensor]:
+        mem, emb = self.memory, self.embedding
+        if not self._eligible(n_id, edge_index, src, raw_msg):
+            self.fallback_calls += 1
+            z, lu = mem(n_id)
+            z2 = emb(z, lu, edge_index, edge_t, edge_x)
+            mem.update_state(src, dst, t, raw_msg)
+            return z2, z, lu
+        self.fast_calls += 1
+        conv = emb.conv
+        dev = n_id.device
+        i32c = lambda v: v if (v.dtype == torch.int32 and v.is_contiguous()) else v.to(torch.int32).contiguous()
+        i64c = lambda v: v if (v.dtype == torch.int64 and v.is_contiguous()) else v.to(torch.int64).contiguous()
+        f32c = lambda v: v if (v.dtype == torch.float32 and v.is_contiguous()) else v.float().contiguous()
+        nodes, src32, dst32, t64 = i32c(n_id), i32c(src), i32c(dst), i64c(t)
+        raw = f32c(raw_msg) if mem.raw_msg_dim else None
+        n, R = src32.numel(), nodes.numel()
+        M, D, T = mem.memory_dim, mem.raw_msg_dim, mem.time_dim
+        W = 2 * M + D + T
+        # ---- TGNMemory.forward (train mode, reuse_forward): the look-ahead rows + the node -> row association --------------------------
+        mem._ensure_store(2 * n)  # (a compaction, if one is due, runs now: the log's pointers are final below)
+        if mem._assoc64 is None or mem._assoc64.device != dev:
+            mem._assoc64 = torch.zeros(mem.num_nodes, dtype=torch.int64, device=dev)
+            mem._reuse_status = torch.zeros(1, dtype=torch.int32, device=dev)
+        mem._stamp += 1
+        ws = self._ws = self._grow(self._ws, R * (W + 7 * M), torch.float32, dev)
+        z = torch.empty((R, M), dtype=torch.float32, device=dev)
+        lu = torch.empty(R, dtype=torch.int64, device=dev)
+        a = mem._fwd_args
+        if a is None:
+            a = mem._fwd_args = _native.TgnMemoryFwd()
+        wkey = (param_key(mem), param_key(emb))
+        if self._wkey != wkey:  # the weights' addresses (and the stacked projections) only move with the parameters
+            gru = mem.memory_updater
+            self._w = (mem.time_enc.w.weight.detach().reshape(-1), mem.time_enc.w.bias.detach(), gru.weight_ih.detach(), gru.bias_ih.detach(),
+                       gru.weight_hh.detach(), gru.bias_hh.detach(), emb.time_enc.w.weight.detach().reshape(-1), emb.time_enc.w.bias.detach(),
+                       conv.lin_edge.weight.detach()) + conv._stacked_projections()
+            self._wkey = wkey
+        tw, tb, W_ih, b_ih, W_hh, b_hh, etw, etb, W_edge, W4, b4 = self._w
+        base = ws.data_ptr()
+        a.nodes, a.R, a.memory, a.last_update, a.M, a.num_nodes = nodes.data_ptr(), R, mem.memory.data_ptr(), mem.last_update.data_ptr(), M, mem.num_nodes
+        a.st_lo_s, a.st_cnt_s, a.st_lo_d, a.st_cnt_d = (mem._st_lo[0].data_ptr(), mem._st_cnt[0].data_ptr(), mem._st_lo[1].data_ptr(),
+                                                        mem._st_cnt[1].data_ptr())  # fmt: skip
+        a.log_other, a.log_t, a.log_raw, a.D = mem._log_other.data_ptr(), mem._log_t.data_ptr(), mem._log_raw.data_ptr(), D
+        a.tw, a.tb, a.T, a.mean = tw.data_ptr(), tb.data_ptr(), T, mem.aggr_module.mean
+        a.W_ih, a.b_ih, a.W_hh, a.b_hh = W_ih.data_ptr(), b_ih.data_ptr(), W_hh.data_ptr(), b_hh.data_ptr()
+        a.ws_aggr, a.ws_h, a.ws_gi, a.ws_gh = base, base + 4 * R * W, base + 4 * R * (W + M), base + 4 * R * (W + 4 * M)
+        a.out_mem, a.out_lu, a.assoc, a.stamp = z.data_ptr(), lu.data_ptr(), mem._assoc64.data_ptr(), mem._stamp
+        # ---- GraphAttentionEmbedding.forward: edge encoding + TransformerConv (inference) ---------------------------------------------
+        U, H, C = R, conv.heads, conv.out_channels
+        HC = H * C
+        ei = i64c(edge_index) if edge_index.dtype != torch.int64 else edge_index
+        E = ei.shape[1]
+        src_e, tgt_e = ei[0], ei[1]
+        if not src_e.is_contiguous():
+            src_e = src_e.contiguous()
+        if not tgt_e.is_contiguous():
+            tgt_e = tgt_e.contiguous()
+        et64, msg = i64c(edge_t), f32c(edge_x)
+        De, Te = msg.shape[1], emb.time_enc.time_dim
+        qkvs = torch.empty((4, U, HC), dtype=torch.float32, device=dev)
+        lib = _native.load()
+        need = int(lib.tgmx_segment_sort_workspace_bytes(E))
+        wsd = getattr(conv, '_seg_ws', None)
+        if wsd is None or wsd[0].device != dev or wsd[0].numel() < need:
+            wsd = conv._seg_ws = (torch.empty(need, dtype=torch.uint8, device=dev), torch.zeros(1, dtype=torch.int32, device=dev))
+        Ep, Up = E + (E & 1), U + (U & 1)
+        fl = self._fl = self._grow(self._fl, E * (Te + De + HC), torch.float32, dev)
+        ints = self._ints = self._grow(self._ints, 2 * Ep + 3 * Up, torch.int64, dev)
+        cnt = getattr(conv, '_tgt_count', None)
+        if cnt is None or cnt.device != dev or cnt.numel() < U:
+            cnt = conv._tgt_count = torch.zeros(max(2 * U, 1 << 14), dtype=torch.int32, device=dev)
+        c = getattr(conv, '_fwd_args', None)
+        if c is None:
+            c = conv._fwd_args = _native.TconvFwd()
+        c.x, c.U, c.in_ch, c.last_update_local = z.data_ptr(), U, M, lu.data_ptr()
+        c.src, c.tgt, c.t, c.msg, c.E, c.D, c.T = src_e.data_ptr(), tgt_e.data_ptr(), et64.data_ptr(), msg.data_ptr(), E, De, Te
+        c.tw, c.tb, c.W4, c.b4, c.W_edge, c.H, c.C = etw.data_ptr(), etb.data_ptr(), W4.data_ptr(), b4.data_ptr(), W_edge.data_ptr(), H, C
+        flp, ip = fl.data_ptr(), ints.data_ptr()
+        c.edge_attr, c.qkvs, c.eproj = flp, qkvs.data_ptr(), flp + 4 * E * (Te + De)
+        c.order, c.seg_lo, c.seg_hi = ip, ip + 8 * Ep, ip + 8 * (Ep + Up)
+        c.sort_ws, c.sort_ws_bytes, c.status = wsd[0].data_ptr(), wsd[0].numel(), wsd[1].data_ptr()
+        c.tgt_count, c.cursor, c.order_big = cnt.data_ptr(), ip + 8 * (Ep + 2 * Up), ip + 8 * (Ep + 3 * Up)
+        # ---- update_state (reuse_forward): commit the rows above for the batch's endpoints, store the batch ----------------------------
+        s = self._args
+        s.mem, s.conv = ctypes.addressof(a), ctypes.addressof(c)
+        s.src, s.dst, s.t, s.raw, s.n = src32.data_ptr(), dst32.data_ptr(), t64.data_ptr(), _native.ptr(raw), n
+        s.memory, s.last_update, s.reuse_status = a.memory, a.last_update, mem._reuse_status.data_ptr()
+        s.log_base, s.log_other, s.log_t, s.log_raw = mem._log_len, a.log_other, a.log_t, a.log_raw
+        s.st_lo_s, s.st_cnt_s, s.st_lo_d, s.st_cnt_d = a.st_lo_s, a.st_cnt_s, a.st_lo_d, a.st_cnt_d
+        _native.check(lib.tgmx_tgn_step(s, _native.stream_ptr()), 'tgmx_tgn_step')
+        # what the three calls leave behind: two state mutations (commit, store), the log grown by both roles' entries, no pending forward
+        mem._version += 2
+        mem._log_len += 2 * n
+        mem._fwd = None
+        conv._edge_ctx = None
+        return qkvs[3], z, lu

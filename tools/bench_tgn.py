@@ -86,7 +86,16 @@ def two_stream_batches(lo, hi):
         yield b0._finalize()
 
 
+_tgn_step = None
+if fast and os.environ.get('TGMX_BENCH_TGN_STEP', '1') != '0':  # the model side of a batch as ONE native call (tgm_amd.nn.TGNStep)
+    from tgm_amd.nn import TGNStep  # noqa: E402
+
+    _tgn_step = TGNStep(mem, enc)
+
+
 def step(batch):
+    if _tgn_step is not None:
+        return _tgn_step.batch(batch)[0], batch
     if fast:
         z, lu = mem(batch.unique_nids)
         z2 = enc(z, lu, batch.sampled_edge_index, batch.sampled_edge_time, batch.sampled_edge_x)
