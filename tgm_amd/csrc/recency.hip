@@ -2829,7 +2829,11 @@ static bool plan_fuse01(const tgmx_recency_step_t* s, long long S0) {
   // static index: a hop-1 wave would repeat hop 0's two prefix searches (dependent reads); that only pays when its own
   // gather is long (comment-shaped, D = 16: 26.9 -> 19.2 G sampled-edges/s fused; wiki-shaped, D = 172: 4.8 -> 5.1)
   if (s->indptr != nullptr && (long long)s->k[1] * s->D * 4 < 4096) return false;
-  if (s->indptr == nullptr) {  // streaming rings: the packed kernel takes narrow hop-1 rows
+  // edge features BY ID (out_eid set, no out_x): no feature row is copied, the packed narrow-row kernel does not apply (it does not
+  // publish edge ids) and the two hops would be two wave-per-seed launches of ~12 us each at the review shape: one launch instead
+  static const bool fuse_by_id = !(getenv("TGMX_FUSE_BY_ID") && atoi(getenv("TGMX_FUSE_BY_ID")) == 0);  // A/B knob
+  const bool by_id = s->out_eid[1] != nullptr && s->out_x[1] == nullptr;
+  if (s->indptr == nullptr && !(by_id && fuse_by_id)) {  // streaming rings: the packed kernel takes narrow hop-1 rows
     LookupArgs a{};
     a.B = s->B; a.D = s->D; a.edge_x = s->ring_x; a.out_x = s->out_x[0];
     if (prepare_lookup(a, s->out_x[1], s->k[1]) < 0) return false;

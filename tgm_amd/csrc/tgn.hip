@@ -1009,23 +1009,32 @@ extern "C" int tgmx_tgn_compact(int64_t* st_lo_s, const int32_t* st_cnt_s, int64
 // ---- one call per module forward (inference / no-grad paths): the launches of TGNMemory's look-ahead and of
 // GraphAttentionEmbedding as C++ sequences -- the same entry points, in the same order, as tgm_amd/nn/tgn.py composes
 // them one ctypes call at a time (a Python-mediated launch costs the host ~8 us, a C++ one ~4; cfg 3 is host-bound).
-extern "C" int tgmx_tgn_memory_forward(const tgmx_tgn_memory_fwd_t* a, tgmx_stream_t stream) {
-  TGMX_REQUIRE(a, "tgn_memory_forward: null argument block");
+static int memory_forward_aggregate(const tgmx_tgn_memory_fwd_t* a, tgmx_stream_t stream) {
   const int64_t R = a->R;
-  if (R == 0) return TGMX_OK;
-  const int M = a->M, W = 2 * a->M + a->D + a->T;
+  const int M = a->M;
   TGMX_REQUIRE(a->ws_aggr && a->ws_h && a->ws_gi && a->ws_gh && a->out_mem && a->out_lu && a->W_ih && a->W_hh, "tgn_memory_forward: null pointer");
   // (the aggregation's launch also writes the hidden-state rows h = memory[nodes]: one launch less than a separate gather)
-  int rc = tgn_aggregate_impl(a->nodes, R, a->memory, a->last_update, M, a->num_nodes, a->st_lo_s, a->st_cnt_s, a->st_lo_d, a->st_cnt_d,
-                              a->log_other, a->log_t, a->log_raw, a->D, a->tw, a->tb, a->T, a->mean, a->ws_aggr, a->out_lu, a->assoc, a->stamp,
-                              a->ws_h, stream);
-  if (rc) return rc;
+  return tgn_aggregate_impl(a->nodes, R, a->memory, a->last_update, M, a->num_nodes, a->st_lo_s, a->st_cnt_s, a->st_lo_d, a->st_cnt_d,
+                            a->log_other, a->log_t, a->log_raw, a->D, a->tw, a->tb, a->T, a->mean, a->ws_aggr, a->out_lu, a->assoc, a->stamp,
+                            a->ws_h, stream);
+}
+
+static int memory_forward_gru(const tgmx_tgn_memory_fwd_t* a, tgmx_stream_t stream) {
+  const int64_t R = a->R;
+  const int M = a->M, W = 2 * a->M + a->D + a->T;
   // GRUCell: gi = aggr W_ih^T + b_ih, gh = h W_hh^T + b_hh, gates
-  // (one launch for the two: they share nothing but the stream, and neither fills the chip)
+  // (one launch for the two: they share nothing but the stream)
   const GemmCall gi{a->ws_aggr, W, a->W_ih, W, a->ws_gi, 3 * M, R, 3 * M, W, a->b_ih, 0, 1, 0, 0, 0};
   const GemmCall gh{a->ws_h, M, a->W_hh, M, a->ws_gh, 3 * M, R, 3 * M, M, a->b_hh, 0, 1, 0, 0, 0};
-  if ((rc = tgmx_internal_sgemm_nt_pair(gi, gh, stream))) return rc;
+  if (int rc = tgmx_internal_sgemm_nt_pair(gi, gh, stream)) return rc;
   return tgmx_tgn_gru_gate(a->ws_gi, a->ws_gh, a->ws_h, M, R, a->out_mem, stream);
+}
+
+extern "C" int tgmx_tgn_memory_forward(const tgmx_tgn_memory_fwd_t* a, tgmx_stream_t stream) {
+  TGMX_REQUIRE(a, "tgn_memory_forward: null argument block");
+  if (a->R == 0) return TGMX_OK;
+  if (int rc = memory_forward_aggregate(a, stream)) return rc;
+  return memory_forward_gru(a, stream);
 }
 
 extern "C" int tgmx_tconv_forward(const tgmx_tconv_fwd_t* a, tgmx_stream_t stream) {
@@ -1081,14 +1090,91 @@ extern "C" int tgmx_tconv_forward(const tgmx_tconv_fwd_t* a, tgmx_stream_t strea
 }
 
 // the model side of one TGN batch: memory forward -> embedding -> update_state (commit of the rows just computed + the batch's store)
+namespace {
+struct StepSide {  // a stream + two events of the library's own, per calling thread: the edge-side chain of a step runs beside the node-side chain
+  hipStream_t stream = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  int device = -1;
+};
+StepSide* step_side() {
+  static thread_local StepSide s;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  if (s.stream && s.device == dev) return &s;
+  if (s.stream) return nullptr;  // (one device per thread: anything else keeps the single-stream order)
+  if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) {
+    s.stream = nullptr;
+    return nullptr;
+  }
+  if (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess) {
+    s.stream = nullptr;
+    return nullptr;
+  }
+  s.device = dev;
+  return &s;
+}
+}  // namespace
+
 extern "C" int tgmx_tgn_step(const tgmx_tgn_step_t* a, tgmx_stream_t stream) {
   TGMX_REQUIRE(a && a->mem, "tgn_step: null argument block");
   const tgmx_tgn_memory_fwd_t* m = a->mem;
   TGMX_REQUIRE(a->n >= 0 && a->n <= 1024, "tgn_step: n=%d (at most 1024 events per call)", a->n);
   TGMX_REQUIRE(m->assoc && a->memory && a->last_update && a->reuse_status, "tgn_step: the commit needs mem->assoc / memory / last_update / reuse_status");
-  int rc = tgmx_tgn_memory_forward(m, stream);
-  if (rc) return rc;
-  if (a->conv && (rc = tgmx_tconv_forward(a->conv, stream))) return rc;
+  int rc = TGMX_OK;
+  const tgmx_tconv_fwd_t* c = a->conv;
+  // Two chains hang off the aggregation: the NODE side (GRU GEMMs, gates, the q / k / v / skip projections of the new memory rows) and the
+  // EDGE side (edge encoding from the new last_update rows, the grouping by target, the edge projection).  They meet at the attention.
+  // The edge side -- four small launches, ~27 us -- runs on a stream of the library's own beside the node side's two GEMM launches; one
+  // fork and one join event per step.  (Round 4 measured this with the host as the bottleneck and lost; with the step issued from C and
+  // the loader on its own stream the host has ~65 us of slack per batch.)  TGMX_TGN_STEP_OVERLAP=0: everything on the caller's stream.
+  static const bool overlap_knob = [] { const char* e = getenv("TGMX_TGN_STEP_OVERLAP"); return !(e && e[0] == '0'); }();
+  const char* knob = getenv("TGMX_TCONV_COUNTING");
+  const bool counting = c && c->E > 0 && c->U > 0 && c->tgt_count && c->cursor && c->order_big && !(knob && atoi(knob) == 0);
+  StepSide* side = (overlap_knob && counting && m->R > 0) ? step_side() : nullptr;
+  if (!side) {
+    if ((rc = tgmx_tgn_memory_forward(m, stream))) return rc;
+    if (c && (rc = tgmx_tconv_forward(c, stream))) return rc;
+  } else {
+    hipStream_t st = (hipStream_t)stream, ss = side->stream;
+    const int64_t U = c->U, E = c->E;
+    const int HC = c->H * c->C, Wd = c->T + c->D;
+    TGMX_REQUIRE(c->x && c->W4 && c->b4 && c->qkvs && c->src && c->tgt && c->t && c->edge_attr && c->eproj && c->order && c->seg_lo && c->seg_hi && c->status,
+                 "tgn_step: null pointer in the embedding's argument block");
+    if ((rc = memory_forward_aggregate(m, stream))) return rc;
+    if (hipEventRecord(side->fork, st) != hipSuccess || hipStreamWaitEvent(ss, side->fork, 0) != hipSuccess) {
+      set_error("tgn_step: fork failed");
+      return TGMX_E_LAUNCH;
+    }
+    // ---- edge side, on the library's stream ----
+    long long blocks = (E * Wd + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(tconv_edge_attr_kernel, dim3((unsigned)blocks), dim3(256), 0, ss, c->last_update_local, c->src, c->t, c->msg, c->tw, c->tb, c->T,
+                       c->D, (long long)E, c->edge_attr, c->tgt, c->tgt_count, (long long)U, c->status);
+    hipLaunchKernelGGL(tconv_group_scan_kernel, dim3(1), dim3(1024), 0, ss, c->tgt_count, (long long)U, c->seg_lo, c->seg_hi, c->cursor);
+    hipLaunchKernelGGL(tconv_group_place_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, ss, c->tgt, (long long)E, (long long)U, c->cursor,
+                       c->order);
+    TGMX_CHECK_LAUNCH("tgn_step(grouping)");
+    if ((rc = tgmx_sgemm_nt(c->edge_attr, Wd, c->W_edge, Wd, c->eproj, HC, E, HC, Wd, nullptr, 0, 1, 0, 0, 0, (tgmx_stream_t)ss))) return rc;
+    if (hipEventRecord(side->join, ss) != hipSuccess) {
+      set_error("tgn_step: join record failed");
+      return TGMX_E_LAUNCH;
+    }
+    // ---- node side, on the caller's stream ----
+    if ((rc = memory_forward_gru(m, stream))) return rc;
+    if ((rc = tgmx_sgemm_nt(c->x, c->in_ch, c->W4, c->in_ch, c->qkvs, HC, U, HC, c->in_ch, c->b4, 0, 4, 0, (int64_t)HC * c->in_ch, U * HC, stream))) return rc;
+    if (hipStreamWaitEvent(st, side->join, 0) != hipSuccess) {
+      set_error("tgn_step: join failed");
+      return TGMX_E_LAUNCH;
+    }
+    float* out = c->qkvs + 3 * U * HC;
+    TconvArgs t{c->qkvs, c->qkvs + U * HC, c->qkvs + 2 * U * HC, c->eproj, c->order, c->src, c->seg_lo, c->seg_hi, out, U, c->H, c->C,
+                1.0f / sqrtf((float)c->C)};
+    t.drop = make_dropout(nullptr);
+    t.unsorted = 1;
+    t.order_big = c->order_big;
+    hipLaunchKernelGGL(tconv_attend_kernel, dim3((unsigned)U), dim3(256), 0, st, t);
+    TGMX_CHECK_LAUNCH("tgn_step(attend)");
+  }
   if (a->n == 0) return TGMX_OK;
   if ((rc = tgmx_tgn_commit_assoc(a->src, a->dst, a->n, m->assoc, m->stamp, m->out_mem, m->out_lu, m->M, m->num_nodes, a->memory, a->last_update,
                                   a->reuse_status, stream)))
