@@ -121,7 +121,8 @@ def cpu_baseline(stream, bs, num_nbrs, n_batches, seed, first_batch):
     g = torch.Generator().manual_seed(seed)
     lo_dst = int(dst.min())
     E = src.numel()
-    all_threads = torch.get_num_threads()
+    restore_threads = torch.get_num_threads()
+    all_threads = os.cpu_count() or restore_threads  # (main() pins the process to 16 torch threads; this leg tries up to 64)
     b = first_batch
     results = {}
     t_all = 0.0
@@ -160,7 +161,7 @@ def cpu_baseline(stream, bs, num_nbrs, n_batches, seed, first_batch):
                 results[threads] = (slots / t_total, 1e3 * t_total / done, done)
                 t_all += t_total
     finally:
-        torch.set_num_threads(all_threads)
+        torch.set_num_threads(restore_threads)
     best = max(results, key=lambda t: results[t][0])
     return dict(
         value=results[best][0],
@@ -502,6 +503,9 @@ def main():
     from tgm_amd.dist import init_process_group
     from tgm_amd.synth import make_stream
 
+    # host-side tensor work of this process (stream generation, DGData's checks) on 16 threads: torch's default is every core, and on a SHARED
+    # 256-core host the OpenMP barriers of small ops under oversubscription made single runs take a minute longer than others
+    torch.set_num_threads(min(16, torch.get_num_threads()))
     rank, world, local = init_process_group()
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     real_world = world

@@ -16,6 +16,7 @@ from tgm_amd.hooks import DeduplicationHook, HookManager, RandomNegativeEdgeSamp
 from tgm_amd.nn import GraphAttentionEmbedding, IdentityMessage, LastAggregator, TGNMemory, sampled_edge_list  # noqa: E402
 from tgm_amd.synth import make_stream  # noqa: E402
 
+torch.set_num_threads(min(8, torch.get_num_threads()))  # (host-side tensor ops on a shared many-core host: not every core)
 dev = torch.device('cuda', 0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 # 'fast' (default): pooled loader running one batch ahead (prefetch=1), SampledEdgeListHook (the loop's edge-list glue as one
