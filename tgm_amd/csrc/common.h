@@ -195,6 +195,47 @@ __device__ __forceinline__ void bitonic_sort_one(long long& key, int& pay, long 
 }
 
 
+// cos AND sin of one argument from ONE range reduction (the attention backward needs both for every (slot, column) it covers: the
+// cosine is the feature, the sine its derivative).  The cosine is cos_t2v's, bit for bit (same path decision, same reduction, same
+// polynomial); the sine comes from the same reduced argument (error ~1e-7, like the cosine's).
+__device__ __forceinline__ void sincos_t2v(float x, float& sn_out, float& cs_out) {
+  float rf;
+  int q;
+  if (__all(fabsf(x) < kCosSmallLimit)) {
+    float k = __builtin_rintf(x * 0.636619772367581343f);
+    float r = __fmaf_rn(-k, 1.57079637050628662109375f, x);
+    r = __fmaf_rn(-k, -4.37113900018624283e-8f, r);
+    const float adj = r > 0.78539819f ? 1.f : (r < -0.78539819f ? -1.f : 0.f);
+    k += adj;
+    r = __fmaf_rn(-adj, 1.57079637050628662109375f, r);
+    r = __fmaf_rn(-adj, -4.37113900018624283e-8f, r);
+    r = __fmaf_rn(-k, -1.71512449e-15f, r);
+    rf = r;
+    q = (int)k & 3;
+  } else {
+    const double xd = (double)x;
+    const double kd = __builtin_rint(xd * 0.63661977236758134308);
+    double r = __builtin_fma(-kd, 1.57079632679489655800e+00, xd);
+    r = __builtin_fma(-kd, 6.12323399573676603587e-17, r);
+    rf = (float)r;
+    q = (int)((long long)kd & 3);
+  }
+  const float r2 = rf * rf;
+  float sp = -1.9515295891e-4f;
+  sp = __fmaf_rn(sp, r2, 8.3321608736e-3f);
+  sp = __fmaf_rn(sp, r2, -1.6666654611e-1f);
+  const float sn = __fmaf_rn(sp * r2, rf, rf);
+  float cp = 2.443315711809948e-5f;
+  cp = __fmaf_rn(cp, r2, -1.388731625493765e-3f);
+  cp = __fmaf_rn(cp, r2, 4.166664568298827e-2f);
+  const float cs = __fmaf_rn(cp * r2, r2, __fmaf_rn(-0.5f, r2, 1.0f));
+  // q: 0 -> (sin r, cos r), 1 -> (cos r, -sin r), 2 -> (-sin r, -cos r), 3 -> (-cos r, sin r)
+  const float cv = (q & 1) ? sn : cs;
+  cs_out = (q == 1 || q == 2) ? -cv : cv;
+  const float sv = (q & 1) ? cs : sn;
+  sn_out = (q >= 2) ? -sv : sv;
+}
+
 // sin counterpart of cos_t2v (backward passes only; always the double-precision range reduction)
 __device__ __forceinline__ float sin_t2v(float x) {
   const double xd = (double)x;

@@ -290,10 +290,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void t
   extern __shared__ __attribute__((aligned(16))) float lds_all[];
   const int lane = lane_id(), wave = threadIdx.x >> 6;
   const int k = a.k, T = a.T, d = a.d, D = a.D, Cs = a.Cs;
-  // (only the cosines are staged: the sines are evaluated where the time gradient consumes them -- two [k, T] tables per wave were
-  // 16.5 KB at k = 20, T = 100: two workgroups per CU, two waves per SIMD, and the kernel is latency-bound)
-  float* s_cos = lds_all + (size_t)wave * (k * T + 2 * k + 2 * H * k);
-  float* s_dt = s_cos + k * T;
+  // (cosines AND sines are staged, one range reduction for each pair: 16.5 KB per wave at k = 20, T = 100 -- affordable since a workgroup
+  // is one wave; the sines used to be re-evaluated where the time gradient consumes them, through the double-precision reduction: a
+  // third of the 2 800 vector instructions a row of this kernel executed, profiles/r05_attention_counters.md)
+  float* s_cos = lds_all + (size_t)wave * (2 * k * T + 2 * k + 2 * H * k);
+  float* s_sin = s_cos + k * T;  // the sines of the same arguments (one range reduction for both: sincos_t2v)
+  float* s_dt = s_sin + k * T;
   float* s_A = s_dt + k;
   float* s_ds = s_A + H * k;
   int* s_eid = reinterpret_cast<int*>(s_ds + H * k);  // [k] (edge features by id)
@@ -374,7 +376,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void t
       const int sl = sb + i;
       if (sl < 0) continue;
       const float dts = s_dt[sl];
-      for (int t = lane; t < T; t += kWave) s_cos[sl * T + t] = cos_t2v(__fmaf_rn(dts, a.tw[t], a.tb[t]));
+      for (int t = lane; t < T; t += kWave) {
+        float sn, cs;
+        sincos_t2v(__fmaf_rn(dts, a.tw[t], a.tb[t]), sn, cs);
+        s_cos[sl * T + t] = cs;
+        s_sin[sl * T + t] = sn;
+      }
     }
     __builtin_amdgcn_wave_barrier();
     // ---- dA[h][s] = dzbar[h] . z[s] ----
@@ -483,7 +490,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void t
         qv[h] = q[h * Cs + col0 + ce];
       }
       float dw = 0.f, db = 0.f;
-      const float tw_c = part == 2 ? a.tw[ce] : 0.f, tb_c = part == 2 ? a.tb[ce] : 0.f;
       float zs[GS];
 #pragma clang loop unroll(full)
       for (int i = 0; i < GS; ++i) zs[i] = load(sb + i > 0 ? sb + i : 0, ce);
@@ -510,7 +516,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void t
           }
           if constexpr (part == 0) dn[i] += dzs;
           if constexpr (part == 2) {
-            const float g = -sin_t2v(__fmaf_rn(s_dt[sl], tw_c, tb_c)) * dzs;  // d cos(arg) / d arg (the argument the cosine above took)
+            const float g = -s_sin[sl * T + c] * dzs;  // d cos(arg) / d arg: the sine staged with the cosine (same argument, same reduction)
             dw = __fmaf_rn(g, s_dt[sl], dw);
             db += g;
           }
@@ -682,7 +688,7 @@ static int attn_backward_impl(const float* qf, const float* probs, const float* 
 static int launch_attn_backward(const AttnBwdArgs& a, int H, tgmx_stream_t stream) {
   const int k = a.k, T = a.T;
   const long long R = a.R;
-  const size_t per_wave = ((size_t)k * T + 2 * (size_t)k + 2 * (size_t)H * k) * sizeof(float);
+  const size_t per_wave = (2 * (size_t)k * T + 2 * (size_t)k + 2 * (size_t)H * k) * sizeof(float);
   static const int waves_knob = [] { const char* e = getenv("TGMX_ATTN_BWD_WPB"); const int v = e ? atoi(e) : 0; return (v == 1 || v == 2 || v == 4) ? v : 1; }();
   // one wave per workgroup: the waves share nothing, and a multi-wave workgroup's wave slots only refill when its SLOWEST row is done
   // (rows differ 10 x in cost: zero-upstream rows end at once); TGMX_ATTN_BWD_WPB = 2 / 4 is the A/B knob
