@@ -5,7 +5,7 @@
 // 16 x the Infinity Cache).  CHUNK = 16: one ring record; 64: one D = 16 feature row; 320: a node's window of B = 20 records;
 // 1280: a node's 20 feature rows (ring_x[n * B ...]); stream: CHUNK = the whole buffer (the guide's calibration case).
 //   hipcc --offload-arch=gfx950 -O3 -o tools/bin/gather_calib tools/gather_calib.hip
-//   rocprofv3 --pmc FETCH_SIZE -- tools/bin/gather_calib ; rocprofv3 --pmc WRITE_SIZE -- tools/bin/gather_calib   (tools/r5_calib.sh)
+//   rocprofv3 --pmc FETCH_SIZE -- tools/bin/gather_calib ; rocprofv3 --pmc WRITE_SIZE -- tools/bin/gather_calib   (tools/gpu_calib_r5.sh)
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Everything round 5's profiles/ are made of (besides tools/r5_calib.sh: the counter calibration and the stall counters), in one gpurun call (run from the repo root on the GPU box):
+# Everything round 5's profiles/ are made of (besides tools/gpu_calib_r5.sh: the counter calibration and the stall counters), in one gpurun call (run from the repo root on the GPU box):
 #   tools/gpu_round5.sh [quick]  -> gpurun_out/profiles_r05/*   (copy into profiles/ afterwards)
 set -u
 cd "$(dirname "$0")/.."
