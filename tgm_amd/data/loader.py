@@ -140,7 +140,10 @@ class DGDataLoader(torch.utils.data.DataLoader):
             try:
                 from .. import _native
 
-                _native.load().tgmx_worker_destroy(side[2])  # finishes pending jobs, joins the library's launch thread
+                lib = _native.load()
+                lib.tgmx_worker_destroy(side[2])  # finishes pending jobs, joins the library's launch thread
+                for e in side[1]:
+                    lib.tgmx_event_destroy(e)
             except Exception:  # noqa: BLE001 -- interpreter shutdown
                 pass
             self._side = None
