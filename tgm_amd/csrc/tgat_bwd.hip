@@ -10,6 +10,7 @@
 //                   d(folded query), d(neighbor features), per-row Time2Vec gradient partials
 // The "NN" products (dX = dY W) reuse sgemm_nt with transposed weight copies.
 #include "common.h"
+#include "lanes.h"
 
 #include <type_traits>
 
@@ -563,6 +564,265 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void t
   body(std::integral_constant<int, G>{});
 }
 
+// ---------------------------------------------------------------------------
+// Register-resident backward row (round 5, after the counters: the waves of the kernel above are parked in s_waitcnt for 54-60 % of
+// their cycles -- a row is ~12 dependent global round trips: it reads every feature TWICE, 4 bytes per lane and load, and each column
+// chunk's loads wait behind the previous chunk's stores).  The forward's layout instead (tgat_attn_reduce_reg_kernel): a lane owns its
+// float4 column of the edge features, its neighbor-feature column and its two Time2Vec columns of EVERY covered slot in registers.  A row
+// is then THREE round trips -- (1) dzbar, the folded query, slot times / ids, attention weights; (2) every feature of the span, all loads
+// in flight together; (3) stores -- with every store after the last load.  The cosines and sines of the lane's own two time columns are
+// staged in LDS between the passes (own-lane write, own-lane read: no barrier, no cross-lane traffic); scores, the softmax backward and
+// the weights' broadcast travel by DPP / v_readlane.
+// Shapes: d <= 64 (one neighbor column per lane: the leaf layers), D % 4 == 0 with D / 4 <= 64, T <= 128, k <= G; others take the kernel
+// above.  Sums are ordered like the forward's (column-in-lane, then xor 32 ... 1): not bit-identical to the kernel above, same tolerance.
+// ---------------------------------------------------------------------------
+// NBV: the neighbor features are a float4 column per lane too (d % 4 == 0, d / 4 <= 64: the layers above the leaves).  Their values and
+// dnbr's old values are 8 more registers per slot: the variant runs ONE wave per SIMD (512 registers) and is launched for few rows only
+// (the 600-row layer of the headline step: 600 waves on 1 024 SIMDs -- the launch lasts as long as one row, occupancy buys nothing).
+template <int H, int G, bool NBV>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NBV ? 1 : 2, NBV ? 1 : 2))) void tgat_attn_backward_reg_kernel(const AttnBwdArgs a) {
+  static_assert(G * H <= 64, "lane = slot * H + head must fit the wave");
+  extern __shared__ __attribute__((aligned(16))) float lds_all[];
+  const int lane = lane_id();
+  const int k = a.k, T = a.T, d = a.d, D = a.D, Cs = a.Cs, D4 = a.D >> 2;
+  float* s_cos = lds_all;        // [k][T]: written and read by the lane that owns the column
+  float* s_sin = s_cos + k * T;  // the sines of the same arguments
+  const long long r = blockIdx.x;
+  if (r >= a.R) return;
+  const float* lv_nbrf = a.nbrf;
+  const float* lv_ex = a.ex;
+  const int32_t* lv_eid = a.eid;
+  const float* lv_table = a.table;
+  const int64_t *lv_seed_t = a.seed_t, *lv_nbr_t = a.nbr_t;
+  float* lv_dnbr = a.dnbr;
+  if (a.n_seg > 0) {
+    int sg = 0;
+    for (int i2 = 1; i2 < a.n_seg; ++i2)
+      if (r >= a.seg_begin[i2]) sg = i2;
+    lv_nbrf = a.seg_nbrf[sg]; lv_ex = a.seg_ex[sg]; lv_eid = a.seg_eid[sg]; lv_table = a.seg_table[sg];
+    lv_seed_t = a.seg_seed_t[sg]; lv_nbr_t = a.seg_nbr_t[sg]; lv_dnbr = a.seg_dnbr[sg];
+  }
+  const float* __restrict__ q = a.qf + r * (long long)H * Cs;
+  const float* __restrict__ dz = a.dzbar + r * (long long)H * Cs;
+  float* __restrict__ dq = a.dqf + r * (long long)H * Cs;
+  const float* __restrict__ nb = lv_nbrf + r * (long long)k * d;
+  const float4* __restrict__ ex4 = lv_ex ? reinterpret_cast<const float4*>(lv_ex + r * (long long)k * D) : nullptr;
+  const float4* __restrict__ table4 = reinterpret_cast<const float4*>(lv_table);
+  float* dnb = lv_dnbr ? lv_dnbr + r * (long long)k * d : nullptr;
+  const int d4 = d >> 2;
+  const bool e_on = lane < D4, n_on = NBV ? lane < d4 : lane < d, t0_on = lane < T, t1_on = lane + kWave < T;
+
+  // ---- round trip 1: everything that depends on the row number only, issued together (dzbar first: the early exit waits for it alone) ----
+  float4 ge[H], qe[H], gn[H], qn[H];  // (gn, qn: .x only unless NBV)
+  float gt0[H], gt1[H], qt0[H], qt1[H];
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    const float* gh = dz + h * Cs;
+    ge[h] = e_on ? make_float4(gh[d + 4 * lane], gh[d + 4 * lane + 1], gh[d + 4 * lane + 2], gh[d + 4 * lane + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (NBV) gn[h] = n_on ? make_float4(gh[4 * lane], gh[4 * lane + 1], gh[4 * lane + 2], gh[4 * lane + 3]) : zero4;
+    else gn[h] = make_float4(n_on ? gh[lane] : 0.f, 0.f, 0.f, 0.f);
+    gt0[h] = t0_on ? gh[d + D + lane] : 0.f;
+    gt1[h] = t1_on ? gh[d + D + lane + kWave] : 0.f;
+  }
+  float my_dt = 0.f;
+  int my_eid = -1;
+  if (lane < k) {
+    my_dt = (float)(lv_seed_t[r] - lv_nbr_t[r * k + lane]);  // int64 subtract, then round-to-nearest f32 (tgat.py:143-145)
+    if (lv_eid) my_eid = lv_eid[r * k + lane];
+  }
+  const int js = lane / H, jh = lane - js * H;  // lane j = slot * H + head
+  const bool live = js < k;
+  const float A = live ? a.probs[r * (long long)H * k + jh * k + js] : 0.f;
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    const float* qh = q + h * Cs;
+    qe[h] = e_on ? make_float4(qh[d + 4 * lane], qh[d + 4 * lane + 1], qh[d + 4 * lane + 2], qh[d + 4 * lane + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (NBV) qn[h] = n_on ? make_float4(qh[4 * lane], qh[4 * lane + 1], qh[4 * lane + 2], qh[4 * lane + 3]) : zero4;
+    else qn[h] = make_float4(n_on ? qh[lane] : 0.f, 0.f, 0.f, 0.f);
+    qt0[h] = t0_on ? qh[d + D + lane] : 0.f;
+    qt1[h] = t1_on ? qh[d + D + lane + kWave] : 0.f;
+  }
+  const float w0 = t0_on ? a.tw[lane] : 0.f, b0 = t0_on ? a.tb[lane] : 0.f;
+  const float w1 = t1_on ? a.tw[lane + kWave] : 0.f, b1 = t1_on ? a.tb[lane + kWave] : 0.f;
+
+  // ---- rows without upstream gradient (see the kernel above): zeros out, no feature read ----
+  {
+    bool nz = false;
+#pragma unroll
+    for (int h = 0; h < H; ++h)
+      nz = nz || ge[h].x != 0.f || ge[h].y != 0.f || ge[h].z != 0.f || ge[h].w != 0.f || gn[h].x != 0.f || gn[h].y != 0.f || gn[h].z != 0.f || gn[h].w != 0.f || gt0[h] != 0.f || gt1[h] != 0.f;
+    if (!__any(nz)) {
+      for (int c = lane; c < H * Cs; c += kWave) dq[c] = 0.f;
+      for (int c = lane; c < 2 * T; c += kWave) a.dtime[r * 2LL * T + c] = 0.f;
+      return;
+    }
+  }
+  // the slots that carry gradient: from the first one with A != 0 in some head to the end (see the kernel above)
+  const unsigned long long amask = __ballot(A != 0.f);
+  const int span = amask ? k - (__ffsll((long long)amask) - 1) / H : k;
+  // the cosine's reduction path, once per row: a sufficient test first, the exact one only if it fails (tgat.hip: row_args_small)
+  bool row_small;
+  {
+    const float m = lanes::wave_max(fabsf(my_dt));
+    const float lim = 0.99f * kCosSmallLimit;
+    row_small = __all(__fmaf_rn(m, fabsf(w0), fabsf(b0)) < lim && __fmaf_rn(m, fabsf(w1), fabsf(b1)) < lim);
+    if (!row_small) {
+      bool small = true;
+      for (int s = 0; s < k; ++s) {
+        const float dt = lanes::bcast(my_dt, s);
+        small = small && fabsf(__fmaf_rn(dt, w0, b0)) < kCosSmallLimit && fabsf(__fmaf_rn(dt, w1, b1)) < kCosSmallLimit;
+      }
+      row_small = __all(small);
+    }
+  }
+  const float mk = live ? dropout_scale(a.drop, (unsigned long long)(a.drop_row0 + r) * (H * k) + jh * k + js) : 0.f;
+
+  auto body = [&](auto gsc, auto smallc) __attribute__((always_inline)) {
+    constexpr int GS = decltype(gsc)::value;  // slots [k - GS, k) (k < GS: slots [0, k), the positions past k re-read slot k - 1 with weight 0)
+    constexpr bool SMALL = decltype(smallc)::value;
+    constexpr int NV = GS * H, NVp = NV <= 4 ? 4 : NV <= 8 ? 8 : NV <= 16 ? 16 : NV <= 32 ? 32 : 64;
+    const int s0 = k > GS ? k - GS : 0;
+    // ---- round trip 2: the span's features, all in flight together; dnbr's old values with them (it is accumulated into) ----
+    float4 ze[GS], zs[GS], dn[GS];  // (zs, dn: .x only unless NBV)
+#pragma unroll
+    for (int i = 0; i < GS; ++i) {
+      const int sl = s0 + i < k ? s0 + i : k - 1;
+      if (lv_eid) {  // wave-uniform: the slot's row of the resident store, zeros for a pad slot
+        const int e = lanes::bcast(my_eid, sl);
+        ze[i] = (e_on && e >= 0) ? table4[(long long)e * D4 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        ze[i] = e_on ? ex4[sl * D4 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      if (NBV) {
+        zs[i] = n_on ? reinterpret_cast<const float4*>(nb + (long long)sl * d)[lane] : zero4;
+        dn[i] = (dnb && n_on) ? reinterpret_cast<const float4*>(dnb + (long long)sl * d)[lane] : zero4;
+      } else {
+        zs[i] = make_float4(n_on ? nb[(long long)sl * d + lane] : 0.f, 0.f, 0.f, 0.f);
+        dn[i] = make_float4((dnb && n_on) ? dnb[(long long)sl * d + lane] : 0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    // ---- pass 1: dA[h][s] = dzbar[h] . z[s]; the lane's cosines and sines go to LDS on the way ----
+    float P[NVp];
+#pragma unroll
+    for (int j = 0; j < NVp; ++j) P[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < GS; ++i) {
+      const int sl = s0 + i < k ? s0 + i : k - 1;
+      const float dt = lanes::bcast(my_dt, sl);
+      float sn0, c0, sn1, c1;
+      lanes::sincos_path<SMALL>(__fmaf_rn(dt, w0, b0), sn0, c0);
+      lanes::sincos_path<SMALL>(__fmaf_rn(dt, w1, b1), sn1, c1);
+      if (t0_on) { s_cos[sl * T + lane] = c0; s_sin[sl * T + lane] = sn0; }
+      if (t1_on) { s_cos[sl * T + lane + kWave] = c1; s_sin[sl * T + lane + kWave] = sn1; }
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        float p = ge[h].x * ze[i].x;
+        p = __fmaf_rn(ge[h].y, ze[i].y, p);
+        p = __fmaf_rn(ge[h].z, ze[i].z, p);
+        p = __fmaf_rn(ge[h].w, ze[i].w, p);
+        p = __fmaf_rn(gn[h].x, zs[i].x, p);
+        if (NBV) {
+          p = __fmaf_rn(gn[h].y, zs[i].y, p);
+          p = __fmaf_rn(gn[h].z, zs[i].z, p);
+          p = __fmaf_rn(gn[h].w, zs[i].w, p);
+        }
+        p = __fmaf_rn(gt0[h], c0, p);  // (a lane past T: its dzbar column is 0)
+        p = __fmaf_rn(gt1[h], c1, p);
+        P[i * H + h] = p;
+      }
+    }
+    float sc = lanes::reduce_scatter<NVp>(P, lane);  // lane L: entry L mod NVp = (position i, head h), i * H + h
+    if (s0 > 0) sc = __shfl(sc, (lane - s0 * H) & (NVp - 1));  // ... to the lane of the ORIGINAL slot
+    // ---- softmax backward in the lanes (slot, head); zbar used A' = A * mk (dropout on the softmax output, attention.py:119) ----
+    const float dA = (live && js >= s0) ? sc * mk : 0.f;
+    const float dot = lanes::butterfly_sum<H>(A * dA);
+    const float ds = A * (dA - dot);  // a masked slot has A == 0
+    const float Ap = A * mk;
+
+    // ---- pass 2, from registers: dqf[h] = scale * sum_s ds[h][s] z[s];  dz[s] = sum_h A' dzbar[h] + scale * ds * qf[h] ----
+    float4 ae[H], an[H];
+    float at0[H], at1[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      ae[h] = an[h] = zero4;
+      at0[h] = at1[h] = 0.f;
+    }
+    float dw0 = 0.f, db0 = 0.f, dw1 = 0.f, db1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < GS; ++i) {
+      const int sp = s0 + i;                 // (sp >= k: a position past the row's slots -- its lanes are not live, every weight is 0)
+      const int sl = sp < k ? sp : k - 1;
+      const float c0 = t0_on ? s_cos[sl * T + lane] : 0.f, sn0 = t0_on ? s_sin[sl * T + lane] : 0.f;
+      const float c1 = t1_on ? s_cos[sl * T + lane + kWave] : 0.f, sn1 = t1_on ? s_sin[sl * T + lane + kWave] : 0.f;
+      const float dt = lanes::bcast(my_dt, sl);
+      float4 dzn = zero4;
+      float dzt0 = 0.f, dzt1 = 0.f;
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        const float wd = lanes::bcast(ds, sp * H + h), wa = lanes::bcast(Ap, sp * H + h);
+        ae[h].x = __fmaf_rn(wd, ze[i].x, ae[h].x); ae[h].y = __fmaf_rn(wd, ze[i].y, ae[h].y);
+        ae[h].z = __fmaf_rn(wd, ze[i].z, ae[h].z); ae[h].w = __fmaf_rn(wd, ze[i].w, ae[h].w);
+        an[h].x = __fmaf_rn(wd, zs[i].x, an[h].x);
+        if (NBV) { an[h].y = __fmaf_rn(wd, zs[i].y, an[h].y); an[h].z = __fmaf_rn(wd, zs[i].z, an[h].z); an[h].w = __fmaf_rn(wd, zs[i].w, an[h].w); }
+        at0[h] = __fmaf_rn(wd, c0, at0[h]);
+        at1[h] = __fmaf_rn(wd, c1, at1[h]);
+        const float sq = a.scale * wd;
+        dzn.x += wa * gn[h].x + sq * qn[h].x;
+        if (NBV) { dzn.y += wa * gn[h].y + sq * qn[h].y; dzn.z += wa * gn[h].z + sq * qn[h].z; dzn.w += wa * gn[h].w + sq * qn[h].w; }
+        dzt0 += wa * gt0[h] + sq * qt0[h];
+        dzt1 += wa * gt1[h] + sq * qt1[h];
+      }
+      dn[i].x += dzn.x;
+      if (NBV) { dn[i].y += dzn.y; dn[i].z += dzn.z; dn[i].w += dzn.w; }
+      const float g0 = -sn0 * dzt0, g1 = -sn1 * dzt1;  // d cos(arg) / d arg
+      dw0 = __fmaf_rn(g0, dt, dw0); db0 += g0;
+      dw1 = __fmaf_rn(g1, dt, dw1); db1 += g1;
+    }
+    // ---- round trip 3: the stores, after the last load ----
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      float* zh = dq + h * Cs;
+      if (NBV) {
+        if (n_on) { zh[4 * lane] = an[h].x * a.scale; zh[4 * lane + 1] = an[h].y * a.scale; zh[4 * lane + 2] = an[h].z * a.scale; zh[4 * lane + 3] = an[h].w * a.scale; }
+      } else if (n_on) {
+        zh[lane] = an[h].x * a.scale;
+      }
+      if (e_on) {
+        zh[d + 4 * lane] = ae[h].x * a.scale; zh[d + 4 * lane + 1] = ae[h].y * a.scale;
+        zh[d + 4 * lane + 2] = ae[h].z * a.scale; zh[d + 4 * lane + 3] = ae[h].w * a.scale;
+      }
+      if (t0_on) zh[d + D + lane] = at0[h] * a.scale;
+      if (t1_on) zh[d + D + lane + kWave] = at1[h] * a.scale;
+    }
+    if (dnb && n_on) {
+#pragma unroll
+      for (int i = 0; i < GS; ++i)
+        if (s0 + i < k) {
+          if (NBV) reinterpret_cast<float4*>(dnb + (long long)(s0 + i) * d)[lane] = dn[i];
+          else dnb[(long long)(s0 + i) * d + lane] = dn[i].x;
+        }
+    }
+    float* dtr = a.dtime + r * 2LL * T;
+    if (t0_on) { dtr[lane] = dw0; dtr[T + lane] = db0; }
+    if (t1_on) { dtr[lane + kWave] = dw1; dtr[T + lane + kWave] = db1; }
+  };
+  auto run = [&](auto n) __attribute__((always_inline)) {
+    if (row_small) body(n, std::true_type{});
+    else body(n, std::false_type{});
+  };
+  if constexpr (G > 16) {
+    if (span <= 4) return run(std::integral_constant<int, 4>{});
+    if (span <= 8) return run(std::integral_constant<int, 8>{});
+    if (span <= 12) return run(std::integral_constant<int, 12>{});
+    if (span <= 16) return run(std::integral_constant<int, 16>{});
+  } else if constexpr (G > 8) {
+    if (span <= 4) return run(std::integral_constant<int, 4>{});
+    if (span <= 8) return run(std::integral_constant<int, 8>{});
+  }
+  run(std::integral_constant<int, G>{});
+}
+
 }  // namespace tgmx
 
 using namespace tgmx;
@@ -697,6 +957,35 @@ static int launch_attn_backward(const AttnBwdArgs& a, int H, tgmx_stream_t strea
   TGMX_REQUIRE(per_wave * waves <= 64 * 1024, "tgat_attn_backward: k*T=%d too large for LDS", k * T);
   const dim3 grid((unsigned)((R + waves - 1) / waves)), block(waves * kWave);
   hipStream_t st = (hipStream_t)stream;
+  // the register-resident row (tgat_attn_backward_reg_kernel) for the shapes it holds; TGMX_ATTN_BWD_REG=0: the A/B knob
+  static const bool reg_knob = [] { const char* e = getenv("TGMX_ATTN_BWD_REG"); return !(e && e[0] == '0'); }();
+  // (the float4-neighbor variant runs one wave per SIMD: for launches that do not fill the SIMDs twice anyway)
+  static const bool nbv_knob = [] { const char* e = getenv("TGMX_ATTN_BWD_REG_NBV"); return !(e && e[0] == '0'); }();
+  const bool nbv = nbv_knob && a.d > 64 && a.d % 4 == 0 && a.d / 4 <= 64 && R <= 2048;
+  if (reg_knob && (H == 1 || H == 2) && k <= 20 && (a.d <= 64 || nbv) && a.D > 0 && a.D % 4 == 0 && a.D / 4 <= 64 && T <= 128) {
+    uintptr_t bits = (uintptr_t)a.ex | (uintptr_t)a.table;  // D % 4 == 0: a biased level pointer keeps its alignment
+    if (nbv) bits |= (uintptr_t)a.nbrf | (uintptr_t)a.dnbr;
+    for (int i = 0; i < a.n_seg; ++i) {
+      bits |= (uintptr_t)a.seg_ex[i] | (uintptr_t)a.seg_table[i];
+      if (nbv) bits |= (uintptr_t)a.seg_nbrf[i] | (uintptr_t)a.seg_dnbr[i];
+    }
+    if ((bits & 15) == 0) {
+      const size_t lds = 2 * (size_t)k * T * sizeof(float);
+      const dim3 rgrid((unsigned)R), rblock(kWave);
+#define TGMX_ATTN_BWD_REG(H_, G_)                                                                             \
+  do {                                                                                                       \
+    if (nbv) hipLaunchKernelGGL((tgat_attn_backward_reg_kernel<H_, G_, true>), rgrid, rblock, lds, st, a);    \
+    else hipLaunchKernelGGL((tgat_attn_backward_reg_kernel<H_, G_, false>), rgrid, rblock, lds, st, a);       \
+  } while (0)
+      if (H == 1 && k <= 10) TGMX_ATTN_BWD_REG(1, 10);
+      else if (H == 1) TGMX_ATTN_BWD_REG(1, 20);
+      else if (k <= 10) TGMX_ATTN_BWD_REG(2, 10);
+      else TGMX_ATTN_BWD_REG(2, 20);
+#undef TGMX_ATTN_BWD_REG
+      TGMX_CHECK_LAUNCH("tgat_attn_backward");
+      return TGMX_OK;
+    }
+  }
 #define TGMX_ATTN_BWD(H_)                                                                                        \
   do {                                                                                                          \
     if (k <= 20) hipLaunchKernelGGL((tgat_attn_backward_kernel<H_, 20>), grid, block, per_wave * waves, st, a); \
