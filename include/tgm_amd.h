@@ -431,11 +431,13 @@ int tgmx_tgat_rres(const float* x, int64_t ldx, int32_t d, const float* tb, cons
  * element strides (bias: [batch, N], i.e. [N] when batch = 1); exact-fp32 MFMA.  Replaces the nn.Linear calls of
  * attention.py:96,125 and tgat.py:36-38 and the folded W_K / W_V contractions.
  * Determinism: a call is reproducible bit for bit.  The ORDER in which a row's K products are summed depends on the kernel the call
- * picks from M alone (M <= 2048: eight contiguous K slices per output block; larger M: four interleaved k-step sets), so one row
- * computed in a 600-row call and in a 12 600-row call can differ in the last bits (both are pinned against float64 in
+ * picks from M alone -- M <= 2048: eight contiguous K slices per output block; M >= 6144:
+ * one ascending chain through 32-wide K chunks staged in LDS; otherwise four interleaved k-step sets -- so one
+ * row computed in a 600-row call and in a 12 600-row call can differ in the last bits (all three are pinned against float64 in
  * tests/test_gemm_gpu.py).  Every bit-identity claim of this library (compact rows, sharded vs single-rank outputs) is between
- * calls of equal M per GEMM; a rank that takes <= 2048 rows of a batch a single rank would run as > 2048 rows is outside it --
- * TGMX_GEMM_SMALL=0 pins the large-M kernel for every M when that matters more than the 600-row layer's 8 us. */
+ * calls whose M falls in the same band per GEMM; a rank whose share of a batch lands in another band is outside it --
+ * TGMX_GEMM_SMALL=0 and TGMX_GEMM_LDS=0 pin the four-set kernel for every M when that matters more than the time (the 600-row
+ * layer's 8 us; 15-30 % of a many-row GEMM). */
 int tgmx_sgemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
                   int64_t M, int32_t N, int32_t K, const float* bias, int32_t relu, int32_t batch,
                   int64_t strideA, int64_t strideB, int64_t strideC, tgmx_stream_t stream);

@@ -1,6 +1,6 @@
-"""The exact-fp32 MFMA GEMM behind every linear layer of the aggregation path (``tgmx_sgemm_nt``): both kernels -- the few-row,
-latency-shaped one (M <= 2048, 16 < K <= 512) and the general one -- against a float64 product, on the shapes the TGAT / TGN / TGCN
-paths run and on the edges of the dispatch (ragged M / N / K, unaligned views, bias + relu, batches)."""
+"""The exact-fp32 MFMA GEMM behind every linear layer of the aggregation path (``tgmx_sgemm_nt``): its three kernels -- the few-row,
+latency-shaped one (M <= 2048, 16 < K <= 512), the many-row one that stages whole lines through LDS (M >= 6144) and the general K-split one -- against a float64 product, on the shapes the TGAT / TGN / TGCN paths run
+and on the edges of the dispatch (ragged M / N / K, unaligned views, untrusted row padding, bias + relu, batches)."""
 
 import pytest
 import torch
@@ -77,3 +77,68 @@ def test_small_and_general_kernels_agree_to_rounding(monkeypatch):
     _ops.sgemm_nt(A[:2048], B, o1)
     _ops.sgemm_nt(A, B, o2)
     assert (o1 - o2[:2048]).abs().max().item() <= 1e-4
+
+
+@pytest.mark.parametrize('M', [6143, 6144, 8118, 12600, 12601])
+@pytest.mark.parametrize('N,K', [(172, 172), (102, 273), (300, 316), (800, 100), (103, 173), (200, 116), (51, 18)])
+def test_sgemm_nt_many_rows_against_float64(M, N, K):
+    """The shapes of the training step and of cfg 3 (12 600 / 8 118 rows) through the LDS-staged kernel, and both sides of its row
+    threshold (6 143 rows: the K-split kernel).  Rows are padded to multiples of 4 floats like the
+    library's own operands, and the padding holds NaNs: a kernel that multiplied it would show."""
+    from tgm_amd.nn import _ops
+
+    pad = lambda x: (x + 3) // 4 * 4
+    g = torch.Generator(device='cpu').manual_seed(M * 1000003 + N * 1009 + K)
+    A = torch.full((M, pad(K)), float('nan')).cuda()
+    B = torch.full((N, pad(K)), float('nan')).cuda()
+    A[:, :K] = torch.randn(M, K, generator=g).cuda()
+    B[:, :K] = torch.randn(N, K, generator=g).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    for b, relu in ((None, False), (bias, True)):
+        full = torch.full((M, pad(N) + 4), 7.0, device='cuda')
+        out = full[:, :N]
+        _ops.sgemm_nt(A[:, :K], B[:, :K], out, bias=b, relu=relu)
+        ref = _ref(A[:, :K], B[:, :K], b, relu)
+        err = (out.double() - ref).abs().max().item()
+        assert err <= 2e-5 * (K**0.5), (M, N, K, err)
+        assert torch.equal(full[:, N:], torch.full((M, pad(N) + 4 - N), 7.0, device='cuda'))  # nothing past N is written
+        out2 = torch.empty_like(full)[:, :N]
+        _ops.sgemm_nt(A[:, :K], B[:, :K], out2, bias=b, relu=relu)
+        assert torch.equal(out, out2)  # the same launch twice: the same bits
+
+
+def test_sgemm_nt_many_rows_batches():
+    """W_V per head at the training step's size: 12 600 rows, two heads side by side in a row, strided operands (LDS-staged)."""
+    from tgm_amd.nn import _ops
+
+    g = torch.Generator(device='cpu').manual_seed(17)
+    H, M, N, K, Kp, Np = 2, 12600, 51, 273, 276, 52
+    A = torch.randn(M, H * Kp, generator=g).cuda()
+    B = torch.randn(H * Np, Kp, generator=g).cuda()
+    bias = torch.randn(H, N, generator=g).cuda()
+    out = torch.zeros(M, H * Np, device='cuda')
+    _ops.sgemm_nt(A, B, out, bias=bias, M=M, N=N, K=K, batch=H, sA=Kp, sB=Np * Kp, sC=Np)
+    for h in range(H):
+        ref = _ref(A[:, h * Kp:h * Kp + K], B[h * Np:h * Np + N, :K], bias[h], False)
+        assert (out[:, h * Np:h * Np + N].double() - ref).abs().max().item() <= 4e-4
+        assert torch.equal(out[:, h * Np + N:(h + 1) * Np], torch.zeros(M, Np - N, device='cuda'))
+
+
+def test_sgemm_nt_many_rows_unaligned_views_equal_the_aligned_call():
+    """The kernel a call takes depends on M alone: column-sliced (not 16-byte-aligned) views of the same numbers go through the same
+    LDS-staged kernel float by float and give the same bits as the aligned copies."""
+    from tgm_amd.nn import _ops
+
+    g = torch.Generator(device='cpu').manual_seed(23)
+    M, N, K = 12600, 172, 273
+    big_a = torch.randn(M, 301, generator=g).cuda()
+    big_b = torch.randn(N, 303, generator=g).cuda()
+    A, B = big_a[:, 1:1 + K], big_b[:, 3:3 + K]  # odd column offsets: no 16-byte loads
+    o_view = torch.empty(M, N, device='cuda')
+    _ops.sgemm_nt(A, B, o_view)
+    Ac = torch.zeros(M, 276, device='cuda'); Ac[:, :K] = A
+    Bc = torch.zeros(N, 276, device='cuda'); Bc[:, :K] = B
+    o_copy = torch.empty(M, N, device='cuda')
+    _ops.sgemm_nt(Ac[:, :K], Bc[:, :K], o_copy)
+    assert torch.equal(o_view, o_copy)
+    assert (o_view.double() - _ref(A, B, None, False)).abs().max().item() <= 4e-4

@@ -175,6 +175,120 @@ __global__ __launch_bounds__(256) void sgemm_nt_pair_kernel(const GemmPairArgs p
   else sgemm_nt_body<true, true, true, 8>(p.g[0], blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
+// The MANY-ROW variant (M >= 6144, see gemm_takes_lds): both operands STAGED THROUGH LDS in whole 128-byte lines.
+// Why: the direct kernel above takes 32 bytes of every 128-byte line per lane and k-step straight from L2 into the
+// MFMA layout; with 4-5 workgroups per CU in flight the lines do not survive in the 32 KB L1 until their other quarters are wanted, and the
+// launch runs at 0.22-0.34 of the fp32-MFMA peak however it is tiled (12 600 x 172 x 172: 23 us for 4.8 us of MFMAs, ~4 us per layer of
+// 256 workgroups).  Here a workgroup owns a 64 x 64 block; per 32-wide k-chunk its 256 threads fetch the block's 64 + 64 rows as 128-byte
+// row segments (eight lanes x 16 bytes per row: every line whole, once), park them in registers while the current chunk's MFMAs run, and
+// store them into the other LDS buffer (rows padded to 36 floats: conflict-free 16-byte reads).  Wave (wr, wc) multiplies rows
+// [32 wr, 32 wr + 32) with columns [32 wc, 32 wc + 32): lane (i, half) reads k-set [16 half, 16 half + 16) of its A row and its B row (four
+// 16-byte LDS reads each) for the chunk's 16 MFMAs -- the same pairing of k with the two k-slots as above.  One barrier per chunk.
+// Summation order: chunk by chunk in ascending k, no cross-wave reduction (differs from the K-split kernel at rounding level).
+constexpr int kLdsBM = 64, kLdsBN = 64, kLdsBK = 32, kLdsLd = kLdsBK + 4;
+constexpr int kLdsFloats = 2 * (kLdsBM + kLdsBN) * kLdsLd;  // two buffers of (A block | B block): 36 864 bytes
+
+// one 16-byte piece of a row's k-chunk: zeros past K (K need not be a multiple of 4; the padding of a padded row is not trusted)
+// (VEC = false: rows that are not 16-byte aligned -- column-sliced views -- are read float by float: same values, same sums)
+template <bool VEC>
+__device__ __forceinline__ float4 lds_gemm_piece(const float* __restrict__ row, int k, int K) {
+  if (VEC && k + 4 <= K) return *reinterpret_cast<const float4*>(row + k);
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (k < K) v.x = row[k];
+  if (k + 1 < K) v.y = row[k + 1];
+  if (k + 2 < K) v.z = row[k + 2];
+  if (k + 3 < K) v.w = row[k + 3];
+  return v;
+}
+
+template <bool AV, bool BV>
+__device__ __forceinline__ void sgemm_nt_lds_body(const GemmArgs& g, const unsigned bx, const unsigned by, const unsigned bz, float* __restrict__ smem) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, half = lane >> 5;
+  const int wr = wave >> 1, wc = wave & 1;
+  const long long m0 = (long long)bx * kLdsBM;
+  const int n0 = by * kLdsBN;
+  const float* __restrict__ A = g.A + (long long)bz * g.sA;
+  const float* __restrict__ B = g.B + (long long)bz * g.sB;
+  float* __restrict__ C = g.C + (long long)bz * g.sC;
+  // staging: thread t moves piece (t & 7) of rows (t >> 3) and (t >> 3) + 32 of the A block and of the B block (rows past the edge are
+  // clamped: their products are never stored)
+  const int sr = tid >> 3, sc = (tid & 7) * 4;
+  const long long ra0 = m0 + sr < g.M ? m0 + sr : g.M - 1, ra1 = m0 + sr + 32 < g.M ? m0 + sr + 32 : g.M - 1;
+  const int rb0 = n0 + sr < g.N ? n0 + sr : g.N - 1, rb1 = n0 + sr + 32 < g.N ? n0 + sr + 32 : g.N - 1;
+  const float* __restrict__ pa0 = A + ra0 * g.lda;
+  const float* __restrict__ pa1 = A + ra1 * g.lda;
+  const float* __restrict__ pb0 = B + (long long)rb0 * g.ldb;
+  const float* __restrict__ pb1 = B + (long long)rb1 * g.ldb;
+  auto As = [&](int buf) { return smem + buf * (kLdsBM + kLdsBN) * kLdsLd; };
+  auto Bs = [&](int buf) { return smem + buf * (kLdsBM + kLdsBN) * kLdsLd + kLdsBM * kLdsLd; };
+  const int nchunks = (g.K + kLdsBK - 1) / kLdsBK;
+  float4 v[4];  // the thread's four staged pieces: rows sr and sr + 32 of the A block and of the B block
+  auto request = [&](int chunk) __attribute__((always_inline)) {
+    const int k = chunk * kLdsBK + sc;
+    v[0] = lds_gemm_piece<AV>(pa0, k, g.K); v[1] = lds_gemm_piece<AV>(pa1, k, g.K);
+    v[2] = lds_gemm_piece<BV>(pb0, k, g.K); v[3] = lds_gemm_piece<BV>(pb1, k, g.K);
+  };
+  auto park = [&](int buf) __attribute__((always_inline)) {
+    *reinterpret_cast<float4*>(As(buf) + sr * kLdsLd + sc) = v[0];
+    *reinterpret_cast<float4*>(As(buf) + (sr + 32) * kLdsLd + sc) = v[1];
+    *reinterpret_cast<float4*>(Bs(buf) + sr * kLdsLd + sc) = v[2];
+    *reinterpret_cast<float4*>(Bs(buf) + (sr + 32) * kLdsLd + sc) = v[3];
+  };
+  request(0);
+  park(0);
+  __syncthreads();
+  floatx16 acc = {0};
+  for (int c = 0; c < nchunks; ++c) {
+    const bool more = c + 1 < nchunks;
+    if (more) request(c + 1);  // the next chunk's lines: in flight during this chunk's MFMAs
+    const float4* __restrict__ ar = reinterpret_cast<const float4*>(As(c & 1) + (wr * 32 + i) * kLdsLd + half * 16);
+    const float4* __restrict__ br = reinterpret_cast<const float4*>(Bs(c & 1) + (wc * 32 + i) * kLdsLd + half * 16);
+    float4 a4[4], b4[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { a4[u] = ar[u]; b4[u] = br[u]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[u].x, b4[u].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[u].y, b4[u].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[u].z, b4[u].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[u].w, b4[u].w, acc, 0, 0, 0);
+    }
+    if (more) {  // (the other buffer was last read in iteration c - 1, behind that iteration's barrier)
+      park((c + 1) & 1);
+      __syncthreads();
+    }
+  }
+  const int col = n0 + wc * 32 + i;
+  if (col < g.N) {
+    const float bias = g.bias ? g.bias[(long long)bz * g.N + col] : 0.f;  // batch b adds row b of a [batch, N] bias
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const long long row = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (row < g.M) {
+        float v = acc[r];
+        if (g.bias) v += bias;
+        if (g.relu) v = v > 0.f ? v : 0.f;
+        C[row * g.ldc + col] = v;
+      }
+    }
+  }
+}
+
+template <bool AV, bool BV>
+__global__ __launch_bounds__(256) void sgemm_nt_lds_kernel(const GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float smem[kLdsFloats];
+  sgemm_nt_lds_body<AV, BV>(g, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+}
+
+// two independent problems in one launch of the kernel above (see sgemm_nt_pair_kernel)
+__global__ __launch_bounds__(256) void sgemm_nt_lds_pair_kernel(const GemmPairArgs p) {
+  __shared__ __attribute__((aligned(16))) float smem[kLdsFloats];
+  const unsigned which = blockIdx.x >= p.tiles0;
+  if (blockIdx.y >= p.ny[which] || blockIdx.z >= p.nz[which]) return;
+  sgemm_nt_lds_body<true, true>(p.g[which], which ? blockIdx.x - p.tiles0 : blockIdx.x, blockIdx.y, blockIdx.z, smem);
+}
+
 // The FEW-ROW variant (M <= 2048: the 600-row layer of the headline forward, whose five GEMMs were 41 us of a 185 us forward at ~8 us
 // each for 0.03-0.2 GFLOP).  Such a launch is one dependent chain -- launch, operand latency, MFMAs, reduction, store -- so the
 // kernel is built to make that chain SHORT instead of wide: a workgroup owns one 32 x 32 output block, its 8 waves split K into
@@ -2240,6 +2354,15 @@ static bool launch_attn_reg(hipStream_t st, const AttnArgs& a) {
 
 using namespace tgmx;
 
+// Which problems take the LDS-staged kernel: M >= 6144 rows.  A function of M ALONE, like the few-row kernel's M <= 2048: the levels of a
+// hop tree that share a layer's weights run as one row batch in one composition and level by level in another (12 600 = 600 + 12 000
+// rows: tests/test_tgat_backward_gpu.py compares the two bit for bit), and a threshold on the number of 64 x 64 blocks -- which fits the
+// measurements a little better (8 118 x 172 x 172, 381 blocks: 13.4 us direct / 14.0 staged; 8 118 x 200 x 116, 508 blocks: 14.0 / 11.2)
+// -- put 12 000 x 51 x 273 x 2 heads and 12 600 x 51 x 273 x 2 heads on different sides.  Below ~6 k rows a launch is at most 1.5 rounds of
+// blocks per CU and the K-split kernel's four short chains per 32 x 64 tile finish sooner (4 100 x 172 x 172: 8.3 / 10.4 us).
+constexpr long long kGemmLdsMinRows = 6144;
+static bool gemm_takes_lds(long long M, int /*N*/, int /*batch*/) { return M >= kGemmLdsMinRows; }
+
 extern "C" int tgmx_sgemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
                              int32_t N, int32_t K, const float* bias, int32_t relu, int32_t batch, int64_t strideA,
                              int64_t strideB, int64_t strideC, tgmx_stream_t stream) {
@@ -2272,6 +2395,16 @@ extern "C" int tgmx_sgemm_nt(const float* A, int64_t lda, const float* B, int64_
     else TGMX_GEMM_S(false, false);
 #undef TGMX_GEMM_S
     TGMX_CHECK_LAUNCH("sgemm_nt(small)");
+    return TGMX_OK;
+  }
+  static const bool lds_knob = [] { const char* e = getenv("TGMX_GEMM_LDS"); return !(e && e[0] == '0'); }();  // A/B knob: 0 = the direct kernel
+  if (lds_knob && K > 16 && gemm_takes_lds(M, N, batch)) {  // many rows: whole lines through LDS (see sgemm_nt_lds_kernel)
+    const dim3 lgrid((unsigned)((M + kLdsBM - 1) / kLdsBM), (unsigned)((N + kLdsBN - 1) / kLdsBN), (unsigned)batch);
+    if (av && bv) hipLaunchKernelGGL((sgemm_nt_lds_kernel<true, true>), lgrid, block, 0, st, g);
+    else if (av) hipLaunchKernelGGL((sgemm_nt_lds_kernel<true, false>), lgrid, block, 0, st, g);
+    else if (bv) hipLaunchKernelGGL((sgemm_nt_lds_kernel<false, true>), lgrid, block, 0, st, g);
+    else hipLaunchKernelGGL((sgemm_nt_lds_kernel<false, false>), lgrid, block, 0, st, g);
+    TGMX_CHECK_LAUNCH("sgemm_nt(lds)");
     return TGMX_OK;
   }
   const bool split = K > 16;
@@ -2315,6 +2448,21 @@ int tgmx_internal_sgemm_nt_pair(const GemmCall& c0, const GemmCall& c1, tgmx_str
     p.g[q] = GemmArgs{c.A, c.B, c.C, c.bias, c.lda, c.ldb, c.ldc, c.sA, c.sB, c.sC, c.M, c.N, c.K, c.relu};
     p.ny[q] = (unsigned)((c.N + 63) / 64);
     p.nz[q] = (unsigned)c.batch;
+  }
+  // a pairable problem (aligned, K > 16) takes the same kernel as alone: the LDS-staged one if gemm_takes_lds (unless TGMX_GEMM_LDS=0)
+  static const bool lds_knob = [] { const char* e = getenv("TGMX_GEMM_LDS"); return !(e && e[0] == '0'); }();
+  const bool l0 = gemm_takes_lds(c0.M, c0.N, c0.batch), l1 = gemm_takes_lds(c1.M, c1.N, c1.batch);
+  if (lds_knob && l0 && l1) {
+    p.tiles0 = (unsigned)((c0.M + kLdsBM - 1) / kLdsBM);
+    const unsigned lt1 = (unsigned)((c1.M + kLdsBM - 1) / kLdsBM);
+    const dim3 lgrid(p.tiles0 + lt1, p.ny[0] > p.ny[1] ? p.ny[0] : p.ny[1], p.nz[0] > p.nz[1] ? p.nz[0] : p.nz[1]);
+    hipLaunchKernelGGL(sgemm_nt_lds_pair_kernel, lgrid, dim3(256), 0, (hipStream_t)stream, p);
+    TGMX_CHECK_LAUNCH("sgemm_nt_pair(lds)");
+    return TGMX_OK;
+  }
+  if (lds_knob && (l0 || l1)) {  // mixed: each through its own kernel
+    if (int rc = solo(c0)) return rc;
+    return solo(c1);
   }
   p.tiles0 = (unsigned)((c0.M + 31) / 32);
   const unsigned tiles1 = (unsigned)((c1.M + 31) / 32);
