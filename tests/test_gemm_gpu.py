@@ -142,3 +142,43 @@ def test_sgemm_nt_many_rows_unaligned_views_equal_the_aligned_call():
     _ops.sgemm_nt(Ac[:, :K], Bc[:, :K], o_copy)
     assert torch.equal(o_view, o_copy)
     assert (o_view.double() - _ref(A, B, None, False)).abs().max().item() <= 4e-4
+
+
+_PAIR_SCRIPT = r'''
+import hashlib, sys, torch
+sys.path.insert(0, %r)
+from tgm_amd.nn import GraphAttentionEmbedding, Time2Vec
+out = []
+for U, E in ((3000, 5000), (5000, 13000), (8000, 13000)):  # K-split | K-split, K-split | LDS-staged, LDS-staged | LDS-staged
+    torch.manual_seed(U)
+    enc = GraphAttentionEmbedding(100, 100, 16, Time2Vec(100)).to('cuda').eval()
+    x = torch.randn(U, 100, device='cuda')
+    lu = torch.randint(1_000_000, 2_000_000, (U,), device='cuda')
+    ei = torch.stack([torch.randint(0, U, (E,), device='cuda'), torch.randint(0, U, (E,), device='cuda')])
+    t = torch.randint(0, 1_000_000, (E,), device='cuda')
+    msg = torch.rand(E, 16, device='cuda')
+    with torch.no_grad():
+        z = enc(x, lu, ei, t, msg)
+    assert torch.isfinite(z).all()
+    out.append(hashlib.sha256(z.cpu().numpy().tobytes()).hexdigest())
+print('HASHES', ' '.join(out))
+'''
+
+
+def test_paired_gemm_launches_equal_their_solo_launches_bit_for_bit():
+    """TransformerConv's projections run as ONE launch of two GEMMs (node projections beside the edge projection).  Whatever kernels the
+    two problems take alone -- both K-split, both LDS-staged (M >= 6144), or one of each (cfg 3 early in a stream: ~5 k unique nodes beside
+    ~13 k edges) -- the pair gives each problem's own bits: TGMX_GEMM_PAIR=0 (two launches) against the default, in fresh processes
+    (the knob is read once)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for knob in ('0', '1'):
+        env = dict(os.environ, TGMX_GEMM_PAIR=knob)
+        r = subprocess.run([sys.executable, '-c', _PAIR_SCRIPT % root], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got[knob] = [ln for ln in r.stdout.splitlines() if ln.startswith('HASHES')][-1]
+    assert got['0'] == got['1'], got

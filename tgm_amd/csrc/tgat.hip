@@ -63,8 +63,9 @@ __device__ __forceinline__ void load_kn(const float* __restrict__ row, int kb, i
 // register layout (no LDS staging).  SPLIT = false: the 4 waves of a block own 4 row tiles (128 rows).
 // SPLIT = true (few tiles): the 4 waves share ONE 32 x 64 tile, wave w takes k-steps w, w + 4, ... and the
 // partial tiles meet in LDS (fixed summation order: deterministic).
-template <bool AV, bool BV, bool SPLIT, int kGemmK>
-__device__ __forceinline__ void sgemm_nt_body(const GemmArgs& g, const unsigned bx, const unsigned by, const unsigned bz) {
+// EXT: the K-split reduction's 32 KB live in LDS the caller provides (a kernel that also instantiates the LDS-staged body: one buffer for both)
+template <bool AV, bool BV, bool SPLIT, int kGemmK, bool EXT = false>
+__device__ __forceinline__ void sgemm_nt_body(const GemmArgs& g, const unsigned bx, const unsigned by, const unsigned bz, float* ext = nullptr) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 31, half = lane >> 5;
   const long long m0 = SPLIT ? (long long)bx * 32 : (long long)bx * 128 + wave * 32;
@@ -114,7 +115,13 @@ __device__ __forceinline__ void sgemm_nt_body(const GemmArgs& g, const unsigned 
     }
   }
   if (SPLIT) {
-    __shared__ float part[4][32][kWave];  // [wave][acc register (0-15: acc0, 16-31: acc1)][lane]
+    float (*part)[32][kWave];  // [wave][acc register (0-15: acc0, 16-31: acc1)][lane]
+    if constexpr (EXT) {
+      part = reinterpret_cast<float (*)[32][kWave]>(ext);
+    } else {
+      __shared__ float part_own[4][32][kWave];
+      part = part_own;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       part[wave][r][lane] = acc0[r];
@@ -166,6 +173,7 @@ __global__ __launch_bounds__(256) void sgemm_nt_kernel(const GemmArgs g) {
 struct GemmPairArgs {
   GemmArgs g[2];
   unsigned tiles0, ny[2], nz[2];
+  int lds[2];  // (mixed pairs) the problem takes the LDS-staged body
 };
 
 __global__ __launch_bounds__(256) void sgemm_nt_pair_kernel(const GemmPairArgs p) {
@@ -287,6 +295,18 @@ __global__ __launch_bounds__(256) void sgemm_nt_lds_pair_kernel(const GemmPairAr
   const unsigned which = blockIdx.x >= p.tiles0;
   if (blockIdx.y >= p.ny[which] || blockIdx.z >= p.nz[which]) return;
   sgemm_nt_lds_body<true, true>(p.g[which], which ? blockIdx.x - p.tiles0 : blockIdx.x, blockIdx.y, blockIdx.z, smem);
+}
+
+// ... and a pair whose problems take DIFFERENT kernels alone (cfg 3's projections: ~5 k unique nodes beside ~13 k edges): each through
+// its own body, unchanged, over one LDS buffer -- still one launch, and each result bit for bit what its own launch gives
+__global__ __launch_bounds__(256) void sgemm_nt_mixed_pair_kernel(const GemmPairArgs p) {
+  __shared__ __attribute__((aligned(16))) float smem[kLdsFloats];
+  static_assert(kLdsFloats >= 4 * 32 * kWave, "the K-split reduction fits the staging buffer");
+  const unsigned which = blockIdx.x >= p.tiles0;
+  if (blockIdx.y >= p.ny[which] || blockIdx.z >= p.nz[which]) return;
+  const unsigned bx = which ? blockIdx.x - p.tiles0 : blockIdx.x;
+  if (p.lds[which]) sgemm_nt_lds_body<true, true>(p.g[which], bx, blockIdx.y, blockIdx.z, smem);
+  else sgemm_nt_body<true, true, true, 8, true>(p.g[which], bx, blockIdx.y, blockIdx.z, smem);
 }
 
 // The FEW-ROW variant (M <= 2048: the 600-row layer of the headline forward, whose five GEMMs were 41 us of a 185 us forward at ~8 us
@@ -2448,6 +2468,7 @@ int tgmx_internal_sgemm_nt_pair(const GemmCall& c0, const GemmCall& c1, tgmx_str
     p.g[q] = GemmArgs{c.A, c.B, c.C, c.bias, c.lda, c.ldb, c.ldc, c.sA, c.sB, c.sC, c.M, c.N, c.K, c.relu};
     p.ny[q] = (unsigned)((c.N + 63) / 64);
     p.nz[q] = (unsigned)c.batch;
+    p.lds[q] = 0;
   }
   // a pairable problem (aligned, K > 16) takes the same kernel as alone: the LDS-staged one if gemm_takes_lds (unless TGMX_GEMM_LDS=0)
   static const bool lds_knob = [] { const char* e = getenv("TGMX_GEMM_LDS"); return !(e && e[0] == '0'); }();
@@ -2460,9 +2481,14 @@ int tgmx_internal_sgemm_nt_pair(const GemmCall& c0, const GemmCall& c1, tgmx_str
     TGMX_CHECK_LAUNCH("sgemm_nt_pair(lds)");
     return TGMX_OK;
   }
-  if (lds_knob && (l0 || l1)) {  // mixed: each through its own kernel
-    if (int rc = solo(c0)) return rc;
-    return solo(c1);
+  if (lds_knob && (l0 || l1)) {  // mixed: each through its own body, one launch
+    p.lds[0] = l0; p.lds[1] = l1;
+    const unsigned t0 = (unsigned)(l0 ? (c0.M + kLdsBM - 1) / kLdsBM : (c0.M + 31) / 32), t1 = (unsigned)(l1 ? (c1.M + kLdsBM - 1) / kLdsBM : (c1.M + 31) / 32);
+    p.tiles0 = t0;
+    const dim3 mgrid(t0 + t1, p.ny[0] > p.ny[1] ? p.ny[0] : p.ny[1], p.nz[0] > p.nz[1] ? p.nz[0] : p.nz[1]);
+    hipLaunchKernelGGL(sgemm_nt_mixed_pair_kernel, mgrid, dim3(256), 0, (hipStream_t)stream, p);
+    TGMX_CHECK_LAUNCH("sgemm_nt_pair(mixed)");
+    return TGMX_OK;
   }
   p.tiles0 = (unsigned)((c0.M + 31) / 32);
   const unsigned tiles1 = (unsigned)((c1.M + 31) / 32);
