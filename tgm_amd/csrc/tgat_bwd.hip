@@ -48,22 +48,37 @@ __device__ __forceinline__ void sgemm_tn_block(const GemmTnArgs& g, int bx, int 
   const int nb0 = n0 + i < g.N ? n0 + i : g.N - 1;
   const int nb1 = n0 + 32 + i < g.N ? n0 + 32 + i : g.N - 1;
   floatx16 acc0 = {0}, acc1 = {0};
-  for (long long r = r0; r < r1; r += 8) {  // 4 MFMA steps (k = 2 rows each) per iteration
-    float a[4], b0[4], b1[4];
+  // 4 MFMA steps (k = 2 rows each) per iteration; the NEXT iteration's twelve values are requested before this one's MFMAs (the loop was
+  // load -> wait -> 8 MFMAs: one exposed latency per 8 rows; same values in the same order: bit-identical)
+  float a[4], b0[4], b1[4], an[4], b0n[4], b1n[4];
+  auto fetch = [&](long long r, float (&x)[4], float (&y0)[4], float (&y1)[4]) __attribute__((always_inline)) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const long long rr = r + 2 * u + half;
       const bool ok = rr < r1;
       const long long rc = ok ? rr : r0;
       const float av = A[rc * g.lda + ma], bv0 = B[rc * g.ldb + nb0], bv1 = B[rc * g.ldb + nb1];
-      a[u] = ok ? av : 0.f;
-      b0[u] = ok ? bv0 : 0.f;
-      b1[u] = ok ? bv1 : 0.f;
+      x[u] = ok ? av : 0.f;
+      y0[u] = ok ? bv0 : 0.f;
+      y1[u] = ok ? bv1 : 0.f;
     }
+  };
+  if (r0 < r1) fetch(r0, a, b0, b1);
+  for (long long r = r0; r < r1; r += 8) {
+    const bool more = r + 8 < r1;
+    if (more) fetch(r + 8, an, b0n, b1n);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b0[u], acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b1[u], acc1, 0, 0, 0);
+    }
+    if (more) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a[u] = an[u];
+        b0[u] = b0n[u];
+        b1[u] = b1n[u];
+      }
     }
   }
   float* __restrict__ P = g.partial + ((long long)batch * g.splits + split) * g.M * g.N;
