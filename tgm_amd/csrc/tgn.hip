@@ -15,6 +15,7 @@
 #include <rocprim/iterator/counting_iterator.hpp>
 
 #include "common.h"
+#include "lanes.h"
 
 namespace tgmx {
 
@@ -242,9 +243,220 @@ struct TconvArgs {
   // in LDS, or for a segment longer than kTconvSegLds into order_big[lo .. hi)
   int unsorted;
   int64_t* order_big;
+  int short_ok;  // floats per lane of the register-resident walks (4 or 2), 0 = the generic walk (tconv_short_ok)
 };
 
+// The register-resident walks apply to H = 2 heads of C = V c columns, c <= 32, V = 4 or 2 floats per lane (cfg 3: C = 50 -> V = 2), rows at
+// V-float-aligned addresses: returns V, or 0 for the generic walk
+static int tconv_short_ok(const TconvArgs& a) {
+  static const bool knob = !(getenv("TGMX_TCONV_SHORT") && atoi(getenv("TGMX_TCONV_SHORT")) == 0);  // A/B knob: 0 = the generic four-wave walk
+  if (!knob || a.H != 2) return 0;
+  const uintptr_t bits = (uintptr_t)a.q | (uintptr_t)a.k | (uintptr_t)a.v | (uintptr_t)a.eproj | (uintptr_t)a.out;
+  if (a.C % 4 == 0 && a.C / 4 <= 32 && (bits & 15) == 0) return 4;
+  if (a.C % 2 == 0 && a.C / 2 <= 32 && (bits & 7) == 0) return 2;
+  return 0;
+}
+
 constexpr int kTconvSegLds = 1024;
+constexpr int kTconvShort = 16;  // segments of up to this many edges take the one-wave, register-resident path below
+
+// The register-resident walks of tconv_attend_kernel (round 5, last session).  A target's incoming edges on ONE wave in the TGAT attention
+// row's layout: lane (h, c) = (lane >> 5, lane & 31) owns V consecutive columns (V = 4 or 2 floats: one 16- / 8-byte load; C / V <= 32) of
+// head h of every row it touches (H = 2), the edges go through in blocks of four whose 12 row pieces (k, v of the source, the edge
+// projection) are ALL requested before the previous block is scored, a score is a five-step butterfly inside the head's 32 lanes (DPP, no
+// LDS) so every lane of a head holds the head's softmax state and weights its own columns -- no broadcast, no barrier.
+//   * a target with <= kTconvShort edges (cfg 3: k = 10 sampled neighbors per hop -- nearly every target): wave 0 alone, ids ranked in registers;
+//   * a longer segment (the review shape's hub items: hundreds of edges, whose walk SETS the launch's duration): the same walk on each of
+//     the four waves over its quarter of the positions, the four states merged in LDS in wave order.
+// What they replace (the generic walk below: one edge at a time, every edge an exposed round trip of 4-byte loads, a 64-lane shuffle
+// reduction through the LDS crossbar per edge and head, three barriers and an LDS merge per head): 40.4 -> 13.9 us per cfg 3 batch,
+// pipeline 200-201 -> 168-170 us (same box, alternating runs).  Same online-softmax recurrence over the edges in ascending edge id; the
+// sums differ from the generic walk's at rounding level (another split of the columns over lanes): same tolerance against the restatement.
+// V floats (2 or 4: one 8- / 16-byte load) of a row: the piece of a head's columns a lane owns
+template <int V>
+struct TcVec {
+  float f[V];
+};
+template <int V>
+__device__ __forceinline__ TcVec<V> tc_load(const float* __restrict__ p) {
+  TcVec<V> r;
+  if constexpr (V == 4) {
+    const float4 x = *reinterpret_cast<const float4*>(p);
+    r.f[0] = x.x; r.f[1] = x.y; r.f[2] = x.z; r.f[3] = x.w;
+  } else {
+    const float2 x = *reinterpret_cast<const float2*>(p);
+    r.f[0] = x.x; r.f[1] = x.y;
+  }
+  return r;
+}
+template <int V>
+__device__ __forceinline__ void tc_store(float* __restrict__ p, const TcVec<V>& r) {
+  if constexpr (V == 4) *reinterpret_cast<float4*>(p) = make_float4(r.f[0], r.f[1], r.f[2], r.f[3]);
+  else *reinterpret_cast<float2*>(p) = make_float2(r.f[0], r.f[1]);
+}
+template <int V>
+__device__ __forceinline__ TcVec<V> tc_zero() {
+  TcVec<V> r;
+#pragma unroll
+  for (int u = 0; u < V; ++u) r.f[u] = 0.f;
+  return r;
+}
+
+// the online-softmax state of one wave over the edges it has walked so far: every lane of a head holds the head's (m, l), a lane its columns' sums
+template <int V>
+struct TconvWalk {
+  float m, l;
+  TcVec<V> acc;
+};
+
+// Walk the n_here (<= 64) edges whose ids / sources lanes 0 .. n_here - 1 hold, in lane order, four at a time.  col = the lane's first column of
+// the H C-wide row (its head's h C + V (lane & 31)), `on` = the lane owns columns at all.
+template <int V>
+__device__ __forceinline__ void tconv_walk_block(const TconvArgs& a, const TcVec<V> q, const bool on, const int col, const int h, const int my_e,
+                                                 const int my_j32, const int n_here, TconvWalk<V>& st) {
+  const long long HC = (long long)a.H * a.C;
+  const float* __restrict__ kp = a.k + col;
+  const float* __restrict__ vp = a.v + col;
+  const float* __restrict__ ep = a.eproj + col;
+  TcVec<V> kk[4], vv[4], ee[4], kn[4], vn[4], en[4];
+  auto request = [&](int c0, TcVec<V> (&K)[4], TcVec<V> (&Vv)[4], TcVec<V> (&E)[4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int sl = c0 + s < n_here ? c0 + s : n_here - 1;  // (clamped: a position past the block re-reads its last edge, not used below)
+      const long long e = __builtin_amdgcn_readlane(my_e, sl), j = __builtin_amdgcn_readlane(my_j32, sl);
+      K[s] = on ? tc_load<V>(kp + j * HC) : tc_zero<V>();
+      Vv[s] = on ? tc_load<V>(vp + j * HC) : tc_zero<V>();
+      E[s] = on ? tc_load<V>(ep + e * HC) : tc_zero<V>();
+    }
+  };
+  request(0, kk, vv, ee);
+  float m = st.m, l = st.l;
+  TcVec<V> acc = st.acc;
+  for (int c0 = 0; c0 < n_here; c0 += 4) {
+    const bool more = c0 + 4 < n_here;
+    if (more) request(c0 + 4, kn, vn, en);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (c0 + s < n_here) {  // wave-uniform
+        float p = q.f[0] * (kk[s].f[0] + ee[s].f[0]);
+#pragma unroll
+        for (int u = 1; u < V; ++u) p = __fmaf_rn(q.f[u], kk[s].f[u] + ee[s].f[u], p);
+        p += lanes::lane_xor<16>(p);  // the head's 32 lanes (lanes past C / V carry zeros)
+        p += lanes::lane_xor<8>(p);
+        p += lanes::lane_xor<4>(p);
+        p += lanes::lane_xor<2>(p);
+        p += lanes::lane_xor<1>(p);
+        const float sc = p * a.scale;
+        const float mn = sc > m ? sc : m;
+        const float corr = expf(m - mn), w = expf(sc - mn);
+        const int e = __builtin_amdgcn_readlane(my_e, c0 + s);
+        // the softmax normalises over every incoming edge; dropout then zeroes / rescales single coefficients
+        const float wd = w * dropout_scale(a.drop, (unsigned long long)e * a.H + h);
+#pragma unroll
+        for (int u = 0; u < V; ++u) acc.f[u] = acc.f[u] * corr + wd * (vv[s].f[u] + ee[s].f[u]);
+        l = l * corr + w;
+        m = mn;
+      }
+    }
+    if (more) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        kk[s] = kn[s];
+        vv[s] = vn[s];
+        ee[s] = en[s];
+      }
+    }
+  }
+  st.m = m;
+  st.l = l;
+  st.acc = acc;
+}
+
+template <int V>
+__device__ __forceinline__ void tconv_attend_short(const TconvArgs& a, const long long i, const long long lo, const int n, const int lane) {
+  const int CV = a.C / V;
+  const long long HC = (long long)a.H * a.C;
+  const int h = lane >> 5, cl = lane & 31;
+  const bool on = cl < CV;
+  const int col = h * a.C + V * (on ? cl : 0);
+  // the segment's edge ids, ascending (lane t holds the t-th), and their sources
+  int my_e = 0;
+  if (lane < n) my_e = (int)a.order[lo + lane];  // (edge ids of one batch: far below 2^31)
+  if (a.unsorted && n > 1) {  // rank = number of smaller ids (ids are distinct); the id travels to the lane of its rank
+    int rank = 0;
+#pragma unroll
+    for (int t = 0; t < kTconvShort; ++t) {
+      const int o = __builtin_amdgcn_readlane(my_e, t);
+      rank += (t < n && o < my_e) ? 1 : 0;
+    }
+    my_e = __builtin_amdgcn_ds_permute((lane < n ? rank : lane) << 2, my_e);
+  }
+  long long my_j = 0;
+  if (lane < n) my_j = a.src[my_e];
+  const TcVec<V> q = on ? tc_load<V>(a.q + i * HC + col) : tc_zero<V>();
+  TconvWalk<V> st{-__builtin_inff(), 0.f, tc_zero<V>()};
+  tconv_walk_block<V>(a, q, on, col, h, my_e, (int)my_j, n, st);
+  if (on) {
+    float* __restrict__ op = a.out + i * HC + col;
+    TcVec<V> o = tc_load<V>(op);
+#pragma unroll
+    for (int u = 0; u < V; ++u) o.f[u] += st.acc.f[u] / st.l;
+    tc_store<V>(op, o);
+  }
+}
+
+// a LONG segment (a hub: hundreds of incoming edges at the review shape, whose walk sets the launch's duration) with the same block walk on
+// each of the workgroup's four waves: wave w takes positions lo + w, lo + w + 4, ... 64 at a time (lane t fetches the id and the source of
+// the t-th), the four states meet in LDS and are merged in wave order (deterministic).  ids(p) = the segment's p-th edge id, ascending.
+template <int V, class Ids>
+__device__ __forceinline__ void tconv_attend_long(const TconvArgs& a, const long long i, const long long lo, const long long hi, const int lane,
+                                                  const int wave, Ids ids, float (*s_wm)[2], float (*s_wl)[2], float (*s_wacc)[kWave][4]) {
+  constexpr int kWavesPerTarget = 4;
+  const int CV = a.C / V;
+  const long long HC = (long long)a.H * a.C;
+  const int h = lane >> 5, cl = lane & 31;
+  const bool on = cl < CV;
+  const int col = h * a.C + V * (on ? cl : 0);
+  const TcVec<V> q = on ? tc_load<V>(a.q + i * HC + col) : tc_zero<V>();
+  TconvWalk<V> st{-__builtin_inff(), 0.f, tc_zero<V>()};
+  for (long long p0 = lo + wave; p0 < hi; p0 += (long long)kWavesPerTarget * kWave) {
+    const long long my_p = p0 + (long long)kWavesPerTarget * lane;
+    int my_e = 0;
+    long long my_j = 0;
+    if (my_p < hi) {
+      my_e = ids(my_p - lo);
+      my_j = a.src[my_e];
+    }
+    const long long left = (hi - p0 + kWavesPerTarget - 1) / kWavesPerTarget;
+    tconv_walk_block<V>(a, q, on, col, h, my_e, (int)my_j, left < kWave ? (int)left : kWave, st);
+  }
+  if (cl == 0) {
+    s_wm[wave][h] = st.m;
+    s_wl[wave][h] = st.l;
+  }
+#pragma unroll
+  for (int u = 0; u < V; ++u) s_wacc[wave][lane][u] = st.acc.f[u];
+  __syncthreads();
+  if (wave == 0 && on) {
+    float M = s_wm[0][h];
+#pragma unroll
+    for (int w2 = 1; w2 < kWavesPerTarget; ++w2) M = fmaxf(M, s_wm[w2][h]);
+    float L = 0.f;
+    TcVec<V> A = tc_zero<V>();
+#pragma unroll
+    for (int w2 = 0; w2 < kWavesPerTarget; ++w2) {
+      const float f = s_wl[w2][h] > 0.f ? expf(s_wm[w2][h] - M) : 0.f;  // a wave without edges has m = -inf, l = 0
+      L += s_wl[w2][h] * f;
+#pragma unroll
+      for (int u = 0; u < V; ++u) A.f[u] += s_wacc[w2][lane][u] * f;
+    }
+    float* __restrict__ op = a.out + i * HC + col;
+    TcVec<V> o = tc_load<V>(op);
+#pragma unroll
+    for (int u = 0; u < V; ++u) o.f[u] += A.f[u] / L;
+    tc_store<V>(op, o);
+  }
+}
 
 // online softmax over a target's incoming edges, head by head
 __global__ __launch_bounds__(256) void tconv_attend_kernel(const TconvArgs a) {
@@ -259,6 +471,13 @@ __global__ __launch_bounds__(256) void tconv_attend_kernel(const TconvArgs a) {
   const int lane = lane_id(), wave = threadIdx.x >> 6;
   const long long lo = a.seg_lo[i], hi = a.seg_hi[i];
   if (hi <= lo) return;  // no incoming edge: only the skip term
+  if (a.short_ok && hi - lo <= kTconvShort) {  // few edges: one wave, everything in registers (the other three waves are done)
+    if (wave == 0) {
+      if (a.short_ok == 4) tconv_attend_short<4>(a, i, lo, (int)(hi - lo), lane);
+      else tconv_attend_short<2>(a, i, lo, (int)(hi - lo), lane);
+    }
+    return;
+  }
   const int HC = a.H * a.C;
   __shared__ int s_raw[kTconvSegLds], s_sorted[kTconvSegLds];  // (edge ids of one batch: far below 2^31)
   const int64_t* ord = a.order + lo;  // position p of the segment reads ord[p - lo] / s_sorted[p - lo] (no __restrict__: the hub path writes what it reads)
@@ -322,6 +541,14 @@ __global__ __launch_bounds__(256) void tconv_attend_kernel(const TconvArgs a) {
       __syncthreads();
       ord = src_buf;
     }
+  }
+  if (a.short_ok) {
+    __shared__ float s_wm[kWavesPerTarget][2], s_wl[kWavesPerTarget][2];
+    __shared__ float s_wacc[kWavesPerTarget][kWave][4];
+    auto ids = [&](long long p) -> int { return in_lds ? s_sorted[p] : (int)ord[p]; };
+    if (a.short_ok == 4) tconv_attend_long<4>(a, i, lo, hi, lane, wave, ids, s_wm, s_wl, s_wacc);
+    else tconv_attend_long<2>(a, i, lo, hi, lane, wave, ids, s_wm, s_wl, s_wacc);
+    return;
   }
   for (int h = 0; h < a.H; ++h) {
     for (int c0 = 0; c0 < a.C; c0 += kWave) {  // output columns of this head handled by this lane
@@ -817,6 +1044,7 @@ extern "C" int tgmx_tconv_attend(const float* q, const float* k, const float* v,
   a.drop = make_dropout(drop);
   a.unsorted = 0;
   a.order_big = nullptr;
+  a.short_ok = tconv_short_ok(a);
   hipLaunchKernelGGL(tconv_attend_kernel, dim3((unsigned)U), dim3(256), 0, (hipStream_t)stream, a);
   TGMX_CHECK_LAUNCH("tconv_attend");
   return TGMX_OK;
@@ -1076,6 +1304,7 @@ extern "C" int tgmx_tconv_forward(const tgmx_tconv_fwd_t* a, tgmx_stream_t strea
     t.drop = make_dropout(nullptr);
     t.unsorted = 1;
     t.order_big = a->order_big;
+    t.short_ok = tconv_short_ok(t);
     hipLaunchKernelGGL(tconv_attend_kernel, dim3((unsigned)U), dim3(256), 0, st, t);
     TGMX_CHECK_LAUNCH("tconv_attend");
     return TGMX_OK;
@@ -1172,6 +1401,7 @@ extern "C" int tgmx_tgn_step(const tgmx_tgn_step_t* a, tgmx_stream_t stream) {
     t.drop = make_dropout(nullptr);
     t.unsorted = 1;
     t.order_big = c->order_big;
+    t.short_ok = tconv_short_ok(t);
     hipLaunchKernelGGL(tconv_attend_kernel, dim3((unsigned)U), dim3(256), 0, st, t);
     TGMX_CHECK_LAUNCH("tgn_step(attend)");
   }
