@@ -382,3 +382,30 @@ def test_tgn_step_equals_the_three_module_calls(aggr):
         y2, y, ylu = step.batch(batch)
     assert step.fast_calls + step.fallback_calls == 41 and torch.equal(z2, y2) and torch.equal(mem_a.memory, mem_b.memory)
 
+
+
+@pytest.mark.parametrize('inference', [False, True])
+@pytest.mark.parametrize('emb,U,E,n_hot', [(100, 2000, 3000, 0), (128, 2000, 3000, 0), (128, 300, 4000, 40), (100, 50, 9000, 3), (6, 300, 2000, 20), (128, 40, 9000, 2)])
+def test_graph_attention_embedding_walks_match_restatement(emb, U, E, n_hot, inference):
+    """The three walks of ``tconv_attend_kernel`` against the restatement: two floats per lane (emb 100: C = 50 per head, cfg 3),
+    four floats per lane (emb 128: C = 64), the generic walk (emb 6: C = 3) -- over segments that are all short (one wave, ids ranked
+    in registers), a few hundred edges long (four waves, sorted in LDS) and thousands long (four waves, merge-sorted through memory)."""
+    from oracle.tgn_ref import graph_attention_embedding_ref
+    from tgm_amd.nn import GraphAttentionEmbedding, Time2Vec
+
+    torch.manual_seed(emb * 7 + U)
+    M, D, T_ = 100, 16, 100
+    enc = GraphAttentionEmbedding(M, emb, D, Time2Vec(T_)).to(DEV).eval()
+    x = torch.randn(U, M)
+    last_update = torch.randint(1_000_000, 2_000_000, (U,))
+    dst = torch.randint(0, n_hot, (E,)) if n_hot else torch.randint(0, U, (E,))
+    if n_hot:
+        dst[:500] = torch.randint(0, U, (500,))  # and a tail of short segments
+    edge_index = torch.stack([torch.randint(0, U, (E,)), dst])
+    t = torch.randint(0, 1_000_000, (E,))
+    msg = torch.rand(E, D)
+    with _grad_mode(inference):
+        out = enc(x.to(DEV), last_update.to(DEV), edge_index.to(DEV), t.to(DEV), msg.to(DEV))
+    ref = graph_attention_embedding_ref({k: v.cpu() for k, v in enc.state_dict().items()}, x, last_update, edge_index, t, msg)
+    assert out.shape == (U, emb)
+    close(out.detach().cpu(), ref, f'graph attention embedding (emb {emb}, U {U}, E {E})')
