@@ -684,6 +684,10 @@ class TGNStep:
         self._args = _native.TgnStep()
         self._ws = self._fl = self._ints = None
         self._wkey = None
+        self._static_key = None  # addresses behind the argument blocks' static fields (see __call__)
+        self._lib = None
+        self._seg_ws_edges, self._seg_ws_bytes = -1, 0  # the segment sort's workspace covers edge lists up to this size
+        self._blocks = (None, None)  # the memory's / the convolution's argument blocks the static fields were written into
         self.fast_calls = self.fallback_calls = 0
 
     def batch(self, batch):
@@ -743,15 +747,6 @@ class TGNStep:
                        conv.lin_edge.weight.detach()) + conv._stacked_projections()
             self._wkey = wkey
         tw, tb, W_ih, b_ih, W_hh, b_hh, etw, etb, W_edge, W4, b4 = self._w
-        base = ws.data_ptr()
-        a.nodes, a.R, a.memory, a.last_update, a.M, a.num_nodes = nodes.data_ptr(), R, mem.memory.data_ptr(), mem.last_update.data_ptr(), M, mem.num_nodes
-        a.st_lo_s, a.st_cnt_s, a.st_lo_d, a.st_cnt_d = (mem._st_lo[0].data_ptr(), mem._st_cnt[0].data_ptr(), mem._st_lo[1].data_ptr(),
-                                                        mem._st_cnt[1].data_ptr())  # fmt: skip
-        a.log_other, a.log_t, a.log_raw, a.D = mem._log_other.data_ptr(), mem._log_t.data_ptr(), mem._log_raw.data_ptr(), D
-        a.tw, a.tb, a.T, a.mean = tw.data_ptr(), tb.data_ptr(), T, mem.aggr_module.mean
-        a.W_ih, a.b_ih, a.W_hh, a.b_hh = W_ih.data_ptr(), b_ih.data_ptr(), W_hh.data_ptr(), b_hh.data_ptr()
-        a.ws_aggr, a.ws_h, a.ws_gi, a.ws_gh = base, base + 4 * R * W, base + 4 * R * (W + M), base + 4 * R * (W + 4 * M)
-        a.out_mem, a.out_lu, a.assoc, a.stamp = z.data_ptr(), lu.data_ptr(), mem._assoc64.data_ptr(), mem._stamp
         # ---- GraphAttentionEmbedding.forward: edge encoding + TransformerConv (inference) ---------------------------------------------
         U, H, C = R, conv.heads, conv.out_channels
         HC = H * C
@@ -765,11 +760,17 @@ class TGNStep:
         et64, msg = i64c(edge_t), f32c(edge_x)
         De, Te = msg.shape[1], emb.time_enc.time_dim
         qkvs = torch.empty((4, U, HC), dtype=torch.float32, device=dev)
-        lib = _native.load()
-        need = int(lib.tgmx_segment_sort_workspace_bytes(E))
+        lib = self._lib
+        if lib is None:
+            lib = self._lib = _native.load()
         wsd = getattr(conv, '_seg_ws', None)
-        if wsd is None or wsd[0].device != dev or wsd[0].numel() < need:
-            wsd = conv._seg_ws = (torch.empty(need, dtype=torch.uint8, device=dev), torch.zeros(1, dtype=torch.int32, device=dev))
+        if wsd is None or E > self._seg_ws_edges or wsd[0].numel() < self._seg_ws_bytes or wsd[0].device != dev:
+            # (the workspace bound is monotone in E: asked again only for a larger edge list than any before, with 25 % of slack)
+            cap = max(E + E // 4, self._seg_ws_edges)
+            need = int(lib.tgmx_segment_sort_workspace_bytes(cap))
+            if wsd is None or wsd[0].device != dev or wsd[0].numel() < need:
+                wsd = conv._seg_ws = (torch.empty(need, dtype=torch.uint8, device=dev), torch.zeros(1, dtype=torch.int32, device=dev))
+            self._seg_ws_edges, self._seg_ws_bytes = cap, need
         Ep, Up = E + (E & 1), U + (U & 1)
         fl = self._fl = self._grow(self._fl, E * (Te + De + HC), torch.float32, dev)
         ints = self._ints = self._grow(self._ints, 2 * Ep + 3 * Up, torch.int64, dev)
@@ -779,21 +780,45 @@ class TGNStep:
         c = getattr(conv, '_fwd_args', None)
         if c is None:
             c = conv._fwd_args = _native.TconvFwd()
-        c.x, c.U, c.in_ch, c.last_update_local = z.data_ptr(), U, M, lu.data_ptr()
-        c.src, c.tgt, c.t, c.msg, c.E, c.D, c.T = src_e.data_ptr(), tgt_e.data_ptr(), et64.data_ptr(), msg.data_ptr(), E, De, Te
-        c.tw, c.tb, c.W4, c.b4, c.W_edge, c.H, c.C = etw.data_ptr(), etb.data_ptr(), W4.data_ptr(), b4.data_ptr(), W_edge.data_ptr(), H, C
-        flp, ip = fl.data_ptr(), ints.data_ptr()
+        if a is not self._blocks[0] or c is not self._blocks[1]:  # (held here: a block's address cannot be reused while it is remembered)
+            self._blocks, self._static_key = (a, c), None
+        s = self._args
+        base, flp, ip = ws.data_ptr(), fl.data_ptr(), ints.data_ptr()
+        # Everything that only moves when a buffer is (re)allocated or the parameters change is written into the argument blocks ONCE per
+        # such event: ~60 ctypes field stores and ~25 data_ptr() calls less per batch (the pipeline is host-bound: every microsecond of
+        # this function is a microsecond of the batch).  The key holds the address of every buffer a static field points into.
+        skey = (wkey, mem.memory.data_ptr(), mem.last_update.data_ptr(), mem._st_lo[0].data_ptr(), mem._st_cnt[0].data_ptr(), mem._st_lo[1].data_ptr(),
+                mem._st_cnt[1].data_ptr(), mem._log_other.data_ptr(), mem._log_t.data_ptr(), mem._log_raw.data_ptr(), mem._assoc64.data_ptr(),
+                mem._reuse_status.data_ptr(), wsd[0].data_ptr(), wsd[0].numel(), wsd[1].data_ptr(), cnt.data_ptr(), M, D, T, De, Te, H, C,
+                mem.num_nodes, mem.aggr_module.mean)  # fmt: skip
+        if skey != self._static_key:
+            a.memory, a.last_update, a.M, a.num_nodes = skey[1], skey[2], M, mem.num_nodes
+            a.st_lo_s, a.st_cnt_s, a.st_lo_d, a.st_cnt_d = skey[3], skey[4], skey[5], skey[6]
+            a.log_other, a.log_t, a.log_raw, a.D = skey[7], skey[8], skey[9], D
+            a.tw, a.tb, a.T, a.mean = tw.data_ptr(), tb.data_ptr(), T, mem.aggr_module.mean
+            a.W_ih, a.b_ih, a.W_hh, a.b_hh = W_ih.data_ptr(), b_ih.data_ptr(), W_hh.data_ptr(), b_hh.data_ptr()
+            a.assoc = skey[10]
+            c.in_ch, c.D, c.T = M, De, Te
+            c.tw, c.tb, c.W4, c.b4, c.W_edge, c.H, c.C = etw.data_ptr(), etb.data_ptr(), W4.data_ptr(), b4.data_ptr(), W_edge.data_ptr(), H, C
+            c.sort_ws, c.sort_ws_bytes, c.status = skey[12], skey[13], skey[14]
+            c.tgt_count = skey[15]
+            s.mem, s.conv = ctypes.addressof(a), ctypes.addressof(c)
+            s.memory, s.last_update, s.reuse_status = a.memory, a.last_update, skey[11]
+            s.log_other, s.log_t, s.log_raw = a.log_other, a.log_t, a.log_raw
+            s.st_lo_s, s.st_cnt_s, s.st_lo_d, s.st_cnt_d = a.st_lo_s, a.st_cnt_s, a.st_lo_d, a.st_cnt_d
+            self._static_key = skey
+        # ---- what changes with every batch ---------------------------------------------------------------------------------------------
+        a.nodes, a.R = nodes.data_ptr(), R
+        a.ws_aggr, a.ws_h, a.ws_gi, a.ws_gh = base, base + 4 * R * W, base + 4 * R * (W + M), base + 4 * R * (W + 4 * M)
+        a.out_mem, a.out_lu, a.stamp = z.data_ptr(), lu.data_ptr(), mem._stamp
+        c.x, c.U, c.last_update_local = a.out_mem, U, a.out_lu
+        c.src, c.tgt, c.t, c.msg, c.E = src_e.data_ptr(), tgt_e.data_ptr(), et64.data_ptr(), msg.data_ptr(), E
         c.edge_attr, c.qkvs, c.eproj = flp, qkvs.data_ptr(), flp + 4 * E * (Te + De)
         c.order, c.seg_lo, c.seg_hi = ip, ip + 8 * Ep, ip + 8 * (Ep + Up)
-        c.sort_ws, c.sort_ws_bytes, c.status = wsd[0].data_ptr(), wsd[0].numel(), wsd[1].data_ptr()
-        c.tgt_count, c.cursor, c.order_big = cnt.data_ptr(), ip + 8 * (Ep + 2 * Up), ip + 8 * (Ep + 3 * Up)
+        c.cursor, c.order_big = ip + 8 * (Ep + 2 * Up), ip + 8 * (Ep + 3 * Up)
         # ---- update_state (reuse_forward): commit the rows above for the batch's endpoints, store the batch ----------------------------
-        s = self._args
-        s.mem, s.conv = ctypes.addressof(a), ctypes.addressof(c)
         s.src, s.dst, s.t, s.raw, s.n = src32.data_ptr(), dst32.data_ptr(), t64.data_ptr(), _native.ptr(raw), n
-        s.memory, s.last_update, s.reuse_status = a.memory, a.last_update, mem._reuse_status.data_ptr()
-        s.log_base, s.log_other, s.log_t, s.log_raw = mem._log_len, a.log_other, a.log_t, a.log_raw
-        s.st_lo_s, s.st_cnt_s, s.st_lo_d, s.st_cnt_d = a.st_lo_s, a.st_cnt_s, a.st_lo_d, a.st_cnt_d
+        s.log_base = mem._log_len
         _native.check(lib.tgmx_tgn_step(s, _native.stream_ptr()), 'tgmx_tgn_step')
         # what the three calls leave behind: two state mutations (commit, store), the log grown by both roles' entries, no pending forward
         mem._version += 2
