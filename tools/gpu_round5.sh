@@ -1,6 +1,10 @@
 #!/bin/bash
 # Everything round 5's profiles/ are made of (besides tools/gpu_calib_r5.sh: the counter calibration and the stall counters), in one gpurun call (run from the repo root on the GPU box):
 #   tools/gpu_round5.sh [quick]  -> gpurun_out/profiles_r05/*   (copy into profiles/ afterwards)
+# Not made here (one-off A/Bs of the round's last session, each from a few-line shell loop over the same tools; the commands are in the files' headers
+# or in DESIGN 3.3 / 3.5): r05_gemm_lds_ab.txt, r05_gemm_two_row_tiles_rejected.txt (tgmx_sgemm_nt over the training step's / cfg 3's shapes with
+# TGMX_GEMM_LDS / a removed TGMX_GEMM_RT knob), r05_tile_w4_rejected.jsonl (bench.py --workload comment with a removed TGMX_TILE_W4 knob),
+# r05_bench_tgat_train_by_id_second_box.jsonl and r05_bench_tgn_second_box.jsonl (the same bench commands as below on another box).
 set -u
 cd "$(dirname "$0")/.."
 ROOT=$PWD
