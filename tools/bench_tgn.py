@@ -19,7 +19,7 @@ from tgm_amd.synth import make_stream  # noqa: E402
 torch.set_num_threads(min(8, torch.get_num_threads()))  # (host-side tensor ops on a shared many-core host: not every core)
 dev = torch.device('cuda', 0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-# 'fast' (default): pooled loader running one batch ahead (prefetch=1), SampledEdgeListHook (the loop's edge-list glue as one
+# 'fast' (default): pooled loader running two batches ahead (prefetch=2; TGMX_BENCH_TGN_PREFETCH), SampledEdgeListHook (the loop's edge-list glue as one
 #   native call inside the hook chain), TGNMemory.reuse_forward;
 # 'reference': fresh tensors, the reference loop's torch glue verbatim, update_state recomputing its rows -- same results
 variant = sys.argv[2] if len(sys.argv) > 2 else 'fast'
@@ -49,7 +49,8 @@ def batches(lo, hi):
     if os.environ.get('TGMX_BENCH_TGN_STREAMS') == 'script':
         return two_stream_batches(lo, hi)
     side = fast and os.environ.get('TGMX_BENCH_TGN_STREAMS', '1') != '0'  # the loader's chain beside the model's (DGDataLoader(side_stream=))
-    return DGDataLoader(dg.slice_events(lo * bs, hi * bs), batch_size=bs, hook_manager=hm, output_pool=2 if fast else 0, prefetch=1 if fast else 0,
+    pf = int(os.environ.get('TGMX_BENCH_TGN_PREFETCH', '2'))  # batches the loader runs ahead (the pool holds one set more); 1 -> 2: 166-167 -> 164-165 us per batch
+    return DGDataLoader(dg.slice_events(lo * bs, hi * bs), batch_size=bs, hook_manager=hm, output_pool=pf + 1 if fast else 0, prefetch=pf if fast else 0,
                         side_stream=side)
 
 
