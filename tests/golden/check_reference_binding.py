@@ -12,7 +12,10 @@ code, the claims a maintainer relies on when dropping our hooks into the referen
      also when the negative hook is the reference's own;
   3. our hooks' ``requires`` / ``produces`` equal the reference hooks' for the same constructor arguments;
   4. our ``DGBatch`` has the reference's fields (names, order, defaults) and our ``HookManager`` resolves the same order;
-  5. ``state_dict`` keys / shapes of our ``TGAT`` equal the reference's for the example configuration.
+  5. ``state_dict`` keys / shapes of our ``TGAT`` equal the reference's for the example configuration;
+  6. the reference's own host-side unit tests (test_dataloader / test_hook_manager / test_registry / test_dgraph /
+     test_deduplication_hook / test_seed, read in place) pass with ``tgm`` resolving to ``tgm_amd``
+     (``replay_reference_tests.py``, its own process: this one has the real ``tgm`` imported).
 
 Prints one line per check and exits non-zero on the first failure.  No kernel runs (no GPU here).
 
@@ -105,6 +108,13 @@ def main() -> None:
     TGAT(**kw).load_state_dict(a)
     RefTGAT(**kw).load_state_dict(b)
     ok(f'TGAT state_dict: {len(a)} tensors with the reference\'s names / shapes / dtypes, loadable both ways')
+    # 6. the reference's unit tests over our classes
+    import subprocess
+
+    r = subprocess.run([sys.executable, os.path.join(HERE, 'replay_reference_tests.py')], capture_output=True, text=True)
+    tail = [ln for ln in r.stdout.splitlines() if ln.startswith('[replay]')]
+    assert r.returncode == 0, '\n'.join(tail) or r.stdout[-2000:] + r.stderr[-2000:]
+    ok(tail[0][len('[replay] '):])
 
 
 if __name__ == '__main__':

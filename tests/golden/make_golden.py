@@ -23,6 +23,8 @@ Fixture families:
   g8_*   TGNMemory (in-tree arithmetic: messages, Last/Mean aggregation, GRU, store semantics)
   g11_*  NeighborSamplerHook (uniform sampling; Python's `random` seeded so the sampled rows are reproducible)
   g12_*  time-unit iteration: slice_time windows, DGDataLoader(batch_unit, drop_last, on_empty) incl. empty windows
+  g13_*  the DGraph view surface: scalar properties, sparse ``node_x`` / ``node_y`` (indices, values, shape) and ``materialize()``
+         over event / time / nested slices of a stream with node events, node labels, edge types and unsorted input
 """
 from __future__ import annotations
 
@@ -624,11 +626,72 @@ def g12_case():
     print(f'g12_time_batches: {len(windows)} slices, {len(configs)} loader configurations, E={E}')
 
 
+def g13_case():
+    """``DGraph`` as a script reads it (tgm/core/graph.py:74-108, 186-356; array_backend.py:178-285): per slice the scalar properties,
+    ``dg.node_x`` / ``dg.node_y`` (``sparse_coo_tensor(T x V x d)``: indices, values, shape -- or None) and every ``materialize()`` field.
+    The stream mixes edges, dynamic node features and node labels with timestamp ties between the three kinds, and is handed to
+    ``DGData.from_raw`` unsorted."""
+    rng = np.random.default_rng(1313)
+    N, E, NX, NY, D, DX, DY = 23, 60, 25, 18, 3, 4, 2
+    T_ = torch.from_numpy
+    perm = rng.permutation(E)
+    ets = np.sort(rng.integers(3, 90, E)).astype(np.int64)[perm]
+    ei = rng.integers(0, N - 4, (E, 2)).astype(np.int32)  # (ids N-4.. appear only as node events / labels: they move the sparse shapes)
+    ex = rng.random((E, D), dtype=np.float32)
+    et = rng.integers(0, 5, E).astype(np.int32)
+    xts = rng.integers(0, 100, NX).astype(np.int64)
+    xid = rng.integers(0, N, NX).astype(np.int32)
+    xid[0] = N - 1  # (the labels' ids must stay inside the id range the edges and node events span)
+    xv = rng.random((NX, DX), dtype=np.float32)
+    yts = rng.integers(0, 100, NY).astype(np.int64)
+    yid = rng.integers(0, N, NY).astype(np.int32)
+    yv = rng.random((NY, DY), dtype=np.float32)
+    sx = rng.random((N, 6), dtype=np.float32)
+    nt = rng.integers(0, 3, N).astype(np.int32)
+    arrays = dict(ets=ets, ei=ei, ex=ex, et=et, xts=xts, xid=xid, xv=xv, yts=yts, yid=yid, yv=yv, sx=sx, nt=nt)
+    data = DGData.from_raw(T_(ets), T_(ei), T_(ex), T_(xts), T_(xid), T_(xv), T_(yts), T_(yid), T_(yv), static_node_x=T_(sx), edge_type=T_(et),
+                           node_type=T_(nt))  # fmt: skip
+    # each entry: a chain of ('t', start, end) / ('e', start, end) slice operations applied to the full graph
+    chains = [[], [['t', 10, 50]], [['t', None, 30]], [['t', 60, None]], [['e', 5, 40]], [['e', None, 17]], [['e', 70, None]], [['e', 20, 80], ['t', 30, 70]],
+              [['t', 20, 80], ['e', 30, 60], ['t', 40, None]], [['t', 95, 99]], [['t', 0, 3]], [['e', 0, 1]], [['t', 200, 300]], [['e', 50, 50]]]  # fmt: skip
+    meta = dict(chains=chains, views=[])
+    for i, chain in enumerate(chains):
+        dg = DGraph(data)
+        for kind, a, b in chain:
+            dg = dg.slice_time(a, b) if kind == 't' else dg.slice_events(a, b)
+        # (read like a script would: the batch first, the view's properties afterwards)
+        batch = dg.materialize()
+        rec = dict(len=len(dg), num_nodes=int(dg.num_nodes), num_node_events=int(dg.num_node_events), num_node_labels=int(dg.num_node_labels),
+                   num_edge_events=int(dg.num_edge_events), num_timestamps=int(dg.num_timestamps), num_events=int(dg.num_events),
+                   start_time=None if dg.start_time is None else int(dg.start_time), end_time=None if dg.end_time is None else int(dg.end_time),
+                   none=[])  # fmt: skip
+        for name in ('node_x', 'node_y'):
+            sp = getattr(dg, name)
+            if sp is None:
+                rec['none'].append(name)
+                continue
+            arrays[f'v{i}_{name}_indices'] = sp._indices().numpy().copy()
+            arrays[f'v{i}_{name}_values'] = sp._values().numpy().copy()
+            rec[f'{name}_shape'] = [int(v) for v in sp.shape]
+        for name in ('edge_src', 'edge_dst', 'edge_time', 'edge_x', 'edge_type', 'node_x_time', 'node_x_nids', 'node_x', 'node_y_time', 'node_y_nids', 'node_y'):
+            v = getattr(batch, name)
+            if v is None:
+                rec['none'].append('batch.' + name)
+            else:
+                arrays[f'v{i}_b_{name}'] = v.numpy().copy()
+        for name in ('node_x_nids', 'node_x_time', 'node_y_nids', 'node_y_time'):
+            arrays[f'v{i}_{name}'] = getattr(dg, name).numpy().copy()
+        meta['views'].append(rec)
+    arrays['meta'] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, 'g13_dgraph_views.npz'), **arrays)
+    print(f'g13_dgraph_views: {len(chains)} views, E={E}, node events {NX}, node labels {NY}')
+
+
 if __name__ == '__main__':
     import warnings
 
     warnings.filterwarnings('ignore')
     only = sys.argv[1:]
-    for fam, fn in [('g1', g1_cases), ('g2', g2_cases), ('g3', g3_case), ('g4', g4_case), ('g5', g5_cases), ('g5n', g5_self_noise), ('g6', g6_case), ('g7', g7_case), ('g8', g8_cases), ('g9', g9_case), ('g10', g10_case), ('g11', g11_cases), ('g12', g12_case)]:
+    for fam, fn in [('g1', g1_cases), ('g2', g2_cases), ('g3', g3_case), ('g4', g4_case), ('g5', g5_cases), ('g5n', g5_self_noise), ('g6', g6_case), ('g7', g7_case), ('g8', g8_cases), ('g9', g9_case), ('g10', g10_case), ('g11', g11_cases), ('g12', g12_case), ('g13', g13_case)]:
         if not only or fam in only:
             fn()

@@ -10,8 +10,9 @@ there is no CPU fallback: without ``libtgm_amd.so`` the hooks raise.
 from .constants import PADDED_NODE_ID
 from .core.batch import DGBatch
 from .core.graph import DGraph
+from .core.timedelta import TimeDeltaDG
 from .data.dg_data import DGData
 from .data.loader import DGDataLoader
 
-__all__ = ['PADDED_NODE_ID', 'DGBatch', 'DGraph', 'DGData', 'DGDataLoader']
+__all__ = ['PADDED_NODE_ID', 'DGBatch', 'DGraph', 'TimeDeltaDG', 'DGData', 'DGDataLoader']
 __version__ = '0.1.0'

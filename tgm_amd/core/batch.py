@@ -1,17 +1,19 @@
 """``DGBatch`` -- the mutable record hooks read from and write onto.
 
 Mirrors tgm/core/batch.py:11-45 (same field names, order and defaults) so that
-hooks written against the reference keep working.  Two private, optional
-fields are added by :meth:`DGraph.materialize`: ``_edge_lo`` (index of the
-batch's first edge in the device-resident edge store; the batch's edges are
-the contiguous range ``[_edge_lo, _edge_lo + len(edge_src))``) and
-``_event_lo`` (the slice's first global event index).  They let device hooks
-address the resident store by edge id instead of copying feature rows.
+hooks written against the reference keep working, and ``dataclasses.asdict`` /
+``fields`` / ``==`` see exactly the reference's record.  Two private instance
+attributes (NOT dataclass fields) are set by :meth:`DGraph.materialize`:
+``_edge_lo`` (index of the batch's first edge in the device-resident edge
+store; the batch's edges are the contiguous range ``[_edge_lo, _edge_lo +
+len(edge_src))``) and ``_event_lo`` (the slice's first global event index).
+They let device hooks address the resident store by edge id instead of copying
+feature rows.
 """
 from __future__ import annotations
 
-from dataclasses import dataclass, field
-from typing import Any, Optional
+from dataclasses import dataclass
+from typing import Any, ClassVar, Optional
 
 from torch import Tensor
 
@@ -32,8 +34,9 @@ class DGBatch:
     node_y_nids: Optional[Tensor] = None
     node_y: Optional[Tensor] = None
 
-    _edge_lo: Optional[int] = field(default=None, repr=False, compare=False)
-    _event_lo: Optional[int] = field(default=None, repr=False, compare=False)
+    # class-level defaults of the two private instance attributes (ClassVar: not fields, so asdict(batch) is the reference's)
+    _edge_lo: ClassVar[Optional[int]] = None
+    _event_lo: ClassVar[Optional[int]] = None
 
     # Hooks whose output SIZE is only known on the device (unique ids, compacted edge lists) enqueue their kernels, start an
     # asynchronous copy of the size and register a finalizer here instead of waiting for it; the loader runs the

@@ -36,9 +36,10 @@ class DGraph:
         self._slice = SliceBounds()
 
     @classmethod
-    def _view(cls, storage: EdgeStore, time_delta: TimeDeltaDG, device: torch.device, s: SliceBounds) -> 'DGraph':
+    def _from_storage(cls, storage: EdgeStore, time_delta: TimeDeltaDG, device: torch.device, slice: SliceBounds) -> 'DGraph':
+        """A view over an existing store (tgm/core/graph.py:406-420; the store is shared, never copied)."""
         g = cls.__new__(cls)
-        g._storage, g._time_delta, g._device, g._slice = storage, time_delta, device, s
+        g._storage, g._time_delta, g._device, g._slice = storage, time_delta, device, slice
         return g
 
     # -- views ------------------------------------------------------------
@@ -49,7 +50,7 @@ class DGraph:
         s = self._slice.copy()
         s.start_idx = _opt_max(start_idx, s.start_idx)
         s.end_idx = _opt_min(end_idx, s.end_idx)
-        return DGraph._view(self._storage, self._time_delta, self._device, s)
+        return DGraph._from_storage(self._storage, self._time_delta, self._device, s)
 
     def slice_time(self, start_time: Optional[int] = None, end_time: Optional[int] = None) -> 'DGraph':
         """New view over timestamps [start_time, end_time)."""
@@ -60,10 +61,10 @@ class DGraph:
         s = self._slice.copy()
         s.start_time = _opt_max(start_time, s.start_time)
         s.end_time = _opt_min(end_time, s.end_time)
-        return DGraph._view(self._storage, self._time_delta, self._device, s)
+        return DGraph._from_storage(self._storage, self._time_delta, self._device, s)
 
     def to(self, device: str | torch.device) -> 'DGraph':
-        return DGraph._view(self._storage, self._time_delta, torch.device(device), self._slice.copy())
+        return DGraph._from_storage(self._storage, self._time_delta, torch.device(device), self._slice.copy())
 
     # -- scalar properties --------------------------------------------------
     @property
@@ -154,77 +155,108 @@ class DGraph:
         return self._storage.node_y_dim
 
     # -- tensors (zero-copy windows of the resident arrays) ------------------
+    # A view is immutable and bound to one device, so every window is cut once and cached: like the reference's cached
+    # ``_edges_cpu`` + ``.to(same device)`` (graph.py:228-248), two reads of ``dg.edge_src`` -- and two ``materialize()`` calls --
+    # hand out the SAME tensor object, which is what ``batch == batch`` (dataclass ``==`` over tensors) relies on.
     @property
     def _arrays(self) -> DeviceArrays:
         return self._storage.on(self._device)
 
-    def _edge_window(self, t: Optional[Tensor]) -> Optional[Tensor]:
-        if t is None:
-            return None
+    @cached_property
+    def _edges(self):
+        arr = self._arrays
         lo, hi = self._edge_range
-        return t.narrow(0, lo, hi - lo)
+        n = hi - lo
+        return arr.src.narrow(0, lo, n), arr.dst.narrow(0, lo, n), arr.ts.narrow(0, lo, n)
 
     @property
     def edge_src(self) -> Tensor:
-        return self._edge_window(self._arrays.src)
+        return self._edges[0]
 
     @property
     def edge_dst(self) -> Tensor:
-        return self._edge_window(self._arrays.dst)
+        return self._edges[1]
 
     @property
     def edge_time(self) -> Tensor:
-        return self._edge_window(self._arrays.ts)
+        return self._edges[2]
 
-    @property
-    def edge_x(self) -> Optional[Tensor]:
+    def _edge_window(self, t: Optional[Tensor]) -> Optional[Tensor]:
         lo, hi = self._edge_range
-        if hi <= lo:
+        if t is None or hi <= lo:  # the reference hands out None for a slice without edges (array_backend.py:262-285)
             return None
+        return t.narrow(0, lo, hi - lo)
+
+    @cached_property
+    def edge_x(self) -> Optional[Tensor]:
         return self._edge_window(self._arrays.edge_x)
 
-    @property
+    @cached_property
     def edge_type(self) -> Optional[Tensor]:
-        lo, hi = self._edge_range
-        if hi <= lo:
-            return None
         return self._edge_window(self._arrays.edge_type)
 
-    def _node_window(self, t: Optional[Tensor], kind: str) -> Optional[Tensor]:
-        if t is None:
-            return None
+    @cached_property
+    def _node_events(self):
+        """(nids, time, rows) windows of the dynamic node features in the slice; empty id / time tensors when there are none."""
+        return self._event_windows('x')
+
+    @cached_property
+    def _node_labels(self):
+        return self._event_windows('y')
+
+    def _event_windows(self, kind: str):
+        arr = self._arrays
+        nids, time, rows = getattr(arr, f'node_{kind}_nids'), getattr(arr, f'node_{kind}_time'), getattr(arr, f'node_{kind}')
+        if nids is None:
+            return torch.empty(0, dtype=torch.int32, device=self._device), torch.empty(0, dtype=torch.int64, device=self._device), None
         lo, hi = getattr(self._storage, f'node_{kind}_range')(self._slice)
-        return t.narrow(0, lo, max(0, hi - lo))
+        n = max(0, hi - lo)
+        return nids.narrow(0, lo, n), time.narrow(0, lo, n), (rows.narrow(0, lo, n) if n else None)
 
     @property
-    def node_x_nids(self) -> Optional[Tensor]:
-        t = self._node_window(self._arrays.node_x_nids, 'x')
-        return torch.empty(0, dtype=torch.int32, device=self._device) if t is None else t
+    def node_x_nids(self) -> Tensor:
+        return self._node_events[0]
 
     @property
-    def node_x_time(self) -> Optional[Tensor]:
-        t = self._node_window(self._arrays.node_x_time, 'x')
-        return torch.empty(0, dtype=torch.int64, device=self._device) if t is None else t
+    def node_x_time(self) -> Tensor:
+        return self._node_events[1]
 
     @property
+    def node_y_nids(self) -> Tensor:
+        return self._node_labels[0]
+
+    @property
+    def node_y_time(self) -> Tensor:
+        return self._node_labels[1]
+
+    def _sparse_events(self, kind: str) -> Optional[Tensor]:
+        """``sparse_coo_tensor(T x V x d)`` over the slice's node events, built from the resident windows (no copy of the rows):
+        indices ``[time ; node]``, T = the slice's end time + 1, V = the largest node id among the slice's edges, node events and
+        node labels + 1 (tgm/core/_storage/backends/array_backend.py:178-256)."""
+        nids, time, rows = self._node_events if kind == 'x' else self._node_labels
+        if rows is None:
+            return None
+        tops = [nids.max()]
+        src, dst, _ = self._edges
+        if src.numel():
+            tops += [src.max(), dst.max()]
+        other = (self._node_labels if kind == 'x' else self._node_events)[0]
+        if other.numel():
+            tops.append(other.max())
+        max_node = int(torch.stack(tops).max())
+        _, ub = self._event_range
+        max_time = self._slice.end_time or self._storage.time_at(ub - 1)
+        return torch.sparse_coo_tensor(torch.stack([time, nids.to(torch.int64)]), rows, (max_time + 1, max_node + 1, rows.shape[1]))
+
+    @cached_property
     def node_x(self) -> Optional[Tensor]:
-        t = self._node_window(self._arrays.node_x, 'x')
-        return None if t is None or t.shape[0] == 0 else t
+        """Dynamic node features as the reference's ``sparse_coo_tensor(T x V x d_node_dynamic)`` (graph.py:300-309)."""
+        return self._sparse_events('x')
 
-    @property
-    def node_y_nids(self) -> Optional[Tensor]:
-        t = self._node_window(self._arrays.node_y_nids, 'y')
-        return torch.empty(0, dtype=torch.int32, device=self._device) if t is None else t
-
-    @property
-    def node_y_time(self) -> Optional[Tensor]:
-        t = self._node_window(self._arrays.node_y_time, 'y')
-        return torch.empty(0, dtype=torch.int64, device=self._device) if t is None else t
-
-    @property
+    @cached_property
     def node_y(self) -> Optional[Tensor]:
-        t = self._node_window(self._arrays.node_y, 'y')
-        return None if t is None or t.shape[0] == 0 else t
+        """Dynamic node labels as the reference's ``sparse_coo_tensor(T x V x d_node_label)`` (graph.py:347-356)."""
+        return self._sparse_events('y')
 
     @property
     def static_node_x(self) -> Optional[Tensor]:
@@ -238,28 +270,23 @@ class DGraph:
     def materialize(self, materialize_features: bool = True) -> DGBatch:
         """Pack the slice into a ``DGBatch`` (tgm/core/graph.py:74-108).
 
-        Dynamic node features are handed out dense (``node_x[i]`` belongs to
-        event ``(node_x_time[i], node_x_nids[i])``), which is what the reference
-        extracts from its sparse tensor via ``_indices()/_values()``.
+        The batch carries the view's cached windows.  ``batch.node_x`` is the dense ``[n, d]`` row window and
+        ``node_x_time / node_x_nids`` its coordinates -- exactly the ``_values()`` / ``_indices()`` of ``dg.node_x`` the
+        reference unpacks, without building the sparse tensor on the per-batch path.
         """
-        arr = self._storage.on(self._device)
-        lb, ub = self._storage.event_range(self._slice)
-        if self._storage.num_edges == self._storage.num_events:
-            lo, hi = lb, max(lb, ub)
-        else:
-            lo, hi = self._edge_range
-        n = hi - lo
-        batch = DGBatch(arr.src.narrow(0, lo, n), arr.dst.narrow(0, lo, n), arr.ts.narrow(0, lo, n))
-        batch._edge_lo = lo
-        batch._event_lo = lb
-        if materialize_features and arr.node_x is not None and self.node_x is not None:
-            batch.node_x_time, batch.node_x_nids, batch.node_x = self.node_x_time, self.node_x_nids, self.node_x
-        if materialize_features and n > 0 and arr.edge_x is not None:
-            batch.edge_x = arr.edge_x.narrow(0, lo, n)
-        if materialize_features and arr.node_y is not None and self.node_y is not None:
-            batch.node_y_time, batch.node_y_nids, batch.node_y = self.node_y_time, self.node_y_nids, self.node_y
-        if n > 0 and arr.edge_type is not None:
-            batch.edge_type = arr.edge_type.narrow(0, lo, n)
+        src, dst, ts = self._edges
+        batch = DGBatch(src, dst, ts)
+        batch._edge_lo = self._edge_range[0]
+        batch._event_lo = self._event_range[0]
+        if materialize_features:
+            nids, time, rows = self._node_events
+            if rows is not None:
+                batch.node_x_time, batch.node_x_nids, batch.node_x = time, nids, rows
+            batch.edge_x = self.edge_x
+            nids, time, rows = self._node_labels
+            if rows is not None:
+                batch.node_y_time, batch.node_y_nids, batch.node_y = time, nids, rows
+        batch.edge_type = self.edge_type
         return batch
 
     def __str__(self) -> str:

@@ -188,9 +188,12 @@ class DGData:
         return n
 
     def _sort_timeline(self) -> None:
-        """Reorder every event array to the (stable) time-sorted order."""
+        """Reorder every event array to time-sorted order.  Events with EQUAL timestamps come out in the order ``torch.argsort``'s default
+        (unstable) host sort leaves them in -- the reference's own call (tgm/data/dg_data.py:356), so unsorted input with ties is
+        reordered exactly as the reference reorders it under the same torch build (pinned by fixture g13_dgraph_views); the
+        per-group regrouping below sorts unique positions, where stability is moot."""
         warnings.warn('Timestamps in DGData are not globally sorted; reordering all events', UserWarning)
-        order = torch.argsort(self.time, stable=True)
+        order = torch.argsort(self.time)
         rank = torch.empty_like(order)
         rank[order] = torch.arange(len(order))
         self.time = self.time[order]

@@ -6,6 +6,7 @@ from .negatives import RandomNegativeEdgeSamplerHook
 from .recency import RecencyNeighborHook
 from .uniform import NeighborSamplerHook
 from .registry import hook, list_hooks
+from . import neighbors  # noqa: E402,F401  (the reference's import path: tgm.hooks.neighbors.recency)
 
 __all__ = [
     'BaseDGHook',

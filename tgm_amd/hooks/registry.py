@@ -1,17 +1,18 @@
 """Class registry used for HookManager's "did you mean ..." suggestions
-(role of tgm/hooks/registry.py:8-22)."""
+(tgm/hooks/registry.py:8-22: a plain list in registration order -- registering
+a class twice lists it twice, and ``list_hooks`` hands out the list itself)."""
 from __future__ import annotations
 
-from typing import Dict, List, Type
+from typing import List, Type
 
-_REGISTRY: Dict[str, Type] = {}
+_HOOK_REGISTRY: List[Type] = []
 
 
 def hook(cls: Type) -> Type:
     """Class decorator: make ``cls`` discoverable by name."""
-    _REGISTRY[cls.__name__] = cls
+    _HOOK_REGISTRY.append(cls)
     return cls
 
 
 def list_hooks() -> List[Type]:
-    return list(_REGISTRY.values())
+    return _HOOK_REGISTRY
