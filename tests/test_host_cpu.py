@@ -254,7 +254,8 @@ def test_reference_side_binding_script():
     script = os.path.join(os.path.dirname(__file__), 'golden', 'check_reference_binding.py')
     r = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count('[binding] ok') == 5
+    assert r.stdout.count('[binding] ok') == 6
+    assert 'reference unit tests against tgm_amd: 103 / 103' in r.stdout, r.stdout
 
 
 def test_loader_is_a_torch_dataloader_like_the_reference():
