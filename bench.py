@@ -73,6 +73,8 @@ def parse_args():
                    "HBM-bound comment-shaped lookup (roofline_hbm_bound), the TGAT aggregation block: 'auto' = at N = 1 on the wiki workload")
     p.add_argument('--scale-comment', default='on', choices=['on', 'off'],
                    help='N > 1: also measure the comment-shaped stream over the static index, batch-sharded and weak, in the same job (scale_comment)')
+    p.add_argument('--tgn-allgather', default='on', choices=['on', 'off'],
+                   help='N > 1: also time the TGN memory module with the commit sharded across the ranks and all-gathered (tgn_memory_allgather)')
     p.add_argument('--no-default-path', action='store_true', help="skip the second timed region (the same steps through DGDataLoader / RecencyNeighborHook with their DEFAULT arguments)")
     return p.parse_args()
 
@@ -378,6 +380,99 @@ def scale_comment_block(args, rank, world, device, n_steps=48):
     torch.cuda.empty_cache()
     out['seconds_spent'] = time.perf_counter() - t_c
     return out
+
+
+def tgn_memory_allgather_block(args, rank, world, device, n_steps=100, n_warm=30):
+    """The one collective north_star names, timed: BASELINE cfg 3's memory module (review-shaped stream, bs = 512 global batch,
+    TGNMemory(Last aggregation, GRU, memory 100, time 100), train mode) with the batch's edges sharded over the ranks.  Per step, on
+    every rank: ``memory(n_id)`` for the unique endpoints of the rank's SLICE of the batch (the rows its share of the embedding
+    reads: messages -> aggregation -> GRU, nothing written), then ``update_state`` of the whole batch with the commit sharded --
+    each rank evaluates rows / N of the commit rows from its replica, ONE ``all_gather_into_tensor`` of fixed-size (memory row,
+    last_update) records (RCCL over xGMI under backend nccl) gives every replica all rows (tgm_amd/nn/tgn.py ``_updated_sharded``;
+    semantics tgm/nn/encoder/tgn.py:165-229).  The all-gather is bracketed by HIP events on the stream it is issued from; the
+    replicas are compared by an exact (integer) checksum of memory and last_update at the end.  ``world == 1`` (the tests'
+    single-process leg): the same steps unsharded, no collective -- its checksum is what the replicas must equal."""
+    from tgm_amd.dist import shard_bounds
+    from tgm_amd.nn import IdentityMessage, LastAggregator, TGNMemory
+    from tgm_amd.synth import make_stream
+
+    dist = torch.distributed
+    t_c = time.perf_counter()
+    edges = int(os.environ.get('TGMX_TGN_ALLGATHER_EDGES', 0)) or 400_000  # a 400 k-edge prefix-shaped stream: the steps touch a few hundred batches
+    rs = make_stream('review', seed=args.seed, device=device, num_edges=edges)
+    gbs, M, T_ = DEFAULTS['review'][0], 100, 100
+    D, N = rs.edge_dim, rs.num_nodes
+    torch.manual_seed(args.seed)  # every replica starts from the same parameters
+    mem = TGNMemory(N, D, M, T_, IdentityMessage(D, M, T_), LastAggregator()).to(device).train()
+    mem.shard_commits = True
+    n_batches = rs.num_edges // gbs
+    n_warm = min(n_warm, max(1, n_batches // 4))
+    n_steps = min(n_steps, n_batches - n_warm)
+    # inputs resident before the timed region: per batch the unique endpoints of this rank's slice of the edges
+    share = []
+    for b in range(n_warm + n_steps):
+        lo, hi = shard_bounds(gbs, rank, world)
+        e = slice(b * gbs + lo, b * gbs + hi)
+        share.append(torch.unique(torch.cat([rs.src[e], rs.dst[e]])))
+
+    def step(b):
+        e = slice(b * gbs, (b + 1) * gbs)
+        with torch.no_grad():
+            mem(share[b])
+            mem.update_state(rs.src[e], rs.dst[e], rs.ts[e], rs.edge_x[e])
+
+    for b in range(n_warm):
+        step(b)
+    mem.allgather_log = log = []
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for b in range(n_warm, n_warm + n_steps):
+        step(b)
+    torch.cuda.synchronize()
+    own_s = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+    wall_s = time.perf_counter() - t0
+    mem.allgather_log = None
+    ag_us = [1e3 * a.elapsed_time(b_) for a, b_, *_ in log]
+    # exact checksums: the float table summed as its int32 bit patterns (any differing bit moves the sum), int64 last_update as is
+    checksum = [int(mem.memory.view(torch.int32).to(torch.int64).sum().item()), int(mem.last_update.sum().item()),
+                int((mem.last_update != 0).sum().item())]
+    mine = {'rank': rank, 'step_us': 1e6 * own_s / n_steps, 'checksum': checksum,
+            'allgather_us': [sum(ag_us) / len(ag_us), min(ag_us), max(ag_us)] if ag_us else None,
+            'commit_rows_per_step': sum(r for _, _, r, _, _ in log) / len(log) if log else None,
+            'bytes_sent_per_step': sum(bs_ for _, _, _, bs_, _ in log) / len(log) if log else 0,
+            'bytes_received_per_step': sum(br for _, _, _, _, br in log) / len(log) if log else 0}
+    ranks = [mine]
+    if world > 1:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, mine)
+        wall_s = max(wall_s, max(r['step_us'] for r in ranks) * 1e-6 * n_steps)
+    del rs, mem
+    torch.cuda.empty_cache()
+    return {
+        'workload': f'BASELINE cfg 3 memory module: tgbl-review-shaped synthetic stream (N={N}, first {edges} edges, D={D}), global batch {gbs} edges, '
+                    f'TGNMemory(Last, GRU, memory {M}, time {T_}) in train mode, {world} rank(s); per step memory(n_id) over the unique endpoints of the '
+                    f"rank's {gbs // world}-edge slice + update_state(whole batch) with the commit rows sharded and all-gathered; {n_steps} timed steps after "
+                    f'{n_warm}, barrier on both sides',
+        'backend': dist.get_backend() if world > 1 else None,
+        'ranks_seen': len(ranks),
+        'steps': n_steps,
+        'wall_us_per_step': 1e6 * wall_s / n_steps,
+        'events_per_s': gbs * n_steps / wall_s,
+        'per_rank_step_us': [r['step_us'] for r in ranks],
+        'per_rank_allgather_us_mean_min_max': [r['allgather_us'] for r in ranks],
+        'allgather_what': 'one all_gather_into_tensor per step of ceil(rows / N) x (memory_dim + 2) float32 words per rank ((memory row, int64 last_update) '
+                          'records), HIP events on the issuing stream; under gloo (functional tests) the figure includes the staging copies through the host',
+        'commit_rows_per_step': mine['commit_rows_per_step'],
+        'bytes_sent_per_rank_per_step': mine['bytes_sent_per_step'],
+        'bytes_received_per_rank_per_step': mine['bytes_received_per_step'],
+        'checksum': checksum,
+        'replicas_identical': all(r['checksum'] == checksum for r in ranks),
+        'seconds_spent': time.perf_counter() - t_c,
+    }
 
 
 def tgat_gflop_folded(S0, num_nbrs, node_dim=1, edge_dim=172, time_dim=100, embed_dim=172, heads=2):
@@ -859,6 +954,11 @@ def main():
             out['scale_comment']['rccl_ranks_seen'] = rccl['ranks_seen']
         except Exception as exc:  # noqa: BLE001 -- every rank takes the same path (the block's collectives are symmetric)
             out['scale_comment'] = {'error': f'{type(exc).__name__}: {exc}'[:300]}
+    if real_world > 1 and args.tgn_allgather != 'off':
+        try:
+            out['tgn_memory_allgather'] = tgn_memory_allgather_block(args, rank, world, device)
+        except Exception as exc:  # noqa: BLE001 -- symmetric across ranks, like scale_comment
+            out['tgn_memory_allgather'] = {'error': f'{type(exc).__name__}: {exc}'[:300]}
     out['valid_edges_per_s'] = out['value'] * out['roofline']['valid_slot_fraction']  # sampled slots that hold a neighbor (pads excluded)
     if default_elapsed is not None:
         out['default_path'] = {

@@ -136,6 +136,47 @@ def test_side_stream_loader_gives_the_single_stream_results(features):
     assert torch.equal(mem1, mem2) and torch.equal(lu1, lu2)
 
 
+@pytest.mark.parametrize('validate', ['deferred', 'sync'])
+def test_side_stream_with_timed_steps_keeps_the_batch_order(validate):
+    """A TIMED step (``profile_hop``: HIP events around the dominant launch) is issued from the calling thread while earlier batches' steps
+    may still sit in the launch worker's queue: it must land on the loader's stream behind them (``CompiledPipeline._order_behind_worker``),
+    or batch j's ring update overtakes batch j - 1's lookups.  Every second step timed, delays on the loader's stream to keep the worker's
+    queue full; sampler outputs equal to the single-stream pass bit for bit.  ``validate='sync'``: the status read waits for the worker too."""
+    from tgm_amd import DGData, DGDataLoader, DGraph
+    from tgm_amd._native import KernelTimer
+    from tgm_amd.hooks import HookManager, RandomNegativeEdgeSamplerHook, RecencyNeighborHook
+    from tgm_amd.synth import make_stream
+
+    st = make_stream('review', seed=9, num_edges=40 * 256 + 31, n_src=2000, n_dst=300)
+    N, bs = st.num_nodes, 256
+
+    def run(side):
+        dg = DGraph(DGData.from_raw(st.ts, torch.stack([st.src, st.dst], 1), st.edge_x), device=DEV)
+        hm = HookManager(keys=['k'])
+        hm.register('k', RandomNegativeEdgeSamplerHook(2000, N, seed=4))
+        hook = RecencyNeighborHook(N, [10, 10], ['edge_src', 'edge_dst', 'neg'], ['edge_time', 'edge_time', 'neg_time'], validate=validate)
+        hm.register('k', hook)
+        hook.profile_hop, hook.profile_every, hook.profile_log = 1, 2, []
+        hook.profile_pool = [KernelTimer() for _ in range(32)]
+        out = []
+        with hm.activate('k'):
+            kw = dict(output_pool=3, prefetch=2, side_stream=True) if side else dict(output_pool=3, prefetch=2)
+            for i, batch in enumerate(DGDataLoader(dg, batch_size=bs, hook_manager=hm, **kw)):
+                if side and i % 3 == 0:
+                    torch.cuda._sleep(2_000_000)  # the consumer's stream lags: productions (and the worker's queue) pile up
+                out.append([t.clone() for t in (batch.neg, batch.nbr_nids[0], batch.nbr_nids[1], batch.nbr_edge_time[1], batch.nbr_edge_x[1])])
+            hook.check()
+        torch.cuda.synchronize()
+        assert len(hook.profile_log) >= 16
+        return out
+
+    one, two = run(False), run(True)
+    assert len(one) == len(two) == 41
+    for b, (x, y) in enumerate(zip(one, two)):
+        for i, (u, v) in enumerate(zip(x, y)):
+            assert torch.equal(u, v), f'batch {b} item {i}'
+
+
 def test_side_stream_argument_checks():
     from tgm_amd import DGData, DGDataLoader, DGraph
 

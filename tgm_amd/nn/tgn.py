@@ -93,6 +93,9 @@ class TGNMemory(TransientCaches, nn.Module):
         self._reuse_status = None  # device int32: 1 = an update_state node was not part of the reused forward
         self._fwd_args = None      # tgmx_tgn_memory_fwd_t, reused
         self.shard_commits = True  # under torch.distributed (world > 1): shard update_state's commit across ranks
+        # a list (ours, None = off): every sharded commit appends (start event, stop event, commit rows, bytes sent, bytes received)
+        # around its all-gather -- HIP events on the stream the collective is issued from (bench.py's tgn_memory_allgather block)
+        self.allgather_log: Optional[list] = None
         self.memory_updater.reset_parameters()
 
     # -- state ------------------------------------------------------------------
@@ -290,12 +293,19 @@ class TGNMemory(TransientCaches, nn.Module):
             rec_l[: hi - lo, :M] = m
             rec_l[: hi - lo, Mp:].view(torch.int64)[:, 0] = l
         rec_g = torch.empty((world * per, Mp + 2), dtype=torch.float32, device=dev)
+        log = self.allgather_log
+        if log is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
         if dist.get_backend() == 'gloo':  # CPU collective (tests): stage through the host
             rc = torch.empty(rec_g.shape)
             dist.all_gather_into_tensor(rc, rec_l.cpu())
             rec_g.copy_(rc)
         else:
             dist.all_gather_into_tensor(rec_g, rec_l)  # the step's only collective
+        if log is not None:
+            ev1.record()
+            log.append((ev0, ev1, R, rec_l.numel() * 4, rec_g.numel() * 4))
         mem_g = rec_g[:, :M].contiguous()
         lu_g = rec_g[:, Mp:].view(torch.int64)[:, 0].contiguous()
         return mem_g[:R], lu_g[:R]

@@ -123,6 +123,7 @@ class CompiledPipeline:
         self._static_ok: Optional[tuple] = None  # host-side seed validation of the resident store (validate='sync')
         self._since_check = 0
         self._async = None  # (worker, wait event or None, record event): DGDataLoader(side_stream=True) sets it around a call
+        self._last_ticket = 0  # the launch worker's newest job of this pipeline (0: none yet)
 
     # -- lowering ---------------------------------------------------------------
     @staticmethod
@@ -472,8 +473,10 @@ class CompiledPipeline:
         if shard is not None:
             s_lo, s_hi = shard_bounds(n, shard.rank, shard.world_size)
             if s_hi == s_lo:
+                self._order_behind_worker()
                 return False
         elif n == 0:
+            self._order_behind_worker()
             return False
         if nbr._validate == 'sync':
             self._validate_static(lo, n, (lo + s_lo, lo + s_hi) if shard is not None else (lo, lo + n))
@@ -517,11 +520,11 @@ class CompiledPipeline:
                                                      ctypes.byref(tk))
             if rc:
                 _native.check(rc, 'tgmx_worker_pipeline_step')
-            batch.__dict__['_ticket'] = tk.value
+            batch.__dict__['_ticket'] = self._last_ticket = tk.value
         else:
             stream = _native.stream_ptr(self._device.index)
-            if asy is not None and asy[1]:  # (a timed launch under side_stream: issued from this thread, ordered the same way)
-                self._lib.tgmx_stream_wait_event(stream, asy[1])
+            # (a timed launch under side_stream: issued from this thread -- behind every job the worker still holds, and behind the hazard event)
+            self._order_behind_worker()
             rc = self._lib.tgmx_pipeline_step(pipe, lo, n, call, out, slot.post, stream)
             if rc:
                 _native.check(rc, 'tgmx_pipeline_step')
@@ -534,6 +537,8 @@ class CompiledPipeline:
                 # seeds that the store does not vouch for: one device -> host read per batch.  Seeds it does vouch for: the status word
                 # still carries the non-seed bits (TGMX_ST_TS_BOUND, TGMX_ST_SCRATCH) -- read it once in a while so that they surface
                 self._since_check = 0
+                if asy is not None and self._last_ticket:  # the status word describes THIS batch only once the worker has issued its step
+                    _native.check(self._lib.tgmx_worker_wait(asy[0], self._last_ticket), 'tgmx_worker_wait')
                 nbr.check()
         d = batch.__dict__
         if shard is not None:
@@ -559,6 +564,18 @@ class CompiledPipeline:
         if slot.post is not None:
             self._defer_post(batch, slot)
         return True
+
+    def _order_behind_worker(self) -> None:
+        """DGDataLoader(side_stream=True): work THIS thread is about to enqueue on the loader's stream (a timed step, or the hooks of a batch
+        the lowered call leaves to them) goes behind every step the launch worker has been handed -- they may not have reached the stream
+        yet -- and behind the consumer's reads of the output set about to be rewritten (the hazard event)."""
+        asy = self._async
+        if asy is None:
+            return
+        if self._last_ticket:
+            _native.check(self._lib.tgmx_worker_wait(asy[0], self._last_ticket), 'tgmx_worker_wait')
+        if asy[1]:
+            _native.check(self._lib.tgmx_stream_wait_event(_native.stream_ptr(self._device.index), asy[1]), 'tgmx_stream_wait_event')
 
     # -- validate='sync' without a device read per batch ------------------------------------------------
     def _validate_static(self, lo: int, n: int, seed_range: tuple) -> None:
