@@ -1872,6 +1872,227 @@ __global__ __launch_bounds__(256) void lookup_tile_kernel(const LookupArgs a, co
   }
 }
 
+// ---- the tile kernel with a COOPERATIVE index phase (round 6) -------------------------------------------------------------------
+// lookup_tile_kernel's index phase reads a seed's window as BCAP loads of ONE lane: every load instruction of the wave touches 64
+// different lines for 16 bytes each (the calibration's "16-byte chunks" pattern, 1.1 TB/s; the lines are re-touched by the next
+// seven instructions and mostly hit in L1 / L2, which is what lifts the phase to 2.5-3.5 TB/s) -- against 4.75 TB/s for the same
+// windows read as 320 CONTIGUOUS bytes by neighbouring lanes (tools/gather_calib.hip, profiles/r05_narrow_row_calibration.md).
+// Here the windows arrive that way: load instruction i serves SPI = 64 / BCAP seeds, BCAP consecutive lanes per seed, lane's record
+// j = lane % BCAP -- 3 windows = ~10 lines per instruction at B = 20 instead of 64.  The pick needs no transposition: a record's
+// lane decides "valid and older than q" for ITSELF, one ballot per instruction gives every lane the bit field of its seed's window
+// (rotated into time order by the ring's write position with two shifts), and the newest qualifying position, the record's own
+// output slot and the row's span are bit arithmetic on that field -- computed redundantly by the BCAP lanes of a seed, no shuffles.
+// Per-seed scalars (window base, q, write position) go from the seed's lane to its record lanes through a small LDS header.
+// Everything after the pick (staging, coalesced flushes, delta-aware copy phase) is lookup_tile_kernel's, fed from the same LDS
+// areas; results are identical (tests: every sampler test runs both, TGMX_TILE_COOP=0 is the A/B knob).  BCAP <= 20 (B <= 20).
+template <bool RING, int VEC, int BCAP, bool RIDE>
+__global__ __launch_bounds__(256) void lookup_tile_coop_kernel(const LookupArgs a, const UpdateArgs u) {
+  extern __shared__ __attribute__((aligned(16))) int lds_eid_all[];
+  constexpr int SPI = kWave / BCAP;                  // seeds per load instruction
+  constexpr int NI = (kWave + SPI - 1) / SPI;        // load instructions per tile
+  unsigned bid = blockIdx.x, nblk = gridDim.x;
+  if constexpr (RING && RIDE) {
+    if (bid < a.side_blocks) {
+      update_side_work(u, a.side_stage, (int)bid);
+      if (a.tail_blocks) tail_signal(u.barrier, true, 0, 0);
+      return;
+    }
+    bid -= a.side_blocks;
+    nblk -= a.side_blocks + a.tail_blocks;
+    if (bid >= nblk) {
+      tail_commit(u, bid - nblk, a.tail_blocks, nblk + a.side_blocks);
+      return;
+    }
+  }
+  const int lane = lane_id();
+  const int wave_in_block = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+  const int k = a.k, B = a.B;
+  // per wave: lookup_tile_kernel's staging area + list area, then the header: [64] x {w0 lo, w0 hi, wlen, wrot} | [64] q | [64] span
+  constexpr int kHdrInts = kWave * 4 + kWave * 2 + kWave;
+  int* L = lds_eid_all + wave_in_block * (kWave * k + kWave * k / 2 + kWave + kHdrInts);
+  int* Lstage = L;
+  int* Lfirst = L + kWave * k;
+  int4* Lhdr = reinterpret_cast<int4*>(L + kWave * k + kWave * k / 2 + kWave);  // (the three areas before it are multiples of 16 bytes: k even or not, 64 k ints are)
+  long long* Lq = reinterpret_cast<long long*>(Lhdr + kWave);
+  int* Lspan = reinterpret_cast<int*>(Lq + kWave);
+  // this lane as a RECORD lane: record j of the seg-th seed of every load instruction
+  const int seg = lane / BCAP, j = lane - seg * BCAP;
+  const bool rec_lane = seg < SPI;
+  const int sh = seg * BCAP;
+  const unsigned long long FM = (1ull << BCAP) - 1, BM = (1ull << B) - 1;
+  const long long tiles = (a.S + kWave - 1) / kWave;
+  for (long long tv = (long long)bid * wpb + wave_in_block; tv < tiles; tv += (long long)nblk * wpb) {
+    const long long t = (long long)(((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)tv >> 32)) << 32) |
+                                    __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)tv));
+    const long long s = t * kWave + lane;
+    const bool act = s < a.S;
+    int n = -1, v_old = 0;
+    long long q = 0;
+    if (act) {
+      if (a.grp.groups > 0) {
+        fetch_seed(a, s, 0, true, n, q);
+      } else {
+        n = a.seeds[s];
+        q = a.qtimes[s];
+      }
+      if (a.out_valid) v_old = a.out_valid[s];
+      int st = 0;
+      if (n >= a.N || n < -1 || (n == -1 && !a.allow_pad)) st |= TGMX_ST_SEED_RANGE;
+      if (q < 0 && !a.allow_pad) st |= TGMX_ST_SEED_TIME;
+      if (st) atomicOr(a.status, st);
+    }
+    const bool live = n >= 0 && n < a.N;
+    long long w0 = 0;
+    int wlen = 0;
+    if (live) {
+      if constexpr (RING) {
+        w0 = (long long)n * B;
+        wlen = B;
+      } else {
+        const long long ra = a.indptr[n], rz = a.indptr[n + 1];
+        const long long hint = a.cursor ? a.cursor[n] : -1;
+        const long long p_hi = lane_prefix_end_hinted(a.recs, ra, rz, a.ev_hi, hint);
+        if (a.cursor && p_hi != hint) a.cursor[n] = p_hi;
+        const long long p_lo = a.ev_lo <= 0 ? ra : ra + lane_prefix_count(a.recs, ra, rz, a.ev_lo);
+        w0 = p_hi - B > p_lo ? p_hi - B : p_lo;
+        wlen = (int)(p_hi - w0);
+      }
+    }
+    int wpos = 0;
+    if constexpr (RING) {
+      if (live) wpos = a.write_pos[n];  // in flight beside the record loads below; consumed after them
+    }
+    Lhdr[lane] = int4{(int)(unsigned)(unsigned long long)w0, (int)(unsigned)((unsigned long long)w0 >> 32), wlen, 0};
+    Lq[lane] = q;
+    for (int c = 0; c < k; ++c) Lstage[lane * k + c] = -1;  // pads; the pick below overwrites what the windows fill
+    __builtin_amdgcn_wave_barrier();
+    // ---- the windows, cooperatively: instruction i = seeds [i SPI, i SPI + SPI), BCAP lanes each
+    Rec r[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int sl = i * SPI + seg;
+      const int4 h = Lhdr[sl < kWave ? sl : kWave - 1];
+      r[i].nbr = -1;  // (a lane without a record holds a pad: `nbr >= 0` below is all the pick asks)
+      r[i].eid = 0;
+      r[i].ts = 0;
+      const long long base = (long long)(((unsigned long long)(unsigned)h.y << 32) | (unsigned)h.x);
+      if (rec_lane && sl < kWave && j < h.z) r[i] = a.recs[base + j];
+    }
+    if constexpr (RING) {
+      Lhdr[lane].w = live ? wpos % B : 0;
+      __builtin_amdgcn_wave_barrier();
+    }
+    // ---- the pick: per instruction one ballot, the rest is arithmetic on the seed's bit field
+    // output slot of the lane's record of instruction i, + 1 (0: not part of the row), four to a register
+    unsigned cs4[(NI + 3) / 4];
+#pragma unroll
+    for (int w = 0; w < (NI + 3) / 4; ++w) cs4[w] = 0;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      // (fence: without it hipcc hoists all NI header reads in front of the loop -- 6 registers each -- and the kernel loses a wave per SIMD)
+      __builtin_amdgcn_sched_barrier(0);
+      const int sl = i * SPI + seg, slc = sl < kWave ? sl : kWave - 1;
+      const long long qq = Lq[slc];
+      const int wrot = RING ? Lhdr[slc].w : 0;
+      const bool has = r[i].nbr >= 0;
+      const unsigned long long m_ok = __ballot(has && r[i].ts < qq), m_nb = __ballot(has);
+      if constexpr (RING) asm volatile("" ::"v"(r[i].eid));  // keep the record ONE 16-byte load (see lookup_tile_kernel)
+      unsigned long long f_ok = (m_ok >> sh) & FM, f_nb = (m_nb >> sh) & FM;  // bit jj = record jj of this lane's seed
+      if constexpr (RING) {  // unrolled (oldest -> newest) position of slot jj is (jj - wrot) mod B: rotate the fields right by wrot
+        f_ok = ((f_ok >> wrot) | (f_ok << (B - wrot))) & BM;
+        f_nb = ((f_nb >> wrot) | (f_nb << (B - wrot))) & BM;
+      }
+      const int cnt = f_ok ? 64 - __clzll((long long)f_ok) : 0;  // 1 + unrolled position of the newest entry with ts < q
+      int iu = j - wrot;
+      if (iu < 0) iu += B;
+      const int c = iu - (cnt - k);  // output slot of unrolled position iu
+      const bool valid = has && iu < cnt && c >= 0;
+      cs4[i >> 2] |= (valid ? (unsigned)(c + 1) : 0u) << (8 * (i & 3));
+      if (valid) Lstage[sl * k + c] = r[i].nbr;
+      if (rec_lane && sl < kWave && j == 0) {
+        // the row's SPAN (lookup_seed): k - its leftmost non-pad output slot; the window's positions [cnt - k, cnt) feed slots [0, k)
+        const int lo = cnt - k > 0 ? cnt - k : 0;
+        const unsigned long long w = (f_nb & ((1ull << cnt) - 1)) >> lo;
+        Lspan[sl] = w ? k - (lo + __builtin_ctzll(w) - (cnt - k)) : 0;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    int first_slot = act ? 0 : k;
+    if (a.out_valid && act) {  // delta feature writes: see LookupArgs::out_valid
+      const int v_new = Lspan[lane];
+      first_slot = k - (v_old > v_new ? v_old : v_new);
+      a.out_valid[s] = v_new;
+      if (a.out_valid_prev) a.out_valid_prev[s] = v_old;
+    }
+    // flush the tile's ids: flat 16-byte pieces of [rows, k]
+    const int rows = (int)((a.S - t * kWave) < kWave ? (a.S - t * kWave) : kWave);
+    const int ne = rows * k;
+    {
+      const int4* __restrict__ L4 = reinterpret_cast<const int4*>(Lstage);
+      int32_t* __restrict__ G = a.out_nid + t * kWave * k;
+      int4* __restrict__ G4 = reinterpret_cast<int4*>(G);
+      for (int f = lane; f < (ne >> 2); f += kWave) G4[f] = L4[f];
+      for (int f = (ne & ~3) + lane; f < ne; f += kWave) G[f] = Lstage[f];
+    }
+    // the times, 32 rows at a time through the same staging area ([32, k] int64 = [64, k] ints)
+    long long* Lts = reinterpret_cast<long long*>(Lstage);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      __builtin_amdgcn_wave_barrier();  // the staging area's previous contents have been read
+      if ((lane >> 5) == half) {
+        const int lr = lane & 31;
+        for (int c = 0; c < k; ++c) Lts[lr * k + c] = 0;
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int sl = i * SPI + seg;
+        const int c1 = (int)((cs4[i >> 2] >> (8 * (i & 3))) & 255u);
+        if (c1 > 0 && (sl >> 5) == half) Lts[(sl & 31) * k + c1 - 1] = r[i].ts;
+      }
+      __builtin_amdgcn_wave_barrier();
+      const int hrows = rows - 32 * half < 32 ? rows - 32 * half : 32;
+      if (hrows > 0) {
+        const int he = hrows * k;
+        const int4* __restrict__ T4 = reinterpret_cast<const int4*>(Lts);
+        int64_t* __restrict__ H = a.out_ts + (t * kWave + 32 * half) * k;
+        int4* __restrict__ H4 = reinterpret_cast<int4*>(H);
+        for (int f = lane; f < (he >> 1); f += kWave) H4[f] = T4[f];
+        if ((he & 1) && lane == 0) H[he - 1] = Lts[he - 1];
+      }
+    }
+    if (a.D > 0) {
+      // the staging area's last tenant: the feature row every output slot is copied from (-1: zeros)
+      __builtin_amdgcn_wave_barrier();
+      for (int c = 0; c < k; ++c) Lstage[lane * k + c] = -1;
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int sl = i * SPI + seg;
+        const int c1 = (int)((cs4[i >> 2] >> (8 * (i & 3))) & 255u);
+        if (c1 > 0) Lstage[sl * k + c1 - 1] = (RING || a.x_by_pos) ? (int)((unsigned)Lhdr[sl].x + (unsigned)j) : r[i].eid;
+      }
+      const int nact = k - first_slot;
+      int incl = nact;
+#pragma unroll
+      for (int d = 1; d < kWave; d <<= 1) {
+        const int up = __shfl_up(incl, d);
+        if (lane >= d) incl += up;
+      }
+      const int n_rows = __shfl(incl, kWave - 1);
+      unsigned short* Llist = reinterpret_cast<unsigned short*>(Lfirst);
+      for (int i = 0; i < nact; ++i) Llist[incl - nact + i] = (unsigned short)((lane << 8) | (first_slot + i));
+      __builtin_amdgcn_wave_barrier();
+      if constexpr (RING) tile_copy<VEC, true>(a, t, rows, k, lane, Lstage, Llist, n_rows, (long long)a.N * B);
+      else tile_copy<VEC, false>(a, t, rows, k, lane, Lstage, Llist, n_rows, 0);
+    }
+    __builtin_amdgcn_wave_barrier();  // the next tile reuses the staging area and the header
+  }
+  if constexpr (RING && RIDE) {
+    if (a.tail_blocks) tail_signal(u.barrier, false, bid, nblk);
+  }
+}
+
 // > 64 KB of LDS per workgroup (static + dynamic) is a per-DEVICE opt-in of the kernel function
 template <auto Kernel>
 static bool lds_optin() {
@@ -1981,20 +2202,27 @@ static int launch_lookup(LookupArgs a, hipStream_t stream, hipEvent_t ev_start, 
       if (tblocks > room) tblocks = room;
     }
     const dim3 tgrid((unsigned)tblocks + a.side_blocks + a.tail_blocks), tblock(wpb * kWave);
-    const size_t tlds = (size_t)wpb * (kWave * a.k + kWave * a.k / 2 + kWave) * sizeof(int);
     const int bcap = a.B <= 10 ? 10 : (a.B <= 20 ? 20 : 32);
-#define TGMX_TILE_LAUNCH(VEC_, BCAP_)                                                                                                       \
+    // the cooperative index phase (windows read as contiguous runs by neighbouring lanes, lookup_tile_coop_kernel): B <= 20, the low 32 bits
+    // of a window's base must address it (rings: checked above; static index: fewer than 2^31 records)
+    static const bool coop_on = !(getenv("TGMX_TILE_COOP") && atoi(getenv("TGMX_TILE_COOP")) == 0);  // A/B knob: 0 = one lane per window
+    const bool coop = coop_on && bcap <= 20;
+    const size_t tlds = (size_t)wpb * (kWave * a.k + kWave * a.k / 2 + kWave + (coop ? kWave * 7 : 0)) * sizeof(int);
+#define TGMX_TILE_LAUNCH_K(KERNEL_, VEC_, BCAP_)                                                                                            \
   do {                                                                                                                                      \
     if (ride) {                                                                                                                             \
-      if (tlds > 32 * 1024 && !lds_optin<lookup_tile_kernel<RING, VEC_, BCAP_, RING>>()) return TGMX_E_LAUNCH;                               \
-      TGMX_LAUNCH_TIMED((lookup_tile_kernel<RING, VEC_, BCAP_, RING>), tgrid, tblock, tlds, stream, ev_start, ev_stop, a, u);                \
-    } else TGMX_LAUNCH_TIMED((lookup_tile_kernel<RING, VEC_, BCAP_, false>), tgrid, tblock, tlds, stream, ev_start, ev_stop, a, u);         \
+      if (tlds > 32 * 1024 && !lds_optin<KERNEL_<RING, VEC_, BCAP_, RING>>()) return TGMX_E_LAUNCH;                                          \
+      TGMX_LAUNCH_TIMED((KERNEL_<RING, VEC_, BCAP_, RING>), tgrid, tblock, tlds, stream, ev_start, ev_stop, a, u);                           \
+    } else TGMX_LAUNCH_TIMED((KERNEL_<RING, VEC_, BCAP_, false>), tgrid, tblock, tlds, stream, ev_start, ev_stop, a, u);                    \
   } while (0)
-#define TGMX_TILE_VEC(VEC_)                         \
-  do {                                              \
-    if (bcap == 10) TGMX_TILE_LAUNCH(VEC_, 10);     \
-    else if (bcap == 20) TGMX_TILE_LAUNCH(VEC_, 20); \
-    else TGMX_TILE_LAUNCH(VEC_, 32);                \
+#define TGMX_TILE_LAUNCH(VEC_, BCAP_) TGMX_TILE_LAUNCH_K(lookup_tile_kernel, VEC_, BCAP_)
+#define TGMX_TILE_VEC(VEC_)                                                           \
+  do {                                                                                \
+    if (bcap == 10 && coop) TGMX_TILE_LAUNCH_K(lookup_tile_coop_kernel, VEC_, 10);    \
+    else if (bcap == 20 && coop) TGMX_TILE_LAUNCH_K(lookup_tile_coop_kernel, VEC_, 20); \
+    else if (bcap == 10) TGMX_TILE_LAUNCH(VEC_, 10);                                  \
+    else if (bcap == 20) TGMX_TILE_LAUNCH(VEC_, 20);                                  \
+    else TGMX_TILE_LAUNCH(VEC_, 32);                                                  \
   } while (0)
     if (vec == 4) TGMX_TILE_VEC(4);
     else {
@@ -2007,6 +2235,7 @@ static int launch_lookup(LookupArgs a, hipStream_t stream, hipEvent_t ev_start, 
     }
 #undef TGMX_TILE_VEC
 #undef TGMX_TILE_LAUNCH
+#undef TGMX_TILE_LAUNCH_K
   } else if (gl < 64) {
     const int per_wave = 64 / gl;
     long long pblocks = ((a.S + per_wave - 1) / per_wave + waves_per_block - 1) / waves_per_block;
