@@ -374,7 +374,7 @@ def scale_comment_block(args, rank, world, device, n_steps=48):
             'per_rank_sampled_edges_per_s': [r['slots'] / (r['us_per_step_own'] * r['steps'] * 1e-6) for r in ranks],
             'per_rank_us_per_step': [r['us_per_step_own'] for r in ranks],
             'per_rank_hop1_hbm_frac': [r['hop1_hbm_frac'] for r in ranks], 'per_rank_hop1_kernel_ms': [r['hop1_kernel_ms'] for r in ranks],
-            'kernel': 'lookup_tile_kernel (hop 1: %d seeds x k=%d per rank)' % (st['shape'][-1][0], st['shape'][-1][1]),
+            'kernel': 'lookup_tile_coop_kernel (hop 1: %d seeds x k=%d per rank)' % (st['shape'][-1][0], st['shape'][-1][1]),
         }
     del cs
     torch.cuda.empty_cache()
@@ -895,7 +895,7 @@ def main():
             hb = {}
             for cmode in ('ring', 'csr'):
                 st_c = probe_variant(cs, cbs, cnb, cmode, device, n_cb // 2, 48, pool=1)
-                hb[cmode] = {'kernel': 'lookup_tile_kernel (hop 1: %d seeds x k=%d)' % (st_c['shape'][-1][0], st_c['shape'][-1][1]),
+                hb[cmode] = {'kernel': 'lookup_tile_coop_kernel (hop 1: %d seeds x k=%d)' % (st_c['shape'][-1][0], st_c['shape'][-1][1]),
                              'achieved': st_c['algo_bytes'] / (st_c['avg_ms'] * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                              'frac': st_c['algo_bytes'] / (st_c['avg_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 'avg_kernel_ms': st_c['avg_ms'],
                              'min_max_kernel_ms': [min(st_c['ker_ms']), max(st_c['ker_ms'])], 'launches_timed': len(st_c['ker_ms']),

@@ -674,6 +674,28 @@ def test_cfg4_comment_shape_reduced_vs_oracle():
     _against_oracle(make_stream('comment', seed=4, num_edges=9 * 4096 + 77, n_src=50_000), 4096, [20, 20], 1000)
 
 
+@pytest.mark.parametrize('bs,ks,D,pool', [(1200, [10, 10], 16, 1), (1200, [10, 10], 6, 3), (1800, [20, 20], 16, 1), (1300, [10, 10], 4, 3), (1100, [12, 12], 8, 1)])
+def test_tile_kernels_cooperative_index_phase_vs_oracle(bs, ks, D, pool):
+    """The narrow-row TILE kernels at shapes the BASELINE configurations do not reach (hop 1 >= 2 tiles per CU, i.e. >= 32 768 seeds):
+    B = 10 (six windows per load instruction of the cooperative index phase, lookup_tile_coop_kernel<.., 10, ..>), B = 12 (five per
+    instruction through the BCAP = 20 body), B = 20; D = 16 (16-byte pieces), D = 4 (one piece per row), D = 6 / 8 (the float-piece copy);
+    m = 2 bs <= 4096 entries, so the ring update's placement RIDES the tile launch (the RIDE instantiations); pool = 1: delta feature
+    writes into one persistent set.  Rings against the CPU restatement of the reference bit for bit, the static index against the rings."""
+    from tgm_amd.synth import make_stream
+
+    st = make_stream('comment', seed=11, num_edges=7 * bs + 19, n_src=6_000, edge_dim=D)
+    _against_oracle(st, bs, ks, 1000, pool=pool)
+    _, hm_r, hook_r, ld_r = _pooled_pipeline(st, bs, ks, mode='ring', key_arith='int64', pool=3)
+    _, hm_c, hook_c, ld_c = _pooled_pipeline(st, bs, ks, mode='csr', pool=3)
+    with hm_r.activate('k'), hm_c.activate('k'):
+        for b, (br, bc) in enumerate(zip(ld_r, ld_c)):
+            for h in range(2):
+                assert torch.equal(br.nbr_nids[h], bc.nbr_nids[h]) and torch.equal(br.nbr_edge_time[h], bc.nbr_edge_time[h]), (b, h)
+                assert torch.equal(br.nbr_edge_x[h], bc.nbr_edge_x[h]), (b, h, 'features')
+    hook_r.check()
+    hook_c.check()
+
+
 def test_cfg4_comment_full_size_midstream_properties():
     """BASELINE cfg 4 at FULL size (N = 1 M, E = 44 M, D = 16, bs = 4096, k = [20, 20]), an epoch opened mid-stream at
     edge 22 M and followed for 120 batches: the streaming rings (intended key order) and the static index over the

@@ -1885,8 +1885,14 @@ __global__ __launch_bounds__(256) void lookup_tile_kernel(const LookupArgs a, co
 // Per-seed scalars (window base, q, write position) go from the seed's lane to its record lanes through a small LDS header.
 // Everything after the pick (staging, coalesced flushes, delta-aware copy phase) is lookup_tile_kernel's, fed from the same LDS
 // areas; results are identical (tests: every sampler test runs both, TGMX_TILE_COOP=0 is the A/B knob).  BCAP <= 20 (B <= 20).
+// Registers: hipcc hoists everything that depends on the lane alone out of the tile loop (first version: 150 registers of LDS addresses,
+// one wave per SIMD); `fresh` below makes every phase recompute them.  Streaming rings WITHOUT riders (the comment-shaped step: the
+// update's front half is a 1 024-thread workgroup on the library's side stream) are held to TWO waves per SIMD on purpose: with three
+// (forced, 145 registers) the same kernel takes 107 instead of 90-99 us per launch on the comment shape -- the front-half workgroup then
+// finds no CU with a quarter of its registers free until tiles retire (profiles/r06_tile_coop_occupancy_sweep.txt).  The static
+// index has no such neighbour and runs at its natural 155 registers (three waves per SIMD; two measure the same).
 template <bool RING, int VEC, int BCAP, bool RIDE>
-__global__ __launch_bounds__(256) void lookup_tile_coop_kernel(const LookupArgs a, const UpdateArgs u) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, (RING && !RIDE) ? 2 : 8))) void lookup_tile_coop_kernel(const LookupArgs a, const UpdateArgs u) {
   extern __shared__ __attribute__((aligned(16))) int lds_eid_all[];
   constexpr int SPI = kWave / BCAP;                  // seeds per load instruction
   constexpr int NI = (kWave + SPI - 1) / SPI;        // load instructions per tile
@@ -1916,10 +1922,15 @@ __global__ __launch_bounds__(256) void lookup_tile_coop_kernel(const LookupArgs 
   long long* Lq = reinterpret_cast<long long*>(Lhdr + kWave);
   int* Lspan = reinterpret_cast<int*>(Lq + kWave);
   // this lane as a RECORD lane: record j of the seg-th seed of every load instruction
-  const int seg = lane / BCAP, j = lane - seg * BCAP;
-  const bool rec_lane = seg < SPI;
-  const int sh = seg * BCAP;
-  const unsigned long long FM = (1ull << BCAP) - 1, BM = (1ull << B) - 1;
+  // (hipcc hoists everything that depends on the lane alone out of the tile loop -- here that is ~150 registers of per-instruction LDS
+  // addresses, live across the whole kernel: one wave per SIMD.  `fresh` hands a phase its own copy of the segment index, so the
+  // addresses are recomputed where they are used: a handful of integer operations per record)
+  const int seg0 = lane / BCAP;
+  auto fresh = [](int v) __attribute__((always_inline)) {
+    asm volatile("" : "+v"(v));
+    return v;
+  };
+  const unsigned FM = (1u << BCAP) - 1, BM = (1u << B) - 1;  // (BCAP, B <= 20: a window's bit field fits 32 bits)
   const long long tiles = (a.S + kWave - 1) / kWave;
   for (long long tv = (long long)bid * wpb + wave_in_block; tv < tiles; tv += (long long)nblk * wpb) {
     const long long t = (long long)(((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)tv >> 32)) << 32) |
@@ -1967,42 +1978,44 @@ __global__ __launch_bounds__(256) void lookup_tile_coop_kernel(const LookupArgs 
     for (int c = 0; c < k; ++c) Lstage[lane * k + c] = -1;  // pads; the pick below overwrites what the windows fill
     __builtin_amdgcn_wave_barrier();
     // ---- the windows, cooperatively: instruction i = seeds [i SPI, i SPI + SPI), BCAP lanes each
+    int seg = fresh(seg0), j = lane - seg * BCAP;
+    bool rec_lane = seg < SPI;
+    // Branch-free: NI unconditional loads -- a lane without a record (a pad / absent seed, the wave's spare lanes) reads record 0 (a store
+    // with an edge has one) and is masked in the pick.
     Rec r[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int sl = i * SPI + seg;
       const int4 h = Lhdr[sl < kWave ? sl : kWave - 1];
-      r[i].nbr = -1;  // (a lane without a record holds a pad: `nbr >= 0` below is all the pick asks)
-      r[i].eid = 0;
-      r[i].ts = 0;
       const long long base = (long long)(((unsigned long long)(unsigned)h.y << 32) | (unsigned)h.x);
-      if (rec_lane && sl < kWave && j < h.z) r[i] = a.recs[base + j];
+      r[i] = a.recs[(rec_lane && sl < kWave && j < h.z) ? base + j : 0];
     }
     if constexpr (RING) {
       Lhdr[lane].w = live ? wpos % B : 0;
       __builtin_amdgcn_wave_barrier();
     }
     // ---- the pick: per instruction one ballot, the rest is arithmetic on the seed's bit field
+    seg = fresh(seg0), j = lane - seg * BCAP, rec_lane = seg < SPI;
+    const int sh = seg * BCAP;
     // output slot of the lane's record of instruction i, + 1 (0: not part of the row), four to a register
     unsigned cs4[(NI + 3) / 4];
 #pragma unroll
     for (int w = 0; w < (NI + 3) / 4; ++w) cs4[w] = 0;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      // (fence: without it hipcc hoists all NI header reads in front of the loop -- 6 registers each -- and the kernel loses a wave per SIMD)
-      __builtin_amdgcn_sched_barrier(0);
       const int sl = i * SPI + seg, slc = sl < kWave ? sl : kWave - 1;
       const long long qq = Lq[slc];
-      const int wrot = RING ? Lhdr[slc].w : 0;
-      const bool has = r[i].nbr >= 0;
+      const int4 h = Lhdr[slc];
+      const int wrot = RING ? h.w : 0;
+      const bool has = rec_lane && sl < kWave && j < h.z && r[i].nbr >= 0;
       const unsigned long long m_ok = __ballot(has && r[i].ts < qq), m_nb = __ballot(has);
       if constexpr (RING) asm volatile("" ::"v"(r[i].eid));  // keep the record ONE 16-byte load (see lookup_tile_kernel)
-      unsigned long long f_ok = (m_ok >> sh) & FM, f_nb = (m_nb >> sh) & FM;  // bit jj = record jj of this lane's seed
+      unsigned f_ok = (unsigned)(m_ok >> sh) & FM, f_nb = (unsigned)(m_nb >> sh) & FM;  // bit jj = record jj of this lane's seed
       if constexpr (RING) {  // unrolled (oldest -> newest) position of slot jj is (jj - wrot) mod B: rotate the fields right by wrot
         f_ok = ((f_ok >> wrot) | (f_ok << (B - wrot))) & BM;
         f_nb = ((f_nb >> wrot) | (f_nb << (B - wrot))) & BM;
       }
-      const int cnt = f_ok ? 64 - __clzll((long long)f_ok) : 0;  // 1 + unrolled position of the newest entry with ts < q
+      const int cnt = f_ok ? 32 - __clz((int)f_ok) : 0;  // 1 + unrolled position of the newest entry with ts < q
       int iu = j - wrot;
       if (iu < 0) iu += B;
       const int c = iu - (cnt - k);  // output slot of unrolled position iu
@@ -2012,8 +2025,8 @@ __global__ __launch_bounds__(256) void lookup_tile_coop_kernel(const LookupArgs 
       if (rec_lane && sl < kWave && j == 0) {
         // the row's SPAN (lookup_seed): k - its leftmost non-pad output slot; the window's positions [cnt - k, cnt) feed slots [0, k)
         const int lo = cnt - k > 0 ? cnt - k : 0;
-        const unsigned long long w = (f_nb & ((1ull << cnt) - 1)) >> lo;
-        Lspan[sl] = w ? k - (lo + __builtin_ctzll(w) - (cnt - k)) : 0;
+        const unsigned w = (f_nb & ((1u << cnt) - 1)) >> lo;
+        Lspan[sl] = w ? k - (lo + __builtin_ctz(w) - (cnt - k)) : 0;
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -2044,6 +2057,7 @@ __global__ __launch_bounds__(256) void lookup_tile_coop_kernel(const LookupArgs 
         for (int c = 0; c < k; ++c) Lts[lr * k + c] = 0;
       }
       __builtin_amdgcn_wave_barrier();
+      seg = fresh(seg0);
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
         const int sl = i * SPI + seg;
@@ -2066,6 +2080,7 @@ __global__ __launch_bounds__(256) void lookup_tile_coop_kernel(const LookupArgs 
       __builtin_amdgcn_wave_barrier();
       for (int c = 0; c < k; ++c) Lstage[lane * k + c] = -1;
       __builtin_amdgcn_wave_barrier();
+      seg = fresh(seg0), j = lane - seg * BCAP;
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
         const int sl = i * SPI + seg;
@@ -2083,8 +2098,12 @@ __global__ __launch_bounds__(256) void lookup_tile_coop_kernel(const LookupArgs 
       unsigned short* Llist = reinterpret_cast<unsigned short*>(Lfirst);
       for (int i = 0; i < nact; ++i) Llist[incl - nact + i] = (unsigned short)((lane << 8) | (first_slot + i));
       __builtin_amdgcn_wave_barrier();
-      if constexpr (RING) tile_copy<VEC, true>(a, t, rows, k, lane, Lstage, Llist, n_rows, (long long)a.N * B);
-      else tile_copy<VEC, false>(a, t, rows, k, lane, Lstage, Llist, n_rows, 0);
+      // (the copy loop's per-lane constants -- ~40 registers of piece columns and offsets -- are recomputed per tile: hoisted out of the tile
+      // loop they would be live across the index phase, whose NI records already fill a third of the register file)
+      int lane_c = lane;
+      asm volatile("" : "+v"(lane_c));
+      if constexpr (RING) tile_copy<VEC, true>(a, t, rows, k, lane_c, Lstage, Llist, n_rows, (long long)a.N * B);
+      else tile_copy<VEC, false>(a, t, rows, k, lane_c, Lstage, Llist, n_rows, 0);
     }
     __builtin_amdgcn_wave_barrier();  // the next tile reuses the staging area and the header
   }
@@ -2213,7 +2232,10 @@ static int launch_lookup(LookupArgs a, hipStream_t stream, hipEvent_t ev_start, 
     if (ride) {                                                                                                                             \
       if (tlds > 32 * 1024 && !lds_optin<KERNEL_<RING, VEC_, BCAP_, RING>>()) return TGMX_E_LAUNCH;                                          \
       TGMX_LAUNCH_TIMED((KERNEL_<RING, VEC_, BCAP_, RING>), tgrid, tblock, tlds, stream, ev_start, ev_stop, a, u);                           \
-    } else TGMX_LAUNCH_TIMED((KERNEL_<RING, VEC_, BCAP_, false>), tgrid, tblock, tlds, stream, ev_start, ev_stop, a, u);                    \
+    } else {                                                                                                                                \
+      if (tlds > 32 * 1024 && !lds_optin<KERNEL_<RING, VEC_, BCAP_, false>>()) return TGMX_E_LAUNCH;                                         \
+      TGMX_LAUNCH_TIMED((KERNEL_<RING, VEC_, BCAP_, false>), tgrid, tblock, tlds, stream, ev_start, ev_stop, a, u);                          \
+    }                                                                                                                                       \
   } while (0)
 #define TGMX_TILE_LAUNCH(VEC_, BCAP_) TGMX_TILE_LAUNCH_K(lookup_tile_kernel, VEC_, BCAP_)
 #define TGMX_TILE_VEC(VEC_)                                                           \
