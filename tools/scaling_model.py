@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Modelled multi-GPU scaling from ONE GPU: run the slowest rank's exact step of a W-rank job (bench.py --emulate-world W)
 for W = 1, 2, 4, 8.  There is no collective on the sampling data path, so the emulated rank misses nothing; what it cannot
-show is interference between processes on a shared host.  Writes profiles/r04_scaling_model.json (the model's inputs -- every emulated run's own numbers -- are the rows of that file).
+show is interference between processes on a shared host.  Writes gpurun_out/profiles_r06/r06_scaling_model.json (copy into profiles/) (the model's inputs -- every emulated run's own numbers -- are the rows of that file).
 
     python tools/scaling_model.py            (on the GPU box, from the repo root)
 """
@@ -39,4 +39,5 @@ for workload, scaling, mode, extra in CASES:
     out[f'{workload}_{scaling}_{mode}'] = rows
     print(workload, scaling, mode, json.dumps(rows), flush=True)
 json.dump({'method': 'bench.py --emulate-world W --emulate-rank W-1 on one MI355X (the last rank; all ranks do the same amount of work); '
-           'no hardware multi-GPU curve exists yet (SCALE was skipped in rounds 1-3)', 'results': out}, open(os.path.join(ROOT, 'profiles', 'r04_scaling_model.json'), 'w'), indent=1)
+           'no hardware multi-GPU curve exists yet (SCALE was skipped in every round so far)', 'results': out},
+          open(sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, 'gpurun_out', 'profiles_r06', 'r06_scaling_model.json'), 'w'), indent=1)
