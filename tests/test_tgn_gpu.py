@@ -384,6 +384,54 @@ def test_tgn_step_equals_the_three_module_calls(aggr):
 
 
 
+def test_tgn_step_survives_module_calls_in_between():
+    """The modules of a TGNStep used DIRECTLY between two steps (``memory(n_id)`` and the embedding on their own, ``reuse_forward`` toggled, a
+    fallback batch): the step's cached static argument fields must not depend on what the modules do with their own argument blocks
+    (they rewrite them in full on every module call).  Twin modules driven by the three module calls only give the reference."""
+    from tgm_amd import DGData, DGDataLoader, DGraph
+    from tgm_amd.hooks import DeduplicationHook, HookManager, RandomNegativeEdgeSamplerHook, RecencyNeighborHook, SampledEdgeListHook
+    from tgm_amd.nn import GraphAttentionEmbedding, IdentityMessage, LastAggregator, TGNMemory, TGNStep
+    from tgm_amd.synth import make_stream
+
+    st = make_stream('review', seed=12, num_edges=24 * 256, n_src=1500, n_dst=200)
+    N, D, M, T_, bs = st.num_nodes, 16, 100, 100, 256
+
+    def build():
+        torch.manual_seed(3)
+        mem = TGNMemory(N, D, M, T_, IdentityMessage(D, M, T_), LastAggregator()).to(DEV).train()
+        mem.reuse_forward = True
+        return mem, GraphAttentionEmbedding(M, 100, D, mem.time_enc).to(DEV).eval()
+
+    dg = DGraph(DGData.from_raw(st.ts, torch.stack([st.src, st.dst], 1), st.edge_x), device=DEV)
+    hm = HookManager(keys=['k'])
+    hm.register('k', RandomNegativeEdgeSamplerHook(1500, N, seed=4))
+    hm.register('k', RecencyNeighborHook(N, [10], ['edge_src', 'edge_dst', 'neg'], ['edge_time', 'edge_time', 'neg_time'], validate='deferred', edge_features='by_id'))
+    hm.register('k', DeduplicationHook(seed_nodes_keys=['neg', 'nbr_nids']))
+    hm.register('k', SampledEdgeListHook(hop=0))
+    (mem_a, enc_a), (mem_b, enc_b) = build(), build()
+    step = TGNStep(mem_b, enc_b)
+    with hm.activate('k'), torch.no_grad():
+        for b, batch in enumerate(DGDataLoader(dg, batch_size=bs, hook_manager=hm)):
+            z, lu = mem_a(batch.unique_nids)
+            z2 = enc_a(z, lu, batch.sampled_edge_index, batch.sampled_edge_time, batch.sampled_edge_x)
+            mem_a.update_state(batch.edge_src, batch.edge_dst, batch.edge_time, batch.edge_x)
+            if b % 4 == 1:  # the modules on their own, on OTHER inputs than the step's: they rewrite their argument blocks (results discarded;
+                some = batch.unique_nids[: max(1, batch.unique_nids.numel() // 3)]  # a pure look-ahead, nothing is committed)
+                mem_b.reuse_forward = False
+                zz, ll = mem_b(some)
+                k_ = min(5, batch.sampled_edge_index.shape[1])
+                if k_:
+                    enc_b(torch.randn(int(batch.unique_nids.numel()), M, device=DEV), torch.zeros(int(batch.unique_nids.numel()), dtype=torch.long, device=DEV),
+                          batch.sampled_edge_index[:, :k_], batch.sampled_edge_time[:k_], batch.sampled_edge_x[:k_])
+                mem_b.reuse_forward = True
+            y2, y, ylu = step.batch(batch)
+            assert torch.equal(z, y) and torch.equal(lu, ylu) and torch.equal(z2, y2), f'batch {b}'
+        mem_a.check()
+        mem_b.check()
+    assert step.fast_calls >= 20
+    assert torch.equal(mem_a.memory, mem_b.memory) and torch.equal(mem_a.last_update, mem_b.last_update)
+
+
 @pytest.mark.parametrize('inference', [False, True])
 @pytest.mark.parametrize('emb,U,E,n_hot', [(100, 2000, 3000, 0), (128, 2000, 3000, 0), (128, 300, 4000, 40), (100, 50, 9000, 3), (6, 300, 2000, 20), (128, 40, 9000, 2)])
 def test_graph_attention_embedding_walks_match_restatement(emb, U, E, n_hot, inference):

@@ -1324,6 +1324,7 @@ struct StepSide {  // a stream + two events of the library's own, per calling th
   hipStream_t stream = nullptr;
   hipEvent_t fork = nullptr, join = nullptr;
   int device = -1;
+  bool failed = false;
 };
 StepSide* step_side() {
   static thread_local StepSide s;
@@ -1331,17 +1332,37 @@ StepSide* step_side() {
   if (hipGetDevice(&dev) != hipSuccess) return nullptr;
   if (s.stream && s.device == dev) return &s;
   if (s.stream) return nullptr;  // (one device per thread: anything else keeps the single-stream order)
+  if (s.failed) return nullptr;  // (a failed set-up is not retried on every call: the step then keeps the single-stream order)
   if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) {
     s.stream = nullptr;
+    s.failed = true;
     return nullptr;
   }
   if (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess) {
+    // partial set-up: give back what was created
+    if (s.fork) (void)hipEventDestroy(s.fork);
+    if (s.join) (void)hipEventDestroy(s.join);
+    (void)hipStreamDestroy(s.stream);
     s.stream = nullptr;
+    s.fork = s.join = nullptr;
+    s.failed = true;
     return nullptr;
   }
   s.device = dev;
   return &s;
 }
+// After the fork the library's stream may hold kernels that read the step's buffers: whatever happens next, the caller's stream is made to wait
+// for them before tgmx_tgn_step returns (the caller frees / reuses the buffers in stream order of ITS stream only).
+struct JoinOnExit {
+  hipStream_t caller, side;
+  hipEvent_t join;
+  bool armed = false, joined = false;
+  ~JoinOnExit() {
+    if (armed && !joined) {
+      if (hipEventRecord(join, side) != hipSuccess || hipStreamWaitEvent(caller, join, 0) != hipSuccess) (void)hipStreamSynchronize(side);
+    }
+  }
+};
 }  // namespace
 
 extern "C" int tgmx_tgn_step(const tgmx_tgn_step_t* a, tgmx_stream_t stream) {
@@ -1374,6 +1395,8 @@ extern "C" int tgmx_tgn_step(const tgmx_tgn_step_t* a, tgmx_stream_t stream) {
       set_error("tgn_step: fork failed");
       return TGMX_E_LAUNCH;
     }
+    JoinOnExit guard{st, ss, side->join};
+    guard.armed = true;  // from here on every return joins the library's stream back into the caller's
     // ---- edge side, on the library's stream ----
     long long blocks = (E * Wd + 255) / 256;
     if (blocks > 16384) blocks = 16384;
@@ -1395,6 +1418,7 @@ extern "C" int tgmx_tgn_step(const tgmx_tgn_step_t* a, tgmx_stream_t stream) {
       set_error("tgn_step: join failed");
       return TGMX_E_LAUNCH;
     }
+    guard.joined = true;
     float* out = c->qkvs + 3 * U * HC;
     TconvArgs t{c->qkvs, c->qkvs + U * HC, c->qkvs + 2 * U * HC, c->eproj, c->order, c->src, c->seg_lo, c->seg_hi, out, U, c->H, c->C,
                 1.0f / sqrtf((float)c->C)};

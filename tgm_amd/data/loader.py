@@ -350,7 +350,13 @@ class DGDataLoader(torch.utils.data.DataLoader):
         if dev.type != 'cuda':
             raise ValueError('side_stream=True needs a device-resident graph (DGraph(..., device="cuda"))')
         lib = _native.load()
-        if self._side is None or self._side[0].device != dev:
+        if self._side is not None and self._side[0].device != dev:
+            # the graph moved to another device: the old worker (joined after its pending jobs) and events go before the new ones come
+            _native.check(lib.tgmx_worker_destroy(self._side[2]), 'tgmx_worker_destroy')
+            for e in self._side[1]:
+                lib.tgmx_event_destroy(e)
+            self._side = None
+        if self._side is None:
             n_ev = 2 * (self._prefetch + 2)
             evs = []
             for _ in range(n_ev):

@@ -697,7 +697,9 @@ class TGNStep:
         self._static_key = None  # addresses behind the argument blocks' static fields (see __call__)
         self._lib = None
         self._seg_ws_edges, self._seg_ws_bytes = -1, 0  # the segment sort's workspace covers edge lists up to this size
-        self._blocks = (None, None)  # the memory's / the convolution's argument blocks the static fields were written into
+        # PRIVATE argument blocks: the modules rewrite theirs (TGNMemory._fwd_args, TransformerConv._fwd_args) in full on every module call
+        # -- a fallback call, or the modules used directly between two steps -- which the static-field cache below could not see
+        self._mem_args, self._conv_args = _native.TgnMemoryFwd(), _native.TconvFwd()
         self.fast_calls = self.fallback_calls = 0
 
     def batch(self, batch):
@@ -746,9 +748,7 @@ class TGNStep:
         ws = self._ws = self._grow(self._ws, R * (W + 7 * M), torch.float32, dev)
         z = torch.empty((R, M), dtype=torch.float32, device=dev)
         lu = torch.empty(R, dtype=torch.int64, device=dev)
-        a = mem._fwd_args
-        if a is None:
-            a = mem._fwd_args = _native.TgnMemoryFwd()
+        a = self._mem_args
         wkey = (param_key(mem), param_key(emb))
         if self._wkey != wkey:  # the weights' addresses (and the stacked projections) only move with the parameters
             gru = mem.memory_updater
@@ -787,11 +787,7 @@ class TGNStep:
         cnt = getattr(conv, '_tgt_count', None)
         if cnt is None or cnt.device != dev or cnt.numel() < U:
             cnt = conv._tgt_count = torch.zeros(max(2 * U, 1 << 14), dtype=torch.int32, device=dev)
-        c = getattr(conv, '_fwd_args', None)
-        if c is None:
-            c = conv._fwd_args = _native.TconvFwd()
-        if a is not self._blocks[0] or c is not self._blocks[1]:  # (held here: a block's address cannot be reused while it is remembered)
-            self._blocks, self._static_key = (a, c), None
+        c = self._conv_args
         s = self._args
         base, flp, ip = ws.data_ptr(), fl.data_ptr(), ints.data_ptr()
         # Everything that only moves when a buffer is (re)allocated or the parameters change is written into the argument blocks ONCE per

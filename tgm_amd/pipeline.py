@@ -440,6 +440,7 @@ class CompiledPipeline:
                     self._last = len(sets) - 1
                 # else: nobody keeps it -- the batch owns plain fresh tensors
         if os_.buf._version != os_.version:
+            self._order_behind_worker()  # (a torch op from this thread on the loader's stream: behind the worker's pending steps)
             self._reinit_set(os_)
         return os_
 
@@ -489,10 +490,13 @@ class CompiledPipeline:
         ring_mode = nbr._mode == 'ring'
         if ring_mode:
             if n > nbr._scratch_edges:
+                self._order_behind_worker()  # the reallocation frees scratch the worker's pending steps may still point at
                 nbr._ensure_scratch(n, self._device)
             if nbr._step.scratch != self._scratch_ptr:
                 self._scratch_ptr = pipe.step.scratch = nbr._step.scratch
         else:
+            if nbr._csr is None or nbr._csr_store is not self._dg._storage or nbr._csr.device != nbr._device:
+                self._order_behind_worker()  # an index (re)build enqueues from this thread
             nbr._ensure_csr(self._dg, lo)
             nbr._check_csr_boundary(lo)
             if nbr._epoch_lo is None:
