@@ -185,7 +185,7 @@ def profile_key(args, bs, num_nbrs, steps, world=1):
 
 
 def committed_profile(key):
-    """(pmc json, its path) of the newest committed profile taken with exactly these arguments (tools/gpu_profile_r4.sh), or (None, None)."""
+    """(pmc json, its path) of the newest committed profile taken with exactly these arguments (tools/gpu_profile_r6.sh), or (None, None)."""
     import glob
 
     for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_*_pmc.json')), reverse=True):  # the newest round's first
@@ -201,7 +201,7 @@ def committed_profile(key):
 
 def kernel_src_sha():
     """Identity of the sampler's kernel sources in THIS tree (there is no .git on the GPU box): a committed counter profile describes the
-    running kernels only if it was taken from the same sources (tools/gpu_profile_r5.sh records this value)."""
+    running kernels only if it was taken from the same sources (tools/gpu_profile_r6.sh records this value)."""
     import hashlib
 
     h = hashlib.sha256()
@@ -213,7 +213,7 @@ def kernel_src_sha():
 
 def pmc_traffic(key, note=None):
     """HBM-side bytes per TIMED launch of the dominant kernel from the committed PMC passes of this very command (rocprofv3 --pmc
-    FETCH_SIZE / WRITE_SIZE, separate runs, averaged over the timed launches only: tools/gpu_profile_r5.sh).  FETCH_SIZE is doubled:
+    FETCH_SIZE / WRITE_SIZE, separate runs, averaged over the timed launches only: tools/gpu_profile_r6.sh).  FETCH_SIZE is doubled:
     the gfx950 correction of MI355X_MICROARCH.md for wide coalesced reads.  None when no profile of these arguments exists, or when
     the newest one was taken from other kernel sources than this tree's (`note` then says which file was passed over and why)."""
     p, path = committed_profile(key)
