@@ -792,7 +792,10 @@ def main():
     achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
     shape = ls['shape']
     fused = len(shape) > 1
-    kernel_name = ('recency_lookup_fused01_kernel (hop 0 + hop 1 in one launch: ' if fused else f'recency_lookup_kernel (hop {last_hop}: ') + \
+    # (which kernel serves the last hop alone: the narrow-row tile kernel from 2 tiles per CU on, the packed kernel below that, a wave per seed for wide rows)
+    solo = ('recency_lookup_kernel' if D * num_nbrs[-1] > 1024 or max(num_nbrs) > 32 else
+            ('lookup_tile_coop_kernel' if shape[-1][0] >= 2 * 64 * 256 and max(num_nbrs) <= 20 else ('lookup_tile_kernel' if shape[-1][0] >= 2 * 64 * 256 else 'lookup_packed_kernel')))
+    kernel_name = ('recency_lookup_fused01_kernel (hop 0 + hop 1 in one launch: ' if fused else f'{solo} (hop {last_hop}: ') + \
         ' + '.join(f'{seeds} seeds x k={k}' for seeds, k in shape) + ')'
 
     lowered = args.pool > 0
