@@ -255,7 +255,10 @@ def test_reference_side_binding_script():
     r = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count('[binding] ok') == 6
-    assert 'reference unit tests against tgm_amd: 103 / 103' in r.stdout, r.stdout
+    import re
+
+    m = re.search(r'reference unit tests against tgm_amd: (\d+) / (\d+)', r.stdout)
+    assert m and m.group(1) == m.group(2) and int(m.group(2)) >= 154, r.stdout
 
 
 def test_loader_is_a_torch_dataloader_like_the_reference():
@@ -383,3 +386,65 @@ def test_sampler_call_tag_survives_inference_tensors():
     assert tag.matches(ids, times)
     ids[0].add_(1)
     assert not tag.matches(ids, times)
+
+
+def test_splits_are_contiguous_ranges_equal_to_the_mask_formulation():
+    """``DGData.split`` (tgm/data/dg_data.py:396-421, tgm/data/split.py:99-243): the contiguous-range cut of the sorted timeline against the
+    reference's formulation (a boolean mask per event group and interval) on a stream with node events, node labels and timestamp ties; a
+    split without edges is dropped, one without node events carries None; ratio splits cut the time span; a shipped split cannot be replaced."""
+    from tgm_amd.data import TemporalRatioSplit, TemporalSplit, TGBSplit
+
+    g = torch.Generator().manual_seed(5)
+    E, NX, NY, N = 300, 40, 30, 25
+    ets = torch.sort(torch.randint(10, 200, (E,), generator=g)).values
+    ei = torch.randint(0, N, (E, 2), generator=g).int()
+    ex = torch.rand(E, 3, generator=g)
+    xts, xid, xv = torch.randint(0, 150, (NX,), generator=g), torch.randint(0, N, (NX,), generator=g).int(), torch.rand(NX, 2, generator=g)
+    yts, yid, yv = torch.randint(0, 220, (NY,), generator=g), torch.randint(0, N, (NY,), generator=g).int(), torch.rand(NY, 4, generator=g)
+    ei[0] = torch.tensor([N - 1, N - 1], dtype=torch.int32)  # (labels may only name ids the edges / node events span)
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        data = DGData.from_raw(ets, ei, ex, xts, xid, xv, yts, yid, yv, static_node_x=torch.rand(N, 2, generator=g), time_delta='s')
+
+    def expect(lo, hi):
+        t_e, t_x, t_y = data.time[data.edge_mask.long()], data.time[data.node_x_mask.long()], data.time[data.node_y_mask.long()]
+        m_e, m_x, m_y = (t_e >= lo) & (t_e < hi), (t_x >= lo) & (t_x < hi), (t_y >= lo) & (t_y < hi)
+        return (data.edge_index[m_e], data.edge_x[m_e], t_e[m_e], data.node_x_nids[m_x], data.node_x[m_x], t_x[m_x], data.node_y_nids[m_y], data.node_y[m_y], t_y[m_y])
+
+    def check(part, lo, hi):
+        # (the part goes through DGData.from_raw like the reference's: its merged timeline -- edges | node events | labels -- is re-sorted there)
+        e_i, e_x, e_t, x_i, x_v, x_t, y_i, y_v, y_t = expect(lo, hi)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            ref = DGData.from_raw(e_t, e_i, e_x, x_t if x_i.numel() else None, x_i if x_i.numel() else None, x_v if x_i.numel() else None,
+                                  y_t if y_i.numel() else None, y_i if y_i.numel() else None, y_v if y_i.numel() else None,
+                                  static_node_x=data.static_node_x, time_delta='s')
+        for f in ('time', 'edge_mask', 'edge_index', 'edge_x', 'node_x_mask', 'node_x_nids', 'node_x', 'node_y_mask', 'node_y_nids', 'node_y'):
+            u, v = getattr(part, f), getattr(ref, f)
+            assert (u is None and v is None) or torch.equal(u, v), f
+        assert part.static_node_x is data.static_node_x and part.time_delta == data.time_delta
+        assert sorted(part.time[part.edge_mask.long()].tolist()) == sorted(e_t.tolist())
+
+    train, val, test = data.split(TemporalSplit(val_time=120, test_time=170))
+    check(train, -1, 120), check(val, 120, 170), check(test, 170, 10**9)
+    assert test.node_x_nids is None  # node events end at t < 150
+    first, last = int(data.time[0]), int(data.time[-1])
+    span = last - first + 1
+    vt = first + int(span * 0.7)
+    parts = data.split()  # the default: 70 / 15 / 15 % of the time span
+    assert len(parts) == 3
+    check(parts[0], -1, vt), check(parts[1], vt, vt + int(span * 0.15)), check(parts[2], vt + int(span * 0.15), 10**9)
+    assert sum(p.edge_index.shape[0] for p in parts) == E
+    assert len(data.split(TemporalSplit(val_time=500, test_time=600))) == 1  # no edge at or after t = 500: two splits do not exist
+    with pytest.raises(ValueError):
+        TemporalSplit(val_time=5, test_time=4)
+    with pytest.raises(ValueError):
+        TemporalRatioSplit(0.5, 0.2, 0.2)
+    shipped = TGBSplit({'train': (10, 99), 'val': (100, 149), 'test': (150, 199)})
+    data._split_strategy = shipped
+    a, b, c = data.split()
+    assert a.edge_index.shape[0] + b.edge_index.shape[0] + c.edge_index.shape[0] == E and int(b.time[b.edge_mask.long()].min()) >= 100
+    with pytest.raises(ValueError, match='Cannot override'):
+        data.split(TemporalRatioSplit())

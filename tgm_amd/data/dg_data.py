@@ -10,7 +10,8 @@ node features.  Ingest is one-shot host work and is deliberately plain torch;
 everything per-batch lives on the device (see ``core/store.py``).
 
 Only ``from_raw`` is provided (csv / pandas / TGB loaders are out of scope,
-SURVEY.md section 2.1).
+SURVEY.md section 2.1); ``split()`` cuts the sorted timeline into contiguous
+ranges (``data/split.py``).
 """
 from __future__ import annotations
 
@@ -24,6 +25,7 @@ from torch import Tensor
 from ..constants import PADDED_NODE_ID
 from ..core.timedelta import TimeDeltaDG
 from ..exceptions import EmptyGraphError, InvalidNodeIDError
+from .split import TemporalRatioSplit, TGBSplit  # (split.py reaches back for DGData inside its functions only)
 
 _INT_DTYPES = (torch.int8, torch.int16, torch.int32, torch.int64, torch.uint8)
 _I32_MAX = torch.iinfo(torch.int32).max
@@ -83,6 +85,8 @@ class DGData:
     static_node_x: Optional[Tensor] = None  # [N, d0] float32
     edge_type: Optional[Tensor] = None
     node_type: Optional[Tensor] = None
+
+    _split_strategy: Optional[object] = None  # a data set that ships its own split (TGB) pins it here (dg_data.py:54)
 
     def __post_init__(self) -> None:
         if isinstance(self.time_delta, str):
@@ -212,6 +216,14 @@ class DGData:
             self.node_y_mask, self.node_y_nids, self.node_y = regroup(self.node_y_mask, self.node_y_nids, self.node_y)
 
     # ------------------------------------------------------------------
+    def split(self, strategy=None):
+        """Chronological parts of the data set (tgm/data/dg_data.py:396-421): ``strategy``, else the data set's own, else
+        ``TemporalRatioSplit()`` (70 / 15 / 15 % of the time span).  A data set that ships its split cannot be split another way."""
+        strategy = strategy or self._split_strategy or TemporalRatioSplit()
+        if isinstance(self._split_strategy, TGBSplit) and strategy is not self._split_strategy:
+            raise ValueError('Cannot override split strategy for TGB datasets')
+        return strategy.apply(self)
+
     def clone(self) -> 'DGData':
         """Deep copy (tensors cloned)."""
         import copy
@@ -356,6 +368,9 @@ class DGData:
     ) -> 'DGData':
         """Concatenate edge / node-event / node-label timelines (in that order) and
         record each group's positions; same argument list as tgm/data/dg_data.py:592-607."""
+        for name, t in (('edge_time', edge_time), ('node_x_time', node_x_time), ('node_y_time', node_y_time)):
+            if t is not None:
+                _need_tensor(t, name)
         E = edge_time.shape[0]
         pieces = [edge_time]
         edge_mask = torch.arange(E)
