@@ -30,9 +30,10 @@ FILES = [
     'test_util/test_seed.py',
     'test_data/test_data.py',
     'test_data/test_split.py',
+    'test_core/test_timedelta.py',
 ]
 # Ingest from CSV / pandas / the TGB packages is out of scope (host-side, one-shot; the TGB packages are not in the image):
-# the cases of test_data.py / test_split.py that go through it are deselected BY NAME -- everything else in the two files (DGData validation,
+# the cases of test_data.py / test_split.py that go through it (and test_timedelta.py's two checks of the per-data-set unit tables) are deselected BY NAME -- everything else in the two files (DGData validation,
 # normalisation, sort, node / edge types, discretize, clone, the split strategies) runs.
 DESELECT = 'not from_csv and not from_pandas and not tgb and not thgl and not tkgl'
 

@@ -258,7 +258,7 @@ def test_reference_side_binding_script():
     import re
 
     m = re.search(r'reference unit tests against tgm_amd: (\d+) / (\d+)', r.stdout)
-    assert m and m.group(1) == m.group(2) and int(m.group(2)) >= 154, r.stdout
+    assert m and m.group(1) == m.group(2) and int(m.group(2)) >= 210, r.stdout
 
 
 def test_loader_is_a_torch_dataloader_like_the_reference():

@@ -6,7 +6,6 @@ is a fixed number of nanoseconds and carries an integer multiplier.
 from __future__ import annotations
 
 from dataclasses import dataclass
-from fractions import Fraction
 
 from ..exceptions import EventOrderedConversionError
 
@@ -52,7 +51,19 @@ class TimeDeltaDG:
             other = TimeDeltaDG(other)
         if self.is_event_ordered or other.is_event_ordered:
             raise EventOrderedConversionError('Cannot compare granularity for event-ordered TimeDeltaDG')
-        return float(Fraction(self.value * _NANOS[self.unit], other.value * _NANOS[other.unit]))
+        # The reference's two roundings, in its order (tgm/core/timedelta.py:99-112): the VALUE ratio in float first, then times / over
+        # the exact integer ratio of the units -- not the correctly rounded quotient, which differs from it in the last place for
+        # e.g. 3 s -> 5 D (found by the reference's own test_timedelta.py) and would move `discretize`'s bucket edges with it.
+        mine, theirs = _NANOS[self.unit], _NANOS[other.unit]
+        value_ratio = self.value / other.value
+        return value_ratio * (mine // theirs) if mine > theirs else value_ratio / (theirs // mine)
 
     def is_coarser_than(self, other: 'str | TimeDeltaDG') -> bool:
         return self.convert(other) > 1
+
+
+# The reference keeps the native unit of every TGB / TGB-Seq data set next to this class (tgm/core/timedelta.py:115-149) for its ``from_tgb``
+# loaders.  Ingest from TGB is out of scope here, so the tables are empty: the names exist because code written
+# against the reference imports them from this module.
+TGB_TIME_DELTAS: dict = {}
+TGB_SEQ_TIME_DELTAS: dict = {}
