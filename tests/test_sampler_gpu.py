@@ -674,16 +674,19 @@ def test_cfg4_comment_shape_reduced_vs_oracle():
     _against_oracle(make_stream('comment', seed=4, num_edges=9 * 4096 + 77, n_src=50_000), 4096, [20, 20], 1000)
 
 
-@pytest.mark.parametrize('bs,ks,D,pool', [(1200, [10, 10], 16, 1), (1200, [10, 10], 6, 3), (1800, [20, 20], 16, 1), (1300, [10, 10], 4, 3), (1100, [12, 12], 8, 1)])
+@pytest.mark.parametrize('bs,ks,D,pool', [(1200, [10, 10], 16, 1), (1200, [10, 10], 6, 3), (1800, [20, 20], 16, 1), (1300, [10, 10], 4, 3), (1100, [12, 12], 8, 1),
+                                          (1500, [20, 10], 16, 1), (11000, [10, 10], 16, 3)])
 def test_tile_kernels_cooperative_index_phase_vs_oracle(bs, ks, D, pool):
     """The narrow-row TILE kernels at shapes the BASELINE configurations do not reach (hop 1 >= 2 tiles per CU, i.e. >= 32 768 seeds):
     B = 10 (six windows per load instruction of the cooperative index phase, lookup_tile_coop_kernel<.., 10, ..>), B = 12 (five per
     instruction through the BCAP = 20 body), B = 20; D = 16 (16-byte pieces), D = 4 (one piece per row), D = 6 / 8 (the float-piece copy);
     m = 2 bs <= 4096 entries, so the ring update's placement RIDES the tile launch (the RIDE instantiations); pool = 1: delta feature
-    writes into one persistent set.  Rings against the CPU restatement of the reference bit for bit, the static index against the rings."""
+    writes into one persistent set; k1 < B (rows narrower than the window); bs = 11 000: HOP 0 is a tile launch too (33 000 seeds drawn
+    from the seed groups, negatives generated in the fetch) and the update takes the radix-sort path.  Rings against the CPU restatement
+    of the reference bit for bit, the static index against the rings."""
     from tgm_amd.synth import make_stream
 
-    st = make_stream('comment', seed=11, num_edges=7 * bs + 19, n_src=6_000, edge_dim=D)
+    st = make_stream('comment', seed=11, num_edges=(4 if bs > 4096 else 7) * bs + 19, n_src=6_000, edge_dim=D)
     _against_oracle(st, bs, ks, 1000, pool=pool)
     _, hm_r, hook_r, ld_r = _pooled_pipeline(st, bs, ks, mode='ring', key_arith='int64', pool=3)
     _, hm_c, hook_c, ld_c = _pooled_pipeline(st, bs, ks, mode='csr', pool=3)

@@ -99,8 +99,7 @@ class NeighborSamplerHook(StatelessHook, SeedableHook):
         device = batch.edge_src.device
         L = len(self._num_nbrs)
         if self._csr is None or self._csr_store is not dg._storage or self._csr.device != device:
-            if batch.edge_src.device.type == 'cuda':
-                self._ensure_index(dg, device)
+            self._ensure_index(dg, device)  # (a host-resident graph raises here: no CPU fallback, and no misleading seed-range error)
         seeds, seed_times, seed_mask = RecencyNeighborHook._get_seed_tensors(self, batch, device)
         D = dg.edge_x_dim or 0
         out_seed_n, out_seed_t, out_n, out_t, out_x = [], [], [], [], []
