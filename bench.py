@@ -713,6 +713,26 @@ def main():
             if real_world > 1:
                 torch.distributed.barrier()
             default_elapsed = time.perf_counter() - t0
+            # The K steps above start on an EMPTY device queue (the synchronize in front of them): for the first ~20 steps every launch pays the
+            # idle-queue submission cost and the host, not the device, paces the loop (tools/default_path_windows.py: the first 20-step window
+            # after a synchronize reads 42-47 us with the host busy 36-46, every later one 36-40 with the host busy 25).  The same loop once
+            # the host is ahead of the device -- what a pass over a data set sees:
+            steady_steps = max(100, steps)
+            for _ in range(20):
+                if it == n_batches:
+                    hm2.reset_state()
+                    it = 0
+                held = loader2(starts[it])
+                it += 1
+            t0 = time.perf_counter()
+            for _ in range(steady_steps):
+                if it == n_batches:
+                    hm2.reset_state()
+                    it = 0
+                held = loader2(starts[it])
+                it += 1
+            torch.cuda.synchronize()
+            steady_elapsed = time.perf_counter() - t0
             hook2.check()
             default_sets = len(loader2._compiled[1]._sets) if loader2._compiled and loader2._compiled[1] is not None else 0
             # the same default arguments with the consumer DROPPING batch i before it asks for batch i + 1 (`del batch` at the end of the
@@ -970,6 +990,11 @@ def main():
             'what': "the same timed steps through DGDataLoader(dg, batch_size, hook_manager=hm) and RecencyNeighborHook(...) with their DEFAULT "
             "arguments (validate='sync': raise-per-call; fresh-tensor semantics: an output set is reused only once nothing can reach its "
             f'tensors), the consumer holding batch i while batch i + 1 is produced like `for batch in loader`; {default_sets} output sets in use',
+            'steady_ms_per_step': 1e3 * steady_elapsed / steady_steps,
+            'steady_what': f'the same held-batch loop over the next {steady_steps} steps, started 20 steps after the timed region without a synchronize in between '
+                           '(host ahead of the device; LATER batches of the stream, whose rows hold more neighbours: a few per cent more bytes per step): the K timed '
+                           'steps above begin on an empty device queue, where the host paces the loop for the first ~20 steps '
+                           '(profiles/r06_default_path_windows.jsonl: first 20-step window after a synchronize 42-57 us with the host busy 36-56, later ones 36-41 / 22-30)',
             'released_ms_per_step': 1e3 * released_elapsed / steps,
             'released_what': 'the same, the consumer dropping batch i before asking for batch i + 1 (one output set, which stays in the Infinity Cache like '
                              "the headline's pool of one): the gap between the two figures is the second 177 MB output set leaving the cache, not host time",
