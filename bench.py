@@ -79,6 +79,19 @@ def parse_args():
     return p.parse_args()
 
 
+def wake_host():
+    """Between the synchronize in front of a timed region and the region's first step: keep the calling core busy for a few milliseconds.
+    `torch.cuda.synchronize()` parks the thread while the device drains (after the untimed replay: several ms), and the core comes back from
+    its idle state SLOW -- the next ~15-30 loader calls take 30-60 us of host time instead of 18-23 (tools/transient_after_sync.py:
+    `headline 0` against `headline 3`, `default 0` against `default 3`).  A 20-step timed region would measure mostly that wake-up -- a
+    property of the host's power management, once per blocking wait, not of the path.  Outside every timed region; TGMX_BENCH_SPIN_MS=0 turns
+    it off (A/B)."""
+    ms = float(os.environ.get('TGMX_BENCH_SPIN_MS', '3'))
+    t = time.perf_counter()
+    while time.perf_counter() - t < ms * 1e-3:
+        pass
+
+
 DEFAULTS = {'wiki': (200, [20, 20]), 'review': (512, [10, 10]), 'comment': (4096, [20, 20])}
 
 
@@ -311,6 +324,7 @@ def probe_variant(stream, bs, num_nbrs, mode, device, first_timed, n_steps, pool
             torch.cuda.synchronize()
             if barrier:
                 torch.distributed.barrier()
+            wake_host()
             t0 = time.perf_counter()
             for i in range(first_timed, first_timed + n_steps):
                 loader(starts[i])
@@ -680,6 +694,7 @@ def main():
         if real_world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
+        wake_host()
         t0 = time.perf_counter()
         run(steps)
         torch.cuda.synchronize()
@@ -702,6 +717,7 @@ def main():
             if real_world > 1:
                 torch.distributed.barrier()
             torch.cuda.synchronize()
+            wake_host()
             t0 = time.perf_counter()
             for _ in range(steps):
                 if it == n_batches:
@@ -713,10 +729,9 @@ def main():
             if real_world > 1:
                 torch.distributed.barrier()
             default_elapsed = time.perf_counter() - t0
-            # The K steps above start on an EMPTY device queue (the synchronize in front of them): for the first ~20 steps every launch pays the
-            # idle-queue submission cost and the host, not the device, paces the loop (tools/default_path_windows.py: the first 20-step window
-            # after a synchronize reads 42-47 us with the host busy 36-46, every later one 36-40 with the host busy 25).  The same loop once
-            # the host is ahead of the device -- what a pass over a data set sees:
+            # The same loop over a longer stretch, without a synchronize in between (what a pass over a data set sees; LATER batches, whose rows
+            # hold a few per cent more neighbours).  Before wake_host() existed the K steps above measured the host's wake-up from the blocking
+            # synchronize: 42-57 us in the first 20-step window, 36-41 in every later one (profiles/r06_default_path_windows.jsonl).
             steady_steps = max(100, steps)
             for _ in range(20):
                 if it == n_batches:
@@ -740,6 +755,7 @@ def main():
             # residency with the default arguments; the difference to the loop above is the second 177 MB set, not host time
             held = None
             torch.cuda.synchronize()
+            wake_host()
             t0 = time.perf_counter()
             for _ in range(steps):
                 if it == n_batches:
@@ -992,9 +1008,7 @@ def main():
             f'tensors), the consumer holding batch i while batch i + 1 is produced like `for batch in loader`; {default_sets} output sets in use',
             'steady_ms_per_step': 1e3 * steady_elapsed / steady_steps,
             'steady_what': f'the same held-batch loop over the next {steady_steps} steps, started 20 steps after the timed region without a synchronize in between '
-                           '(host ahead of the device; LATER batches of the stream, whose rows hold more neighbours: a few per cent more bytes per step): the K timed '
-                           'steps above begin on an empty device queue, where the host paces the loop for the first ~20 steps '
-                           '(profiles/r06_default_path_windows.jsonl: first 20-step window after a synchronize 42-57 us with the host busy 36-56, later ones 36-41 / 22-30)',
+                           '(LATER batches of the stream, whose rows hold more neighbours: a few per cent more bytes per step)',
             'released_ms_per_step': 1e3 * released_elapsed / steps,
             'released_what': 'the same, the consumer dropping batch i before asking for batch i + 1 (one output set, which stays in the Infinity Cache like '
                              "the headline's pool of one): the gap between the two figures is the second 177 MB output set leaving the cache, not host time",
