@@ -1371,6 +1371,7 @@ extern "C" int tgmx_tgn_step(const tgmx_tgn_step_t* a, tgmx_stream_t stream) {
   TGMX_REQUIRE(a->n >= 0 && a->n <= 1024, "tgn_step: n=%d (at most 1024 events per call)", a->n);
   TGMX_REQUIRE(m->assoc && a->memory && a->last_update && a->reuse_status, "tgn_step: the commit needs mem->assoc / memory / last_update / reuse_status");
   int rc = TGMX_OK;
+  bool stored = false;  // the batch's message store has been issued (on the library's stream, beside the node side)
   const tgmx_tconv_fwd_t* c = a->conv;
   // Two chains hang off the aggregation: the NODE side (GRU GEMMs, gates, the q / k / v / skip projections of the new memory rows) and the
   // EDGE side (edge encoding from the new last_update rows, the grouping by target, the edge projection).  They meet at the attention.
@@ -1407,6 +1408,16 @@ extern "C" int tgmx_tgn_step(const tgmx_tgn_step_t* a, tgmx_stream_t stream) {
                        c->order);
     TGMX_CHECK_LAUNCH("tgn_step(grouping)");
     if ((rc = tgmx_sgemm_nt(c->edge_attr, Wd, c->W_edge, Wd, c->eproj, HC, E, HC, Wd, nullptr, 0, 1, 0, 0, 0, (tgmx_stream_t)ss))) return rc;
+    // The batch's message store (tgn.py:173,176: one latency-bound workgroup per role, ~12 us) only needs the aggregation above to be done
+    // with the OLD windows -- it is behind the fork -- and the next step's aggregation to come after it -- the join covers that: it runs here,
+    // beside the node side's GEMMs, instead of at the end of the caller's stream.  TGMX_TGN_STORE_SIDE=0: behind the commit, as before (A/B).
+    static const bool store_side = [] { const char* e = getenv("TGMX_TGN_STORE_SIDE"); return !(e && e[0] == '0'); }();
+    if (store_side && a->n > 0) {
+      if ((rc = tgmx_tgn_store_batch(a->src, a->dst, a->t, a->raw, m->D, a->n, a->log_base, a->log_other, a->log_t, a->log_raw, a->st_lo_s, a->st_cnt_s,
+                                     a->st_lo_d, a->st_cnt_d, (tgmx_stream_t)ss)))
+        return rc;
+      stored = true;
+    }
     if (hipEventRecord(side->join, ss) != hipSuccess) {
       set_error("tgn_step: join record failed");
       return TGMX_E_LAUNCH;
@@ -1430,6 +1441,10 @@ extern "C" int tgmx_tgn_step(const tgmx_tgn_step_t* a, tgmx_stream_t stream) {
     TGMX_CHECK_LAUNCH("tgn_step(attend)");
   }
   if (a->n == 0) return TGMX_OK;
+  if (stored) {
+    return tgmx_tgn_commit_assoc(a->src, a->dst, a->n, m->assoc, m->stamp, m->out_mem, m->out_lu, m->M, m->num_nodes, a->memory, a->last_update,
+                                 a->reuse_status, stream);
+  }
   if ((rc = tgmx_tgn_commit_assoc(a->src, a->dst, a->n, m->assoc, m->stamp, m->out_mem, m->out_lu, m->M, m->num_nodes, a->memory, a->last_update,
                                   a->reuse_status, stream)))
     return rc;
