@@ -699,6 +699,41 @@ def test_tile_kernels_cooperative_index_phase_vs_oracle(bs, ks, D, pool):
     hook_c.check()
 
 
+def _tile_fuzz_seeds():
+    import os
+
+    return list(range(int(os.environ.get('TGMX_FUZZ', 0)) or 4))
+
+
+@pytest.mark.parametrize('seed', _tile_fuzz_seeds())
+def test_tile_kernels_fuzz_vs_oracle(seed):
+    """Seeded random shapes in the tile kernels' range (hop 1 >= 32 768 seeds): B anywhere in 4..20 (windows shorter than their lane group,
+    3 / 6 windows per load instruction), k1 <= k0 or k1 >= k0, D in {4, 6, 8, 12, 16}, pools of 1 and 3, few nodes (rings wrap, hubs, pad rows):
+    rings against the CPU restatement of the reference bit for bit, the static index against the rings.  TGMX_FUZZ=n runs n configurations."""
+    from tgm_amd.synth import make_stream
+
+    rng = np.random.default_rng(9000 + seed)
+    k0, k1 = int(rng.integers(4, 21)), int(rng.integers(4, 21))
+    D = int(rng.choice([4, 6, 8, 12, 16]))
+    bs = int(np.ceil(33_000 / (3 * k0))) + int(rng.integers(0, 400))
+    if bs > 2048:  # (keep m = 2 bs on the riders' path here; the radix-sort path has its own case above)
+        bs = 2048
+        k0 = max(k0, int(np.ceil(33_000 / (3 * bs))))
+    pool = int(rng.choice([1, 3]))
+    st = make_stream('comment', seed=100 + seed, num_edges=5 * bs + int(rng.integers(1, 50)), n_src=int(rng.integers(800, 5000)), edge_dim=D)
+    ks = [k0, k1]
+    _against_oracle(st, bs, ks, 1000, pool=pool)
+    _, hm_r, hook_r, ld_r = _pooled_pipeline(st, bs, ks, mode='ring', key_arith='int64', pool=3)
+    _, hm_c, hook_c, ld_c = _pooled_pipeline(st, bs, ks, mode='csr', pool=3)
+    with hm_r.activate('k'), hm_c.activate('k'):
+        for b, (br, bc) in enumerate(zip(ld_r, ld_c)):
+            for h in range(2):
+                assert torch.equal(br.nbr_nids[h], bc.nbr_nids[h]) and torch.equal(br.nbr_edge_time[h], bc.nbr_edge_time[h]), (seed, ks, D, bs, b, h)
+                assert torch.equal(br.nbr_edge_x[h], bc.nbr_edge_x[h]), (seed, ks, D, bs, b, h, 'features')
+    hook_r.check()
+    hook_c.check()
+
+
 def test_cfg4_comment_full_size_midstream_properties():
     """BASELINE cfg 4 at FULL size (N = 1 M, E = 44 M, D = 16, bs = 4096, k = [20, 20]), an epoch opened mid-stream at
     edge 22 M and followed for 120 batches: the streaming rings (intended key order) and the static index over the
