@@ -122,15 +122,17 @@ def test_graph_attention_embedding_matches_restatement(inference):
     close(out.cpu(), ref, 'graph attention embedding')
 
 
-@pytest.mark.parametrize('U,E,hubs', [(300, 4000, 40), (7000, 15000, 0), (50, 6000, 2), (1, 7, 0), (9000, 3, 0), (40, 23000, 1), (5000, 30000, 3), (2049, 70000, 0)])
-def test_counting_grouping_equals_the_segment_sort_path(U, E, hubs, monkeypatch):
+@pytest.mark.parametrize('fused', ['1', '0'])
+@pytest.mark.parametrize('U,E,hubs', [(300, 4000, 40), (7000, 15000, 0), (50, 6000, 2), (1, 7, 0), (9000, 3, 0), (40, 23000, 1), (5000, 30000, 3), (2049, 70000, 0),
+                                      (16000, 20000, 0), (16001, 20000, 0), (40000, 9000, 5)])
+def test_counting_grouping_equals_the_segment_sort_path(U, E, hubs, fused, monkeypatch):
     """tgmx_tconv_forward groups a batch's edges by target with counts + an atomic cursor and lets the attention sort every segment
     by edge id (ascending edge id = the stable order of a sort by target): the embedding must equal the segment-sort path's BIT FOR
     BIT, also for hubs with more incoming edges than the attention's LDS buffer holds (> 1024: runs ranked in LDS, then merged pairwise --
     3 000 edges = 2 passes, 22 500 = 5 passes over a ragged last run),
-    repeatedly (the count buffer is left zero), and after the batch shape changed.  U > 2048 takes the round-5 arrangement -- the edge
-    encoding + ranks ride the node-projection GEMM, scan + placement ride the edge-projection GEMM -- smaller U the three small launches;
-    (5000, 30000, 3): 10 000-edge hubs through the riding path."""
+    repeatedly (the count buffer is left zero), and after the batch shape changed.  Up to 16 000 targets the scan and the placement are ONE
+    launch (every workgroup scans the counts itself; the attention clears them), beyond that -- and with TGMX_TCONV_GROUP_FUSED=0 -- two."""
+    monkeypatch.setenv('TGMX_TCONV_GROUP_FUSED', fused)
     from tgm_amd.nn import GraphAttentionEmbedding, Time2Vec
 
     torch.manual_seed(U + E)
@@ -324,12 +326,14 @@ def test_group_ids_large_matches_torch(n):
     assert torch.equal(first, ref_first)
 
 
-@pytest.mark.parametrize('aggr', ['last', 'mean'])
-def test_tgn_step_equals_the_three_module_calls(aggr):
+@pytest.mark.parametrize('aggr,rider', [('last', '1'), ('mean', '1'), ('last', '0')])
+def test_tgn_step_equals_the_three_module_calls(aggr, rider, monkeypatch):
     """TGNStep (tgmx_tgn_step: memory look-ahead -> embedding -> update_state as ONE native call) against memory(n_id), embedding(...),
     memory.update_state(...) on twin modules: z, last_update, z2 of every batch and the final memory / last_update tables equal BIT FOR BIT
     over 40 batches of a review-shaped stream, with a small message log so that compactions fall at different points of the sequence
-    (before the forward here, between commit and store there), and the fallback (an evaluation-mode memory) gives the module path's results."""
+    (before the forward here, between commit and store there), and the fallback (an evaluation-mode memory) gives the module path's results.
+    rider: the commit as extra workgroups of the attention's launch (default) or as its own launch behind it (TGMX_TGN_COMMIT_RIDER=0)."""
+    monkeypatch.setenv('TGMX_TGN_COMMIT_RIDER', rider)
     from tgm_amd import DGData, DGDataLoader, DGraph
     from tgm_amd.hooks import DeduplicationHook, HookManager, RandomNegativeEdgeSamplerHook, RecencyNeighborHook, SampledEdgeListHook
     from tgm_amd.nn import GraphAttentionEmbedding, IdentityMessage, LastAggregator, MeanAggregator, TGNMemory, TGNStep

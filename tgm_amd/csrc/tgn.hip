@@ -198,14 +198,19 @@ __global__ __launch_bounds__(256) void tgn_commit_kernel(const int32_t* __restri
 // edge_attr[e] = [cos(fma(float(last_update[src_local[e]] - t[e]), w, b)) | msg[e, :]]
 // tgt / tgt_count (optional): the thread that writes an edge's first column also counts the edge for its target (the first pass of
 // the counting grouping in tgmx_tconv_forward); a target outside [0, U) is clamped and flagged like tgmx_segment_sort does.
+// rel_zero (optional): [U] zeroed for the fused scan + placement that follows.
 __global__ __launch_bounds__(256) void tconv_edge_attr_kernel(const int64_t* __restrict__ lu_local, const int64_t* __restrict__ src,
                                                               const int64_t* __restrict__ t, const float* __restrict__ msg,
                                                               const float* __restrict__ tw, const float* __restrict__ tb, int T,
                                                               int D, long long E, float* __restrict__ out, const int64_t* __restrict__ tgt,
-                                                              int32_t* __restrict__ tgt_count, long long U, int32_t* status) {
+                                                              int32_t* __restrict__ tgt_count, long long U, int32_t* status,
+                                                              int64_t* __restrict__ rel_zero) {
   const int W = T + D;
   const long long total = E * W;
   const long long step = (long long)gridDim.x * blockDim.x;
+  if (rel_zero) {  // the running count per target of tconv_group_scan_place_kernel, one launch on
+    for (long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x; u < U; u += step) rel_zero[u] = 0;
+  }
   for (long long x = (long long)blockIdx.x * blockDim.x + threadIdx.x; x < total; x += step) {
     const long long e = x / W;
     const int c = (int)(x - e * W);
@@ -223,6 +228,22 @@ __global__ __launch_bounds__(256) void tconv_edge_attr_kernel(const int64_t* __r
     out[x] = v;
   }
 }
+
+// The memory commit of a TGN step (tgn_commit_assoc_kernel below: 2n waves, a row copy each) as extra workgroups of the attention's launch:
+// it reads the look-ahead rows the GRU gates wrote two launches earlier and writes `memory` / `last_update`, which the attention does not
+// touch -- one launch less per batch on a host-bound step (tgmx_tgn_step).  n = 0: no rider.
+struct CommitRider {
+  const int32_t* src;
+  const int32_t* dst;
+  const int64_t* assoc;
+  const float* val;
+  const int64_t* lu;
+  float* memory;
+  int64_t* last_update;
+  int32_t* status;
+  long long n, stamp;
+  int M, N;
+};
 
 struct TconvArgs {
   const float* q;      // [U, H*C]
@@ -244,7 +265,24 @@ struct TconvArgs {
   int unsorted;
   int64_t* order_big;
   int short_ok;  // floats per lane of the register-resident walks (4 or 2), 0 = the generic walk (tconv_short_ok)
+  CommitRider commit;  // workgroups U .. U + ceil(2n / 4) of the launch (tgmx_tgn_step)
+  int32_t* count_zero;  // [U] or NULL: the grouping's histogram, cleared here when the fused scan + placement left it standing
 };
+
+// memory[v] = val[row(v)], last_update[v] = lu[row(v)] for batch entry e of [src | dst]; one wave per entry
+__device__ __forceinline__ void commit_entry(const CommitRider& c, long long e) {
+  if (e >= 2 * c.n) return;
+  int v = e < c.n ? c.src[e] : c.dst[e - c.n];
+  if (v < 0) v += c.N;
+  const long long as = c.assoc[v];
+  if ((as >> 32) != c.stamp) {
+    if (lane_id() == 0) atomicOr(c.status, 1);
+    return;
+  }
+  const long long row = as & 0xffffffffll;
+  for (int col = lane_id(); col < c.M; col += kWave) c.memory[(long long)v * c.M + col] = c.val[row * c.M + col];
+  if (lane_id() == 0) c.last_update[v] = c.lu[row];
+}
 
 // The register-resident walks apply to H = 2 heads of C = V c columns, c <= 32, V = 4 or 2 floats per lane (cfg 3: C = 50 -> V = 2), rows at
 // V-float-aligned addresses: returns V, or 0 for the generic walk
@@ -467,7 +505,11 @@ __global__ __launch_bounds__(256) void tconv_attend_kernel(const TconvArgs a) {
   constexpr int kWavesPerTarget = 4;
   __shared__ float s_m[kWavesPerTarget], s_l[kWavesPerTarget], s_acc[kWavesPerTarget][kWave];
   const long long i = blockIdx.x;
-  if (i >= a.U) return;
+  if (i >= a.U) {
+    if (a.commit.n) commit_entry(a.commit, (i - a.U) * kWavesPerTarget + (threadIdx.x >> 6));
+    return;
+  }
+  if (a.count_zero && threadIdx.x == 0) a.count_zero[i] = 0;
   const int lane = lane_id(), wave = threadIdx.x >> 6;
   const long long lo = a.seg_lo[i], hi = a.seg_hi[i];
   if (hi <= lo) return;  // no incoming edge: only the skip term
@@ -661,18 +703,8 @@ __global__ __launch_bounds__(256) void tgn_commit_assoc_kernel(const int32_t* __
                                                                const float* __restrict__ val, const int64_t* __restrict__ lu, int M, int N,
                                                                float* __restrict__ memory, int64_t* __restrict__ last_update,
                                                                int32_t* __restrict__ status) {
-  const long long e = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (e >= 2 * n) return;
-  int v = e < n ? src[e] : dst[e - n];
-  if (v < 0) v += N;
-  const long long as = assoc[v];
-  if ((as >> 32) != stamp) {
-    if (lane_id() == 0) atomicOr(status, 1);
-    return;
-  }
-  const long long row = as & 0xffffffffll;
-  for (int c = lane_id(); c < M; c += kWave) memory[(long long)v * M + c] = val[row * M + c];
-  if (lane_id() == 0) last_update[v] = lu[row];
+  const CommitRider c{src, dst, assoc, val, lu, memory, last_update, status, n, stamp, M, N};
+  commit_entry(c, (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
 }
 
 // ---- message store of one batch, BOTH roles, one launch (tgn.py:218-229 called twice, :173,176) -----------------------
@@ -878,6 +910,63 @@ __global__ __launch_bounds__(256) void tconv_group_place_kernel(const int64_t* _
   order[p] = e;
 }
 
+// The two launches above as ONE, for U <= kGroupFusedMaxU targets: every workgroup of the placement scans the U counts itself (26 KB from L2
+// at the review shape: cheaper than a launch boundary on a host-bound step) into LDS, then places its 1024 edges at seg_lo[target] + a running
+// count per target.  `rel` [U] must be ZERO on entry (tconv_edge_attr_kernel zeroes it beside the histogram); `count` is read by every
+// workgroup for the whole launch, so it is zeroed one launch later (tconv_attend_kernel: the workgroup of target i clears count[i]).
+// Workgroup 0 also writes seg_lo / seg_hi for the attention.
+constexpr int kGroupFusedMaxU = 16000;  // (64 000 B of the 64 KB a workgroup may declare)
+constexpr int kGroupFusedThreads = 1024;
+__global__ __launch_bounds__(kGroupFusedThreads) void tconv_group_scan_place_kernel(const int64_t* __restrict__ tgt, long long E, int U,
+                                                                                    const int32_t* __restrict__ count, int64_t* __restrict__ rel,
+                                                                                    int64_t* __restrict__ seg_lo, int64_t* __restrict__ seg_hi,
+                                                                                    int64_t* __restrict__ order) {
+  constexpr int P = kGroupFusedThreads;
+  __shared__ int s_lo[kGroupFusedMaxU];
+  __shared__ int wave_tot[P / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // the counts into LDS with coalesced, independent loads (a thread walking its own chunk of global memory pays one L2 latency per count);
+  // the target of this thread's edge is requested alongside
+  const long long e = (long long)blockIdx.x * P + tid;
+  long long i = e < E ? tgt[e] : 0;
+#pragma unroll 16
+  for (int u = tid; u < U; u += P) s_lo[u] = count[u];
+  __syncthreads();
+  const int per = (U + P - 1) / P;
+  const int u0 = tid * per, u1 = u0 + per < U ? u0 + per : U;
+  int v = 0;
+  for (int u = u0; u < u1; ++u) v += s_lo[u];
+  int incl = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int o = __shfl_up(incl, off);
+    if (lane >= off) incl += o;
+  }
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  int pos = incl - v, total = 0;
+  for (int q = 0; q < P / 64; ++q) {
+    if (q < wave) pos += wave_tot[q];
+    total += wave_tot[q];
+  }
+  for (int u = u0; u < u1; ++u) {  // (in place: the chunk's counts become its exclusive prefix sums)
+    const int c = s_lo[u];
+    s_lo[u] = pos;
+    pos += c;
+  }
+  __syncthreads();
+  if (blockIdx.x == 0) {
+    for (int u = tid; u < U; u += P) {
+      seg_lo[u] = s_lo[u];
+      seg_hi[u] = u + 1 < U ? s_lo[u + 1] : total;
+    }
+  }
+  if (e >= E) return;
+  i = i < 0 ? 0 : (i >= U ? U - 1 : i);
+  const unsigned long long r = atomicAdd(reinterpret_cast<unsigned long long*>(&rel[i]), 1ull);
+  order[s_lo[i] + (long long)r] = e;
+}
+
 // ---- the sampled edge list of one hop, as the reference's TGN loop builds it (examples/linkproppred/tgn.py:80-92) ------
 //   mask = nbr != -1;  edge_index = [global_to_local(seed.repeat_interleave(k)[mask]); global_to_local(nbr[mask])]
 //   edge_t = nbr_t[mask];  edge_x = nbr_x[mask]     -- order = slot order, local ids = position in the sorted unique ids
@@ -1029,7 +1118,7 @@ extern "C" int tgmx_tconv_edge_attr(const int64_t* last_update_local, const int6
   long long blocks = (E * (T + D) + 255) / 256;
   if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(tconv_edge_attr_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, last_update_local, src, t,
-                     msg, tw, tb, T, D, (long long)E, out, (const int64_t*)nullptr, (int32_t*)nullptr, 0ll, (int32_t*)nullptr);
+                     msg, tw, tb, T, D, (long long)E, out, (const int64_t*)nullptr, (int32_t*)nullptr, 0ll, (int32_t*)nullptr, (int64_t*)nullptr);
   TGMX_CHECK_LAUNCH("tconv_edge_attr");
   return TGMX_OK;
 }
@@ -1247,15 +1336,22 @@ static int memory_forward_aggregate(const tgmx_tgn_memory_fwd_t* a, tgmx_stream_
                             a->ws_h, stream);
 }
 
-static int memory_forward_gru(const tgmx_tgn_memory_fwd_t* a, tgmx_stream_t stream) {
+// GRUCell: gi = aggr W_ih^T + b_ih, gh = h W_hh^T + b_hh (one launch for the two: they share nothing but the stream), then the gates
+static int memory_forward_gru_gemms(const tgmx_tgn_memory_fwd_t* a, tgmx_stream_t stream) {
   const int64_t R = a->R;
   const int M = a->M, W = 2 * a->M + a->D + a->T;
-  // GRUCell: gi = aggr W_ih^T + b_ih, gh = h W_hh^T + b_hh, gates
-  // (one launch for the two: they share nothing but the stream)
   const GemmCall gi{a->ws_aggr, W, a->W_ih, W, a->ws_gi, 3 * M, R, 3 * M, W, a->b_ih, 0, 1, 0, 0, 0};
   const GemmCall gh{a->ws_h, M, a->W_hh, M, a->ws_gh, 3 * M, R, 3 * M, M, a->b_hh, 0, 1, 0, 0, 0};
-  if (int rc = tgmx_internal_sgemm_nt_pair(gi, gh, stream)) return rc;
-  return tgmx_tgn_gru_gate(a->ws_gi, a->ws_gh, a->ws_h, M, R, a->out_mem, stream);
+  return tgmx_internal_sgemm_nt_pair(gi, gh, stream);
+}
+
+static int memory_forward_gru_gates(const tgmx_tgn_memory_fwd_t* a, tgmx_stream_t stream) {
+  return tgmx_tgn_gru_gate(a->ws_gi, a->ws_gh, a->ws_h, a->M, a->R, a->out_mem, stream);
+}
+
+static int memory_forward_gru(const tgmx_tgn_memory_fwd_t* a, tgmx_stream_t stream) {
+  if (int rc = memory_forward_gru_gemms(a, stream)) return rc;
+  return memory_forward_gru_gates(a, stream);
 }
 
 extern "C" int tgmx_tgn_memory_forward(const tgmx_tgn_memory_fwd_t* a, tgmx_stream_t stream) {
@@ -1263,6 +1359,30 @@ extern "C" int tgmx_tgn_memory_forward(const tgmx_tgn_memory_fwd_t* a, tgmx_stre
   if (a->R == 0) return TGMX_OK;
   if (int rc = memory_forward_aggregate(a, stream)) return rc;
   return memory_forward_gru(a, stream);
+}
+
+// edge encoding + histogram, then the grouping of the edge ids by target (counting grouping): two launches for U <= kGroupFusedMaxU targets
+// (tconv_group_scan_place_kernel), three beyond.  Returns whether the fused kernel ran: the attention then clears the histogram (count_zero).
+// TGMX_TCONV_GROUP_FUSED=0: always three (A/B).
+static bool launch_edge_grouping(const tgmx_tconv_fwd_t* a, hipStream_t st) {
+  const int64_t U = a->U, E = a->E;
+  const int Wd = a->T + a->D;
+  const char* e = getenv("TGMX_TCONV_GROUP_FUSED");  // (read per call, like TGMX_TCONV_COUNTING: the tests switch it)
+  const bool fused = !(e && e[0] == '0') && U <= kGroupFusedMaxU;
+  long long blocks = (E * Wd + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(tconv_edge_attr_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a->last_update_local, a->src, a->t, a->msg, a->tw, a->tb,
+                     a->T, a->D, (long long)E, a->edge_attr, a->tgt, a->tgt_count, (long long)U, a->status, fused ? a->cursor : (int64_t*)nullptr);
+  if (fused) {
+    hipLaunchKernelGGL(tconv_group_scan_place_kernel, dim3((unsigned)((E + kGroupFusedThreads - 1) / kGroupFusedThreads)), dim3(kGroupFusedThreads), 0, st,
+                       a->tgt, (long long)E, (int)U, a->tgt_count,
+                       a->cursor, a->seg_lo, a->seg_hi, a->order);
+  } else {
+    hipLaunchKernelGGL(tconv_group_scan_kernel, dim3(1), dim3(1024), 0, st, a->tgt_count, (long long)U, a->seg_lo, a->seg_hi, a->cursor);
+    hipLaunchKernelGGL(tconv_group_place_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, a->tgt, (long long)E, (long long)U, a->cursor,
+                       a->order);
+  }
+  return fused;
 }
 
 extern "C" int tgmx_tconv_forward(const tgmx_tconv_fwd_t* a, tgmx_stream_t stream) {
@@ -1288,13 +1408,7 @@ extern "C" int tgmx_tconv_forward(const tgmx_tconv_fwd_t* a, tgmx_stream_t strea
     // walking it -- ascending edge id is the order a stable sort by target gives, so the result equals the sorted path's bit for bit.
     // 3 launches less work than: keys + 4-5 radix-sort launches + the library's copy-back + bounds (~50 us of a 264 us batch, round 4).
     hipStream_t st = (hipStream_t)stream;
-    long long blocks = (E * Wd + 255) / 256;
-    if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(tconv_edge_attr_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a->last_update_local, a->src, a->t, a->msg, a->tw, a->tb,
-                       a->T, a->D, (long long)E, a->edge_attr, a->tgt, a->tgt_count, (long long)U, a->status);
-    hipLaunchKernelGGL(tconv_group_scan_kernel, dim3(1), dim3(1024), 0, st, a->tgt_count, (long long)U, a->seg_lo, a->seg_hi, a->cursor);
-    hipLaunchKernelGGL(tconv_group_place_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, a->tgt, (long long)E, (long long)U, a->cursor,
-                       a->order);
+    const bool fused_group = launch_edge_grouping(a, st);
     TGMX_CHECK_LAUNCH("tconv_forward(grouping)");
     // the node projections (x -> q, k, v, skip) and the edge projection (edge_attr -> eproj) do not depend on each other: one launch
     const GemmCall eproj{a->edge_attr, Wd, a->W_edge, Wd, a->eproj, HC, E, HC, Wd, nullptr, 0, 1, 0, 0, 0};
@@ -1305,6 +1419,7 @@ extern "C" int tgmx_tconv_forward(const tgmx_tconv_fwd_t* a, tgmx_stream_t strea
     t.unsorted = 1;
     t.order_big = a->order_big;
     t.short_ok = tconv_short_ok(t);
+    t.count_zero = fused_group ? a->tgt_count : nullptr;
     hipLaunchKernelGGL(tconv_attend_kernel, dim3((unsigned)U), dim3(256), 0, st, t);
     TGMX_CHECK_LAUNCH("tconv_attend");
     return TGMX_OK;
@@ -1322,7 +1437,7 @@ extern "C" int tgmx_tconv_forward(const tgmx_tconv_fwd_t* a, tgmx_stream_t strea
 namespace {
 struct StepSide {  // a stream + two events of the library's own, per calling thread: the edge-side chain of a step runs beside the node-side chain
   hipStream_t stream = nullptr;
-  hipEvent_t fork = nullptr, join = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr, join_store = nullptr;
   int device = -1;
   bool failed = false;
 };
@@ -1338,13 +1453,15 @@ StepSide* step_side() {
     s.failed = true;
     return nullptr;
   }
-  if (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess) {
+  if (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&s.join_store, hipEventDisableTiming) != hipSuccess) {
     // partial set-up: give back what was created
     if (s.fork) (void)hipEventDestroy(s.fork);
     if (s.join) (void)hipEventDestroy(s.join);
+    if (s.join_store) (void)hipEventDestroy(s.join_store);
     (void)hipStreamDestroy(s.stream);
     s.stream = nullptr;
-    s.fork = s.join = nullptr;
+    s.fork = s.join = s.join_store = nullptr;
     s.failed = true;
     return nullptr;
   }
@@ -1372,6 +1489,7 @@ extern "C" int tgmx_tgn_step(const tgmx_tgn_step_t* a, tgmx_stream_t stream) {
   TGMX_REQUIRE(m->assoc && a->memory && a->last_update && a->reuse_status, "tgn_step: the commit needs mem->assoc / memory / last_update / reuse_status");
   int rc = TGMX_OK;
   bool stored = false;  // the batch's message store has been issued (on the library's stream, beside the node side)
+  bool committed = false;  // the commit has been issued (as extra workgroups of the attention's launch)
   const tgmx_tconv_fwd_t* c = a->conv;
   // Two chains hang off the aggregation: the NODE side (GRU GEMMs, gates, the q / k / v / skip projections of the new memory rows) and the
   // EDGE side (edge encoding from the new last_update rows, the grouping by target, the edge projection).  They meet at the attention.
@@ -1398,38 +1516,48 @@ extern "C" int tgmx_tgn_step(const tgmx_tgn_step_t* a, tgmx_stream_t stream) {
     }
     JoinOnExit guard{st, ss, side->join};
     guard.armed = true;  // from here on every return joins the library's stream back into the caller's
+    // The node side's first launch -- the GRU's two GEMMs, the longest kernel of the step (30-40 us) -- goes out BEFORE the edge side's five:
+    // issued behind them, the caller's stream sat idle for the ~25 us the host needs to issue those (kernel trace, round 6); its remaining
+    // two launches follow the edge side and are queued long before the GEMMs finish.  TGMX_TGN_NODE_FIRST=0: the edge side first (A/B).
+    const char* nf = getenv("TGMX_TGN_NODE_FIRST");
+    const bool node_first = !(nf && nf[0] == '0');
+    if (node_first && (rc = memory_forward_gru_gemms(m, stream))) return rc;
     // ---- edge side, on the library's stream ----
-    long long blocks = (E * Wd + 255) / 256;
-    if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(tconv_edge_attr_kernel, dim3((unsigned)blocks), dim3(256), 0, ss, c->last_update_local, c->src, c->t, c->msg, c->tw, c->tb, c->T,
-                       c->D, (long long)E, c->edge_attr, c->tgt, c->tgt_count, (long long)U, c->status);
-    hipLaunchKernelGGL(tconv_group_scan_kernel, dim3(1), dim3(1024), 0, ss, c->tgt_count, (long long)U, c->seg_lo, c->seg_hi, c->cursor);
-    hipLaunchKernelGGL(tconv_group_place_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, ss, c->tgt, (long long)E, (long long)U, c->cursor,
-                       c->order);
+    const bool fused_group = launch_edge_grouping(c, ss);
     TGMX_CHECK_LAUNCH("tgn_step(grouping)");
     if ((rc = tgmx_sgemm_nt(c->edge_attr, Wd, c->W_edge, Wd, c->eproj, HC, E, HC, Wd, nullptr, 0, 1, 0, 0, 0, (tgmx_stream_t)ss))) return rc;
     // The batch's message store (tgn.py:173,176: one latency-bound workgroup per role, ~12 us) only needs the aggregation above to be done
     // with the OLD windows -- it is behind the fork -- and the next step's aggregation to come after it -- the join covers that: it runs here,
     // beside the node side's GEMMs, instead of at the end of the caller's stream.  TGMX_TGN_STORE_SIDE=0: behind the commit, as before (A/B).
     static const bool store_side = [] { const char* e = getenv("TGMX_TGN_STORE_SIDE"); return !(e && e[0] == '0'); }();
+    // Two joins: the attention waits for the edge projection only, the caller's stream picks up the store behind the attention's launch (the
+    // store is the side chain's last and longest launch, and the attention needs nothing of it).  TGMX_TGN_STORE_JOIN_LATE=0: one join behind
+    // the store (A/B).
+    const char* jl = getenv("TGMX_TGN_STORE_JOIN_LATE");
+    const bool two_joins = store_side && a->n > 0 && !(jl && jl[0] == '0');
+    if (two_joins && hipEventRecord(side->join, ss) != hipSuccess) {
+      set_error("tgn_step: join record failed");
+      return TGMX_E_LAUNCH;
+    }
     if (store_side && a->n > 0) {
       if ((rc = tgmx_tgn_store_batch(a->src, a->dst, a->t, a->raw, m->D, a->n, a->log_base, a->log_other, a->log_t, a->log_raw, a->st_lo_s, a->st_cnt_s,
                                      a->st_lo_d, a->st_cnt_d, (tgmx_stream_t)ss)))
         return rc;
       stored = true;
     }
-    if (hipEventRecord(side->join, ss) != hipSuccess) {
+    if (hipEventRecord(two_joins ? side->join_store : side->join, ss) != hipSuccess) {
       set_error("tgn_step: join record failed");
       return TGMX_E_LAUNCH;
     }
     // ---- node side, on the caller's stream ----
-    if ((rc = memory_forward_gru(m, stream))) return rc;
+    if (!node_first && (rc = memory_forward_gru_gemms(m, stream))) return rc;
+    if ((rc = memory_forward_gru_gates(m, stream))) return rc;
     if ((rc = tgmx_sgemm_nt(c->x, c->in_ch, c->W4, c->in_ch, c->qkvs, HC, U, HC, c->in_ch, c->b4, 0, 4, 0, (int64_t)HC * c->in_ch, U * HC, stream))) return rc;
     if (hipStreamWaitEvent(st, side->join, 0) != hipSuccess) {
       set_error("tgn_step: join failed");
       return TGMX_E_LAUNCH;
     }
-    guard.joined = true;
+    guard.joined = !two_joins;  // (two joins: the store is still out; an error return from here on takes the guard's record + wait)
     float* out = c->qkvs + 3 * U * HC;
     TconvArgs t{c->qkvs, c->qkvs + U * HC, c->qkvs + 2 * U * HC, c->eproj, c->order, c->src, c->seg_lo, c->seg_hi, out, U, c->H, c->C,
                 1.0f / sqrtf((float)c->C)};
@@ -1437,10 +1565,33 @@ extern "C" int tgmx_tgn_step(const tgmx_tgn_step_t* a, tgmx_stream_t stream) {
     t.unsorted = 1;
     t.order_big = c->order_big;
     t.short_ok = tconv_short_ok(t);
-    hipLaunchKernelGGL(tconv_attend_kernel, dim3((unsigned)U), dim3(256), 0, st, t);
+    t.count_zero = fused_group ? c->tgt_count : nullptr;
+    // the commit of the look-ahead rows rides the attention's launch as ceil(2n / 4) extra workgroups (CommitRider: it depends on the gates'
+    // launch, two back on this stream, and on nothing of the attention's).  TGMX_TGN_COMMIT_RIDER=0: its own launch behind the attention (A/B)
+    const char* rider_knob = getenv("TGMX_TGN_COMMIT_RIDER");  // (read per call: the tests switch it)
+    unsigned extra = 0;
+    if (!(rider_knob && rider_knob[0] == '0') && a->n > 0) {
+      t.commit = CommitRider{a->src, a->dst, m->assoc, m->out_mem, m->out_lu, a->memory, a->last_update, a->reuse_status, a->n, (long long)m->stamp, m->M,
+                             m->num_nodes};
+      extra = (unsigned)((2 * a->n + 3) / 4);
+      committed = true;
+    }
+    hipLaunchKernelGGL(tconv_attend_kernel, dim3((unsigned)U + extra), dim3(256), 0, st, t);
     TGMX_CHECK_LAUNCH("tgn_step(attend)");
+    if (two_joins) {
+      if (hipStreamWaitEvent(st, side->join_store, 0) != hipSuccess) {
+        set_error("tgn_step: join failed");
+        return TGMX_E_LAUNCH;
+      }
+      guard.joined = true;
+    }
   }
   if (a->n == 0) return TGMX_OK;
+  if (committed) {
+    if (stored) return TGMX_OK;
+    return tgmx_tgn_store_batch(a->src, a->dst, a->t, a->raw, m->D, a->n, a->log_base, a->log_other, a->log_t, a->log_raw, a->st_lo_s, a->st_cnt_s,
+                                a->st_lo_d, a->st_cnt_d, stream);
+  }
   if (stored) {
     return tgmx_tgn_commit_assoc(a->src, a->dst, a->n, m->assoc, m->stamp, m->out_mem, m->out_lu, m->M, m->num_nodes, a->memory, a->last_update,
                                  a->reuse_status, stream);

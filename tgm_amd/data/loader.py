@@ -374,6 +374,7 @@ class DGDataLoader(torch.utils.data.DataLoader):
         set_stream = torch.cuda.set_stream
         n_prod = len(evs) // 2
         use_worker = os.environ.get('TGMX_LOADER_WORKER', '1') != '0'  # A/B knob: 0 = this thread issues the loader's launches itself
+        finalize_first = os.environ.get('TGMX_LOADER_FINALIZE_FIRST', '1') != '0'  # A/B knob: 0 = read the sizes back behind the submission
         ahead: deque = deque()
         j = 0
         last_ticket = 0
@@ -381,6 +382,13 @@ class DGDataLoader(torch.utils.data.DataLoader):
         _native.check(handoff(main_p, side_p, evs[n_prod]), 'tgmx_stream_handoff')
         try:
             for s in self._starts:
+                if finalize_first and len(ahead) == self._prefetch and ahead:
+                    # the batch this iteration will hand out: its three sizes are read back NOW, while the launch worker is idle -- behind the
+                    # submission below the read (hipEventSynchronize) queued behind the worker's launches on the runtime's locks
+                    b0, _, tk0 = ahead[0]
+                    if tk0 is not None:
+                        _native.check(wwait(worker, tk0), 'tgmx_worker_wait')
+                    b0._finalize()
                 hz = None
                 if j:
                     # this production may rewrite the set of a batch the consumer has finished ENQUEUING work for: after that work

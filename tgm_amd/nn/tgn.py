@@ -707,7 +707,7 @@ class TGNStep:
                     batch.edge_time, batch.edge_x)
 
     def _eligible(self, n_id: Tensor, edge_index: Tensor, src: Tensor, raw_msg: Optional[Tensor]) -> bool:
-        mem, conv = self.memory, self.embedding.conv
+        mem, conv = self.memory, self.embedding._modules['conv']  # (registered submodule: the dict, not Module.__getattr__ -- see __call__)
         n = src.numel()
         return (not torch.is_grad_enabled() and not _COMPOSE_IN_PYTHON and mem.training and mem.reuse_forward and n_id.is_cuda and n_id.numel() > 0
                 and 0 < n <= 1024 and edge_index.shape[1] > 0 and not (conv.training and conv.dropout > 0) and not mem._sharded(2 * n)
@@ -729,7 +729,10 @@ class TGNStep:
             mem.update_state(src, dst, t, raw_msg)
             return z2, z, lu
         self.fast_calls += 1
-        conv = emb.conv
+        # Registered buffers / submodules are read from the modules' dicts and plain attributes are written through `__dict__`:
+        # nn.Module.__getattr__ / __setattr__ cost 1-2 us per access, a dozen of them per batch on a host-bound step.
+        md, bufs = mem.__dict__, mem._buffers
+        conv = emb._modules['conv']
         dev = n_id.device
         i32c = lambda v: v if (v.dtype == torch.int32 and v.is_contiguous()) else v.to(torch.int32).contiguous()
         i64c = lambda v: v if (v.dtype == torch.int64 and v.is_contiguous()) else v.to(torch.int64).contiguous()
@@ -744,7 +747,7 @@ class TGNStep:
         if mem._assoc64 is None or mem._assoc64.device != dev:
             mem._assoc64 = torch.zeros(mem.num_nodes, dtype=torch.int64, device=dev)
             mem._reuse_status = torch.zeros(1, dtype=torch.int32, device=dev)
-        mem._stamp += 1
+        stamp = md['_stamp'] = md['_stamp'] + 1
         ws = self._ws = self._grow(self._ws, R * (W + 7 * M), torch.float32, dev)
         z = torch.empty((R, M), dtype=torch.float32, device=dev)
         lu = torch.empty(R, dtype=torch.int64, device=dev)
@@ -768,7 +771,7 @@ class TGNStep:
         if not tgt_e.is_contiguous():
             tgt_e = tgt_e.contiguous()
         et64, msg = i64c(edge_t), f32c(edge_x)
-        De, Te = msg.shape[1], emb.time_enc.time_dim
+        De, Te = msg.shape[1], emb._modules['time_enc'].time_dim
         qkvs = torch.empty((4, U, HC), dtype=torch.float32, device=dev)
         lib = self._lib
         if lib is None:
@@ -793,15 +796,16 @@ class TGNStep:
         # Everything that only moves when a buffer is (re)allocated or the parameters change is written into the argument blocks ONCE per
         # such event: ~60 ctypes field stores and ~25 data_ptr() calls less per batch (the pipeline is host-bound: every microsecond of
         # this function is a microsecond of the batch).  The key holds the address of every buffer a static field points into.
-        skey = (wkey, mem.memory.data_ptr(), mem.last_update.data_ptr(), mem._st_lo[0].data_ptr(), mem._st_cnt[0].data_ptr(), mem._st_lo[1].data_ptr(),
+        aggr_mean = (mem._modules.get('aggr_module') or mem.aggr_module).mean
+        skey = (wkey, bufs['memory'].data_ptr(), bufs['last_update'].data_ptr(), mem._st_lo[0].data_ptr(), mem._st_cnt[0].data_ptr(), mem._st_lo[1].data_ptr(),
                 mem._st_cnt[1].data_ptr(), mem._log_other.data_ptr(), mem._log_t.data_ptr(), mem._log_raw.data_ptr(), mem._assoc64.data_ptr(),
                 mem._reuse_status.data_ptr(), wsd[0].data_ptr(), wsd[0].numel(), wsd[1].data_ptr(), cnt.data_ptr(), M, D, T, De, Te, H, C,
-                mem.num_nodes, mem.aggr_module.mean)  # fmt: skip
+                mem.num_nodes, aggr_mean)  # fmt: skip
         if skey != self._static_key:
             a.memory, a.last_update, a.M, a.num_nodes = skey[1], skey[2], M, mem.num_nodes
             a.st_lo_s, a.st_cnt_s, a.st_lo_d, a.st_cnt_d = skey[3], skey[4], skey[5], skey[6]
             a.log_other, a.log_t, a.log_raw, a.D = skey[7], skey[8], skey[9], D
-            a.tw, a.tb, a.T, a.mean = tw.data_ptr(), tb.data_ptr(), T, mem.aggr_module.mean
+            a.tw, a.tb, a.T, a.mean = tw.data_ptr(), tb.data_ptr(), T, aggr_mean
             a.W_ih, a.b_ih, a.W_hh, a.b_hh = W_ih.data_ptr(), b_ih.data_ptr(), W_hh.data_ptr(), b_hh.data_ptr()
             a.assoc = skey[10]
             c.in_ch, c.D, c.T = M, De, Te
@@ -816,7 +820,7 @@ class TGNStep:
         # ---- what changes with every batch ---------------------------------------------------------------------------------------------
         a.nodes, a.R = nodes.data_ptr(), R
         a.ws_aggr, a.ws_h, a.ws_gi, a.ws_gh = base, base + 4 * R * W, base + 4 * R * (W + M), base + 4 * R * (W + 4 * M)
-        a.out_mem, a.out_lu, a.stamp = z.data_ptr(), lu.data_ptr(), mem._stamp
+        a.out_mem, a.out_lu, a.stamp = z.data_ptr(), lu.data_ptr(), stamp
         c.x, c.U, c.last_update_local = a.out_mem, U, a.out_lu
         c.src, c.tgt, c.t, c.msg, c.E = src_e.data_ptr(), tgt_e.data_ptr(), et64.data_ptr(), msg.data_ptr(), E
         c.edge_attr, c.qkvs, c.eproj = flp, qkvs.data_ptr(), flp + 4 * E * (Te + De)
@@ -827,8 +831,8 @@ class TGNStep:
         s.log_base = mem._log_len
         _native.check(lib.tgmx_tgn_step(s, _native.stream_ptr()), 'tgmx_tgn_step')
         # what the three calls leave behind: two state mutations (commit, store), the log grown by both roles' entries, no pending forward
-        mem._version += 2
-        mem._log_len += 2 * n
-        mem._fwd = None
-        conv._edge_ctx = None
+        md['_version'] += 2
+        md['_log_len'] += 2 * n
+        md['_fwd'] = None
+        conv.__dict__['_edge_ctx'] = None
         return qkvs[3], z, lu

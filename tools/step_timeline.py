@@ -11,7 +11,7 @@ idx = [i for i, r in enumerate(rows) if anchor in r[0]]
 if len(idx) < 4:  # no such kernel: show the last launches as they come
     lo, hi = max(0, len(rows) - int(sys.argv[3]) - 1 if len(sys.argv) > 3 else len(rows) - 25), len(rows) - 1
 else:
-    lo, hi = idx[-4], idx[-3]
+    lo, hi = idx[-5], idx[-3]
 t0 = rows[lo][1]
 for name, s, e, g, q in rows[lo:hi]:
     short = name.split('(')[0].replace('void ', '').replace('tgmx::', '')[:60]
