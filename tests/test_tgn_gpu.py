@@ -334,6 +334,7 @@ def test_tgn_step_equals_the_three_module_calls(aggr, rider, monkeypatch):
     (before the forward here, between commit and store there), and the fallback (an evaluation-mode memory) gives the module path's results.
     rider: the commit as extra workgroups of the attention's launch (default) or as its own launch behind it (TGMX_TGN_COMMIT_RIDER=0)."""
     monkeypatch.setenv('TGMX_TGN_COMMIT_RIDER', rider)
+    monkeypatch.setenv('TGMX_TGN_STORE_RIDER', rider)  # (likewise the batch's message store: two workgroups of the grouping's launch, or its own)
     from tgm_amd import DGData, DGDataLoader, DGraph
     from tgm_amd.hooks import DeduplicationHook, HookManager, RandomNegativeEdgeSamplerHook, RecencyNeighborHook, SampledEdgeListHook
     from tgm_amd.nn import GraphAttentionEmbedding, IdentityMessage, LastAggregator, MeanAggregator, TGNMemory, TGNStep

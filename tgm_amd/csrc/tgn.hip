@@ -725,18 +725,19 @@ struct StoreBatchArgs {
   int n, D;
 };
 
-__global__ __launch_bounds__(1024) void tgn_store_batch_kernel(const StoreBatchArgs a) {
-  __shared__ long long s_key[1024];
-  __shared__ int s_pay[1024];
-  __shared__ int s_id[1024];
-  __shared__ int s_start[1024];
-  __shared__ int s_perm[1024];
-  __shared__ int wave_tot[16];
-  const int role = blockIdx.x;
+struct StoreLds {
+  long long key[1024];
+  int pay[1024], id[1024], start[1024], perm[1024], wave_tot[16];
+};
+
+// one role's workgroup of P threads (a power of two >= n); the result does not depend on P (keys are unique: the entry index rides in them)
+__device__ __forceinline__ void store_batch_body(const StoreBatchArgs& a, const int role, StoreLds& L, const int P) {
+  long long* s_key = L.key;
+  int *s_pay = L.pay, *s_id = L.id, *s_start = L.start, *s_perm = L.perm, *wave_tot = L.wave_tot;
   const int32_t* ids = role == 0 ? a.src : a.dst;
   const int32_t* oth = role == 0 ? a.dst : a.src;
   const int n = a.n;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, P = blockDim.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   long long key = 0x7fffffffffffffffLL;
   int pay = tid;
   if (tid < n) key = (((long long)ids[tid] + (1ll << 31)) << kPackBits) | (long long)tid;
@@ -788,6 +789,11 @@ __global__ __launch_bounds__(1024) void tgn_store_batch_kernel(const StoreBatchA
     for (int u = 0; u < 4; ++u)
       if (xs[u] < total) log_raw[base * a.D + xs[u]] = v[u];
   }
+}
+
+__global__ __launch_bounds__(1024) void tgn_store_batch_kernel(const StoreBatchArgs a) {
+  __shared__ StoreLds L;
+  store_batch_body(a, blockIdx.x, L, blockDim.x);
 }
 
 // ---- message-log compaction (TGNMemory's append-only log, nn/tgn.py _compact_into) ---------------------------------------------
@@ -914,16 +920,24 @@ __global__ __launch_bounds__(256) void tconv_group_place_kernel(const int64_t* _
 // at the review shape: cheaper than a launch boundary on a host-bound step) into LDS, then places its 1024 edges at seg_lo[target] + a running
 // count per target.  `rel` [U] must be ZERO on entry (tconv_edge_attr_kernel zeroes it beside the histogram); `count` is read by every
 // workgroup for the whole launch, so it is zeroed one launch later (tconv_attend_kernel: the workgroup of target i clears count[i]).
-// Workgroup 0 also writes seg_lo / seg_hi for the attention.
+// Workgroup 0 also writes seg_lo / seg_hi for the attention.  store.n > 0: two more workgroups store the batch's messages (see below).
 constexpr int kGroupFusedMaxU = 16000;  // (64 000 B of the 64 KB a workgroup may declare)
 constexpr int kGroupFusedThreads = 1024;
 __global__ __launch_bounds__(kGroupFusedThreads) void tconv_group_scan_place_kernel(const int64_t* __restrict__ tgt, long long E, int U,
                                                                                     const int32_t* __restrict__ count, int64_t* __restrict__ rel,
                                                                                     int64_t* __restrict__ seg_lo, int64_t* __restrict__ seg_hi,
-                                                                                    int64_t* __restrict__ order) {
+                                                                                    int64_t* __restrict__ order, const StoreBatchArgs store) {
   constexpr int P = kGroupFusedThreads;
-  __shared__ int s_lo[kGroupFusedMaxU];
+  static_assert(sizeof(StoreLds) <= kGroupFusedMaxU * sizeof(int), "the store rider's LDS lives in the scan's buffer");
+  __shared__ __align__(16) int s_lo[kGroupFusedMaxU];
   __shared__ int wave_tot[P / 64];
+  // tgmx_tgn_step: the batch's message store (tgn_store_batch_kernel: one workgroup per role) as the launch's LAST two workgroups -- it
+  // shares nothing with the grouping but the stream position (behind the aggregation, in front of the join)
+  const unsigned group_blocks = (unsigned)((E + P - 1) / P);
+  if (blockIdx.x >= group_blocks) {
+    store_batch_body(store, (int)(blockIdx.x - group_blocks), *reinterpret_cast<StoreLds*>(s_lo), P);
+    return;
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // the counts into LDS with coalesced, independent loads (a thread walking its own chunk of global memory pays one L2 latency per count);
   // the target of this thread's edge is requested alongside
@@ -1364,7 +1378,7 @@ extern "C" int tgmx_tgn_memory_forward(const tgmx_tgn_memory_fwd_t* a, tgmx_stre
 // edge encoding + histogram, then the grouping of the edge ids by target (counting grouping): two launches for U <= kGroupFusedMaxU targets
 // (tconv_group_scan_place_kernel), three beyond.  Returns whether the fused kernel ran: the attention then clears the histogram (count_zero).
 // TGMX_TCONV_GROUP_FUSED=0: always three (A/B).
-static bool launch_edge_grouping(const tgmx_tconv_fwd_t* a, hipStream_t st) {
+static bool launch_edge_grouping(const tgmx_tconv_fwd_t* a, hipStream_t st, const StoreBatchArgs* store = nullptr, bool* stored = nullptr) {
   const int64_t U = a->U, E = a->E;
   const int Wd = a->T + a->D;
   const char* e = getenv("TGMX_TCONV_GROUP_FUSED");  // (read per call, like TGMX_TCONV_COUNTING: the tests switch it)
@@ -1374,9 +1388,12 @@ static bool launch_edge_grouping(const tgmx_tconv_fwd_t* a, hipStream_t st) {
   hipLaunchKernelGGL(tconv_edge_attr_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a->last_update_local, a->src, a->t, a->msg, a->tw, a->tb,
                      a->T, a->D, (long long)E, a->edge_attr, a->tgt, a->tgt_count, (long long)U, a->status, fused ? a->cursor : (int64_t*)nullptr);
   if (fused) {
-    hipLaunchKernelGGL(tconv_group_scan_place_kernel, dim3((unsigned)((E + kGroupFusedThreads - 1) / kGroupFusedThreads)), dim3(kGroupFusedThreads), 0, st,
-                       a->tgt, (long long)E, (int)U, a->tgt_count,
-                       a->cursor, a->seg_lo, a->seg_hi, a->order);
+    StoreBatchArgs none{};
+    const bool ride = store && store->n > 0;
+    hipLaunchKernelGGL(tconv_group_scan_place_kernel, dim3((unsigned)((E + kGroupFusedThreads - 1) / kGroupFusedThreads) + (ride ? 2u : 0u)),
+                       dim3(kGroupFusedThreads), 0, st, a->tgt, (long long)E, (int)U, a->tgt_count, a->cursor, a->seg_lo, a->seg_hi, a->order,
+                       ride ? *store : none);
+    if (ride && stored) *stored = true;
   } else {
     hipLaunchKernelGGL(tconv_group_scan_kernel, dim3(1), dim3(1024), 0, st, a->tgt_count, (long long)U, a->seg_lo, a->seg_hi, a->cursor);
     hipLaunchKernelGGL(tconv_group_place_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, a->tgt, (long long)E, (long long)U, a->cursor,
@@ -1510,36 +1527,47 @@ extern "C" int tgmx_tgn_step(const tgmx_tgn_step_t* a, tgmx_stream_t stream) {
     TGMX_REQUIRE(c->x && c->W4 && c->b4 && c->qkvs && c->src && c->tgt && c->t && c->edge_attr && c->eproj && c->order && c->seg_lo && c->seg_hi && c->status,
                  "tgn_step: null pointer in the embedding's argument block");
     if ((rc = memory_forward_aggregate(m, stream))) return rc;
-    if (hipEventRecord(side->fork, st) != hipSuccess || hipStreamWaitEvent(ss, side->fork, 0) != hipSuccess) {
+    if (hipEventRecord(side->fork, st) != hipSuccess) {
       set_error("tgn_step: fork failed");
       return TGMX_E_LAUNCH;
     }
-    JoinOnExit guard{st, ss, side->join};
-    guard.armed = true;  // from here on every return joins the library's stream back into the caller's
     // The node side's first launch -- the GRU's two GEMMs, the longest kernel of the step (30-40 us) -- goes out BEFORE the edge side's five:
     // issued behind them, the caller's stream sat idle for the ~25 us the host needs to issue those (kernel trace, round 6); its remaining
     // two launches follow the edge side and are queued long before the GEMMs finish.  TGMX_TGN_NODE_FIRST=0: the edge side first (A/B).
     const char* nf = getenv("TGMX_TGN_NODE_FIRST");
     const bool node_first = !(nf && nf[0] == '0');
-    if (node_first && (rc = memory_forward_gru_gemms(m, stream))) return rc;
+    if (node_first && (rc = memory_forward_gru_gemms(m, stream))) return rc;  // (nothing on the library's stream yet: a plain return)
+    if (hipStreamWaitEvent(ss, side->fork, 0) != hipSuccess) {  // (the other stream's wait is issued behind the GEMMs' launch: they start sooner)
+      set_error("tgn_step: fork failed");
+      return TGMX_E_LAUNCH;
+    }
+    JoinOnExit guard{st, ss, side->join};
+    guard.armed = true;  // from here on every return joins the library's stream back into the caller's
     // ---- edge side, on the library's stream ----
-    const bool fused_group = launch_edge_grouping(c, ss);
+    // the batch's message store rides the grouping's launch when that is the fused one (TGMX_TGN_STORE_RIDER=0: its own launch, A/B)
+    static const bool store_side = [] { const char* e = getenv("TGMX_TGN_STORE_SIDE"); return !(e && e[0] == '0'); }();
+    const char* sr = getenv("TGMX_TGN_STORE_RIDER");
+    StoreBatchArgs sargs{a->src, a->dst, a->t, a->raw, a->log_other, a->log_t, a->log_raw, {a->st_lo_s, a->st_lo_d}, {a->st_cnt_s, a->st_cnt_d}, a->log_base,
+                         a->n, m->D};
+    const bool store_rides = store_side && a->n > 0 && !(sr && sr[0] == '0') && a->src && a->dst && a->t && (m->D == 0 || (a->raw && a->log_raw)) &&
+                             a->log_other && a->log_t && a->st_lo_s && a->st_cnt_s && a->st_lo_d && a->st_cnt_d && a->log_base >= 0;
+    const bool fused_group = launch_edge_grouping(c, ss, store_rides ? &sargs : nullptr, &stored);
     TGMX_CHECK_LAUNCH("tgn_step(grouping)");
     if ((rc = tgmx_sgemm_nt(c->edge_attr, Wd, c->W_edge, Wd, c->eproj, HC, E, HC, Wd, nullptr, 0, 1, 0, 0, 0, (tgmx_stream_t)ss))) return rc;
     // The batch's message store (tgn.py:173,176: one latency-bound workgroup per role, ~12 us) only needs the aggregation above to be done
     // with the OLD windows -- it is behind the fork -- and the next step's aggregation to come after it -- the join covers that: it runs here,
     // beside the node side's GEMMs, instead of at the end of the caller's stream.  TGMX_TGN_STORE_SIDE=0: behind the commit, as before (A/B).
-    static const bool store_side = [] { const char* e = getenv("TGMX_TGN_STORE_SIDE"); return !(e && e[0] == '0'); }();
-    // Two joins: the attention waits for the edge projection only, the caller's stream picks up the store behind the attention's launch (the
-    // store is the side chain's last and longest launch, and the attention needs nothing of it).  TGMX_TGN_STORE_JOIN_LATE=0: one join behind
-    // the store (A/B).
+    // TGMX_TGN_STORE_JOIN_LATE=1 (A/B, off by default): two joins -- the attention waits for the edge projection only, the caller's stream
+    // picks up the store behind the attention's launch (the store is the side chain's last and longest launch, and the attention needs
+    // nothing of it).  Measured over 16 alternating segments: 137.4 us per batch with two joins, 134.9 with one -- the second record + wait cost
+    // the host more than the attention gains on a step whose host side is the longer one.
     const char* jl = getenv("TGMX_TGN_STORE_JOIN_LATE");
-    const bool two_joins = store_side && a->n > 0 && !(jl && jl[0] == '0');
+    const bool two_joins = store_side && a->n > 0 && jl && jl[0] == '1';
     if (two_joins && hipEventRecord(side->join, ss) != hipSuccess) {
       set_error("tgn_step: join record failed");
       return TGMX_E_LAUNCH;
     }
-    if (store_side && a->n > 0) {
+    if (store_side && a->n > 0 && !stored) {
       if ((rc = tgmx_tgn_store_batch(a->src, a->dst, a->t, a->raw, m->D, a->n, a->log_base, a->log_other, a->log_t, a->log_raw, a->st_lo_s, a->st_cnt_s,
                                      a->st_lo_d, a->st_cnt_d, (tgmx_stream_t)ss)))
         return rc;
