@@ -332,7 +332,7 @@ typedef struct tgmx_pipeline_post {
   int64_t* edge_t;             /* [edge_cap] */
   float* edge_x;               /* [edge_cap, D] */
   int64_t* dev_sizes;          /* device [3]: unique count | status (low word) | edge count; status word zero at first use */
-  int64_t* host_sizes;         /* pinned host [3] */
+  int64_t* host_sizes;         /* pinned host [3], device-accessible (hipHostMalloc / torch pin_memory): written by a kernel's stores */
   tgmx_event_t sizes_ready;
 } tgmx_pipeline_post_t;
 
