@@ -894,6 +894,11 @@ def main():
                                      and args.pool == 1)
     rl = out['roofline']
     rl['traffic'] = pmc_traffic(pkey, rl)
+    if args.mode == 'ring' and 256 < 2 * bs_rank <= 1024 and len(num_nbrs) >= 2 and os.environ.get('TGMX_MERGE_LATE', '1') != '0' and 'packed' in kernel_name:
+        # (two packed lookup launches, 512 < m <= 1024: the review-shaped step since round 6)
+        rl['launch_carries'] = ("the ring update's merge + placement riders (a workgroup per 256-entry chunk, the last one out places): they, not the "
+                                'lookups, set this launch\'s duration -- the lookups alone need ~8 us (TGMX_MERGE_LATE=0 puts sort + merge back into the hop-0 '
+                                'launch: that one then lasts ~13 us and the step ~2 us longer)')
     rl['literal_8d_bytes'] = ls['literal_8d_bytes']
     rl['literal_8d_frac'] = ls['literal_8d_bytes'] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
     rl['literal_8d_note'] = ('SURVEY 8(d) read literally: (28 + 8D) B per output slot + 68 B per seed.  It charges every PAD slot a 16-byte record read, a '

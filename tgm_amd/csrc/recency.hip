@@ -790,9 +790,12 @@ __device__ __forceinline__ void update_merge_riding(const UpdateArgs& a, int c0,
 //              lookups a single launch commits records, write_pos and feature rows
 //   kSideAll   (fused hop 0 + 1 launch, m <= 1024): ONE workgroup does all of it -- chunk sorts one after the other,
 //              merge, placement decisions -- inside the single lookup launch
+//   kSideSort / kSideMergePlace (hop 0 / hop 1 as two launches, m <= 1024, round 6): hop 0's riders only chunk-sort (no barrier inside a
+//     launch: the launch boundary is the barrier), hop 1's riders rank their chunks and the last one out decides the placement -- the
+//     update's chain is spread over BOTH lookup launches instead of pacing the first (review shape: 13.4 + 7.1 us -> see DESIGN 3.2)
 //   kSideSortMerge (fused hop 0 + 1 launch, 1024 < m <= 4096): workgroup c chunk-sorts, all riders meet at a barrier of
 //              their own (they are the launch's first <= 16 workgroups: resident together), then workgroup c merges
-constexpr int kSideSort = 1, kSideMerge = 2, kSidePlace = 3, kSideAll = 4, kSideSortMerge = 5, kSidePlaceOnly = 6, kSideSortMergePlace = 7;
+constexpr int kSideSort = 1, kSideMerge = 2, kSidePlace = 3, kSideAll = 4, kSideSortMerge = 5, kSidePlaceOnly = 6, kSideSortMergePlace = 7, kSideMergePlace = 8;
 
 // Barrier between the `parts` rider workgroups of one launch: bar[0] counts arrivals, bar[1] is the generation.  It
 // resets itself, so the words only have to be zero when the scratch buffer is first used.  What crosses it (the
@@ -989,6 +992,23 @@ __device__ __forceinline__ void update_side_work(const UpdateArgs& u, int stage,
       }
       __syncthreads();
       if (!last_out) return;
+      SortLds<1> none;
+      update_block_body<NCH, PCAP, true, true, true>(u, W.place, none);
+      return;
+    }
+    if (stage == kSideMergePlace) {
+      // the chunk sorts ran in the PREVIOUS launch (hop 0, kSideSort): rank this rider's chunk; the last rider out decides the placement
+      const int chunks = (int)((u.m + kChunk - 1) / kChunk);
+      __shared__ int last_mp;
+      update_merge_riding<1, NCH, true>(u, block, W.smp);
+      __syncthreads();  // every thread's device-coherent stores have completed
+      if (threadIdx.x == 0) {
+        const int prev = __hip_atomic_fetch_add(&u.barrier[5], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_mp = prev == chunks - 1;
+        if (last_mp) __hip_atomic_store(&u.barrier[5], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // zero for the next launch
+      }
+      __syncthreads();
+      if (!last_mp) return;
       SortLds<1> none;
       update_block_body<NCH, PCAP, true, true, true>(u, W.place, none);
       return;
@@ -3260,11 +3280,15 @@ extern "C" int tgmx_recency_step(const tgmx_recency_step_t* s, tgmx_stream_t str
     // only decides the placement -- the one workgroup that merged AND placed made hop 1 last 17.7 us at the review shape (TGMX_SPLIT_MERGE=0: A/B)
     static const bool split_merge_on = !(getenv("TGMX_SPLIT_MERGE") && atoi(getenv("TGMX_SPLIT_MERGE")) == 0);
     const bool split_merge = split_merge_on && ride_place && s->n_hops >= 2;
+    // round 6: hop 0 carries the chunk sorts only, hop 1 the merge (a rider per chunk) + the placement (the last rider out): the riders no
+    // longer pace the first launch (TGMX_MERGE_LATE=0: sort + barrier + merge in hop 0, placement in hop 1, as in rounds 3-5 -- A/B)
+    static const bool merge_late_on = !(getenv("TGMX_MERGE_LATE") && atoi(getenv("TGMX_MERGE_LATE")) == 0);
+    const bool merge_late = merge_late_on && split_merge && side_chunks > 1;
+    const int stage = h == 0 ? ((split_merge && !merge_late) ? kSideSortMerge : kSideSort)
+                             : (ride_place ? (merge_late ? kSideMergePlace : (split_merge ? kSidePlaceOnly : kSidePlace)) : kSideMerge);
     const int rc = csr ? launch_lookup<false>(a, st, e0, e1)
-                       : launch_lookup<true>(a, st, e0, e1, ride ? &u : nullptr,
-                                             h == 0 ? (split_merge ? kSideSortMerge : kSideSort)
-                                                    : (ride_place ? (split_merge ? kSidePlaceOnly : kSidePlace) : kSideMerge),
-                                             (h == 1 && ride_place) ? 1u : side_chunks, (h == 1 && ride_place) ? tail_blocks : 0u);
+                       : launch_lookup<true>(a, st, e0, e1, ride ? &u : nullptr, stage,
+                                             (h == 1 && ride_place && !merge_late) ? 1u : side_chunks, (h == 1 && ride_place) ? tail_blocks : 0u);
     if (rc) return rc;
     if (const int rs = enqueue_side()) return rs;
     cur_n = s->out_nid[h];
