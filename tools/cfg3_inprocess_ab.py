@@ -2,7 +2,7 @@
 """cfg 3 (TGN step + prefetching loader) A/B INSIDE one process: the per-call knobs of tgmx_tgn_step / the loader are switched between segments of
 the same run (box-to-box and run-to-run drift of the host side is 10-20 % on this pool -- larger than the effects under test).
 usage: cfg3_inprocess_ab.py ROUNDS SEG "A=1 B=0" "C=1" ...   (each argument one configuration = environment assignments; "-" = defaults)"""
-import json, os, statistics, sys, time
+import contextlib, json, os, statistics, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tgm_amd import DGData, DGDataLoader, DGraph
@@ -34,6 +34,7 @@ def batches(lo, hi):
 
 
 res = {c: [] for c in cfgs}
+high = torch.cuda.Stream(device=dev, priority=-1)
 with hm.activate('k'), torch.no_grad():
     for b in batches(0, 200):
         step.batch(b)
@@ -51,14 +52,18 @@ with hm.activate('k'), torch.no_grad():
             # every segment replays the SAME stretch of the stream from a reset state (identical work per segment): `lead` batches untimed, `seg` timed
             hm.reset_state()
             mem.reset_state()
-            for b in batches(0, lead):
-                step.batch(b)
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for b in batches(lead, lead + seg):
-                step.batch(b)
-            torch.cuda.synchronize()
-            res[c].append(1e6 * (time.perf_counter() - t0) / seg)
+            # AB_MAIN_HIGH=1: the consumer's (model's) stream is a high-priority one of its own instead of the default stream
+            ctx = torch.cuda.stream(high) if os.environ.get('AB_MAIN_HIGH') == '1' else contextlib.nullcontext()
+            with ctx:
+                for b in batches(0, lead):
+                    step.batch(b)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for b in batches(lead, lead + seg):
+                    step.batch(b)
+                torch.cuda.synchronize()
+                res[c].append(1e6 * (time.perf_counter() - t0) / seg)
 for c in cfgs:
     v = res[c]
     print(json.dumps({'config': c, 'median_us_per_batch': round(statistics.median(v), 1), 'min': round(min(v), 1), 'all': [round(x, 1) for x in v]}))
