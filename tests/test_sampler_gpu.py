@@ -239,6 +239,15 @@ def _check_ring_against_oracle(N, E, D, tmax, num_nbrs, bs, directed, key_arith,
     hook.check()
 
 
+@pytest.mark.parametrize('bs,directed,tmax', [(129, False, 40_000), (200, False, 300), (300, False, 40_000), (511, False, 5), (512, False, 40_000),
+                                              (257, True, 300), (1024, True, 40_000)])
+def test_riders_spread_over_both_lookup_launches_vs_oracle(bs, directed, tmax):
+    """Two packed lookup launches (narrow rows, two hops) with 256 < m <= 1024 update entries -- the review-shaped step: the chunk sorts ride
+    hop 0, the merge (a rider per chunk) and the last-one-out placement ride hop 1 (round 6).  m = 257 ... 1024 (2 to 4 chunks, ragged last
+    chunk), heavy ties (tmax = 5: the key order decides), ids / times / feature rows of every batch bit-exact against the oracle."""
+    _check_ring_against_oracle(600, 12 * bs, 16, tmax, [10, 10], bs, directed, 'int32', validate='deferred')
+
+
 def test_csr_mode_equals_ring_int64_random():
     """Stateless CSR lookup == streaming rings with the intended key order, mid-size, non-bipartite."""
     DGData, DGDataLoader, DGraph, HookManager, RecencyNeighborHook, ReplayNegatives = _mk()
