@@ -55,7 +55,7 @@ def parse_args():
     p.add_argument('--batch-size', type=int, default=None, help='edges per rank per step (default: 200 wiki, 512 review, 4096 comment)')
     p.add_argument('--num-nbrs', type=int, nargs='+', default=None)
     p.add_argument('--mode', default='ring', choices=['ring', 'csr'])
-    p.add_argument('--cpu-batches', type=int, default=8, help='batches of the CPU-baseline sample PER thread setting (0 = skip); ~0.1-0.3 s each')
+    p.add_argument('--cpu-batches', type=int, default=30, help='batches of the CPU-baseline sample PER thread setting (0 = skip); ~0.1 s each: 30 x 4 settings = ~12 s of CPU work')
     p.add_argument('--scaling', default='weak', choices=['weak', 'strong', 'batch'],
                    help="N > 1: 'weak' = global batch N x bs, rank r seeds from its slice; 'strong' = global batch bs, split N ways; 'batch' = "
                    "the single-GPU schedule of bs-edge batches dealt round-robin to the ranks (DGDataLoader(batch_shard=), static index only: "
@@ -967,16 +967,17 @@ def main():
             t_c = time.perf_counter()
             res = {}
             for name, env in (('two_streams', {}), ('one_stream', {'TGMX_BENCH_TGN_STREAMS': '0'})):
-                r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'bench_tgn.py'), '300'], env=dict(os.environ, TGMX_BENCH_TGN_NO_LOADER_PASS='1', **env),
+                r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'bench_tgn.py'), '300'], env=dict(os.environ, TGMX_BENCH_TGN_NO_LOADER_PASS='1', TGMX_BENCH_TGN_REPEATS='3', **env),
                                    capture_output=True, text=True, timeout=240)
                 line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
                 if r.returncode or not line:
                     raise RuntimeError(f'tools/bench_tgn.py ({name}) failed: {r.stderr[-200:]}')
                 d = json.loads(line[-1])
                 res[name] = {k: d[k] for k in ('pipeline_us_per_batch', 'host_busy_us_per_batch', 'host_waiting_for_the_device_us_per_batch', 'events_per_s',
-                                               'sampled_edges_per_s')}
+                                               'sampled_edges_per_s', 'windows_us_per_batch')}
             out['pipeline_cfg3'] = {'what': 'BASELINE cfg 3: review-shaped synthetic (N = 350 k, E = 4.8 M, D = 16), TGN memory (Last, GRU, 100) + TransformerConv embedding, '
-                                            'k = [10, 10], bs = 512; 300 batches after 100 of warm-up; tools/bench_tgn.py in its own process on this GPU', **res,
+                                            'k = [10, 10], bs = 512; the same 300 batches after 100 of warm-up three times (state reset in between), the MEDIAN repeat reported (windows_us_per_batch: all three); '
+                                            'tools/bench_tgn.py in its own process on this GPU', **res,
                                     'seconds_spent': time.perf_counter() - t_c}
 
         guarded('variants', _variants)

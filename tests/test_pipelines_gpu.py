@@ -136,6 +136,61 @@ def test_side_stream_loader_gives_the_single_stream_results(features):
     assert torch.equal(mem1, mem2) and torch.equal(lu1, lu2)
 
 
+def test_two_side_stream_loaders_interleaved_share_one_stream():
+    """Every DGDataLoader(side_stream=True) of a process issues on ONE loader stream per device (a stream per loader made the second, third, ...
+    loader land on a hardware queue the caller's or the library's streams use: cfg 3 ran at the one-stream speed through every loader but the
+    first).  Two loaders over two graphs with their own hooks, consumed alternately (a train / validation interleaving): every batch equals
+    the single-stream pass's bit for bit, and the two loaders hold the same stream object."""
+    from tgm_amd import DGData, DGDataLoader, DGraph
+    from tgm_amd.hooks import DeduplicationHook, HookManager, RandomNegativeEdgeSamplerHook, RecencyNeighborHook, SampledEdgeListHook
+    from tgm_amd.synth import make_stream
+
+    def pipeline(seed, side):
+        st = make_stream('review', seed=seed, num_edges=12 * 256 + 31, n_src=900, n_dst=150)
+        dg = DGraph(DGData.from_raw(st.ts, torch.stack([st.src, st.dst], 1), st.edge_x), device=DEV)
+        hm = HookManager(keys=['k'])
+        hm.register('k', RandomNegativeEdgeSamplerHook(900, st.num_nodes, seed=seed))
+        hook = RecencyNeighborHook(st.num_nodes, [10, 10], ['edge_src', 'edge_dst', 'neg'], ['edge_time', 'edge_time', 'neg_time'], validate='deferred',
+                                   edge_features='by_id')
+        hm.register('k', hook)
+        hm.register('k', DeduplicationHook(seed_nodes_keys=['neg', 'nbr_nids']))
+        hm.register('k', SampledEdgeListHook(hop=0))
+        kw = dict(output_pool=3, prefetch=2, side_stream=True) if side else {}
+        return hm, hook, DGDataLoader(dg, batch_size=256, hook_manager=hm, **kw)
+
+    def grab(batch):
+        return [t.clone() for t in (batch.neg, batch.unique_nids, batch.nbr_nids[0], batch.nbr_nids[1], batch.nbr_edge_time[1], batch.sampled_edge_index,
+                                    batch.sampled_edge_time, batch.sampled_edge_x)]
+
+    def run(side):
+        (hm_a, hook_a, ld_a), (hm_b, hook_b, ld_b) = pipeline(21, side), pipeline(22, side)
+        out_a, out_b = [], []
+        # a HookManager activation is a context of its own: the two pipelines alternate batch by batch, each under its own manager
+        it_a = it_b = None
+        for _ in range(13):
+            with hm_a.activate('k'):
+                it_a = it_a or iter(ld_a)
+                out_a.append(grab(next(it_a)))
+            with hm_b.activate('k'):
+                it_b = it_b or iter(ld_b)
+                out_b.append(grab(next(it_b)))
+        for it in (it_a, it_b):
+            it.close()  # (the generators hand their stream's work back to the caller's stream)
+        hook_a.check()
+        hook_b.check()
+        torch.cuda.synchronize()
+        return out_a, out_b, ld_a, ld_b
+
+    a1, b1, _, _ = run(False)
+    a2, b2, ld_a, ld_b = run(True)
+    assert ld_a._side[0] is ld_b._side[0]
+    for name, one, two in (('a', a1, a2), ('b', b1, b2)):
+        assert len(one) == len(two) == 13
+        for i, (x, y) in enumerate(zip(one, two)):
+            for j, (u, v) in enumerate(zip(x, y)):
+                assert torch.equal(u, v), f'loader {name} batch {i} item {j}'
+
+
 @pytest.mark.parametrize('validate', ['deferred', 'sync'])
 def test_side_stream_with_timed_steps_keeps_the_batch_order(validate):
     """A TIMED step (``profile_hop``: HIP events around the dominant launch) is issued from the calling thread while earlier batches' steps

@@ -29,6 +29,27 @@ from ..core import DGBatch, DGraph, TimeDeltaDG
 from ..exceptions import EmptyBatchError, EventOrderedConversionError, InvalidDiscretizationError
 
 
+_SIDE_STREAMS: dict = {}
+
+
+def _shared_side_stream(dev):
+    """ONE loader stream per device for every ``DGDataLoader(side_stream=True)`` of the process.  A stream per loader looked harmless and was
+    not: the runtime maps streams onto a handful of hardware queues (4 by default), the process already owns three (the caller's, the
+    library's side streams of ``tgmx_tgn_step`` and of the large ring update), and the second, third, ... loader's stream landed on a queue one
+    of those uses -- its launches then serialize with them (cfg 3: 140 us per batch through the first loader of a process, 180 / 199 alternating
+    through every later one, the one-stream figure; ``HISTORY.md`` 3.5).  Loaders that iterate at the same time share the stream: correct
+    (stream order), merely not concurrent with each other.  TGMX_LOADER_OWN_STREAM=1: a stream per loader, as before (A/B)."""
+    import torch
+
+    if os.environ.get('TGMX_LOADER_OWN_STREAM') == '1':
+        return torch.cuda.Stream(device=dev)
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    s = _SIDE_STREAMS.get(key)
+    if s is None:
+        s = _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return s
+
+
 class DGDataLoader(torch.utils.data.DataLoader):
     def __init__(
         self,
@@ -366,7 +387,7 @@ class DGDataLoader(torch.utils.data.DataLoader):
             with torch.cuda.device(dev):
                 w = ctypes.c_void_p()
                 _native.check(lib.tgmx_worker_create(ctypes.byref(w)), 'tgmx_worker_create')
-            self._side = (torch.cuda.Stream(device=dev), evs, w)
+            self._side = (_shared_side_stream(dev), evs, w)
         side, evs, worker = self._side
         main = torch.cuda.current_stream(dev)
         side_p, main_p = side.cuda_stream, main.cuda_stream

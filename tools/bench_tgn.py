@@ -184,14 +184,29 @@ with hm.activate('k'), torch.no_grad():
         print(json.dumps({'host_us_per_phase': {k: 1e6 * v / cnt for k, v in ph.items()}, 'waiting_in_next_us': 1e6 * _waited[0] / cnt, 'batches': cnt,
                           'model_chain_on_device_us': sum(chain) / len(chain), 'caller_stream_idle_between_model_steps_us': sum(idle) / len(idle)}))
         sys.exit(0)
-    _waited[0] = 0.0
-    t0 = time.perf_counter()
-    for batch in batches(100, 100 + n):
-        z2, b = step(batch)
-    t1 = time.perf_counter()
-    waited = _waited[0]
-    torch.cuda.synchronize()
-    t2 = time.perf_counter()
+    # TGMX_BENCH_TGN_REPEATS=r (bench.py's cfg 3 block: 3): the SAME window r times -- hooks and memory reset, the 100 warm-up batches replayed,
+    # the same n batches timed -- and the figures of the MEDIAN repeat reported, every repeat's time listed: one descheduled moment of the host
+    # thread inside a 45 ms window otherwise decides the line (seen: 203 us against 145-147 in the two runs beside it).  (Later stretches of
+    # the stream are heavier by construction -- 5 k -> 12 k unique nodes per batch between batch 150 and 1 400 -- so the repeats do not move on.)
+    reps = max(1, int(os.environ.get('TGMX_BENCH_TGN_REPEATS', '1')))
+    windows = []
+    for rep in range(reps):
+        if rep:
+            hm.reset_state()
+            mem.reset_state()
+            for batch in batches(0, 100):
+                z2, b = step(batch)
+            torch.cuda.synchronize()
+        _waited[0] = 0.0
+        t0 = time.perf_counter()
+        for batch in batches(100, 100 + n):
+            z2, b = step(batch)
+        t1 = time.perf_counter()
+        waited = _waited[0]
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        windows.append((t2 - t0, t0, t1, t2, waited))
+    _, t0, t1, t2, waited = sorted(windows)[len(windows) // 2]
     hook.check()
     mem.check()
     # loader + hooks only, same stream
@@ -209,4 +224,5 @@ print(json.dumps({
     'host_busy_us_per_batch': 1e6 * (t1 - t0 - waited) / n, 'host_waiting_for_the_device_us_per_batch': 1e6 * waited / n,
     'events_per_s': bs * n / (t2 - t0), 'sampled_edges_per_s': slots * n / (t2 - t0),
     'loader_hooks_only_us_per_batch': 1e6 * (t4 - t3) / n, 'unique_nodes_last_batch': int(b.unique_nids.numel()),
+    'windows_us_per_batch': [round(1e6 * w[0] / n, 1) for w in windows],
 }))
