@@ -829,6 +829,22 @@ int tgmx_tgcn_concat(const float* a, int64_t lda, const float* b, const float* g
 int tgmx_tgcn_output(const float* u_pre, const float* c_pre, const float* H, int64_t n, float* out,
                      tgmx_stream_t stream);
 
+/* The whole TGCN cell forward (tgm/nn/encoder/tgcn.py:118-156, inference) as ONE call: tgmx_gcn_norm_dense, the two GEMMs of the three
+ * convolutions over the shared A_hat (G = A_hat (X [W_u | W_r | W_c]^T) + [b_u | b_r | b_c]), per gate tgmx_tgcn_concat + its Linear, and
+ * tgmx_tgcn_output -- the same launches in the same order as the entry points above called one by one (identical results), issued back to
+ * back from C: a snapshot of a 255-node graph is 13 launches and the Python-composed sequence was host-bound at ~160 us.  Gate order
+ * u, r, c everywhere.  Scratch: A [N, ldA] (ldA >= N, a multiple of 4), norm_ws [2 N], xwt [3 C, N], G [N, 3 C], cat [N, 2 C], pre [3][N, C]. */
+typedef struct tgmx_tgcn_fwd {
+  const float* x; int64_t N; int32_t in_ch, C;          /* node features [N, in_ch]; C = out_channels */
+  const int64_t* src; const int64_t* dst; const float* edge_w; int64_t E; float fill; int32_t add_self_loops;
+  const float* W3; const float* b3;                     /* stacked GCN weights [3 C, in_ch] and biases [3 C] */
+  const float* lin_w[3]; const float* lin_b[3];         /* linear_{u,r,c}: [C, 2 C], [C] */
+  const float* H;                                       /* [N, C] recurrent state */
+  float* A; int64_t ldA; float* norm_ws; float* xwt; float* G; float* cat; float* pre[3];
+  float* out;                                           /* [N, C] */
+} tgmx_tgcn_fwd_t;
+int tgmx_tgcn_forward(const tgmx_tgcn_fwd_t* args, tgmx_stream_t stream);
+
 /* Backward of the TGCN cell (tgcn.py:151-156 under loss.backward(), examples/nodeproppred/tgcn.py:92).  out = U H + (1 - U) tanh(c_pre),
  * U = sigmoid(u_pre):  du_pre = dout (H - Cc) U (1 - U), dc_pre = dout (1 - U) (1 - Cc^2), dH = dout U (n = N * C elements each). */
 int tgmx_tgcn_gate_backward(const float* dout, const float* u_pre, const float* c_pre, const float* H, int64_t n, float* du_pre,

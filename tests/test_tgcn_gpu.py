@@ -45,6 +45,44 @@ def test_tgcn_trade_shaped_vs_oracle():
     close(out.cpu(), gcn_conv_ref(x, ei, None, conv.lin.weight.detach().cpu(), conv.bias.detach().cpu(), add_self_loops=False), 'gcn no loops')
 
 
+@pytest.mark.parametrize('N,Fin,C,weighted,improved', [(255, 16, 32, False, False), (255, 64, 128, True, True), (7, 3, 5, True, False), (1000, 16, 32, False, False)])
+def test_tgcn_forward_as_one_call_equals_the_composed_sequence(N, Fin, C, weighted, improved, monkeypatch):
+    """TGCN.forward in inference = ONE native call (tgmx_tgcn_forward: the 13 launches of a snapshot issued back to back from C, stacked weights
+    cached against the parameters' versions, scratch kept between snapshots) -- bit for bit what the Python-composed sequence of the same
+    entry points gives (TGMX_TGCN_PY=1; with edge weights: to the last-bit noise of the degree sums' float atomics), over a recurrence of snapshots with changing edge counts, after an in-place parameter update, and for
+    a deep copy of the cell (the cached argument block and scratch stay behind)."""
+    import copy
+
+    from tgm_amd.nn import TGCN
+
+    torch.manual_seed(N + C)
+    cell = TGCN(Fin, C, improved=improved).to(DEV).eval()
+    twin = copy.deepcopy(cell)
+    H1 = H2 = None
+    with torch.no_grad():
+        for snap in range(5):
+            E = 50 + 700 * snap
+            ei = torch.randint(0, N, (2, E), device=DEV)
+            ew = (torch.rand(E, device=DEV) + 0.1) if weighted else None
+            x = torch.randn(N, Fin, device=DEV)
+            monkeypatch.delenv('TGMX_TGCN_PY', raising=False)
+            H1 = cell(x, ei, ew, H1)
+            monkeypatch.setenv('TGMX_TGCN_PY', '1')
+            H2 = twin(x, ei, ew, H2)
+            # (weighted edges: A_hat's degree sums are float atomics -- their order, hence the last bit, differs from run to run on EITHER path)
+            same = torch.allclose(H1, H2, rtol=1e-5, atol=1e-6) if weighted else torch.equal(H1, H2)
+            assert same, f'snapshot {snap}: max |d| = {(H1 - H2).abs().max().item():.3e}'
+            H2 = H1.clone()  # (the recurrences continue from one state)
+            if snap == 2:  # the cached stacked weights follow the parameters
+                for m in (cell, twin):
+                    m.conv_r.lin.weight.mul_(1.5)
+                    m.linear_c.bias.add_(0.25)
+        monkeypatch.delenv('TGMX_TGCN_PY', raising=False)
+        clone = copy.deepcopy(cell)
+        ya, yb = clone(x, ei, ew, H2), cell(x, ei, ew, H2)
+        assert torch.allclose(ya, yb, rtol=1e-5, atol=1e-6) if weighted else torch.equal(ya, yb)
+
+
 @pytest.mark.parametrize('improved', [False, True])
 def test_tgcn_backward_matches_autograd_through_the_oracle(improved):
     """The reference trains this cell (examples/nodeproppred/tgcn.py:92: loss.backward() through tgcn.py:151-156).  Hand-written backward

@@ -70,6 +70,7 @@ SIGNATURES = {
     'tgmx_gcn_norm_dense': (c_int32, [_P, _P, _P, c_int64, c_int64, ctypes.c_float, c_int32, _P, c_int64, _P, _P]),
     'tgmx_tgcn_concat': (c_int32, [_P, c_int64, _P, _P, c_int32, c_int64, _P, _P]),
     'tgmx_tgcn_output': (c_int32, [_P, _P, _P, c_int64, _P, _P]),
+    'tgmx_tgcn_forward': (c_int32, [_P, _P]),
     'tgmx_tgcn_gate_backward': (c_int32, [_P, _P, _P, _P, c_int64, _P, _P, _P, _P]),
     'tgmx_tgcn_reset_backward': (c_int32, [_P, _P, _P, _P, _P, c_int32, c_int64, _P, _P, _P]),
     'tgmx_sgemm_tn_workspace_bytes': (c_size_t, [c_int64, c_int32, c_int32, c_int32]),
@@ -214,6 +215,20 @@ class TgnStep(ctypes.Structure):
         ('memory', c_void_p), ('last_update', c_void_p), ('reuse_status', c_void_p),
         ('log_base', c_int64), ('log_other', c_void_p), ('log_t', c_void_p), ('log_raw', c_void_p),
         ('st_lo_s', c_void_p), ('st_cnt_s', c_void_p), ('st_lo_d', c_void_p), ('st_cnt_d', c_void_p),
+    ]  # fmt: skip
+
+
+class TgcnFwd(ctypes.Structure):
+    """tgmx_tgcn_fwd_t (include/tgm_amd.h)."""
+
+    _fields_ = [
+        ('x', c_void_p), ('N', c_int64), ('in_ch', c_int32), ('C', c_int32),
+        ('src', c_void_p), ('dst', c_void_p), ('edge_w', c_void_p), ('E', c_int64), ('fill', ctypes.c_float), ('add_self_loops', c_int32),
+        ('W3', c_void_p), ('b3', c_void_p),
+        ('lin_w', c_void_p * 3), ('lin_b', c_void_p * 3),
+        ('H', c_void_p),
+        ('A', c_void_p), ('ldA', c_int64), ('norm_ws', c_void_p), ('xwt', c_void_p), ('G', c_void_p), ('cat', c_void_p), ('pre', c_void_p * 3),
+        ('out', c_void_p),
     ]  # fmt: skip
 
 

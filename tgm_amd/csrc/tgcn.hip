@@ -190,3 +190,23 @@ extern "C" int tgmx_tgcn_output(const float* u_pre, const float* c_pre, const fl
   TGMX_CHECK_LAUNCH("tgcn_output");
   return TGMX_OK;
 }
+
+// the cell's inference forward as one call (tgm_amd/nn/tgcn.py TGCN.forward composes the same entry points one ctypes call at a time)
+extern "C" int tgmx_tgcn_forward(const tgmx_tgcn_fwd_t* a, tgmx_stream_t stream) {
+  TGMX_REQUIRE(a, "tgcn_forward: null argument block");
+  const int64_t N = a->N;
+  const int C = a->C;
+  TGMX_REQUIRE(N > 0 && C > 0 && a->in_ch > 0 && a->ldA >= N, "tgcn_forward: bad sizes");
+  TGMX_REQUIRE(a->x && a->W3 && a->b3 && a->H && a->A && a->norm_ws && a->xwt && a->G && a->cat && a->out, "tgcn_forward: null pointer");
+  for (int g = 0; g < 3; ++g) TGMX_REQUIRE(a->lin_w[g] && a->lin_b[g] && a->pre[g], "tgcn_forward: null pointer (gate %d)", g);
+  int rc = tgmx_gcn_norm_dense(a->src, a->dst, a->edge_w, a->E, N, a->fill, a->add_self_loops, a->A, a->ldA, a->norm_ws, stream);
+  if (rc) return rc;
+  // (X W3^T)^T = W3 X^T: [3C, N];  G = A_hat (X W3^T) + b3: [N, 3C]
+  if ((rc = tgmx_sgemm_nt(a->W3, a->in_ch, a->x, a->in_ch, a->xwt, N, 3 * C, (int32_t)N, a->in_ch, nullptr, 0, 1, 0, 0, 0, stream))) return rc;
+  if ((rc = tgmx_sgemm_nt(a->A, a->ldA, a->xwt, N, a->G, 3 * C, N, 3 * C, (int32_t)N, a->b3, 0, 1, 0, 0, 0, stream))) return rc;
+  for (int g = 0; g < 3; ++g) {  // u, r, c: the candidate's input is gated by the reset gate's pre-activation
+    if ((rc = tgmx_tgcn_concat(a->G + g * C, 3 * C, a->H, g == 2 ? a->pre[1] : nullptr, C, N, a->cat, stream))) return rc;
+    if ((rc = tgmx_sgemm_nt(a->cat, 2 * C, a->lin_w[g], 2 * C, a->pre[g], C, N, C, 2 * C, a->lin_b[g], 0, 1, 0, 0, 0, stream))) return rc;
+  }
+  return tgmx_tgcn_output(a->pre[0], a->pre[2], a->H, N * C, a->out, stream);
+}

@@ -10,7 +10,9 @@ With gradients enabled the same arithmetic runs inside ``torch.autograd.Function
 """
 from __future__ import annotations
 
+import ctypes
 import math
+import os
 from typing import Optional
 
 import torch
@@ -19,6 +21,7 @@ from torch import Tensor
 
 from .. import _native
 from . import _ops
+from ._paramver import TransientCaches
 
 _MAX_DENSE_NODES = 16384  # A_hat is dense: 16384^2 floats = 1 GiB
 
@@ -70,7 +73,7 @@ def normalized_adjacency(edge_index: Tensor, edge_weight: Optional[Tensor], N: i
     return A[:, :N]
 
 
-class TGCN(nn.Module):
+class TGCN(TransientCaches, nn.Module):
     def __init__(self, in_channels: int, out_channels: int, improved: bool = False, cached: bool = False, add_self_loops: bool = True) -> None:
         super().__init__()
         self.in_channels, self.out_channels = in_channels, out_channels
@@ -87,13 +90,17 @@ class TGCN(nn.Module):
         f32 = dict(dtype=torch.float32, device=dev)
         H = torch.zeros((N, C), **f32) if H is None else _ops._f32c(H, 'H')
         stream = _native.stream_ptr()
+        grad = torch.is_grad_enabled() and (x.requires_grad or H.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if not grad and os.environ.get('TGMX_TGCN_PY') is None:
+            return self._forward_native(x, edge_index, edge_weight, H)
         A = normalized_adjacency(edge_index, edge_weight, N, 2.0 if self.improved else 1.0, self.add_self_loops)
-        if torch.is_grad_enabled() and (x.requires_grad or H.requires_grad or any(p.requires_grad for p in self.parameters())):
+        if grad:
             from ._tgcn_train import TGCNCellFn
 
             gates = (self.conv_u, self.conv_r, self.conv_c), (self.linear_u, self.linear_r, self.linear_c)
             return TGCNCellFn.apply(x, A, H, *[c.lin.weight for c in gates[0]], *[c.bias for c in gates[0]], *[l.weight for l in gates[1]],
                                     *[l.bias for l in gates[1]])  # fmt: skip
+        # (TGMX_TGCN_PY=1, A/B: the same launches composed from Python, one ctypes call each)
         # the three convolutions share A_hat: G = A_hat @ (X [W_u | W_r | W_c]^T) + [b_u | b_r | b_c]
         W3 = torch.cat([self.conv_u.lin.weight.detach(), self.conv_r.lin.weight.detach(), self.conv_c.lin.weight.detach()])
         b3 = torch.cat([self.conv_u.bias.detach(), self.conv_r.bias.detach(), self.conv_c.bias.detach()])
@@ -108,4 +115,60 @@ class TGCN(nn.Module):
             _ops.sgemm_nt(cat, lin.weight.detach(), pre[g], bias=lin.bias.detach())
         out = torch.empty((N, C), **f32)
         _native.check(lib.tgmx_tgcn_output(pre[0].data_ptr(), pre[2].data_ptr(), H.data_ptr(), N * C, out.data_ptr(), stream), 'tgmx_tgcn_output')
+        return out
+
+    def _forward_native(self, x: Tensor, edge_index: Tensor, edge_weight: Optional[Tensor], H: Tensor) -> Tensor:
+        """The inference forward as ONE native call (``tgmx_tgcn_forward``): the launches of the Python-composed sequence above in the same order
+        (identical results), the stacked GCN weights cached against the parameters' versions, the scratch kept between snapshots -- a
+        255-node snapshot is 13 launches and was host-bound at ~160 us when every launch was its own ctypes call between torch ops."""
+        from ._paramver import param_key
+
+        if x.shape[0] > _MAX_DENSE_NODES:
+            raise NotImplementedError(f'tgm_amd GCNConv builds a dense adjacency; {x.shape[0]} nodes exceed {_MAX_DENSE_NODES}')
+        _native.require_device(edge_index, 'edge_index')
+        lib = _native.load()
+        N, C, dev = x.shape[0], self.out_channels, x.device
+        d = self.__dict__
+        key = param_key(self)
+        if d.get('_tgmx_w3_key') != key:
+            convs, lins = (self.conv_u, self.conv_r, self.conv_c), (self.linear_u, self.linear_r, self.linear_c)
+            d['_tgmx_w3'] = (torch.cat([c.lin.weight.detach() for c in convs]).contiguous(), torch.cat([c.bias.detach() for c in convs]).contiguous(),
+                             [_ops._f32c(l.weight.detach(), 'weight') for l in lins], [_ops._f32c(l.bias.detach(), 'bias') for l in lins])
+            d['_tgmx_w3_key'] = key
+        W3, b3, lw, lb = d['_tgmx_w3']
+        ws = d.get('_tgmx_ws')
+        ld = (N + 3) // 4 * 4
+        up = lambda n: (n + 63) // 64 * 64  # 256-byte granules: every region a 16-byte aligned GEMM operand
+        sizes = [up(N * ld), up(2 * N), up(3 * C * N), up(3 * C * N), up(2 * C * N), up(C * N), up(C * N), up(C * N)]
+        need = sum(sizes)
+        if ws is None or ws.numel() < need or ws.device != dev:
+            ws = d['_tgmx_ws'] = torch.empty(need, dtype=torch.float32, device=dev)
+        ei = edge_index if edge_index.dtype == torch.int64 else edge_index.to(torch.int64)
+        src, dst = ei[0], ei[1]
+        if not src.is_contiguous():
+            src = src.contiguous()
+        if not dst.is_contiguous():
+            dst = dst.contiguous()
+        w = None if edge_weight is None else _ops._f32c(edge_weight, 'edge_weight')
+        out = torch.empty((N, C), dtype=torch.float32, device=dev)
+        a = d.get('_tgmx_args')
+        if a is None:
+            a = d['_tgmx_args'] = _native.TgcnFwd()
+        base = ws.data_ptr()
+        a.x, a.N, a.in_ch, a.C = x.data_ptr(), N, x.shape[1], C
+        a.src, a.dst, a.edge_w, a.E = src.data_ptr(), dst.data_ptr(), _native.ptr(w), src.numel()
+        a.fill, a.add_self_loops = (2.0 if self.improved else 1.0), (1 if self.add_self_loops else 0)
+        a.W3, a.b3 = W3.data_ptr(), b3.data_ptr()
+        for g in range(3):
+            a.lin_w[g], a.lin_b[g] = lw[g].data_ptr(), lb[g].data_ptr()
+        a.H = H.data_ptr()
+        ptrs, off = [], 0
+        for n_ in sizes:
+            ptrs.append(base + 4 * off)
+            off += n_
+        a.A, a.ldA, a.norm_ws, a.xwt, a.G, a.cat = ptrs[0], ld, ptrs[1], ptrs[2], ptrs[3], ptrs[4]
+        for g in range(3):
+            a.pre[g] = ptrs[5 + g]
+        a.out = out.data_ptr()
+        _native.check(lib.tgmx_tgcn_forward(ctypes.byref(a), _native.stream_ptr()), 'tgmx_tgcn_forward')
         return out
