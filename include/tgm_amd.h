@@ -842,6 +842,7 @@ typedef struct tgmx_tgcn_fwd {
   const float* H;                                       /* [N, C] recurrent state */
   float* A; int64_t ldA; float* norm_ws; float* xwt; float* G; float* cat; float* pre[3];
   float* out;                                           /* [N, C] */
+  int32_t idx32;                                        /* != 0: src / dst point at int32 ids (a DGBatch's edge_src / edge_dst as they are) */
 } tgmx_tgcn_fwd_t;
 int tgmx_tgcn_forward(const tgmx_tgcn_fwd_t* args, tgmx_stream_t stream);
 

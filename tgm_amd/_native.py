@@ -228,7 +228,7 @@ class TgcnFwd(ctypes.Structure):
         ('lin_w', c_void_p * 3), ('lin_b', c_void_p * 3),
         ('H', c_void_p),
         ('A', c_void_p), ('ldA', c_int64), ('norm_ws', c_void_p), ('xwt', c_void_p), ('G', c_void_p), ('cat', c_void_p), ('pre', c_void_p * 3),
-        ('out', c_void_p),
+        ('out', c_void_p), ('idx32', c_int32),
     ]  # fmt: skip
 
 

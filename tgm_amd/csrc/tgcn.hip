@@ -19,7 +19,8 @@ __global__ __launch_bounds__(256) void gcn_init_kernel(float* deg, float* loop_w
 }
 
 // existing self loops replace the fill value (add_remaining_self_loops); other edges add to the in-degree
-__global__ __launch_bounds__(256) void gcn_degree_kernel(const int64_t* src, const int64_t* dst, const float* w, long long E,
+template <typename IdxT>
+__global__ __launch_bounds__(256) void gcn_degree_kernel(const IdxT* src, const IdxT* dst, const float* w, long long E,
                                                          float* deg, float* loop_w, int add_self_loops) {
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
@@ -42,7 +43,8 @@ __global__ __launch_bounds__(256) void gcn_dinv_kernel(float* deg, const float* 
 }
 
 // A[dst, src] += dinv[src] * w * dinv[dst]   (messages flow src -> dst, aggregated at dst)
-__global__ __launch_bounds__(256) void gcn_fill_kernel(const int64_t* src, const int64_t* dst, const float* w, long long E,
+template <typename IdxT>
+__global__ __launch_bounds__(256) void gcn_fill_kernel(const IdxT* src, const IdxT* dst, const float* w, long long E,
                                                        const float* dinv, float* A, long long ld, int add_self_loops) {
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
@@ -151,8 +153,9 @@ extern "C" int tgmx_tgcn_reset_backward(const float* dcat_c, const float* dcat_u
   return TGMX_OK;
 }
 
-extern "C" int tgmx_gcn_norm_dense(const int64_t* src, const int64_t* dst, const float* weight, int64_t E, int64_t N, float fill,
-                                   int32_t add_self_loops, float* A, int64_t ld, float* workspace, tgmx_stream_t stream) {
+template <typename IdxT>
+static int gcn_norm_dense_impl(const IdxT* src, const IdxT* dst, const float* weight, int64_t E, int64_t N, float fill, int32_t add_self_loops,
+                               float* A, int64_t ld, float* workspace, tgmx_stream_t stream) {
   TGMX_REQUIRE(E >= 0 && N > 0 && ld >= N, "gcn_norm_dense: bad sizes");
   TGMX_REQUIRE(A && workspace && (E == 0 || (src && dst)), "gcn_norm_dense: null pointer");
   hipStream_t st = (hipStream_t)stream;
@@ -161,11 +164,16 @@ extern "C" int tgmx_gcn_norm_dense(const int64_t* src, const int64_t* dst, const
   long long blocks = (N * ld + 255) / 256;
   if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(gcn_init_kernel, dim3((unsigned)blocks), dim3(256), 0, st, deg, loop_w, A, (long long)N, (long long)ld);
-  if (E) hipLaunchKernelGGL(gcn_degree_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, src, dst, weight, (long long)E, deg, loop_w, add_self_loops);
+  if (E) hipLaunchKernelGGL(gcn_degree_kernel<IdxT>, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, src, dst, weight, (long long)E, deg, loop_w, add_self_loops);
   hipLaunchKernelGGL(gcn_dinv_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, deg, loop_w, weight, fill, A, (long long)N, (long long)ld, add_self_loops);
-  if (E) hipLaunchKernelGGL(gcn_fill_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, src, dst, weight, (long long)E, deg, A, (long long)ld, add_self_loops);
+  if (E) hipLaunchKernelGGL(gcn_fill_kernel<IdxT>, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, src, dst, weight, (long long)E, deg, A, (long long)ld, add_self_loops);
   TGMX_CHECK_LAUNCH("gcn_norm_dense");
   return TGMX_OK;
+}
+
+extern "C" int tgmx_gcn_norm_dense(const int64_t* src, const int64_t* dst, const float* weight, int64_t E, int64_t N, float fill,
+                                   int32_t add_self_loops, float* A, int64_t ld, float* workspace, tgmx_stream_t stream) {
+  return gcn_norm_dense_impl<int64_t>(src, dst, weight, E, N, fill, add_self_loops, A, ld, workspace, stream);
 }
 
 extern "C" int tgmx_tgcn_concat(const float* a, int64_t lda, const float* b, const float* gate_pre, int32_t C, int64_t N, float* out,
@@ -199,7 +207,10 @@ extern "C" int tgmx_tgcn_forward(const tgmx_tgcn_fwd_t* a, tgmx_stream_t stream)
   TGMX_REQUIRE(N > 0 && C > 0 && a->in_ch > 0 && a->ldA >= N, "tgcn_forward: bad sizes");
   TGMX_REQUIRE(a->x && a->W3 && a->b3 && a->H && a->A && a->norm_ws && a->xwt && a->G && a->cat && a->out, "tgcn_forward: null pointer");
   for (int g = 0; g < 3; ++g) TGMX_REQUIRE(a->lin_w[g] && a->lin_b[g] && a->pre[g], "tgcn_forward: null pointer (gate %d)", g);
-  int rc = tgmx_gcn_norm_dense(a->src, a->dst, a->edge_w, a->E, N, a->fill, a->add_self_loops, a->A, a->ldA, a->norm_ws, stream);
+  // (idx32: the loader's batches carry int32 endpoints -- read as they are instead of through a widened copy)
+  int rc = a->idx32 ? gcn_norm_dense_impl<int32_t>(reinterpret_cast<const int32_t*>(a->src), reinterpret_cast<const int32_t*>(a->dst), a->edge_w, a->E, N,
+                                                   a->fill, a->add_self_loops, a->A, a->ldA, a->norm_ws, stream)
+                    : tgmx_gcn_norm_dense(a->src, a->dst, a->edge_w, a->E, N, a->fill, a->add_self_loops, a->A, a->ldA, a->norm_ws, stream);
   if (rc) return rc;
   // (X W3^T)^T = W3 X^T: [3C, N];  G = A_hat (X W3^T) + b3: [N, 3C]
   if ((rc = tgmx_sgemm_nt(a->W3, a->in_ch, a->x, a->in_ch, a->xwt, N, 3 * C, (int32_t)N, a->in_ch, nullptr, 0, 1, 0, 0, 0, stream))) return rc;

@@ -143,7 +143,7 @@ class TGCN(TransientCaches, nn.Module):
         need = sum(sizes)
         if ws is None or ws.numel() < need or ws.device != dev:
             ws = d['_tgmx_ws'] = torch.empty(need, dtype=torch.float32, device=dev)
-        ei = edge_index if edge_index.dtype == torch.int64 else edge_index.to(torch.int64)
+        ei = edge_index if edge_index.dtype in (torch.int64, torch.int32) else edge_index.to(torch.int64)
         src, dst = ei[0], ei[1]
         if not src.is_contiguous():
             src = src.contiguous()
@@ -157,6 +157,7 @@ class TGCN(TransientCaches, nn.Module):
         base = ws.data_ptr()
         a.x, a.N, a.in_ch, a.C = x.data_ptr(), N, x.shape[1], C
         a.src, a.dst, a.edge_w, a.E = src.data_ptr(), dst.data_ptr(), _native.ptr(w), src.numel()
+        a.idx32 = 1 if ei.dtype == torch.int32 else 0
         a.fill, a.add_self_loops = (2.0 if self.improved else 1.0), (1 if self.add_self_loops else 0)
         a.W3, a.b3 = W3.data_ptr(), b3.data_ptr()
         for g in range(3):
