@@ -103,6 +103,44 @@ def test_uniform_hook_against_reference(case):
         assert sampled_rows > 0
 
 
+def test_uniform_hook_deferred_validation_raises_at_check():
+    """validate='deferred' (extension, like RecencyNeighborHook's): a seed outside [0, num_nodes) is still caught on the device, but the
+    ValueError of the reference surfaces at ``hook.check()`` instead of costing every batch a device -> host read; 'sync' (default) raises in
+    the call.  Valid batches give the same neighbours either way (same seed, same call counter)."""
+    from tgm_amd import DGData, DGDataLoader, DGraph
+    from tgm_amd.hooks import HookManager, NeighborSamplerHook, RandomNegativeEdgeSamplerHook
+
+    g = torch.Generator().manual_seed(3)
+    N, E = 50, 600
+    ei = torch.randint(0, N, (E, 2), generator=g).int()
+    data = DGData.from_raw(torch.arange(E), ei, torch.rand(E, 4, generator=g))
+
+    def run(validate, bad):
+        dg = DGraph(data, device=DEV)
+        hm = HookManager(keys=['k'])
+        hm.register('k', RandomNegativeEdgeSamplerHook(0, N + (40 if bad else 0), seed=5))  # bad: some negatives are not node ids
+        hook = NeighborSamplerHook([4, 3], ['edge_src', 'edge_dst', 'neg'], ['edge_time', 'edge_time', 'neg_time'], seed=7, validate=validate)
+        hm.register('k', hook)
+        out = []
+        with hm.activate('k'):
+            for batch in DGDataLoader(dg, batch_size=100, hook_manager=hm):
+                out.append([t.clone() for t in (batch.nbr_nids[0], batch.nbr_nids[1], batch.nbr_edge_time[1])])
+        return hook, out
+
+    hook_s, a = run('sync', False)
+    hook_d, b = run('deferred', False)
+    hook_d.check()
+    assert all(torch.equal(x, y) for p, q in zip(a, b) for x, y in zip(p, q))
+    with pytest.raises(ValueError, match='Seed nodes must satisfy'):
+        run('sync', True)
+    hook_d, _ = run('deferred', True)  # no error while iterating ...
+    with pytest.raises(ValueError, match='Seed nodes must satisfy'):
+        hook_d.check()  # ... it is raised here
+    hook_d.check()  # (and cleared)
+    with pytest.raises(ValueError, match='validate must be'):
+        NeighborSamplerHook([2], ['edge_src'], ['edge_time'], validate='off')
+
+
 def test_uniform_draw_is_uniform():
     """One hub with 12 candidates, k = 4, 3000 independent calls: every candidate is drawn ~1000 times, in every slot ~250."""
     from tgm_amd import _native

@@ -44,7 +44,7 @@ class NeighborSamplerHook(StatelessHook, SeedableHook):
     _cls_produces = {'seed_nids', 'seed_times', 'nbr_nids', 'nbr_edge_time', 'nbr_edge_x', 'seed_node_nbr_mask'}
 
     def __init__(self, num_nbrs: List[int], seed_nodes_keys: List[str], seed_times_keys: List[str], directed: bool = False,
-                 id: Optional[str] = None, seed: Optional[int] = None) -> None:  # fmt: skip
+                 id: Optional[str] = None, seed: Optional[int] = None, validate: str = 'sync') -> None:  # fmt: skip
         super().__init__()
         if not len(num_nbrs):
             raise ValueError('num_nbrs must be non-empty')
@@ -62,7 +62,11 @@ class NeighborSamplerHook(StatelessHook, SeedableHook):
         self._seed_nodes_keys = list(seed_nodes_keys)
         self._seed_times_keys = list(seed_times_keys)
         self._warned_seed_None = False
-        self._validate = 'sync'
+        # validate (extension, like RecencyNeighborHook's): 'sync' = the reference's raise-per-call (one device -> host read per batch, which
+        # makes every batch wait for its own kernels); 'deferred' = the seeds are still checked on the device, the error surfaces at check()
+        if validate not in ('sync', 'deferred'):
+            raise ValueError(f"validate must be 'sync' or 'deferred', got {validate!r}")
+        self._validate = validate
         self._num_nodes = 0  # taken from the graph at the first call
         self._mask_cache: Dict[tuple, Dict[str, Tensor]] = {}
         self._rng_seed = int(seed) if seed is not None else int(torch.seed() & 0x7FFFFFFFFFFFFFFF)
@@ -94,6 +98,12 @@ class NeighborSamplerHook(StatelessHook, SeedableHook):
             self._status = torch.zeros(1, dtype=torch.int32, device=device)
             self._mask_cache.clear()
         return self._csr
+
+    def check(self) -> None:
+        """Raise the ``ValueError`` the reference would have raised for bad seeds seen since the last check (one device -> host read)."""
+        if self._status is not None and int(self._status.item()):
+            self._status.zero_()
+            raise ValueError(f'Seed nodes must satisfy 0 <= x < {self._num_nodes}')
 
     def __call__(self, dg: DGraph, batch: DGBatch) -> DGBatch:
         device = batch.edge_src.device
@@ -147,9 +157,8 @@ class NeighborSamplerHook(StatelessHook, SeedableHook):
                     out_t.append(nts)
                     out_x.append(nx)
                     cur_n, cur_t = nid.view(-1), nts.view(-1)
-            if int(self._status.item()):
-                self._status.zero_()
-                raise ValueError(f'Seed nodes must satisfy 0 <= x < {self._num_nodes}')
+            if self._validate == 'sync':
+                self.check()
         self.add_batch_attribute(batch, 'seed_nids', out_seed_n)
         self.add_batch_attribute(batch, 'seed_times', out_seed_t)
         self.add_batch_attribute(batch, 'nbr_nids', out_n)
